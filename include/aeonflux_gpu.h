@@ -1,0 +1,249 @@
+/*
+ * aeonflux_gpu.h — C ABI of the MI355X batch engine for aeonflux's credential NIZKs.
+ *
+ * This is the drop-in boundary: the entry points a Rust `extern "C"` shim
+ *  would bind behind `Issuer::issue` (/root/reference/src/issuer.rs:111-124),
+ * `Issuer::verify` (src/issuer.rs:141-147), `CredentialIssuance::verify` (src/issuer.rs:48-57)
+ * and `AnonymousCredential::show` (src/credential.rs:37-46).  The reference has no FFI/plugin
+ * layer of its own (Cargo.toml:22 is commented out), so the batch forms below are new; each
+ * item of a batch has exactly the semantics of one call of the cited reference method.
+ *
+ * Conventions
+ *  - Sc = 32-byte little-endian canonical scalar mod l; Pt = 32-byte compressed ristretto255.
+ *  - All per-item data is struct-of-arrays: a field `f` of a batch of `count` items is one
+ *    contiguous array `[count][32]`; repeated fields are `[k][count][32]` (k-major).
+ *  - Pointers in the *_soa structs are HOST pointers for afx_*() calls and DEVICE pointers for
+ *    the afx_*_dev() calls (inputs already resident in HBM; no PCIe in the call).
+ *  - Return value: AFX_OK or a negative AFX_E_* batch-level error.  Per-item results go to
+ *    status[i] (AFX_ST_*).  Inputs that would make the reference panic (out-of-range indices,
+ *    length mismatches: src/nizk/presentation.rs:81,100,346,351,407) and encodings the reference
+ *    cannot hold in memory (non-canonical scalars, undecodable points) give
+ *    AFX_ST_VERIFICATION_FAILURE, never a fault.
+ *  - The engine has NO CPU fallback: every arithmetic step runs in HIP kernels on gfx950; calls
+ *    fail with AFX_E_NO_DEVICE when no GPU is usable.
+ *  - Every random draw the reference makes (caller csprng and zkp's hidden thread_rng()) is an
+ *    explicit input, so runs are reproducible (SURVEY.md §8b "Randomness").
+ */
+#ifndef AEONFLUX_GPU_H
+#define AEONFLUX_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFX_MAX_ATTRIBUTES 32
+
+/* batch-level return codes */
+#define AFX_OK 0
+#define AFX_E_BAD_ARGS (-1)    /* null pointer, bad length, n mismatch, unsupported shape        */
+#define AFX_E_BAD_PARAMS (-2)  /* SystemParameters / key bytes do not parse (parameters.rs:92-153) */
+#define AFX_E_NO_DEVICE (-3)   /* no usable HIP device / kernel image (there is no CPU fallback)  */
+#define AFX_E_HIP (-4)         /* a HIP runtime call failed; see afx_last_error()                 */
+#define AFX_E_NO_KEY (-5)      /* operation needs the issuer secret key but ctx has none          */
+
+/* per-item status == the reference's CredentialError outcome (src/errors.rs:73-89) */
+#define AFX_ST_OK 0
+#define AFX_ST_VERIFICATION_FAILURE 1  /* CredentialError::VerificationFailure (errors.rs:152-156) */
+#define AFX_ST_MAC_CREATION 2          /* CredentialError::MacCreation (amacs.rs:285-287)          */
+#define AFX_ST_NO_SYMMETRIC_KEY 3      /* CredentialError::NoSymmetricKey (presentation.rs:150-157) */
+
+/* amacs::Attribute (src/amacs.rs:168-179): kinds of a credential's attributes */
+#define AFX_ATTR_PUBLIC_SCALAR 0
+#define AFX_ATTR_SECRET_SCALAR 1
+#define AFX_ATTR_PUBLIC_POINT 2
+#define AFX_ATTR_EITHER_POINT 3
+#define AFX_ATTR_SECRET_POINT 4
+
+/* amacs::EncryptedAttribute (src/amacs.rs:207-217): kinds as sent in a presentation */
+#define AFX_ENC_PUBLIC_SCALAR 0
+#define AFX_ENC_SECRET_SCALAR 1
+#define AFX_ENC_PUBLIC_POINT 2
+#define AFX_ENC_SECRET_POINT 3
+
+typedef struct afx_ctx afx_ctx;
+
+/* The batch-uniform part of a ProofOfValidCredential (src/nizk/presentation.rs:118-127): everything
+ * that is not a Sc or Pt.  Heterogeneous traffic is grouped by shape on the host. */
+typedef struct {
+  uint32_t n_attributes;                                /* encrypted_attributes.len()                  */
+  uint8_t kinds[AFX_MAX_ATTRIBUTES];                    /* AFX_ENC_* per position                      */
+  uint32_t n_responses;                                 /* proof.responses.len()                       */
+  uint32_t n_hidden_scalars;                            /* hidden_scalar_indices.len()                 */
+  uint16_t hidden_scalar_indices[AFX_MAX_ATTRIBUTES];
+  uint32_t n_enc_proofs;                                /* proofs_of_encryption.len()                  */
+  uint16_t enc_indices[AFX_MAX_ATTRIBUTES];             /* ProofOfEncryption.index (encryption.rs:36)  */
+} afx_shape;
+
+/* ProofOfEncryption (src/nizk/encryption.rs:32-41), SoA over the batch */
+typedef struct {
+  const uint8_t* challenge;  /* [count] Sc                      proof.challenge        */
+  const uint8_t* responses;  /* [6][count] Sc                   proof.responses a,a0,a1,m3,z,z1 */
+  const uint8_t* pk;         /* [count] Pt                      public_key.pk          */
+  const uint8_t* E1;         /* [count] Pt                      ciphertext.E1          */
+  const uint8_t* E2;         /* [count] Pt                      ciphertext.E2          */
+  const uint8_t* C_y_1;      /* [count] Pt */
+  const uint8_t* C_y_2;      /* [count] Pt */
+  const uint8_t* C_y_3;      /* [count] Pt */
+  const uint8_t* C_y_2p;     /* [count] Pt                      C_y_2_prime            */
+} afx_encproof_soa;
+
+/* ProofOfValidCredential (src/nizk/presentation.rs:118-127), SoA over the batch */
+typedef struct {
+  const uint8_t* challenge;    /* [count] Sc                            proof.challenge               */
+  const uint8_t* responses;    /* [n_responses][count] Sc               proof.responses               */
+  const uint8_t* C_x_0;        /* [count] Pt */
+  const uint8_t* C_x_1;        /* [count] Pt */
+  const uint8_t* C_V;          /* [count] Pt */
+  const uint8_t* C_y;          /* [n_attributes][count] Pt */
+  const uint8_t* attr_values;  /* [n_attributes][count] 32 B: Sc for PUBLIC_SCALAR rows, Pt for
+                                  PUBLIC_POINT rows; rows of secret kinds are never read            */
+  const afx_encproof_soa* enc; /* [n_enc_proofs] (host array of structs, also for *_dev calls)     */
+} afx_presentation_soa;
+
+/* ---- context ------------------------------------------------------------------------------- */
+
+/* Build an engine context on HIP device `device`.
+ *   sysparams      : SystemParameters::to_bytes layout (src/parameters.rs:155-184)
+ *   amacs_key      : amacs::SecretKey::to_bytes layout (src/amacs.rs:110-125), or NULL/0 for a
+ *                    user-side context (show / issuance-verify only).  Every y_i is read (the
+ *                    reference's from_bytes re-reads one chunk, src/amacs.rs:148-150 — a bug).
+ *   issuer_params  : C_W || I (64 B; intended IssuerParameters layout, src/issuer.rs:155,163)
+ * Decompresses the generators, builds the fixed-base window tables in HBM.  ctx is immutable
+ * after creation; concurrent calls on one ctx are serialised on its stream. */
+int afx_ctx_create(afx_ctx** out, int device, const uint8_t* sysparams, size_t sysparams_len,
+                   const uint8_t* amacs_key, size_t amacs_key_len, const uint8_t issuer_params[64]);
+/* Overwrites device and host copies of the key and tables before freeing (Zeroize+Drop on
+ * amacs::SecretKey, src/amacs.rs:64-82). */
+void afx_ctx_destroy(afx_ctx* ctx);
+const char* afx_last_error(void);
+uint32_t afx_ctx_n_attributes(const afx_ctx* ctx);
+/* The HIP stream (hipStream_t) every call on this ctx launches on; for event timing in bench.py. */
+void* afx_ctx_stream(const afx_ctx* ctx);
+
+/* ---- Issuer::verify (src/issuer.rs:141-147 -> src/nizk/presentation.rs:324-443) ------------- */
+
+/* status[i] = AFX_ST_OK iff Issuer::verify(presentation_i).is_ok().  Host pointers. */
+int afx_verify_presentations(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* batch,
+                             size_t count, uint8_t* status);
+/* Same, all SoA arrays and `status` in device memory; asynchronous on afx_ctx_stream(ctx). */
+int afx_verify_presentations_dev(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* batch,
+                                 size_t count, uint8_t* status_dev);
+
+/* ProofOfEncryption::verify alone (src/nizk/encryption.rs:154-210); `index` = ProofOfEncryption.index */
+int afx_verify_encryption_proofs(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* batch, size_t count,
+                                 uint8_t* status);
+int afx_verify_encryption_proofs_dev(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* batch, size_t count,
+                                     uint8_t* status_dev);
+
+/* ---- Issuer::issue (src/issuer.rs:111-124 = Amac::tag src/amacs.rs:276-294 +
+ *      ProofOfIssuance::prove src/nizk/issuance.rs:40-129) ----------------------------------- */
+
+/* Attributes of a batch of credential requests of one layout (user.rs:137-139). */
+typedef struct {
+  uint32_t n_attributes;              /* request.attributes.len(); != ctx n => every status MAC_CREATION */
+  uint8_t kinds[AFX_MAX_ATTRIBUTES];  /* AFX_ATTR_* per position                                         */
+  const uint8_t* values;              /* [n_attributes][count] 32 B: Sc for scalar kinds; Pt (M1) for point kinds */
+} afx_attributes_soa;
+
+typedef struct {
+  const uint8_t* t_wide;    /* [count][64]  the 64 bytes Scalar::random draws        (amacs.rs:289)  */
+  const uint8_t* U_wide;    /* [count][64]  the 64 bytes RistrettoPoint::random draws (amacs.rs:290) */
+  const uint8_t* rng_seed;  /* [count][32]  the 32 bytes zkp's prove_compact draws from thread_rng() */
+} afx_issue_randomness;
+
+typedef struct {
+  uint8_t* t;          /* [count] Sc    amac.t */
+  uint8_t* U;          /* [count] Pt    amac.U */
+  uint8_t* V;          /* [count] Pt    amac.V */
+  uint8_t* challenge;  /* [count] Sc    ProofOfIssuance.0.challenge */
+  uint8_t* responses;  /* [n+5][count] Sc  ProofOfIssuance.0.responses (w,w',x_0,x_1,y_0..y_{n-1},1) */
+} afx_issuance_soa;
+
+int afx_issue(afx_ctx* ctx, const afx_attributes_soa* requests, const afx_issue_randomness* rnd, size_t count,
+              const afx_issuance_soa* out, uint8_t* status);
+int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, const afx_issue_randomness* rnd, size_t count,
+                  const afx_issuance_soa* out, uint8_t* status_dev);
+
+/* CredentialIssuance::verify (src/issuer.rs:48-57 -> src/nizk/issuance.rs:132-218), user side. */
+int afx_verify_issuances(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* issuances,
+                         uint32_t n_responses, size_t count, uint8_t* status);
+int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* issuances,
+                             uint32_t n_responses, size_t count, uint8_t* status_dev);
+
+/* ---- AnonymousCredential::show (src/credential.rs:37-46 -> src/nizk/presentation.rs:139-321) - */
+
+/* A batch of credentials of one layout, as the user holds them. */
+typedef struct {
+  uint32_t n_attributes;
+  uint8_t kinds[AFX_MAX_ATTRIBUTES];  /* AFX_ATTR_* per position (after hide_attribute/reveal_attribute) */
+  const uint8_t* values;              /* [n][count] 32 B: Sc (scalar kinds) or Pt M1 (point kinds)        */
+  const uint8_t* M2;                  /* [n][count] Pt: Plaintext.M2 rows for SECRET_POINT positions     */
+  const uint8_t* m3;                  /* [n][count] Sc: Plaintext.m3 rows for SECRET_POINT positions     */
+  const uint8_t* t;                   /* [count] Sc */
+  const uint8_t* U;                   /* [count] Pt */
+  const uint8_t* V;                   /* [count] Pt */
+} afx_credentials_soa;
+
+/* symmetric::Keypair (src/symmetric.rs:52-56,68-81); one keypair per item */
+typedef struct {
+  const uint8_t* a;   /* [count] Sc */
+  const uint8_t* a0;  /* [count] Sc */
+  const uint8_t* a1;  /* [count] Sc */
+  const uint8_t* pk;  /* [count] Pt */
+} afx_keypairs_soa;
+
+typedef struct {
+  const uint8_t* z_wide;     /* [count][64]   Scalar::random for the nonce z (presentation.rs:162)       */
+  const uint8_t* rng_seed;   /* [count][32]   thread_rng() draw of the presentation's prove_compact      */
+  const uint8_t* enc_seeds;  /* [n_secret_points][count][32]  same for each ProofOfEncryption, in order   */
+} afx_show_randomness;
+
+/* Output arrays mirror afx_presentation_soa / afx_encproof_soa but writable. */
+typedef struct {
+  uint8_t* challenge; uint8_t* responses;
+  uint8_t* pk; uint8_t* E1; uint8_t* E2; uint8_t* C_y_1; uint8_t* C_y_2; uint8_t* C_y_3; uint8_t* C_y_2p;
+} afx_encproof_out;
+typedef struct {
+  uint8_t* challenge; uint8_t* responses;      /* [3+hs][count] */
+  uint8_t* C_x_0; uint8_t* C_x_1; uint8_t* C_V;
+  uint8_t* C_y;                                /* [n][count] */
+  uint8_t* attr_values;                        /* [n][count]: revealed values copied through */
+  const afx_encproof_out* enc;                 /* [n_secret_points] */
+} afx_presentation_out;
+
+/* keypairs == NULL with a SECRET_POINT attribute => every status AFX_ST_NO_SYMMETRIC_KEY.
+ * `shape_out` receives the presentation shape (kinds, hidden indices, enc indices). */
+int afx_show(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs,
+             const afx_show_randomness* rnd, size_t count, const afx_presentation_out* out, afx_shape* shape_out,
+             uint8_t* status);
+int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs,
+                 const afx_show_randomness* rnd, size_t count, const afx_presentation_out* out, afx_shape* shape_out,
+                 uint8_t* status_dev);
+
+/* ---- setup helpers (cold path; still GPU arithmetic) ---------------------------------------- */
+
+/* IssuerParameters::generate (src/parameters.rs:349-362) and W = w*G_w (src/amacs.rs:104): given
+ * sysparams and the key scalars laid out as amacs::SecretKey::to_bytes minus the trailing W
+ * (u32 n || w || w' || x0 || x1 || y[n]), writes W (32 B) and C_W || I (64 B). */
+int afx_issuer_keygen(int device, const uint8_t* sysparams, size_t sysparams_len, const uint8_t* key_scalars,
+                      size_t key_scalars_len, uint8_t W_out[32], uint8_t issuer_params_out[64]);
+
+/* Batch ristretto255 primitives (dalek CompressedRistretto::decompress -> compress round trip,
+ * RistrettoPoint::from_uniform_bytes, Scalar::from_bytes_mod_order_wide); used to build synthetic
+ * attribute values and by the parity tests of the K* rows. */
+int afx_points_from_uniform_bytes(afx_ctx* ctx, const uint8_t* wide /*[count][64]*/, size_t count, uint8_t* out /*[count] Pt*/);
+int afx_scalars_from_wide_bytes(afx_ctx* ctx, const uint8_t* wide /*[count][64]*/, size_t count, uint8_t* out /*[count] Sc*/);
+int afx_points_validate(afx_ctx* ctx, const uint8_t* pts /*[count] Pt*/, size_t count, uint8_t* ok /*[count]*/,
+                        uint8_t* reencoded /*[count] Pt or NULL*/);
+/* out[i] = sum_k scalars[k][i] * points[k][i]  (RistrettoPoint::multiscalar_mul, amacs.rs:270) */
+int afx_multiscalar_mul(afx_ctx* ctx, uint32_t n_terms, const uint8_t* scalars /*[n_terms][count] Sc*/,
+                        const uint8_t* points /*[n_terms][count] Pt*/, size_t count, uint8_t* out /*[count] Pt*/,
+                        uint8_t* ok /*[count]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AEONFLUX_GPU_H */
