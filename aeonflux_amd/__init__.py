@@ -1,0 +1,154 @@
+"""aeonflux_amd — MI355X (gfx950) batch engine for aeonflux's credential NIZKs.
+
+Python mirror of the C ABI in include/aeonflux_gpu.h (ctypes over aeonflux_amd/lib/libaeonflux_gpu.so).
+All arithmetic runs in HIP kernels; there is no CPU fallback: importing the engine without the built
+library, or creating a context without a GPU, raises.  PyTorch is used by callers only for device memory
+and process groups (bench.py); this module takes raw pointers.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaeonflux_gpu.so")
+MAX_ATTRIBUTES = 32
+
+OK, E_BAD_ARGS, E_BAD_PARAMS, E_NO_DEVICE, E_HIP, E_NO_KEY = 0, -1, -2, -3, -4, -5
+ST_OK, ST_VERIFICATION_FAILURE, ST_MAC_CREATION, ST_NO_SYMMETRIC_KEY = 0, 1, 2, 3
+ATTR_PUBLIC_SCALAR, ATTR_SECRET_SCALAR, ATTR_PUBLIC_POINT, ATTR_EITHER_POINT, ATTR_SECRET_POINT = range(5)
+ENC_PUBLIC_SCALAR, ENC_SECRET_SCALAR, ENC_PUBLIC_POINT, ENC_SECRET_POINT = range(4)
+
+
+class AfxError(RuntimeError):
+    def __init__(self, rc, msg):
+        super().__init__("aeonflux_gpu error %d: %s" % (rc, msg))
+        self.rc = rc
+
+
+class Shape(C.Structure):
+    _fields_ = [("n_attributes", C.c_uint32), ("kinds", C.c_uint8 * MAX_ATTRIBUTES), ("n_responses", C.c_uint32),
+                ("n_hidden_scalars", C.c_uint32), ("hidden_scalar_indices", C.c_uint16 * MAX_ATTRIBUTES),
+                ("n_enc_proofs", C.c_uint32), ("enc_indices", C.c_uint16 * MAX_ATTRIBUTES)]
+
+
+class EncProofSoA(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("challenge", "responses", "pk", "E1", "E2", "C_y_1", "C_y_2", "C_y_3", "C_y_2p")]
+
+
+class PresentationSoA(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("challenge", "responses", "C_x_0", "C_x_1", "C_V", "C_y", "attr_values")] + \
+               [("enc", C.POINTER(EncProofSoA))]
+
+
+class AttributesSoA(C.Structure):
+    _fields_ = [("n_attributes", C.c_uint32), ("kinds", C.c_uint8 * MAX_ATTRIBUTES), ("values", C.c_void_p)]
+
+
+class IssueRandomness(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("t_wide", "U_wide", "rng_seed")]
+
+
+class IssuanceSoA(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("t", "U", "V", "challenge", "responses")]
+
+
+class CredentialsSoA(C.Structure):
+    _fields_ = [("n_attributes", C.c_uint32), ("kinds", C.c_uint8 * MAX_ATTRIBUTES)] + \
+               [(k, C.c_void_p) for k in ("values", "M2", "m3", "t", "U", "V")]
+
+
+class KeypairsSoA(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("a", "a0", "a1", "pk")]
+
+
+class ShowRandomness(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("z_wide", "rng_seed", "enc_seeds")]
+
+
+class EncProofOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("challenge", "responses", "pk", "E1", "E2", "C_y_1", "C_y_2", "C_y_3", "C_y_2p")]
+
+
+class PresentationOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("challenge", "responses", "C_x_0", "C_x_1", "C_V", "C_y", "attr_values")] + \
+               [("enc", C.POINTER(EncProofOut))]
+
+
+_LIB = None
+
+
+def lib():
+    """Load the HIP engine.  Raises if it has not been built (python __graft_entry__.py build)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("aeonflux_amd: %s is missing — build it with `make -C aeonflux_amd/csrc`; "
+                              "there is no CPU fallback" % LIB_PATH)
+        _LIB = C.CDLL(LIB_PATH)
+        _LIB.afx_last_error.restype = C.c_char_p
+        _LIB.afx_ctx_stream.restype = C.c_void_p
+        _LIB.afx_ctx_stream.argtypes = [C.c_void_p]
+        _LIB.afx_ctx_n_attributes.restype = C.c_uint32
+        _LIB.afx_ctx_n_attributes.argtypes = [C.c_void_p]
+        _LIB.afx_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p]
+        _LIB.afx_ctx_destroy.argtypes = [C.c_void_p]
+        _LIB.afx_ctx_destroy.restype = None
+        for name in ("afx_verify_presentations", "afx_verify_presentations_dev"):
+            getattr(_LIB, name).argtypes = [C.c_void_p, C.POINTER(Shape), C.POINTER(PresentationSoA), C.c_size_t, C.c_void_p]
+        for name in ("afx_verify_encryption_proofs", "afx_verify_encryption_proofs_dev"):
+            getattr(_LIB, name).argtypes = [C.c_void_p, C.c_uint16, C.POINTER(EncProofSoA), C.c_size_t, C.c_void_p]
+        _LIB.afx_points_from_uniform_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        _LIB.afx_scalars_from_wide_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        _LIB.afx_points_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        _LIB.afx_multiscalar_mul.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        for name in ("afx_issue", "afx_issue_dev"):
+            if hasattr(_LIB, name):
+                getattr(_LIB, name).argtypes = [C.c_void_p, C.POINTER(AttributesSoA), C.POINTER(IssueRandomness), C.c_size_t,
+                                                C.POINTER(IssuanceSoA), C.c_void_p]
+        for name in ("afx_verify_issuances", "afx_verify_issuances_dev"):
+            if hasattr(_LIB, name):
+                getattr(_LIB, name).argtypes = [C.c_void_p, C.POINTER(AttributesSoA), C.POINTER(IssuanceSoA), C.c_uint32, C.c_size_t, C.c_void_p]
+        for name in ("afx_show", "afx_show_dev"):
+            if hasattr(_LIB, name):
+                getattr(_LIB, name).argtypes = [C.c_void_p, C.POINTER(CredentialsSoA), C.POINTER(KeypairsSoA), C.POINTER(ShowRandomness),
+                                                C.c_size_t, C.POINTER(PresentationOut), C.POINTER(Shape), C.c_void_p]
+        if hasattr(_LIB, "afx_issuer_keygen"):
+            _LIB.afx_issuer_keygen.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p]
+    return _LIB
+
+
+def check(rc):
+    if rc != OK:
+        raise AfxError(rc, (lib().afx_last_error() or b"").decode())
+
+
+class Context:
+    """An issuer-side (key given) or user-side (key=None) engine context on one GPU."""
+
+    def __init__(self, sysparams, amacs_key, issuer_params, device=0):
+        h = C.c_void_p()
+        check(lib().afx_ctx_create(C.byref(h), device, sysparams, len(sysparams), amacs_key, len(amacs_key) if amacs_key else 0,
+                                   issuer_params))
+        self.h = h
+        self.n = lib().afx_ctx_n_attributes(h)
+        self.device = device
+
+    @property
+    def stream(self):
+        return lib().afx_ctx_stream(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().afx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    # ---- Issuer::verify ----
+    def verify_presentations(self, shape, soa, count, status_ptr, device_pointers=False):
+        fn = lib().afx_verify_presentations_dev if device_pointers else lib().afx_verify_presentations
+        check(fn(self.h, C.byref(shape), C.byref(soa), count, status_ptr))
+
+    def verify_encryption_proofs(self, index, soa, count, status_ptr, device_pointers=False):
+        fn = lib().afx_verify_encryption_proofs_dev if device_pointers else lib().afx_verify_encryption_proofs
+        check(fn(self.h, index, C.byref(soa), count, status_ptr))

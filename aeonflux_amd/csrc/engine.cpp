@@ -1,0 +1,290 @@
+// Engine core: device buffers, launch assembler, Schnorr constraint-system builder.
+#include "engine.hpp"
+#include <string.h>
+#include <algorithm>
+#include <stdexcept>
+
+namespace afx {
+
+static thread_local std::string g_error;
+void set_error(const std::string& s) { g_error = s; }
+const char* last_error() { return g_error.c_str(); }
+
+int DevBuf::ensure(size_t n) {
+  if (n <= cap) return AFX_OK;
+  if (p) {
+    hipError_t e = hipFree(p);
+    p = nullptr; cap = 0;
+    if (e != hipSuccess) { set_error(std::string("hipFree: ") + hipGetErrorString(e)); return AFX_E_HIP; }
+  }
+  const size_t want = (n + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e)); return AFX_E_HIP; }
+  cap = want;
+  return AFX_OK;
+}
+void DevBuf::release(bool wipe) {
+  if (!p) return;
+  if (wipe) (void)hipMemset(p, 0, cap);
+  (void)hipFree(p);
+  p = nullptr; cap = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Assembler
+// ------------------------------------------------------------------------------------------------
+Assembler::Assembler(afx_ctx* c, uint32_t cnt, bool sizing) : ctx(c), count(cnt), sizing_(sizing) {
+  blob_.reserve(1 << 16);
+  blob_base_ = (uint8_t*)ctx->blob_dev[ctx->blob_next].p;
+  ws_base_ = sizing ? nullptr : (uint8_t*)ctx->ws.p;
+  bad_ = (uint32_t*)ws_alloc(sizeof(uint32_t) * (size_t)count);
+  Launch l;
+  l.kind = L_FILL_BAD;
+  launches.push_back(l);
+}
+uint8_t* Assembler::ws_alloc(size_t bytes) {
+  const size_t off = (ws_off_ + 255) & ~size_t(255);
+  ws_off_ = off + bytes;
+  return ws_base_ + off;
+}
+int32_t* Assembler::new_var() { return (int32_t*)ws_alloc(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)count); }
+uint8_t* Assembler::new_enc() { return ws_alloc(32 * (size_t)count); }
+uint64_t* Assembler::new_state() { return (uint64_t*)ws_alloc(sizeof(uint64_t) * 25 * (size_t)count); }
+size_t Assembler::blob_alloc(size_t bytes, size_t align) {
+  const size_t off = (blob_.size() + align - 1) & ~(align - 1);
+  blob_.resize(off + bytes);
+  return off;
+}
+template <class T>
+void Assembler::add_jobs(LaunchKind k, const std::vector<T>& jobs, uint32_t max_fixed) {
+  if (jobs.empty()) return;
+  Launch l;
+  l.kind = k;
+  l.njobs = (uint32_t)jobs.size();
+  l.max_fixed = max_fixed;
+  l.jobs_off = blob_alloc(sizeof(T) * jobs.size(), 16);
+  memcpy(blob_.data() + l.jobs_off, jobs.data(), sizeof(T) * jobs.size());
+  launches.push_back(l);
+}
+void Assembler::decode(const std::vector<afx_decode_job>& jobs) { add_jobs(L_DECODE, jobs, 0); }
+void Assembler::sccheck(const std::vector<afx_sccheck_job>& jobs) { add_jobs(L_SCCHECK, jobs, 0); }
+void Assembler::pointop(const std::vector<afx_pointop_job>& jobs) { add_jobs(L_POINTOP, jobs, 0); }
+void Assembler::scalarop(const std::vector<afx_scalarop_job>& jobs) { add_jobs(L_SCALAROP, jobs, 0); }
+void Assembler::hash(const std::vector<afx_hash_program>& progs) { add_jobs(L_HASH, progs, 0); }
+void Assembler::msm(std::vector<afx_msm_job> jobs) {
+  if (jobs.empty()) return;
+  // longest jobs first: blockIdx.y is the job and low block ids are dispatched first
+  std::stable_sort(jobs.begin(), jobs.end(), [](const afx_msm_job& a, const afx_msm_job& b) {
+    return a.n_var * 8 + (a.n_terms - a.n_var) * 7 > b.n_var * 8 + (b.n_terms - b.n_var) * 7;
+  });
+  uint32_t dslot = 0, tslot = 0, max_fixed = 0;
+  for (afx_msm_job& j : jobs) {
+    j.digit_slot = dslot; dslot += j.n_terms;
+    j.table_slot = tslot; tslot += j.n_var;
+    max_fixed = std::max(max_fixed, j.n_terms - j.n_var);
+  }
+  max_digit_slots = std::max<size_t>(max_digit_slots, dslot);
+  max_table_slots = std::max<size_t>(max_table_slots, tslot);
+  add_jobs(L_MSM, jobs, max_fixed);
+}
+void Assembler::from_uniform(const uint8_t* wide, uint8_t* out_enc, int32_t* out_var) {
+  Launch l; l.kind = L_FROM_UNIFORM; l.in = wide; l.out = out_enc; l.out_var = out_var;
+  launches.push_back(l);
+}
+void Assembler::reduce_wide(const uint8_t* wide, uint8_t* out) {
+  Launch l; l.kind = L_REDUCE_WIDE; l.in = wide; l.out = out;
+  launches.push_back(l);
+}
+void Assembler::copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
+  Launch l; l.kind = L_COPY; l.in = src; l.out = dst; l.bytes = bytes;
+  launches.push_back(l);
+}
+void Assembler::finish(uint8_t* status_dev, uint8_t fail_code) {
+  Launch l; l.kind = L_FINISH; l.out = status_dev; l.fail_code = fail_code;
+  launches.push_back(l);
+}
+size_t Assembler::total_ws_bytes() const {
+  size_t off = (ws_off_ + 255) & ~size_t(255);
+  off += max_table_slots * (size_t)count * AFX_VAR_TABLE_DWORDS * sizeof(int32_t);
+  off = (off + 255) & ~size_t(255);
+  off += max_digit_slots * 8 * (size_t)count * sizeof(uint32_t);
+  return off + 256;
+}
+
+int Assembler::run() {
+  if (sizing_) { set_error("run() on a sizing assembler"); return AFX_E_BAD_ARGS; }
+  if (total_ws_bytes() > ctx->ws.cap) { set_error("workspace smaller than the sized plan"); return AFX_E_BAD_ARGS; }
+  int32_t* table_ws = (int32_t*)ws_alloc(max_table_slots * (size_t)count * AFX_VAR_TABLE_DWORDS * sizeof(int32_t));
+  uint32_t* digit_ws = (uint32_t*)ws_alloc(max_digit_slots * 8 * (size_t)count * sizeof(uint32_t));
+  hipStream_t s = ctx->stream;
+  const int slot = ctx->blob_next;
+  if (blob_.size() > ctx->blob_dev[slot].cap || blob_.size() > ctx->blob_host_cap[slot]) { set_error("plan blob too large"); return AFX_E_BAD_ARGS; }
+  // the pinned mirror of this slot may still be the source of an in-flight copy from two calls ago
+  AFX_HIP(hipEventSynchronize(ctx->blob_event[slot]));
+  memcpy(ctx->blob_host[slot], blob_.data(), blob_.size());
+  if (!blob_.empty()) AFX_HIP(hipMemcpyAsync(ctx->blob_dev[slot].p, ctx->blob_host[slot], blob_.size(), hipMemcpyHostToDevice, s));
+  AFX_HIP(hipEventRecord(ctx->blob_event[slot], s));
+  ctx->blob_next ^= 1;
+  const int32_t* ft = (const int32_t*)ctx->d_fixed_tables.p;
+  for (const Launch& l : launches) {
+    const uint8_t* jobs = blob_base_ + l.jobs_off;
+    switch (l.kind) {
+      case L_FILL_BAD: AFX_HIP(afxk_fill_u32(s, bad_, fail_all ? AFX_BAD_SHAPE : 0u, count)); break;
+      case L_DECODE: AFX_HIP(afxk_decode(s, (const afx_decode_job*)jobs, l.njobs, bad_, count)); break;
+      case L_SCCHECK: AFX_HIP(afxk_sccheck(s, (const afx_sccheck_job*)jobs, l.njobs, bad_, count)); break;
+      case L_POINTOP: AFX_HIP(afxk_pointop(s, (const afx_pointop_job*)jobs, l.njobs, bad_, count)); break;
+      case L_SCALAROP: AFX_HIP(afxk_scalarop(s, (const afx_scalarop_job*)jobs, l.njobs, count)); break;
+      case L_MSM: AFX_HIP(afxk_msm(s, (const afx_msm_job*)jobs, l.njobs, l.max_fixed, ft, table_ws, digit_ws, bad_, count)); break;
+      case L_HASH: AFX_HIP(afxk_hash(s, (const afx_hash_program*)jobs, l.njobs, bad_, count)); break;
+      case L_FROM_UNIFORM: AFX_HIP(afxk_from_uniform(s, l.in, l.out, l.out_var, count)); break;
+      case L_REDUCE_WIDE: AFX_HIP(afxk_reduce_wide(s, l.in, l.out, count)); break;
+      case L_COPY: AFX_HIP(hipMemcpyAsync(l.out, l.in, l.bytes, hipMemcpyDeviceToDevice, s)); break;
+      case L_FINISH: AFX_HIP(afxk_finish(s, bad_, l.out, count, 0, l.fail_code)); break;
+    }
+  }
+  return AFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SchnorrBuilder
+// ------------------------------------------------------------------------------------------------
+SchnorrBuilder::SchnorrBuilder(Assembler& as, const char* transcript_label, const char* proof_label)
+    : as_(as), sim_(transcript_label) {
+  // TranscriptProtocol::domain_sep (zkp toolbox)
+  sim_.append_message_const("dom-sep", (const uint8_t*)"schnorrzkp/1.0/ristretto255", 27);
+  sim_.append_message_const("dom-sep", (const uint8_t*)proof_label, strlen(proof_label));
+}
+int SchnorrBuilder::field_of(const uint8_t* dev) {
+  for (size_t i = 0; i < fields_.size(); i++)
+    if (fields_[i] == dev) return (int)i;
+  fields_.push_back(dev);
+  return (int)fields_.size() - 1;
+}
+int SchnorrBuilder::allocate_scalar(const char* label, const ScalarVar& v) {
+  sim_.append_message_const("scvar", (const uint8_t*)label, strlen(label));
+  scalars_.push_back(v);
+  return (int)scalars_.size() - 1;
+}
+int SchnorrBuilder::allocate_point(const char* label, const PointVar& p) {
+  sim_.append_message_const("ptvar", (const uint8_t*)label, strlen(label));
+  if (p.is_const) {
+    const Enc& e = p.neg ? as_.ctx->gen_neg_enc[p.gen] : as_.ctx->gen_enc[p.gen];
+    // validate_and_append_point_var rejects the identity encoding: with a constant point, for every item
+    bool nz = false;
+    for (uint8_t b : e) nz |= (b != 0);
+    if (!nz) as_.fail_all = true;
+    sim_.append_message_const("val", e.data(), 32);
+  } else {
+    sim_.append_message_hole32("val", field_of(p.enc_dev));
+  }
+  points_.push_back(p);
+  point_labels_.push_back(label);
+  return (int)points_.size() - 1;
+}
+void SchnorrBuilder::constrain(int lhs, const std::vector<std::pair<int, int>>& terms) { constraints_.push_back({ lhs, terms }); }
+
+afx_msm_term SchnorrBuilder::term_for(const uint8_t* scalar, uint32_t stride, const PointVar& p, bool negate) {
+  afx_msm_term t;
+  memset(&t, 0, sizeof t);
+  t.scalar = scalar;
+  t.scalar_stride = stride;
+  if (p.is_const) { t.fixed_idx = (int32_t)p.gen; t.var = nullptr; t.negate = (negate != p.neg) ? 1u : 0u; }
+  else { t.fixed_idx = -1; t.var = p.var; t.negate = negate ? 1u : 0u; }
+  return t;
+}
+static void order_terms(afx_msm_job& j, const std::vector<afx_msm_term>& terms) {
+  if (terms.size() > AFX_MSM_MAX_TERMS) throw std::length_error("too many terms in one multiscalar job");
+  j.n_terms = (uint32_t)terms.size();
+  j.n_var = 0;
+  uint32_t k = 0;
+  for (const afx_msm_term& t : terms) if (t.fixed_idx < 0) { j.term[k++] = t; j.n_var++; }
+  for (const afx_msm_term& t : terms) if (t.fixed_idx >= 0) j.term[k++] = t;
+}
+afx_hash_program SchnorrBuilder::make_program(const StrobeSim& sim) {
+  std::vector<afx_hash_record> recs;
+  sim.emit(recs);
+  afx_hash_program p;
+  memset(&p, 0, sizeof p);
+  p.init_state = as_.put(sim.init_state, 25);
+  p.n_records = (uint32_t)recs.size();
+  p.records = as_.put(recs.data(), recs.size());
+  p.fields = as_.put(fields_.data(), fields_.size());
+  return p;
+}
+
+void SchnorrBuilder::verify_compact(const uint8_t* challenge_dev, std::vector<afx_msm_job>& msm_out, std::vector<afx_hash_program>& hash_out) {
+  // R_j = sum resp[s] * P  - c * LHS, appended as "blindcom"
+  for (auto& cn : constraints_) {
+    std::vector<afx_msm_term> terms;
+    for (auto& sp : cn.second) terms.push_back(term_for(scalars_[sp.first].dev, scalars_[sp.first].stride, points_[sp.second], false));
+    terms.push_back(term_for(challenge_dev, 32, points_[cn.first], true));
+    afx_msm_job j;
+    memset(&j, 0, sizeof j);
+    order_terms(j, terms);
+    j.out_enc = as_.new_enc();
+    msm_out.push_back(j);
+    sim_.append_message_const("blindcom", (const uint8_t*)point_labels_[cn.first].c_str(), point_labels_[cn.first].size());
+    sim_.append_message_hole32("val", field_of(j.out_enc));
+  }
+  sim_.challenge64("chal", AFX_SQ_CHALLENGE_COMPARE, 0);
+  afx_hash_program p = make_program(sim_);
+  p.challenge = challenge_dev;
+  hash_out.push_back(p);
+}
+
+void SchnorrBuilder::prove_compact(const uint8_t* rng_seed_dev, uint8_t* challenge_out, uint8_t* responses_out, size_t response_row_stride,
+                                   std::vector<afx_hash_program>& rng_hash, std::vector<afx_msm_job>& msm_out,
+                                   std::vector<afx_hash_program>& chal_hash, std::vector<afx_scalarop_job>& resp_ops) {
+  const size_t ns = scalars_.size();
+  // TranscriptRngBuilder: clone, rekey with every witness, finalize with the external 32 bytes
+  StrobeSim rng = sim_;
+  const uint8_t len32[4] = { 32, 0, 0, 0 }, len64[4] = { 64, 0, 0, 0 };
+  for (size_t i = 0; i < ns; i++) {
+    rng.meta_ad_const((const uint8_t*)"", 0, false);
+    rng.meta_ad_const(len32, 4, true);
+    if (scalars_[i].stride == 0) rng.key_const(scalars_[i].host.data(), 32);
+    else rng.key_hole32(field_of(scalars_[i].dev));
+  }
+  rng.meta_ad_const((const uint8_t*)"rng", 3, false);
+  rng.key_hole32(field_of(rng_seed_dev));
+  std::vector<uint8_t*> blind(ns);
+  for (size_t i = 0; i < ns; i++) {
+    blind[i] = as_.new_enc();
+    rng.meta_ad_const(len64, 4, false);
+    rng.prf64(AFX_SQ_SCALAR_OUT, (uint32_t)i);
+  }
+  // the rng's last prf closes on a completed record, so emit() sees everything
+  // commitments R_j = sum blind[s] * P
+  for (auto& cn : constraints_) {
+    std::vector<afx_msm_term> terms;
+    for (auto& sp : cn.second) terms.push_back(term_for(blind[sp.first], 32, points_[sp.second], false));
+    afx_msm_job j;
+    memset(&j, 0, sizeof j);
+    order_terms(j, terms);
+    j.out_enc = as_.new_enc();
+    msm_out.push_back(j);
+    sim_.append_message_const("blindcom", (const uint8_t*)point_labels_[cn.first].c_str(), point_labels_[cn.first].size());
+    sim_.append_message_hole32("val", field_of(j.out_enc));
+  }
+  sim_.challenge64("chal", AFX_SQ_SCALAR_OUT, 0);
+  // programs are made after all field_of() calls so both share the final field table
+  afx_hash_program pr = make_program(rng);
+  pr.outs = as_.put(blind.data(), blind.size());
+  rng_hash.push_back(pr);
+  afx_hash_program pc = make_program(sim_);
+  uint8_t* couts[1] = { challenge_out };
+  pc.outs = as_.put(couts, 1);
+  chal_hash.push_back(pc);
+  // responses s*c + b
+  for (size_t i = 0; i < ns; i++) {
+    afx_scalarop_job o;
+    memset(&o, 0, sizeof o);
+    o.a = scalars_[i].dev; o.a_stride = scalars_[i].stride;
+    o.b = challenge_out; o.b_stride = 32;
+    o.c = blind[i]; o.c_stride = 32;
+    o.out = responses_out + i * response_row_stride;
+    resp_ops.push_back(o);
+  }
+}
+
+}  // namespace afx

@@ -1,0 +1,205 @@
+// Host side of the engine: context (generators, tables, key on the device), workspace, the plan
+// "assembler" that turns a statement into kernel launches, and the Schnorr constraint-system builder that
+// mirrors zkp's toolbox API (allocate_scalar / allocate_point / constrain / verify_compact / prove_compact)
+// so the statement code in statements.cpp reads like /root/reference/src/nizk/*.rs.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <array>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../include/aeonflux_gpu.h"
+#include "kernels.h"
+#include "plan.h"
+#include "strobe_sim.hpp"
+
+namespace afx {
+
+void set_error(const std::string& s);
+const char* last_error();
+#define AFX_HIP(call)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e__ = (call);                                                                           \
+    if (e__ != hipSuccess) {                                                                           \
+      afx::set_error(std::string(#call) + ": " + hipGetErrorString(e__));                             \
+      return AFX_E_HIP;                                                                                \
+    }                                                                                                  \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n);      // grow-only; returns AFX_OK / AFX_E_HIP
+  void release(bool wipe);
+};
+
+using Enc = std::array<uint8_t, 32>;
+
+}  // namespace afx
+
+struct afx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint32_t n = 0, g = 0;
+  bool has_key = false;
+  // generator ids: index into the SystemParameters point list, then I, C_W, W
+  uint32_t ngen = 0;
+  uint32_t id_G() const { return 0; }
+  uint32_t id_Gw() const { return 1; }
+  uint32_t id_Gwp() const { return 2; }
+  uint32_t id_Gx0() const { return 3; }
+  uint32_t id_Gx1() const { return 4; }
+  uint32_t id_Gy(uint32_t i) const { return 5 + i; }
+  uint32_t id_Gm(uint32_t i) const { return 5 + g + i; }
+  uint32_t id_GV() const { return 5 + g + n; }
+  uint32_t id_Ga() const { return 6 + g + n; }
+  uint32_t id_Ga0() const { return 7 + g + n; }
+  uint32_t id_Ga1() const { return 8 + g + n; }
+  uint32_t id_I() const { return 9 + g + n; }
+  uint32_t id_CW() const { return 10 + g + n; }
+  uint32_t id_W() const { return 11 + g + n; }
+  std::vector<afx::Enc> gen_enc, gen_neg_enc;   // host copies of compress(G), compress(-G)
+  // device residents
+  afx::DevBuf d_gen_enc, d_fixed_tables, d_gen_ext, d_key, d_consts;
+  // key scalar slots in d_key ([k][32]): w, w', x0, x1, y[0..n), then constants one, zero
+  const uint8_t* key_w() const { return (const uint8_t*)d_key.p; }
+  const uint8_t* key_wp() const { return (const uint8_t*)d_key.p + 32; }
+  const uint8_t* key_x0() const { return (const uint8_t*)d_key.p + 64; }
+  const uint8_t* key_x1() const { return (const uint8_t*)d_key.p + 96; }
+  const uint8_t* key_y(uint32_t i) const { return (const uint8_t*)d_key.p + 128 + 32 * i; }
+  const uint8_t* const_one() const { return (const uint8_t*)d_consts.p; }
+  std::vector<afx::Enc> host_key;               // w, w', x0, x1, y...; wiped on destroy
+  const int32_t* gen_ext(uint32_t id) const { return (const int32_t*)d_gen_ext.p + (size_t)id * AFX_VAR_DWORDS; }
+  // per-call scratch (grow-only; zeroed on destroy)
+  afx::DevBuf ws, staging;
+  // plan blobs: two-deep ring of (pinned host, device) pairs so a call can be assembled while the
+  // previous one still runs; `blob_event[i]` marks the end of the copy that last used slot i
+  afx::DevBuf blob_dev[2];
+  void* blob_host[2] = { nullptr, nullptr };
+  size_t blob_host_cap[2] = { 0, 0 };
+  hipEvent_t blob_event[2] = { nullptr, nullptr };
+  int blob_next = 0;
+};
+
+namespace afx {
+
+enum LaunchKind { L_FILL_BAD, L_DECODE, L_SCCHECK, L_POINTOP, L_SCALAROP, L_MSM, L_HASH, L_FROM_UNIFORM, L_REDUCE_WIDE, L_COPY, L_FINISH };
+
+struct Launch {
+  LaunchKind kind;
+  size_t jobs_off = 0;      // offset of the job array in the blob
+  uint32_t njobs = 0;
+  uint32_t max_fixed = 0;   // L_MSM: LDS sizing
+  // L_FROM_UNIFORM / L_REDUCE_WIDE / L_FINISH direct arguments
+  const uint8_t* in = nullptr;
+  uint8_t* out = nullptr;
+  int32_t* out_var = nullptr;
+  uint8_t fail_code = AFX_ST_VERIFICATION_FAILURE;
+  size_t bytes = 0;         // L_COPY
+};
+
+// Builds one call's kernel launch list over a chunk of `count` items.
+class Assembler {
+ public:
+  // sizing == true: dry run that only measures workspace / blob needs (device addresses are meaningless)
+  Assembler(afx_ctx* ctx, uint32_t count, bool sizing);
+  afx_ctx* ctx;
+  uint32_t count;
+  bool fail_all = false;      // statement-level failure for every item (reference would panic / reject all)
+
+  // workspace (device addresses are final; the bump pointer starts at the chunk workspace base)
+  int32_t* new_var();         // extended point, SoA [40][count]
+  uint8_t* new_enc();         // [count][32]
+  uint64_t* new_state();      // [25][count]
+  size_t total_ws_bytes() const;   // workspace incl. window tables and recoded scalars
+  size_t blob_bytes() const { return blob_.size(); }
+
+  // launches, executed in the order added
+  void decode(const std::vector<afx_decode_job>& jobs);
+  void sccheck(const std::vector<afx_sccheck_job>& jobs);
+  void pointop(const std::vector<afx_pointop_job>& jobs);
+  void scalarop(const std::vector<afx_scalarop_job>& jobs);
+  void msm(std::vector<afx_msm_job> jobs);   // assigns digit/table slots
+  void hash(const std::vector<afx_hash_program>& progs);
+  void from_uniform(const uint8_t* wide, uint8_t* out_enc, int32_t* out_var);
+  void reduce_wide(const uint8_t* wide, uint8_t* out);
+  void copy(uint8_t* dst, const uint8_t* src, size_t bytes);   // device-to-device
+  void finish(uint8_t* status_dev, uint8_t fail_code);
+
+  // blob: plan data copied to the device in one transfer; returns DEVICE address of the copy
+  template <class T>
+  const T* put(const T* src, size_t n) {
+    const size_t off = blob_alloc(sizeof(T) * n, alignof(T) < 8 ? 8 : alignof(T));
+    memcpy(blob_.data() + off, src, sizeof(T) * n);
+    return reinterpret_cast<const T*>(blob_base_ + off);
+  }
+  size_t blob_alloc(size_t bytes, size_t align);
+
+  uint32_t* bad() const { return bad_; }
+  int run();   // upload blob, launch everything on ctx->stream (asynchronous)
+
+  size_t max_digit_slots = 0, max_table_slots = 0;
+  std::vector<Launch> launches;
+
+ private:
+  uint8_t* ws_alloc(size_t bytes);
+  template <class T>
+  void add_jobs(LaunchKind k, const std::vector<T>& jobs, uint32_t max_fixed);
+  bool sizing_ = false;
+  std::vector<uint8_t> blob_;
+  uint8_t* blob_base_ = nullptr;   // device address the blob will live at
+  uint8_t* ws_base_ = nullptr;
+  size_t ws_off_ = 0;
+  uint32_t* bad_ = nullptr;
+  friend class SchnorrBuilder;
+};
+
+// A point variable of a constraint system: a batch constant (generator id, maybe negated) or a per-item
+// variable (extended coordinates in the workspace + the [count][32] array holding its encoding).
+struct PointVar {
+  bool is_const = true;
+  uint32_t gen = 0;
+  bool neg = false;
+  const int32_t* var = nullptr;
+  const uint8_t* enc_dev = nullptr;
+  static PointVar Const(uint32_t gen, bool neg = false) { PointVar p; p.is_const = true; p.gen = gen; p.neg = neg; return p; }
+  static PointVar Var(const int32_t* var, const uint8_t* enc) { PointVar p; p.is_const = false; p.var = var; p.enc_dev = enc; return p; }
+};
+// A scalar variable: verifier side = the response array; prover side = the witness (per item, or a batch
+// constant such as the issuer key when stride == 0; `host` holds its bytes then).
+struct ScalarVar {
+  const uint8_t* dev = nullptr;
+  uint32_t stride = 32;
+  Enc host{};   // only for stride == 0 (needed as constant bytes in the prover's rng rekeying)
+};
+
+// zkp::toolbox::{prover::Prover, verifier::Verifier} + SchnorrCS, batch form.
+class SchnorrBuilder {
+ public:
+  SchnorrBuilder(Assembler& as, const char* transcript_label, const char* proof_label);
+  int allocate_scalar(const char* label, const ScalarVar& v);
+  int allocate_point(const char* label, const PointVar& p);
+  void constrain(int lhs, const std::vector<std::pair<int, int>>& terms);
+  // Verifier::verify_compact over the batch: commitments, transcript, challenge comparison
+  void verify_compact(const uint8_t* challenge_dev, std::vector<afx_msm_job>& msm_out, std::vector<afx_hash_program>& hash_out);
+  // Prover::prove_compact over the batch.  Fills: rng hash program (blindings), commitment msm jobs,
+  // challenge hash program, response scalar ops.  rng_seed_dev: [count][32].
+  void prove_compact(const uint8_t* rng_seed_dev, uint8_t* challenge_out, uint8_t* responses_out /* [nsc][count][32] */,
+                     size_t response_row_stride, std::vector<afx_hash_program>& rng_hash, std::vector<afx_msm_job>& msm_out,
+                     std::vector<afx_hash_program>& chal_hash, std::vector<afx_scalarop_job>& resp_ops);
+  size_t num_scalars() const { return scalars_.size(); }
+
+ private:
+  int field_of(const uint8_t* dev);
+  afx_msm_term term_for(const uint8_t* scalar, uint32_t stride, const PointVar& p, bool negate);
+  afx_hash_program make_program(const StrobeSim& sim);
+  Assembler& as_;
+  StrobeSim sim_;
+  std::vector<ScalarVar> scalars_;
+  std::vector<PointVar> points_;
+  std::vector<std::string> point_labels_;
+  std::vector<std::pair<int, std::vector<std::pair<int, int>>>> constraints_;
+  std::vector<const uint8_t*> fields_;
+};
+
+}  // namespace afx

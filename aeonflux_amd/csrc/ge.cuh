@@ -1,0 +1,227 @@
+// edwards25519 extended-coordinate arithmetic and the ristretto255 group for gfx950, one point per lane.
+//
+// Replaces curve25519-dalek's RistrettoPoint / CompressedRistretto [3P] at the reference's call sites:
+// decompress/compress (/root/reference/src/nizk/presentation.rs:373-412, src/nizk/encryption.rs:172-185,
+// src/nizk/issuance.rs:162-189), point +,-,neg (src/nizk/presentation.rs:342-351, encryption.rs:183,185),
+// from_uniform_bytes (src/amacs.rs:290).  Formulas: RFC 9496 §4.3 (decode, encode, MAP) and the
+// hwcd-2008 a=-1 extended addition/doubling.  Only group elements and canonical encodings are
+// contractual: the addition schedules here are this engine's own.
+#pragma once
+#include "constants.cuh"
+#include "fe.cuh"
+
+AFX_DEV fe fe_const(const int32_t* c) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 10; i++) r.v[i] = c[i];
+  return r;
+}
+
+struct ge_p3 { fe X, Y, Z, T; };        // extended: x = X/Z, y = Y/Z, xy = T/Z
+struct ge_p2 { fe X, Y, Z; };           // projective
+struct ge_p1p1 { fe X, Y, Z, T; };      // completed: ((X:Z), (Y:T))
+struct ge_cached { fe YpX, YmX, Z, T2d; };
+struct ge_niels { fe ypx, ymx, xy2d; }; // affine precomputed (Z = 1)
+
+AFX_DEV ge_p3 ge_identity() {
+  ge_p3 r;
+  r.X = fe_zero(); r.Y = fe_one(); r.Z = fe_one(); r.T = fe_zero();
+  return r;
+}
+AFX_DEV ge_cached ge_cached_identity() {
+  ge_cached r;
+  r.YpX = fe_one(); r.YmX = fe_one(); r.Z = fe_one(); r.T2d = fe_zero();
+  return r;
+}
+AFX_DEV ge_niels ge_niels_identity() {
+  ge_niels r;
+  r.ypx = fe_one(); r.ymx = fe_one(); r.xy2d = fe_zero();
+  return r;
+}
+AFX_DEV ge_p2 ge_p1p1_to_p2(const ge_p1p1& p) {
+  ge_p2 r;
+  // p.T may be four reduced terms deep (ge_p2_dbl): keep it in fe_mul's wide first operand
+  r.X = fe_mul(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul(p.T, p.Z);
+  return r;
+}
+AFX_DEV ge_p3 ge_p1p1_to_p3(const ge_p1p1& p) {
+  ge_p3 r;
+  r.X = fe_mul(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul(p.T, p.Z); r.T = fe_mul(p.X, p.Y);
+  return r;
+}
+AFX_DEV ge_p2 ge_p3_to_p2(const ge_p3& p) {
+  ge_p2 r;
+  r.X = p.X; r.Y = p.Y; r.Z = p.Z;
+  return r;
+}
+AFX_DEV ge_cached ge_p3_to_cached(const ge_p3& p) {
+  ge_cached r;
+  r.YpX = fe_add(p.Y, p.X); r.YmX = fe_sub(p.Y, p.X); r.Z = p.Z; r.T2d = fe_mul(p.T, fe_const(FEC_D2));
+  return r;
+}
+// cached form with (YpX, YmX) carried so the entry can itself be added to lazily (tables in memory)
+AFX_DEV ge_cached ge_p3_to_cached_reduced(const ge_p3& p) {
+  ge_cached r = ge_p3_to_cached(p);
+  r.YpX = fe_carry(r.YpX); r.YmX = fe_carry(r.YmX);
+  return r;
+}
+AFX_DEV ge_p1p1 ge_p2_dbl(const ge_p2& p) {
+  ge_p1p1 r;
+  fe XX = fe_sq(p.X), YY = fe_sq(p.Y), ZZ = fe_sq(p.Z);
+  fe B = fe_add(ZZ, ZZ);
+  fe A = fe_add(p.X, p.Y);
+  fe AA = fe_sq(A);
+  r.Y = fe_add(YY, XX);
+  r.Z = fe_sub(YY, XX);
+  r.X = fe_sub(AA, r.Y);
+  r.T = fe_sub(B, r.Z);
+  return r;
+}
+// p + q (q cached).  neg: subtract instead (swap the two products' partners, flip the sign of C).
+AFX_DEV ge_p1p1 ge_add_cached(const ge_p3& p, const ge_cached& q, bool neg) {
+  ge_p1p1 r;
+  fe qp = q.YpX, qm = q.YmX;
+  fe_cswap(qp, qm, neg);
+  fe A = fe_mul(fe_add(p.Y, p.X), qp);
+  fe B = fe_mul(fe_sub(p.Y, p.X), qm);
+  fe C = fe_cneg(fe_mul(q.T2d, p.T), neg);
+  fe ZZ = fe_mul(p.Z, q.Z);
+  fe D = fe_add(ZZ, ZZ);
+  r.X = fe_sub(A, B);
+  r.Y = fe_add(A, B);
+  r.Z = fe_add(D, C);
+  r.T = fe_sub(D, C);
+  return r;
+}
+AFX_DEV ge_p1p1 ge_madd(const ge_p3& p, const ge_niels& q, bool neg) {
+  ge_p1p1 r;
+  fe qp = q.ypx, qm = q.ymx;
+  fe_cswap(qp, qm, neg);
+  fe A = fe_mul(fe_add(p.Y, p.X), qp);
+  fe B = fe_mul(fe_sub(p.Y, p.X), qm);
+  fe C = fe_cneg(fe_mul(q.xy2d, p.T), neg);
+  fe D = fe_add(p.Z, p.Z);
+  r.X = fe_sub(A, B);
+  r.Y = fe_add(A, B);
+  r.Z = fe_add(D, C);
+  r.T = fe_sub(D, C);
+  return r;
+}
+AFX_DEV ge_p3 ge_add(const ge_p3& p, const ge_p3& q) { return ge_p1p1_to_p3(ge_add_cached(p, ge_p3_to_cached(q), false)); }
+AFX_DEV ge_p3 ge_sub(const ge_p3& p, const ge_p3& q) { return ge_p1p1_to_p3(ge_add_cached(p, ge_p3_to_cached(q), true)); }
+AFX_DEV ge_p3 ge_neg(const ge_p3& p) {
+  ge_p3 r;
+  r.X = fe_neg(p.X); r.Y = p.Y; r.Z = p.Z; r.T = fe_neg(p.T);
+  return r;
+}
+AFX_DEV ge_p3 ge_double(const ge_p3& p) { return ge_p1p1_to_p3(ge_p2_dbl(ge_p3_to_p2(p))); }
+AFX_DEV ge_p3 ge_carry(const ge_p3& p) {
+  ge_p3 r;
+  r.X = fe_carry(p.X); r.Y = fe_carry(p.Y); r.Z = fe_carry(p.Z); r.T = fe_carry(p.T);
+  return r;
+}
+
+// RFC 9496 §4.2 SQRT_RATIO_M1(u, v) (dalek FieldElement::sqrt_ratio_i).  u, v reduced or one add deep.
+AFX_DEV bool fe_sqrt_ratio_i(fe& r_out, const fe& u, const fe& v) {
+  const fe sqrt_m1 = fe_const(FEC_SQRT_M1);
+  fe v3 = fe_mul(fe_sq(v), v);
+  fe v7 = fe_mul(fe_sq(v3), v);
+  fe r = fe_mul(fe_mul(u, v3), fe_pow22523(fe_mul(u, v7)));
+  fe check = fe_mul(v, fe_sq(r));
+  fe uc = fe_carry(u);
+  fe neg_u = fe_neg(uc);
+  fe neg_u_i = fe_mul(neg_u, sqrt_m1);
+  const bool correct = fe_eq(check, uc);
+  const bool flipped = fe_eq(check, neg_u);
+  const bool flipped_i = fe_eq(check, neg_u_i);
+  fe r_prime = fe_mul(r, sqrt_m1);
+  fe_cmov(r, r_prime, flipped | flipped_i);
+  r_out = fe_abs(r);
+  return correct | flipped;
+}
+
+// RFC 9496 §4.3.1 Decode (CompressedRistretto::decompress).  w = 8 LE dwords.  Returns false on any
+// rejection; on success r is the extended point with Z = 1 and all limbs reduced.
+AFX_DEV bool ristretto_decode(ge_p3& r, const uint32_t w[8]) {
+  fe s = fe_frombytes(w);
+  uint32_t chk[8];
+  fe_tobytes(chk, s);
+  bool canonical = true;
+#pragma unroll
+  for (int i = 0; i < 8; i++) canonical &= (chk[i] == w[i]);
+  const bool s_neg = (chk[0] & 1) != 0;
+  const fe one = fe_one();
+  fe ss = fe_sq(s);
+  fe u1 = fe_sub(one, ss);
+  fe u2 = fe_add(one, ss);
+  fe u2s = fe_sq(u2);
+  fe v = fe_carry(fe_sub(fe_neg(fe_mul(fe_const(FEC_D), fe_sq(u1))), u2s));
+  fe I;
+  const bool was_square = fe_sqrt_ratio_i(I, one, fe_mul(v, u2s));
+  fe Dx = fe_mul(I, u2);
+  fe Dy = fe_mul(fe_mul(I, Dx), v);
+  fe sDx = fe_mul(s, Dx);
+  fe x = fe_abs(fe_add(sDx, sDx));
+  fe y = fe_mul(u1, Dy);
+  fe t = fe_mul(x, y);
+  const bool ok = canonical & !s_neg & was_square & !fe_is_negative(t) & !fe_is_zero(y);
+  r.X = fe_carry(x); r.Y = y; r.Z = one; r.T = t;
+  return ok;
+}
+
+// RFC 9496 §4.3.2 Encode (RistrettoPoint::compress).  p: limbs reduced (outputs of fe_mul / ge_carry).
+AFX_DEV void ristretto_encode(uint32_t w[8], const ge_p3& p) {
+  const fe one = fe_one();
+  fe u1 = fe_mul(fe_add(p.Z, p.Y), fe_sub(p.Z, p.Y));
+  fe u2 = fe_mul(p.X, p.Y);
+  fe I;
+  fe_sqrt_ratio_i(I, one, fe_mul(u1, fe_sq(u2)));
+  fe D1 = fe_mul(u1, I);
+  fe D2 = fe_mul(u2, I);
+  fe Zinv = fe_mul(fe_mul(D1, D2), p.T);
+  const fe sqrt_m1 = fe_const(FEC_SQRT_M1);
+  fe ix = fe_mul(p.X, sqrt_m1);
+  fe iy = fe_mul(p.Y, sqrt_m1);
+  fe ead = fe_mul(D1, fe_const(FEC_INVSQRT_A_MINUS_D));
+  const bool rotate = fe_is_negative(fe_mul(p.T, Zinv));
+  fe x = p.X, y = p.Y, Dinv = D2;
+  fe_cmov(x, iy, rotate);
+  fe_cmov(y, ix, rotate);
+  fe_cmov(Dinv, ead, rotate);
+  y = fe_cneg(y, fe_is_negative(fe_mul(x, Zinv)));
+  fe s = fe_abs(fe_mul(Dinv, fe_sub(p.Z, y)));
+  fe_tobytes(w, s);
+}
+
+// RFC 9496 §4.3.4 MAP
+AFX_DEV ge_p3 ristretto_elligator(const fe& r0) {
+  const fe one = fe_one();
+  const fe d = fe_const(FEC_D);
+  fe r = fe_mul(fe_const(FEC_SQRT_M1), fe_sq(r0));
+  fe u = fe_mul(fe_add(r, one), fe_const(FEC_ONE_MINUS_D_SQ));
+  fe c = fe_neg(one);
+  fe v = fe_mul(fe_sub(c, fe_mul(r, d)), fe_add(r, d));
+  fe s;
+  const bool was_square = fe_sqrt_ratio_i(s, u, v);
+  fe s_prime = fe_neg(fe_abs(fe_mul(s, r0)));
+  fe_cmov(s, s_prime, !was_square);
+  fe_cmov(c, r, !was_square);
+  fe N = fe_carry(fe_sub(fe_mul(fe_mul(c, fe_sub(r, one)), fe_const(FEC_D_MINUS_ONE_SQ)), v));
+  fe w0 = fe_mul(fe_add(s, s), v);
+  fe w1 = fe_mul(N, fe_const(FEC_SQRT_AD_MINUS_ONE));
+  fe ss = fe_sq(s);
+  fe w2 = fe_sub(one, ss);
+  fe w3 = fe_add(one, ss);
+  ge_p3 p;
+  p.X = fe_mul(w0, w3); p.Y = fe_mul(w2, w1); p.Z = fe_mul(w1, w3); p.T = fe_mul(w0, w2);
+  return p;
+}
+// RistrettoPoint::from_uniform_bytes: w = 16 LE dwords
+AFX_DEV ge_p3 ristretto_from_uniform(const uint32_t w[16]) {
+  ge_p3 p1 = ristretto_elligator(fe_frombytes(w));
+  ge_p3 p2 = ristretto_elligator(fe_frombytes(w + 8));
+  return ge_add(p1, p2);
+}
+AFX_DEV bool is_identity_encoding(const uint32_t w[8]) {
+  return (w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) == 0;
+}

@@ -1,0 +1,456 @@
+// HIP kernels of the aeonflux batch NIZK engine for gfx950 (MI355X).  One proof (or one constraint of one
+// proof) per lane; all control flow is uniform across a wave because the statement shape is batch-uniform.
+//
+// Kernel inventory (SURVEY.md §8a row K* -> kernel):
+//   k_setup_generators  decompress SystemParameters generators once, build affine window tables
+//   k_decode            CompressedRistretto::decompress, coalesced 32-byte loads          (P4 ii, E1)
+//   k_sccheck           Scalar canonicity
+//   k_pointop           +-P +-Q (+ compress): C_V - W, C_y+M, C_y_1-E2, -E1               (P1, E1)
+//   k_scalarop          a*b+c mod l: y_i*m_i, -t*z, responses s*c+b                       (P1, S1, I2)
+//   k_msm               R = sum s_k P_k (+-addend) -> compress.  Fixed bases from LDS window tables,
+//                       variable bases from per-lane window tables in HBM, shared doublings  (P1, P4 iii, I1)
+//   k_hash              STROBE-128/merlin transcript over Keccak-f[1600] driven by a precompiled byte
+//                       schedule; squeezes challenges / blinding factors                   (P2, P4 iv-v)
+//   k_finish            per-item status byte
+//   k_from_uniform, k_reduce_wide   RistrettoPoint::from_uniform_bytes, Scalar::from_bytes_mod_order_wide
+#include <hip/hip_runtime.h>
+#include "ge.cuh"
+#include "keccak.cuh"
+#include "plan.h"
+#include "sc.cuh"
+
+// ---------------------------------------------------------------------------------------------
+// memory helpers
+// ---------------------------------------------------------------------------------------------
+AFX_DEV void enc_load(uint32_t w[8], const uint8_t* arr, uint32_t item) {
+  const uint4* p = reinterpret_cast<const uint4*>(arr + 32ull * item);
+  const uint4 a = p[0], b = p[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+AFX_DEV void enc_store(uint8_t* arr, uint32_t item, const uint32_t w[8]) {
+  uint4* p = reinterpret_cast<uint4*>(arr + 32ull * item);
+  p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+AFX_DEV sc sc_load_item(const uint8_t* arr, uint32_t stride, uint32_t item) {
+  uint32_t w[8];
+  enc_load(w, arr, stride ? item : 0);
+  sc r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = w[i];
+  return r;
+}
+AFX_DEV fe fe_load_soa(const int32_t* base, uint32_t c, uint32_t count, uint32_t item) {
+  fe r;
+#pragma unroll
+  for (int l = 0; l < 10; l++) r.v[l] = base[(size_t)(c * 10 + l) * count + item];
+  return r;
+}
+AFX_DEV ge_p3 var_load(const int32_t* base, uint32_t count, uint32_t item) {
+  ge_p3 p;
+  p.X = fe_load_soa(base, 0, count, item);
+  p.Y = fe_load_soa(base, 1, count, item);
+  p.Z = fe_load_soa(base, 2, count, item);
+  p.T = fe_load_soa(base, 3, count, item);
+  return p;
+}
+AFX_DEV void fe_store_soa(int32_t* base, uint32_t c, uint32_t count, uint32_t item, const fe& f) {
+#pragma unroll
+  for (int l = 0; l < 10; l++) base[(size_t)(c * 10 + l) * count + item] = f.v[l];
+}
+AFX_DEV void var_store(int32_t* base, uint32_t count, uint32_t item, const ge_p3& p) {
+  fe_store_soa(base, 0, count, item, p.X);
+  fe_store_soa(base, 1, count, item, p.Y);
+  fe_store_soa(base, 2, count, item, p.Z);
+  fe_store_soa(base, 3, count, item, p.T);
+}
+AFX_DEV ge_p3 p3_load_uniform(const int32_t* c40) {
+  ge_p3 p;
+#pragma unroll
+  for (int l = 0; l < 10; l++) { p.X.v[l] = c40[l]; p.Y.v[l] = c40[10 + l]; p.Z.v[l] = c40[20 + l]; p.T.v[l] = c40[30 + l]; }
+  return p;
+}
+// one window-table entry (cached form), 40 contiguous dwords, 16-byte aligned
+AFX_DEV void cached_store(int32_t* p, const ge_cached& q) {
+  int32_t v[40];
+#pragma unroll
+  for (int l = 0; l < 10; l++) { v[l] = q.YpX.v[l]; v[10 + l] = q.YmX.v[l]; v[20 + l] = q.Z.v[l]; v[30 + l] = q.T2d.v[l]; }
+  int4* d = reinterpret_cast<int4*>(p);
+#pragma unroll
+  for (int i = 0; i < 10; i++) d[i] = make_int4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+AFX_DEV ge_cached cached_load(const int32_t* p) {
+  const int4* s = reinterpret_cast<const int4*>(p);
+  int32_t v[40];
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    const int4 t = s[i];
+    v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+  }
+  ge_cached q;
+#pragma unroll
+  for (int l = 0; l < 10; l++) { q.YpX.v[l] = v[l]; q.YmX.v[l] = v[10 + l]; q.Z.v[l] = v[20 + l]; q.T2d.v[l] = v[30 + l]; }
+  return q;
+}
+
+// ---------------------------------------------------------------------------------------------
+// setup: generators -> extended coords, 0..8 multiples as affine niels, encoding of the negation
+// ---------------------------------------------------------------------------------------------
+__global__ void k_setup_generators(const uint8_t* __restrict__ enc, uint32_t ngen, int32_t* __restrict__ fixed_tables,
+                                   int32_t* __restrict__ ext, uint8_t* __restrict__ neg_enc, uint32_t* __restrict__ ok) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ngen) return;
+  uint32_t w[8];
+  enc_load(w, enc, g);
+  ge_p3 P;
+  const bool good = ristretto_decode(P, w);
+  ok[g] = good ? 1u : 0u;
+  if (!good) P = ge_identity();
+  int32_t* e = ext + (size_t)g * AFX_VAR_DWORDS;
+#pragma unroll
+  for (int l = 0; l < 10; l++) { e[l] = P.X.v[l]; e[10 + l] = P.Y.v[l]; e[20 + l] = P.Z.v[l]; e[30 + l] = P.T.v[l]; }
+  uint32_t nw[8];
+  ristretto_encode(nw, ge_neg(P));
+  enc_store(neg_enc, g, nw);
+  int32_t* tab = fixed_tables + (size_t)g * AFX_FIXED_TABLE_DWORDS;
+  const fe d2 = fe_const(FEC_D2);
+  ge_p3 Q = ge_identity();
+  const ge_cached cP = ge_p3_to_cached(P);
+#pragma unroll 1
+  for (int k = 0; k < AFX_TABLE_ENTRIES; k++) {
+    const fe zinv = fe_invert(Q.Z);
+    const fe x = fe_mul(Q.X, zinv), y = fe_mul(Q.Y, zinv);
+    const fe ypx = fe_carry(fe_add(y, x)), ymx = fe_carry(fe_sub(y, x)), xy2d = fe_mul(fe_mul(x, y), d2);
+#pragma unroll
+    for (int l = 0; l < 10; l++) { tab[k * 30 + l] = ypx.v[l]; tab[k * 30 + 10 + l] = ymx.v[l]; tab[k * 30 + 20 + l] = xy2d.v[l]; }
+    Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decode / scalar checks / small point and scalar ops
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(AFX_BLOCK) k_decode(const afx_decode_job* __restrict__ jobs, uint32_t* __restrict__ bad, uint32_t count) {
+  const afx_decode_job job = jobs[blockIdx.y];
+  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  if (item >= count) return;
+  uint32_t w[8];
+  enc_load(w, job.enc, item);
+  ge_p3 P;
+  const bool ok = ristretto_decode(P, w);
+  uint32_t flags = ok ? 0u : AFX_BAD_DECODE;
+  if (job.reject_identity && is_identity_encoding(w)) flags |= AFX_BAD_IDENTITY;
+  if (flags) atomicOr(&bad[item], flags);
+  if (job.out) var_store(job.out, count, item, ok ? P : ge_identity());
+}
+
+__global__ void __launch_bounds__(AFX_BLOCK) k_sccheck(const afx_sccheck_job* __restrict__ jobs, uint32_t* __restrict__ bad, uint32_t count) {
+  const afx_sccheck_job job = jobs[blockIdx.y];
+  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  if (item >= count) return;
+  const sc s = sc_load_item(job.sc, 32, item);
+  if (!sc_is_canonical(s)) atomicOr(&bad[item], AFX_BAD_SCALAR);
+}
+
+__global__ void __launch_bounds__(AFX_BLOCK) k_pointop(const afx_pointop_job* __restrict__ jobs, uint32_t* __restrict__ bad, uint32_t count) {
+  const afx_pointop_job job = jobs[blockIdx.y];
+  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  if (item >= count) return;
+  ge_p3 A = var_load(job.a, count, item);
+  if (job.sa < 0) A = ge_neg(A);
+  ge_p3 R = A;
+  if (job.sb != 0) {
+    const ge_p3 B = job.b ? var_load(job.b, count, item) : p3_load_uniform(job.b_const);
+    R = ge_p1p1_to_p3(ge_add_cached(A, ge_p3_to_cached(B), job.sb < 0));
+  } else {
+    R = ge_carry(R);
+  }
+  if (job.out) var_store(job.out, count, item, R);
+  if (job.out_enc) {
+    uint32_t w[8];
+    ristretto_encode(w, R);
+    enc_store(job.out_enc, item, w);
+    if (job.reject_identity && is_identity_encoding(w)) atomicOr(&bad[item], AFX_BAD_IDENTITY);
+  }
+}
+
+__global__ void __launch_bounds__(AFX_BLOCK) k_scalarop(const afx_scalarop_job* __restrict__ jobs, uint32_t count) {
+  const afx_scalarop_job job = jobs[blockIdx.y];
+  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  if (item >= count) return;
+  const sc a = sc_load_item(job.a, job.a_stride, item);
+  const sc b = sc_load_item(job.b, job.b_stride, item);
+  sc r;
+  if (job.c) r = sc_muladd(a, b, sc_load_item(job.c, job.c_stride, item));
+  else r = sc_mul(a, b);
+  if (job.negate) r = sc_neg(r);
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = r.v[i];
+  enc_store(job.out, item, w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_msm: one small multiscalar multiplication per lane
+// ---------------------------------------------------------------------------------------------
+// Straus with a shared doubling chain and signed radix-16 digits in [-8,7] (s + 0x88..88 recoding, so every
+// lane adds at every window: no divergence; a zero digit adds table entry 0 = identity).
+//   fixed bases   : 9-entry affine-niels tables, staged in LDS per workgroup (1080 B per base)
+//   variable bases: 9-entry cached tables built per lane into HBM workspace (1440 B per base per item),
+//                   gathered back as 10 x 16-byte loads per addition
+// Field multiplications per window: 4 doublings (4 x 4S + 3 x 3M + 4M) + per variable term 8M, per fixed term 7M.
+__global__ void __launch_bounds__(AFX_BLOCK, 2)
+k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_tables, int32_t* __restrict__ table_ws,
+      uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count) {
+  extern __shared__ int32_t lds_tab[];
+  const afx_msm_job* job = &jobs[blockIdx.y];
+  const uint32_t nt = job->n_terms, nv = job->n_var;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t t = nv; t < nt; t++) {
+    const int32_t* src = fixed_tables + (size_t)job->term[t].fixed_idx * AFX_FIXED_TABLE_DWORDS;
+    for (uint32_t i = tid; i < AFX_FIXED_TABLE_DWORDS; i += AFX_BLOCK) lds_tab[(t - nv) * AFX_FIXED_TABLE_DWORDS + i] = src[i];
+  }
+  __syncthreads();
+  const uint32_t item = blockIdx.x * AFX_BLOCK + tid;
+  if (item >= count) return;
+
+  // recode scalars: s' = s + 0x88..88, stored [slot][8][count]
+  const uint32_t dslot = job->digit_slot;
+#pragma unroll 1
+  for (uint32_t t = 0; t < nt; t++) {
+    const sc s = sc_load_item(job->term[t].scalar, job->term[t].scalar_stride, item);
+    uint32_t b[8];
+    sc_bias_radix16(b, s);
+#pragma unroll
+    for (int i = 0; i < 8; i++) digit_ws[((size_t)(dslot + t) * 8 + i) * count + item] = b[i];
+  }
+  // per-lane window tables for the variable bases
+  const uint32_t tslot = job->table_slot;
+#pragma unroll 1
+  for (uint32_t t = 0; t < nv; t++) {
+    int32_t* tab = table_ws + ((size_t)(tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
+    const ge_p3 P = var_load(job->term[t].var, count, item);
+    const ge_cached cP = ge_p3_to_cached_reduced(P);
+    cached_store(tab, ge_cached_identity());
+    cached_store(tab + AFX_VAR_DWORDS, cP);
+    ge_p3 Q = P;
+#pragma unroll 1
+    for (int k = 2; k < AFX_TABLE_ENTRIES; k++) {
+      Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
+      cached_store(tab + k * AFX_VAR_DWORDS, ge_p3_to_cached_reduced(Q));
+    }
+  }
+
+  ge_p3 acc = ge_identity();
+#pragma unroll 1
+  for (int w = 63; w >= 0; w--) {
+    if (w != 63) {
+      ge_p2 a2 = ge_p3_to_p2(acc);
+#pragma unroll 1
+      for (int k = 0; k < 3; k++) a2 = ge_p1p1_to_p2(ge_p2_dbl(a2));
+      acc = ge_p1p1_to_p3(ge_p2_dbl(a2));
+    }
+    const uint32_t wi = (uint32_t)w >> 3, sh = ((uint32_t)w & 7) * 4;
+#pragma unroll 1
+    for (uint32_t t = 0; t < nt; t++) {
+      const uint32_t word = digit_ws[((size_t)(dslot + t) * 8 + wi) * count + item];
+      const int d = (int)((word >> sh) & 15u) - 8;
+      const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
+      const bool neg = (d < 0) != (job->term[t].negate != 0);
+      if (t < nv) {
+        const int32_t* tab = table_ws + ((size_t)(tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
+        acc = ge_p1p1_to_p3(ge_add_cached(acc, cached_load(tab + idx * AFX_VAR_DWORDS), neg));
+      } else {
+        const int32_t* e = lds_tab + (t - nv) * AFX_FIXED_TABLE_DWORDS + idx * AFX_NIELS_DWORDS;
+        ge_niels q;
+#pragma unroll
+        for (int l = 0; l < 10; l++) { q.ypx.v[l] = e[l]; q.ymx.v[l] = e[10 + l]; q.xy2d.v[l] = e[20 + l]; }
+        acc = ge_p1p1_to_p3(ge_madd(acc, q, neg));
+      }
+    }
+  }
+  if (job->addend) {
+    const ge_p3 A = var_load(job->addend, count, item);
+    acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_p3_to_cached(A), job->addend_negate != 0));
+  }
+  if (job->out_var) var_store(job->out_var, count, item, acc);
+  if (job->out_enc) {
+    uint32_t wenc[8];
+    ristretto_encode(wenc, acc);
+    enc_store(job->out_enc, item, wenc);
+    if (job->reject_identity && is_identity_encoding(wenc)) atomicOr(&bad[item], AFX_BAD_IDENTITY);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_hash: STROBE-128 / merlin transcripts
+// ---------------------------------------------------------------------------------------------
+AFX_DEV uint64_t load_u64(const uint8_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return (uint64_t)v.x | ((uint64_t)v.y << 32);
+}
+
+__global__ void __launch_bounds__(AFX_BLOCK) k_hash(const afx_hash_program* __restrict__ progs, uint32_t* __restrict__ bad, uint32_t count) {
+  const afx_hash_program* prog = &progs[blockIdx.y];
+  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  if (item >= count) return;
+  uint64_t st[25];
+  if (prog->load_state) {
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = prog->load_state[(size_t)i * count + item];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = prog->init_state[i];
+  }
+  const uint32_t nrec = prog->n_records;
+#pragma unroll 1
+  for (uint32_t r = 0; r < nrec; r++) {
+    const afx_hash_record* rec = &prog->records[r];
+#pragma unroll
+    for (int w = 0; w < 21; w++) {
+      const afx_hash_word hw = rec->w[w];
+      uint64_t v = hw.c;
+      if (hw.field >= 0) {
+        const uint8_t* f = prog->fields[hw.field] + 32ull * item;
+        const int q = hw.q;
+        const uint64_t lo = (q >= 0) ? load_u64(f + 8 * q) : 0ull;
+        const uint64_t hi = (q < 3) ? load_u64(f + 8 * (q + 1)) : 0ull;
+        const uint32_t sh = 8u * hw.r;
+        const uint64_t val = sh ? ((lo >> sh) | (hi << (64u - sh))) : lo;
+        v ^= val & hw.fmask;
+      }
+      st[w] = (st[w] & hw.keep) ^ v;
+    }
+    keccak_f1600(st);
+    if (rec->squeeze != AFX_SQ_NONE) {
+      uint32_t x[16];
+#pragma unroll
+      for (int i = 0; i < 8; i++) { x[2 * i] = (uint32_t)st[i]; x[2 * i + 1] = (uint32_t)(st[i] >> 32); }
+      const sc c = sc_reduce512(x);
+      if (rec->squeeze == AFX_SQ_CHALLENGE_COMPARE) {
+        const sc want = sc_load_item(prog->challenge, 32, item);
+        if (!sc_eq(c, want)) atomicOr(&bad[item], AFX_BAD_CHALLENGE);
+      } else {
+        uint32_t w8[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w8[i] = c.v[i];
+        enc_store(prog->outs[rec->squeeze_out], item, w8);
+      }
+    }
+  }
+  if (prog->save_state) {
+#pragma unroll
+    for (int i = 0; i < 25; i++) prog->save_state[(size_t)i * count + item] = st[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// status / utilities
+// ---------------------------------------------------------------------------------------------
+__global__ void k_finish(const uint32_t* __restrict__ bad, uint8_t* __restrict__ status, uint32_t count, uint32_t fail_all, uint8_t fail_code) {
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= count) return;
+  status[item] = (fail_all || bad[item]) ? fail_code : 0;
+}
+__global__ void k_fill_u32(uint32_t* p, uint32_t v, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void __launch_bounds__(AFX_BLOCK) k_from_uniform(const uint8_t* __restrict__ wide, uint8_t* __restrict__ out_enc, int32_t* out_var, uint32_t count) {
+  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  if (item >= count) return;
+  uint32_t w[16];
+  enc_load(w, wide, 2 * item);
+  enc_load(w + 8, wide, 2 * item + 1);
+  const ge_p3 P = ristretto_from_uniform(w);
+  if (out_var) var_store(out_var, count, item, P);
+  if (out_enc) {
+    uint32_t e[8];
+    ristretto_encode(e, P);
+    enc_store(out_enc, item, e);
+  }
+}
+__global__ void __launch_bounds__(AFX_BLOCK) k_reduce_wide(const uint8_t* __restrict__ wide, uint8_t* __restrict__ out, uint32_t count) {
+  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  if (item >= count) return;
+  uint32_t w[16];
+  enc_load(w, wide, 2 * item);
+  enc_load(w + 8, wide, 2 * item + 1);
+  const sc r = sc_reduce512(w);
+  uint32_t o[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) o[i] = r.v[i];
+  enc_store(out, item, o);
+}
+// decode -> ok flag -> re-encode (round-trip parity test of decode+encode)
+__global__ void __launch_bounds__(AFX_BLOCK) k_validate(const uint8_t* __restrict__ enc, uint8_t* __restrict__ ok, uint8_t* __restrict__ reenc, uint32_t count) {
+  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  if (item >= count) return;
+  uint32_t w[8];
+  enc_load(w, enc, item);
+  ge_p3 P;
+  const bool good = ristretto_decode(P, w);
+  ok[item] = good ? 1 : 0;
+  if (reenc) {
+    uint32_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (good) ristretto_encode(e, P);
+    enc_store(reenc, item, e);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-callable launch wrappers (engine.cpp is plain C++ and never sees a kernel symbol)
+// ---------------------------------------------------------------------------------------------
+#include "kernels.h"
+static inline dim3 grid_for(uint32_t count, uint32_t njobs) { return dim3((count + AFX_BLOCK - 1) / AFX_BLOCK, njobs, 1); }
+
+hipError_t afxk_setup_generators(hipStream_t s, const uint8_t* enc, uint32_t ngen, int32_t* fixed_tables, int32_t* ext, uint8_t* neg_enc, uint32_t* ok) {
+  hipLaunchKernelGGL(k_setup_generators, dim3((ngen + 63) / 64), dim3(64), 0, s, enc, ngen, fixed_tables, ext, neg_enc, ok);
+  return hipGetLastError();
+}
+hipError_t afxk_decode(hipStream_t s, const afx_decode_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count) {
+  hipLaunchKernelGGL(k_decode, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, bad, count);
+  return hipGetLastError();
+}
+hipError_t afxk_sccheck(hipStream_t s, const afx_sccheck_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count) {
+  hipLaunchKernelGGL(k_sccheck, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, bad, count);
+  return hipGetLastError();
+}
+hipError_t afxk_pointop(hipStream_t s, const afx_pointop_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count) {
+  hipLaunchKernelGGL(k_pointop, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, bad, count);
+  return hipGetLastError();
+}
+hipError_t afxk_scalarop(hipStream_t s, const afx_scalarop_job* jobs, uint32_t njobs, uint32_t count) {
+  hipLaunchKernelGGL(k_scalarop, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, count);
+  return hipGetLastError();
+}
+hipError_t afxk_msm(hipStream_t s, const afx_msm_job* jobs, uint32_t njobs, uint32_t max_fixed, const int32_t* fixed_tables,
+                    int32_t* table_ws, uint32_t* digit_ws, uint32_t* bad, uint32_t count) {
+  const size_t lds = (size_t)max_fixed * AFX_FIXED_TABLE_DWORDS * sizeof(int32_t);
+  hipLaunchKernelGGL(k_msm, grid_for(count, njobs), dim3(AFX_BLOCK), lds, s, jobs, fixed_tables, table_ws, digit_ws, bad, count);
+  return hipGetLastError();
+}
+hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count) {
+  hipLaunchKernelGGL(k_hash, grid_for(count, nprogs), dim3(AFX_BLOCK), 0, s, progs, bad, count);
+  return hipGetLastError();
+}
+hipError_t afxk_finish(hipStream_t s, const uint32_t* bad, uint8_t* status, uint32_t count, uint32_t fail_all, uint8_t fail_code) {
+  hipLaunchKernelGGL(k_finish, dim3((count + 255) / 256), dim3(256), 0, s, bad, status, count, fail_all, fail_code);
+  return hipGetLastError();
+}
+hipError_t afxk_fill_u32(hipStream_t s, uint32_t* p, uint32_t v, uint32_t n) {
+  hipLaunchKernelGGL(k_fill_u32, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
+  return hipGetLastError();
+}
+hipError_t afxk_from_uniform(hipStream_t s, const uint8_t* wide, uint8_t* out_enc, int32_t* out_var, uint32_t count) {
+  hipLaunchKernelGGL(k_from_uniform, dim3((count + AFX_BLOCK - 1) / AFX_BLOCK), dim3(AFX_BLOCK), 0, s, wide, out_enc, out_var, count);
+  return hipGetLastError();
+}
+hipError_t afxk_reduce_wide(hipStream_t s, const uint8_t* wide, uint8_t* out, uint32_t count) {
+  hipLaunchKernelGGL(k_reduce_wide, dim3((count + AFX_BLOCK - 1) / AFX_BLOCK), dim3(AFX_BLOCK), 0, s, wide, out, count);
+  return hipGetLastError();
+}
+hipError_t afxk_validate(hipStream_t s, const uint8_t* enc, uint8_t* ok, uint8_t* reenc, uint32_t count) {
+  hipLaunchKernelGGL(k_validate, dim3((count + AFX_BLOCK - 1) / AFX_BLOCK), dim3(AFX_BLOCK), 0, s, enc, ok, reenc, count);
+  return hipGetLastError();
+}

@@ -1,0 +1,108 @@
+// Plain-old-data "plan" structures shared by the host engine (engine.cpp) and the HIP kernels
+// (kernels.hip).  A plan is the batch-uniform description of one proof statement: which points to
+// decompress, which small multiscalar multiplications to run, and the STROBE/merlin byte schedule
+// with 32-byte holes for per-item values.  Per-item data never appears here — only device pointers
+// to struct-of-arrays batches.
+#pragma once
+#include <stdint.h>
+
+#define AFX_MSM_MAX_TERMS 72   /* Z job: 2 + n + #public scalars <= 2 + 2n; issuance: n + 4 */
+#define AFX_TABLE_ENTRIES 9            /* 0*P (identity) .. 8*P */
+#define AFX_VAR_DWORDS 40              /* extended point: X,Y,Z,T x 10 limbs */
+#define AFX_NIELS_DWORDS 30            /* affine niels: y+x, y-x, 2dxy */
+#define AFX_FIXED_TABLE_DWORDS (AFX_TABLE_ENTRIES * AFX_NIELS_DWORDS)
+#define AFX_VAR_TABLE_DWORDS (AFX_TABLE_ENTRIES * AFX_VAR_DWORDS)
+#define AFX_BLOCK 256
+
+/* per-item failure bits OR-ed into the `bad` word of an item */
+#define AFX_BAD_DECODE 1u
+#define AFX_BAD_IDENTITY 2u
+#define AFX_BAD_SCALAR 4u
+#define AFX_BAD_CHALLENGE 8u
+#define AFX_BAD_SHAPE 16u
+
+/* variable point storage: struct-of-arrays, limb (c*10+l) of item i at base[(c*10+l)*count + i] */
+typedef int32_t* afx_var_t;
+
+typedef struct {
+  const uint8_t* enc;      /* [count][32] compressed input                                            */
+  afx_var_t out;           /* extended coordinates out (or null)                                       */
+  uint32_t reject_identity; /* the point is allocated into a transcript: identity encoding fails      */
+} afx_decode_job;
+
+typedef struct {
+  const uint8_t* sc;       /* [count][32] scalar array to test for canonicity */
+} afx_sccheck_job;
+
+/* out = sa*A + sb*B, sa,sb in {-1,0,+1}; B may be a batch constant (extended coords, 40 dwords) */
+typedef struct {
+  const int32_t* a;        /* var (SoA)                           */
+  const int32_t* b;        /* var (SoA), or null                  */
+  const int32_t* b_const;  /* 40 dwords uniform, or null          */
+  int32_t sa, sb;
+  afx_var_t out;           /* may be null                         */
+  uint8_t* out_enc;        /* [count][32] compressed, may be null */
+  uint32_t reject_identity;
+} afx_pointop_job;
+
+/* out[i] = a[i or uniform] * b[i] (+ c[i])  mod l ; optionally negated */
+typedef struct {
+  const uint8_t* a; uint32_t a_stride;   /* 32 per item, 0 = uniform */
+  const uint8_t* b; uint32_t b_stride;
+  const uint8_t* c; uint32_t c_stride;   /* null = no addend */
+  uint32_t negate;
+  uint8_t* out;                          /* [count][32] */
+} afx_scalarop_job;
+
+typedef struct {
+  const uint8_t* scalar;   /* [count][32] per item, or one 32-byte scalar when scalar_stride == 0 */
+  uint32_t scalar_stride;  /* 32 or 0 */
+  int32_t fixed_idx;       /* >= 0: generator id with an LDS window table; -1: variable point      */
+  const int32_t* var;      /* variable point (SoA) when fixed_idx < 0                              */
+  uint32_t negate;         /* subtract the term                                                    */
+} afx_msm_term;
+
+typedef struct {
+  uint32_t n_terms;
+  uint32_t n_var;                       /* number of variable terms (they come first in term[])   */
+  afx_msm_term term[AFX_MSM_MAX_TERMS];
+  const int32_t* addend;                /* optional variable point added at the end               */
+  uint32_t addend_negate;
+  uint8_t* out_enc;                     /* [count][32] compressed result, may be null             */
+  afx_var_t out_var;                    /* extended result, may be null                           */
+  uint32_t reject_identity;
+  uint32_t digit_slot;                  /* first recoded-scalar slot of this job in digit_ws (one per term)   */
+  uint32_t table_slot;                  /* first window-table slot of this job in table_ws (one per var term) */
+} afx_msm_job;
+
+/* one 8-byte word of a STROBE rate block: st = (st & keep) ^ c ^ (field_word & fmask) */
+typedef struct {
+  uint64_t c;
+  uint64_t keep;
+  uint64_t fmask;
+  int32_t field;   /* -1: none; else index into the program's field pointer table ([count][32] arrays) */
+  int8_t q;        /* 64-bit word of the field holding the lowest selected byte, -1..3             */
+  uint8_t r;       /* byte rotation 0..7                                                            */
+  uint16_t pad;
+} afx_hash_word;
+
+#define AFX_SQ_NONE 0
+#define AFX_SQ_CHALLENGE_COMPARE 1   /* reduce 64 bytes mod l, compare with challenge[item]        */
+#define AFX_SQ_SCALAR_OUT 2          /* reduce 64 bytes mod l, store to outs[squeeze_out][item]    */
+
+typedef struct {
+  afx_hash_word w[21];   /* bytes 0..167 of the block: rate (166) + the two pad bytes            */
+  uint32_t squeeze;      /* AFX_SQ_* applied after the permutation                              */
+  uint32_t squeeze_out;
+} afx_hash_record;
+
+typedef struct {
+  const uint64_t* init_state;      /* 25 words, uniform; or null                                */
+  const uint64_t* load_state;      /* per item SoA [25][count]; or null                         */
+  uint64_t* save_state;            /* per item SoA [25][count]; or null                         */
+  uint32_t n_records;
+  const afx_hash_record* records;
+  const uint8_t* const* fields;    /* device table of [count][32] array pointers                */
+  uint8_t* const* outs;            /* device table of [count][32] output arrays                 */
+  const uint8_t* challenge;        /* [count][32] for AFX_SQ_CHALLENGE_COMPARE                  */
+} afx_hash_program;

@@ -1,0 +1,470 @@
+// The aeonflux statements, batch form, and the C ABI of include/aeonflux_gpu.h.
+//
+// Each build_* function restates one reference method as a list of GPU launches over a batch; the
+// transcript labels, allocation order and constraint lists are those of
+//   /root/reference/src/nizk/presentation.rs:324-443 (verify) and :139-321 (prove),
+//   /root/reference/src/nizk/encryption.rs:154-210 (verify) and :58-142 (prove),
+//   /root/reference/src/nizk/issuance.rs:132-218 (verify) and :40-129 (prove),
+//   /root/reference/src/amacs.rs:225-294 (Messages, Amac::tag / compute_V).
+// No arithmetic happens on the host: the host only lays out launches and transcript byte schedules.
+#include <string.h>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <vector>
+#include "engine.hpp"
+#include "statements.hpp"
+
+using namespace afx;
+
+static const uint8_t SC_L_BYTES[32] = { 0xed, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x58, 0xd6, 0x9c, 0xf7, 0xa2, 0xde, 0xf9, 0xde, 0x14,
+                                        0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x10 };
+static bool host_scalar_is_canonical(const uint8_t* s) {
+  for (int i = 31; i >= 0; i--) {
+    if (s[i] < SC_L_BYTES[i]) return true;
+    if (s[i] > SC_L_BYTES[i]) return false;
+  }
+  return false;
+}
+static uint32_t rd32(const uint8_t* b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); }
+static size_t sizeof_system_parameters(uint32_t n) { return n < 3 ? 32 * (5 + 3 + (size_t)n + 4) + 4 : 32 * (5 + 2 * (size_t)n + 4) + 4; }  // parameters.rs:34-40
+static size_t sizeof_secret_key(uint32_t n) { return 32 * (5 + (size_t)n) + 4; }                                                           // amacs.rs:44-46
+
+
+extern "C" const char* afx_last_error(void) { return afx::last_error(); }
+extern "C" uint32_t afx_ctx_n_attributes(const afx_ctx* ctx) { return ctx ? ctx->n : 0; }
+extern "C" void* afx_ctx_stream(const afx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" void afx_ctx_destroy(afx_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  // Zeroize + Drop of amacs::SecretKey (src/amacs.rs:64-82): wipe every copy of the key and anything derived
+  c->d_key.release(true);
+  c->ws.release(true);
+  c->staging.release(true);
+  c->d_fixed_tables.release(true);
+  c->d_gen_ext.release(true);
+  c->d_gen_enc.release(false);
+  c->d_consts.release(false);
+  for (int i = 0; i < 2; i++) {
+    c->blob_dev[i].release(true);
+    if (c->blob_host[i]) { memset(c->blob_host[i], 0, c->blob_host_cap[i]); (void)hipHostFree(c->blob_host[i]); }
+    if (c->blob_event[i]) (void)hipEventDestroy(c->blob_event[i]);
+  }
+  for (auto& k : c->host_key) { volatile uint8_t* p = k.data(); for (int i = 0; i < 32; i++) p[i] = 0; }
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t splen, const uint8_t* key, size_t klen,
+                           const uint8_t* key_scalars_only, const uint8_t* issuer_params) {
+  if (!out || !sp) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    set_error("no usable HIP device (this engine has no CPU fallback)");
+    return AFX_E_NO_DEVICE;
+  }
+  if (splen < 4) { set_error("SystemParameters too short"); return AFX_E_BAD_PARAMS; }
+  const uint32_t n = rd32(sp);
+  if (n == 0 || n > AFX_MAX_ATTRIBUTES || splen != sizeof_system_parameters(n)) { set_error("SystemParameters length / attribute count"); return AFX_E_BAD_PARAMS; }
+  std::unique_ptr<afx_ctx, void (*)(afx_ctx*)> c(new afx_ctx(), afx_ctx_destroy);
+  c->device = device;
+  c->n = n;
+  c->g = n < 3 ? 3 : n;
+  AFX_HIP(hipSetDevice(device));
+  AFX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  const uint32_t np = 9 + c->g + n;
+  c->ngen = np + 3;
+  c->gen_enc.assign(c->ngen, Enc{});
+  for (uint32_t i = 0; i < np; i++) memcpy(c->gen_enc[i].data(), sp + 4 + 32 * (size_t)i, 32);
+  if (issuer_params) {   // C_W || I  (src/issuer.rs:155,163)
+    memcpy(c->gen_enc[c->id_CW()].data(), issuer_params, 32);
+    memcpy(c->gen_enc[c->id_I()].data(), issuer_params + 32, 32);
+  }
+  const uint8_t* ks = nullptr;
+  if (key && klen) {
+    if (klen != sizeof_secret_key(n) || rd32(key) != n) { set_error("amacs key length / attribute count"); return AFX_E_BAD_PARAMS; }
+    ks = key + 4;
+    memcpy(c->gen_enc[c->id_W()].data(), key + 4 + 32 * (size_t)(4 + n), 32);
+  } else if (key_scalars_only) {
+    ks = key_scalars_only + 4;
+  }
+  if (ks) {
+    c->host_key.assign(4 + n, Enc{});
+    for (uint32_t i = 0; i < 4 + n; i++) {
+      if (!host_scalar_is_canonical(ks + 32 * (size_t)i)) { set_error("non-canonical key scalar"); return AFX_E_BAD_PARAMS; }   // amacs.rs:141-149
+      memcpy(c->host_key[i].data(), ks + 32 * (size_t)i, 32);
+    }
+    c->has_key = true;
+  }
+  int rc;
+  if ((rc = c->d_gen_enc.ensure(32 * (size_t)c->ngen)) || (rc = c->d_fixed_tables.ensure(sizeof(int32_t) * AFX_FIXED_TABLE_DWORDS * (size_t)c->ngen)) ||
+      (rc = c->d_gen_ext.ensure(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)c->ngen)) || (rc = c->d_key.ensure(32 * (size_t)(4 + n))) ||
+      (rc = c->d_consts.ensure(64)) || (rc = c->staging.ensure(32 * (size_t)c->ngen + 4 * (size_t)c->ngen)))
+    return rc;
+  for (int i = 0; i < 2; i++) {
+    if ((rc = c->blob_dev[i].ensure(BLOB_CAP))) return rc;
+    AFX_HIP(hipHostMalloc(&c->blob_host[i], BLOB_CAP, hipHostMallocDefault));
+    c->blob_host_cap[i] = BLOB_CAP;
+    AFX_HIP(hipEventCreateWithFlags(&c->blob_event[i], hipEventDisableTiming));
+  }
+  std::vector<uint8_t> flat(32 * (size_t)c->ngen);
+  for (uint32_t i = 0; i < c->ngen; i++) memcpy(flat.data() + 32 * (size_t)i, c->gen_enc[i].data(), 32);
+  AFX_HIP(hipMemcpyAsync(c->d_gen_enc.p, flat.data(), flat.size(), hipMemcpyHostToDevice, c->stream));
+  uint8_t* d_neg = (uint8_t*)c->staging.p;
+  uint32_t* d_ok = (uint32_t*)((uint8_t*)c->staging.p + 32 * (size_t)c->ngen);
+  AFX_HIP(afxk_setup_generators(c->stream, (const uint8_t*)c->d_gen_enc.p, c->ngen, (int32_t*)c->d_fixed_tables.p, (int32_t*)c->d_gen_ext.p, d_neg, d_ok));
+  std::vector<uint8_t> neg(32 * (size_t)c->ngen);
+  std::vector<uint32_t> ok(c->ngen);
+  AFX_HIP(hipMemcpyAsync(neg.data(), d_neg, neg.size(), hipMemcpyDeviceToHost, c->stream));
+  AFX_HIP(hipMemcpyAsync(ok.data(), d_ok, 4 * (size_t)c->ngen, hipMemcpyDeviceToHost, c->stream));
+  if (c->has_key) {
+    std::vector<uint8_t> kflat(32 * (size_t)(4 + n));
+    for (uint32_t i = 0; i < 4 + n; i++) memcpy(kflat.data() + 32 * (size_t)i, c->host_key[i].data(), 32);
+    AFX_HIP(hipMemcpyAsync(c->d_key.p, kflat.data(), kflat.size(), hipMemcpyHostToDevice, c->stream));
+    AFX_HIP(hipStreamSynchronize(c->stream));
+    volatile uint8_t* p = kflat.data();
+    for (size_t i = 0; i < kflat.size(); i++) p[i] = 0;
+  }
+  uint8_t consts[64];
+  memset(consts, 0, sizeof consts);
+  consts[0] = 1;   // Scalar::one()
+  AFX_HIP(hipMemcpyAsync(c->d_consts.p, consts, 64, hipMemcpyHostToDevice, c->stream));
+  AFX_HIP(hipStreamSynchronize(c->stream));
+  for (uint32_t i = 0; i < c->ngen; i++)
+    if (!ok[i]) { set_error("generator / key point " + std::to_string(i) + " does not decompress"); return AFX_E_BAD_PARAMS; }   // parameters.rs:77-89
+  c->gen_neg_enc.assign(c->ngen, Enc{});
+  for (uint32_t i = 0; i < c->ngen; i++) memcpy(c->gen_neg_enc[i].data(), neg.data() + 32 * (size_t)i, 32);
+  *out = c.release();
+  return AFX_OK;
+}
+
+extern "C" int afx_ctx_create(afx_ctx** out, int device, const uint8_t* sysparams, size_t sysparams_len, const uint8_t* amacs_key,
+                              size_t amacs_key_len, const uint8_t issuer_params[64]) {
+  if (!issuer_params) { set_error("issuer_params is required"); return AFX_E_BAD_ARGS; }
+  return afx_ctx_create_impl(out, device, sysparams, sysparams_len, amacs_key, amacs_key_len, nullptr, issuer_params);
+}
+
+// ProofOfEncryption::verify, src/nizk/encryption.rs:154-210
+static void add_encproof_verify(Assembler& as, JobSets& js, uint16_t index, const afx_encproof_soa& e, size_t total, size_t off) {
+  afx_ctx* c = as.ctx;
+  auto row = [&](const uint8_t* base, size_t k) { return base + (k * total + off) * 32; };
+  if (index >= c->n) { as.fail_all = true; return; }   // G_m[self.index] panics, encryption.rs:179
+  js.sccheck.push_back({ row(e.challenge, 0) });
+  for (int k = 0; k < 6; k++) js.sccheck.push_back({ row(e.responses, k) });
+  int32_t *v_pk = as.new_var(), *v_E1 = as.new_var(), *v_E2 = as.new_var(), *v_Cy1 = as.new_var(), *v_Cy2 = as.new_var(),
+          *v_Cy3 = as.new_var(), *v_Cy2p = as.new_var(), *v_D1 = as.new_var(), *v_D2 = as.new_var();
+  uint8_t *e_D1 = as.new_enc(), *e_D2 = as.new_enc();
+  js.decode.push_back({ row(e.pk, 0), v_pk, 1 });
+  js.decode.push_back({ row(e.E1, 0), v_E1, 1 });
+  js.decode.push_back({ row(e.E2, 0), v_E2, 0 });
+  js.decode.push_back({ row(e.C_y_1, 0), v_Cy1, 0 });
+  js.decode.push_back({ row(e.C_y_2, 0), v_Cy2, 1 });
+  js.decode.push_back({ row(e.C_y_3, 0), v_Cy3, 1 });
+  js.decode.push_back({ row(e.C_y_2p, 0), v_Cy2p, 1 });
+  afx_pointop_job d1 = { v_Cy1, v_E2, nullptr, +1, -1, v_D1, e_D1, 1 };    // C_y_1 - E2   (:183)
+  afx_pointop_job d2 = { v_E1, nullptr, nullptr, -1, 0, v_D2, e_D2, 1 };   // -E1          (:185)
+  js.pointop.push_back(d1);
+  js.pointop.push_back(d2);
+  auto resp = [&](int k) { ScalarVar s; s.dev = row(e.responses, k); s.stride = 32; return s; };
+  SchnorrBuilder v(as, "2019/1416 anonymous credentials", "2019/1416 proof of encryption");
+  const int a = v.allocate_scalar("a", resp(0));
+  const int a0 = v.allocate_scalar("a0", resp(1));
+  const int a1 = v.allocate_scalar("a1", resp(2));
+  const int m3 = v.allocate_scalar("m3", resp(3));
+  const int z = v.allocate_scalar("z", resp(4));
+  const int z1 = v.allocate_scalar("z1", resp(5));
+  const int pk = v.allocate_point("pk", PointVar::Var(v_pk, row(e.pk, 0)));
+  const int G_a = v.allocate_point("G_a", PointVar::Const(c->id_Ga()));
+  const int G_a_0 = v.allocate_point("G_a_0", PointVar::Const(c->id_Ga0()));
+  const int G_a_1 = v.allocate_point("G_a_1", PointVar::Const(c->id_Ga1()));
+  const int G_y_1 = v.allocate_point("G_y_1", PointVar::Const(c->id_Gy(0)));
+  const int G_y_2 = v.allocate_point("G_y_2", PointVar::Const(c->id_Gy(1)));
+  const int G_y_3 = v.allocate_point("G_y_3", PointVar::Const(c->id_Gy(2)));
+  const int G_m_3 = v.allocate_point("G_m_3", PointVar::Const(c->id_Gm(index)));
+  const int C_y_2 = v.allocate_point("C_y_2", PointVar::Var(v_Cy2, row(e.C_y_2, 0)));
+  const int C_y_3 = v.allocate_point("C_y_3", PointVar::Var(v_Cy3, row(e.C_y_3, 0)));
+  const int C_y_2p = v.allocate_point("C_y_2'", PointVar::Var(v_Cy2p, row(e.C_y_2p, 0)));
+  const int C_y_1_minus_E2 = v.allocate_point("C_y_1-E2", PointVar::Var(v_D1, e_D1));
+  const int E1 = v.allocate_point("E1", PointVar::Var(v_E1, row(e.E1, 0)));
+  const int minus_E1 = v.allocate_point("-E1", PointVar::Var(v_D2, e_D2));
+  v.constrain(pk, { { a, G_a }, { a0, G_a_0 }, { a1, G_a_1 } });
+  v.constrain(C_y_1_minus_E2, { { z, G_y_1 }, { a, minus_E1 } });
+  v.constrain(C_y_2p, { { a1, C_y_2 } });
+  v.constrain(E1, { { a0, C_y_2 }, { m3, C_y_2p }, { z1, G_y_2 } });
+  v.constrain(C_y_3, { { z, G_y_3 }, { m3, G_m_3 } });
+  v.verify_compact(row(e.challenge, 0), js.msm1, js.hash);
+}
+
+
+// Issuer::verify -> ProofOfValidCredential::verify, src/nizk/presentation.rs:324-443
+static void build_presentation_verify(Assembler& as, const afx_shape& sh, const afx_presentation_soa& b, size_t total, size_t off,
+                                      uint8_t* status_dev) {
+  afx_ctx* c = as.ctx;
+  JobSets js;
+  auto row = [&](const uint8_t* base, size_t k) { return base + (k * total + off) * 32; };
+  const uint32_t n = sh.n_attributes, hs = sh.n_hidden_scalars;
+  // shapes on which the reference indexes out of range (panics) or zkp rejects every proof
+  if (n > c->n || n > AFX_MAX_ATTRIBUTES || hs > AFX_MAX_ATTRIBUTES || sh.n_enc_proofs > AFX_MAX_ATTRIBUTES ||
+      sh.n_responses != 3 + hs /* verify_compact: responses.len() != num_scalars */)
+    as.fail_all = true;
+  for (uint32_t i = 0; i < n && !as.fail_all; i++)
+    if (sh.kinds[i] > AFX_ENC_SECRET_POINT) as.fail_all = true;
+  for (uint32_t j = 0; j < hs && !as.fail_all; j++)
+    if (sh.hidden_scalar_indices[j] >= c->n) as.fail_all = true;   // G_m[*i], presentation.rs:407
+  uint32_t keep[AFX_MAX_ATTRIBUTES], k = 0;
+  for (uint32_t i = 0; i < n && !as.fail_all; i++)
+    if (sh.kinds[i] != AFX_ENC_SECRET_POINT) keep[k++] = i;
+  // constraint #3 uses the compact index as an original position (presentation.rs:427-433)
+  int hidden_slot[AFX_MAX_ATTRIBUTES];
+  for (uint32_t j = 0; j < k && !as.fail_all; j++) {
+    hidden_slot[j] = -1;
+    if (sh.kinds[j] == AFX_ENC_SECRET_POINT) continue;
+    if (j >= c->g) { as.fail_all = true; break; }
+    if (sh.kinds[j] == AFX_ENC_SECRET_SCALAR) {
+      for (uint32_t h = 0; h < hs; h++)
+        if (sh.hidden_scalar_indices[h] == j) { hidden_slot[j] = (int)h; break; }
+      if (hidden_slot[j] < 0) as.fail_all = true;   // H_s[i] / G_m[i] lookup panics (:81, :100)
+    }
+  }
+  if (as.fail_all) { emit(as, js, status_dev, AFX_ST_VERIFICATION_FAILURE); return; }
+
+  js.sccheck.push_back({ row(b.challenge, 0) });
+  for (uint32_t r = 0; r < sh.n_responses; r++) js.sccheck.push_back({ row(b.responses, r) });
+  int32_t *v_Cx0 = as.new_var(), *v_Cx1 = as.new_var(), *v_CV = as.new_var(), *v_A = as.new_var(), *v_Z = as.new_var();
+  uint8_t* e_Z = as.new_enc();
+  js.decode.push_back({ row(b.C_x_0, 0), v_Cx0, 1 });
+  js.decode.push_back({ row(b.C_x_1, 0), v_Cx1, 1 });
+  js.decode.push_back({ row(b.C_V, 0), v_CV, 0 });
+  int32_t* v_Cy[AFX_MAX_ATTRIBUTES];
+  // Z = C_V - W - x0*C_x0 - x1*C_x1 - sum y_i * X_i                                  (:342-352)
+  std::vector<afx_msm_term> zterms;
+  zterms.push_back(mk_term(c->key_x0(), 0, v_Cx0, -1, true));
+  zterms.push_back(mk_term(c->key_x1(), 0, v_Cx1, -1, true));
+  for (uint32_t i = 0; i < n; i++) {
+    v_Cy[i] = as.new_var();
+    js.decode.push_back({ row(b.C_y, i), v_Cy[i], sh.kinds[i] != AFX_ENC_SECRET_POINT ? 1u : 0u });
+    const int32_t* X = v_Cy[i];
+    if (sh.kinds[i] == AFX_ENC_PUBLIC_SCALAR) {
+      // y_i*(C_y_i + m_i*G_m_i) = y_i*C_y_i + (y_i*m_i)*G_m_i : the second part is a fixed-base term
+      js.sccheck.push_back({ row(b.attr_values, i) });
+      uint8_t* ym = as.new_enc();
+      afx_scalarop_job so;
+      memset(&so, 0, sizeof so);
+      so.a = c->key_y(i); so.a_stride = 0; so.b = row(b.attr_values, i); so.b_stride = 32; so.out = ym;
+      js.scalarop.push_back(so);
+      zterms.push_back(mk_term(ym, 32, nullptr, (int32_t)c->id_Gm(i), true));
+    } else if (sh.kinds[i] == AFX_ENC_PUBLIC_POINT) {
+      int32_t *v_M = as.new_var(), *v_X = as.new_var();
+      js.decode.push_back({ row(b.attr_values, i), v_M, 0 });
+      afx_pointop_job po = { v_Cy[i], v_M, nullptr, +1, +1, v_X, nullptr, 0 };
+      js.pointop.push_back(po);
+      X = v_X;
+    }
+    zterms.push_back(mk_term(c->key_y(i), 0, X, -1, true));
+  }
+  afx_pointop_job pa = { v_CV, nullptr, c->gen_ext(c->id_W()), +1, -1, v_A, nullptr, 0 };   // C_V - W
+  js.pointop.push_back(pa);
+  afx_msm_job zj;
+  memset(&zj, 0, sizeof zj);
+  set_terms(zj, zterms);
+  zj.addend = v_A;
+  zj.out_var = v_Z;
+  zj.out_enc = e_Z;
+  zj.reject_identity = 1;
+  js.msm1.push_back(zj);
+
+  auto resp = [&](uint32_t r) { ScalarVar s; s.dev = row(b.responses, r); s.stride = 32; return s; };
+  SchnorrBuilder v(as, "2019/1416 anonymous credential", "2019/1416 presentation proof");
+  const int z = v.allocate_scalar("z", resp(0));
+  const int z_0 = v.allocate_scalar("z_0", resp(1));
+  const int t = v.allocate_scalar("t", resp(2));
+  int H_s[AFX_MAX_ATTRIBUTES];
+  for (uint32_t j = 0; j < hs; j++) H_s[j] = v.allocate_scalar("m", resp(3 + j));
+  const int I = v.allocate_point("I", PointVar::Const(c->id_I()));
+  const int C_x_1 = v.allocate_point("C_x_1", PointVar::Var(v_Cx1, row(b.C_x_1, 0)));
+  const int C_x_0 = v.allocate_point("C_x_0", PointVar::Var(v_Cx0, row(b.C_x_0, 0)));
+  const int G_x_0 = v.allocate_point("G_x_0", PointVar::Const(c->id_Gx0()));
+  const int G_x_1 = v.allocate_point("G_x_1", PointVar::Const(c->id_Gx1()));
+  int C_y[AFX_MAX_ATTRIBUTES], G_y[AFX_MAX_ATTRIBUTES], G_m[AFX_MAX_ATTRIBUTES];
+  for (uint32_t j = 0; j < k; j++) C_y[j] = v.allocate_point("C_y", PointVar::Var(v_Cy[keep[j]], row(b.C_y, keep[j])));
+  for (uint32_t i = 0; i < c->g; i++) G_y[i] = v.allocate_point("G_y", PointVar::Const(c->id_Gy(i)));
+  for (uint32_t j = 0; j < hs; j++) G_m[j] = v.allocate_point("G_m", PointVar::Const(c->id_Gm(sh.hidden_scalar_indices[j])));
+  const int Z = v.allocate_point("Z", PointVar::Var(v_Z, e_Z));
+  v.constrain(Z, { { z, I } });
+  v.constrain(C_x_1, { { t, C_x_0 }, { z_0, G_x_0 }, { z, G_x_1 } });
+  for (uint32_t j = 0; j < k; j++) {
+    if (sh.kinds[j] == AFX_ENC_SECRET_POINT) continue;
+    if (sh.kinds[j] == AFX_ENC_SECRET_SCALAR) v.constrain(C_y[j], { { z, G_y[j] }, { H_s[hidden_slot[j]], G_m[hidden_slot[j]] } });
+    else v.constrain(C_y[j], { { z, G_y[j] } });
+  }
+  v.verify_compact(row(b.challenge, 0), js.msm2, js.hash);
+  // proofs of encryption: verified independently, whatever their number (:438-440)
+  for (uint32_t e = 0; e < sh.n_enc_proofs && !as.fail_all; e++) add_encproof_verify(as, js, sh.enc_indices[e], b.enc[e], total, off);
+  emit(as, js, status_dev, AFX_ST_VERIFICATION_FAILURE);
+}
+
+extern "C" int afx_verify_presentations_dev(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* batch, size_t count,
+                                            uint8_t* status_dev) {
+  if (!ctx || !shape || !batch || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (!ctx->has_key) { set_error("Issuer::verify needs the issuer key"); return AFX_E_NO_KEY; }
+  if (count == 0) return AFX_OK;
+  if (shape->n_enc_proofs && shape->n_enc_proofs <= AFX_MAX_ATTRIBUTES && !batch->enc) { set_error("enc proofs missing"); return AFX_E_BAD_ARGS; }
+  const afx_shape sh = *shape;
+  const afx_presentation_soa b = *batch;
+  std::vector<afx_encproof_soa> encs;
+  if (b.enc && sh.n_enc_proofs <= AFX_MAX_ATTRIBUTES) encs.assign(b.enc, b.enc + sh.n_enc_proofs);
+  return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
+    afx_presentation_soa bb = b;
+    bb.enc = encs.data();
+    build_presentation_verify(as, sh, bb, count, off, status_dev + off);
+  });
+}
+
+extern "C" int afx_verify_encryption_proofs_dev(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* batch, size_t count, uint8_t* status_dev) {
+  if (!ctx || !batch || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (count == 0) return AFX_OK;
+  const afx_encproof_soa e = *batch;
+  return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
+    JobSets js;
+    add_encproof_verify(as, js, index, e, count, off);
+    emit(as, js, status_dev + off, AFX_ST_VERIFICATION_FAILURE);
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-pointer front ends: stage the SoA batch into HBM, run the *_dev form, fetch the status bytes
+// ------------------------------------------------------------------------------------------------
+
+static void stage_encproof(Stager& st, const afx_encproof_soa& e, size_t count, size_t offs[9]) {
+  const uint8_t* f[9] = { e.challenge, e.responses, e.pk, e.E1, e.E2, e.C_y_1, e.C_y_2, e.C_y_3, e.C_y_2p };
+  for (int i = 0; i < 9; i++) offs[i] = st.add(f[i], 32 * count * (i == 1 ? 6 : 1));
+}
+static afx_encproof_soa dev_encproof(const Stager& st, const size_t offs[9]) {
+  afx_encproof_soa d = { st.dev(offs[0]), st.dev(offs[1]), st.dev(offs[2]), st.dev(offs[3]), st.dev(offs[4]),
+                         st.dev(offs[5]), st.dev(offs[6]), st.dev(offs[7]), st.dev(offs[8]) };
+  return d;
+}
+
+extern "C" int afx_verify_presentations(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* b, size_t count, uint8_t* status) {
+  if (!ctx || !shape || !b || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (count == 0) return AFX_OK;
+  AFX_HIP(hipSetDevice(ctx->device));
+  const uint32_t n = std::min<uint32_t>(shape->n_attributes, AFX_MAX_ATTRIBUTES);
+  const uint32_t nr = std::min<uint32_t>(shape->n_responses, 3 + AFX_MAX_ATTRIBUTES);
+  const uint32_t ne = shape->n_enc_proofs <= AFX_MAX_ATTRIBUTES ? shape->n_enc_proofs : 0;
+  if (!b->challenge || !b->C_x_0 || !b->C_x_1 || !b->C_V || (n && !b->C_y) || (nr && !b->responses) || (ne && !b->enc)) { set_error("null batch array"); return AFX_E_BAD_ARGS; }
+  Stager st(ctx);
+  const size_t o_ch = st.add(b->challenge, 32 * count), o_rs = st.add(b->responses, 32 * count * nr), o_x0 = st.add(b->C_x_0, 32 * count),
+               o_x1 = st.add(b->C_x_1, 32 * count), o_cv = st.add(b->C_V, 32 * count), o_cy = st.add(b->C_y, 32 * count * n),
+               o_av = st.add(b->attr_values, b->attr_values ? 32 * count * n : 0);
+  std::vector<std::array<size_t, 9>> eo(ne);
+  for (uint32_t e = 0; e < ne; e++) stage_encproof(st, b->enc[e], count, eo[e].data());
+  const size_t o_st = st.add(nullptr, count);
+  int rc = st.upload();
+  if (rc) return rc;
+  std::vector<afx_encproof_soa> de(ne);
+  for (uint32_t e = 0; e < ne; e++) de[e] = dev_encproof(st, eo[e].data());
+  afx_presentation_soa d = { st.dev(o_ch), st.dev(o_rs), st.dev(o_x0), st.dev(o_x1), st.dev(o_cv), st.dev(o_cy), st.dev(o_av), de.data() };
+  if ((rc = afx_verify_presentations_dev(ctx, shape, &d, count, st.dev(o_st)))) return rc;
+  AFX_HIP(hipMemcpyAsync(status, st.dev(o_st), count, hipMemcpyDeviceToHost, ctx->stream));
+  AFX_HIP(hipStreamSynchronize(ctx->stream));
+  return AFX_OK;
+}
+
+extern "C" int afx_verify_encryption_proofs(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* b, size_t count, uint8_t* status) {
+  if (!ctx || !b || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (count == 0) return AFX_OK;
+  AFX_HIP(hipSetDevice(ctx->device));
+  Stager st(ctx);
+  size_t eo[9];
+  stage_encproof(st, *b, count, eo);
+  const size_t o_st = st.add(nullptr, count);
+  int rc = st.upload();
+  if (rc) return rc;
+  afx_encproof_soa d = dev_encproof(st, eo);
+  if ((rc = afx_verify_encryption_proofs_dev(ctx, index, &d, count, st.dev(o_st)))) return rc;
+  AFX_HIP(hipMemcpyAsync(status, st.dev(o_st), count, hipMemcpyDeviceToHost, ctx->stream));
+  AFX_HIP(hipStreamSynchronize(ctx->stream));
+  return AFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch primitives (K* rows): from_uniform_bytes, from_bytes_mod_order_wide, decompress/compress, MSM
+// ------------------------------------------------------------------------------------------------
+extern "C" int afx_points_from_uniform_bytes(afx_ctx* ctx, const uint8_t* wide, size_t count, uint8_t* out) {
+  if (!ctx || !wide || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (count == 0) return AFX_OK;
+  AFX_HIP(hipSetDevice(ctx->device));
+  Stager st(ctx);
+  const size_t o_in = st.add(wide, 64 * count), o_out = st.add(nullptr, 32 * count);
+  int rc = st.upload();
+  if (rc) return rc;
+  AFX_HIP(afxk_from_uniform(ctx->stream, st.dev(o_in), st.dev(o_out), nullptr, (uint32_t)count));
+  AFX_HIP(hipMemcpyAsync(out, st.dev(o_out), 32 * count, hipMemcpyDeviceToHost, ctx->stream));
+  AFX_HIP(hipStreamSynchronize(ctx->stream));
+  return AFX_OK;
+}
+extern "C" int afx_scalars_from_wide_bytes(afx_ctx* ctx, const uint8_t* wide, size_t count, uint8_t* out) {
+  if (!ctx || !wide || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (count == 0) return AFX_OK;
+  AFX_HIP(hipSetDevice(ctx->device));
+  Stager st(ctx);
+  const size_t o_in = st.add(wide, 64 * count), o_out = st.add(nullptr, 32 * count);
+  int rc = st.upload();
+  if (rc) return rc;
+  AFX_HIP(afxk_reduce_wide(ctx->stream, st.dev(o_in), st.dev(o_out), (uint32_t)count));
+  AFX_HIP(hipMemcpyAsync(out, st.dev(o_out), 32 * count, hipMemcpyDeviceToHost, ctx->stream));
+  AFX_HIP(hipStreamSynchronize(ctx->stream));
+  return AFX_OK;
+}
+extern "C" int afx_points_validate(afx_ctx* ctx, const uint8_t* pts, size_t count, uint8_t* ok, uint8_t* reencoded) {
+  if (!ctx || !pts || !ok) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (count == 0) return AFX_OK;
+  AFX_HIP(hipSetDevice(ctx->device));
+  Stager st(ctx);
+  const size_t o_in = st.add(pts, 32 * count), o_ok = st.add(nullptr, count), o_re = st.add(nullptr, 32 * count);
+  int rc = st.upload();
+  if (rc) return rc;
+  AFX_HIP(afxk_validate(ctx->stream, st.dev(o_in), st.dev(o_ok), reencoded ? st.dev(o_re) : nullptr, (uint32_t)count));
+  AFX_HIP(hipMemcpyAsync(ok, st.dev(o_ok), count, hipMemcpyDeviceToHost, ctx->stream));
+  if (reencoded) AFX_HIP(hipMemcpyAsync(reencoded, st.dev(o_re), 32 * count, hipMemcpyDeviceToHost, ctx->stream));
+  AFX_HIP(hipStreamSynchronize(ctx->stream));
+  return AFX_OK;
+}
+extern "C" int afx_multiscalar_mul(afx_ctx* ctx, uint32_t n_terms, const uint8_t* scalars, const uint8_t* points, size_t count, uint8_t* out, uint8_t* ok) {
+  if (!ctx || !scalars || !points || !out || !ok) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (n_terms == 0 || n_terms > AFX_MSM_MAX_TERMS) { set_error("n_terms out of range"); return AFX_E_BAD_ARGS; }
+  if (count == 0) return AFX_OK;
+  AFX_HIP(hipSetDevice(ctx->device));
+  Stager st(ctx);
+  const size_t o_s = st.add(scalars, 32 * count * n_terms), o_p = st.add(points, 32 * count * n_terms), o_out = st.add(nullptr, 32 * count),
+               o_ok = st.add(nullptr, count);
+  int rc = st.upload();
+  if (rc) return rc;
+  rc = run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
+    JobSets js;
+    std::vector<afx_msm_term> terms;
+    for (uint32_t k = 0; k < n_terms; k++) {
+      int32_t* v = as.new_var();
+      js.sccheck.push_back({ st.dev(o_s) + (k * count + off) * 32 });
+      js.decode.push_back({ st.dev(o_p) + (k * count + off) * 32, v, 0 });
+      terms.push_back(mk_term(st.dev(o_s) + (k * count + off) * 32, 32, v, -1, false));
+    }
+    afx_msm_job j;
+    memset(&j, 0, sizeof j);
+    set_terms(j, terms);
+    j.out_enc = st.dev(o_out) + off * 32;
+    js.msm1.push_back(j);
+    emit(as, js, st.dev(o_ok) + off, 1);
+  });
+  if (rc) return rc;
+  AFX_HIP(hipMemcpyAsync(out, st.dev(o_out), 32 * count, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<uint8_t> bad(count);
+  AFX_HIP(hipMemcpyAsync(bad.data(), st.dev(o_ok), count, hipMemcpyDeviceToHost, ctx->stream));
+  AFX_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < count; i++) ok[i] = bad[i] ? 0 : 1;
+  return AFX_OK;
+}

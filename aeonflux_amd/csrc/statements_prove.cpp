@@ -1,0 +1,559 @@
+// Issuance (Issuer::issue, CredentialIssuance::verify) and presentation (AnonymousCredential::show) in batch
+// form.  Restates, as GPU launch lists:
+//   /root/reference/src/issuer.rs:111-124  Issuer::issue  = Amac::tag (src/amacs.rs:276-294, compute_V :256-272,
+//                                           Messages::from_attributes :225-243) + ProofOfIssuance::prove
+//                                           (src/nizk/issuance.rs:40-129)
+//   /root/reference/src/issuer.rs:48-57    CredentialIssuance::verify -> src/nizk/issuance.rs:132-218
+//   /root/reference/src/credential.rs:37-46 show -> src/nizk/presentation.rs:139-321 + src/nizk/encryption.rs:58-142
+//                                           + Keypair::encrypt (src/symmetric.rs:252-261)
+//   /root/reference/src/parameters.rs:349-362, src/amacs.rs:104  IssuerParameters::generate, W = w*G_w
+#include "statements.hpp"
+
+static bool is_scalar_kind(uint8_t k) { return k == AFX_ATTR_PUBLIC_SCALAR || k == AFX_ATTR_SECRET_SCALAR; }
+
+static afx_scalarop_job mk_scalarop(const uint8_t* a, uint32_t as_, const uint8_t* b, uint32_t bs, const uint8_t* c, uint32_t cs, bool neg, uint8_t* out) {
+  afx_scalarop_job o;
+  memset(&o, 0, sizeof o);
+  o.a = a; o.a_stride = as_; o.b = b; o.b_stride = bs; o.c = c; o.c_stride = cs; o.negate = neg ? 1u : 0u; o.out = out;
+  return o;
+}
+static afx_msm_job mk_job(const std::vector<afx_msm_term>& terms, const int32_t* addend, int32_t* out_var, uint8_t* out_enc, bool reject_identity) {
+  afx_msm_job j;
+  memset(&j, 0, sizeof j);
+  set_terms(j, terms);
+  j.addend = addend;
+  j.out_var = out_var;
+  j.out_enc = out_enc;
+  j.reject_identity = reject_identity ? 1u : 0u;
+  return j;
+}
+static ScalarVar sv_item(const uint8_t* dev) { ScalarVar s; s.dev = dev; s.stride = 32; return s; }
+static ScalarVar sv_uniform(const uint8_t* dev, const Enc& host) { ScalarVar s; s.dev = dev; s.stride = 0; s.host = host; return s; }
+
+// the transcript / constraint part shared by ProofOfIssuance::prove (:48-126) and ::verify (:142-215)
+struct IssuanceVars {
+  ScalarVar w, wp, x0, x1, y[AFX_MAX_ATTRIBUTES], one;
+  PointVar U, V, tU, M[AFX_MAX_ATTRIBUTES];
+  uint32_t n_messages;
+};
+static void issuance_statement(SchnorrBuilder& b, afx_ctx* c, const IssuanceVars& iv) {
+  const uint32_t n = c->n, g = c->g;
+  const int w = b.allocate_scalar("w", iv.w);
+  const int w_prime = b.allocate_scalar("w'", iv.wp);
+  const int x_0 = b.allocate_scalar("x_0", iv.x0);
+  const int x_1 = b.allocate_scalar("x_1", iv.x1);
+  int y[AFX_MAX_ATTRIBUTES];
+  for (uint32_t i = 0; i < n; i++) y[i] = b.allocate_scalar("y", iv.y[i]);
+  const int one = b.allocate_scalar("1", iv.one);
+  const int G_V = b.allocate_point("G_V", PointVar::Const(c->id_GV()));
+  const int G_w = b.allocate_point("G_w", PointVar::Const(c->id_Gw()));
+  const int G_w_prime = b.allocate_point("G_w_prime", PointVar::Const(c->id_Gwp()));
+  const int neg_G_x_0 = b.allocate_point("-G_x_0", PointVar::Const(c->id_Gx0(), true));
+  const int neg_G_x_1 = b.allocate_point("-G_x_1", PointVar::Const(c->id_Gx1(), true));
+  int neg_G_y[AFX_MAX_ATTRIBUTES];
+  for (uint32_t i = 0; i < g; i++) neg_G_y[i] = b.allocate_point("-G_y", PointVar::Const(c->id_Gy(i), true));
+  const int C_W = b.allocate_point("C_W", PointVar::Const(c->id_CW()));
+  const int I = b.allocate_point("I", PointVar::Const(c->id_I()));
+  const int U = b.allocate_point("U", iv.U);
+  const int V = b.allocate_point("V", iv.V);
+  const int tU = b.allocate_point("tU", iv.tU);
+  int M[AFX_MAX_ATTRIBUTES];
+  for (uint32_t i = 0; i < iv.n_messages; i++) M[i] = b.allocate_point("M", iv.M[i]);
+  b.constrain(C_W, { { w, G_w }, { w_prime, G_w_prime } });
+  std::vector<std::pair<int, int>> rhs = { { one, G_V }, { x_0, neg_G_x_0 }, { x_1, neg_G_x_1 } };
+  for (uint32_t i = 0; i < n; i++) rhs.push_back({ y[i], neg_G_y[i] });   // y.zip(neg_G_y) stops at n (:114)
+  b.constrain(I, rhs);
+  rhs = { { w, G_w }, { x_0, U }, { x_1, tU } };
+  for (uint32_t i = 0; i < n && i < iv.n_messages; i++) rhs.push_back({ y[i], M[i] });
+  b.constrain(V, rhs);
+}
+
+// Messages::from_attributes (src/amacs.rs:225-243): scalar kinds -> m*G_m[i] (one fixed-base job each),
+// point kinds -> the decoded point.  Returns per-attribute PointVars.
+static void messages_from_attributes(Assembler& as, const afx_attributes_soa& a, size_t total, size_t off, bool reject_identity,
+                                     std::vector<afx_sccheck_job>& sccheck, std::vector<afx_decode_job>& decode,
+                                     std::vector<afx_msm_job>& msm, PointVar M[AFX_MAX_ATTRIBUTES]) {
+  afx_ctx* c = as.ctx;
+  for (uint32_t i = 0; i < a.n_attributes; i++) {
+    const uint8_t* val = a.values + (i * total + off) * 32;
+    int32_t* v = as.new_var();
+    if (is_scalar_kind(a.kinds[i])) {
+      sccheck.push_back({ val });
+      uint8_t* e = as.new_enc();
+      msm.push_back(mk_job({ mk_term(val, 32, nullptr, (int32_t)c->id_Gm(i), false) }, nullptr, v, e, reject_identity));
+      M[i] = PointVar::Var(v, e);
+    } else {
+      decode.push_back({ val, v, reject_identity ? 1u : 0u });
+      M[i] = PointVar::Var(v, val);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CredentialIssuance::verify
+// ------------------------------------------------------------------------------------------------
+extern "C" int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* iss, uint32_t n_responses,
+                                        size_t count, uint8_t* status_dev) {
+  if (!ctx || !attrs || !iss || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (count == 0) return AFX_OK;
+  const afx_attributes_soa a = *attrs;
+  const afx_issuance_soa s = *iss;
+  return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
+    afx_ctx* c = as.ctx;
+    JobSets js;
+    auto row = [&](const uint8_t* base, size_t k) { return base + (k * count + off) * 32; };
+    bool bad_kind = false;
+    for (uint32_t i = 0; i < a.n_attributes && i < AFX_MAX_ATTRIBUTES; i++) bad_kind |= a.kinds[i] > AFX_ATTR_SECRET_POINT;
+    // more attributes than generators: Messages::from_attributes indexes G_m[i] (panic); wrong response count: zkp rejects
+    if (a.n_attributes > c->n || n_responses != c->n + 5 || bad_kind) as.fail_all = true;
+    if (as.fail_all) { emit(as, js, status_dev + off, AFX_ST_VERIFICATION_FAILURE); return; }
+    js.sccheck.push_back({ row(s.t, 0) });
+    js.sccheck.push_back({ row(s.challenge, 0) });
+    for (uint32_t r = 0; r < n_responses; r++) js.sccheck.push_back({ row(s.responses, r) });
+    IssuanceVars iv;
+    int32_t *v_U = as.new_var(), *v_V = as.new_var(), *v_tU = as.new_var();
+    uint8_t* e_tU = as.new_enc();
+    js.decode.push_back({ row(s.U, 0), v_U, 1 });
+    js.decode.push_back({ row(s.V, 0), v_V, 1 });
+    messages_from_attributes(as, a, count, off, true, js.sccheck, js.decode, js.msm1, iv.M);
+    js.msm1.push_back(mk_job({ mk_term(row(s.t, 0), 32, v_U, -1, false) }, nullptr, v_tU, e_tU, true));   // t*U (:189)
+    iv.n_messages = a.n_attributes;
+    iv.w = sv_item(row(s.responses, 0)); iv.wp = sv_item(row(s.responses, 1)); iv.x0 = sv_item(row(s.responses, 2)); iv.x1 = sv_item(row(s.responses, 3));
+    for (uint32_t i = 0; i < c->n; i++) iv.y[i] = sv_item(row(s.responses, 4 + i));
+    iv.one = sv_item(row(s.responses, 4 + c->n));
+    iv.U = PointVar::Var(v_U, row(s.U, 0));
+    iv.V = PointVar::Var(v_V, row(s.V, 0));
+    iv.tU = PointVar::Var(v_tU, e_tU);
+    SchnorrBuilder v(as, "2019/1416 anonymous credential", "2019/1416 issuance proof");
+    issuance_statement(v, c, iv);
+    v.verify_compact(row(s.challenge, 0), js.msm2, js.hash);
+    emit(as, js, status_dev + off, AFX_ST_VERIFICATION_FAILURE);
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// Issuer::issue
+// ------------------------------------------------------------------------------------------------
+extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, const afx_issue_randomness* rnd, size_t count,
+                             const afx_issuance_soa* out, uint8_t* status_dev) {
+  if (!ctx || !requests || !rnd || !out || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (!ctx->has_key) { set_error("Issuer::issue needs the issuer key"); return AFX_E_NO_KEY; }
+  if (count == 0) return AFX_OK;
+  const afx_attributes_soa a = *requests;
+  const afx_issue_randomness r = *rnd;
+  const afx_issuance_soa o = *out;
+  return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
+    afx_ctx* c = as.ctx;
+    const uint32_t n = c->n;
+    auto row = [&](const uint8_t* base, size_t k) { return base + (k * count + off) * 32; };
+    auto orow = [&](uint8_t* base, size_t k) { return base + (k * count + off) * 32; };
+    bool bad_kind = false;
+    for (uint32_t i = 0; i < a.n_attributes && i < AFX_MAX_ATTRIBUTES; i++) bad_kind |= a.kinds[i] > AFX_ATTR_SECRET_POINT;
+    // Amac::tag: attributes.len() != NUMBER_OF_ATTRIBUTES -> MacError::MessageLengthError -> MacCreation (amacs.rs:285-287)
+    if (a.n_attributes != n || bad_kind) { as.fail_all = true; as.finish(status_dev + off, AFX_ST_MAC_CREATION); return; }
+    std::vector<afx_sccheck_job> sccheck;
+    std::vector<afx_decode_job> decode;
+    std::vector<afx_msm_job> msm1;
+    std::vector<afx_scalarop_job> sc1;
+    // t = Scalar::random, U = RistrettoPoint::random (amacs.rs:289-290)
+    int32_t* v_U = as.new_var();
+    as.reduce_wide(r.t_wide + off * 64, orow(o.t, 0));
+    as.from_uniform(r.U_wide + off * 64, orow(o.U, 0), v_U);
+    IssuanceVars iv;
+    messages_from_attributes(as, a, count, off, false, sccheck, decode, msm1, iv.M);
+    // V = W + (x0 + x1*t)*U + sum y_i*M_i (amacs.rs:267-270); scalar attributes fold into fixed-base terms (y_i*m_i)*G_m[i]
+    uint8_t* k_xt = as.new_enc();
+    sc1.push_back(mk_scalarop(c->key_x1(), 0, orow(o.t, 0), 32, c->key_x0(), 0, false, k_xt));
+    std::vector<afx_msm_term> vterms = { mk_term(k_xt, 32, v_U, -1, false) };
+    for (uint32_t i = 0; i < n; i++) {
+      if (is_scalar_kind(a.kinds[i])) {
+        uint8_t* ym = as.new_enc();
+        sc1.push_back(mk_scalarop(c->key_y(i), 0, row(a.values, i), 32, nullptr, 0, false, ym));
+        vterms.push_back(mk_term(ym, 32, nullptr, (int32_t)c->id_Gm(i), false));
+      } else {
+        vterms.push_back(mk_term(c->key_y(i), 0, iv.M[i].var, -1, false));
+      }
+    }
+    int32_t *v_Vp = as.new_var(), *v_V = as.new_var(), *v_tU = as.new_var();
+    uint8_t* e_tU = as.new_enc();
+    msm1.push_back(mk_job(vterms, nullptr, v_Vp, nullptr, false));
+    msm1.push_back(mk_job({ mk_term(orow(o.t, 0), 32, v_U, -1, false) }, nullptr, v_tU, e_tU, false));   // t*U (issuance.rs:91)
+    afx_pointop_job pv = { v_Vp, nullptr, c->gen_ext(c->id_W()), +1, +1, v_V, orow(o.V, 0), 0 };
+    as.sccheck(sccheck);
+    as.decode(decode);
+    as.scalarop(sc1);
+    as.msm(msm1);
+    as.pointop({ pv });
+    // ProofOfIssuance::prove
+    iv.n_messages = n;
+    Enc one{};
+    one[0] = 1;
+    iv.w = sv_uniform(c->key_w(), c->host_key[0]); iv.wp = sv_uniform(c->key_wp(), c->host_key[1]);
+    iv.x0 = sv_uniform(c->key_x0(), c->host_key[2]); iv.x1 = sv_uniform(c->key_x1(), c->host_key[3]);
+    for (uint32_t i = 0; i < n; i++) iv.y[i] = sv_uniform(c->key_y(i), c->host_key[4 + i]);
+    iv.one = sv_uniform(c->const_one(), one);
+    iv.U = PointVar::Var(v_U, orow(o.U, 0));
+    iv.V = PointVar::Var(v_V, orow(o.V, 0));
+    iv.tU = PointVar::Var(v_tU, e_tU);
+    SchnorrBuilder p(as, "2019/1416 anonymous credential", "2019/1416 issuance proof");
+    issuance_statement(p, c, iv);
+    std::vector<afx_hash_program> rng_hash, chal_hash;
+    std::vector<afx_msm_job> commit;
+    std::vector<afx_scalarop_job> resp;
+    p.prove_compact(r.rng_seed + off * 32, orow(o.challenge, 0), orow(o.responses, 0), 32 * count, rng_hash, commit, chal_hash, resp);
+    as.hash(rng_hash);
+    as.msm(commit);
+    as.hash(chal_hash);
+    as.scalarop(resp);
+    as.finish(status_dev + off, AFX_ST_MAC_CREATION);
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// AnonymousCredential::show
+// ------------------------------------------------------------------------------------------------
+extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
+                            size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status_dev) {
+  if (!ctx || !creds || !rnd || !out || !shape_out || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  const afx_credentials_soa cr = *creds;
+  const uint32_t na = cr.n_attributes;
+  if (na == 0 || na > ctx->n) { set_error("credential attribute count does not fit the system parameters"); return AFX_E_BAD_ARGS; }
+  for (uint32_t i = 0; i < na; i++)
+    if (cr.kinds[i] > AFX_ATTR_SECRET_POINT) { set_error("unknown attribute kind"); return AFX_E_BAD_ARGS; }
+  // the presentation's shape (encrypted_attributes kinds, hidden_scalar_indices, proofs_of_encryption indices; :293-320)
+  afx_shape sh;
+  memset(&sh, 0, sizeof sh);
+  sh.n_attributes = na;
+  uint32_t hs = 0, nsp = 0;
+  for (uint32_t i = 0; i < na; i++) {
+    switch (cr.kinds[i]) {
+      case AFX_ATTR_PUBLIC_SCALAR: sh.kinds[i] = AFX_ENC_PUBLIC_SCALAR; break;
+      case AFX_ATTR_SECRET_SCALAR: sh.kinds[i] = AFX_ENC_SECRET_SCALAR; sh.hidden_scalar_indices[hs++] = (uint16_t)i; break;
+      case AFX_ATTR_SECRET_POINT: sh.kinds[i] = AFX_ENC_SECRET_POINT; sh.enc_indices[nsp++] = (uint16_t)i; break;
+      default: sh.kinds[i] = AFX_ENC_PUBLIC_POINT; break;
+    }
+  }
+  sh.n_hidden_scalars = hs;
+  sh.n_responses = 3 + hs;
+  sh.n_enc_proofs = nsp;
+  *shape_out = sh;
+  if (count == 0) return AFX_OK;
+  if (nsp && (!cr.M2 || !cr.m3 || !out->enc)) { set_error("hidden group elements need M2, m3 and enc outputs"); return AFX_E_BAD_ARGS; }
+  const bool no_key = nsp && !keypairs;   // CredentialError::NoSymmetricKey (:150-157)
+  const afx_keypairs_soa kp = keypairs ? *keypairs : afx_keypairs_soa{ nullptr, nullptr, nullptr, nullptr };
+  const afx_show_randomness r = *rnd;
+  const afx_presentation_out o = *out;
+  std::vector<afx_encproof_out> eo;
+  if (nsp) eo.assign(o.enc, o.enc + nsp);
+  return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t cc) {
+    afx_ctx* c = as.ctx;
+    auto row = [&](const uint8_t* base, size_t k) { return base + (k * count + off) * 32; };
+    auto orow = [&](uint8_t* base, size_t k) { return base + (k * count + off) * 32; };
+    if (no_key) { as.fail_all = true; as.finish(status_dev + off, AFX_ST_NO_SYMMETRIC_KEY); return; }
+    std::vector<afx_sccheck_job> sccheck;
+    std::vector<afx_decode_job> decode;
+    std::vector<afx_scalarop_job> sc1, sc2;
+    std::vector<afx_msm_job> msm1, msm1b;
+    std::vector<afx_pointop_job> pops;
+    uint8_t *z = as.new_enc(), *z_0 = as.new_enc();
+    as.reduce_wide(r.z_wide + off * 64, z);                                       // z = Scalar::random (:162)
+    sc1.push_back(mk_scalarop(row(cr.t, 0), 32, z, 32, nullptr, 0, true, z_0));   // z_0 = -t*z (:163)
+    sccheck.push_back({ row(cr.t, 0) });
+    int32_t *v_U = as.new_var(), *v_V = as.new_var();
+    decode.push_back({ row(cr.U, 0), v_U, 0 });
+    decode.push_back({ row(cr.V, 0), v_V, 0 });
+    // commitments (:169-184)
+    int32_t* v_Cy[AFX_MAX_ATTRIBUTES];
+    int32_t* v_M1[AFX_MAX_ATTRIBUTES] = { nullptr };
+    for (uint32_t i = 0; i < na; i++) {
+      v_Cy[i] = as.new_var();
+      std::vector<afx_msm_term> t = { mk_term(z, 32, nullptr, (int32_t)c->id_Gy(i), false) };
+      const int32_t* addend = nullptr;
+      if (is_scalar_kind(cr.kinds[i])) {
+        sccheck.push_back({ row(cr.values, i) });
+        if (cr.kinds[i] == AFX_ATTR_SECRET_SCALAR) t.push_back(mk_term(row(cr.values, i), 32, nullptr, (int32_t)c->id_Gm(i), false));
+      } else {
+        v_M1[i] = as.new_var();
+        decode.push_back({ row(cr.values, i), v_M1[i], 0 });
+        if (cr.kinds[i] == AFX_ATTR_SECRET_POINT) addend = v_M1[i];
+      }
+      msm1.push_back(mk_job(t, addend, v_Cy[i], orow(o.C_y, i), false));
+      // revealed values travel with the presentation (:298-302)
+      if (cr.kinds[i] != AFX_ATTR_SECRET_SCALAR && cr.kinds[i] != AFX_ATTR_SECRET_POINT && o.attr_values)
+        as.copy(orow(o.attr_values, i), row(cr.values, i), 32 * (size_t)cc);
+    }
+    int32_t *v_Cx0 = as.new_var(), *v_Cx1 = as.new_var(), *v_Z = as.new_var();
+    uint8_t* e_Z = as.new_enc();
+    msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gx0(), false) }, v_U, v_Cx0, orow(o.C_x_0, 0), false));
+    msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gx1(), false), mk_term(row(cr.t, 0), 32, v_U, -1, false) }, nullptr, v_Cx1, orow(o.C_x_1, 0), false));
+    msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_GV(), false) }, v_V, nullptr, orow(o.C_V, 0), false));
+    msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_I(), false) }, nullptr, v_Z, e_Z, false));
+
+    // the presentation proof's statement (:187-273); witnesses z, z_0, t, hidden scalars
+    SchnorrBuilder p(as, "2019/1416 anonymous credential", "2019/1416 presentation proof");
+    const int zv = p.allocate_scalar("z", sv_item(z));
+    const int z_0v = p.allocate_scalar("z_0", sv_item(z_0));
+    const int tv = p.allocate_scalar("t", sv_item(row(cr.t, 0)));
+    int H_s[AFX_MAX_ATTRIBUTES];
+    for (uint32_t j = 0; j < hs; j++) H_s[j] = p.allocate_scalar("m", sv_item(row(cr.values, sh.hidden_scalar_indices[j])));
+    const int I = p.allocate_point("I", PointVar::Const(c->id_I()));
+    const int C_x_1 = p.allocate_point("C_x_1", PointVar::Var(v_Cx1, orow(o.C_x_1, 0)));
+    const int C_x_0 = p.allocate_point("C_x_0", PointVar::Var(v_Cx0, orow(o.C_x_0, 0)));
+    const int G_x_0 = p.allocate_point("G_x_0", PointVar::Const(c->id_Gx0()));
+    const int G_x_1 = p.allocate_point("G_x_1", PointVar::Const(c->id_Gx1()));
+    int C_y[AFX_MAX_ATTRIBUTES], G_y[AFX_MAX_ATTRIBUTES], G_m[AFX_MAX_ATTRIBUTES];
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < na; i++)
+      if (cr.kinds[i] != AFX_ATTR_SECRET_POINT) C_y[k++] = p.allocate_point("C_y", PointVar::Var(v_Cy[i], orow(o.C_y, i)));
+    for (uint32_t i = 0; i < c->g; i++) G_y[i] = p.allocate_point("G_y", PointVar::Const(c->id_Gy(i)));
+    for (uint32_t j = 0; j < hs; j++) G_m[j] = p.allocate_point("G_m", PointVar::Const(c->id_Gm(sh.hidden_scalar_indices[j])));
+    const int Z = p.allocate_point("Z", PointVar::Var(v_Z, e_Z));
+    p.constrain(Z, { { zv, I } });
+    p.constrain(C_x_1, { { tv, C_x_0 }, { z_0v, G_x_0 }, { zv, G_x_1 } });
+    for (uint32_t j = 0; j < k; j++) {   // compact index used as an original position, literally (:267-273)
+      if (cr.kinds[j] == AFX_ATTR_SECRET_POINT) continue;
+      if (cr.kinds[j] == AFX_ATTR_SECRET_SCALAR) {
+        int slot = -1;
+        for (uint32_t h = 0; h < hs; h++) if (sh.hidden_scalar_indices[h] == j) slot = (int)h;
+        p.constrain(C_y[j], { { zv, G_y[j] }, { H_s[slot], G_m[slot] } });
+      } else {
+        p.constrain(C_y[j], { { zv, G_y[j] } });
+      }
+    }
+    std::vector<afx_hash_program> rng_hash, chal_hash;
+    std::vector<afx_msm_job> commit;
+    std::vector<afx_scalarop_job> resp;
+    p.prove_compact(r.rng_seed + off * 32, orow(o.challenge, 0), orow(o.responses, 0), 32 * count, rng_hash, commit, chal_hash, resp);
+
+    // proofs of encryption, one per hidden group element, in attribute order (:293-309 -> encryption.rs:58-142)
+    for (uint32_t e = 0; e < nsp; e++) {
+      const uint32_t i = sh.enc_indices[e];
+      const afx_encproof_out& q = eo[e];
+      const uint8_t *a = row(kp.a, 0), *a0 = row(kp.a0, 0), *a1 = row(kp.a1, 0), *m3 = row(cr.m3, i);
+      sccheck.push_back({ a }); sccheck.push_back({ a0 }); sccheck.push_back({ a1 }); sccheck.push_back({ m3 });
+      int32_t *v_M2 = as.new_var(), *v_pk = as.new_var();
+      decode.push_back({ row(cr.M2, i), v_M2, 0 });
+      decode.push_back({ row(kp.pk, 0), v_pk, 0 });
+      as.copy(orow(q.pk, 0), row(kp.pk, 0), 32 * (size_t)cc);
+      uint8_t *kk = as.new_enc(), *z1 = as.new_enc();
+      sc1.push_back(mk_scalarop(a1, 32, m3, 32, a0, 32, false, kk));        // a0 + a1*m3
+      sc2.push_back(mk_scalarop(z, 32, kk, 32, nullptr, 0, true, z1));      // z1 = -z(a0 + a1*m3) (encryption.rs:78)
+      int32_t *v_E1 = as.new_var(), *v_E2 = as.new_var(), *v_C1 = as.new_var(), *v_C2 = as.new_var(), *v_C3 = as.new_var(),
+              *v_C2p = as.new_var(), *v_D1 = as.new_var(), *v_D2 = as.new_var();
+      uint8_t *e_D1 = as.new_enc(), *e_D2 = as.new_enc();
+      // Keypair::encrypt (symmetric.rs:252-261): E1 = M2*(a0 + a1*m3), E2 = E1*a + M1
+      msm1.push_back(mk_job({ mk_term(kk, 32, v_M2, -1, false) }, nullptr, v_E1, orow(q.E1, 0), false));
+      msm1b.push_back(mk_job({ mk_term(a, 32, v_E1, -1, false) }, v_M1[i], v_E2, orow(q.E2, 0), false));
+      // C_y_1..3, C_y_2' (encryption.rs:70-75)
+      msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gy(0), false) }, v_M1[i], v_C1, orow(q.C_y_1, 0), false));
+      msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gy(1), false) }, v_M2, v_C2, orow(q.C_y_2, 0), false));
+      msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gy(2), false), mk_term(m3, 32, nullptr, (int32_t)c->id_Gm(i), false) }, nullptr, v_C3, orow(q.C_y_3, 0), false));
+      msm1b.push_back(mk_job({ mk_term(a1, 32, v_C2, -1, false) }, nullptr, v_C2p, orow(q.C_y_2p, 0), false));
+      afx_pointop_job d1 = { v_C1, v_E2, nullptr, +1, -1, v_D1, e_D1, 0 };
+      afx_pointop_job d2 = { v_E1, nullptr, nullptr, -1, 0, v_D2, e_D2, 0 };
+      pops.push_back(d1);
+      pops.push_back(d2);
+      SchnorrBuilder ep(as, "2019/1416 anonymous credentials", "2019/1416 proof of encryption");
+      const int sa = ep.allocate_scalar("a", sv_item(a));
+      const int sa0 = ep.allocate_scalar("a0", sv_item(a0));
+      const int sa1 = ep.allocate_scalar("a1", sv_item(a1));
+      const int sm3 = ep.allocate_scalar("m3", sv_item(m3));
+      const int sz = ep.allocate_scalar("z", sv_item(z));
+      const int sz1 = ep.allocate_scalar("z1", sv_item(z1));
+      const int pk = ep.allocate_point("pk", PointVar::Var(v_pk, row(kp.pk, 0)));
+      const int G_a = ep.allocate_point("G_a", PointVar::Const(c->id_Ga()));
+      const int G_a_0 = ep.allocate_point("G_a_0", PointVar::Const(c->id_Ga0()));
+      const int G_a_1 = ep.allocate_point("G_a_1", PointVar::Const(c->id_Ga1()));
+      const int G_y_1 = ep.allocate_point("G_y_1", PointVar::Const(c->id_Gy(0)));
+      const int G_y_2 = ep.allocate_point("G_y_2", PointVar::Const(c->id_Gy(1)));
+      const int G_y_3 = ep.allocate_point("G_y_3", PointVar::Const(c->id_Gy(2)));
+      const int G_m_3 = ep.allocate_point("G_m_3", PointVar::Const(c->id_Gm(i)));
+      const int C_y_2 = ep.allocate_point("C_y_2", PointVar::Var(v_C2, orow(q.C_y_2, 0)));
+      const int C_y_3 = ep.allocate_point("C_y_3", PointVar::Var(v_C3, orow(q.C_y_3, 0)));
+      const int C_y_2p = ep.allocate_point("C_y_2'", PointVar::Var(v_C2p, orow(q.C_y_2p, 0)));
+      const int C_y_1_minus_E2 = ep.allocate_point("C_y_1-E2", PointVar::Var(v_D1, e_D1));
+      const int E1 = ep.allocate_point("E1", PointVar::Var(v_E1, orow(q.E1, 0)));
+      const int minus_E1 = ep.allocate_point("-E1", PointVar::Var(v_D2, e_D2));
+      ep.constrain(pk, { { sa, G_a }, { sa0, G_a_0 }, { sa1, G_a_1 } });
+      ep.constrain(C_y_1_minus_E2, { { sz, G_y_1 }, { sa, minus_E1 } });
+      ep.constrain(C_y_2p, { { sa1, C_y_2 } });
+      ep.constrain(E1, { { sa0, C_y_2 }, { sm3, C_y_2p }, { sz1, G_y_2 } });
+      ep.constrain(C_y_3, { { sz, G_y_3 }, { sm3, G_m_3 } });
+      ep.prove_compact(r.enc_seeds + (e * count + off) * 32, orow(q.challenge, 0), orow(q.responses, 0), 32 * count, rng_hash, commit, chal_hash, resp);
+    }
+    as.sccheck(sccheck);
+    as.decode(decode);
+    as.scalarop(sc1);
+    as.scalarop(sc2);
+    as.msm(msm1);
+    as.msm(msm1b);
+    as.pointop(pops);
+    as.hash(rng_hash);
+    as.msm(commit);
+    as.hash(chal_hash);
+    as.scalarop(resp);
+    as.finish(status_dev + off, AFX_ST_VERIFICATION_FAILURE);
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-pointer front ends
+// ------------------------------------------------------------------------------------------------
+static int fetch(afx_ctx* ctx, void* dst, const uint8_t* src_dev, size_t n) {
+  if (!dst || !n) return AFX_OK;
+  AFX_HIP(hipMemcpyAsync(dst, src_dev, n, hipMemcpyDeviceToHost, ctx->stream));
+  return AFX_OK;
+}
+
+extern "C" int afx_issue(afx_ctx* ctx, const afx_attributes_soa* req, const afx_issue_randomness* rnd, size_t count,
+                         const afx_issuance_soa* out, uint8_t* status) {
+  if (!ctx || !req || !rnd || !out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (!rnd->t_wide || !rnd->U_wide || !rnd->rng_seed || !out->t || !out->U || !out->V || !out->challenge || !out->responses || (req->n_attributes && !req->values)) {
+    set_error("null batch array");
+    return AFX_E_BAD_ARGS;
+  }
+  if (count == 0) return AFX_OK;
+  AFX_HIP(hipSetDevice(ctx->device));
+  const uint32_t na = std::min<uint32_t>(req->n_attributes, AFX_MAX_ATTRIBUTES), nr = ctx->n + 5;
+  Stager st(ctx);
+  const size_t o_val = st.add(req->values, 32 * count * na), o_tw = st.add(rnd->t_wide, 64 * count), o_uw = st.add(rnd->U_wide, 64 * count),
+               o_seed = st.add(rnd->rng_seed, 32 * count), o_t = st.add(nullptr, 32 * count), o_U = st.add(nullptr, 32 * count),
+               o_V = st.add(nullptr, 32 * count), o_ch = st.add(nullptr, 32 * count), o_rs = st.add(nullptr, 32 * count * nr),
+               o_st = st.add(nullptr, count);
+  int rc = st.upload();
+  if (rc) return rc;
+  afx_attributes_soa da = *req;
+  da.values = st.dev(o_val);
+  afx_issue_randomness dr = { st.dev(o_tw), st.dev(o_uw), st.dev(o_seed) };
+  afx_issuance_soa dout = { st.dev(o_t), st.dev(o_U), st.dev(o_V), st.dev(o_ch), st.dev(o_rs) };
+  if ((rc = afx_issue_dev(ctx, &da, &dr, count, &dout, st.dev(o_st)))) return rc;
+  if ((rc = fetch(ctx, out->t, st.dev(o_t), 32 * count)) || (rc = fetch(ctx, out->U, st.dev(o_U), 32 * count)) ||
+      (rc = fetch(ctx, out->V, st.dev(o_V), 32 * count)) || (rc = fetch(ctx, out->challenge, st.dev(o_ch), 32 * count)) ||
+      (rc = fetch(ctx, out->responses, st.dev(o_rs), 32 * count * nr)) || (rc = fetch(ctx, status, st.dev(o_st), count)))
+    return rc;
+  AFX_HIP(hipStreamSynchronize(ctx->stream));
+  return AFX_OK;
+}
+
+extern "C" int afx_verify_issuances(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* iss, uint32_t n_responses,
+                                    size_t count, uint8_t* status) {
+  if (!ctx || !attrs || !iss || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (!iss->t || !iss->U || !iss->V || !iss->challenge || (n_responses && !iss->responses) || (attrs->n_attributes && !attrs->values)) {
+    set_error("null batch array");
+    return AFX_E_BAD_ARGS;
+  }
+  if (count == 0) return AFX_OK;
+  AFX_HIP(hipSetDevice(ctx->device));
+  const uint32_t na = std::min<uint32_t>(attrs->n_attributes, AFX_MAX_ATTRIBUTES), nr = std::min<uint32_t>(n_responses, AFX_MAX_ATTRIBUTES + 5);
+  Stager st(ctx);
+  const size_t o_val = st.add(attrs->values, 32 * count * na), o_t = st.add(iss->t, 32 * count), o_U = st.add(iss->U, 32 * count),
+               o_V = st.add(iss->V, 32 * count), o_ch = st.add(iss->challenge, 32 * count), o_rs = st.add(iss->responses, 32 * count * nr),
+               o_st = st.add(nullptr, count);
+  int rc = st.upload();
+  if (rc) return rc;
+  afx_attributes_soa da = *attrs;
+  da.values = st.dev(o_val);
+  afx_issuance_soa di = { st.dev(o_t), st.dev(o_U), st.dev(o_V), st.dev(o_ch), st.dev(o_rs) };
+  if ((rc = afx_verify_issuances_dev(ctx, &da, &di, n_responses, count, st.dev(o_st)))) return rc;
+  if ((rc = fetch(ctx, status, st.dev(o_st), count))) return rc;
+  AFX_HIP(hipStreamSynchronize(ctx->stream));
+  return AFX_OK;
+}
+
+extern "C" int afx_show(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
+                        size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status) {
+  if (!ctx || !creds || !rnd || !out || !shape_out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  const uint32_t na = creds->n_attributes;
+  if (na == 0 || na > ctx->n) { set_error("credential attribute count does not fit the system parameters"); return AFX_E_BAD_ARGS; }
+  uint32_t hs = 0, nsp = 0;
+  for (uint32_t i = 0; i < na; i++) { hs += creds->kinds[i] == AFX_ATTR_SECRET_SCALAR; nsp += creds->kinds[i] == AFX_ATTR_SECRET_POINT; }
+  if (!creds->values || !creds->t || !creds->U || !creds->V || !rnd->z_wide || !rnd->rng_seed || !out->challenge || !out->responses ||
+      !out->C_x_0 || !out->C_x_1 || !out->C_V || !out->C_y || (nsp && (!rnd->enc_seeds || !out->enc || !creds->M2 || !creds->m3))) {
+    set_error("null batch array");
+    return AFX_E_BAD_ARGS;
+  }
+  if (keypairs && nsp && (!keypairs->a || !keypairs->a0 || !keypairs->a1 || !keypairs->pk)) { set_error("null keypair array"); return AFX_E_BAD_ARGS; }
+  AFX_HIP(hipSetDevice(ctx->device));
+  Stager st(ctx);
+  const size_t row = 32 * count;
+  const size_t o_val = st.add(creds->values, row * na), o_M2 = st.add(nsp ? creds->M2 : nullptr, nsp ? row * na : 0),
+               o_m3 = st.add(nsp ? creds->m3 : nullptr, nsp ? row * na : 0), o_t = st.add(creds->t, row), o_U = st.add(creds->U, row),
+               o_V = st.add(creds->V, row), o_zw = st.add(rnd->z_wide, 64 * count), o_seed = st.add(rnd->rng_seed, row),
+               o_es = st.add(nsp ? rnd->enc_seeds : nullptr, row * nsp);
+  size_t o_kp[4] = { 0, 0, 0, 0 };
+  if (keypairs && nsp) { o_kp[0] = st.add(keypairs->a, row); o_kp[1] = st.add(keypairs->a0, row); o_kp[2] = st.add(keypairs->a1, row); o_kp[3] = st.add(keypairs->pk, row); }
+  const size_t o_ch = st.add(nullptr, row), o_rs = st.add(nullptr, row * (3 + hs)), o_x0 = st.add(nullptr, row), o_x1 = st.add(nullptr, row),
+               o_cv = st.add(nullptr, row), o_cy = st.add(nullptr, row * na), o_av = st.add(nullptr, row * na), o_st = st.add(nullptr, count);
+  std::vector<std::array<size_t, 9>> oe(nsp);
+  for (uint32_t e = 0; e < nsp; e++)
+    for (int f = 0; f < 9; f++) oe[e][f] = st.add(nullptr, row * (f == 1 ? 6 : 1));
+  int rc = st.upload();
+  if (rc) return rc;
+  afx_credentials_soa dc = *creds;
+  dc.values = st.dev(o_val); dc.M2 = nsp ? st.dev(o_M2) : nullptr; dc.m3 = nsp ? st.dev(o_m3) : nullptr;
+  dc.t = st.dev(o_t); dc.U = st.dev(o_U); dc.V = st.dev(o_V);
+  afx_keypairs_soa dk = { st.dev(o_kp[0]), st.dev(o_kp[1]), st.dev(o_kp[2]), st.dev(o_kp[3]) };
+  afx_show_randomness dr = { st.dev(o_zw), st.dev(o_seed), st.dev(o_es) };
+  std::vector<afx_encproof_out> de(nsp);
+  for (uint32_t e = 0; e < nsp; e++)
+    de[e] = { st.dev(oe[e][0]), st.dev(oe[e][1]), st.dev(oe[e][2]), st.dev(oe[e][3]), st.dev(oe[e][4]), st.dev(oe[e][5]), st.dev(oe[e][6]), st.dev(oe[e][7]), st.dev(oe[e][8]) };
+  afx_presentation_out dout = { st.dev(o_ch), st.dev(o_rs), st.dev(o_x0), st.dev(o_x1), st.dev(o_cv), st.dev(o_cy), st.dev(o_av), de.data() };
+  if ((rc = afx_show_dev(ctx, &dc, (keypairs && nsp) ? &dk : nullptr, &dr, count, &dout, shape_out, st.dev(o_st)))) return rc;
+  if (count == 0) return AFX_OK;
+  if ((rc = fetch(ctx, out->challenge, st.dev(o_ch), row)) || (rc = fetch(ctx, out->responses, st.dev(o_rs), row * (3 + hs))) ||
+      (rc = fetch(ctx, out->C_x_0, st.dev(o_x0), row)) || (rc = fetch(ctx, out->C_x_1, st.dev(o_x1), row)) || (rc = fetch(ctx, out->C_V, st.dev(o_cv), row)) ||
+      (rc = fetch(ctx, out->C_y, st.dev(o_cy), row * na)) || (rc = fetch(ctx, out->attr_values, st.dev(o_av), row * na)) || (rc = fetch(ctx, status, st.dev(o_st), count)))
+    return rc;
+  for (uint32_t e = 0; e < nsp; e++) {
+    uint8_t* dst[9] = { out->enc[e].challenge, out->enc[e].responses, out->enc[e].pk, out->enc[e].E1, out->enc[e].E2,
+                        out->enc[e].C_y_1, out->enc[e].C_y_2, out->enc[e].C_y_3, out->enc[e].C_y_2p };
+    for (int f = 0; f < 9; f++)
+      if ((rc = fetch(ctx, dst[f], st.dev(oe[e][f]), row * (f == 1 ? 6 : 1)))) return rc;
+  }
+  AFX_HIP(hipStreamSynchronize(ctx->stream));
+  return AFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// IssuerParameters::generate + W = w*G_w
+// ------------------------------------------------------------------------------------------------
+extern "C" int afx_issuer_keygen(int device, const uint8_t* sysparams, size_t sysparams_len, const uint8_t* key_scalars, size_t key_scalars_len,
+                                 uint8_t W_out[32], uint8_t issuer_params_out[64]) {
+  if (!sysparams || !key_scalars || !W_out || !issuer_params_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (sysparams_len < 4) { set_error("SystemParameters too short"); return AFX_E_BAD_PARAMS; }
+  const uint32_t n = (uint32_t)sysparams[0] | ((uint32_t)sysparams[1] << 8) | ((uint32_t)sysparams[2] << 16) | ((uint32_t)sysparams[3] << 24);
+  if (n == 0 || n > AFX_MAX_ATTRIBUTES || key_scalars_len != 4 + 32 * (size_t)(4 + n) || memcmp(key_scalars, sysparams, 4) != 0) {
+    set_error("key scalar block length / attribute count");
+    return AFX_E_BAD_PARAMS;
+  }
+  afx_ctx* c = nullptr;
+  int rc = afx_ctx_create_impl(&c, device, sysparams, sysparams_len, nullptr, 0, key_scalars, nullptr);
+  if (rc) return rc;
+  Stager st(c);
+  const size_t o_out = st.add(nullptr, 96), o_st = st.add(nullptr, 1);
+  if ((rc = st.upload())) { afx_ctx_destroy(c); return rc; }
+  rc = run_chunked(c, 1, [&](Assembler& as, size_t, uint32_t) {
+    std::vector<afx_msm_job> jobs;
+    jobs.push_back(mk_job({ mk_term(c->key_w(), 0, nullptr, (int32_t)c->id_Gw(), false) }, nullptr, nullptr, st.dev(o_out), false));   // W (amacs.rs:104)
+    jobs.push_back(mk_job({ mk_term(c->key_w(), 0, nullptr, (int32_t)c->id_Gw(), false), mk_term(c->key_wp(), 0, nullptr, (int32_t)c->id_Gwp(), false) },
+                          nullptr, nullptr, st.dev(o_out) + 32, false));                                                               // C_W (parameters.rs:350-351)
+    std::vector<afx_msm_term> it = { mk_term(c->const_one(), 0, nullptr, (int32_t)c->id_GV(), false), mk_term(c->key_x0(), 0, nullptr, (int32_t)c->id_Gx0(), true),
+                                     mk_term(c->key_x1(), 0, nullptr, (int32_t)c->id_Gx1(), true) };
+    for (uint32_t i = 0; i < c->n; i++) it.push_back(mk_term(c->key_y(i), 0, nullptr, (int32_t)c->id_Gy(i), true));
+    jobs.push_back(mk_job(it, nullptr, nullptr, st.dev(o_out) + 64, false));                                                           // I (parameters.rs:353-359)
+    as.msm(jobs);
+    as.finish(st.dev(o_st), 1);
+  });
+  uint8_t buf[96];
+  if (!rc) {
+    hipError_t e = hipMemcpyAsync(buf, st.dev(o_out), 96, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = AFX_E_HIP; }
+  }
+  if (!rc) {
+    memcpy(W_out, buf, 32);
+    memcpy(issuer_params_out, buf + 32, 64);
+  }
+  afx_ctx_destroy(c);
+  return rc;
+}

@@ -1,0 +1,55 @@
+// TEST INFRASTRUCTURE: a fake HIP runtime + no-op kernel launchers, so the host half of the engine
+// (context parsing, plan assembly, STROBE schedule compilation, C ABI argument handling) can be exercised
+// on a machine without a GPU under ASan/UBSan.  Nothing here computes results: every "kernel" is a no-op
+// and status bytes come back as whatever malloc'ed memory held.  Never shipped, never loaded by the product.
+#include <hip/hip_runtime_api.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../aeonflux_amd/csrc/kernels.h"
+
+extern "C" {
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return hipSuccess; }
+hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)0x1; return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)0x1; return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+const char* hipGetErrorString(hipError_t) { return "fake"; }
+}
+
+// walk the job arrays like the kernels would, touching every pointer-sized field (ASan catches bad blobs)
+static volatile uintptr_t sink;
+hipError_t afxk_setup_generators(hipStream_t, const uint8_t*, uint32_t ngen, int32_t*, int32_t*, uint8_t*, uint32_t* ok) {
+  for (uint32_t i = 0; i < ngen; i++) ok[i] = 1;
+  return hipSuccess;
+}
+hipError_t afxk_decode(hipStream_t, const afx_decode_job* j, uint32_t n, uint32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].enc; return hipSuccess; }
+hipError_t afxk_sccheck(hipStream_t, const afx_sccheck_job* j, uint32_t n, uint32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].sc; return hipSuccess; }
+hipError_t afxk_pointop(hipStream_t, const afx_pointop_job* j, uint32_t n, uint32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
+hipError_t afxk_scalarop(hipStream_t, const afx_scalarop_job* j, uint32_t n, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
+hipError_t afxk_msm(hipStream_t, const afx_msm_job* j, uint32_t n, uint32_t, const int32_t*, int32_t*, uint32_t*, uint32_t*, uint32_t) {
+  for (uint32_t i = 0; i < n; i++)
+    for (uint32_t t = 0; t < j[i].n_terms; t++) sink += (uintptr_t)j[i].term[t].scalar;
+  return hipSuccess;
+}
+hipError_t afxk_hash(hipStream_t, const afx_hash_program* p, uint32_t n, uint32_t*, uint32_t) {
+  for (uint32_t i = 0; i < n; i++)
+    for (uint32_t r = 0; r < p[i].n_records; r++)
+      for (int w = 0; w < 21; w++)
+        if (p[i].records[r].w[w].field >= 0) sink += (uintptr_t)p[i].fields[p[i].records[r].w[w].field];
+  return hipSuccess;
+}
+hipError_t afxk_finish(hipStream_t, const uint32_t*, uint8_t* status, uint32_t count, uint32_t, uint8_t) { memset(status, 0x5a, count); return hipSuccess; }
+hipError_t afxk_fill_u32(hipStream_t, uint32_t* p, uint32_t v, uint32_t n) { for (uint32_t i = 0; i < n; i++) p[i] = v; return hipSuccess; }
+hipError_t afxk_from_uniform(hipStream_t, const uint8_t*, uint8_t*, int32_t*, uint32_t) { return hipSuccess; }
+hipError_t afxk_reduce_wide(hipStream_t, const uint8_t*, uint8_t*, uint32_t) { return hipSuccess; }
+hipError_t afxk_validate(hipStream_t, const uint8_t*, uint8_t*, uint8_t*, uint32_t) { return hipSuccess; }

@@ -1,0 +1,101 @@
+"""GPU parity for Issuer::verify: the HIP path through the C ABI must give
+the ORACLE's accept/reject for every item — committed flows, seeded batches with every kind of corruption,
+ragged batch sizes, and the shapes on which the reference panics."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from tests.helpers import corrupt, gpu_verify, make_batch, pres_from_json
+
+pytestmark = pytest.mark.gpu
+H = bytes.fromhex
+
+
+def test_committed_flows(flows):
+    import aeonflux_amd as afx
+    n_checked = 0
+    for r in flows:
+        if "presentation" not in r:
+            continue
+        ctx = afx.Context(H(r["params"]), H(r["key"]), H(r["issuer_params"]))
+        p = pres_from_json(r)
+        assert gpu_verify(afx, ctx, [p]) == [r["verify"]], r["name"]
+        ctx.close()
+        n_checked += 1
+    assert n_checked >= 12
+
+
+@pytest.mark.parametrize("n,layout,hide,count", [
+    (4, "SSPE", [0, 3], 200),           # BASELINE config 1/2 shape  s S P e
+    (8, "SSPPEEEE", [4, 5, 6, 7], 70),  # BASELINE config 3/4 shape  S S P P e e e e
+    (1, "S", [], 65),
+    (3, "ESS", [0], 33),                # leading hidden point: honest proofs are rejected (App. B)
+    (6, "SSSPSE", [0, 2, 4, 5], 64),
+    (2, "SP", [], 1),
+])
+def test_batches_with_corruptions(n, layout, hide, count):
+    import aeonflux_amd as afx
+    params, key, ip, issuer, pres = make_batch(n, layout, hide, count, b"gpu-verify-%d-%s" % (n, layout.encode()))
+    corrupt(pres, b"corrupt-" + layout.encode())
+    want = [issuer.verify_presentation(p) for p in pres]
+    ctx = afx.Context(params, key, ip)
+    got = gpu_verify(afx, ctx, pres)
+    ctx.close()
+    assert got == want
+    if count > 30 and layout != "ESS":
+        assert 0 in want and 1 in want
+
+
+def test_shapes_the_reference_panics_on():
+    import oracle
+    import aeonflux_amd as afx
+    from tests.soa import shape_of
+    params, key, ip, issuer, pres = make_batch(4, "SSPE", [0, 3], 3, b"panic-shapes")
+    ctx = afx.Context(params, key, ip)
+    base = shape_of(pres[0])
+    assert gpu_verify(afx, ctx, pres) == [0, 0, 0]
+
+    def variant(**kw):
+        s = oracle.Shape.from_buffer_copy(bytes(base))
+        for k, v in kw.items():
+            if isinstance(v, tuple):
+                getattr(s, k)[v[0]] = v[1]
+            else:
+                setattr(s, k, v)
+        return s
+    for s in (variant(n_hidden_scalars=0), variant(hidden_scalar_indices=(0, 1)), variant(hidden_scalar_indices=(0, 9)),
+              variant(enc_indices=(0, 7)), variant(kinds=(1, 1)), variant(kinds=(0, 0)), variant(n_responses=3)):
+        # same answer as the oracle given the same (mis-shaped) presentation
+        want = []
+        for p in pres:
+            q = oracle.Presentation.from_buffer_copy(bytes(p))
+            q.n_hidden_scalars = s.n_hidden_scalars
+            q.n_responses = s.n_responses
+            for k in range(32):
+                q.hidden_scalar_indices[k] = s.hidden_scalar_indices[k]
+                q.kinds[k] = s.kinds[k]
+            for e in range(q.n_enc_proofs):
+                q.enc[e].index = s.enc_indices[e]
+            want.append(issuer.verify_presentation(q))
+        assert gpu_verify(afx, ctx, pres, shape=s) == want
+        assert want == [1, 1, 1]
+    ctx.close()
+
+
+def test_encryption_proofs_alone():
+    import aeonflux_amd as afx
+    from tests.soa import presentation_arrays
+    params, key, ip, issuer, pres = make_batch(5, "SESSS", [1], 40, b"enc-alone")
+    pres[3].enc[0].C_y_3[2] ^= 4
+    pres[17].enc[0].pk[0] ^= 1
+    a = presentation_arrays(pres)["enc"][0]
+    soa = afx.EncProofSoA()
+    for f in ("challenge", "responses", "pk", "E1", "E2", "C_y_1", "C_y_2", "C_y_3", "C_y_2p"):
+        setattr(soa, f, a[f].ctypes.data)
+    status = np.full(len(pres), 9, np.uint8)
+    ctx = afx.Context(params, key, ip)
+    ctx.verify_encryption_proofs(1, soa, len(pres), status.ctypes.data)
+    ctx.close()
+    assert status.tolist() == [issuer.verify_encryption_proof(p.enc[0]) for p in pres]
+    assert status[3] == 1 and status[17] == 1 and status.sum() == 2
