@@ -111,6 +111,8 @@ def lib():
             if hasattr(_LIB, name):
                 getattr(_LIB, name).argtypes = [C.c_void_p, C.POINTER(CredentialsSoA), C.POINTER(KeypairsSoA), C.POINTER(ShowRandomness),
                                                 C.c_size_t, C.POINTER(PresentationOut), C.POINTER(Shape), C.c_void_p]
+        _LIB.afx_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
+        _LIB.afx_ctx_get_timing.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         if hasattr(_LIB, "afx_issuer_keygen"):
             _LIB.afx_issuer_keygen.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p]
     return _LIB
@@ -143,6 +145,15 @@ class Context:
 
     def __del__(self):
         self.close()
+
+    def set_timing(self, enable):
+        check(lib().afx_ctx_set_timing(self.h, 1 if enable else 0))
+
+    def get_timing(self, kernel):
+        """(total_ms, launches) of one kernel since set_timing(True); synchronises the context's stream"""
+        ms, n = C.c_double(0), C.c_uint64(0)
+        check(lib().afx_ctx_get_timing(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     # ---- Issuer::verify ----
     def verify_presentations(self, shape, soa, count, status_ptr, device_pointers=False):

@@ -1,0 +1,152 @@
+"""Batch front end over the C ABI with numpy arrays (host pointers) — the Python mirror of the reference's
+`Issuer::issue`, `CredentialIssuance::verify`, `AnonymousCredential::show`, `Issuer::verify` for whole batches.
+
+Layout convention everywhere: a field of a batch is a uint8 array of shape [count, 32]; a repeated field is
+[k, count, 32] (k-major), exactly the struct-of-arrays layout of include/aeonflux_gpu.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import (AttributesSoA, CredentialsSoA, EncProofOut, EncProofSoA, IssuanceSoA, IssueRandomness, KeypairsSoA,
+               PresentationOut, PresentationSoA, Shape, ShowRandomness, check, lib)
+
+ENC_FIELDS = ("challenge", "responses", "pk", "E1", "E2", "C_y_1", "C_y_2", "C_y_3", "C_y_2p")
+PRES_FIELDS = ("challenge", "responses", "C_x_0", "C_x_1", "C_V", "C_y", "attr_values")
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a
+
+
+def _attrs(kinds, values):
+    s = AttributesSoA()
+    s.n_attributes = len(kinds)
+    for i, k in enumerate(kinds):
+        s.kinds[i] = k
+    s.values = values.ctypes.data
+    return s
+
+
+def issue(ctx, kinds, values, t_wide, U_wide, rng_seed):
+    """Issuer::issue over a batch.  values [n,count,32], t_wide/U_wide [count,64], rng_seed [count,32].
+    Returns (dict(t,U,V,challenge,responses[n+5,count,32]), status[count])."""
+    values, t_wide, U_wide, rng_seed = map(_u8, (values, t_wide, U_wide, rng_seed))
+    cnt = t_wide.shape[0]
+    req = _attrs(kinds, values)
+    rnd = IssueRandomness(t_wide.ctypes.data, U_wide.ctypes.data, rng_seed.ctypes.data)
+    o = {k: np.zeros((cnt, 32), np.uint8) for k in ("t", "U", "V", "challenge")}
+    o["responses"] = np.zeros((ctx.n + 5, cnt, 32), np.uint8)
+    out = IssuanceSoA(*(o[k].ctypes.data for k in ("t", "U", "V", "challenge", "responses")))
+    status = np.full(cnt, 255, np.uint8)
+    check(lib().afx_issue(ctx.h, C.byref(req), C.byref(rnd), cnt, C.byref(out), status.ctypes.data))
+    return o, status
+
+
+def verify_issuances(ctx, kinds, values, issuance, n_responses=None):
+    """CredentialIssuance::verify over a batch; issuance = dict as returned by issue()."""
+    values = _u8(values)
+    iss = {k: _u8(issuance[k]) for k in ("t", "U", "V", "challenge", "responses")}
+    cnt = iss["t"].shape[0]
+    req = _attrs(kinds, values)
+    s = IssuanceSoA(*(iss[k].ctypes.data for k in ("t", "U", "V", "challenge", "responses")))
+    status = np.full(cnt, 255, np.uint8)
+    nr = iss["responses"].shape[0] if n_responses is None else n_responses
+    check(lib().afx_verify_issuances(ctx.h, C.byref(req), C.byref(s), nr, cnt, status.ctypes.data))
+    return status
+
+
+def show(ctx, kinds, values, t, U, V, keypairs, z_wide, rng_seed, enc_seeds=None, M2=None, m3=None):
+    """AnonymousCredential::show over a batch.  kinds: AFX_ATTR_* after hide/reveal.  values/M2/m3 [n,count,32];
+    keypairs: dict(a,a0,a1,pk -> [count,32]) or None; enc_seeds [#secret points, count, 32].
+    Returns (presentation dict incl. 'enc' list, Shape, status)."""
+    n = len(kinds)
+    values, t, U, V, z_wide, rng_seed = map(_u8, (values, t, U, V, z_wide, rng_seed))
+    cnt = t.shape[0]
+    nsp = sum(1 for k in kinds if k == 4)
+    hs = sum(1 for k in kinds if k == 1)
+    cs = CredentialsSoA()
+    cs.n_attributes = n
+    for i, k in enumerate(kinds):
+        cs.kinds[i] = k
+    keep = [values, t, U, V, z_wide, rng_seed]
+    cs.values, cs.t, cs.U, cs.V = values.ctypes.data, t.ctypes.data, U.ctypes.data, V.ctypes.data
+    if nsp:
+        M2, m3, enc_seeds = _u8(M2), _u8(m3), _u8(enc_seeds)
+        keep += [M2, m3, enc_seeds]
+        cs.M2, cs.m3 = M2.ctypes.data, m3.ctypes.data
+    kp = None
+    if keypairs is not None:
+        ka = {f: _u8(keypairs[f]) for f in ("a", "a0", "a1", "pk")}
+        keep.append(ka)
+        kp = KeypairsSoA(*(ka[f].ctypes.data for f in ("a", "a0", "a1", "pk")))
+    rnd = ShowRandomness(z_wide.ctypes.data, rng_seed.ctypes.data, enc_seeds.ctypes.data if nsp else None)
+    o = {k: np.zeros((cnt, 32), np.uint8) for k in ("challenge", "C_x_0", "C_x_1", "C_V")}
+    o["responses"] = np.zeros((3 + hs, cnt, 32), np.uint8)
+    o["C_y"] = np.zeros((n, cnt, 32), np.uint8)
+    o["attr_values"] = np.zeros((n, cnt, 32), np.uint8)
+    o["enc"] = []
+    eouts = (EncProofOut * max(1, nsp))()
+    for e in range(nsp):
+        d = {f: np.zeros(((6, cnt, 32) if f == "responses" else (cnt, 32)), np.uint8) for f in ENC_FIELDS}
+        for f, v in d.items():
+            setattr(eouts[e], f, v.ctypes.data)
+        o["enc"].append(d)
+    out = PresentationOut()
+    for f in PRES_FIELDS:
+        setattr(out, f, o[f].ctypes.data)
+    out.enc = C.cast(eouts, C.POINTER(EncProofOut))
+    shape = Shape()
+    status = np.full(cnt, 255, np.uint8)
+    check(lib().afx_show(ctx.h, C.byref(cs), C.byref(kp) if kp is not None else None, C.byref(rnd), cnt, C.byref(out),
+                         C.byref(shape), status.ctypes.data))
+    return o, shape, status
+
+
+def presentation_soa(p, ptr=lambda a: a.ctypes.data):
+    """afx_presentation_soa over a presentation dict (numpy arrays by default; pass ptr=lambda t: t.data_ptr()
+    for torch device tensors).  Returns (soa, keepalive)."""
+    encs = (EncProofSoA * max(1, len(p["enc"])))()
+    for e, d in enumerate(p["enc"]):
+        for f in ENC_FIELDS:
+            setattr(encs[e], f, ptr(d[f]))
+    soa = PresentationSoA()
+    for f in PRES_FIELDS:
+        setattr(soa, f, ptr(p[f]))
+    soa.enc = C.cast(encs, C.POINTER(EncProofSoA))
+    return soa, encs
+
+
+def verify_presentations(ctx, shape, p):
+    """Issuer::verify over a batch of presentations held in host numpy arrays."""
+    p = dict(p, **{f: _u8(p[f]) for f in PRES_FIELDS}, enc=[{f: _u8(d[f]) for f in ENC_FIELDS} for d in p["enc"]])
+    cnt = p["challenge"].shape[0]
+    soa, keep = presentation_soa(p)
+    status = np.full(cnt, 255, np.uint8)
+    check(lib().afx_verify_presentations(ctx.h, C.byref(shape), C.byref(soa), cnt, status.ctypes.data))
+    return status
+
+
+def points_from_uniform(ctx, wide):
+    wide = _u8(wide)
+    out = np.zeros((wide.shape[0], 32), np.uint8)
+    check(lib().afx_points_from_uniform_bytes(ctx.h, wide.ctypes.data, wide.shape[0], out.ctypes.data))
+    return out
+
+
+def scalars_from_wide(ctx, wide):
+    wide = _u8(wide)
+    out = np.zeros((wide.shape[0], 32), np.uint8)
+    check(lib().afx_scalars_from_wide_bytes(ctx.h, wide.ctypes.data, wide.shape[0], out.ctypes.data))
+    return out
+
+
+def multiscalar_mul(ctx, scalars, points):
+    """out[i] = sum_k scalars[k,i] * points[k,i];  scalars, points: [n_terms, count, 32]"""
+    scalars, points = _u8(scalars), _u8(points)
+    nt, cnt = scalars.shape[0], scalars.shape[1]
+    out = np.zeros((cnt, 32), np.uint8)
+    ok = np.zeros(cnt, np.uint8)
+    check(lib().afx_multiscalar_mul(ctx.h, nt, scalars.ctypes.data, points.ctypes.data, cnt, out.ctypes.data, ok.ctypes.data))
+    return out, ok

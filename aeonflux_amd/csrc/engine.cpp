@@ -128,6 +128,14 @@ int Assembler::run() {
   const int32_t* ft = (const int32_t*)ctx->d_fixed_tables.p;
   for (const Launch& l : launches) {
     const uint8_t* jobs = blob_base_ + l.jobs_off;
+    afx_ctx::TimedLaunch tl = { (int)l.kind, nullptr, nullptr };
+    if (ctx->timing) {
+      for (hipEvent_t* e : { &tl.start, &tl.stop }) {
+        if (ctx->event_pool.empty()) AFX_HIP(hipEventCreate(e));
+        else { *e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+      }
+      AFX_HIP(hipEventRecord(tl.start, s));
+    }
     switch (l.kind) {
       case L_FILL_BAD: AFX_HIP(afxk_fill_u32(s, bad_, fail_all ? AFX_BAD_SHAPE : 0u, count)); break;
       case L_DECODE: AFX_HIP(afxk_decode(s, (const afx_decode_job*)jobs, l.njobs, bad_, count)); break;
@@ -140,6 +148,10 @@ int Assembler::run() {
       case L_REDUCE_WIDE: AFX_HIP(afxk_reduce_wide(s, l.in, l.out, count)); break;
       case L_COPY: AFX_HIP(hipMemcpyAsync(l.out, l.in, l.bytes, hipMemcpyDeviceToDevice, s)); break;
       case L_FINISH: AFX_HIP(afxk_finish(s, bad_, l.out, count, 0, l.fail_code)); break;
+    }
+    if (ctx->timing) {
+      AFX_HIP(hipEventRecord(tl.stop, s));
+      ctx->timed.push_back(tl);
     }
   }
   return AFX_OK;

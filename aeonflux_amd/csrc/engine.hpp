@@ -79,6 +79,13 @@ struct afx_ctx {
   size_t blob_host_cap[2] = { 0, 0 };
   hipEvent_t blob_event[2] = { nullptr, nullptr };
   int blob_next = 0;
+  // optional per-launch HIP-event timing on `stream` (bench.py's roofline figure)
+  bool timing = false;
+  struct TimedLaunch { int kind; hipEvent_t start, stop; };
+  std::vector<TimedLaunch> timed;          // recorded, not yet read back
+  std::vector<hipEvent_t> event_pool;      // recycled events
+  double kind_ms[16] = { 0 };
+  uint64_t kind_launches[16] = { 0 };
 };
 
 namespace afx {

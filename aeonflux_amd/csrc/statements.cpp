@@ -35,6 +35,41 @@ extern "C" const char* afx_last_error(void) { return afx::last_error(); }
 extern "C" uint32_t afx_ctx_n_attributes(const afx_ctx* ctx) { return ctx ? ctx->n : 0; }
 extern "C" void* afx_ctx_stream(const afx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+static const char* const KIND_NAMES[] = { "k_fill_u32", "k_decode", "k_sccheck", "k_pointop", "k_scalarop", "k_msm", "k_hash",
+                                          "k_from_uniform", "k_reduce_wide", "copy", "k_finish" };
+static int drain_timing(afx_ctx* c) {
+  AFX_HIP(hipStreamSynchronize(c->stream));
+  for (auto& t : c->timed) {
+    float ms = 0;
+    AFX_HIP(hipEventElapsedTime(&ms, t.start, t.stop));
+    c->kind_ms[t.kind] += ms;
+    c->kind_launches[t.kind] += 1;
+    c->event_pool.push_back(t.start);
+    c->event_pool.push_back(t.stop);
+  }
+  c->timed.clear();
+  return AFX_OK;
+}
+extern "C" int afx_ctx_set_timing(afx_ctx* c, int enable) {
+  if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  AFX_HIP(hipSetDevice(c->device));
+  int rc = drain_timing(c);
+  if (rc) return rc;
+  for (int k = 0; k < 16; k++) { c->kind_ms[k] = 0; c->kind_launches[k] = 0; }
+  c->timing = enable != 0;
+  return AFX_OK;
+}
+extern "C" int afx_ctx_get_timing(afx_ctx* c, const char* kernel, double* total_ms, uint64_t* launches) {
+  if (!c || !kernel || !total_ms || !launches) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  AFX_HIP(hipSetDevice(c->device));
+  int rc = drain_timing(c);
+  if (rc) return rc;
+  for (size_t k = 0; k < sizeof KIND_NAMES / sizeof KIND_NAMES[0]; k++)
+    if (strcmp(kernel, KIND_NAMES[k]) == 0) { *total_ms = c->kind_ms[k]; *launches = c->kind_launches[k]; return AFX_OK; }
+  set_error("unknown kernel name");
+  return AFX_E_BAD_ARGS;
+}
+
 extern "C" void afx_ctx_destroy(afx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
@@ -52,6 +87,8 @@ extern "C" void afx_ctx_destroy(afx_ctx* c) {
     if (c->blob_host[i]) { memset(c->blob_host[i], 0, c->blob_host_cap[i]); (void)hipHostFree(c->blob_host[i]); }
     if (c->blob_event[i]) (void)hipEventDestroy(c->blob_event[i]);
   }
+  for (auto& t : c->timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   for (auto& k : c->host_key) { volatile uint8_t* p = k.data(); for (int i = 0; i < 32; i++) p[i] = 0; }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

@@ -123,6 +123,13 @@ uint32_t afx_ctx_n_attributes(const afx_ctx* ctx);
 /* The HIP stream (hipStream_t) every call on this ctx launches on; for event timing in bench.py. */
 void* afx_ctx_stream(const afx_ctx* ctx);
 
+/* Per-kernel device timing with HIP events on afx_ctx_stream(ctx) (measurement aid; off by default).
+ * set_timing(ctx, 1) resets the counters and starts recording every launch; get_timing synchronises the
+ * stream and returns the summed duration and launch count of one kernel ("k_msm", "k_hash", "k_decode",
+ * "k_pointop", "k_scalarop", "k_sccheck", "k_finish", "k_from_uniform", "k_reduce_wide", "k_fill_u32"). */
+int afx_ctx_set_timing(afx_ctx* ctx, int enable);
+int afx_ctx_get_timing(afx_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
+
 /* ---- Issuer::verify (src/issuer.rs:141-147 -> src/nizk/presentation.rs:324-443) ------------- */
 
 /* status[i] = AFX_ST_OK iff Issuer::verify(presentation_i).is_ok().  Host pointers. */
