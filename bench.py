@@ -194,7 +194,7 @@ def main():
         olib = oracle.load(native=True)
         olib.afxo_ctx_new.restype = C.c_void_p
         S = min(args.cpu_sample, count)
-        threads = os.cpu_count() or 1
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
         sub = {f: np.ascontiguousarray(pres[f][..., :S, :]) for f in batch.PRES_FIELDS}
         sub["enc"] = [{f: np.ascontiguousarray(d[f][..., :S, :]) for f in batch.ENC_FIELDS} for d in pres["enc"]]
         osoa, keep2 = batch.presentation_soa(sub)

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Per-kernel sums/averages of PMC counters from a rocprofv3 rocpd database (--pmc ... --kernel-trace).
+Usage: tools/rocpd_pmc.py db [kernel_name_filter]"""
+import sqlite3
+import sys
+
+
+def main(path, flt=None):
+    db = sqlite3.connect(path)
+    tables = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
+    kd = next(t for t in tables if "kernel_dispatch" in t)
+    ks = next(t for t in tables if "kernel_symbol" in t)
+    pe = next(t for t in tables if "rocpd_pmc_event" in t)
+    pi = next(t for t in tables if "rocpd_info_pmc" in t)
+    cols = [r[1] for r in db.execute(f"pragma table_info('{pe}')")]
+    icols = [r[1] for r in db.execute(f"pragma table_info('{pi}')")]
+    namecol = "symbol" if "symbol" in icols else "name"
+    q = f"""select s.display_name, i.{namecol}, count(*), sum(p.value), avg(p.value), avg(d.end - d.start)
+            from {pe} p join {pi} i on p.pmc_id = i.id join {kd} d on p.event_id = d.event_id join {ks} s on d.kernel_id = s.id
+            group by s.display_name, i.{namecol} order by s.display_name"""
+    print("# PMC per kernel from %s" % path)
+    print("%-28s %-24s %7s %18s %18s %10s" % ("kernel", "counter", "calls", "sum", "avg/dispatch", "avg_ms"))
+    for r in db.execute(q):
+        name = (r[0] or "?").split("(")[0]
+        if flt and flt not in name:
+            continue
+        print("%-28s %-24s %7d %18.0f %18.1f %10.4f" % (name[:28], r[1], r[2], r[3], r[4], r[5] / 1e6))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
