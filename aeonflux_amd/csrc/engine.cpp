@@ -73,19 +73,51 @@ void Assembler::scalarop(const std::vector<afx_scalarop_job>& jobs) { add_jobs(L
 void Assembler::hash(const std::vector<afx_hash_program>& progs) { add_jobs(L_HASH, progs, 0); }
 void Assembler::msm(std::vector<afx_msm_job> jobs) {
   if (jobs.empty()) return;
-  // longest jobs first: blockIdx.y is the job and low block ids are dispatched first
-  std::stable_sort(jobs.begin(), jobs.end(), [](const afx_msm_job& a, const afx_msm_job& b) {
-    return a.n_var * 8 + (a.n_terms - a.n_var) * 7 > b.n_var * 8 + (b.n_terms - b.n_var) * 7;
-  });
+  auto cost = [](const afx_msm_job& j) { return 240u + j.n_var * 80u + (j.n_terms - j.n_var) * 35u; };
+  const size_t n = jobs.size();
+  // a job named as another's successor (chain_to) is run by that job's lanes, not by grid rows of its own
+  std::vector<int> is_successor(n, 0);
+  for (size_t i = 0; i < n; i++)
+    if (jobs[i].chain_to >= 0) {
+      if ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i) throw std::logic_error("bad msm chain");
+      is_successor[jobs[i].chain_to] = 1;
+    }
+  std::vector<uint32_t> total(n);
+  for (size_t i = 0; i < n; i++) {
+    total[i] = 0;
+    for (int32_t k = (int32_t)i, guard = 0; k >= 0; k = jobs[k].chain_to) {
+      total[i] += cost(jobs[k]);
+      if (++guard > (int)n) throw std::logic_error("msm chain cycle");
+    }
+  }
+  // grid rows: chain heads, longest first (blockIdx.y is the job and low block ids are dispatched first)
+  std::vector<size_t> heads, order;
+  for (size_t i = 0; i < n; i++) if (!is_successor[i]) heads.push_back(i);
+  std::stable_sort(heads.begin(), heads.end(), [&](size_t a, size_t b) { return total[a] > total[b]; });
+  order = heads;
+  for (size_t i = 0; i < n; i++) if (is_successor[i]) order.push_back(i);
+  std::vector<uint32_t> new_index(n);
+  for (size_t k = 0; k < n; k++) new_index[order[k]] = (uint32_t)k;
+  std::vector<afx_msm_job> out(n);
   uint32_t dslot = 0, tslot = 0, max_fixed = 0;
-  for (afx_msm_job& j : jobs) {
+  for (size_t k = 0; k < n; k++) {
+    afx_msm_job j = jobs[order[k]];
+    j.next_job = j.chain_to >= 0 ? new_index[j.chain_to] + 1 : 0;
     j.digit_slot = dslot; dslot += j.n_terms;
     j.table_slot = tslot; tslot += j.n_var;
-    max_fixed = std::max(max_fixed, j.n_terms - j.n_var);
+    if (j.n_terms - j.n_var <= AFX_FIXED_LDS_MAX) max_fixed = std::max(max_fixed, j.n_terms - j.n_var);
+    out[k] = j;
   }
   max_digit_slots = std::max<size_t>(max_digit_slots, dslot);
   max_table_slots = std::max<size_t>(max_table_slots, tslot);
-  add_jobs(L_MSM, jobs, max_fixed);
+  // the launch has one grid row per chain head; successors sit behind them in the same array
+  Launch l;
+  l.kind = L_MSM;
+  l.njobs = (uint32_t)heads.size();
+  l.max_fixed = max_fixed;
+  l.jobs_off = blob_alloc(sizeof(afx_msm_job) * n, 16);
+  memcpy(blob_.data() + l.jobs_off, out.data(), sizeof(afx_msm_job) * n);
+  launches.push_back(l);
 }
 void Assembler::from_uniform(const uint8_t* wide, uint8_t* out_enc, int32_t* out_var) {
   Launch l; l.kind = L_FROM_UNIFORM; l.in = wide; l.out = out_enc; l.out_var = out_var;
@@ -208,6 +240,7 @@ static void order_terms(afx_msm_job& j, const std::vector<afx_msm_term>& terms) 
   if (terms.size() > AFX_MSM_MAX_TERMS) throw std::length_error("too many terms in one multiscalar job");
   j.n_terms = (uint32_t)terms.size();
   j.n_var = 0;
+  j.chain_to = -1;
   uint32_t k = 0;
   for (const afx_msm_term& t : terms) if (t.fixed_idx < 0) { j.term[k++] = t; j.n_var++; }
   for (const afx_msm_term& t : terms) if (t.fixed_idx >= 0) j.term[k++] = t;

@@ -88,6 +88,33 @@ AFX_DEV fe fe_carry64(int64_t h[10]) {
   return r;
 }
 
+// Same chain for column sums H[k] = h[k] + ROUND[k] whose rounding constants (2^25 for even k, 2^24 for odd k)
+// were folded into the accumulators' initial values: the first visit of every limb needs no 64-bit rounding
+// add, and its remainder comes from the low dword alone: h - (c << b) = ((H & (2^b - 1)) - 2^(b-1)).
+AFX_DEV fe fe_carry64_prerounded(int64_t H[10]) {
+  int64_t c;
+  int32_t r[10];
+  c = H[0] >> 26; H[1] += c; r[0] = (int32_t)((uint32_t)H[0] & 0x3ffffffu) - (1 << 25);
+  c = H[4] >> 26; H[5] += c; r[4] = (int32_t)((uint32_t)H[4] & 0x3ffffffu) - (1 << 25);
+  c = H[1] >> 25; H[2] += c; r[1] = (int32_t)((uint32_t)H[1] & 0x1ffffffu) - (1 << 24);
+  c = H[5] >> 25; H[6] += c; r[5] = (int32_t)((uint32_t)H[5] & 0x1ffffffu) - (1 << 24);
+  c = H[2] >> 26; H[3] += c; r[2] = (int32_t)((uint32_t)H[2] & 0x3ffffffu) - (1 << 25);
+  c = H[6] >> 26; H[7] += c; r[6] = (int32_t)((uint32_t)H[6] & 0x3ffffffu) - (1 << 25);
+  c = H[3] >> 25; r[3] = (int32_t)((uint32_t)H[3] & 0x1ffffffu) - (1 << 24);
+  int64_t h4 = (int64_t)r[4] + c;                                   // second visit of limb 4: plain value
+  c = H[7] >> 25; H[8] += c; r[7] = (int32_t)((uint32_t)H[7] & 0x1ffffffu) - (1 << 24);
+  c = (h4 + (1LL << 25)) >> 26; H[5] = (int64_t)r[5] + c; r[4] = (int32_t)(h4 - (c << 26));
+  c = H[8] >> 26; H[9] += c; r[8] = (int32_t)((uint32_t)H[8] & 0x3ffffffu) - (1 << 25);
+  c = H[9] >> 25; r[9] = (int32_t)((uint32_t)H[9] & 0x1ffffffu) - (1 << 24);
+  int64_t h0 = (int64_t)r[0] + c * 19;                              // second visit of limb 0
+  c = (h0 + (1LL << 25)) >> 26; r[0] = (int32_t)(h0 - (c << 26));
+  int64_t h1 = (int64_t)r[1] + c;
+  fe o;
+  o.v[0] = r[0]; o.v[1] = (int32_t)h1; o.v[2] = r[2]; o.v[3] = r[3]; o.v[4] = r[4];
+  o.v[5] = (int32_t)H[5]; o.v[6] = r[6]; o.v[7] = r[7]; o.v[8] = r[8]; o.v[9] = r[9];
+  return o;
+}
+
 // re-normalise a lazily added value (any limbs that fit int32)
 AFX_DEV fe fe_carry(const fe& f) {
   int64_t h[10];
@@ -105,7 +132,7 @@ AFX_DEV fe fe_mul(const fe& f, const fe& g) {
   }
   int64_t h[10];
 #pragma unroll
-  for (int k = 0; k < 10; k++) h[k] = 0;
+  for (int k = 0; k < 10; k++) h[k] = (k & 1) ? (1LL << 24) : (1LL << 25);
 #pragma unroll
   for (int i = 0; i < 10; i++) {
 #pragma unroll
@@ -116,7 +143,7 @@ AFX_DEV fe fe_mul(const fe& f, const fe& g) {
       h[k % 10] += (int64_t)a * (int64_t)b;
     }
   }
-  return fe_carry64(h);
+  return fe_carry64_prerounded(h);
 }
 
 AFX_DEV fe fe_sq(const fe& f) {
@@ -129,7 +156,7 @@ AFX_DEV fe fe_sq(const fe& f) {
   }
   int64_t h[10];
 #pragma unroll
-  for (int k = 0; k < 10; k++) h[k] = 0;
+  for (int k = 0; k < 10; k++) h[k] = (k & 1) ? (1LL << 24) : (1LL << 25);
 #pragma unroll
   for (int i = 0; i < 10; i++) {
 #pragma unroll
@@ -141,7 +168,7 @@ AFX_DEV fe fe_sq(const fe& f) {
       h[k % 10] += (int64_t)a * (int64_t)b;
     }
   }
-  return fe_carry64(h);
+  return fe_carry64_prerounded(h);
 }
 
 // f^(2^n), n >= 1, rolled loop (keeps the inversion chains small in code size)

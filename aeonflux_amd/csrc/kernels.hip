@@ -117,7 +117,7 @@ __global__ void k_setup_generators(const uint8_t* __restrict__ enc, uint32_t nge
   ge_p3 Q = ge_identity();
   const ge_cached cP = ge_p3_to_cached(P);
 #pragma unroll 1
-  for (int k = 0; k < AFX_TABLE_ENTRIES; k++) {
+  for (int k = 0; k < AFX_FIXED_ENTRIES; k++) {
     const fe zinv = fe_invert(Q.Z);
     const fe x = fe_mul(Q.X, zinv), y = fe_mul(Q.Y, zinv);
     const fe ypx = fe_carry(fe_add(y, x)), ymx = fe_carry(fe_sub(y, x)), xy2d = fe_mul(fe_mul(x, y), d2);
@@ -130,7 +130,7 @@ __global__ void k_setup_generators(const uint8_t* __restrict__ enc, uint32_t nge
 // ---------------------------------------------------------------------------------------------
 // decode / scalar checks / small point and scalar ops
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(AFX_BLOCK) k_decode(const afx_decode_job* __restrict__ jobs, uint32_t* __restrict__ bad, uint32_t count) {
+__global__ void __launch_bounds__(AFX_BLOCK, 2) k_decode(const afx_decode_job* __restrict__ jobs, uint32_t* __restrict__ bad, uint32_t count) {
   const afx_decode_job job = jobs[blockIdx.y];
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
   if (item >= count) return;
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_sccheck(const afx_sccheck_job* __
   if (!sc_is_canonical(s)) atomicOr(&bad[item], AFX_BAD_SCALAR);
 }
 
-__global__ void __launch_bounds__(AFX_BLOCK) k_pointop(const afx_pointop_job* __restrict__ jobs, uint32_t* __restrict__ bad, uint32_t count) {
+__global__ void __launch_bounds__(AFX_BLOCK, 2) k_pointop(const afx_pointop_job* __restrict__ jobs, uint32_t* __restrict__ bad, uint32_t count) {
   const afx_pointop_job job = jobs[blockIdx.y];
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
   if (item >= count) return;
@@ -193,34 +193,53 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_scalarop(const afx_scalarop_job* 
 // ---------------------------------------------------------------------------------------------
 // k_msm: one small multiscalar multiplication per lane
 // ---------------------------------------------------------------------------------------------
-// Straus with a shared doubling chain and signed radix-16 digits in [-8,7] (s + 0x88..88 recoding, so every
-// lane adds at every window: no divergence; a zero digit adds table entry 0 = identity).
-//   fixed bases   : 9-entry affine-niels tables, staged in LDS per workgroup (1080 B per base)
-//   variable bases: 9-entry cached tables built per lane into HBM workspace (1440 B per base per item),
-//                   gathered back as 10 x 16-byte loads per addition
-// Field multiplications per window: 4 doublings (4 x 4S + 3 x 3M + 4M) + per variable term 8M, per fixed term 7M.
+// Straus with a shared doubling chain.  Scalars are recoded without carries (s + 0x88..88 for 4-bit signed
+// digits in [-8,7], s + 0x80..80 for 8-bit signed digits in [-128,127]), so every lane adds at every window:
+// no divergence; a zero digit adds table entry 0 = the identity.
+//   variable bases: 4-bit windows, 9-entry cached tables built per lane into HBM workspace (1440 B per base per
+//                   item), gathered back as 10 x 16-byte loads per addition
+//   fixed bases   : 8-bit windows (an addition every second 4-bit window), 129-entry affine-niels tables built at
+//                   context creation; staged in LDS when the job has <= 4 of them (15.1 KB each), else read from L2
+// Field work per 4-bit window: 4 doublings (4 x 4S + 3 x 3M + 4M), 8M per variable term, 7M per fixed term (every
+// other window); the last addition of a window skips the T coordinate (-1M).
+AFX_DEV ge_p3 msm_finish_add(const ge_p1p1& r, bool want_t) {
+  ge_p3 o;
+  o.X = fe_mul(r.T, r.X); o.Y = fe_mul(r.Y, r.Z); o.Z = fe_mul(r.T, r.Z);
+  if (want_t) o.T = fe_mul(r.X, r.Y);
+  else o.T = o.X;   // unused by the doublings that follow
+  return o;
+}
+
 __global__ void __launch_bounds__(AFX_BLOCK, 2)
 k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_tables, int32_t* __restrict__ table_ws,
       uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count) {
   extern __shared__ int32_t lds_tab[];
-  const afx_msm_job* job = &jobs[blockIdx.y];
-  const uint32_t nt = job->n_terms, nv = job->n_var;
   const uint32_t tid = threadIdx.x;
-  for (uint32_t t = nv; t < nt; t++) {
-    const int32_t* src = fixed_tables + (size_t)job->term[t].fixed_idx * AFX_FIXED_TABLE_DWORDS;
-    for (uint32_t i = tid; i < AFX_FIXED_TABLE_DWORDS; i += AFX_BLOCK) lds_tab[(t - nv) * AFX_FIXED_TABLE_DWORDS + i] = src[i];
+  // lanes past the end of the batch shadow the last item (identical values, identical stores): every lane of the
+  // block reaches every barrier
+  const uint32_t item = min(blockIdx.x * AFX_BLOCK + tid, count - 1);
+  const afx_msm_job* job = &jobs[blockIdx.y];
+#pragma unroll 1
+  for (;;) {
+  const uint32_t nt = job->n_terms, nv = job->n_var, nf = nt - nv;
+  const bool in_lds = nf <= AFX_FIXED_LDS_MAX;
+  __syncthreads();   // the previous job of this chain is done with the LDS tables
+  if (in_lds) {
+    for (uint32_t t = nv; t < nt; t++) {
+      const int4* src = reinterpret_cast<const int4*>(fixed_tables + (size_t)job->term[t].fixed_idx * AFX_FIXED_TABLE_DWORDS);
+      int4* dst = reinterpret_cast<int4*>(lds_tab + (t - nv) * AFX_FIXED_TABLE_DWORDS);
+      for (uint32_t i = tid; i < AFX_FIXED_TABLE_DWORDS / 4; i += AFX_BLOCK) dst[i] = src[i];
+    }
   }
   __syncthreads();
-  const uint32_t item = blockIdx.x * AFX_BLOCK + tid;
-  if (item >= count) return;
 
-  // recode scalars: s' = s + 0x88..88, stored [slot][8][count]
+  // recode scalars, stored [slot][8][count]
   const uint32_t dslot = job->digit_slot;
 #pragma unroll 1
   for (uint32_t t = 0; t < nt; t++) {
     const sc s = sc_load_item(job->term[t].scalar, job->term[t].scalar_stride, item);
     uint32_t b[8];
-    sc_bias_radix16(b, s);
+    sc_bias(b, s, t < nv ? 0x88888888u : 0x80808080u);
 #pragma unroll
     for (int i = 0; i < 8; i++) digit_ws[((size_t)(dslot + t) * 8 + i) * count + item] = b[i];
   }
@@ -244,28 +263,48 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_ta
   ge_p3 acc = ge_identity();
 #pragma unroll 1
   for (int w = 63; w >= 0; w--) {
+    const bool fixed_now = ((w & 1) == 0) && nf != 0;
+    const uint32_t nadd = nv + (fixed_now ? nf : 0);
     if (w != 63) {
       ge_p2 a2 = ge_p3_to_p2(acc);
 #pragma unroll 1
       for (int k = 0; k < 3; k++) a2 = ge_p1p1_to_p2(ge_p2_dbl(a2));
-      acc = ge_p1p1_to_p3(ge_p2_dbl(a2));
+      acc = msm_finish_add(ge_p2_dbl(a2), nadd != 0);
     }
-    const uint32_t wi = (uint32_t)w >> 3, sh = ((uint32_t)w & 7) * 4;
+    const uint32_t wi = (uint32_t)w >> 3;
+    uint32_t done = 0;
 #pragma unroll 1
-    for (uint32_t t = 0; t < nt; t++) {
+    for (uint32_t t = 0; t < nv; t++) {
       const uint32_t word = digit_ws[((size_t)(dslot + t) * 8 + wi) * count + item];
-      const int d = (int)((word >> sh) & 15u) - 8;
+      const int d = (int)((word >> (((uint32_t)w & 7) * 4)) & 15u) - 8;
       const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
       const bool neg = (d < 0) != (job->term[t].negate != 0);
-      if (t < nv) {
-        const int32_t* tab = table_ws + ((size_t)(tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
-        acc = ge_p1p1_to_p3(ge_add_cached(acc, cached_load(tab + idx * AFX_VAR_DWORDS), neg));
-      } else {
-        const int32_t* e = lds_tab + (t - nv) * AFX_FIXED_TABLE_DWORDS + idx * AFX_NIELS_DWORDS;
+      const int32_t* tab = table_ws + ((size_t)(tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
+      done++;
+      acc = msm_finish_add(ge_add_cached(acc, cached_load(tab + idx * AFX_VAR_DWORDS), neg), done != nadd || w == 0);
+    }
+    if (fixed_now) {
+#pragma unroll 1
+      for (uint32_t t = nv; t < nt; t++) {
+        const uint32_t word = digit_ws[((size_t)(dslot + t) * 8 + wi) * count + item];
+        const int d = (int)((word >> (((uint32_t)w & 6) * 4)) & 255u) - 128;
+        const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
+        const bool neg = (d < 0) != (job->term[t].negate != 0);
         ge_niels q;
+        if (in_lds) {
+          const int32_t* e = lds_tab + (t - nv) * AFX_FIXED_TABLE_DWORDS + idx * AFX_NIELS_DWORDS;
 #pragma unroll
-        for (int l = 0; l < 10; l++) { q.ypx.v[l] = e[l]; q.ymx.v[l] = e[10 + l]; q.xy2d.v[l] = e[20 + l]; }
-        acc = ge_p1p1_to_p3(ge_madd(acc, q, neg));
+          for (int l = 0; l < 10; l++) { q.ypx.v[l] = e[l]; q.ymx.v[l] = e[10 + l]; q.xy2d.v[l] = e[20 + l]; }
+        } else {
+          const int2* e = reinterpret_cast<const int2*>(fixed_tables + (size_t)job->term[t].fixed_idx * AFX_FIXED_TABLE_DWORDS + idx * AFX_NIELS_DWORDS);
+          int32_t v[30];
+#pragma unroll
+          for (int l = 0; l < 15; l++) { const int2 x = e[l]; v[2 * l] = x.x; v[2 * l + 1] = x.y; }
+#pragma unroll
+          for (int l = 0; l < 10; l++) { q.ypx.v[l] = v[l]; q.ymx.v[l] = v[10 + l]; q.xy2d.v[l] = v[20 + l]; }
+        }
+        done++;
+        acc = msm_finish_add(ge_madd(acc, q, neg), done != nadd || w == 0);
       }
     }
   }
@@ -279,6 +318,9 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_ta
     ristretto_encode(wenc, acc);
     enc_store(job->out_enc, item, wenc);
     if (job->reject_identity && is_identity_encoding(wenc)) atomicOr(&bad[item], AFX_BAD_IDENTITY);
+  }
+  if (job->next_job == 0) break;
+  job = &jobs[job->next_job - 1];
   }
 }
 
@@ -356,7 +398,7 @@ __global__ void k_fill_u32(uint32_t* p, uint32_t v, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
-__global__ void __launch_bounds__(AFX_BLOCK) k_from_uniform(const uint8_t* __restrict__ wide, uint8_t* __restrict__ out_enc, int32_t* out_var, uint32_t count) {
+__global__ void __launch_bounds__(AFX_BLOCK, 2) k_from_uniform(const uint8_t* __restrict__ wide, uint8_t* __restrict__ out_enc, int32_t* out_var, uint32_t count) {
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
   if (item >= count) return;
   uint32_t w[16];
@@ -383,7 +425,7 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_reduce_wide(const uint8_t* __rest
   enc_store(out, item, o);
 }
 // decode -> ok flag -> re-encode (round-trip parity test of decode+encode)
-__global__ void __launch_bounds__(AFX_BLOCK) k_validate(const uint8_t* __restrict__ enc, uint8_t* __restrict__ ok, uint8_t* __restrict__ reenc, uint32_t count) {
+__global__ void __launch_bounds__(AFX_BLOCK, 2) k_validate(const uint8_t* __restrict__ enc, uint8_t* __restrict__ ok, uint8_t* __restrict__ reenc, uint32_t count) {
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
   if (item >= count) return;
   uint32_t w[8];
@@ -426,6 +468,7 @@ hipError_t afxk_scalarop(hipStream_t s, const afx_scalarop_job* jobs, uint32_t n
 }
 hipError_t afxk_msm(hipStream_t s, const afx_msm_job* jobs, uint32_t njobs, uint32_t max_fixed, const int32_t* fixed_tables,
                     int32_t* table_ws, uint32_t* digit_ws, uint32_t* bad, uint32_t count) {
+  // max_fixed = the largest fixed-term count among the jobs that stage their tables in LDS (<= AFX_FIXED_LDS_MAX)
   const size_t lds = (size_t)max_fixed * AFX_FIXED_TABLE_DWORDS * sizeof(int32_t);
   hipLaunchKernelGGL(k_msm, grid_for(count, njobs), dim3(AFX_BLOCK), lds, s, jobs, fixed_tables, table_ws, digit_ws, bad, count);
   return hipGetLastError();

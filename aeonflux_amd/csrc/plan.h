@@ -7,10 +7,12 @@
 #include <stdint.h>
 
 #define AFX_MSM_MAX_TERMS 72   /* Z job: 2 + n + #public scalars <= 2 + 2n; issuance: n + 4 */
-#define AFX_TABLE_ENTRIES 9            /* 0*P (identity) .. 8*P */
+#define AFX_TABLE_ENTRIES 9            /* variable bases: 0*P (identity) .. 8*P, signed 4-bit windows */
+#define AFX_FIXED_ENTRIES 129         /* fixed bases: 0*G .. 128*G, signed 8-bit windows          */
+#define AFX_FIXED_LDS_MAX 4           /* a job stages its fixed tables in LDS when it has at most this many */
 #define AFX_VAR_DWORDS 40              /* extended point: X,Y,Z,T x 10 limbs */
 #define AFX_NIELS_DWORDS 30            /* affine niels: y+x, y-x, 2dxy */
-#define AFX_FIXED_TABLE_DWORDS (AFX_TABLE_ENTRIES * AFX_NIELS_DWORDS)
+#define AFX_FIXED_TABLE_DWORDS 3872    /* AFX_FIXED_ENTRIES * AFX_NIELS_DWORDS = 3870, padded to a 16-byte multiple */
 #define AFX_VAR_TABLE_DWORDS (AFX_TABLE_ENTRIES * AFX_VAR_DWORDS)
 #define AFX_BLOCK 256
 
@@ -71,6 +73,9 @@ typedef struct {
   uint8_t* out_enc;                     /* [count][32] compressed result, may be null             */
   afx_var_t out_var;                    /* extended result, may be null                           */
   uint32_t reject_identity;
+  uint32_t next_job;                    /* 1 + index of a job the same lane runs right after this one (it may
+                                           consume this job's out_var); 0 = none.  Successors are not grid rows */
+  int32_t chain_to;                     /* host only: index (in the vector handed to Assembler::msm) of the successor, -1 none */
   uint32_t digit_slot;                  /* first recoded-scalar slot of this job in digit_ws (one per term)   */
   uint32_t table_slot;                  /* first window-table slot of this job in table_ws (one per var term) */
 } afx_msm_job;

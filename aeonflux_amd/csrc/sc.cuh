@@ -161,13 +161,14 @@ AFX_DEV void sc_store(uint8_t* p, const sc& a) {
 #pragma unroll
   for (int i = 0; i < 8; i++) q[i] = a.v[i];
 }
-// Signed radix-16 recoding without carries: with s' = s + 0x88..88, digit_i = nibble_i(s') - 8 in [-8, 7]
-// and sum digit_i 16^i = s.  Needs s < 2^255 (any canonical scalar).
-AFX_DEV void sc_bias_radix16(uint32_t out[8], const sc& s) {
+// Signed fixed-window recoding without carries: with s' = s + 0x88..88, digit_i = nibble_i(s') - 8 in [-8, 7]
+// and sum digit_i 16^i = s; with s' = s + 0x80..80, digit_i = byte_i(s') - 128 in [-128, 127] and
+// sum digit_i 256^i = s.  Needs s < 2^255 (any canonical scalar).
+AFX_DEV void sc_bias(uint32_t out[8], const sc& s, uint32_t bias) {
   uint64_t c = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    c += (uint64_t)s.v[i] + 0x88888888u;
+    c += (uint64_t)s.v[i] + bias;
     out[i] = (uint32_t)c;
     c >>= 32;
   }

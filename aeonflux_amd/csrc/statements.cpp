@@ -311,6 +311,7 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
   zj.out_var = v_Z;
   zj.out_enc = e_Z;
   zj.reject_identity = 1;
+  const size_t z_index = js.msm1.size();
   js.msm1.push_back(zj);
 
   auto resp = [&](uint32_t r) { ScalarVar s; s.dev = row(b.responses, r); s.stride = 32; return s; };
@@ -337,7 +338,10 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
     if (sh.kinds[j] == AFX_ENC_SECRET_SCALAR) v.constrain(C_y[j], { { z, G_y[j] }, { H_s[hidden_slot[j]], G_m[hidden_slot[j]] } });
     else v.constrain(C_y[j], { { z, G_y[j] } });
   }
-  v.verify_compact(row(b.challenge, 0), js.msm2, js.hash);
+  // one launch for everything: the lane that finishes Z goes straight on to constraint #1 (Z = z*I), the only job that needs it
+  const size_t first_constraint = js.msm1.size();
+  v.verify_compact(row(b.challenge, 0), js.msm1, js.hash);
+  js.msm1[z_index].chain_to = (int32_t)first_constraint;
   // proofs of encryption: verified independently, whatever their number (:438-440)
   for (uint32_t e = 0; e < sh.n_enc_proofs && !as.fail_all; e++) add_encproof_verify(as, js, sh.enc_indices[e], b.enc[e], total, off);
   emit(as, js, status_dev, AFX_ST_VERIFICATION_FAILURE);

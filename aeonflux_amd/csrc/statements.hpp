@@ -62,6 +62,7 @@ inline void set_terms(afx_msm_job& j, const std::vector<afx_msm_term>& terms) {
   if (terms.size() > AFX_MSM_MAX_TERMS) throw std::length_error("too many terms in one multiscalar job");
   j.n_terms = (uint32_t)terms.size();
   j.n_var = 0;
+  j.chain_to = -1;
   uint32_t k = 0;
   for (const afx_msm_term& t : terms) if (t.fixed_idx < 0) { j.term[k++] = t; j.n_var++; }
   for (const afx_msm_term& t : terms) if (t.fixed_idx >= 0) j.term[k++] = t;
