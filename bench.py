@@ -37,6 +37,24 @@ def algorithmic_bytes(shape):
     return 32 * (4 + hs) + 96 + 32 * n + 32 * pub + 448 * hp + (n + 2 * hs + 4 * hp) + 1
 
 
+def usable_cores():
+    """host cores this process may actually use: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def load_fixture(name):
     with open(os.path.join(ROOT, "tests", "golden", "flows.json")) as f:
         flows = json.load(f)["flows"]
@@ -103,12 +121,105 @@ def corrupt(pres, count, seed):
     return want
 
 
+def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
+    """secondary metric: credentials issued / s, C5 = 2^20 issuances, 16 attributes S x8 P x4 E x4"""
+    n, layout, count = 16, "SSSSSSSSPPPPEEEE", (args.batch or (1 << 20))
+    params, key, ip = load_fixture("c5_16attrs")
+    issuer = afx.Context(params, key, ip, device=local_rank)
+    rng = np.random.default_rng(4242 + rank)
+    rb = lambda *shape: rng.integers(0, 256, size=shape, dtype=np.uint8)
+    dev = torch.device("cuda", local_rank)
+    values = np.zeros((n, count, 32), np.uint8)
+    kinds = []
+    for i, c in enumerate(layout):
+        kinds.append({"S": afx.ATTR_PUBLIC_SCALAR, "P": afx.ATTR_PUBLIC_POINT, "E": afx.ATTR_EITHER_POINT}[c])
+        for o in range(0, count, 1 << 18):
+            w = rb(min(1 << 18, count - o), 64)
+            values[i, o:o + w.shape[0]] = batch.scalars_from_wide(issuer, w) if c == "S" else batch.points_from_uniform(issuer, w)
+    d_in = {k: torch.from_numpy(v).to(dev) for k, v in dict(values=values, t_wide=rb(count, 64), U_wide=rb(count, 64), seed=rb(count, 32)).items()}
+    d_out = {k: torch.zeros((count, 32), dtype=torch.uint8, device=dev) for k in ("t", "U", "V", "challenge")}
+    d_out["responses"] = torch.zeros((n + 5, count, 32), dtype=torch.uint8, device=dev)
+    status = torch.full((count,), 255, dtype=torch.uint8, device=dev)
+    req = afx.AttributesSoA()
+    req.n_attributes = n
+    for i, k in enumerate(kinds):
+        req.kinds[i] = k
+    req.values = d_in["values"].data_ptr()
+    rnd = afx.IssueRandomness(d_in["t_wide"].data_ptr(), d_in["U_wide"].data_ptr(), d_in["seed"].data_ptr())
+    out = afx.IssuanceSoA(*(d_out[k].data_ptr() for k in ("t", "U", "V", "challenge", "responses")))
+    fn = afx.lib().afx_issue_dev
+
+    def step():
+        afx.check(fn(issuer.h, C.byref(req), C.byref(rnd), count, C.byref(out), status.data_ptr()))
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    assert not status.cpu().numpy().any(), "issue failed"
+    # parity spot check of the first 64 credentials against the CPU oracle (checker only)
+    if rank == 0 and not args.no_cpu_baseline:
+        import oracle
+        octx = oracle.Ctx(params, key, ip)
+        h = {k: v[..., :64, :].cpu().numpy() for k, v in d_out.items()}
+        hin = {k: v[..., :64, :].cpu().numpy() for k, v in d_in.items()}
+        for i in range(64):
+            vals = [bytes(hin["values"][k, i]) + bytes(64) for k in range(n)]
+            st, t, U, V, ch, resp = octx.issue(kinds, vals, bytes(hin["t_wide"][i]), bytes(hin["U_wide"][i]), bytes(hin["seed"][i]))
+            assert st == 0 and t == bytes(h["t"][i]) and U == bytes(h["U"][i]) and V == bytes(h["V"][i]) and ch == bytes(h["challenge"][i])
+            assert all(resp[k] == bytes(h["responses"][k, i]) for k in range(n + 5)), "GPU issuance differs from the oracle"
+    issuer.set_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    msm_ms, msm_launches = issuer.get_timing("k_msm")
+    hash_ms, _ = issuer.get_timing("k_hash")
+    issuer.set_timing(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        S = 256
+        hin = {k: v[..., :S, :].cpu().numpy() for k, v in d_in.items()}
+        t0 = time.perf_counter()
+        for i in range(S):
+            vals = [bytes(hin["values"][k, i]) + bytes(64) for k in range(n)]
+            octx.issue(kinds, vals, bytes(hin["t_wide"][i]), bytes(hin["U_wide"][i]), bytes(hin["seed"][i]))
+        cpu = {"value": S / (time.perf_counter() - t0), "unit": "credentials/s", "cores": 1, "kind": "port",
+               "sample": "first %d issuances of the same batch through the oracle (one thread, called from python)" % S}
+    if rank == 0:
+        ab = 32 * n + n + 160 + 96 + 32 * (n + 6)
+        per_step = msm_ms / 1e3 / args.steps
+        achieved = ab * count / per_step / 1e9 if per_step > 0 else 0.0
+        print(json.dumps({
+            "metric": "credentials issued/sec (secondary; aMAC tag + issuance NIZK)", "value": count * world * args.steps / elapsed,
+            "unit": "credentials/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic (random attribute values)",
+            "config": {"workload": "C5: batch issue 2^20 credentials, 16 attributes (S x8, P x4, E x4)", "credentials_per_gpu": count,
+                       "algorithmic_bytes_per_credential": ab, "parallelism": "host-sharded x%d, no collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": "k_msm", "launches_per_step": msm_launches / args.steps, "avg_launch_ms": msm_ms / max(1, msm_launches),
+                         "kernel_ms_per_step": msm_ms / args.steps, "other_kernels_ms_per_step": {"k_hash": hash_ms / args.steps}},
+            "cpu_baseline": cpu}))
+    issuer.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["c5"])
     ap.add_argument("--batch", type=int, default=0, help="presentations per GPU (default: the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -128,6 +239,8 @@ def main():
     import aeonflux_amd as afx
     from aeonflux_amd import batch
 
+    if args.workload == "c5":
+        return bench_issue(args, afx, batch, torch, dist, rank, world, local_rank)
     n, layout, hide, count, fixture, desc = WORKLOADS[args.workload]
     if args.batch:
         count = args.batch
@@ -194,7 +307,7 @@ def main():
         olib = oracle.load(native=True)
         olib.afxo_ctx_new.restype = C.c_void_p
         S = min(args.cpu_sample, count)
-        threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        threads = usable_cores()
         sub = {f: np.ascontiguousarray(pres[f][..., :S, :]) for f in batch.PRES_FIELDS}
         sub["enc"] = [{f: np.ascontiguousarray(d[f][..., :S, :]) for f in batch.ENC_FIELDS} for d in pres["enc"]]
         osoa, keep2 = batch.presentation_soa(sub)
@@ -206,10 +319,16 @@ def main():
         olib.afxo_verify_presentations_soa(octx, C.byref(oshape), C.byref(osoa), S, ost.ctypes.data, threads)
         cpu_s = time.perf_counter() - t0
         assert np.array_equal(ost, got[:S]), "GPU and CPU-oracle statuses differ on the sample"
-        S1 = min(S, 512)
+        S1 = min(S, 256)   # single-thread figure on its own contiguous sub-batch (rows are count-strided)
+        sub1 = {f: np.ascontiguousarray(pres[f][..., :S1, :]) for f in batch.PRES_FIELDS}
+        sub1["enc"] = [{f: np.ascontiguousarray(d[f][..., :S1, :]) for f in batch.ENC_FIELDS} for d in pres["enc"]]
+        osoa1, keep3 = batch.presentation_soa(sub1)
+        osoa1 = oracle.PresentationSoA.from_buffer_copy(bytes(osoa1))
+        ost1 = np.full(S1, 255, np.uint8)
         t0 = time.perf_counter()
-        olib.afxo_verify_presentations_soa(octx, C.byref(oshape), C.byref(osoa), S1, ost.ctypes.data, 1)
+        olib.afxo_verify_presentations_soa(octx, C.byref(oshape), C.byref(osoa1), S1, ost1.ctypes.data, 1)
         cpu1_s = time.perf_counter() - t0
+        assert np.array_equal(ost1, got[:S1])
         cpu = {"value": S / cpu_s, "unit": "presentations/s", "cores": threads, "kind": "port",
                "sample": "first %d presentations of the same batch, oracle/ restated CPU path (gcc -O3 -march=native, 5x51 limbs, "
                          "NAF-5 Straus), %d threads; statuses equal to the GPU's" % (S, threads),
