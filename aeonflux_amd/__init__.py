@@ -111,6 +111,12 @@ def lib():
             if hasattr(_LIB, name):
                 getattr(_LIB, name).argtypes = [C.c_void_p, C.POINTER(CredentialsSoA), C.POINTER(KeypairsSoA), C.POINTER(ShowRandomness),
                                                 C.c_size_t, C.POINTER(PresentationOut), C.POINTER(Shape), C.c_void_p]
+        _LIB.afx_wire_header_bytes.restype = C.c_size_t
+        _LIB.afx_wire_header_bytes.argtypes = [C.POINTER(Shape)]
+        _LIB.afx_wire_cells_per_record.restype = C.c_uint32
+        _LIB.afx_wire_cells_per_record.argtypes = [C.POINTER(Shape)]
+        _LIB.afx_wire_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Shape), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        _LIB.afx_verify_presentations_wire.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _LIB.afx_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_get_timing.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         if hasattr(_LIB, "afx_issuer_keygen"):

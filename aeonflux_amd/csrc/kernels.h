@@ -16,3 +16,4 @@ hipError_t afxk_fill_u32(hipStream_t s, uint32_t* p, uint32_t v, uint32_t n);
 hipError_t afxk_from_uniform(hipStream_t s, const uint8_t* wide, uint8_t* out_enc, int32_t* out_var, uint32_t count);
 hipError_t afxk_reduce_wide(hipStream_t s, const uint8_t* wide, uint8_t* out, uint32_t count);
 hipError_t afxk_validate(hipStream_t s, const uint8_t* enc, uint8_t* ok, uint8_t* reenc, uint32_t count);
+hipError_t afxk_aos_to_soa(hipStream_t s, const uint8_t* rec, uint8_t* soa, const uint32_t* row_of_cell, uint32_t cells, uint32_t count);

@@ -440,6 +440,20 @@ __global__ void __launch_bounds__(AFX_BLOCK, 2) k_validate(const uint8_t* __rest
   }
 }
 
+// wire records (array of structs, `cells` 32-byte cells per item) -> struct-of-arrays rows [row][count][32];
+// row_of_cell maps a record cell to its SoA row (revealed attribute values land on their attribute position)
+__global__ void __launch_bounds__(AFX_BLOCK) k_aos_to_soa(const uint8_t* __restrict__ rec, uint8_t* __restrict__ soa,
+                                                          const uint32_t* __restrict__ row_of_cell, uint32_t cells, uint32_t count) {
+  const uint64_t t = (uint64_t)blockIdx.x * AFX_BLOCK + threadIdx.x;   // t = cell * count + item: writes are coalesced
+  if (t >= (uint64_t)cells * count) return;
+  const uint32_t cell = (uint32_t)(t / count), item = (uint32_t)(t % count);
+  const uint4* src = reinterpret_cast<const uint4*>(rec + ((uint64_t)item * cells + cell) * 32);
+  uint4* dst = reinterpret_cast<uint4*>(soa + ((uint64_t)row_of_cell[cell] * count + item) * 32);
+  const uint4 a = src[0], b = src[1];
+  dst[0] = a;
+  dst[1] = b;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-callable launch wrappers (engine.cpp is plain C++ and never sees a kernel symbol)
 // ---------------------------------------------------------------------------------------------
@@ -495,5 +509,10 @@ hipError_t afxk_reduce_wide(hipStream_t s, const uint8_t* wide, uint8_t* out, ui
 }
 hipError_t afxk_validate(hipStream_t s, const uint8_t* enc, uint8_t* ok, uint8_t* reenc, uint32_t count) {
   hipLaunchKernelGGL(k_validate, dim3((count + AFX_BLOCK - 1) / AFX_BLOCK), dim3(AFX_BLOCK), 0, s, enc, ok, reenc, count);
+  return hipGetLastError();
+}
+hipError_t afxk_aos_to_soa(hipStream_t s, const uint8_t* rec, uint8_t* soa, const uint32_t* row_of_cell, uint32_t cells, uint32_t count) {
+  const uint64_t n = (uint64_t)cells * count;
+  hipLaunchKernelGGL(k_aos_to_soa, dim3((uint32_t)((n + AFX_BLOCK - 1) / AFX_BLOCK)), dim3(AFX_BLOCK), 0, s, rec, soa, row_of_cell, cells, count);
   return hipGetLastError();
 }

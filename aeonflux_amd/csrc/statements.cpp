@@ -509,3 +509,95 @@ extern "C" int afx_multiscalar_mul(afx_ctx* ctx, uint32_t n_terms, const uint8_t
   for (size_t i = 0; i < count; i++) ok[i] = bad[i] ? 0 : 1;
   return AFX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// wire format: header parsing on the host, AoS -> SoA transposition on the GPU
+// ------------------------------------------------------------------------------------------------
+static bool wire_shape_ok(const afx_shape& sh) {
+  if (sh.n_attributes > AFX_MAX_ATTRIBUTES || sh.n_responses > 3 + AFX_MAX_ATTRIBUTES || sh.n_hidden_scalars > AFX_MAX_ATTRIBUTES ||
+      sh.n_enc_proofs > AFX_MAX_ATTRIBUTES)
+    return false;
+  for (uint32_t i = 0; i < sh.n_attributes; i++)
+    if (sh.kinds[i] > AFX_ENC_SECRET_POINT) return false;
+  return true;
+}
+extern "C" uint32_t afx_wire_cells_per_record(const afx_shape* sh) {
+  if (!sh || !wire_shape_ok(*sh)) return 0;
+  uint32_t pub = 0;
+  for (uint32_t i = 0; i < sh->n_attributes; i++) pub += (sh->kinds[i] == AFX_ENC_PUBLIC_SCALAR || sh->kinds[i] == AFX_ENC_PUBLIC_POINT);
+  return 1 + sh->n_responses + 3 + sh->n_attributes + pub + 14 * sh->n_enc_proofs;
+}
+extern "C" size_t afx_wire_header_bytes(const afx_shape* sh) {
+  if (!sh || !wire_shape_ok(*sh)) return 0;
+  const size_t raw = 32 + sh->n_attributes + 2 * (size_t)sh->n_hidden_scalars + 2 * (size_t)sh->n_enc_proofs;
+  return (raw + 31) & ~size_t(31);
+}
+extern "C" int afx_wire_parse(const uint8_t* blob, size_t len, afx_shape* shape_out, size_t* count_out, size_t* records_offset_out) {
+  if (!blob || !shape_out || !count_out || !records_offset_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (len < 32 || memcmp(blob, "AFXP", 4) != 0 || rd32(blob + 4) != 1) { set_error("not an AFXP v1 batch"); return AFX_E_BAD_ARGS; }
+  afx_shape sh;
+  memset(&sh, 0, sizeof sh);
+  const uint32_t count = rd32(blob + 8), cells = rd32(blob + 12);
+  sh.n_attributes = rd32(blob + 16); sh.n_responses = rd32(blob + 20); sh.n_hidden_scalars = rd32(blob + 24); sh.n_enc_proofs = rd32(blob + 28);
+  if (sh.n_attributes > AFX_MAX_ATTRIBUTES || sh.n_responses > 3 + AFX_MAX_ATTRIBUTES || sh.n_hidden_scalars > AFX_MAX_ATTRIBUTES || sh.n_enc_proofs > AFX_MAX_ATTRIBUTES) {
+    set_error("shape field out of range");
+    return AFX_E_BAD_ARGS;
+  }
+  const size_t raw = 32 + sh.n_attributes + 2 * (size_t)sh.n_hidden_scalars + 2 * (size_t)sh.n_enc_proofs, hdr = (raw + 31) & ~size_t(31);
+  if (len < hdr) { set_error("truncated header"); return AFX_E_BAD_ARGS; }
+  const uint8_t* p = blob + 32;
+  for (uint32_t i = 0; i < sh.n_attributes; i++) sh.kinds[i] = *p++;
+  for (uint32_t i = 0; i < sh.n_hidden_scalars; i++) { sh.hidden_scalar_indices[i] = (uint16_t)(p[0] | (p[1] << 8)); p += 2; }
+  for (uint32_t i = 0; i < sh.n_enc_proofs; i++) { sh.enc_indices[i] = (uint16_t)(p[0] | (p[1] << 8)); p += 2; }
+  if (!wire_shape_ok(sh) || cells != afx_wire_cells_per_record(&sh)) { set_error("cells_per_record does not match the shape"); return AFX_E_BAD_ARGS; }
+  if ((len - hdr) / 32 / (cells ? cells : 1) < count || len != hdr + (size_t)count * cells * 32) { set_error("record area length"); return AFX_E_BAD_ARGS; }
+  *shape_out = sh;
+  *count_out = count;
+  *records_offset_out = hdr;
+  return AFX_OK;
+}
+extern "C" int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out) {
+  if (!ctx || !status || !count_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  afx_shape sh;
+  size_t count = 0, off = 0;
+  int rc = afx_wire_parse(blob, len, &sh, &count, &off);
+  if (rc) return rc;
+  *count_out = count;
+  if (count == 0) return AFX_OK;
+  if (status_cap < count) { set_error("status buffer too small"); return AFX_E_BAD_ARGS; }
+  if (count > 0xffffffffu / 64) { set_error("batch too large for one call"); return AFX_E_BAD_ARGS; }
+  AFX_HIP(hipSetDevice(ctx->device));
+  const uint32_t cells = afx_wire_cells_per_record(&sh);
+  // SoA rows: challenge | responses | C_x_0 C_x_1 C_V | C_y[n] | attr_values[n] (secret rows stay unused) | enc proofs
+  const uint32_t n = sh.n_attributes;
+  const uint32_t row_resp = 1, row_cx = row_resp + sh.n_responses, row_cy = row_cx + 3, row_av = row_cy + n, row_enc = row_av + n;
+  const uint32_t rows = row_enc + 14 * sh.n_enc_proofs;
+  std::vector<uint32_t> row_of_cell;
+  for (uint32_t r = 0; r < row_av; r++) row_of_cell.push_back(r);
+  for (uint32_t i = 0; i < n; i++)
+    if (sh.kinds[i] == AFX_ENC_PUBLIC_SCALAR || sh.kinds[i] == AFX_ENC_PUBLIC_POINT) row_of_cell.push_back(row_av + i);
+  for (uint32_t r = row_enc; r < rows; r++) row_of_cell.push_back(r);
+  if (row_of_cell.size() != cells) { set_error("internal: wire cell map"); return AFX_E_BAD_ARGS; }
+  Stager st(ctx);
+  const size_t o_rec = st.add(blob + off, (size_t)count * cells * 32), o_map = st.add((const uint8_t*)row_of_cell.data(), 4 * (size_t)cells),
+               o_soa = st.add(nullptr, (size_t)count * rows * 32), o_st = st.add(nullptr, count);
+  if ((rc = st.upload())) return rc;
+  AFX_HIP(afxk_aos_to_soa(ctx->stream, st.dev(o_rec), st.dev(o_soa), (const uint32_t*)st.dev(o_map), cells, (uint32_t)count));
+  auto rowp = [&](uint32_t r) { return (const uint8_t*)st.dev(o_soa) + (size_t)r * count * 32; };
+  afx_presentation_soa d;
+  d.challenge = rowp(0);
+  d.responses = rowp(row_resp);
+  d.C_x_0 = rowp(row_cx); d.C_x_1 = rowp(row_cx + 1); d.C_V = rowp(row_cx + 2);
+  d.C_y = rowp(row_cy);
+  d.attr_values = rowp(row_av);
+  std::vector<afx_encproof_soa> encs(sh.n_enc_proofs);
+  for (uint32_t e = 0; e < sh.n_enc_proofs; e++) {
+    const uint32_t r = row_enc + 14 * e;
+    encs[e] = { rowp(r), rowp(r + 1), rowp(r + 7), rowp(r + 8), rowp(r + 9), rowp(r + 10), rowp(r + 11), rowp(r + 12), rowp(r + 13) };
+  }
+  d.enc = encs.data();
+  if ((rc = afx_verify_presentations_dev(ctx, &sh, &d, count, st.dev(o_st)))) return rc;
+  AFX_HIP(hipMemcpyAsync(status, st.dev(o_st), count, hipMemcpyDeviceToHost, ctx->stream));
+  AFX_HIP(hipStreamSynchronize(ctx->stream));
+  return AFX_OK;
+}

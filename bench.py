@@ -182,7 +182,7 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
     hash_ms, _ = issuer.get_timing("k_hash")
     issuer.set_timing(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     cpu = None
@@ -223,11 +223,12 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="presentations per GPU (default: the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL; the driver's launch) or gloo (testing two ranks on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("AFX_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
@@ -235,7 +236,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
     import aeonflux_amd as afx
     from aeonflux_amd import batch
 
@@ -295,7 +299,7 @@ def main():
     dec_ms, _ = issuer.get_timing("k_decode")
     issuer.set_timing(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     got = status.cpu().numpy()

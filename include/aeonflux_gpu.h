@@ -139,6 +139,25 @@ int afx_verify_presentations(afx_ctx* ctx, const afx_shape* shape, const afx_pre
 int afx_verify_presentations_dev(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* batch,
                                  size_t count, uint8_t* status_dev);
 
+/* ---- wire format (the reference defines none: presentation.rs:117-127 holds decoded
+ *      points and has no to_bytes) ------------------------------------------------------------------
+ * A batch of same-shape presentations, in the crate's "u32le n || 32-byte items" style (parameters.rs:155-184):
+ *   header : "AFXP" | u32le version (1) | u32le count | u32le cells_per_record
+ *            | u32le n_attributes | u32le n_responses | u32le n_hidden_scalars | u32le n_enc_proofs
+ *            | kinds[n_attributes] (u8) | hidden_scalar_indices[..] (u16le) | enc_indices[..] (u16le) | zero pad to 32 B
+ *   records: count x cells_per_record x 32 bytes, array of structs, each record =
+ *            challenge | responses[n_responses] | C_x_0 | C_x_1 | C_V | C_y[n_attributes]
+ *            | value of every PUBLIC_SCALAR / PUBLIC_POINT attribute, in position order
+ *            | per proof of encryption: challenge | responses[6] | pk | E1 | E2 | C_y_1 | C_y_2 | C_y_3 | C_y_2'
+ * A single ProofOfValidCredential::to_bytes is the same with count = 1. */
+size_t afx_wire_header_bytes(const afx_shape* shape);
+uint32_t afx_wire_cells_per_record(const afx_shape* shape);
+/* Parse the header (host).  Returns AFX_OK and fills shape/count/records offset, or AFX_E_BAD_ARGS. */
+int afx_wire_parse(const uint8_t* blob, size_t len, afx_shape* shape_out, size_t* count_out, size_t* records_offset_out);
+/* Issuer::verify over a serialized batch: the records are copied to HBM, transposed to struct-of-arrays by a
+ * kernel, and verified.  status must hold `count` bytes (status_cap >= count). */
+int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out);
+
 /* ProofOfEncryption::verify alone (src/nizk/encryption.rs:154-210); `index` = ProofOfEncryption.index */
 int afx_verify_encryption_proofs(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* batch, size_t count,
                                  uint8_t* status);

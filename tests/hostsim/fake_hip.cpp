@@ -55,3 +55,4 @@ hipError_t afxk_fill_u32(hipStream_t, uint32_t* p, uint32_t v, uint32_t n) { for
 hipError_t afxk_from_uniform(hipStream_t, const uint8_t*, uint8_t*, int32_t*, uint32_t) { return hipSuccess; }
 hipError_t afxk_reduce_wide(hipStream_t, const uint8_t*, uint8_t*, uint32_t) { return hipSuccess; }
 hipError_t afxk_validate(hipStream_t, const uint8_t*, uint8_t*, uint8_t*, uint32_t) { return hipSuccess; }
+hipError_t afxk_aos_to_soa(hipStream_t, const uint8_t*, uint8_t*, const uint32_t* m, uint32_t cells, uint32_t) { for (uint32_t i = 0; i < cells; i++) sink += m[i]; return hipSuccess; }

@@ -1,0 +1,70 @@
+"""Wire format.  CPU: pack/unpack round trip and header validation through the C ABI's
+host-side parser.  GPU: serialized batch -> transposing loader -> Issuer::verify equals the oracle."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+
+def synthetic(count=5, seed=3):
+    import aeonflux_amd as afx
+    rng = np.random.default_rng(seed)
+    sh = afx.Shape()
+    sh.n_attributes, sh.n_responses, sh.n_hidden_scalars, sh.n_enc_proofs = 4, 4, 1, 1
+    for i, k in enumerate((1, 0, 2, 3)):
+        sh.kinds[i] = k
+    sh.hidden_scalar_indices[0] = 0
+    sh.enc_indices[0] = 3
+    rb = lambda *s: rng.integers(0, 256, size=s, dtype=np.uint8)
+    p = {"challenge": rb(count, 32), "responses": rb(4, count, 32), "C_x_0": rb(count, 32), "C_x_1": rb(count, 32), "C_V": rb(count, 32),
+         "C_y": rb(4, count, 32), "attr_values": rb(4, count, 32),
+         "enc": [{f: (rb(6, count, 32) if f == "responses" else rb(count, 32)) for f in ("challenge", "responses", "pk", "E1", "E2", "C_y_1", "C_y_2", "C_y_3", "C_y_2p")}]}
+    p["attr_values"][0] = 0
+    p["attr_values"][3] = 0   # secret positions do not travel
+    return sh, p
+
+
+def test_pack_unpack_roundtrip_and_c_parser():
+    import aeonflux_amd as afx
+    from aeonflux_amd import wire
+    sh, p = synthetic()
+    blob = wire.pack_presentations(sh, p)
+    assert len(blob) == 64 + 5 * 28 * 32   # README shape: 28 cells = 896 B per presentation
+    sh2, p2 = wire.unpack_presentations(blob)
+    assert bytes(sh2) == bytes(sh)
+    for k in ("challenge", "responses", "C_x_0", "C_x_1", "C_V", "C_y", "attr_values"):
+        assert np.array_equal(p[k], p2[k]), k
+    for f, v in p["enc"][0].items():
+        assert np.array_equal(v, p2["enc"][0][f]), f
+    lib = afx.lib()
+    shape, count, off = afx.Shape(), C.c_size_t(0), C.c_size_t(0)
+    assert lib.afx_wire_parse(blob, len(blob), C.byref(shape), C.byref(count), C.byref(off)) == 0
+    assert (count.value, off.value, bytes(shape)) == (5, 64, bytes(sh))
+    assert lib.afx_wire_cells_per_record(C.byref(sh)) == 28 and lib.afx_wire_header_bytes(C.byref(sh)) == 64
+    # malformed blobs are rejected by the host parser, never read out of bounds
+    bad = [blob[:-1], blob + b"\0", b"XFXP" + blob[4:], blob[:4] + struct.pack("<I", 2) + blob[8:], blob[:12] + struct.pack("<I", 27) + blob[16:],
+           blob[:16] + struct.pack("<I", 99) + blob[20:], blob[:8] + struct.pack("<I", 1 << 30) + blob[12:], blob[:20], blob[:32] + b"\x09" + blob[33:]]
+    for b in bad:
+        assert lib.afx_wire_parse(b, len(b), C.byref(shape), C.byref(count), C.byref(off)) == afx.E_BAD_ARGS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,layout,hide,count", [(4, "SSPE", [0, 3], 130), (8, "SSPPEEEE", [4, 5, 6, 7], 20), (2, "SP", [], 3)])
+def test_wire_verify_matches_oracle(n, layout, hide, count):
+    import aeonflux_amd as afx
+    from aeonflux_amd import wire
+    from tests.helpers import corrupt, make_batch
+    from tests.soa import presentation_arrays, shape_of
+    params, key, ip, issuer, pres = make_batch(n, layout, hide, count, b"wire-%d" % n)
+    corrupt(pres, b"wire-corrupt")
+    want = [issuer.verify_presentation(p) for p in pres]
+    a = presentation_arrays(pres)
+    sh = afx.Shape.from_buffer_copy(bytes(shape_of(pres[0])))
+    blob = wire.pack_presentations(sh, a)
+    ctx = afx.Context(params, key, ip)
+    status = np.full(count, 9, np.uint8)
+    cnt = C.c_size_t(0)
+    afx.check(afx.lib().afx_verify_presentations_wire(ctx.h, blob, len(blob), status.ctypes.data, count, C.byref(cnt)))
+    ctx.close()
+    assert cnt.value == count and status.tolist() == want
