@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libaeonflux_gpu.so")
 MAX_ATTRIBUTES = 32
 
 OK, E_BAD_ARGS, E_BAD_PARAMS, E_NO_DEVICE, E_HIP, E_NO_KEY = 0, -1, -2, -3, -4, -5
-ST_OK, ST_VERIFICATION_FAILURE, ST_MAC_CREATION, ST_NO_SYMMETRIC_KEY = 0, 1, 2, 3
+ST_OK, ST_VERIFICATION_FAILURE, ST_MAC_CREATION, ST_NO_SYMMETRIC_KEY, ST_UNDECRYPTABLE = 0, 1, 2, 3, 4
 ATTR_PUBLIC_SCALAR, ATTR_SECRET_SCALAR, ATTR_PUBLIC_POINT, ATTR_EITHER_POINT, ATTR_SECRET_POINT = range(5)
 ENC_PUBLIC_SCALAR, ENC_SECRET_SCALAR, ENC_PUBLIC_POINT, ENC_SECRET_POINT = range(4)
 
@@ -111,6 +111,11 @@ def lib():
             if hasattr(_LIB, name):
                 getattr(_LIB, name).argtypes = [C.c_void_p, C.POINTER(CredentialsSoA), C.POINTER(KeypairsSoA), C.POINTER(ShowRandomness),
                                                 C.c_size_t, C.POINTER(PresentationOut), C.POINTER(Shape), C.c_void_p]
+        _LIB.afx_system_parameters_generate.argtypes = [C.c_int, C.c_uint32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        _LIB.afx_plaintexts_from_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _LIB.afx_keypairs_derive.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _LIB.afx_encrypt.argtypes = [C.c_void_p, C.POINTER(KeypairsSoA), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        _LIB.afx_decrypt.argtypes = [C.c_void_p, C.POINTER(KeypairsSoA), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB.afx_wire_header_bytes.restype = C.c_size_t
         _LIB.afx_wire_header_bytes.argtypes = [C.POINTER(Shape)]
         _LIB.afx_wire_cells_per_record.restype = C.c_uint32

@@ -49,6 +49,7 @@ extern "C" {
 #define AFX_ST_VERIFICATION_FAILURE 1  /* CredentialError::VerificationFailure (errors.rs:152-156) */
 #define AFX_ST_MAC_CREATION 2          /* CredentialError::MacCreation (amacs.rs:285-287)          */
 #define AFX_ST_NO_SYMMETRIC_KEY 3      /* CredentialError::NoSymmetricKey (presentation.rs:150-157) */
+#define AFX_ST_UNDECRYPTABLE 4         /* CredentialError::UndecryptableAttribute (symmetric.rs:285-288) */
 
 /* amacs::Attribute (src/amacs.rs:168-179): kinds of a credential's attributes */
 #define AFX_ATTR_PUBLIC_SCALAR 0
@@ -256,6 +257,24 @@ int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypa
  * (u32 n || w || w' || x0 || x1 || y[n]), writes W (32 B) and C_W || I (64 B). */
 int afx_issuer_keygen(int device, const uint8_t* sysparams, size_t sysparams_len, const uint8_t* key_scalars,
                       size_t key_scalars_len, uint8_t W_out[32], uint8_t issuer_params_out[64]);
+
+/* SystemParameters::hash_and_pray (src/parameters.rs:196-326).  `rng_stream` stands in for csprng.fill_bytes: it is
+ * consumed 32 bytes per attempt, in the reference's order (G_w, G_w', G_x0, G_x1, G_y.., G_m.., G_V, G_a, G_a0, G_a1);
+ * the decompression tests run on the GPU.  Writes SystemParameters::to_bytes; *consumed_out = bytes of the stream used.
+ * AFX_E_BAD_ARGS if the stream runs out, AFX_E_BAD_PARAMS for CredentialError::NoSystemParameters (duplicates). */
+int afx_system_parameters_generate(int device, uint32_t n_attributes, const uint8_t* rng_stream, size_t stream_len,
+                                   uint8_t* params_out, size_t params_cap, size_t* consumed_out);
+/* impl From<&[u8; 30]> for Plaintext (src/symmetric.rs:135-143): M1 = encode_to_group (src/encoding.rs:56-70; counter out),
+ * M2 = hash-to-group, m3 = hash-to-scalar.  msgs [count][30]; SHA-512 runs on the host, everything else on the GPU. */
+int afx_plaintexts_from_bytes(afx_ctx* ctx, const uint8_t* msgs, size_t count, uint8_t* M1, uint8_t* M2, uint8_t* m3, uint32_t* counters);
+/* Keypair::derive (src/symmetric.rs:197-215): master_secrets [count][64] -> a, a0, a1, pk ([count][32] each). */
+int afx_keypairs_derive(afx_ctx* ctx, const uint8_t* master_secrets, size_t count, uint8_t* a, uint8_t* a0, uint8_t* a1, uint8_t* pk);
+/* Keypair::encrypt (src/symmetric.rs:252-261) and Keypair::decrypt (:273-289; status AFX_ST_UNDECRYPTABLE on mismatch;
+ * `messages` [count][30] = decode_from_group of the recovered M1, may be NULL). */
+int afx_encrypt(afx_ctx* ctx, const afx_keypairs_soa* keypairs, const uint8_t* M1, const uint8_t* M2, const uint8_t* m3, size_t count,
+                uint8_t* E1, uint8_t* E2, uint8_t* status);
+int afx_decrypt(afx_ctx* ctx, const afx_keypairs_soa* keypairs, const uint8_t* E1, const uint8_t* E2, size_t count, uint8_t* M1,
+                uint8_t* M2, uint8_t* m3, uint8_t* messages, uint8_t* status);
 
 /* Batch ristretto255 primitives (dalek CompressedRistretto::decompress -> compress round trip,
  * RistrettoPoint::from_uniform_bytes, Scalar::from_bytes_mod_order_wide); used to build synthetic
