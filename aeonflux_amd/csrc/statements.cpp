@@ -236,6 +236,38 @@ static void add_encproof_verify(Assembler& as, JobSets& js, uint16_t index, cons
 }
 
 
+// Shapes on which the reference indexes out of range (panics) or zkp rejects every proof: every item fails, and no
+// per-item array is touched.  Also yields the compact C_y list and, per compact index, which hidden-scalar slot
+// constraint #3 looks up (presentation.rs:427-433 uses the compact index as an original position).
+static bool presentation_shape_rejects(const afx_ctx* c, const afx_shape& sh, uint32_t keep[AFX_MAX_ATTRIBUTES], uint32_t* k_out,
+                                       int hidden_slot[AFX_MAX_ATTRIBUTES]) {
+  const uint32_t n = sh.n_attributes, hs = sh.n_hidden_scalars;
+  if (n > c->n || n > AFX_MAX_ATTRIBUTES || hs > AFX_MAX_ATTRIBUTES || sh.n_enc_proofs > AFX_MAX_ATTRIBUTES ||
+      sh.n_responses != 3 + hs /* verify_compact: responses.len() != num_scalars */)
+    return true;
+  for (uint32_t i = 0; i < n; i++)
+    if (sh.kinds[i] > AFX_ENC_SECRET_POINT) return true;
+  for (uint32_t j = 0; j < hs; j++)
+    if (sh.hidden_scalar_indices[j] >= c->n) return true;   // G_m[*i], presentation.rs:407
+  for (uint32_t e = 0; e < sh.n_enc_proofs; e++)
+    if (sh.enc_indices[e] >= c->n) return true;             // G_m[self.index], encryption.rs:179
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < n; i++)
+    if (sh.kinds[i] != AFX_ENC_SECRET_POINT) keep[k++] = i;
+  for (uint32_t j = 0; j < k; j++) {
+    hidden_slot[j] = -1;
+    if (sh.kinds[j] == AFX_ENC_SECRET_POINT) continue;
+    if (j >= c->g) return true;
+    if (sh.kinds[j] == AFX_ENC_SECRET_SCALAR) {
+      for (uint32_t h = 0; h < hs; h++)
+        if (sh.hidden_scalar_indices[h] == j) { hidden_slot[j] = (int)h; break; }
+      if (hidden_slot[j] < 0) return true;   // H_s[i] / G_m[i] lookup panics (:81, :100)
+    }
+  }
+  *k_out = k;
+  return false;
+}
+
 // Issuer::verify -> ProofOfValidCredential::verify, src/nizk/presentation.rs:324-443
 static void build_presentation_verify(Assembler& as, const afx_shape& sh, const afx_presentation_soa& b, size_t total, size_t off,
                                       uint8_t* status_dev) {
@@ -243,29 +275,9 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
   JobSets js;
   auto row = [&](const uint8_t* base, size_t k) { return base + (k * total + off) * 32; };
   const uint32_t n = sh.n_attributes, hs = sh.n_hidden_scalars;
-  // shapes on which the reference indexes out of range (panics) or zkp rejects every proof
-  if (n > c->n || n > AFX_MAX_ATTRIBUTES || hs > AFX_MAX_ATTRIBUTES || sh.n_enc_proofs > AFX_MAX_ATTRIBUTES ||
-      sh.n_responses != 3 + hs /* verify_compact: responses.len() != num_scalars */)
-    as.fail_all = true;
-  for (uint32_t i = 0; i < n && !as.fail_all; i++)
-    if (sh.kinds[i] > AFX_ENC_SECRET_POINT) as.fail_all = true;
-  for (uint32_t j = 0; j < hs && !as.fail_all; j++)
-    if (sh.hidden_scalar_indices[j] >= c->n) as.fail_all = true;   // G_m[*i], presentation.rs:407
   uint32_t keep[AFX_MAX_ATTRIBUTES], k = 0;
-  for (uint32_t i = 0; i < n && !as.fail_all; i++)
-    if (sh.kinds[i] != AFX_ENC_SECRET_POINT) keep[k++] = i;
-  // constraint #3 uses the compact index as an original position (presentation.rs:427-433)
   int hidden_slot[AFX_MAX_ATTRIBUTES];
-  for (uint32_t j = 0; j < k && !as.fail_all; j++) {
-    hidden_slot[j] = -1;
-    if (sh.kinds[j] == AFX_ENC_SECRET_POINT) continue;
-    if (j >= c->g) { as.fail_all = true; break; }
-    if (sh.kinds[j] == AFX_ENC_SECRET_SCALAR) {
-      for (uint32_t h = 0; h < hs; h++)
-        if (sh.hidden_scalar_indices[h] == j) { hidden_slot[j] = (int)h; break; }
-      if (hidden_slot[j] < 0) as.fail_all = true;   // H_s[i] / G_m[i] lookup panics (:81, :100)
-    }
-  }
+  if (presentation_shape_rejects(c, sh, keep, &k, hidden_slot)) as.fail_all = true;
   if (as.fail_all) { emit(as, js, status_dev, AFX_ST_VERIFICATION_FAILURE); return; }
 
   js.sccheck.push_back({ row(b.challenge, 0) });
@@ -393,9 +405,13 @@ extern "C" int afx_verify_presentations(afx_ctx* ctx, const afx_shape* shape, co
   if (!ctx || !shape || !b || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
-  const uint32_t n = std::min<uint32_t>(shape->n_attributes, AFX_MAX_ATTRIBUTES);
-  const uint32_t nr = std::min<uint32_t>(shape->n_responses, 3 + AFX_MAX_ATTRIBUTES);
-  const uint32_t ne = shape->n_enc_proofs <= AFX_MAX_ATTRIBUTES ? shape->n_enc_proofs : 0;
+  {
+    // a shape every item fails on says nothing reliable about the arrays' extents: answer without reading them
+    uint32_t keep[AFX_MAX_ATTRIBUTES], k = 0;
+    int slot[AFX_MAX_ATTRIBUTES];
+    if (presentation_shape_rejects(ctx, *shape, keep, &k, slot)) { memset(status, AFX_ST_VERIFICATION_FAILURE, count); return AFX_OK; }
+  }
+  const uint32_t n = shape->n_attributes, nr = shape->n_responses, ne = shape->n_enc_proofs;
   if (!b->challenge || !b->C_x_0 || !b->C_x_1 || !b->C_V || (n && !b->C_y) || (nr && !b->responses) || (ne && !b->enc)) { set_error("null batch array"); return AFX_E_BAD_ARGS; }
   Stager st(ctx);
   const size_t o_ch = st.add(b->challenge, 32 * count), o_rs = st.add(b->responses, 32 * count * nr), o_x0 = st.add(b->C_x_0, 32 * count),

@@ -414,7 +414,9 @@ extern "C" int afx_issue(afx_ctx* ctx, const afx_attributes_soa* req, const afx_
   }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
-  const uint32_t na = std::min<uint32_t>(req->n_attributes, AFX_MAX_ATTRIBUTES), nr = ctx->n + 5;
+  // wrong attribute count: every request is MacCreation (amacs.rs:285-287); the arrays' extents are not trusted then
+  if (req->n_attributes != ctx->n) { memset(status, AFX_ST_MAC_CREATION, count); return AFX_OK; }
+  const uint32_t na = req->n_attributes, nr = ctx->n + 5;
   Stager st(ctx);
   const size_t o_val = st.add(req->values, 32 * count * na), o_tw = st.add(rnd->t_wide, 64 * count), o_uw = st.add(rnd->U_wide, 64 * count),
                o_seed = st.add(rnd->rng_seed, 32 * count), o_t = st.add(nullptr, 32 * count), o_U = st.add(nullptr, 32 * count),
@@ -444,7 +446,9 @@ extern "C" int afx_verify_issuances(afx_ctx* ctx, const afx_attributes_soa* attr
   }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
-  const uint32_t na = std::min<uint32_t>(attrs->n_attributes, AFX_MAX_ATTRIBUTES), nr = std::min<uint32_t>(n_responses, AFX_MAX_ATTRIBUTES + 5);
+  // shapes every item fails on (zkp: responses.len() != num_scalars; G_m[i] out of range): answer without reading the arrays
+  if (attrs->n_attributes > ctx->n || n_responses != ctx->n + 5) { memset(status, AFX_ST_VERIFICATION_FAILURE, count); return AFX_OK; }
+  const uint32_t na = attrs->n_attributes, nr = n_responses;
   Stager st(ctx);
   const size_t o_val = st.add(attrs->values, 32 * count * na), o_t = st.add(iss->t, 32 * count), o_U = st.add(iss->U, 32 * count),
                o_V = st.add(iss->V, 32 * count), o_ch = st.add(iss->challenge, 32 * count), o_rs = st.add(iss->responses, 32 * count * nr),

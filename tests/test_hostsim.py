@@ -1,0 +1,89 @@
+"""CPU-only: the engine's host half (context parsing, plan assembly, STROBE schedule compilation, C ABI argument
+handling) built against a fake HIP runtime with no-op kernels (tests/hostsim/fake_hip.cpp) under ASan/UBSan, and
+driven through every entry point.  Results are meaningless (the kernels are stubs); what is checked is that the
+host code builds every launch list without touching memory it does not own and fails cleanly on bad input."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "aeonflux_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def hostsim_lib(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("hostsim") / "libafx_hostsim.so")
+    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp")]
+    srcs.append(os.path.join(ROOT, "tests", "hostsim", "fake_hip.cpp"))
+    cmd = ["g++", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fPIC", "-std=c++17",
+           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-shared", "-o", out] + srcs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("cannot build the host simulation: " + r.stderr[-400:])
+    return out
+
+
+DRIVER = r"""
+import os, sys, ctypes as C
+sys.path.insert(0, %(root)r)
+import numpy as np
+import aeonflux_amd as afx
+afx.LIB_PATH = %(lib)r
+from aeonflux_amd import batch, wire
+from tests.helpers import make_credentials
+from tests.soa import presentation_arrays, shape_of
+for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 14, 15]), (8, "SSPPEEEE", [4, 5, 6, 7]), (1, "S", []), (3, "ESS", [0])):
+    d = make_credentials(n, layout, 3, b"hostsim-%%d" %% n)
+    ctx = afx.Context(d["params"], d["key"], d["ip"])
+    creds = d["creds"]
+    kinds = creds[0]["kinds"]
+    values = np.stack([np.stack([np.frombuffer(c["values"][i][:32], np.uint8) for c in creds]) for i in range(n)])
+    rb = lambda *s: np.zeros(s, np.uint8)
+    iss, st = batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
+    batch.verify_issuances(ctx, kinds, values, iss)
+    batch.verify_issuances(ctx, kinds, values, iss, n_responses=2)
+    k2 = list(kinds)
+    for i in hide:
+        k2[i] = 1 if k2[i] == 0 else 4
+    nsp = sum(1 for k in k2 if k == 4)
+    kp = {f: rb(3, 32) for f in ("a", "a0", "a1", "pk")}
+    pres, shape, st = batch.show(ctx, k2, values, iss["t"], iss["U"], iss["V"], kp, rb(3, 64), rb(3, 32), rb(max(nsp, 1), 3, 32), values, values)
+    batch.verify_presentations(ctx, shape, pres)
+    blob = wire.pack_presentations(shape, pres)
+    stt, cnt = np.zeros(3, np.uint8), C.c_size_t(0)
+    assert afx.lib().afx_verify_presentations_wire(ctx.h, blob, len(blob), stt.ctypes.data, 3, C.byref(cnt)) == 0 and cnt.value == 3
+    assert afx.lib().afx_verify_presentations_wire(ctx.h, blob[:-1], len(blob) - 1, stt.ctypes.data, 3, C.byref(cnt)) == afx.E_BAD_ARGS
+    # mis-shaped requests take the fail-all path
+    bad = afx.Shape.from_buffer_copy(bytes(shape))
+    bad.n_responses += 1   # claims a row the arrays do not have: must be rejected without reading them
+    batch.verify_presentations(ctx, bad, pres)
+    bad = afx.Shape.from_buffer_copy(bytes(shape))
+    bad.n_attributes = 40
+    batch.verify_presentations(ctx, bad, pres)
+    batch.multiscalar_mul(ctx, rb(24, 3, 32), rb(24, 3, 32))
+    ms = rb(3, 64)
+    o = [rb(3, 32) for _ in range(4)]
+    assert afx.lib().afx_keypairs_derive(ctx.h, ms.ctypes.data, 3, *(x.ctypes.data for x in o)) == 0
+    ctx.close()
+# bad parameters / keys are rejected on the host
+d = make_credentials(2, "SP", 1, b"hostsim-bad")
+for params, key in ((d["params"][:-1], d["key"]), (d["params"], d["key"][:-1]), (b"\x09" + d["params"][1:], d["key"]), (d["params"], d["key"][:4] + b"\xff" * 32 + d["key"][36:])):
+    try:
+        afx.Context(params, key, d["ip"])
+        raise SystemExit("accepted bad parameters")
+    except afx.AfxError as e:
+        assert e.rc == afx.E_BAD_PARAMS, e.rc
+print("hostsim ok")
+"""
+
+
+def test_every_entry_point_assembles_cleanly_under_asan(hostsim_lib, tmp_path):
+    script = tmp_path / "drive.py"
+    script.write_text(DRIVER % {"root": ROOT, "lib": hostsim_lib})
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "hostsim ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
