@@ -6,6 +6,7 @@
 #include <hip/hip_runtime_api.h>
 #include <array>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/aeonflux_gpu.h"
@@ -38,6 +39,7 @@ using Enc = std::array<uint8_t, 32>;
 }  // namespace afx
 
 struct afx_ctx {
+  std::recursive_mutex mu;   // one call at a time per context (workspace, staging and the plan ring are shared)
   int device = 0;
   hipStream_t stream = nullptr;
   uint32_t n = 0, g = 0;

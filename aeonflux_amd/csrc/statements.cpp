@@ -361,6 +361,8 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
 
 extern "C" int afx_verify_presentations_dev(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* batch, size_t count,
                                             uint8_t* status_dev) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !shape || !batch || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (!ctx->has_key) { set_error("Issuer::verify needs the issuer key"); return AFX_E_NO_KEY; }
   if (count == 0) return AFX_OK;
@@ -377,6 +379,8 @@ extern "C" int afx_verify_presentations_dev(afx_ctx* ctx, const afx_shape* shape
 }
 
 extern "C" int afx_verify_encryption_proofs_dev(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* batch, size_t count, uint8_t* status_dev) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !batch || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   const afx_encproof_soa e = *batch;
@@ -402,6 +406,8 @@ static afx_encproof_soa dev_encproof(const Stager& st, const size_t offs[9]) {
 }
 
 extern "C" int afx_verify_presentations(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* b, size_t count, uint8_t* status) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !shape || !b || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -432,6 +438,8 @@ extern "C" int afx_verify_presentations(afx_ctx* ctx, const afx_shape* shape, co
 }
 
 extern "C" int afx_verify_encryption_proofs(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* b, size_t count, uint8_t* status) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !b || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -452,6 +460,8 @@ extern "C" int afx_verify_encryption_proofs(afx_ctx* ctx, uint16_t index, const 
 // batch primitives (K* rows): from_uniform_bytes, from_bytes_mod_order_wide, decompress/compress, MSM
 // ------------------------------------------------------------------------------------------------
 extern "C" int afx_points_from_uniform_bytes(afx_ctx* ctx, const uint8_t* wide, size_t count, uint8_t* out) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !wide || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -465,6 +475,8 @@ extern "C" int afx_points_from_uniform_bytes(afx_ctx* ctx, const uint8_t* wide, 
   return AFX_OK;
 }
 extern "C" int afx_scalars_from_wide_bytes(afx_ctx* ctx, const uint8_t* wide, size_t count, uint8_t* out) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !wide || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -478,6 +490,8 @@ extern "C" int afx_scalars_from_wide_bytes(afx_ctx* ctx, const uint8_t* wide, si
   return AFX_OK;
 }
 extern "C" int afx_points_validate(afx_ctx* ctx, const uint8_t* pts, size_t count, uint8_t* ok, uint8_t* reencoded) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !pts || !ok) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -492,6 +506,8 @@ extern "C" int afx_points_validate(afx_ctx* ctx, const uint8_t* pts, size_t coun
   return AFX_OK;
 }
 extern "C" int afx_multiscalar_mul(afx_ctx* ctx, uint32_t n_terms, const uint8_t* scalars, const uint8_t* points, size_t count, uint8_t* out, uint8_t* ok) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !scalars || !points || !out || !ok) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (n_terms == 0 || n_terms > AFX_MSM_MAX_TERMS) { set_error("n_terms out of range"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
@@ -573,6 +589,8 @@ extern "C" int afx_wire_parse(const uint8_t* blob, size_t len, afx_shape* shape_
   return AFX_OK;
 }
 extern "C" int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !status || !count_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   afx_shape sh;
   size_t count = 0, off = 0;

@@ -94,6 +94,8 @@ static void messages_from_attributes(Assembler& as, const afx_attributes_soa& a,
 // ------------------------------------------------------------------------------------------------
 extern "C" int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* iss, uint32_t n_responses,
                                         size_t count, uint8_t* status_dev) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !attrs || !iss || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   const afx_attributes_soa a = *attrs;
@@ -136,6 +138,8 @@ extern "C" int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* 
 // ------------------------------------------------------------------------------------------------
 extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, const afx_issue_randomness* rnd, size_t count,
                              const afx_issuance_soa* out, uint8_t* status_dev) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !requests || !rnd || !out || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (!ctx->has_key) { set_error("Issuer::issue needs the issuer key"); return AFX_E_NO_KEY; }
   if (count == 0) return AFX_OK;
@@ -214,6 +218,8 @@ extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, c
 // ------------------------------------------------------------------------------------------------
 extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
                             size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status_dev) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !creds || !rnd || !out || !shape_out || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   const afx_credentials_soa cr = *creds;
   const uint32_t na = cr.n_attributes;
@@ -407,6 +413,8 @@ static int fetch(afx_ctx* ctx, void* dst, const uint8_t* src_dev, size_t n) {
 
 extern "C" int afx_issue(afx_ctx* ctx, const afx_attributes_soa* req, const afx_issue_randomness* rnd, size_t count,
                          const afx_issuance_soa* out, uint8_t* status) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !req || !rnd || !out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (!rnd->t_wide || !rnd->U_wide || !rnd->rng_seed || !out->t || !out->U || !out->V || !out->challenge || !out->responses || (req->n_attributes && !req->values)) {
     set_error("null batch array");
@@ -439,6 +447,8 @@ extern "C" int afx_issue(afx_ctx* ctx, const afx_attributes_soa* req, const afx_
 
 extern "C" int afx_verify_issuances(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* iss, uint32_t n_responses,
                                     size_t count, uint8_t* status) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !attrs || !iss || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (!iss->t || !iss->U || !iss->V || !iss->challenge || (n_responses && !iss->responses) || (attrs->n_attributes && !attrs->values)) {
     set_error("null batch array");
@@ -466,6 +476,8 @@ extern "C" int afx_verify_issuances(afx_ctx* ctx, const afx_attributes_soa* attr
 
 extern "C" int afx_show(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
                         size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !creds || !rnd || !out || !shape_out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   const uint32_t na = creds->n_attributes;
   if (na == 0 || na > ctx->n) { set_error("credential attribute count does not fit the system parameters"); return AFX_E_BAD_ARGS; }

@@ -108,6 +108,8 @@ extern "C" int afx_system_parameters_generate(int device, uint32_t n, const uint
 }
 
 extern "C" int afx_plaintexts_from_bytes(afx_ctx* ctx, const uint8_t* msgs, size_t count, uint8_t* M1, uint8_t* M2, uint8_t* m3, uint32_t* counters) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !msgs || !M1 || !M2 || !m3) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -159,6 +161,8 @@ extern "C" int afx_plaintexts_from_bytes(afx_ctx* ctx, const uint8_t* msgs, size
 }
 
 extern "C" int afx_keypairs_derive(afx_ctx* ctx, const uint8_t* master_secrets, size_t count, uint8_t* a, uint8_t* a0, uint8_t* a1, uint8_t* pk) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !master_secrets || !a || !a0 || !a1 || !pk) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -193,6 +197,8 @@ extern "C" int afx_keypairs_derive(afx_ctx* ctx, const uint8_t* master_secrets, 
 
 extern "C" int afx_encrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8_t* M1, const uint8_t* M2, const uint8_t* m3, size_t count,
                            uint8_t* E1, uint8_t* E2, uint8_t* status) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !kp || !kp->a || !kp->a0 || !kp->a1 || !M1 || !M2 || !m3 || !E1 || !E2 || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -221,6 +227,8 @@ extern "C" int afx_encrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8
 
 extern "C" int afx_decrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8_t* E1, const uint8_t* E2, size_t count, uint8_t* M1, uint8_t* M2,
                            uint8_t* m3, uint8_t* messages, uint8_t* status) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !kp || !kp->a || !kp->a0 || !kp->a1 || !E1 || !E2 || !M1 || !M2 || !m3 || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
