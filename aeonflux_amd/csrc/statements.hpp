@@ -9,7 +9,7 @@
 
 namespace afx {
 static constexpr size_t BLOB_CAP = size_t(4) << 20;
-static constexpr uint32_t CHUNK = 1u << 16;   // items per pass: bounds the window-table workspace (~35-80 KB per item)
+static constexpr uint32_t CHUNK = 1u << 17;   // items per pass: bounds the window-table workspace (~35-80 KB per item => 5-10 GB)
 }
 using namespace afx;
 

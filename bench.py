@@ -37,6 +37,16 @@ def algorithmic_bytes(shape):
     return 32 * (4 + hs) + 96 + 32 * n + 32 * pub + 448 * hp + (n + 2 * hs + 4 * hp) + 1
 
 
+def measured_traffic(workload):
+    """HBM bytes per k_msm launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json; collected with
+    tools/collect_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH §HBM)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            return json.load(f).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
 def usable_cores():
     """host cores this process may actually use: affinity mask, capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -304,6 +314,16 @@ def main():
         elapsed = float(t.item())
     got = status.cpu().numpy()
     assert np.array_equal(got, want), "status mismatch after the timed steps"
+    # PCIe-inclusive rate through the host-pointer entry point (never `value`; DESIGN.md quotes it)
+    pcie = None
+    if rank == 0:
+        hsoa, keep_h = batch.presentation_soa(pres)
+        hst = np.full(count, 255, np.uint8)
+        afx.check(afx.lib().afx_verify_presentations(issuer.h, C.byref(shape), C.byref(hsoa), count, hst.ctypes.data))
+        t0 = time.perf_counter()
+        afx.check(afx.lib().afx_verify_presentations(issuer.h, C.byref(shape), C.byref(hsoa), count, hst.ctypes.data))
+        pcie = count / (time.perf_counter() - t0)
+        assert np.array_equal(hst, want)
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -350,8 +370,8 @@ def main():
             "data": "synthetic (GPU-issued and GPU-shown credentials, random attribute values, 1% corrupted; all distinct)",
             "config": {"workload": desc, "presentations_per_gpu": count, "attributes": n, "shape": layout, "hidden": hide,
                        "algorithmic_bytes_per_presentation": ab, "parallelism": "host-sharded x%d, no collective" % world,
-                       "input_generation_s": round(gen_s, 2)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                       "input_generation_s": round(gen_s, 2), "host_pointer_api_presentations_per_s": pcie},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": measured_traffic(args.workload),
                          "kernel": "k_msm", "launches_per_step": msm_launches / args.steps,
                          "avg_launch_ms": msm_ms / max(1, msm_launches), "kernel_ms_per_step": msm_ms / args.steps,
                          "other_kernels_ms_per_step": {"k_hash": hash_ms / args.steps, "k_decode": dec_ms / args.steps},
