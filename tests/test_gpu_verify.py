@@ -99,3 +99,31 @@ def test_encryption_proofs_alone():
     ctx.close()
     assert status.tolist() == [issuer.verify_encryption_proof(p.enc[0]) for p in pres]
     assert status[3] == 1 and status[17] == 1 and status.sum() == 2
+
+
+def test_empty_and_chunk_boundary_batches():
+    """count == 0 is a no-op; a batch larger than the engine's internal chunk (2^17 items) crosses the chunk boundary
+    with a ragged last chunk.  The big batch is a tiling of 60 distinct presentations (some corrupted)."""
+    import ctypes as C
+    import aeonflux_amd as afx
+    from aeonflux_amd import batch
+    from tests.soa import presentation_arrays, shape_of
+    params, key, ip, issuer, pres = make_batch(4, "SSPE", [0, 3], 60, b"gpu-chunks")
+    corrupt(pres, b"chunk-corrupt")
+    want = np.array([issuer.verify_presentation(p) for p in pres], np.uint8)
+    a = presentation_arrays(pres)
+    sh = afx.Shape.from_buffer_copy(bytes(shape_of(pres[0])))
+    ctx = afx.Context(params, key, ip)
+    soa, keep = batch.presentation_soa(a)
+    st = np.full(4, 77, np.uint8)
+    afx.check(afx.lib().afx_verify_presentations(ctx.h, C.byref(sh), C.byref(soa), 0, st.ctypes.data))
+    assert st.tolist() == [77] * 4
+    total = (1 << 17) + 77
+    reps = -(-total // 60)
+    tile = lambda x: np.ascontiguousarray(np.concatenate([x] * reps, axis=-2)[..., :total, :])
+    big = {k: tile(v) for k, v in a.items() if k != "enc"}
+    big["enc"] = [{k: tile(v) for k, v in d.items()} for d in a["enc"]]
+    got = batch.verify_presentations(ctx, sh, big)
+    ctx.close()
+    assert np.array_equal(got, np.concatenate([want] * reps)[:total])
+    assert 0 < got.sum() < total
