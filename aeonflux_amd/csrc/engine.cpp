@@ -105,7 +105,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     j.next_job = j.chain_to >= 0 ? new_index[j.chain_to] + 1 : 0;
     j.digit_slot = dslot; dslot += j.n_terms;
     j.table_slot = tslot; tslot += j.n_var;
-    if (j.n_terms - j.n_var <= AFX_FIXED_LDS_MAX) max_fixed = std::max(max_fixed, j.n_terms - j.n_var);
+    if (j.n_var != 0 && j.n_terms - j.n_var <= AFX_FIXED_LDS_MAX) max_fixed = std::max(max_fixed, j.n_terms - j.n_var);
     out[k] = j;
   }
   max_digit_slots = std::max<size_t>(max_digit_slots, dslot);
@@ -174,7 +174,7 @@ int Assembler::run() {
       case L_SCCHECK: AFX_HIP(afxk_sccheck(s, (const afx_sccheck_job*)jobs, l.njobs, bad_, count)); break;
       case L_POINTOP: AFX_HIP(afxk_pointop(s, (const afx_pointop_job*)jobs, l.njobs, bad_, count)); break;
       case L_SCALAROP: AFX_HIP(afxk_scalarop(s, (const afx_scalarop_job*)jobs, l.njobs, count)); break;
-      case L_MSM: AFX_HIP(afxk_msm(s, (const afx_msm_job*)jobs, l.njobs, l.max_fixed, ft, table_ws, digit_ws, bad_, count)); break;
+      case L_MSM: AFX_HIP(afxk_msm(s, (const afx_msm_job*)jobs, l.njobs, l.max_fixed, ft, (const int32_t*)ctx->d_pos_tables.p, table_ws, digit_ws, bad_, count)); break;
       case L_HASH: AFX_HIP(afxk_hash(s, (const afx_hash_program*)jobs, l.njobs, bad_, count)); break;
       case L_FROM_UNIFORM: AFX_HIP(afxk_from_uniform(s, l.in, l.out, l.out_var, count)); break;
       case L_REDUCE_WIDE: AFX_HIP(afxk_reduce_wide(s, l.in, l.out, count)); break;

@@ -127,6 +127,30 @@ __global__ void k_setup_generators(const uint8_t* __restrict__ enc, uint32_t nge
   }
 }
 
+// positional tables for jobs made of fixed bases only (no doubling chain at all): thread (g, j) writes
+// d * 256^j * G_g for d = 0..128 as affine niels.  One-time work at context creation.
+__global__ void k_setup_postables(const int32_t* __restrict__ ext, uint32_t ngen, int32_t* __restrict__ postab) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ngen * 32) return;
+  const uint32_t g = t / 32, j = t % 32;
+  ge_p3 P = p3_load_uniform(ext + (size_t)g * AFX_VAR_DWORDS);
+#pragma unroll 1
+  for (uint32_t k = 0; k < 8 * j; k++) P = ge_double(P);
+  int32_t* tab = postab + (size_t)g * AFX_POS_TABLE_DWORDS + (size_t)j * AFX_FIXED_TABLE_DWORDS;
+  const fe d2 = fe_const(FEC_D2);
+  const ge_cached cP = ge_p3_to_cached(P);
+  ge_p3 Q = ge_identity();
+#pragma unroll 1
+  for (int k = 0; k < AFX_FIXED_ENTRIES; k++) {
+    const fe zinv = fe_invert(Q.Z);
+    const fe x = fe_mul(Q.X, zinv), y = fe_mul(Q.Y, zinv);
+    const fe ypx = fe_carry(fe_add(y, x)), ymx = fe_carry(fe_sub(y, x)), xy2d = fe_mul(fe_mul(x, y), d2);
+#pragma unroll
+    for (int l = 0; l < 10; l++) { tab[k * 30 + l] = ypx.v[l]; tab[k * 30 + 10 + l] = ymx.v[l]; tab[k * 30 + 20 + l] = xy2d.v[l]; }
+    Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // decode / scalar checks / small point and scalar ops
 // ---------------------------------------------------------------------------------------------
@@ -211,8 +235,8 @@ AFX_DEV ge_p3 msm_finish_add(const ge_p1p1& r, bool want_t) {
 }
 
 __global__ void __launch_bounds__(AFX_BLOCK, 2)
-k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_tables, int32_t* __restrict__ table_ws,
-      uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count) {
+k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_tables, const int32_t* __restrict__ pos_tables,
+      int32_t* __restrict__ table_ws, uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count) {
   extern __shared__ int32_t lds_tab[];
   const uint32_t tid = threadIdx.x;
   // lanes past the end of the batch shadow the last item (identical values, identical stores): every lane of the
@@ -222,7 +246,7 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_ta
 #pragma unroll 1
   for (;;) {
   const uint32_t nt = job->n_terms, nv = job->n_var, nf = nt - nv;
-  const bool in_lds = nf <= AFX_FIXED_LDS_MAX;
+  const bool in_lds = nf <= AFX_FIXED_LDS_MAX && nv != 0;
   __syncthreads();   // the previous job of this chain is done with the LDS tables
   if (in_lds) {
     for (uint32_t t = nv; t < nt; t++) {
@@ -261,6 +285,28 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_ta
   }
 
   ge_p3 acc = ge_identity();
+  if (nv == 0) {
+    // fixed bases only: sum over byte positions of positional-table entries, no doublings (32 additions per base)
+#pragma unroll 1
+    for (uint32_t j = 0; j < 32; j++) {
+#pragma unroll 1
+      for (uint32_t t = 0; t < nt; t++) {
+        const uint32_t word = digit_ws[((size_t)(dslot + t) * 8 + (j >> 2)) * count + item];
+        const int d = (int)((word >> ((j & 3) * 8)) & 255u) - 128;
+        const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
+        const bool neg = (d < 0) != (job->term[t].negate != 0);
+        const int2* e = reinterpret_cast<const int2*>(pos_tables + (size_t)job->term[t].fixed_idx * AFX_POS_TABLE_DWORDS +
+                                                      (size_t)j * AFX_FIXED_TABLE_DWORDS + idx * AFX_NIELS_DWORDS);
+        int32_t v[30];
+#pragma unroll
+        for (int l = 0; l < 15; l++) { const int2 x = e[l]; v[2 * l] = x.x; v[2 * l + 1] = x.y; }
+        ge_niels q;
+#pragma unroll
+        for (int l = 0; l < 10; l++) { q.ypx.v[l] = v[l]; q.ymx.v[l] = v[10 + l]; q.xy2d.v[l] = v[20 + l]; }
+        acc = ge_p1p1_to_p3(ge_madd(acc, q, neg));
+      }
+    }
+  } else {
 #pragma unroll 1
   for (int w = 63; w >= 0; w--) {
     const bool fixed_now = ((w & 1) == 0) && nf != 0;
@@ -307,6 +353,7 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_ta
         acc = msm_finish_add(ge_madd(acc, q, neg), done != nadd || w == 0);
       }
     }
+  }
   }
   if (job->addend) {
     const ge_p3 A = var_load(job->addend, count, item);
@@ -480,11 +527,15 @@ hipError_t afxk_scalarop(hipStream_t s, const afx_scalarop_job* jobs, uint32_t n
   hipLaunchKernelGGL(k_scalarop, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, count);
   return hipGetLastError();
 }
-hipError_t afxk_msm(hipStream_t s, const afx_msm_job* jobs, uint32_t njobs, uint32_t max_fixed, const int32_t* fixed_tables,
+hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen, int32_t* postab) {
+  hipLaunchKernelGGL(k_setup_postables, dim3((ngen * 32 + 63) / 64), dim3(64), 0, s, ext, ngen, postab);
+  return hipGetLastError();
+}
+hipError_t afxk_msm(hipStream_t s, const afx_msm_job* jobs, uint32_t njobs, uint32_t max_fixed, const int32_t* fixed_tables, const int32_t* pos_tables,
                     int32_t* table_ws, uint32_t* digit_ws, uint32_t* bad, uint32_t count) {
   // max_fixed = the largest fixed-term count among the jobs that stage their tables in LDS (<= AFX_FIXED_LDS_MAX)
   const size_t lds = (size_t)max_fixed * AFX_FIXED_TABLE_DWORDS * sizeof(int32_t);
-  hipLaunchKernelGGL(k_msm, grid_for(count, njobs), dim3(AFX_BLOCK), lds, s, jobs, fixed_tables, table_ws, digit_ws, bad, count);
+  hipLaunchKernelGGL(k_msm, grid_for(count, njobs), dim3(AFX_BLOCK), lds, s, jobs, fixed_tables, pos_tables, table_ws, digit_ws, bad, count);
   return hipGetLastError();
 }
 hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count) {

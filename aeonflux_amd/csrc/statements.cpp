@@ -79,6 +79,7 @@ extern "C" void afx_ctx_destroy(afx_ctx* c) {
   c->ws.release(true);
   c->staging.release(true);
   c->d_fixed_tables.release(true);
+  c->d_pos_tables.release(true);
   c->d_gen_ext.release(true);
   c->d_gen_enc.release(false);
   c->d_consts.release(false);
@@ -138,6 +139,7 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   }
   int rc;
   if ((rc = c->d_gen_enc.ensure(32 * (size_t)c->ngen)) || (rc = c->d_fixed_tables.ensure(sizeof(int32_t) * AFX_FIXED_TABLE_DWORDS * (size_t)c->ngen)) ||
+      (rc = c->d_pos_tables.ensure(sizeof(int32_t) * AFX_POS_TABLE_DWORDS * (size_t)c->ngen)) ||
       (rc = c->d_gen_ext.ensure(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)c->ngen)) || (rc = c->d_key.ensure(32 * (size_t)(4 + n))) ||
       (rc = c->d_consts.ensure(64)) || (rc = c->staging.ensure(32 * (size_t)c->ngen + 4 * (size_t)c->ngen)))
     return rc;
@@ -153,6 +155,7 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   uint8_t* d_neg = (uint8_t*)c->staging.p;
   uint32_t* d_ok = (uint32_t*)((uint8_t*)c->staging.p + 32 * (size_t)c->ngen);
   AFX_HIP(afxk_setup_generators(c->stream, (const uint8_t*)c->d_gen_enc.p, c->ngen, (int32_t*)c->d_fixed_tables.p, (int32_t*)c->d_gen_ext.p, d_neg, d_ok));
+  AFX_HIP(afxk_setup_postables(c->stream, (const int32_t*)c->d_gen_ext.p, c->ngen, (int32_t*)c->d_pos_tables.p));
   std::vector<uint8_t> neg(32 * (size_t)c->ngen);
   std::vector<uint32_t> ok(c->ngen);
   AFX_HIP(hipMemcpyAsync(neg.data(), d_neg, neg.size(), hipMemcpyDeviceToHost, c->stream));

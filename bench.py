@@ -224,12 +224,124 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
         dist.destroy_process_group()
 
 
+def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
+    """secondary metric: presentations created / s (AnonymousCredential::show), C2 shape, device-resident inputs"""
+    n, layout, hide, count = 4, "SSPE", [0, 3], (args.batch or (1 << 16))
+    params, key, ip = load_fixture("readme_4attrs_sSPe")
+    issuer = afx.Context(params, key, ip, device=local_rank)
+    user = afx.Context(params, None, ip, device=local_rank)
+    rng = np.random.default_rng(99 + rank)
+    rb = lambda *shape: rng.integers(0, 256, size=shape, dtype=np.uint8)
+    dev = torch.device("cuda", local_rank)
+    values, M2, m3 = (np.zeros((n, count, 32), np.uint8) for _ in range(3))
+    kinds = []
+    for i, c in enumerate(layout):
+        kinds.append({"S": afx.ATTR_PUBLIC_SCALAR, "P": afx.ATTR_PUBLIC_POINT, "E": afx.ATTR_EITHER_POINT}[c])
+        values[i] = batch.scalars_from_wide(issuer, rb(count, 64)) if c == "S" else batch.points_from_uniform(issuer, rb(count, 64))
+        if c == "E":
+            M2[i] = batch.points_from_uniform(issuer, rb(count, 64))
+            m3[i] = batch.scalars_from_wide(issuer, rb(count, 64))
+    iss, st = batch.issue(issuer, kinds, values, rb(count, 64), rb(count, 64), rb(count, 32))
+    assert not st.any()
+    skinds = list(kinds)
+    for i in hide:
+        skinds[i] = afx.ATTR_SECRET_SCALAR if skinds[i] == afx.ATTR_PUBLIC_SCALAR else afx.ATTR_SECRET_POINT
+    g = max(3, n)
+    gen = lambda idx: np.frombuffer(params[4 + 32 * idx:4 + 32 * idx + 32], np.uint8)
+    a, a0, a1 = (batch.scalars_from_wide(issuer, rb(count, 64)) for _ in range(3))
+    pk, ok = batch.multiscalar_mul(issuer, np.stack([a, a0, a1]), np.stack([np.broadcast_to(gen(5 + g + n + 1 + k), (count, 32)) for k in range(3)]))
+    host_in = dict(values=values, M2=M2, m3=m3, t=iss["t"], U=iss["U"], V=iss["V"], a=a, a0=a0, a1=a1, pk=pk,
+                   z_wide=rb(count, 64), seed=rb(count, 32), enc_seeds=rb(1, count, 32))
+    d = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in host_in.items()}
+    o = {k: torch.zeros((count, 32), dtype=torch.uint8, device=dev) for k in ("challenge", "C_x_0", "C_x_1", "C_V")}
+    o["responses"] = torch.zeros((4, count, 32), dtype=torch.uint8, device=dev)
+    o["C_y"] = torch.zeros((n, count, 32), dtype=torch.uint8, device=dev)
+    o["attr_values"] = torch.zeros((n, count, 32), dtype=torch.uint8, device=dev)
+    eo = {f: torch.zeros(((6, count, 32) if f == "responses" else (count, 32)), dtype=torch.uint8, device=dev) for f in batch.ENC_FIELDS}
+    cs = afx.CredentialsSoA()
+    cs.n_attributes = n
+    for i, k in enumerate(skinds):
+        cs.kinds[i] = k
+    for f in ("values", "M2", "m3", "t", "U", "V"):
+        setattr(cs, f, d[f].data_ptr())
+    kp = afx.KeypairsSoA(*(d[f].data_ptr() for f in ("a", "a0", "a1", "pk")))
+    rnd = afx.ShowRandomness(d["z_wide"].data_ptr(), d["seed"].data_ptr(), d["enc_seeds"].data_ptr())
+    eouts = (afx.EncProofOut * 1)()
+    for f in batch.ENC_FIELDS:
+        setattr(eouts[0], f, eo[f].data_ptr())
+    out = afx.PresentationOut()
+    for f in batch.PRES_FIELDS:
+        setattr(out, f, o[f].data_ptr())
+    out.enc = C.cast(eouts, C.POINTER(afx.EncProofOut))
+    shape = afx.Shape()
+    status = torch.full((count,), 255, dtype=torch.uint8, device=dev)
+    fn = afx.lib().afx_show_dev
+
+    def step():
+        afx.check(fn(user.h, C.byref(cs), C.byref(kp), C.byref(rnd), count, C.byref(out), C.byref(shape), status.data_ptr()))
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    assert not status.cpu().numpy().any(), "show failed"
+    # every presentation made here must verify on the issuer's side (GPU), and the first 16 must equal the oracle's bytes
+    pres = {f: o[f].cpu().numpy() for f in batch.PRES_FIELDS}
+    pres["enc"] = [{f: eo[f].cpu().numpy() for f in batch.ENC_FIELDS}]
+    assert not batch.verify_presentations(issuer, shape, pres).any(), "a shown presentation does not verify"
+    if rank == 0 and not args.no_cpu_baseline:
+        import oracle
+        octx = oracle.Ctx(params, None, ip)
+        for i in range(16):
+            vals = [bytes(values[k, i]) + bytes(M2[k, i]) + bytes(m3[k, i]) for k in range(n)]
+            kpb = bytes(a[i]) + bytes(a0[i]) + bytes(a1[i]) + bytes(pk[i])
+            st, p = octx.show(skinds, vals, bytes(iss["t"][i]), bytes(iss["U"][i]), bytes(iss["V"][i]), kpb, bytes(host_in["z_wide"][i]),
+                              bytes(host_in["seed"][i]), bytes(host_in["enc_seeds"][0, i]))
+            assert st == 0 and bytes(p.challenge) == bytes(pres["challenge"][i]) and bytes(p.enc[0].challenge) == bytes(pres["enc"][0]["challenge"][i])
+            assert all(bytes(p.responses[k]) == bytes(pres["responses"][k, i]) for k in range(4)), "GPU show differs from the oracle"
+    user.set_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    msm_ms, msm_launches = user.get_timing("k_msm")
+    hash_ms, _ = user.get_timing("k_hash")
+    user.set_timing(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        ab = 32 * n + n + 96 + 32 + 128 + 96 + 64 + 32 + 32 + 907   # credential + keypair + randomness read, presentation written
+        per_step = msm_ms / 1e3 / args.steps
+        achieved = ab * count / per_step / 1e9 if per_step > 0 else 0.0
+        print(json.dumps({
+            "metric": "credential presentations created/sec (secondary; AnonymousCredential::show)", "value": count * world * args.steps / elapsed,
+            "unit": "presentations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic (GPU-issued credentials)",
+            "config": {"workload": "show 2^16 credentials, 4 attributes (s S P e)", "credentials_per_gpu": count, "algorithmic_bytes_per_presentation": ab,
+                       "parallelism": "host-sharded x%d, no collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "kernel": "k_msm",
+                         "launches_per_step": msm_launches / args.steps, "avg_launch_ms": msm_ms / max(1, msm_launches),
+                         "kernel_ms_per_step": msm_ms / args.steps, "other_kernels_ms_per_step": {"k_hash": hash_ms / args.steps}},
+            "cpu_baseline": None}))
+    issuer.close()
+    user.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["c5"])
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["c5", "show"])
     ap.add_argument("--batch", type=int, default=0, help="presentations per GPU (default: the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -255,6 +367,8 @@ def main():
 
     if args.workload == "c5":
         return bench_issue(args, afx, batch, torch, dist, rank, world, local_rank)
+    if args.workload == "show":
+        return bench_show(args, afx, batch, torch, dist, rank, world, local_rank)
     n, layout, hide, count, fixture, desc = WORKLOADS[args.workload]
     if args.batch:
         count = args.batch

@@ -38,7 +38,8 @@ hipError_t afxk_decode(hipStream_t, const afx_decode_job* j, uint32_t n, uint32_
 hipError_t afxk_sccheck(hipStream_t, const afx_sccheck_job* j, uint32_t n, uint32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].sc; return hipSuccess; }
 hipError_t afxk_pointop(hipStream_t, const afx_pointop_job* j, uint32_t n, uint32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
 hipError_t afxk_scalarop(hipStream_t, const afx_scalarop_job* j, uint32_t n, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
-hipError_t afxk_msm(hipStream_t, const afx_msm_job* j, uint32_t n, uint32_t, const int32_t*, int32_t*, uint32_t*, uint32_t*, uint32_t) {
+hipError_t afxk_setup_postables(hipStream_t, const int32_t*, uint32_t, int32_t*) { return hipSuccess; }
+hipError_t afxk_msm(hipStream_t, const afx_msm_job* j, uint32_t n, uint32_t, const int32_t*, const int32_t*, int32_t*, uint32_t*, uint32_t*, uint32_t) {
   for (uint32_t i = 0; i < n; i++)
     for (uint32_t t = 0; t < j[i].n_terms; t++) sink += (uintptr_t)j[i].term[t].scalar;
   return hipSuccess;
