@@ -122,6 +122,8 @@ def lib():
         _LIB.afx_wire_cells_per_record.argtypes = [C.POINTER(Shape)]
         _LIB.afx_wire_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Shape), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         _LIB.afx_verify_presentations_wire.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        _LIB.afx_ctx_set_pipelining.argtypes = [C.c_void_p, C.c_int]
+        _LIB.afx_ctx_synchronize.argtypes = [C.c_void_p]
         _LIB.afx_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_get_timing.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         if hasattr(_LIB, "afx_issuer_keygen"):
@@ -156,6 +158,13 @@ class Context:
 
     def __del__(self):
         self.close()
+
+    def set_pipelining(self, enable):
+        """alternate successive *_dev calls between two streams (independent calls only); see afx_ctx_set_pipelining"""
+        check(lib().afx_ctx_set_pipelining(self.h, 1 if enable else 0))
+
+    def synchronize(self):
+        check(lib().afx_ctx_synchronize(self.h))
 
     def set_timing(self, enable):
         check(lib().afx_ctx_set_timing(self.h, 1 if enable else 0))

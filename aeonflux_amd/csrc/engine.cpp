@@ -33,10 +33,11 @@ void DevBuf::release(bool wipe) {
 // ------------------------------------------------------------------------------------------------
 // Assembler
 // ------------------------------------------------------------------------------------------------
-Assembler::Assembler(afx_ctx* c, uint32_t cnt, bool sizing) : ctx(c), count(cnt), sizing_(sizing) {
+Assembler::Assembler(afx_ctx* c, uint32_t cnt, bool sizing, int ln) : ctx(c), lane(ln), count(cnt), sizing_(sizing) {
   blob_.reserve(1 << 16);
-  blob_base_ = (uint8_t*)ctx->blob_dev[ctx->blob_next].p;
-  ws_base_ = sizing ? nullptr : (uint8_t*)ctx->ws.p;
+  afx_ctx::Lane& L = ctx->lane[lane];
+  blob_base_ = (uint8_t*)L.blob_dev[L.blob_next].p;
+  ws_base_ = sizing ? nullptr : (uint8_t*)L.ws.p;
   bad_ = (uint32_t*)ws_alloc(sizeof(uint32_t) * (size_t)count);
   Launch l;
   l.kind = L_FILL_BAD;
@@ -145,18 +146,19 @@ size_t Assembler::total_ws_bytes() const {
 
 int Assembler::run() {
   if (sizing_) { set_error("run() on a sizing assembler"); return AFX_E_BAD_ARGS; }
-  if (total_ws_bytes() > ctx->ws.cap) { set_error("workspace smaller than the sized plan"); return AFX_E_BAD_ARGS; }
+  afx_ctx::Lane& L = ctx->lane[lane];
+  if (total_ws_bytes() > L.ws.cap) { set_error("workspace smaller than the sized plan"); return AFX_E_BAD_ARGS; }
   int32_t* table_ws = (int32_t*)ws_alloc(max_table_slots * (size_t)count * AFX_VAR_TABLE_DWORDS * sizeof(int32_t));
   uint32_t* digit_ws = (uint32_t*)ws_alloc(max_digit_slots * 8 * (size_t)count * sizeof(uint32_t));
-  hipStream_t s = ctx->stream;
-  const int slot = ctx->blob_next;
-  if (blob_.size() > ctx->blob_dev[slot].cap || blob_.size() > ctx->blob_host_cap[slot]) { set_error("plan blob too large"); return AFX_E_BAD_ARGS; }
+  hipStream_t s = L.stream;
+  const int slot = L.blob_next;
+  if (blob_.size() > L.blob_dev[slot].cap || blob_.size() > L.blob_host_cap[slot]) { set_error("plan blob too large"); return AFX_E_BAD_ARGS; }
   // the pinned mirror of this slot may still be the source of an in-flight copy from two calls ago
-  AFX_HIP(hipEventSynchronize(ctx->blob_event[slot]));
-  memcpy(ctx->blob_host[slot], blob_.data(), blob_.size());
-  if (!blob_.empty()) AFX_HIP(hipMemcpyAsync(ctx->blob_dev[slot].p, ctx->blob_host[slot], blob_.size(), hipMemcpyHostToDevice, s));
-  AFX_HIP(hipEventRecord(ctx->blob_event[slot], s));
-  ctx->blob_next ^= 1;
+  AFX_HIP(hipEventSynchronize(L.blob_event[slot]));
+  memcpy(L.blob_host[slot], blob_.data(), blob_.size());
+  if (!blob_.empty()) AFX_HIP(hipMemcpyAsync(L.blob_dev[slot].p, L.blob_host[slot], blob_.size(), hipMemcpyHostToDevice, s));
+  AFX_HIP(hipEventRecord(L.blob_event[slot], s));
+  L.blob_next ^= 1;
   const int32_t* ft = (const int32_t*)ctx->d_fixed_tables.p;
   for (const Launch& l : launches) {
     const uint8_t* jobs = blob_base_ + l.jobs_off;
@@ -174,7 +176,15 @@ int Assembler::run() {
       case L_SCCHECK: AFX_HIP(afxk_sccheck(s, (const afx_sccheck_job*)jobs, l.njobs, bad_, count)); break;
       case L_POINTOP: AFX_HIP(afxk_pointop(s, (const afx_pointop_job*)jobs, l.njobs, bad_, count)); break;
       case L_SCALAROP: AFX_HIP(afxk_scalarop(s, (const afx_scalarop_job*)jobs, l.njobs, count)); break;
-      case L_MSM: AFX_HIP(afxk_msm(s, (const afx_msm_job*)jobs, l.njobs, l.max_fixed, ft, (const int32_t*)ctx->d_pos_tables.p, table_ws, digit_ws, bad_, count)); break;
+      case L_MSM: {
+        // pipelined lanes: the heavy kernel of one lane never runs beside the other lane's (only the light kernels
+        // overlap it), which keeps per-launch timings meaningful and the VALU free of two competing table working sets
+        afx_ctx::Lane& other = ctx->lane[lane ^ 1];
+        if (ctx->pipelining && other.msm_recorded) AFX_HIP(hipStreamWaitEvent(s, other.msm_done, 0));
+        AFX_HIP(afxk_msm(s, (const afx_msm_job*)jobs, l.njobs, l.max_fixed, ft, (const int32_t*)ctx->d_pos_tables.p, table_ws, digit_ws, bad_, count));
+        if (ctx->pipelining) { AFX_HIP(hipEventRecord(L.msm_done, s)); L.msm_recorded = true; }
+        break;
+      }
       case L_HASH: AFX_HIP(afxk_hash(s, (const afx_hash_program*)jobs, l.njobs, bad_, count)); break;
       case L_FROM_UNIFORM: AFX_HIP(afxk_from_uniform(s, l.in, l.out, l.out_var, count)); break;
       case L_REDUCE_WIDE: AFX_HIP(afxk_reduce_wide(s, l.in, l.out, count)); break;

@@ -73,14 +73,26 @@ struct afx_ctx {
   std::vector<afx::Enc> host_key;               // w, w', x0, x1, y...; wiped on destroy
   const int32_t* gen_ext(uint32_t id) const { return (const int32_t*)d_gen_ext.p + (size_t)id * AFX_VAR_DWORDS; }
   // per-call scratch (grow-only; zeroed on destroy)
-  afx::DevBuf ws, staging;
-  // plan blobs: two-deep ring of (pinned host, device) pairs so a call can be assembled while the
-  // previous one still runs; `blob_event[i]` marks the end of the copy that last used slot i
-  afx::DevBuf blob_dev[2];
-  void* blob_host[2] = { nullptr, nullptr };
-  size_t blob_host_cap[2] = { 0, 0 };
-  hipEvent_t blob_event[2] = { nullptr, nullptr };
-  int blob_next = 0;
+  afx::DevBuf staging;
+  // Execution lanes.  A lane = one HIP stream + its own workspace + a two-deep ring of (pinned host, device) plan
+  // blobs (`blob_event[i]` marks the end of the copy that last used slot i, so a call can be assembled while the
+  // previous one still runs).  Lane 0's stream is `stream`.  With pipelining off (default) every call runs on lane 0,
+  // strictly ordered; with afx_ctx_set_pipelining(ctx, 1) successive *_dev calls alternate between the two lanes so
+  // one call's launch tail and small kernels overlap the next call's work (the caller guarantees independence).
+  struct Lane {
+    hipStream_t stream = nullptr;
+    afx::DevBuf ws;
+    afx::DevBuf blob_dev[2];
+    void* blob_host[2] = { nullptr, nullptr };
+    size_t blob_host_cap[2] = { 0, 0 };
+    hipEvent_t blob_event[2] = { nullptr, nullptr };
+    int blob_next = 0;
+    hipEvent_t msm_done = nullptr;   // end of this lane's latest k_msm launch
+    bool msm_recorded = false;
+  } lane[2];
+  bool pipelining = false;
+  unsigned lane_next = 0;
+  int force_lane0 = 0;   // host-pointer front ends stay on lane 0 (they read results back on `stream`)
   // optional per-launch HIP-event timing on `stream` (bench.py's roofline figure)
   bool timing = false;
   struct TimedLaunch { int kind; hipEvent_t start, stop; };
@@ -111,8 +123,9 @@ struct Launch {
 class Assembler {
  public:
   // sizing == true: dry run that only measures workspace / blob needs (device addresses are meaningless)
-  Assembler(afx_ctx* ctx, uint32_t count, bool sizing);
+  Assembler(afx_ctx* ctx, uint32_t count, bool sizing, int lane = 0);
   afx_ctx* ctx;
+  int lane;
   uint32_t count;
   bool fail_all = false;      // statement-level failure for every item (reference would panic / reject all)
 

@@ -38,7 +38,8 @@ extern "C" void* afx_ctx_stream(const afx_ctx* ctx) { return ctx ? (void*)ctx->s
 static const char* const KIND_NAMES[] = { "k_fill_u32", "k_decode", "k_sccheck", "k_pointop", "k_scalarop", "k_msm", "k_hash",
                                           "k_from_uniform", "k_reduce_wide", "copy", "k_finish" };
 static int drain_timing(afx_ctx* c) {
-  AFX_HIP(hipStreamSynchronize(c->stream));
+  for (auto& L : c->lane)
+    if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
   for (auto& t : c->timed) {
     float ms = 0;
     AFX_HIP(hipEventElapsedTime(&ms, t.start, t.stop));
@@ -48,6 +49,24 @@ static int drain_timing(afx_ctx* c) {
     c->event_pool.push_back(t.stop);
   }
   c->timed.clear();
+  return AFX_OK;
+}
+extern "C" int afx_ctx_set_pipelining(afx_ctx* c, int enable) {
+  if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  AFX_HIP(hipSetDevice(c->device));
+  for (auto& L : c->lane)
+    if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
+  c->pipelining = enable != 0;
+  c->lane_next = 0;
+  for (auto& L : c->lane) L.msm_recorded = false;
+  return AFX_OK;
+}
+extern "C" int afx_ctx_synchronize(afx_ctx* c) {
+  if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  AFX_HIP(hipSetDevice(c->device));
+  for (auto& L : c->lane)
+    if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
   return AFX_OK;
 }
 extern "C" int afx_ctx_set_timing(afx_ctx* c, int enable) {
@@ -73,25 +92,30 @@ extern "C" int afx_ctx_get_timing(afx_ctx* c, const char* kernel, double* total_
 extern "C" void afx_ctx_destroy(afx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& L : c->lane)
+    if (L.stream) (void)hipStreamSynchronize(L.stream);
   // Zeroize + Drop of amacs::SecretKey (src/amacs.rs:64-82): wipe every copy of the key and anything derived
   c->d_key.release(true);
-  c->ws.release(true);
+  for (auto& L : c->lane) L.ws.release(true);
   c->staging.release(true);
   c->d_fixed_tables.release(true);
   c->d_pos_tables.release(true);
   c->d_gen_ext.release(true);
   c->d_gen_enc.release(false);
   c->d_consts.release(false);
-  for (int i = 0; i < 2; i++) {
-    c->blob_dev[i].release(true);
-    if (c->blob_host[i]) { memset(c->blob_host[i], 0, c->blob_host_cap[i]); (void)hipHostFree(c->blob_host[i]); }
-    if (c->blob_event[i]) (void)hipEventDestroy(c->blob_event[i]);
-  }
+  for (auto& L : c->lane)
+    for (int i = 0; i < 2; i++) {
+      L.blob_dev[i].release(true);
+      if (L.blob_host[i]) { memset(L.blob_host[i], 0, L.blob_host_cap[i]); (void)hipHostFree(L.blob_host[i]); }
+      if (L.blob_event[i]) (void)hipEventDestroy(L.blob_event[i]);
+    }
+  for (auto& L : c->lane)
+    if (L.msm_done) (void)hipEventDestroy(L.msm_done);
   for (auto& t : c->timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   for (auto& k : c->host_key) { volatile uint8_t* p = k.data(); for (int i = 0; i < 32; i++) p[i] = 0; }
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  for (auto& L : c->lane)
+    if (L.stream) (void)hipStreamDestroy(L.stream);
   delete c;
 }
 
@@ -112,7 +136,8 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   c->n = n;
   c->g = n < 3 ? 3 : n;
   AFX_HIP(hipSetDevice(device));
-  AFX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (auto& L : c->lane) AFX_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+  c->stream = c->lane[0].stream;
   const uint32_t np = 9 + c->g + n;
   c->ngen = np + 3;
   c->gen_enc.assign(c->ngen, Enc{});
@@ -143,12 +168,14 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
       (rc = c->d_gen_ext.ensure(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)c->ngen)) || (rc = c->d_key.ensure(32 * (size_t)(4 + n))) ||
       (rc = c->d_consts.ensure(64)) || (rc = c->staging.ensure(32 * (size_t)c->ngen + 4 * (size_t)c->ngen)))
     return rc;
-  for (int i = 0; i < 2; i++) {
-    if ((rc = c->blob_dev[i].ensure(BLOB_CAP))) return rc;
-    AFX_HIP(hipHostMalloc(&c->blob_host[i], BLOB_CAP, hipHostMallocDefault));
-    c->blob_host_cap[i] = BLOB_CAP;
-    AFX_HIP(hipEventCreateWithFlags(&c->blob_event[i], hipEventDisableTiming));
-  }
+  for (auto& L : c->lane)
+    for (int i = 0; i < 2; i++) {
+      if ((rc = L.blob_dev[i].ensure(BLOB_CAP))) return rc;
+      AFX_HIP(hipHostMalloc(&L.blob_host[i], BLOB_CAP, hipHostMallocDefault));
+      L.blob_host_cap[i] = BLOB_CAP;
+      AFX_HIP(hipEventCreateWithFlags(&L.blob_event[i], hipEventDisableTiming));
+    }
+  for (auto& L : c->lane) AFX_HIP(hipEventCreateWithFlags(&L.msm_done, hipEventDisableTiming));
   std::vector<uint8_t> flat(32 * (size_t)c->ngen);
   for (uint32_t i = 0; i < c->ngen; i++) memcpy(flat.data() + 32 * (size_t)i, c->gen_enc[i].data(), 32);
   AFX_HIP(hipMemcpyAsync(c->d_gen_enc.p, flat.data(), flat.size(), hipMemcpyHostToDevice, c->stream));

@@ -24,15 +24,17 @@ using BuildFn = std::function<void(Assembler&, size_t /*chunk offset*/, uint32_t
 
 inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build) {
   AFX_HIP(hipSetDevice(c->device));
+  // all chunks of one call run on one lane; calls alternate lanes only when the caller switched pipelining on
+  const int lane = (c->pipelining && !c->force_lane0) ? (int)(c->lane_next++ & 1u) : 0;
   for (size_t off = 0; off < count; off += CHUNK) {
     const uint32_t cc = (uint32_t)std::min<size_t>(CHUNK, count - off);
     try {
-      Assembler sizing(c, cc, true);
+      Assembler sizing(c, cc, true, lane);
       build(sizing, off, cc);
-      int rc = c->ws.ensure(sizing.total_ws_bytes());
+      int rc = c->lane[lane].ws.ensure(sizing.total_ws_bytes());
       if (rc) return rc;
       if (sizing.blob_bytes() > BLOB_CAP) { set_error("plan blob exceeds its fixed capacity"); return AFX_E_BAD_ARGS; }
-      Assembler as(c, cc, false);
+      Assembler as(c, cc, false, lane);
       build(as, off, cc);
       if ((rc = as.run())) return rc;
     } catch (const std::exception& e) {
@@ -87,7 +89,11 @@ struct Stager {
   size_t bytes = 0;
   struct Copy { size_t off; const uint8_t* src; size_t len; };
   std::vector<Copy> copies;
-  explicit Stager(afx_ctx* ctx) : c(ctx) {}
+  // a staged (host-pointer) call reads its results back on lane 0's stream: keep its device work on lane 0
+  explicit Stager(afx_ctx* ctx) : c(ctx) { c->force_lane0++; }
+  ~Stager() { c->force_lane0--; }
+  Stager(const Stager&) = delete;
+  Stager& operator=(const Stager&) = delete;
   // reserve `len` bytes, to be filled from host `src` (or left for output when src == nullptr); returns offset
   size_t add(const uint8_t* src, size_t len) {
     const size_t off = (bytes + 255) & ~size_t(255);

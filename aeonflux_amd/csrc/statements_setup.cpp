@@ -35,11 +35,12 @@ static int bare_ctx(afx_ctx** out, int device) {
   }
   afx_ctx* c = new afx_ctx();
   c->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->lane[0].stream, hipStreamNonBlocking) != hipSuccess) {
     afx_ctx_destroy(c);
     set_error("hipStreamCreate failed");
     return AFX_E_HIP;
   }
+  c->stream = c->lane[0].stream;
   *out = c;
   return AFX_OK;
 }

@@ -345,6 +345,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="presentations per GPU (default: the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipelining", action="store_true", help="alternate steps between the engine's two streams (measured slower: the "
+                    "path is VALU-bound, overlap only adds contention; default off)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL; the driver's launch) or gloo (testing two ranks on one GPU)")
     args = ap.parse_args()
 
@@ -411,6 +413,7 @@ def main():
     if not np.array_equal(got, want):
         bad = np.nonzero(got != want)[0]
         raise SystemExit("status mismatch at %d items, first %s" % (bad.size, bad[:8]))
+    issuer.set_pipelining(args.pipelining)
     issuer.set_timing(True)
     fence()
     t0 = time.perf_counter()
@@ -422,6 +425,7 @@ def main():
     hash_ms, _ = issuer.get_timing("k_hash")
     dec_ms, _ = issuer.get_timing("k_decode")
     issuer.set_timing(False)
+    issuer.set_pipelining(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -484,6 +488,7 @@ def main():
             "data": "synthetic (GPU-issued and GPU-shown credentials, random attribute values, 1% corrupted; all distinct)",
             "config": {"workload": desc, "presentations_per_gpu": count, "attributes": n, "shape": layout, "hidden": hide,
                        "algorithmic_bytes_per_presentation": ab, "parallelism": "host-sharded x%d, no collective" % world,
+                       "step_pipelining": "2 streams" if args.pipelining else "off",
                        "input_generation_s": round(gen_s, 2), "host_pointer_api_presentations_per_s": pcie},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": measured_traffic(args.workload),
                          "kernel": "k_msm", "launches_per_step": msm_launches / args.steps,

@@ -124,6 +124,13 @@ uint32_t afx_ctx_n_attributes(const afx_ctx* ctx);
 /* The HIP stream (hipStream_t) every call on this ctx launches on; for event timing in bench.py. */
 void* afx_ctx_stream(const afx_ctx* ctx);
 
+/* Cross-call pipelining (off by default).  Off: every *_dev call runs on afx_ctx_stream(ctx), strictly ordered.
+ * On: successive *_dev calls alternate between two internal streams (each with its own workspace), so the launch
+ * tail and small kernels of one call overlap the next call's work; the caller guarantees the calls are independent
+ * (they may share read-only inputs) and waits with afx_ctx_synchronize (or a device-wide synchronise). */
+int afx_ctx_set_pipelining(afx_ctx* ctx, int enable);
+int afx_ctx_synchronize(afx_ctx* ctx);
+
 /* Per-kernel device timing with HIP events on afx_ctx_stream(ctx) (measurement aid; off by default).
  * set_timing(ctx, 1) resets the counters and starts recording every launch; get_timing synchronises the
  * stream and returns the summed duration and launch count of one kernel ("k_msm", "k_hash", "k_decode",
