@@ -103,9 +103,9 @@ void merlin_challenge_bytes(merlin_transcript* t, const uint8_t* label, size_t l
 
 /* ---- zkp 0.7 toolbox (Schnorr constraint systems, CompactProof) ---- */
 #define ZKP_MAX_SCALARS 48
-#define ZKP_MAX_POINTS  96
+#define ZKP_MAX_POINTS  128
 #define ZKP_MAX_CONSTRAINTS 48
-#define ZKP_MAX_TERMS 24
+#define ZKP_MAX_TERMS 72
 typedef struct {
   int lhs;
   int n;

@@ -244,3 +244,50 @@ def test_issuer_keygen_matches_oracle():
         out = C.create_string_buffer(64)
         afx.check(afx.lib().afx_issuer_keygen(0, params, len(params), key[:-32], len(key) - 32, W, out))
         assert W.raw == key[-32:] and out.raw == ip
+
+
+def test_maximum_attribute_count_full_cycle():
+    """AFX_MAX_ATTRIBUTES = 32 attributes (mixed kinds, hidden scalars and trailing hidden points): issue, the user's
+    issuance check, show and the issuer's verify on the GPU, all byte-identical to the oracle."""
+    import aeonflux_amd as afx
+    from aeonflux_amd import batch
+    n, layout, count = 32, "SSSSSSSSSSSSPPPPPPPPPPPPSSSSEEEE", 5
+    hide = [0, 5, 11, 24, 28, 29, 30, 31]
+    d = make_credentials(n, layout, count, b"gpu-max-attrs")
+    creds, user, issuer = d["creds"], d["user"], d["issuer"]
+    ctx = afx.Context(d["params"], d["key"], d["ip"])
+    kinds = creds[0]["kinds"]
+    col = lambda f: np.stack([np.frombuffer(f(c), np.uint8) for c in creds])
+    values = np.stack([col(lambda c, i=i: c["values"][i][:32]) for i in range(n)])
+    iss, st = batch.issue(ctx, kinds, values, col(lambda c: c["rnd"][0]), col(lambda c: c["rnd"][1]), col(lambda c: c["rnd"][2]))
+    assert st.tolist() == [0] * count
+    for i, c in enumerate(creds):
+        assert (iss["t"][i].tobytes(), iss["U"][i].tobytes(), iss["V"][i].tobytes(), iss["challenge"][i].tobytes()) == (c["t"], c["U"], c["V"], c["challenge"])
+        assert [iss["responses"][k, i].tobytes() for k in range(n + 5)] == c["responses"]
+    assert batch.verify_issuances(ctx, kinds, values, iss).tolist() == [0] * count
+    iss["responses"][n + 4, 2, 0] ^= 1
+    assert batch.verify_issuances(ctx, kinds, values, iss).tolist() == [0, 0, 1, 0, 0]
+    skinds = list(kinds)
+    for i in hide:
+        skinds[i] = 1 if skinds[i] == 0 else 4
+    take = d["take"]
+    kps = [user.keypair_derive(take(64)) for _ in range(count)]
+    zw, sd, es = [take(64) for _ in range(count)], [take(32) for _ in range(count)], [take(32 * 4) for _ in range(count)]
+    want = [user.show(skinds, c["values"], c["t"], c["U"], c["V"], kp, z, s, e)[1] for c, kp, z, s, e in zip(creds, kps, zw, sd, es)]
+    M2 = np.stack([col(lambda c, i=i: c["values"][i][32:64]) for i in range(n)])
+    m3 = np.stack([col(lambda c, i=i: c["values"][i][64:96]) for i in range(n)])
+    kpd = {f: np.stack([np.frombuffer(k[32 * j:32 * j + 32], np.uint8) for k in kps]) for j, f in enumerate(("a", "a0", "a1", "pk"))}
+    esr = np.stack([np.stack([np.frombuffer(e[32 * j:32 * j + 32], np.uint8) for e in es]) for j in range(4)])
+    pres, shape, st = batch.show(ctx, skinds, values, col(lambda c: c["t"]), col(lambda c: c["U"]), col(lambda c: c["V"]), kpd,
+                                 np.stack([np.frombuffer(z, np.uint8) for z in zw]), np.stack([np.frombuffer(s, np.uint8) for s in sd]), esr, M2, m3)
+    assert st.tolist() == [0] * count
+    for i, p in enumerate(want):
+        assert pres["challenge"][i].tobytes() == bytes(p.challenge)
+        assert all(pres["responses"][k, i].tobytes() == bytes(p.responses[k]) for k in range(p.n_responses))
+        assert all(pres["C_y"][k, i].tobytes() == bytes(p.C_y[k]) for k in range(n))
+        assert all(pres["enc"][e]["E2"][i].tobytes() == bytes(p.enc[e].E2) and pres["enc"][e]["challenge"][i].tobytes() == bytes(p.enc[e].challenge) for e in range(4))
+    assert [issuer.verify_presentation(p) for p in want] == [0] * count
+    assert batch.verify_presentations(ctx, shape, pres).tolist() == [0] * count
+    pres["C_y"][17, 3, 4] ^= 2
+    assert batch.verify_presentations(ctx, shape, pres).tolist() == [0, 0, 0, 1, 0]
+    ctx.close()
