@@ -70,26 +70,31 @@ AFX_DEV ge_p3 p3_load_uniform(const int32_t* c40) {
   for (int l = 0; l < 10; l++) { p.X.v[l] = c40[l]; p.Y.v[l] = c40[10 + l]; p.Z.v[l] = c40[20 + l]; p.T.v[l] = c40[30 + l]; }
   return p;
 }
-// one window-table entry (cached form), 40 contiguous dwords, 16-byte aligned
+// one window-table entry (cached form): four field elements in canonical 32-byte form, 128 contiguous bytes,
+// 16-byte aligned = exactly two 64-byte HBM sectors per gather (the 40-limb form straddled 3.5 on average)
 AFX_DEV void cached_store(int32_t* p, const ge_cached& q) {
-  int32_t v[40];
+  uint32_t w[32];
+  fe_tobytes(w, q.YpX);
+  fe_tobytes(w + 8, q.YmX);
+  fe_tobytes(w + 16, q.Z);
+  fe_tobytes(w + 24, q.T2d);
+  uint4* d = reinterpret_cast<uint4*>(p);
 #pragma unroll
-  for (int l = 0; l < 10; l++) { v[l] = q.YpX.v[l]; v[10 + l] = q.YmX.v[l]; v[20 + l] = q.Z.v[l]; v[30 + l] = q.T2d.v[l]; }
-  int4* d = reinterpret_cast<int4*>(p);
-#pragma unroll
-  for (int i = 0; i < 10; i++) d[i] = make_int4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+  for (int i = 0; i < 8; i++) d[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 AFX_DEV ge_cached cached_load(const int32_t* p) {
-  const int4* s = reinterpret_cast<const int4*>(p);
-  int32_t v[40];
+  const uint4* s = reinterpret_cast<const uint4*>(p);
+  uint32_t w[32];
 #pragma unroll
-  for (int i = 0; i < 10; i++) {
-    const int4 t = s[i];
-    v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+  for (int i = 0; i < 8; i++) {
+    const uint4 t = s[i];
+    w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
   }
   ge_cached q;
-#pragma unroll
-  for (int l = 0; l < 10; l++) { q.YpX.v[l] = v[l]; q.YmX.v[l] = v[10 + l]; q.Z.v[l] = v[20 + l]; q.T2d.v[l] = v[30 + l]; }
+  q.YpX = fe_frombytes(w);
+  q.YmX = fe_frombytes(w + 8);
+  q.Z = fe_frombytes(w + 16);
+  q.T2d = fe_frombytes(w + 24);
   return q;
 }
 
@@ -275,12 +280,12 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_ta
     const ge_p3 P = var_load(job->term[t].var, count, item);
     const ge_cached cP = ge_p3_to_cached_reduced(P);
     cached_store(tab, ge_cached_identity());
-    cached_store(tab + AFX_VAR_DWORDS, cP);
+    cached_store(tab + AFX_TABLE_ENTRY_DWORDS, cP);
     ge_p3 Q = P;
 #pragma unroll 1
     for (int k = 2; k < AFX_TABLE_ENTRIES; k++) {
       Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
-      cached_store(tab + k * AFX_VAR_DWORDS, ge_p3_to_cached_reduced(Q));
+      cached_store(tab + k * AFX_TABLE_ENTRY_DWORDS, ge_p3_to_cached_reduced(Q));
     }
   }
 
@@ -327,7 +332,7 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_ta
       const bool neg = (d < 0) != (job->term[t].negate != 0);
       const int32_t* tab = table_ws + ((size_t)(tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
       done++;
-      acc = msm_finish_add(ge_add_cached(acc, cached_load(tab + idx * AFX_VAR_DWORDS), neg), done != nadd || w == 0);
+      acc = msm_finish_add(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), neg), done != nadd || w == 0);
     }
     if (fixed_now) {
 #pragma unroll 1

@@ -14,7 +14,8 @@
 #define AFX_VAR_DWORDS 40              /* extended point: X,Y,Z,T x 10 limbs */
 #define AFX_NIELS_DWORDS 30            /* affine niels: y+x, y-x, 2dxy */
 #define AFX_FIXED_TABLE_DWORDS 3872    /* AFX_FIXED_ENTRIES * AFX_NIELS_DWORDS = 3870, padded to a 16-byte multiple */
-#define AFX_VAR_TABLE_DWORDS (AFX_TABLE_ENTRIES * AFX_VAR_DWORDS)
+#define AFX_TABLE_ENTRY_DWORDS 32       /* a window-table entry: 4 field elements as canonical 256-bit words = 128 B = 2 HBM sectors */
+#define AFX_VAR_TABLE_DWORDS (AFX_TABLE_ENTRIES * AFX_TABLE_ENTRY_DWORDS)
 #define AFX_BLOCK 256
 
 /* per-item failure bits OR-ed into the `bad` word of an item */
