@@ -150,3 +150,28 @@ def multiscalar_mul(ctx, scalars, points):
     ok = np.zeros(cnt, np.uint8)
     check(lib().afx_multiscalar_mul(ctx.h, nt, scalars.ctypes.data, points.ctypes.data, cnt, out.ctypes.data, ok.ctypes.data))
     return out, ok
+
+
+def shape_key(shape):
+    """the batch-uniform part of a presentation, as a hashable key (SURVEY.md §7 "heterogeneous batches")"""
+    return bytes(shape)
+
+
+def verify_mixed(ctx, items):
+    """Issuer::verify over presentations of different shapes: items = [(Shape, presentation dict with count 1 or more)].
+    Groups by shape on the host, runs one batch per group, returns the statuses in the order given."""
+    groups = {}
+    for pos, (shape, p) in enumerate(items):
+        groups.setdefault(shape_key(shape), (shape, []))[1].append((pos, p))
+    out = [None] * len(items)
+    for shape, members in groups.values():
+        cat = {f: np.concatenate([_u8(p[f]) for _, p in members], axis=-2) for f in PRES_FIELDS}
+        cat["enc"] = [{f: np.concatenate([_u8(p["enc"][e][f]) for _, p in members], axis=-2) for f in ENC_FIELDS}
+                      for e in range(shape.n_enc_proofs)]
+        st = verify_presentations(ctx, shape, cat)
+        o = 0
+        for pos, p in members:
+            k = _u8(p["challenge"]).shape[0]
+            out[pos] = st[o:o + k]
+            o += k
+    return out

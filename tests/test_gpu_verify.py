@@ -127,3 +127,30 @@ def test_empty_and_chunk_boundary_batches():
     ctx.close()
     assert np.array_equal(got, np.concatenate([want] * reps)[:total])
     assert 0 < got.sum() < total
+
+
+def test_mixed_shapes_grouped_on_the_host():
+    """presentations of one issuer with different hide/reveal choices (different shapes) in one request stream"""
+    import aeonflux_amd as afx
+    from aeonflux_amd import batch
+    from tests.helpers import make_credentials
+    from tests.soa import presentation_arrays, shape_of
+    d = make_credentials(4, "SSPE", 12, b"gpu-mixed")
+    take, user, issuer = d["take"], d["user"], d["issuer"]
+    items, want = [], []
+    for i, cr in enumerate(d["creds"]):
+        hide = [[0, 3], [3], [0, 1], [], [1, 3]][i % 5]
+        kinds = list(cr["kinds"])
+        for j in hide:
+            kinds[j] = 1 if kinds[j] == 0 else 4
+        nsp = sum(1 for k in kinds if k == 4)
+        st, p = user.show(kinds, cr["values"], cr["t"], cr["U"], cr["V"], user.keypair_derive(take(64)), take(64), take(32), take(32 * nsp))
+        assert st == 0
+        if i in (4, 7):
+            p.C_V[3] ^= 1
+        want.append(issuer.verify_presentation(p))
+        items.append((afx.Shape.from_buffer_copy(bytes(shape_of(p))), presentation_arrays([p])))
+    ctx = afx.Context(d["params"], d["key"], d["ip"])
+    got = batch.verify_mixed(ctx, items)
+    ctx.close()
+    assert [int(g[0]) for g in got] == want and sum(want) == 2
