@@ -237,9 +237,19 @@ int SchnorrBuilder::allocate_point(const char* label, const PointVar& p) {
 }
 void SchnorrBuilder::constrain(int lhs, const std::vector<std::pair<int, int>>& terms) { constraints_.push_back({ lhs, terms }); }
 
-afx_msm_term SchnorrBuilder::term_for(const uint8_t* scalar, uint32_t stride, const PointVar& p, bool negate) {
+afx_msm_term SchnorrBuilder::term_for(const uint8_t* scalar, uint32_t stride, const PointVar& p, bool negate, std::vector<afx_scalarop_job>* pre_ops) {
   afx_msm_term t;
   memset(&t, 0, sizeof t);
+  if (!p.is_const && p.has_alt && pre_ops) {
+    // s * (m * G) = (s*m) * G: a fixed-base term (8-bit windows, no per-lane table) instead of a variable-base one
+    uint8_t* prod = as_.new_enc();
+    afx_scalarop_job o;
+    memset(&o, 0, sizeof o);
+    o.a = scalar; o.a_stride = stride; o.b = p.alt_scalar; o.b_stride = 32; o.out = prod;
+    pre_ops->push_back(o);
+    t.scalar = prod; t.scalar_stride = 32; t.fixed_idx = (int32_t)p.alt_gen; t.var = nullptr; t.negate = negate ? 1u : 0u;
+    return t;
+  }
   t.scalar = scalar;
   t.scalar_stride = stride;
   if (p.is_const) { t.fixed_idx = (int32_t)p.gen; t.var = nullptr; t.negate = (negate != p.neg) ? 1u : 0u; }
@@ -267,12 +277,13 @@ afx_hash_program SchnorrBuilder::make_program(const StrobeSim& sim) {
   return p;
 }
 
-void SchnorrBuilder::verify_compact(const uint8_t* challenge_dev, std::vector<afx_msm_job>& msm_out, std::vector<afx_hash_program>& hash_out) {
+void SchnorrBuilder::verify_compact(const uint8_t* challenge_dev, std::vector<afx_msm_job>& msm_out, std::vector<afx_hash_program>& hash_out,
+                                    std::vector<afx_scalarop_job>* pre_ops) {
   // R_j = sum resp[s] * P  - c * LHS, appended as "blindcom"
   for (auto& cn : constraints_) {
     std::vector<afx_msm_term> terms;
-    for (auto& sp : cn.second) terms.push_back(term_for(scalars_[sp.first].dev, scalars_[sp.first].stride, points_[sp.second], false));
-    terms.push_back(term_for(challenge_dev, 32, points_[cn.first], true));
+    for (auto& sp : cn.second) terms.push_back(term_for(scalars_[sp.first].dev, scalars_[sp.first].stride, points_[sp.second], false, pre_ops));
+    terms.push_back(term_for(challenge_dev, 32, points_[cn.first], true, pre_ops));
     afx_msm_job j;
     memset(&j, 0, sizeof j);
     order_terms(j, terms);
@@ -289,7 +300,8 @@ void SchnorrBuilder::verify_compact(const uint8_t* challenge_dev, std::vector<af
 
 void SchnorrBuilder::prove_compact(const uint8_t* rng_seed_dev, uint8_t* challenge_out, uint8_t* responses_out, size_t response_row_stride,
                                    std::vector<afx_hash_program>& rng_hash, std::vector<afx_msm_job>& msm_out,
-                                   std::vector<afx_hash_program>& chal_hash, std::vector<afx_scalarop_job>& resp_ops) {
+                                   std::vector<afx_hash_program>& chal_hash, std::vector<afx_scalarop_job>& resp_ops,
+                                   std::vector<afx_scalarop_job>* pre_ops) {
   const size_t ns = scalars_.size();
   // TranscriptRngBuilder: clone, rekey with every witness, finalize with the external 32 bytes
   StrobeSim rng = sim_;
@@ -312,7 +324,7 @@ void SchnorrBuilder::prove_compact(const uint8_t* rng_seed_dev, uint8_t* challen
   // commitments R_j = sum blind[s] * P
   for (auto& cn : constraints_) {
     std::vector<afx_msm_term> terms;
-    for (auto& sp : cn.second) terms.push_back(term_for(blind[sp.first], 32, points_[sp.second], false));
+    for (auto& sp : cn.second) terms.push_back(term_for(blind[sp.first], 32, points_[sp.second], false, pre_ops));
     afx_msm_job j;
     memset(&j, 0, sizeof j);
     order_terms(j, terms);

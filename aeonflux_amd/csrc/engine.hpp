@@ -184,6 +184,11 @@ struct PointVar {
   bool neg = false;
   const int32_t* var = nullptr;
   const uint8_t* enc_dev = nullptr;
+  // optional fixed-base form of a variable point: P = alt_scalar[item] * G_alt_gen (e.g. M_i = m_i * G_m_i,
+  // src/amacs.rs:234-235).  A term s*P then runs as the fixed-base term (s*alt_scalar)*G, one scalar product away.
+  bool has_alt = false;
+  uint32_t alt_gen = 0;
+  const uint8_t* alt_scalar = nullptr;
   static PointVar Const(uint32_t gen, bool neg = false) { PointVar p; p.is_const = true; p.gen = gen; p.neg = neg; return p; }
   static PointVar Var(const int32_t* var, const uint8_t* enc) { PointVar p; p.is_const = false; p.var = var; p.enc_dev = enc; return p; }
 };
@@ -203,17 +208,20 @@ class SchnorrBuilder {
   int allocate_point(const char* label, const PointVar& p);
   void constrain(int lhs, const std::vector<std::pair<int, int>>& terms);
   // Verifier::verify_compact over the batch: commitments, transcript, challenge comparison
-  void verify_compact(const uint8_t* challenge_dev, std::vector<afx_msm_job>& msm_out, std::vector<afx_hash_program>& hash_out);
+  // `pre_ops` receives the scalar products that fixed-base forms of variable points need (run them before msm_out)
+  void verify_compact(const uint8_t* challenge_dev, std::vector<afx_msm_job>& msm_out, std::vector<afx_hash_program>& hash_out,
+                      std::vector<afx_scalarop_job>* pre_ops = nullptr);
   // Prover::prove_compact over the batch.  Fills: rng hash program (blindings), commitment msm jobs,
   // challenge hash program, response scalar ops.  rng_seed_dev: [count][32].
   void prove_compact(const uint8_t* rng_seed_dev, uint8_t* challenge_out, uint8_t* responses_out /* [nsc][count][32] */,
                      size_t response_row_stride, std::vector<afx_hash_program>& rng_hash, std::vector<afx_msm_job>& msm_out,
-                     std::vector<afx_hash_program>& chal_hash, std::vector<afx_scalarop_job>& resp_ops);
+                     std::vector<afx_hash_program>& chal_hash, std::vector<afx_scalarop_job>& resp_ops,
+                     std::vector<afx_scalarop_job>* pre_ops = nullptr);
   size_t num_scalars() const { return scalars_.size(); }
 
  private:
   int field_of(const uint8_t* dev);
-  afx_msm_term term_for(const uint8_t* scalar, uint32_t stride, const PointVar& p, bool negate);
+  afx_msm_term term_for(const uint8_t* scalar, uint32_t stride, const PointVar& p, bool negate, std::vector<afx_scalarop_job>* pre_ops);
   afx_hash_program make_program(const StrobeSim& sim);
   Assembler& as_;
   StrobeSim sim_;

@@ -82,6 +82,7 @@ static void messages_from_attributes(Assembler& as, const afx_attributes_soa& a,
       uint8_t* e = as.new_enc();
       msm.push_back(mk_job({ mk_term(val, 32, nullptr, (int32_t)c->id_Gm(i), false) }, nullptr, v, e, reject_identity));
       M[i] = PointVar::Var(v, e);
+      M[i].has_alt = true; M[i].alt_gen = c->id_Gm(i); M[i].alt_scalar = val;   // M_i = m_i * G_m_i
     } else {
       decode.push_back({ val, v, reject_identity ? 1u : 0u });
       M[i] = PointVar::Var(v, val);
@@ -128,7 +129,7 @@ extern "C" int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* 
     iv.tU = PointVar::Var(v_tU, e_tU);
     SchnorrBuilder v(as, "2019/1416 anonymous credential", "2019/1416 issuance proof");
     issuance_statement(v, c, iv);
-    v.verify_compact(row(s.challenge, 0), js.msm2, js.hash);
+    v.verify_compact(row(s.challenge, 0), js.msm2, js.hash, &js.scalarop);   // (resp_y * m_i) * G_m_i products: inputs only
     emit(as, js, status_dev + off, AFX_ST_VERIFICATION_FAILURE);
   });
 }
@@ -203,9 +204,10 @@ extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, c
     issuance_statement(p, c, iv);
     std::vector<afx_hash_program> rng_hash, chal_hash;
     std::vector<afx_msm_job> commit;
-    std::vector<afx_scalarop_job> resp;
-    p.prove_compact(r.rng_seed + off * 32, orow(o.challenge, 0), orow(o.responses, 0), 32 * count, rng_hash, commit, chal_hash, resp);
+    std::vector<afx_scalarop_job> resp, blind_products;
+    p.prove_compact(r.rng_seed + off * 32, orow(o.challenge, 0), orow(o.responses, 0), 32 * count, rng_hash, commit, chal_hash, resp, &blind_products);
     as.hash(rng_hash);
+    as.scalarop(blind_products);   // (blinding_y * m_i) for the scalar attributes' fixed-base terms
     as.msm(commit);
     as.hash(chal_hash);
     as.scalarop(resp);
