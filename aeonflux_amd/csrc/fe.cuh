@@ -8,6 +8,11 @@
 // FieldElement [3P] does (e.g. under /root/reference/src/nizk/presentation.rs:342-351); only canonical
 // encodings are contractual.
 //
+// The kernels built on this file are VALU-issue bound and their time is the sum of per-opcode issue costs
+// (profiles/r01_valu_rates_ubench.txt, profiles/r01_fe_rates_ubench.txt), so the code below is written against
+// that price list: 64-bit adds (v_lshl_add_u64, ~4.6-6.3 cycles) are avoided by feeding each column's carry into
+// the next column's mad chain as its addend.
+//
 // Bounds discipline (same as the classic 10-limb schedule): fe_sq and fe_mul's SECOND operand accept
 // limbs up to 1.65*2^26 (even) / 1.65*2^25 (odd) in magnitude (the 19x / 38x premultiplications must
 // fit int32); fe_mul's FIRST operand may be up to 4*2^26 / 4*2^25 (column sums stay < 2^63: worst
@@ -88,33 +93,6 @@ AFX_DEV fe fe_carry64(int64_t h[10]) {
   return r;
 }
 
-// Same chain for column sums H[k] = h[k] + ROUND[k] whose rounding constants (2^25 for even k, 2^24 for odd k)
-// were folded into the accumulators' initial values: the first visit of every limb needs no 64-bit rounding
-// add, and its remainder comes from the low dword alone: h - (c << b) = ((H & (2^b - 1)) - 2^(b-1)).
-AFX_DEV fe fe_carry64_prerounded(int64_t H[10]) {
-  int64_t c;
-  int32_t r[10];
-  c = H[0] >> 26; H[1] += c; r[0] = (int32_t)((uint32_t)H[0] & 0x3ffffffu) - (1 << 25);
-  c = H[4] >> 26; H[5] += c; r[4] = (int32_t)((uint32_t)H[4] & 0x3ffffffu) - (1 << 25);
-  c = H[1] >> 25; H[2] += c; r[1] = (int32_t)((uint32_t)H[1] & 0x1ffffffu) - (1 << 24);
-  c = H[5] >> 25; H[6] += c; r[5] = (int32_t)((uint32_t)H[5] & 0x1ffffffu) - (1 << 24);
-  c = H[2] >> 26; H[3] += c; r[2] = (int32_t)((uint32_t)H[2] & 0x3ffffffu) - (1 << 25);
-  c = H[6] >> 26; H[7] += c; r[6] = (int32_t)((uint32_t)H[6] & 0x3ffffffu) - (1 << 25);
-  c = H[3] >> 25; r[3] = (int32_t)((uint32_t)H[3] & 0x1ffffffu) - (1 << 24);
-  int64_t h4 = (int64_t)r[4] + c;                                   // second visit of limb 4: plain value
-  c = H[7] >> 25; H[8] += c; r[7] = (int32_t)((uint32_t)H[7] & 0x1ffffffu) - (1 << 24);
-  c = (h4 + (1LL << 25)) >> 26; H[5] = (int64_t)r[5] + c; r[4] = (int32_t)(h4 - (c << 26));
-  c = H[8] >> 26; H[9] += c; r[8] = (int32_t)((uint32_t)H[8] & 0x3ffffffu) - (1 << 25);
-  c = H[9] >> 25; r[9] = (int32_t)((uint32_t)H[9] & 0x1ffffffu) - (1 << 24);
-  int64_t h0 = (int64_t)r[0] + c * 19;                              // second visit of limb 0
-  c = (h0 + (1LL << 25)) >> 26; r[0] = (int32_t)(h0 - (c << 26));
-  int64_t h1 = (int64_t)r[1] + c;
-  fe o;
-  o.v[0] = r[0]; o.v[1] = (int32_t)h1; o.v[2] = r[2]; o.v[3] = r[3]; o.v[4] = r[4];
-  o.v[5] = (int32_t)H[5]; o.v[6] = r[6]; o.v[7] = r[7]; o.v[8] = r[8]; o.v[9] = r[9];
-  return o;
-}
-
 // re-normalise a lazily added value (any limbs that fit int32)
 AFX_DEV fe fe_carry(const fe& f) {
   int64_t h[10];
@@ -123,27 +101,48 @@ AFX_DEV fe fe_carry(const fe& f) {
   return fe_carry64(h);
 }
 
+// Pins a partial sum: the volatile (input-only, empty) statement forces the value to exist at this point, which keeps
+// LLVM's reassociation from pulling the carry out of the mad chain into a separate 64-bit add.  It emits no code and,
+// having no outputs, triggers none of the hazard no-ops the compiler puts after inline-asm definitions.
+#define AFX_PIN(x) asm volatile("" ::"v"(x))
+
+// Schoolbook product, columns in order 0..9: column k's mad chain starts from the carry out of column k-1 (the
+// mad's 64-bit addend), so the carry chain needs no 64-bit additions.  Each carry arrives with the next limb's
+// rounding constant already in it (2^50 added to the high dword before the shift), which makes every limb come out
+// centred: r_k = (H_k mod 2^b) - 2^(b-1).
 AFX_DEV fe fe_mul(const fe& f, const fe& g) {
   int32_t g19[10], f2[10];
 #pragma unroll
   for (int i = 0; i < 10; i++) {
-    g19[i] = (int32_t)(19u * (uint32_t)g.v[i]);  // only in-bounds entries are consumed
+    g19[i] = (int32_t)(19u * (uint32_t)g.v[i]);
     f2[i] = (int32_t)(2u * (uint32_t)f.v[i]);
   }
-  int64_t h[10];
+  fe r;
+  int64_t c = 1LL << 25;  // rounding constant of limb 0; later carries arrive with the next limb's constant folded in
+  uint32_t u0 = 0;
 #pragma unroll
-  for (int k = 0; k < 10; k++) h[k] = (k & 1) ? (1LL << 24) : (1LL << 25);
+  for (int k = 0; k < 10; k++) {
+    int64_t H = c;
 #pragma unroll
-  for (int i = 0; i < 10; i++) {
-#pragma unroll
-    for (int j = 0; j < 10; j++) {
-      const int k = i + j;
+    for (int i = 0; i < 10; i++) {
+      const int j = (k - i + 10) % 10;
+      const bool wrap = i > k;
       const int32_t a = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
-      const int32_t b = (k >= 10) ? g19[j] : g.v[j];
-      h[k % 10] += (int64_t)a * (int64_t)b;
+      const int32_t b = wrap ? g19[j] : g.v[j];
+      H += (int64_t)a * (int64_t)b;
+      AFX_PIN(H);
     }
+    const int bits = (k & 1) ? 25 : 26;
+    const uint32_t lo = (uint32_t)H & ((1u << bits) - 1);
+    if (k == 0) u0 = lo; else r.v[k] = (int32_t)lo - (1 << (bits - 1));
+    c = (k < 9) ? ((H + (1LL << 50)) >> bits) : (H >> bits);
   }
-  return fe_carry64_prerounded(h);
+  // wrap: limb 0 gets 19 * carry(limb 9); u0 still holds limb 0 with its rounding constant
+  int64_t H0 = (int64_t)u0 + c * 19;
+  const int32_t c0 = (int32_t)(H0 >> 26);
+  r.v[0] = (int32_t)((uint32_t)H0 & 0x3ffffffu) - (1 << 25);
+  r.v[1] += c0;
+  return r;
 }
 
 AFX_DEV fe fe_sq(const fe& f) {
@@ -151,24 +150,36 @@ AFX_DEV fe fe_sq(const fe& f) {
 #pragma unroll
   for (int i = 0; i < 10; i++) {
     f2[i] = (int32_t)(2u * (uint32_t)f.v[i]);
-    f19[i] = (int32_t)(19u * (uint32_t)f.v[i]);  // consumed for even i only
-    f38[i] = (int32_t)(38u * (uint32_t)f.v[i]);  // consumed for odd i only
+    f19[i] = (int32_t)(19u * (uint32_t)f.v[i]);
+    f38[i] = (int32_t)(38u * (uint32_t)f.v[i]);
   }
-  int64_t h[10];
+  fe r;
+  int64_t c = 1LL << 25;
+  uint32_t u0 = 0;
 #pragma unroll
-  for (int k = 0; k < 10; k++) h[k] = (k & 1) ? (1LL << 24) : (1LL << 25);
+  for (int k = 0; k < 10; k++) {
+    int64_t H = c;
 #pragma unroll
-  for (int i = 0; i < 10; i++) {
-#pragma unroll
-    for (int j = i; j < 10; j++) {
-      const int k = i + j;
+    for (int i = 0; i < 10; i++) {
+      const int j = (k - i + 10) % 10;
+      if (j < i) continue;
+      const bool wrap = i + j >= 10;
       const bool odd2 = (i & 1) && (j & 1);
       const int32_t a = (i == j) ? f.v[i] : f2[i];
-      const int32_t b = (k >= 10) ? (odd2 ? f38[j] : f19[j]) : (odd2 ? f2[j] : f.v[j]);
-      h[k % 10] += (int64_t)a * (int64_t)b;
+      const int32_t b = wrap ? (odd2 ? f38[j] : f19[j]) : (odd2 ? f2[j] : f.v[j]);
+      H += (int64_t)a * (int64_t)b;
+      AFX_PIN(H);
     }
+    const int bits = (k & 1) ? 25 : 26;
+    const uint32_t lo = (uint32_t)H & ((1u << bits) - 1);
+    if (k == 0) u0 = lo; else r.v[k] = (int32_t)lo - (1 << (bits - 1));
+    c = (k < 9) ? ((H + (1LL << 50)) >> bits) : (H >> bits);
   }
-  return fe_carry64_prerounded(h);
+  int64_t H0 = (int64_t)u0 + c * 19;
+  const int32_t c0 = (int32_t)(H0 >> 26);
+  r.v[0] = (int32_t)((uint32_t)H0 & 0x3ffffffu) - (1 << 25);
+  r.v[1] += c0;
+  return r;
 }
 
 // f^(2^n), n >= 1, rolled loop (keeps the inversion chains small in code size)

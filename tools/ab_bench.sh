@@ -1,0 +1,19 @@
+#!/bin/bash
+# Compare builds of the library on the same GPU box: tools/ab_bench.sh <workload> <rounds> <variant.so>...
+# Alternates the default build and each variant so that box-to-box and thermal differences cancel.
+set -u
+WL=$1; ROUNDS=$2; shift 2
+LIB=aeonflux_amd/lib/libaeonflux_gpu.so
+cp $LIB /tmp/ab_default.so
+for r in $(seq $ROUNDS); do
+  for which in /tmp/ab_default.so "$@"; do
+    cp $which $LIB
+    python bench.py --workload $WL --steps 10 --warmup 2 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); r = d['roofline']
+        print('%-50s' % '$which', round(d['value']), 'ms/step', round(d['ms_per_step'], 3), 'k_msm', round(r['kernel_ms_per_step'], 3), r['other_kernels_ms_per_step'])"
+  done
+done
+cp /tmp/ab_default.so $LIB

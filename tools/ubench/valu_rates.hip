@@ -18,11 +18,11 @@ constexpr int ITERS = 4096;
 constexpr int NCH = 8;  // independent chains per lane
 
 enum Op { MAD_U64_U32, MAD_I64_I32, MUL_LO_U32, MUL_HI_U32, MAD_U32_U24, MUL_HI_U32_U24, FMA_F64, ADD_F64,
-          ADD_U64, ADD_U32, ADD3_U32, LSHL_ADD_U64, ALIGNBIT, XOR3, FMA_F32, MUL_U64, ADDC_PAIR, OP_COUNT };
+          ADD_U64, ADD_U32, ADD3_U32, LSHL_ADD_U64, ALIGNBIT, XOR3, FMA_F32, MUL_U64, ADDC_PAIR, ASHR_I64, LSHL_B64, ASHR_I32, AND_B32, BFE_I32, SUB_U32, ADD_LIT, MAD_I32_I24, LSHL_ADD_U32, AND_OR, MUL_U32_U24, CNDMASK, OP_COUNT };
 
 static const char* op_name[] = { "v_mad_u64_u32", "v_mad_i64_i32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24",
   "v_mul_hi_u32_u24", "v_fma_f64", "v_add_f64", "u64 add (C)", "v_add_u32", "v_add3_u32", "v_lshl_add_u64",
-  "v_alignbit_b32", "v_xor3/bfi(C xor)", "v_fma_f32", "u64 mul (C)", "v_add_co+v_addc pair" };
+  "v_alignbit_b32", "v_xor3/bfi(C xor)", "v_fma_f32", "u64 mul (C)", "v_add_co+v_addc pair", "v_ashrrev_i64", "v_lshlrev_b64", "v_ashrrev_i32", "v_and_b32", "v_bfe_i32", "v_sub_u32", "v_add_u32 literal", "v_mad_i32_i24", "v_lshl_add_u32", "v_and_or_b32", "v_mul_u32_u24", "v_cndmask_b32" };
 
 template <int OP>
 __global__ void __launch_bounds__(256) k_rate(uint64_t* out, uint32_t seed) {
@@ -79,6 +79,30 @@ __global__ void __launch_bounds__(256) k_rate(uint64_t* out, uint32_t seed) {
       } else if constexpr (OP == MUL_U64) {
         a64[c] *= ((uint64_t)x << 32 | y);
         asm volatile("" : "+v"(a64[c]));
+      } else if constexpr (OP == ASHR_I64) {
+        asm volatile("v_ashrrev_i64 %0, 3, %0" : "+v"(a64[c]));
+      } else if constexpr (OP == LSHL_B64) {
+        asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a64[c]));
+      } else if constexpr (OP == ASHR_I32) {
+        asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(a32[c]));
+      } else if constexpr (OP == AND_B32) {
+        asm volatile("v_and_b32 %0, 0x3ffffff, %0" : "+v"(a32[c]));
+      } else if constexpr (OP == BFE_I32) {
+        asm volatile("v_bfe_i32 %0, %0, 0, 26" : "+v"(a32[c]));
+      } else if constexpr (OP == SUB_U32) {
+        asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a32[c]) : "v"(y));
+      } else if constexpr (OP == ADD_LIT) {
+        asm volatile("v_add_u32 %0, 0x40000, %0" : "+v"(a32[c]));
+      } else if constexpr (OP == MAD_I32_I24) {
+        asm volatile("v_mad_i32_i24 %0, %1, 19, %0" : "+v"(a32[c]) : "v"(y));
+      } else if constexpr (OP == LSHL_ADD_U32) {
+        asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a32[c]) : "v"(y));
+      } else if constexpr (OP == AND_OR) {
+        asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a32[c]) : "v"(y), "v"(x));
+      } else if constexpr (OP == MUL_U32_U24) {
+        asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a32[c]) : "v"(y));
+      } else if constexpr (OP == CNDMASK) {
+        asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a32[c]) : "v"(y));
       } else if constexpr (OP == ADDC_PAIR) {
         uint32_t lo = (uint32_t)a64[c], hi = (uint32_t)(a64[c] >> 32);
         asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(y) : "vcc");
@@ -124,8 +148,8 @@ int main() {
   double clk = p.clockRate / 1e6;  // kHz -> GHz
   printf("device %s  CUs=%d  clock=%.3f GHz (nominal; DVFS may lower it)\n", p.name, ncu, clk);
   uint64_t* d_out; CK(hipMalloc(&d_out, sizeof(uint64_t) * ncu * 8 * 256));
-  for (int pass = 0; pass < 2; ++pass) {
-    int bpc = pass == 0 ? 8 : 1;  // 8 blocks x 256 thr = 8 waves/SIMD ; 1 block x 256 = 1 wave/SIMD
+  for (int pass = 0; pass < 3; ++pass) {
+    int bpc = pass == 0 ? 8 : (pass == 1 ? 1 : 2);  // 8 / 1 / 2 waves per SIMD (k_msm runs at 2)
     printf("== %d block(s) of 256 threads per CU ==\n", bpc);
     if (run<MAD_U64_U32>(d_out, bpc, 256, clk, ncu, 1)) return 1;
     if (run<MAD_I64_I32>(d_out, bpc, 256, clk, ncu, 1)) return 1;
@@ -144,6 +168,18 @@ int main() {
     if (run<ALIGNBIT>(d_out, bpc, 256, clk, ncu, 1)) return 1;
     if (run<XOR3>(d_out, bpc, 256, clk, ncu, 1)) return 1;
     if (run<MUL_U64>(d_out, bpc, 256, clk, ncu, 1)) return 1;
+    if (run<ASHR_I64>(d_out, bpc, 256, clk, ncu, 1)) return 1;
+    if (run<LSHL_B64>(d_out, bpc, 256, clk, ncu, 1)) return 1;
+    if (run<ASHR_I32>(d_out, bpc, 256, clk, ncu, 1)) return 1;
+    if (run<AND_B32>(d_out, bpc, 256, clk, ncu, 1)) return 1;
+    if (run<BFE_I32>(d_out, bpc, 256, clk, ncu, 1)) return 1;
+    if (run<SUB_U32>(d_out, bpc, 256, clk, ncu, 1)) return 1;
+    if (run<ADD_LIT>(d_out, bpc, 256, clk, ncu, 1)) return 1;
+    if (run<MAD_I32_I24>(d_out, bpc, 256, clk, ncu, 1)) return 1;
+    if (run<LSHL_ADD_U32>(d_out, bpc, 256, clk, ncu, 1)) return 1;
+    if (run<AND_OR>(d_out, bpc, 256, clk, ncu, 1)) return 1;
+    if (run<MUL_U32_U24>(d_out, bpc, 256, clk, ncu, 1)) return 1;
+    if (run<CNDMASK>(d_out, bpc, 256, clk, ncu, 1)) return 1;
   }
   CK(hipFree(d_out));
   return 0;
