@@ -123,6 +123,8 @@ def lib():
         _LIB.afx_wire_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Shape), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         _LIB.afx_verify_presentations_wire.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _LIB.afx_ctx_set_pipelining.argtypes = [C.c_void_p, C.c_int]
+        _LIB.afx_ctx_set_challenge_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+        _LIB.afx_ctx_get_challenge_trace.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.afx_ctx_synchronize.argtypes = [C.c_void_p]
         _LIB.afx_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_get_timing.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -158,6 +160,17 @@ class Context:
 
     def __del__(self):
         self.close()
+
+    def set_challenge_trace(self, rows, count):
+        """parity aid: verification calls also record each recomputed challenge in a [rows][count][32] array; (0, 0) = off"""
+        check(lib().afx_ctx_set_challenge_trace(self.h, rows, count))
+        self._trace_shape = (rows, count)
+
+    def get_challenge_trace(self):
+        import numpy as np
+        out = np.zeros(self._trace_shape + (32,), np.uint8)
+        check(lib().afx_ctx_get_challenge_trace(self.h, out.ctypes.data))
+        return out
 
     def set_pipelining(self, enable):
         """alternate successive *_dev calls between two streams (independent calls only); see afx_ctx_set_pipelining"""

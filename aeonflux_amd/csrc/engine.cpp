@@ -277,7 +277,7 @@ afx_hash_program SchnorrBuilder::make_program(const StrobeSim& sim) {
   return p;
 }
 
-void SchnorrBuilder::verify_compact(const uint8_t* challenge_dev, std::vector<afx_msm_job>& msm_out, std::vector<afx_hash_program>& hash_out,
+void SchnorrBuilder::verify_compact(const uint8_t* challenge_dev, uint32_t trace_row, size_t total, size_t off, std::vector<afx_msm_job>& msm_out, std::vector<afx_hash_program>& hash_out,
                                     std::vector<afx_scalarop_job>* pre_ops) {
   // R_j = sum resp[s] * P  - c * LHS, appended as "blindcom"
   for (auto& cn : constraints_) {
@@ -295,6 +295,11 @@ void SchnorrBuilder::verify_compact(const uint8_t* challenge_dev, std::vector<af
   sim_.challenge64("chal", AFX_SQ_CHALLENGE_COMPARE, 0);
   afx_hash_program p = make_program(sim_);
   p.challenge = challenge_dev;
+  afx_ctx* c = as_.ctx;
+  if (c->trace) {
+    if (total > c->trace_count || trace_row >= c->trace_rows) as_.plan_error = "challenge trace array too small for this call";
+    else p.trace = c->trace + ((size_t)trace_row * c->trace_count + off) * 32;
+  }
   hash_out.push_back(p);
 }
 

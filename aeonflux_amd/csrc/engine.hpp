@@ -91,6 +91,10 @@ struct afx_ctx {
     bool msm_recorded = false;
   } lane[2];
   bool pipelining = false;
+  // parity aid (afx_ctx_set_challenge_trace): device array [trace_rows][trace_count][32] receiving every recomputed challenge
+  uint8_t* trace = nullptr;
+  size_t trace_rows = 0, trace_count = 0;
+  afx::DevBuf trace_buf;
   unsigned lane_next = 0;
   int force_lane0 = 0;   // host-pointer front ends stay on lane 0 (they read results back on `stream`)
   // optional per-launch HIP-event timing on `stream` (bench.py's roofline figure)
@@ -128,6 +132,7 @@ class Assembler {
   int lane;
   uint32_t count;
   bool fail_all = false;      // statement-level failure for every item (reference would panic / reject all)
+  std::string plan_error;     // a request the plan cannot serve (reported as AFX_E_BAD_ARGS, nothing is launched)
 
   // workspace (device addresses are final; the bump pointer starts at the chunk workspace base)
   int32_t* new_var();         // extended point, SoA [40][count]
@@ -209,7 +214,8 @@ class SchnorrBuilder {
   void constrain(int lhs, const std::vector<std::pair<int, int>>& terms);
   // Verifier::verify_compact over the batch: commitments, transcript, challenge comparison
   // `pre_ops` receives the scalar products that fixed-base forms of variable points need (run them before msm_out)
-  void verify_compact(const uint8_t* challenge_dev, std::vector<afx_msm_job>& msm_out, std::vector<afx_hash_program>& hash_out,
+  // trace_row: which row of the context's challenge trace (afx_ctx_set_challenge_trace) this proof reports to
+  void verify_compact(const uint8_t* challenge_dev, uint32_t trace_row, size_t total, size_t off, std::vector<afx_msm_job>& msm_out, std::vector<afx_hash_program>& hash_out,
                       std::vector<afx_scalarop_job>* pre_ops = nullptr);
   // Prover::prove_compact over the batch.  Fills: rng hash program (blindings), commitment msm jobs,
   // challenge hash program, response scalar ops.  rng_seed_dev: [count][32].

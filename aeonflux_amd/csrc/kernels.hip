@@ -424,6 +424,12 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_hash(const afx_hash_program* __re
       if (rec->squeeze == AFX_SQ_CHALLENGE_COMPARE) {
         const sc want = sc_load_item(prog->challenge, 32, item);
         if (!sc_eq(c, want)) atomicOr(&bad[item], AFX_BAD_CHALLENGE);
+        if (prog->trace) {
+          uint32_t w8[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) w8[i] = c.v[i];
+          enc_store(prog->trace, item, w8);
+        }
       } else {
         uint32_t w8[8];
 #pragma unroll

@@ -112,4 +112,5 @@ typedef struct {
   const uint8_t* const* fields;    /* device table of [count][32] array pointers                */
   uint8_t* const* outs;            /* device table of [count][32] output arrays                 */
   const uint8_t* challenge;        /* [count][32] for AFX_SQ_CHALLENGE_COMPARE                  */
+  uint8_t* trace;                  /* optional [count][32]: the recomputed challenge is also stored here (parity aid) */
 } afx_hash_program;

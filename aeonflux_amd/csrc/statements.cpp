@@ -62,6 +62,33 @@ extern "C" int afx_ctx_set_pipelining(afx_ctx* c, int enable) {
   for (auto& L : c->lane) L.msm_recorded = false;
   return AFX_OK;
 }
+extern "C" int afx_ctx_set_challenge_trace(afx_ctx* c, size_t rows, size_t count) {
+  if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  AFX_HIP(hipSetDevice(c->device));
+  for (auto& L : c->lane)
+    if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
+  c->trace = nullptr;
+  c->trace_rows = c->trace_count = 0;
+  if (rows == 0 || count == 0) { c->trace_buf.release(false); return AFX_OK; }
+  int rc = c->trace_buf.ensure(rows * count * 32);
+  if (rc) return rc;
+  AFX_HIP(hipMemsetAsync(c->trace_buf.p, 0, rows * count * 32, c->stream));
+  c->trace = (uint8_t*)c->trace_buf.p;
+  c->trace_rows = rows;
+  c->trace_count = count;
+  return AFX_OK;
+}
+extern "C" int afx_ctx_get_challenge_trace(afx_ctx* c, uint8_t* host_out) {
+  if (!c || !host_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  if (!c->trace) { set_error("challenge trace is off"); return AFX_E_BAD_ARGS; }
+  AFX_HIP(hipSetDevice(c->device));
+  for (auto& L : c->lane)
+    if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
+  AFX_HIP(hipMemcpy(host_out, c->trace, c->trace_rows * c->trace_count * 32, hipMemcpyDeviceToHost));
+  return AFX_OK;
+}
 extern "C" int afx_ctx_synchronize(afx_ctx* c) {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   AFX_HIP(hipSetDevice(c->device));
@@ -98,6 +125,7 @@ extern "C" void afx_ctx_destroy(afx_ctx* c) {
   c->d_key.release(true);
   for (auto& L : c->lane) L.ws.release(true);
   c->staging.release(true);
+  c->trace_buf.release(false);
   c->d_fixed_tables.release(true);
   c->d_pos_tables.release(true);
   c->d_gen_ext.release(true);
@@ -215,7 +243,7 @@ extern "C" int afx_ctx_create(afx_ctx** out, int device, const uint8_t* sysparam
 }
 
 // ProofOfEncryption::verify, src/nizk/encryption.rs:154-210
-static void add_encproof_verify(Assembler& as, JobSets& js, uint16_t index, const afx_encproof_soa& e, size_t total, size_t off) {
+static void add_encproof_verify(Assembler& as, JobSets& js, uint16_t index, const afx_encproof_soa& e, size_t total, size_t off, uint32_t trace_row) {
   afx_ctx* c = as.ctx;
   auto row = [&](const uint8_t* base, size_t k) { return base + (k * total + off) * 32; };
   if (index >= c->n) { as.fail_all = true; return; }   // G_m[self.index] panics, encryption.rs:179
@@ -262,7 +290,7 @@ static void add_encproof_verify(Assembler& as, JobSets& js, uint16_t index, cons
   v.constrain(C_y_2p, { { a1, C_y_2 } });
   v.constrain(E1, { { a0, C_y_2 }, { m3, C_y_2p }, { z1, G_y_2 } });
   v.constrain(C_y_3, { { z, G_y_3 }, { m3, G_m_3 } });
-  v.verify_compact(row(e.challenge, 0), js.msm1, js.hash);
+  v.verify_compact(row(e.challenge, 0), trace_row, total, off, js.msm1, js.hash);
 }
 
 
@@ -382,10 +410,10 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
   }
   // one launch for everything: the lane that finishes Z goes straight on to constraint #1 (Z = z*I), the only job that needs it
   const size_t first_constraint = js.msm1.size();
-  v.verify_compact(row(b.challenge, 0), js.msm1, js.hash);
+  v.verify_compact(row(b.challenge, 0), 0, total, off, js.msm1, js.hash);
   js.msm1[z_index].chain_to = (int32_t)first_constraint;
   // proofs of encryption: verified independently, whatever their number (:438-440)
-  for (uint32_t e = 0; e < sh.n_enc_proofs && !as.fail_all; e++) add_encproof_verify(as, js, sh.enc_indices[e], b.enc[e], total, off);
+  for (uint32_t e = 0; e < sh.n_enc_proofs && !as.fail_all; e++) add_encproof_verify(as, js, sh.enc_indices[e], b.enc[e], total, off, 1 + e);
   emit(as, js, status_dev, AFX_ST_VERIFICATION_FAILURE);
 }
 
@@ -416,7 +444,7 @@ extern "C" int afx_verify_encryption_proofs_dev(afx_ctx* ctx, uint16_t index, co
   const afx_encproof_soa e = *batch;
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
     JobSets js;
-    add_encproof_verify(as, js, index, e, count, off);
+    add_encproof_verify(as, js, index, e, count, off, 0);
     emit(as, js, status_dev + off, AFX_ST_VERIFICATION_FAILURE);
   });
 }

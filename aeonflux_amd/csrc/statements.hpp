@@ -31,6 +31,7 @@ inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build) {
     try {
       Assembler sizing(c, cc, true, lane);
       build(sizing, off, cc);
+      if (!sizing.plan_error.empty()) { set_error(sizing.plan_error); return AFX_E_BAD_ARGS; }
       int rc = c->lane[lane].ws.ensure(sizing.total_ws_bytes());
       if (rc) return rc;
       if (sizing.blob_bytes() > BLOB_CAP) { set_error("plan blob exceeds its fixed capacity"); return AFX_E_BAD_ARGS; }

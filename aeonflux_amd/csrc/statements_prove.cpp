@@ -129,7 +129,7 @@ extern "C" int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* 
     iv.tU = PointVar::Var(v_tU, e_tU);
     SchnorrBuilder v(as, "2019/1416 anonymous credential", "2019/1416 issuance proof");
     issuance_statement(v, c, iv);
-    v.verify_compact(row(s.challenge, 0), js.msm2, js.hash, &js.scalarop);   // (resp_y * m_i) * G_m_i products: inputs only
+    v.verify_compact(row(s.challenge, 0), 0, count, off, js.msm2, js.hash, &js.scalarop);   // (resp_y * m_i) * G_m_i products: inputs only
     emit(as, js, status_dev + off, AFX_ST_VERIFICATION_FAILURE);
   });
 }

@@ -131,6 +131,18 @@ void* afx_ctx_stream(const afx_ctx* ctx);
 int afx_ctx_set_pipelining(afx_ctx* ctx, int enable);
 int afx_ctx_synchronize(afx_ctx* ctx);
 
+/* Challenge trace (parity aid; off by default).  set(rows, count) allocates a device array [rows][count][32]; while it
+ * exists, every verification call (presentations, proofs of encryption, issuances) of at most `count` items also
+ * stores the challenge it RECOMPUTES for item i of proof r in cell (r, i): r = 0 for the main proof (or the only
+ * one), r = 1 + e for the e-th attached proof of encryption; a call that needs more rows or items fails with
+ * AFX_E_BAD_ARGS.  get() waits for the context's work and copies the array to host_out (rows * count * 32 bytes).
+ * The value is what zkp's verify_compact compares with the proof's challenge (presentation.rs:435,
+ * encryption.rs:209, issuance.rs:217), so equal traces mean every recomputed commitment of the item was equal too.
+ * Items rejected before the transcript stage (non-canonical scalar, undecodable point) still get a value; it is
+ * computed with the identity in place of the undecodable point and means nothing.  set(0, 0) frees the array. */
+int afx_ctx_set_challenge_trace(afx_ctx* ctx, size_t rows, size_t count);
+int afx_ctx_get_challenge_trace(afx_ctx* ctx, uint8_t* host_out);
+
 /* Per-kernel device timing with HIP events on afx_ctx_stream(ctx) (measurement aid; off by default).
  * set_timing(ctx, 1) resets the counters and starts recording every launch; get_timing synchronises the
  * stream and returns the summed duration and launch count of one kernel ("k_msm", "k_hash", "k_decode",

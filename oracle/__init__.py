@@ -268,6 +268,10 @@ def decrypt(keypair, ciphertext):
     return (rc, o.raw)
 
 
+def debug_reset():
+    lib().afxo_debug_reset()
+
+
 def debug_last():
     commits = _buf(32 * 48)
     n = C.c_int(0)

@@ -807,6 +807,11 @@ void afxo_merlin_simple(const uint8_t* label, size_t llen, const uint8_t* l1, si
   merlin_append_message(&t, l1, l1len, m1, m1len);
   merlin_challenge_bytes(&t, l2, l2len, out, outlen);
 }
+void afxo_debug_reset(void) {
+  zkp_debug_ncommit = 0;
+  memset(zkp_debug_commit, 0, sizeof zkp_debug_commit);
+  memset(zkp_debug_challenge, 0, sizeof zkp_debug_challenge);
+}
 void afxo_debug_last(uint8_t* commits, int* ncommit, uint8_t challenge[32]) {
   *ncommit = zkp_debug_ncommit;
   memcpy(commits, zkp_debug_commit, 32 * (size_t)zkp_debug_ncommit);

@@ -291,3 +291,46 @@ def test_maximum_attribute_count_full_cycle():
     pres["C_y"][17, 3, 4] ^= 2
     assert batch.verify_presentations(ctx, shape, pres).tolist() == [0, 0, 0, 1, 0]
     ctx.close()
+
+
+def test_issuance_verification_recomputes_the_oracles_challenge():
+    """CredentialIssuance::verify: recomputed challenge equal to the oracle's, also for tampered issuances"""
+    import oracle
+    import aeonflux_amd as afx
+    from aeonflux_amd import batch
+    n, cnt = 4, 24
+    d = make_credentials(n, "SSPE", cnt, b"gpu-iss-trace")
+    user = d["user"]
+    kinds = list(d["creds"][0]["kinds"])
+    vals = np.zeros((n, cnt, 32), np.uint8)
+    iss = {k: np.zeros((cnt, 32), np.uint8) for k in ("t", "U", "V", "challenge")}
+    iss["responses"] = np.zeros((n + 5, cnt, 32), np.uint8)
+    want, want_status = [], []
+    for i, cr in enumerate(d["creds"]):
+        t, resp = bytearray(cr["t"]), [bytearray(r) for r in cr["responses"]]
+        if i % 4 == 1:
+            resp[i % (n + 5)][3] ^= 2
+        if i % 4 == 2:
+            t[5] ^= 1
+        oracle.debug_reset()
+        want_status.append(user.issuance_verify(kinds, cr["values"], bytes(t), cr["U"], cr["V"], cr["challenge"], [bytes(r) for r in resp]))
+        commits, c2 = oracle.debug_last()
+        want.append(c2 if commits else None)
+        for k in range(n):
+            vals[k, i] = np.frombuffer(cr["values"][k][:32], np.uint8)
+        for name, v in (("t", bytes(t)), ("U", cr["U"]), ("V", cr["V"]), ("challenge", cr["challenge"])):
+            iss[name][i] = np.frombuffer(v, np.uint8)
+        for k in range(n + 5):
+            iss["responses"][k, i] = np.frombuffer(bytes(resp[k]), np.uint8)
+    ctx = afx.Context(d["params"], None, d["ip"])
+    ctx.set_challenge_trace(1, cnt)
+    st = batch.verify_issuances(ctx, kinds, vals, iss)
+    got = ctx.get_challenge_trace()
+    ctx.close()
+    assert st.tolist() == want_status and 0 in want_status and 1 in want_status
+    reached = 0
+    for i in range(cnt):
+        if want[i] is not None:
+            assert bytes(got[0, i]) == want[i], i
+            reached += 1
+    assert reached >= cnt - 6

@@ -154,3 +154,47 @@ def test_mixed_shapes_grouped_on_the_host():
     got = batch.verify_mixed(ctx, items)
     ctx.close()
     assert [int(g[0]) for g in got] == want and sum(want) == 2
+
+
+def test_recomputed_challenges_equal_the_oracles():
+    """Beyond accept/reject: for every item whose verification reaches the transcript stage in the oracle — valid or
+    corrupted — the challenge the GPU recomputes (a hash over all of its recomputed commitments) is the oracle's, for
+    the main proof and for every attached proof of encryption (afx_ctx_set_challenge_trace)."""
+    import oracle
+    import aeonflux_amd as afx
+    n_items = 96
+    params, key, ip, issuer, pres = make_batch(8, "SSPPEEEE", [4, 5, 6, 7], n_items, b"gpu-trace")
+    corrupt(pres, b"trace-corrupt")
+    ne = pres[0].n_enc_proofs
+    want = [[None] * n_items for _ in range(1 + ne)]
+    for i, p in enumerate(pres):
+        q = oracle.Presentation.from_buffer_copy(bytes(p))
+        q.n_enc_proofs = 0                                   # the main proof alone
+        oracle.debug_reset()
+        issuer.verify_presentation(q)
+        commits, ch = oracle.debug_last()
+        if commits:
+            want[0][i] = ch
+        for e in range(ne):
+            oracle.debug_reset()
+            issuer.verify_encryption_proof(p.enc[e])
+            commits, ch = oracle.debug_last()
+            if commits:
+                want[1 + e][i] = ch
+    ctx = afx.Context(params, key, ip)
+    ctx.set_challenge_trace(1 + ne, n_items)
+    got_status = gpu_verify(afx, ctx, pres)
+    got = ctx.get_challenge_trace()
+    ctx.set_challenge_trace(0, 0)
+    ctx.close()
+    assert got_status == [issuer.verify_presentation(p) for p in pres]
+    reached = failing_reached = 0
+    for r in range(1 + ne):
+        for i in range(n_items):
+            if want[r][i] is None:
+                continue
+            assert bytes(got[r, i]) == want[r][i], (r, i)
+            reached += 1
+            proof_challenge = bytes(pres[i].challenge) if r == 0 else bytes(pres[i].enc[r - 1].challenge)
+            failing_reached += want[r][i] != proof_challenge
+    assert reached > (1 + ne) * n_items * 0.8 and failing_reached >= 10

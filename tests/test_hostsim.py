@@ -52,6 +52,18 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     kp = {f: rb(3, 32) for f in ("a", "a0", "a1", "pk")}
     pres, shape, st = batch.show(ctx, k2, values, iss["t"], iss["U"], iss["V"], kp, rb(3, 64), rb(3, 32), rb(max(nsp, 1), 3, 32), values, values)
     batch.verify_presentations(ctx, shape, pres)
+    # challenge trace: rows for the main proof and each proof of encryption; too small a buffer is refused
+    ctx.set_challenge_trace(1 + nsp, 3)
+    batch.verify_presentations(ctx, shape, pres)
+    batch.verify_issuances(ctx, kinds, values, iss)
+    assert ctx.get_challenge_trace().shape == (1 + nsp, 3, 32)
+    ctx.set_challenge_trace(1, 2)
+    try:
+        batch.verify_presentations(ctx, shape, pres)
+        raise SystemExit("trace overflow accepted")
+    except afx.AfxError as e:
+        assert e.rc == afx.E_BAD_ARGS
+    ctx.set_challenge_trace(0, 0)
     blob = wire.pack_presentations(shape, pres)
     stt, cnt = np.zeros(3, np.uint8), C.c_size_t(0)
     assert afx.lib().afx_verify_presentations_wire(ctx.h, blob, len(blob), stt.ctypes.data, 3, C.byref(cnt)) == 0 and cnt.value == 3
