@@ -72,9 +72,71 @@ void Assembler::sccheck(const std::vector<afx_sccheck_job>& jobs) { add_jobs(L_S
 void Assembler::pointop(const std::vector<afx_pointop_job>& jobs) { add_jobs(L_POINTOP, jobs, 0); }
 void Assembler::scalarop(const std::vector<afx_scalarop_job>& jobs) { add_jobs(L_SCALAROP, jobs, 0); }
 void Assembler::hash(const std::vector<afx_hash_program>& progs) { add_jobs(L_HASH, progs, 0); }
+// Order of the grid rows of one k_msm launch.  Rows are dispatched in order, each row = ceil(count / 256) blocks of
+// equal duration, onto 2 * n_cu resident blocks: when a row is a fraction 1/m of the device the launch behaves like
+// list scheduling on m machines, and longest-first alone leaves the last rows unbalanced (C2 at 2^16 items: two
+// "machines", makespan 6 % above the mean load).  So: longest-first assignment to m bins, pairwise move/swap
+// refinement of the maximum load, then rows sorted by their planned start time.  cost[] in kilo-cycles per wave.
+static std::vector<size_t> balanced_row_order(const std::vector<size_t>& heads, const std::vector<uint32_t>& cost, uint32_t m) {
+  std::vector<size_t> order = heads;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+  if (m <= 1 || order.size() <= m) return order;
+  std::vector<std::vector<size_t>> bin(m);
+  std::vector<uint64_t> load(m, 0);
+  for (size_t r : order) {
+    const size_t k = std::min_element(load.begin(), load.end()) - load.begin();
+    bin[k].push_back(r);
+    load[k] += cost[r];
+  }
+  for (int pass = 0; pass < 64; pass++) {
+    const size_t hi = std::max_element(load.begin(), load.end()) - load.begin();
+    uint64_t best = load[hi];
+    int bi = -1, bj = -1; size_t bk = 0;
+    for (size_t k = 0; k < m; k++) {
+      if (k == hi) continue;
+      for (size_t i = 0; i < bin[hi].size(); i++) {
+        const uint64_t ci = cost[bin[hi][i]];
+        // move i to bin k
+        uint64_t mk = std::max(load[hi] - ci, load[k] + ci);
+        if (mk < best) { best = mk; bi = (int)i; bj = -1; bk = k; }
+        for (size_t j = 0; j < bin[k].size(); j++) {
+          const uint64_t cj = cost[bin[k][j]];
+          if (cj >= ci) continue;
+          mk = std::max(load[hi] - ci + cj, load[k] + ci - cj);
+          if (mk < best) { best = mk; bi = (int)i; bj = (int)j; bk = k; }
+        }
+      }
+    }
+    if (bi < 0) break;
+    const size_t ri = bin[hi][bi];
+    load[hi] -= cost[ri]; load[bk] += cost[ri];
+    if (bj >= 0) {
+      const size_t rj = bin[bk][bj];
+      load[bk] -= cost[rj]; load[hi] += cost[rj];
+      bin[hi][bi] = rj; bin[bk][bj] = ri;
+    } else {
+      bin[hi].erase(bin[hi].begin() + bi);
+      bin[bk].push_back(ri);
+    }
+  }
+  struct Slot { uint64_t start; size_t bin, row; };
+  std::vector<Slot> plan;
+  for (size_t k = 0; k < m; k++) {
+    std::stable_sort(bin[k].begin(), bin[k].end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+    uint64_t t = 0;
+    for (size_t r : bin[k]) { plan.push_back({ t, k, r }); t += cost[r]; }
+  }
+  std::stable_sort(plan.begin(), plan.end(), [](const Slot& a, const Slot& b) { return a.start != b.start ? a.start < b.start : a.bin < b.bin; });
+  order.clear();
+  for (const Slot& s : plan) order.push_back(s.row);
+  return order;
+}
+
 void Assembler::msm(std::vector<afx_msm_job> jobs) {
   if (jobs.empty()) return;
-  auto cost = [](const afx_msm_job& j) { return 240u + j.n_var * 80u + (j.n_terms - j.n_var) * 35u; };
+  // kilo-cycles of VALU issue per wave (profiles/r01_fe_rates_ubench.txt): 63 windows of 4 doublings + the final
+  // encoding; 64 additions + the 9-entry table per variable base; 32 additions per fixed base
+  auto cost = [](const afx_msm_job& j) { return (j.n_var ? 1320u : 160u) + j.n_var * 470u + (j.n_terms - j.n_var) * 175u; };
   const size_t n = jobs.size();
   // a job named as another's successor (chain_to) is run by that job's lanes, not by grid rows of its own
   std::vector<int> is_successor(n, 0);
@@ -91,11 +153,11 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
       if (++guard > (int)n) throw std::logic_error("msm chain cycle");
     }
   }
-  // grid rows: chain heads, longest first (blockIdx.y is the job and low block ids are dispatched first)
+  // grid rows: chain heads (blockIdx.y is the job and low block ids are dispatched first)
   std::vector<size_t> heads, order;
   for (size_t i = 0; i < n; i++) if (!is_successor[i]) heads.push_back(i);
-  std::stable_sort(heads.begin(), heads.end(), [&](size_t a, size_t b) { return total[a] > total[b]; });
-  order = heads;
+  const uint32_t blocks_per_row = (count + AFX_BLOCK - 1) / AFX_BLOCK, resident = 2 * ctx->n_cu;
+  order = balanced_row_order(heads, total, blocks_per_row >= resident ? 1u : (resident + blocks_per_row / 2) / blocks_per_row);
   for (size_t i = 0; i < n; i++) if (is_successor[i]) order.push_back(i);
   std::vector<uint32_t> new_index(n);
   for (size_t k = 0; k < n; k++) new_index[order[k]] = (uint32_t)k;

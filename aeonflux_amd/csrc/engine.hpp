@@ -91,6 +91,7 @@ struct afx_ctx {
     bool msm_recorded = false;
   } lane[2];
   bool pipelining = false;
+  uint32_t n_cu = 256;   // compute units of the device (k_msm keeps 2 blocks resident on each)
   // parity aid (afx_ctx_set_challenge_trace): device array [trace_rows][trace_count][32] receiving every recomputed challenge
   uint8_t* trace = nullptr;
   size_t trace_rows = 0, trace_count = 0;

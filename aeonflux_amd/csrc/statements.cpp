@@ -164,6 +164,11 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   c->n = n;
   c->g = n < 3 ? 3 : n;
   AFX_HIP(hipSetDevice(device));
+  {
+    int cus = 0;
+    AFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    if (cus > 0) c->n_cu = (uint32_t)cus;
+  }
   for (auto& L : c->lane) AFX_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
   c->stream = c->lane[0].stream;
   const uint32_t np = 9 + c->g + n;
