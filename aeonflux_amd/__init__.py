@@ -123,6 +123,7 @@ def lib():
         _LIB.afx_wire_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Shape), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         _LIB.afx_verify_presentations_wire.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _LIB.afx_ctx_set_pipelining.argtypes = [C.c_void_p, C.c_int]
+        _LIB.afx_ctx_get_plan_stats.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.afx_ctx_set_challenge_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
         _LIB.afx_ctx_get_challenge_trace.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.afx_ctx_synchronize.argtypes = [C.c_void_p]
@@ -160,6 +161,13 @@ class Context:
 
     def __del__(self):
         self.close()
+
+    def plan_stats(self):
+        """per-item operation counts of the most recent call (afx_plan_stats) as a dict"""
+        names = ("msm_jobs", "doublings", "var_additions", "fixed_additions", "table_additions", "encodings", "decodings", "keccak_permutations", "field_mul", "field_sq")
+        v = (C.c_uint64 * len(names))()
+        check(lib().afx_ctx_get_plan_stats(self.h, v))
+        return dict(zip(names, (int(x) for x in v)))
 
     def set_challenge_trace(self, rows, count):
         """parity aid: verification calls also record each recomputed challenge in a [rows][count][32] array; (0, 0) = off"""

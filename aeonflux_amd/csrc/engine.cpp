@@ -67,11 +67,27 @@ void Assembler::add_jobs(LaunchKind k, const std::vector<T>& jobs, uint32_t max_
   memcpy(blob_.data() + l.jobs_off, jobs.data(), sizeof(T) * jobs.size());
   launches.push_back(l);
 }
-void Assembler::decode(const std::vector<afx_decode_job>& jobs) { add_jobs(L_DECODE, jobs, 0); }
+void Assembler::decode(const std::vector<afx_decode_job>& jobs) {
+  stats.decodings += jobs.size();
+  stats.field_mul += AFX_DECODE_MUL * jobs.size();
+  stats.field_sq += AFX_DECODE_SQ * jobs.size();
+  add_jobs(L_DECODE, jobs, 0);
+}
 void Assembler::sccheck(const std::vector<afx_sccheck_job>& jobs) { add_jobs(L_SCCHECK, jobs, 0); }
-void Assembler::pointop(const std::vector<afx_pointop_job>& jobs) { add_jobs(L_POINTOP, jobs, 0); }
+void Assembler::pointop(const std::vector<afx_pointop_job>& jobs) {
+  for (const afx_pointop_job& j : jobs) {
+    stats.var_additions += j.sb != 0;
+    stats.encodings += j.out_enc != nullptr;
+    stats.field_mul += (j.sb != 0 ? 9 : 0) + (j.out_enc ? AFX_ENCODE_MUL : 0);
+    stats.field_sq += j.out_enc ? AFX_ENCODE_SQ : 0;
+  }
+  add_jobs(L_POINTOP, jobs, 0);
+}
 void Assembler::scalarop(const std::vector<afx_scalarop_job>& jobs) { add_jobs(L_SCALAROP, jobs, 0); }
-void Assembler::hash(const std::vector<afx_hash_program>& progs) { add_jobs(L_HASH, progs, 0); }
+void Assembler::hash(const std::vector<afx_hash_program>& progs) {
+  for (const afx_hash_program& p : progs) stats.keccak_permutations += p.n_records;
+  add_jobs(L_HASH, progs, 0);
+}
 // Order of the grid rows of one k_msm launch.  Rows are dispatched in order, each row = ceil(count / 256) blocks of
 // equal duration, onto 2 * n_cu resident blocks: when a row is a fraction 1/m of the device the launch behaves like
 // list scheduling on m machines, and longest-first alone leaves the last rows unbalanced (C2 at 2^16 items: two
@@ -145,6 +161,33 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
       if ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i) throw std::logic_error("bad msm chain");
       is_successor[jobs[i].chain_to] = 1;
     }
+  for (const afx_msm_job& j : jobs) {
+    const uint64_t nv = j.n_var, nf = j.n_terms - j.n_var;
+    stats.msm_jobs++;
+    stats.doublings += nv ? 252 : 0;
+    stats.var_additions += 64 * nv;
+    stats.fixed_additions += 32 * nf;
+    stats.table_additions += (AFX_TABLE_ENTRIES - 2) * nv;
+    stats.encodings += j.out_enc ? 1 : 0;
+    stats.var_additions += j.addend ? 1 : 0;
+    // field operations, following k_msm's schedule statement by statement
+    uint64_t M = 0, S = 0;
+    if (nv) {
+      M += nv * (1 + (AFX_TABLE_ENTRIES - 2) * 9);            // tables: 2dT of P, then (add 4M + to p3 4M + 2dT 1M) per entry
+      for (int w = 63; w >= 0; w--) {
+        const uint64_t nadd = nv + ((w & 1) == 0 ? nf : 0);
+        if (w != 63) { S += 16; M += 3 * 3 + 4; }             // three doublings to p2, the fourth to p3
+        M += nv * 4 + (nadd - nv) * 3;                        // cached / niels additions
+        M += nadd * 4 - (w != 0 ? 1 : 0);                     // back to p3; the window's last one skips T
+      }
+    } else {
+      M += 32 * nf * 7;                                       // positional tables: niels addition + to p3
+    }
+    if (j.addend) M += 9;
+    if (j.out_enc) { M += AFX_ENCODE_MUL; S += AFX_ENCODE_SQ; }
+    stats.field_mul += M;
+    stats.field_sq += S;
+  }
   std::vector<uint32_t> total(n);
   for (size_t i = 0; i < n; i++) {
     total[i] = 0;
@@ -209,6 +252,7 @@ size_t Assembler::total_ws_bytes() const {
 int Assembler::run() {
   if (sizing_) { set_error("run() on a sizing assembler"); return AFX_E_BAD_ARGS; }
   afx_ctx::Lane& L = ctx->lane[lane];
+  ctx->last_stats = stats;
   if (total_ws_bytes() > L.ws.cap) { set_error("workspace smaller than the sized plan"); return AFX_E_BAD_ARGS; }
   int32_t* table_ws = (int32_t*)ws_alloc(max_table_slots * (size_t)count * AFX_VAR_TABLE_DWORDS * sizeof(int32_t));
   uint32_t* digit_ws = (uint32_t*)ws_alloc(max_digit_slots * 8 * (size_t)count * sizeof(uint32_t));

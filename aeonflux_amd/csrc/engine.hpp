@@ -91,6 +91,7 @@ struct afx_ctx {
     bool msm_recorded = false;
   } lane[2];
   bool pipelining = false;
+  afx_plan_stats last_stats = {};   // per-item operation counts of the most recent plan
   uint32_t n_cu = 256;   // compute units of the device (k_msm keeps 2 blocks resident on each)
   // parity aid (afx_ctx_set_challenge_trace): device array [trace_rows][trace_count][32] receiving every recomputed challenge
   uint8_t* trace = nullptr;
@@ -134,6 +135,7 @@ class Assembler {
   uint32_t count;
   bool fail_all = false;      // statement-level failure for every item (reference would panic / reject all)
   std::string plan_error;     // a request the plan cannot serve (reported as AFX_E_BAD_ARGS, nothing is launched)
+  afx_plan_stats stats = {};  // per-item operation counts of this plan
 
   // workspace (device addresses are final; the bump pointer starts at the chunk workspace base)
   int32_t* new_var();         // extended point, SoA [40][count]

@@ -104,13 +104,25 @@ AFX_DEV fe fe_carry(const fe& f) {
 // Pins a partial sum: the volatile (input-only, empty) statement forces the value to exist at this point, which keeps
 // LLVM's reassociation from pulling the carry out of the mad chain into a separate 64-bit add.  It emits no code and,
 // having no outputs, triggers none of the hazard no-ops the compiler puts after inline-asm definitions.
+#if defined(__HIPCC__)
 #define AFX_PIN(x) asm volatile("" ::"v"(x))
+#else
+#define AFX_PIN(x) ((void)0)   // host build of this header (tests/hostsim/arith_host.cpp)
+#endif
+// operation counters for the host build (the per-item counts DESIGN.md publishes are measured with them)
+#ifdef AFX_COUNT_OPS
+extern thread_local uint64_t afx_n_mul, afx_n_sq;
+#define AFX_COUNT(x) (++(x))
+#else
+#define AFX_COUNT(x) ((void)0)
+#endif
 
 // Schoolbook product, columns in order 0..9: column k's mad chain starts from the carry out of column k-1 (the
 // mad's 64-bit addend), so the carry chain needs no 64-bit additions.  Each carry arrives with the next limb's
 // rounding constant already in it (2^50 added to the high dword before the shift), which makes every limb come out
 // centred: r_k = (H_k mod 2^b) - 2^(b-1).
 AFX_DEV fe fe_mul(const fe& f, const fe& g) {
+  AFX_COUNT(afx_n_mul);
   int32_t g19[10], f2[10];
 #pragma unroll
   for (int i = 0; i < 10; i++) {
@@ -146,6 +158,7 @@ AFX_DEV fe fe_mul(const fe& f, const fe& g) {
 }
 
 AFX_DEV fe fe_sq(const fe& f) {
+  AFX_COUNT(afx_n_sq);
   int32_t f2[10], f19[10], f38[10];
 #pragma unroll
   for (int i = 0; i < 10; i++) {

@@ -17,6 +17,12 @@
 #define AFX_TABLE_ENTRY_DWORDS 32       /* a window-table entry: 4 field elements as canonical 256-bit words = 128 B = 2 HBM sectors */
 #define AFX_VAR_TABLE_DWORDS (AFX_TABLE_ENTRIES * AFX_TABLE_ENTRY_DWORDS)
 #define AFX_BLOCK 256
+/* field multiplications / squarings of one ristretto255 decoding / encoding as ge.cuh implements them
+ * (measured on the host build of that header: tests/test_device_arith_on_host.py) */
+#define AFX_DECODE_MUL 27
+#define AFX_DECODE_SQ 257
+#define AFX_ENCODE_MUL 32
+#define AFX_ENCODE_SQ 255
 
 /* per-item failure bits OR-ed into the `bad` word of an item */
 #define AFX_BAD_DECODE 1u

@@ -89,6 +89,12 @@ extern "C" int afx_ctx_get_challenge_trace(afx_ctx* c, uint8_t* host_out) {
   AFX_HIP(hipMemcpy(host_out, c->trace, c->trace_rows * c->trace_count * 32, hipMemcpyDeviceToHost));
   return AFX_OK;
 }
+extern "C" int afx_ctx_get_plan_stats(afx_ctx* c, afx_plan_stats* out) {
+  if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  *out = c->last_stats;
+  return AFX_OK;
+}
 extern "C" int afx_ctx_synchronize(afx_ctx* c) {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   AFX_HIP(hipSetDevice(c->device));

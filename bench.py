@@ -189,6 +189,7 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
     fence()
     elapsed = time.perf_counter() - t0
     msm_ms, msm_launches = issuer.get_timing("k_msm")
+    valu = valu_side(issuer, count, (msm_ms + issuer.get_timing("k_decode")[0] + issuer.get_timing("k_pointop")[0]) / args.steps)
     hash_ms, _ = issuer.get_timing("k_hash")
     issuer.set_timing(False)
     if dist is not None:
@@ -218,7 +219,7 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "kernel": "k_msm", "launches_per_step": msm_launches / args.steps, "avg_launch_ms": msm_ms / max(1, msm_launches),
                          "kernel_ms_per_step": msm_ms / args.steps, "other_kernels_ms_per_step": {"k_hash": hash_ms / args.steps}},
-            "cpu_baseline": cpu}))
+            "valu": valu, "cpu_baseline": cpu}))
     issuer.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -310,6 +311,7 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
     fence()
     elapsed = time.perf_counter() - t0
     msm_ms, msm_launches = user.get_timing("k_msm")
+    valu = valu_side(user, count, (msm_ms + user.get_timing("k_decode")[0] + user.get_timing("k_pointop")[0]) / args.steps)
     hash_ms, _ = user.get_timing("k_hash")
     user.set_timing(False)
     if dist is not None:
@@ -329,11 +331,29 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "kernel": "k_msm",
                          "launches_per_step": msm_launches / args.steps, "avg_launch_ms": msm_ms / max(1, msm_launches),
                          "kernel_ms_per_step": msm_ms / args.steps, "other_kernels_ms_per_step": {"k_hash": hash_ms / args.steps}},
-            "cpu_baseline": None}))
+            "valu": valu, "cpu_baseline": None}))
     issuer.close()
     user.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+# measured v_mad_i64_i32 issue rate at the occupancy the kernels run at (profiles/r01_valu_rates_ubench.txt, 2 waves
+# per SIMD: 5.54 cycles per wave-instruction): 64 lanes / 5.54 cycles x 1024 SIMDs x 2.4 GHz.  No published figure
+# exists for this opcode, so the "peak" of the compute-side figure is this microbenchmark's.
+MAD_PEAK_T = 64 / 5.54 * 1024 * 2.4e9 / 1e12
+
+
+def valu_side(ctx, items_per_step, field_kernel_ms_per_step):
+    """compute-side figure beside the HBM roofline: 32x32->64-bit multiply-adds of the field arithmetic per second.
+    Counts come from the engine's own plan of the last call (afx_ctx_get_plan_stats); a field multiplication is
+    100 v_mad_i64_i32, a squaring 55 (aeonflux_amd/csrc/fe.cuh)."""
+    st = ctx.plan_stats()
+    mads = 100 * st["field_mul"] + 55 * st["field_sq"]
+    achieved = mads * items_per_step / (field_kernel_ms_per_step / 1e3) / 1e12 if field_kernel_ms_per_step > 0 else 0.0
+    return {"unit": "T multiply-adds/s (v_mad_i64_i32)", "achieved": achieved, "peak": MAD_PEAK_T, "frac": achieved / MAD_PEAK_T,
+            "peak_source": "tools/ubench/valu_rates.hip on this GPU (no published figure)", "per_item": dict(st, mads=mads),
+            "time_base": "summed durations of the kernels doing field arithmetic (k_msm, k_decode, k_pointop)"}
 
 
 def main():
@@ -424,6 +444,8 @@ def main():
     msm_ms, msm_launches = issuer.get_timing("k_msm")
     hash_ms, _ = issuer.get_timing("k_hash")
     dec_ms, _ = issuer.get_timing("k_decode")
+    pop_ms, _ = issuer.get_timing("k_pointop")
+    valu = valu_side(issuer, count, (msm_ms + dec_ms + pop_ms) / args.steps)
     issuer.set_timing(False)
     issuer.set_pipelining(False)
     if dist is not None:
@@ -494,7 +516,8 @@ def main():
                          "kernel": "k_msm", "launches_per_step": msm_launches / args.steps,
                          "avg_launch_ms": msm_ms / max(1, msm_launches), "kernel_ms_per_step": msm_ms / args.steps,
                          "other_kernels_ms_per_step": {"k_hash": hash_ms / args.steps, "k_decode": dec_ms / args.steps},
-                         "note": "integer-ALU bound path: see DESIGN.md for the VALU-side figure"},
+                         "note": "integer-ALU bound path: the compute-side figure is in \"valu\""},
+            "valu": valu,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

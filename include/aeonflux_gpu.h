@@ -143,6 +143,23 @@ int afx_ctx_synchronize(afx_ctx* ctx);
 int afx_ctx_set_challenge_trace(afx_ctx* ctx, size_t rows, size_t count);
 int afx_ctx_get_challenge_trace(afx_ctx* ctx, uint8_t* host_out);
 
+/* Per-item operation counts of the context's most recent call (measurement aid: the compute-side figure beside the
+ * HBM roofline is derived from these).  Counts are what ONE item executes, summed over all
+ * the jobs of its statement; every lane executes the same schedule, so they do not depend on the data. */
+typedef struct afx_plan_stats {
+  uint64_t msm_jobs;           /* multiscalar multiplications (grid rows of k_msm plus chained jobs)            */
+  uint64_t doublings;          /* point doublings in their shared doubling chains (4S + 3M, every fourth 4S + 4M) */
+  uint64_t var_additions;      /* additions of a per-item window-table entry (8M, last of a window 7M)          */
+  uint64_t fixed_additions;    /* additions of a generator-table entry (7M, last of a window 6M)                */
+  uint64_t table_additions;    /* additions spent building the per-item window tables (8M)                      */
+  uint64_t encodings;          /* ristretto255 encodings (1 inverse square root = 254S + 11M, plus ~14M)        */
+  uint64_t decodings;          /* ristretto255 decodings (same size)                                            */
+  uint64_t keccak_permutations;
+  uint64_t field_mul, field_sq; /* GF(2^255-19) multiplications / squarings of all of the above, from the kernels' own
+                                  schedule (tests/test_device_arith_on_host.py pins the per-block counts)        */
+} afx_plan_stats;
+int afx_ctx_get_plan_stats(afx_ctx* ctx, afx_plan_stats* out);
+
 /* Per-kernel device timing with HIP events on afx_ctx_stream(ctx) (measurement aid; off by default).
  * set_timing(ctx, 1) resets the counters and starts recording every launch; get_timing synchronises the
  * stream and returns the summed duration and launch count of one kernel ("k_msm", "k_hash", "k_decode",

@@ -1,0 +1,116 @@
+// The engine's DEVICE arithmetic headers (fe.cuh, sc.cuh, ge.cuh), compiled for the host so that the CPU test-suite
+// can check them against the oracle without a GPU, and so that the field-operation counts DESIGN.md publishes are
+// measured rather than estimated.  Test infrastructure only: nothing in the product links this file.
+#include <stdint.h>
+#include <string.h>
+thread_local uint64_t afx_n_mul = 0, afx_n_sq = 0;
+#define AFX_COUNT_OPS 1
+#include "../../aeonflux_amd/csrc/ge.cuh"
+#include "../../aeonflux_amd/csrc/sc.cuh"
+
+static void load8(uint32_t w[8], const uint8_t* p) { memcpy(w, p, 32); }
+static sc sc_from(const uint8_t* p) { sc s; memcpy(s.v, p, 32); return s; }
+
+extern "C" {
+
+void arith_counters(uint64_t out[2], int reset) {
+  out[0] = afx_n_mul; out[1] = afx_n_sq;
+  if (reset) afx_n_mul = afx_n_sq = 0;
+}
+
+// out = canonical encoding of a*b, a^2, 1/a, a^((p-5)/8) over GF(2^255-19); inputs 32-byte little endian (bit 255 ignored)
+void arith_fe(uint8_t out[4][32], const uint8_t a[32], const uint8_t b[32]) {
+  uint32_t wa[8], wb[8], w[8];
+  load8(wa, a); load8(wb, b);
+  const fe x = fe_frombytes(wa), y = fe_frombytes(wb);
+  fe_tobytes(w, fe_mul(x, y)); memcpy(out[0], w, 32);
+  fe_tobytes(w, fe_sq(x)); memcpy(out[1], w, 32);
+  fe_tobytes(w, fe_invert(x)); memcpy(out[2], w, 32);
+  fe_tobytes(w, fe_pow22523(x)); memcpy(out[3], w, 32);
+}
+
+// lazily-added operands at the documented bounds: (a0 + a1 + a2 + a3) * (b0 - b1), and (a0 - a1)^2
+void arith_fe_lazy(uint8_t out[2][32], const uint8_t a[4][32], const uint8_t b[2][32]) {
+  fe x[4], y[2];
+  uint32_t w[8];
+  for (int i = 0; i < 4; i++) { load8(w, a[i]); x[i] = fe_carry(fe_frombytes(w)); }
+  for (int i = 0; i < 2; i++) { load8(w, b[i]); y[i] = fe_carry(fe_frombytes(w)); }
+  const fe s = fe_add(fe_add(x[0], x[1]), fe_add(x[2], x[3]));   // four reduced terms: fe_mul's first operand
+  fe_tobytes(w, fe_mul(s, fe_sub(y[0], y[1]))); memcpy(out[0], w, 32);
+  fe_tobytes(w, fe_sq(fe_sub(x[0], x[1]))); memcpy(out[1], w, 32);
+}
+
+int arith_decode_encode(uint8_t out[32], const uint8_t in[32]) {
+  uint32_t w[8], o[8];
+  load8(w, in);
+  ge_p3 P;
+  const bool ok = ristretto_decode(P, w);
+  if (!ok) return 0;
+  ristretto_encode(o, P);
+  memcpy(out, o, 32);
+  return 1;
+}
+
+// out = s*P by plain double-and-add over the engine's point formulas; add_out = P + Q, sub_out = P - Q, dbl_out = 2P
+int arith_point_ops(uint8_t mul_out[32], uint8_t add_out[32], uint8_t sub_out[32], uint8_t dbl_out[32], const uint8_t s[32],
+                    const uint8_t p[32], const uint8_t q[32]) {
+  uint32_t w[8], o[8];
+  ge_p3 P, Q;
+  load8(w, p); if (!ristretto_decode(P, w)) return 0;
+  load8(w, q); if (!ristretto_decode(Q, w)) return 0;
+  ge_p3 acc = ge_identity();
+  const ge_cached cP = ge_p3_to_cached(P);
+  for (int bit = 255; bit >= 0; bit--) {
+    acc = ge_double(acc);
+    if ((s[bit >> 3] >> (bit & 7)) & 1) acc = ge_p1p1_to_p3(ge_add_cached(acc, cP, false));
+  }
+  ristretto_encode(o, acc); memcpy(mul_out, o, 32);
+  ristretto_encode(o, ge_add(P, Q)); memcpy(add_out, o, 32);
+  ristretto_encode(o, ge_sub(P, Q)); memcpy(sub_out, o, 32);
+  ristretto_encode(o, ge_double(P)); memcpy(dbl_out, o, 32);
+  return 1;
+}
+
+void arith_from_uniform(uint8_t out[32], const uint8_t wide[64]) {
+  uint32_t w[16], o[8];
+  memcpy(w, wide, 64);
+  ristretto_encode(o, ristretto_from_uniform(w));
+  memcpy(out, o, 32);
+}
+
+// scalars: reduce a 64-byte value; a*b + c; -a; canonicity of a
+void arith_sc(uint8_t red[32], uint8_t muladd[32], uint8_t neg[32], int* canonical, const uint8_t wide[64], const uint8_t a[32],
+              const uint8_t b[32], const uint8_t c[32]) {
+  uint32_t x[16];
+  memcpy(x, wide, 64);
+  sc r = sc_reduce512(x); memcpy(red, r.v, 32);
+  r = sc_muladd(sc_from(a), sc_from(b), sc_from(c)); memcpy(muladd, r.v, 32);
+  r = sc_neg(sc_from(a)); memcpy(neg, r.v, 32);
+  *canonical = sc_is_canonical(sc_from(a)) ? 1 : 0;
+}
+
+// signed-digit recoding used by k_msm: digits of s + bias; returns sum(d_i * radix^i) check value via the caller
+void arith_sc_bias(uint32_t out[8], const uint8_t s[32], uint32_t bias) { sc_bias(out, sc_from(s), bias); }
+
+// field-operation counts (mul, sq) of the building blocks of k_msm / k_decode, measured on this build
+void arith_op_counts(uint64_t out[8][2]) {
+  uint8_t enc[32] = { 0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
+                      0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76 };   // basepoint
+  uint32_t w[8], o[8];
+  load8(w, enc);
+  ge_p3 P;
+  uint64_t c[2];
+  arith_counters(c, 1);
+  ristretto_decode(P, w); arith_counters(out[0], 1);                                     // decode
+  ristretto_encode(o, P); arith_counters(out[1], 1);                                     // encode
+  ge_p2 p2 = ge_p1p1_to_p2(ge_p2_dbl(ge_p3_to_p2(P))); arith_counters(out[2], 1);        // doubling -> p2
+  ge_p3 p3 = ge_p1p1_to_p3(ge_p2_dbl(p2)); arith_counters(out[3], 1);                    // doubling -> p3
+  const ge_cached cP = ge_p3_to_cached_reduced(P); arith_counters(out[4], 1);            // p3 -> table entry
+  p3 = ge_p1p1_to_p3(ge_add_cached(p3, cP, false)); arith_counters(out[5], 1);           // + variable-base entry -> p3
+  ge_niels nq = ge_niels_identity();
+  p3 = ge_p1p1_to_p3(ge_madd(p3, nq, false)); arith_counters(out[6], 1);                 // + generator entry -> p3
+  p2 = ge_p1p1_to_p2(ge_add_cached(p3, cP, false)); arith_counters(out[7], 1);           // + variable-base entry -> p2
+  (void)p2;
+}
+
+}  // extern "C"

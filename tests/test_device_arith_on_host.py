@@ -1,0 +1,135 @@
+"""CPU-only: the engine's DEVICE arithmetic headers (aeonflux_amd/csrc/fe.cuh, sc.cuh, ge.cuh) compiled for the host
+(tests/hostsim/arith_host.cpp) and compared with the oracle and with Python integers.  This is the arithmetic the
+kernels run, statement for statement, so a slip in a carry chain or a bound shows up here without a GPU.  The same
+build measures the field-operation counts that DESIGN.md section 3 publishes."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = 2 ** 255 - 19
+L = 2 ** 252 + 27742317777372353535851937790883648493
+
+
+@pytest.fixture(scope="module")
+def arith(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("arith") / "libarith_host.so")
+    cmd = ["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-I" + os.path.join(ROOT, "tests", "hostsim", "include"), "-o", out,
+           os.path.join(ROOT, "tests", "hostsim", "arith_host.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return C.CDLL(out)
+
+
+def stream(seed, n):
+    return hashlib.shake_256(seed).digest(n)
+
+
+def test_field_ops_against_python_integers(arith):
+    s = stream(b"fe-host", 64 * 400)
+    edge = [bytes(32), (1).to_bytes(32, "little"), (P - 1).to_bytes(32, "little"), (P).to_bytes(32, "little"), b"\xff" * 32,
+            (2 ** 255 - 1).to_bytes(32, "little"), (2 ** 254).to_bytes(32, "little"), (19).to_bytes(32, "little")]
+    cases = [(s[64 * i:64 * i + 32], s[64 * i + 32:64 * i + 64]) for i in range(400)] + [(a, b) for a in edge for b in edge]
+    out = ((C.c_uint8 * 32) * 4)()
+    for a, b in cases:
+        arith.arith_fe(out, a, b)
+        x, y = int.from_bytes(a, "little") % 2 ** 255, int.from_bytes(b, "little") % 2 ** 255
+        got = [int.from_bytes(bytes(o), "little") for o in out]
+        assert got[0] == x * y % P and got[1] == x * x % P
+        assert got[2] == pow(x, P - 2, P) and got[3] == pow(x, (P - 5) // 8, P)
+
+
+def test_lazily_added_operands_at_the_documented_bounds(arith):
+    s = stream(b"fe-lazy", 192 * 300)
+    big = (2 ** 255 - 20).to_bytes(32, "little")
+    cases = [[s[192 * i + 32 * k:192 * i + 32 * k + 32] for k in range(6)] for i in range(300)] + [[big] * 4 + [big, bytes(32)], [big] * 4 + [bytes(32), big]]
+    out = ((C.c_uint8 * 32) * 2)()
+    for c in cases:
+        a = ((C.c_uint8 * 32) * 4)(*[(C.c_uint8 * 32)(*x) for x in c[:4]])
+        b = ((C.c_uint8 * 32) * 2)(*[(C.c_uint8 * 32)(*x) for x in c[4:]])
+        arith.arith_fe_lazy(out, a, b)
+        v = [int.from_bytes(x, "little") % 2 ** 255 for x in c]
+        assert int.from_bytes(bytes(out[0]), "little") == (v[0] + v[1] + v[2] + v[3]) * (v[4] - v[5]) % P
+        assert int.from_bytes(bytes(out[1]), "little") == (v[0] - v[1]) ** 2 % P
+
+
+def test_group_ops_against_the_oracle(arith, primitives):
+    import oracle
+    s = stream(b"ge-host", 64 * 3 * 40)
+    o = [(C.c_uint8 * 32)() for _ in range(4)]
+    for i in range(40):
+        p = oracle.point_from_uniform(s[192 * i:192 * i + 64])
+        q = oracle.point_from_uniform(s[192 * i + 64:192 * i + 128])
+        k = oracle.scalar_reduce_wide(s[192 * i + 128:192 * i + 192])
+        assert arith.arith_point_ops(o[0], o[1], o[2], o[3], k, p, q) == 1
+        assert bytes(o[0]) == oracle.point_scalarmult(k, p)
+        assert bytes(o[1]) == oracle.point_add(p, q) and bytes(o[2]) == oracle.point_sub(p, q)
+        assert bytes(o[3]) == oracle.point_add(p, p)
+        arith.arith_from_uniform(o[0], s[192 * i:192 * i + 64])
+        assert bytes(o[0]) == p
+    # committed fixtures (libsodium / RFC 9496): generator multiples round-trip, invalid encodings are refused,
+    # hash-to-group and scalar multiplication vectors
+    for enc in primitives["base_multiples"]:
+        assert arith.arith_decode_encode(o[0], bytes.fromhex(enc)) == 1 and bytes(o[0]).hex() == enc
+    for v in primitives["validity"]:
+        assert arith.arith_decode_encode(o[0], bytes.fromhex(v["in"])) == (1 if v["valid"] else 0), v["in"]
+    for v in primitives["from_uniform"]:
+        arith.arith_from_uniform(o[0], bytes.fromhex(v["in"]))
+        assert bytes(o[0]).hex() == v["out"]
+    for v in primitives["scalarmult"]:
+        p = bytes.fromhex(v["p"])
+        assert arith.arith_point_ops(o[0], o[1], o[2], o[3], bytes.fromhex(v["s"]), p, p) == 1 and bytes(o[0]).hex() == v["out"]
+
+
+def test_scalar_ops_against_python_integers(arith):
+    s = stream(b"sc-host", 160 * 300)
+    red, ma, ng = ((C.c_uint8 * 32)() for _ in range(3))
+    can = C.c_int(0)
+    edge = [(L - 1).to_bytes(32, "little"), L.to_bytes(32, "little"), bytes(32), b"\xff" * 32]
+    for i in range(300):
+        wide = s[160 * i:160 * i + 64]
+        a, b, c = (s[160 * i + 64 + 32 * k:160 * i + 96 + 32 * k] for k in range(3))
+        if i < 4:
+            a = edge[i]
+            wide = b"\xff" * 64 if i == 0 else wide
+        ai = int.from_bytes(a, "little")
+        # sc_muladd / sc_neg take canonical inputs (the kernels check canonicity first); reduce them here
+        a_r, b_r, c_r = ((int.from_bytes(x, "little") % L).to_bytes(32, "little") for x in (a, b, c))
+        arith.arith_sc(red, ma, ng, C.byref(can), wide, a_r, b_r, c_r)
+        assert int.from_bytes(bytes(red), "little") == int.from_bytes(wide, "little") % L
+        av, bv, cv = (int.from_bytes(x, "little") for x in (a_r, b_r, c_r))
+        assert int.from_bytes(bytes(ma), "little") == (av * bv + cv) % L
+        assert int.from_bytes(bytes(ng), "little") == (-av) % L
+        arith.arith_sc(red, ma, ng, C.byref(can), wide, a, b_r, c_r)
+        assert can.value == (1 if ai < L else 0)
+
+
+def test_signed_digit_recoding(arith):
+    """k_msm's carry-free recoding: the digits of s + bias minus the per-digit offset sum back to s"""
+    s = stream(b"digits", 32 * 100)
+    out = (C.c_uint32 * 8)()
+    for i in range(100):
+        k = int.from_bytes(s[32 * i:32 * i + 32], "little") % L
+        kb = k.to_bytes(32, "little")
+        arith.arith_sc_bias(out, kb, 0x88888888)
+        v = sum(int(out[j]) << (32 * j) for j in range(8))
+        assert sum((((v >> (4 * j)) & 15) - 8) << (4 * j) for j in range(64)) == k
+        arith.arith_sc_bias(out, kb, 0x80808080)
+        v = sum(int(out[j]) << (32 * j) for j in range(8))
+        assert sum((((v >> (8 * j)) & 255) - 128) << (8 * j) for j in range(32)) == k
+
+
+# field multiplications / squarings per building block: the constants behind afx_plan_stats.field_mul / field_sq
+# (aeonflux_amd/csrc/engine.cpp Assembler::msm, plan.h AFX_DECODE_* / AFX_ENCODE_*) and DESIGN.md section 3
+OP_COUNTS = {"decode": (27, 257), "encode": (32, 255), "double_to_p2": (3, 4), "double_to_p3": (4, 4), "table_entry": (1, 0),
+             "add_var_to_p3": (8, 0), "add_fixed_to_p3": (7, 0), "add_var_to_p2": (7, 0)}
+
+
+def test_operation_counts_are_the_published_ones(arith):
+    out = ((C.c_uint64 * 2) * 8)()
+    arith.arith_op_counts(out)
+    got = {k: (int(out[i][0]), int(out[i][1])) for i, k in enumerate(OP_COUNTS)}
+    assert got == OP_COUNTS, got
