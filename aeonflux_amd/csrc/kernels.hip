@@ -239,6 +239,47 @@ AFX_DEV ge_p3 msm_finish_add(const ge_p1p1& r, bool want_t) {
   return o;
 }
 
+// per-lane context of one job inside k_msm
+struct msm_env {
+  const afx_msm_job* job;
+  const int32_t* fixed_tables;
+  const int32_t* lds_tab;
+  const int32_t* table_ws;
+  const uint32_t* digit_ws;
+  uint32_t count, item, dslot, tslot, nv;
+  bool in_lds;
+};
+// acc += (4-bit signed digit of window w) * (variable base t), from the lane's own window table
+AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w, bool want_t) {
+  const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * 8 + ((uint32_t)w >> 3)) * e.count + e.item];
+  const int d = (int)((word >> (((uint32_t)w & 7) * 4)) & 15u) - 8;
+  const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
+  const bool neg = (d < 0) != (e.job->term[t].negate != 0);
+  const int32_t* tab = e.table_ws + ((size_t)(e.tslot + t) * e.count + e.item) * AFX_VAR_TABLE_DWORDS;
+  return msm_finish_add(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), neg), want_t);
+}
+// acc += (8-bit signed digit at window w, w even) * (generator of term t), from the LDS or L2 copy of its table
+AFX_DEV ge_p3 msm_add_fixed(const msm_env& e, const ge_p3& acc, uint32_t t, int w, bool want_t) {
+  const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * 8 + ((uint32_t)w >> 3)) * e.count + e.item];
+  const int d = (int)((word >> (((uint32_t)w & 6) * 4)) & 255u) - 128;
+  const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
+  const bool neg = (d < 0) != (e.job->term[t].negate != 0);
+  ge_niels q;
+  if (e.in_lds) {
+    const int32_t* p = e.lds_tab + (t - e.nv) * AFX_FIXED_TABLE_DWORDS + idx * AFX_NIELS_DWORDS;
+#pragma unroll
+    for (int l = 0; l < 10; l++) { q.ypx.v[l] = p[l]; q.ymx.v[l] = p[10 + l]; q.xy2d.v[l] = p[20 + l]; }
+  } else {
+    const int2* p = reinterpret_cast<const int2*>(e.fixed_tables + (size_t)e.job->term[t].fixed_idx * AFX_FIXED_TABLE_DWORDS + idx * AFX_NIELS_DWORDS);
+    int32_t v[30];
+#pragma unroll
+    for (int l = 0; l < 15; l++) { const int2 x = p[l]; v[2 * l] = x.x; v[2 * l + 1] = x.y; }
+#pragma unroll
+    for (int l = 0; l < 10; l++) { q.ypx.v[l] = v[l]; q.ymx.v[l] = v[10 + l]; q.xy2d.v[l] = v[20 + l]; }
+  }
+  return msm_finish_add(ge_madd(acc, q, neg), want_t);
+}
+
 __global__ void __launch_bounds__(AFX_BLOCK, 2)
 k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_tables, const int32_t* __restrict__ pos_tables,
       int32_t* __restrict__ table_ws, uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count) {
@@ -250,7 +291,7 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_ta
   const afx_msm_job* job = &jobs[blockIdx.y];
 #pragma unroll 1
   for (;;) {
-  const uint32_t nt = job->n_terms, nv = job->n_var, nf = nt - nv;
+  const uint32_t nt = job->n_terms, nv = job->n_var, nf = nt - nv, nu = job->n_uni;
   const bool in_lds = nf <= AFX_FIXED_LDS_MAX && nv != 0;
   __syncthreads();   // the previous job of this chain is done with the LDS tables
   if (in_lds) {
@@ -262,33 +303,47 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_ta
   }
   __syncthreads();
 
-  // recode scalars, stored [slot][8][count]
+  // recode the per-item scalars, stored [slot][8][count] (batch-constant NAF terms need none)
   const uint32_t dslot = job->digit_slot;
 #pragma unroll 1
-  for (uint32_t t = 0; t < nt; t++) {
+  for (uint32_t t = nu; t < nt; t++) {
     const sc s = sc_load_item(job->term[t].scalar, job->term[t].scalar_stride, item);
     uint32_t b[8];
     sc_bias(b, s, t < nv ? 0x88888888u : 0x80808080u);
 #pragma unroll
     for (int i = 0; i < 8; i++) digit_ws[((size_t)(dslot + t) * 8 + i) * count + item] = b[i];
   }
-  // per-lane window tables for the variable bases
+  // per-lane window tables for the variable bases: multiples 0..8 for 4-bit signed windows, or the odd multiples
+  // 1, 3, ..., 15 for the terms that run a width-5 NAF
   const uint32_t tslot = job->table_slot;
 #pragma unroll 1
   for (uint32_t t = 0; t < nv; t++) {
     int32_t* tab = table_ws + ((size_t)(tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
     const ge_p3 P = var_load(job->term[t].var, count, item);
-    const ge_cached cP = ge_p3_to_cached_reduced(P);
-    cached_store(tab, ge_cached_identity());
-    cached_store(tab + AFX_TABLE_ENTRY_DWORDS, cP);
     ge_p3 Q = P;
+    if (t < nu) {
+      const ge_cached c2 = ge_p3_to_cached(ge_double(P));
+      cached_store(tab, ge_p3_to_cached_reduced(P));
 #pragma unroll 1
-    for (int k = 2; k < AFX_TABLE_ENTRIES; k++) {
-      Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
-      cached_store(tab + k * AFX_TABLE_ENTRY_DWORDS, ge_p3_to_cached_reduced(Q));
+      for (int k = 1; k < 8; k++) {
+        Q = ge_p1p1_to_p3(ge_add_cached(Q, c2, false));
+        cached_store(tab + k * AFX_TABLE_ENTRY_DWORDS, ge_p3_to_cached_reduced(Q));
+      }
+    } else {
+      const ge_cached cP = ge_p3_to_cached_reduced(P);
+      cached_store(tab, ge_cached_identity());
+      cached_store(tab + AFX_TABLE_ENTRY_DWORDS, cP);
+#pragma unroll 1
+      for (int k = 2; k < AFX_TABLE_ENTRIES; k++) {
+        Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
+        cached_store(tab + k * AFX_TABLE_ENTRY_DWORDS, ge_p3_to_cached_reduced(Q));
+      }
     }
   }
 
+  msm_env env;
+  env.job = job; env.fixed_tables = fixed_tables; env.lds_tab = lds_tab; env.table_ws = table_ws; env.digit_ws = digit_ws;
+  env.count = count; env.item = item; env.dslot = dslot; env.tslot = tslot; env.nv = nv; env.in_lds = in_lds;
   ge_p3 acc = ge_identity();
   if (nv == 0) {
     // fixed bases only: sum over byte positions of positional-table entries, no doublings (32 additions per base)
@@ -311,6 +366,38 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_ta
         acc = ge_p1p1_to_p3(ge_madd(acc, q, neg));
       }
     }
+  } else if (nu != 0) {
+    // some scalars are batch constants: bit-serial chain, their width-5 NAF digits (the same for every lane, so the
+    // branches are uniform) add odd multiples at ~1/6 of the bit positions; per-item terms keep their windows
+    const int8_t* naf = job->naf;
+    const uint8_t* nafc = job->naf_count;
+    const int top = job->top_bit;
+#pragma unroll 1
+    for (int bit = top; bit >= 0; bit--) {
+      const uint32_t nuni = nafc[bit];
+      const uint32_t nadd = nuni + ((bit & 3) == 0 ? nv - nu : 0u) + ((bit & 7) == 0 ? nf : 0u);
+      if (bit != top) acc = msm_finish_add(ge_p2_dbl(ge_p3_to_p2(acc)), nadd != 0 || bit == 0);
+      uint32_t done = 0;
+      if (nuni != 0) {
+#pragma unroll 1
+        for (uint32_t t = 0; t < nu; t++) {
+          const int d = naf[t * 256 + bit];
+          if (d == 0) continue;
+          const uint32_t idx = (uint32_t)((d < 0 ? -d : d) - 1) >> 1;
+          const int32_t* tab = table_ws + ((size_t)(tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
+          done++;
+          acc = msm_finish_add(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), d < 0), done != nadd || bit == 0);
+        }
+      }
+      if ((bit & 3) == 0) {
+#pragma unroll 1
+        for (uint32_t t = nu; t < nv; t++) { done++; acc = msm_add_var(env, acc, t, bit >> 2, done != nadd || bit == 0); }
+      }
+      if ((bit & 7) == 0) {
+#pragma unroll 1
+        for (uint32_t t = nv; t < nt; t++) { done++; acc = msm_add_fixed(env, acc, t, bit >> 2, done != nadd || bit == 0); }
+      }
+    }
   } else {
 #pragma unroll 1
   for (int w = 63; w >= 0; w--) {
@@ -322,41 +409,12 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_ta
       for (int k = 0; k < 3; k++) a2 = ge_p1p1_to_p2(ge_p2_dbl(a2));
       acc = msm_finish_add(ge_p2_dbl(a2), nadd != 0);
     }
-    const uint32_t wi = (uint32_t)w >> 3;
     uint32_t done = 0;
 #pragma unroll 1
-    for (uint32_t t = 0; t < nv; t++) {
-      const uint32_t word = digit_ws[((size_t)(dslot + t) * 8 + wi) * count + item];
-      const int d = (int)((word >> (((uint32_t)w & 7) * 4)) & 15u) - 8;
-      const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
-      const bool neg = (d < 0) != (job->term[t].negate != 0);
-      const int32_t* tab = table_ws + ((size_t)(tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
-      done++;
-      acc = msm_finish_add(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), neg), done != nadd || w == 0);
-    }
+    for (uint32_t t = 0; t < nv; t++) { done++; acc = msm_add_var(env, acc, t, w, done != nadd || w == 0); }
     if (fixed_now) {
 #pragma unroll 1
-      for (uint32_t t = nv; t < nt; t++) {
-        const uint32_t word = digit_ws[((size_t)(dslot + t) * 8 + wi) * count + item];
-        const int d = (int)((word >> (((uint32_t)w & 6) * 4)) & 255u) - 128;
-        const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
-        const bool neg = (d < 0) != (job->term[t].negate != 0);
-        ge_niels q;
-        if (in_lds) {
-          const int32_t* e = lds_tab + (t - nv) * AFX_FIXED_TABLE_DWORDS + idx * AFX_NIELS_DWORDS;
-#pragma unroll
-          for (int l = 0; l < 10; l++) { q.ypx.v[l] = e[l]; q.ymx.v[l] = e[10 + l]; q.xy2d.v[l] = e[20 + l]; }
-        } else {
-          const int2* e = reinterpret_cast<const int2*>(fixed_tables + (size_t)job->term[t].fixed_idx * AFX_FIXED_TABLE_DWORDS + idx * AFX_NIELS_DWORDS);
-          int32_t v[30];
-#pragma unroll
-          for (int l = 0; l < 15; l++) { const int2 x = e[l]; v[2 * l] = x.x; v[2 * l + 1] = x.y; }
-#pragma unroll
-          for (int l = 0; l < 10; l++) { q.ypx.v[l] = v[l]; q.ymx.v[l] = v[10 + l]; q.xy2d.v[l] = v[20 + l]; }
-        }
-        done++;
-        acc = msm_finish_add(ge_madd(acc, q, neg), done != nadd || w == 0);
-      }
+      for (uint32_t t = nv; t < nt; t++) { done++; acc = msm_add_fixed(env, acc, t, w, done != nadd || w == 0); }
     }
   }
   }

@@ -197,7 +197,7 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is an N=1 figure
         S = 256
         hin = {k: v[..., :S, :].cpu().numpy() for k, v in d_in.items()}
         t0 = time.perf_counter()
@@ -466,7 +466,7 @@ def main():
         assert np.array_equal(hst, want)
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is an N=1 figure
         import oracle   # ORACLE: only here, as the timed CPU baseline and the checker
         olib = oracle.load(native=True)
         olib.afxo_ctx_new.restype = C.c_void_p
