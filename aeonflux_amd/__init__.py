@@ -124,6 +124,11 @@ def lib():
         _LIB.afx_verify_presentations_wire.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _LIB.afx_ctx_set_pipelining.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_get_plan_stats.argtypes = [C.c_void_p, C.c_void_p]
+        _LIB.afx_ctx_issuer_parameters.argtypes = [C.c_void_p, C.c_void_p]
+        _LIB.afx_issuance_wire_header_bytes.restype = C.c_size_t
+        _LIB.afx_issuance_wire_header_bytes.argtypes = [C.c_uint32]
+        _LIB.afx_issuance_wire_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _LIB.afx_verify_issuances_wire.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         _LIB.afx_ctx_set_challenge_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
         _LIB.afx_ctx_get_challenge_trace.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.afx_ctx_synchronize.argtypes = [C.c_void_p]
@@ -161,6 +166,21 @@ class Context:
 
     def __del__(self):
         self.close()
+
+    def issuer_parameters(self):
+        """IssuerParameters as C_W || I (64 bytes)"""
+        out = C.create_string_buffer(64)
+        check(lib().afx_ctx_issuer_parameters(self.h, out))
+        return out.raw
+
+    def verify_issuances_wire(self, blob):
+        """CredentialIssuance::verify over an AFXI batch; returns the status array"""
+        import numpy as np
+        n, kinds, nr, count, off = C.c_uint32(0), (C.c_uint8 * 32)(), C.c_uint32(0), C.c_size_t(0), C.c_size_t(0)
+        check(lib().afx_issuance_wire_parse(blob, len(blob), C.byref(n), kinds, C.byref(nr), C.byref(count), C.byref(off)))
+        status = np.full(max(1, count.value), 255, np.uint8)
+        check(lib().afx_verify_issuances_wire(self.h, blob, len(blob), status.ctypes.data, status.size, C.byref(count)))
+        return status[:count.value]
 
     def plan_stats(self):
         """per-item operation counts of the most recent call (afx_plan_stats) as a dict"""

@@ -10,7 +10,9 @@
 #define AFX_TABLE_ENTRIES 9            /* variable bases: 0*P (identity) .. 8*P, signed 4-bit windows */
 #define AFX_FIXED_ENTRIES 129         /* fixed bases: 0*G .. 128*G, signed 8-bit windows          */
 #define AFX_POS_TABLE_DWORDS (32 * AFX_FIXED_TABLE_DWORDS) /* positional tables: for every byte position j, d * 256^j * G */
-#define AFX_FIXED_LDS_MAX 4           /* a job stages its fixed tables in LDS when it has at most this many */
+#ifndef AFX_FIXED_LDS_MAX
+#define AFX_FIXED_LDS_MAX 4
+#endif /* a job stages its fixed tables in LDS when it has at most this many */
 #define AFX_VAR_DWORDS 40              /* extended point: X,Y,Z,T x 10 limbs */
 #define AFX_NIELS_DWORDS 30            /* affine niels: y+x, y-x, 2dxy */
 #define AFX_FIXED_TABLE_DWORDS 3872    /* AFX_FIXED_ENTRIES * AFX_NIELS_DWORDS = 3870, padded to a 16-byte multiple */

@@ -704,3 +704,64 @@ extern "C" int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, 
   AFX_HIP(hipStreamSynchronize(ctx->stream));
   return AFX_OK;
 }
+
+// ---- CredentialIssuance batches ("AFXI" v1) -----------------------------------------------------
+extern "C" size_t afx_issuance_wire_header_bytes(uint32_t n_attributes) {
+  if (n_attributes > AFX_MAX_ATTRIBUTES) return 0;
+  return (24 + (size_t)n_attributes + 31) & ~size_t(31);
+}
+extern "C" int afx_issuance_wire_parse(const uint8_t* blob, size_t len, uint32_t* n_out, uint8_t kinds_out[AFX_MAX_ATTRIBUTES], uint32_t* nr_out,
+                                       size_t* count_out, size_t* records_offset_out) {
+  if (!blob || !n_out || !kinds_out || !nr_out || !count_out || !records_offset_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (len < 24 || memcmp(blob, "AFXI", 4) != 0 || rd32(blob + 4) != 1) { set_error("not an AFXI v1 batch"); return AFX_E_BAD_ARGS; }
+  const uint32_t count = rd32(blob + 8), cells = rd32(blob + 12), n = rd32(blob + 16), nr = rd32(blob + 20);
+  if (n > AFX_MAX_ATTRIBUTES || nr > AFX_MAX_ATTRIBUTES + 5) { set_error("layout field out of range"); return AFX_E_BAD_ARGS; }
+  const size_t hdr = afx_issuance_wire_header_bytes(n);
+  if (len < hdr) { set_error("truncated header"); return AFX_E_BAD_ARGS; }
+  for (uint32_t i = 0; i < n; i++)
+    if (blob[24 + i] > AFX_ATTR_SECRET_POINT) { set_error("attribute kind out of range"); return AFX_E_BAD_ARGS; }
+  if (cells != 4 + nr + n) { set_error("cells_per_record does not match the layout"); return AFX_E_BAD_ARGS; }
+  if ((len - hdr) / 32 / cells < count || len != hdr + (size_t)count * cells * 32) { set_error("record area length"); return AFX_E_BAD_ARGS; }
+  memset(kinds_out, 0, AFX_MAX_ATTRIBUTES);
+  memcpy(kinds_out, blob + 24, n);
+  *n_out = n; *nr_out = nr; *count_out = count; *records_offset_out = hdr;
+  return AFX_OK;
+}
+extern "C" int afx_verify_issuances_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  if (!ctx || !status || !count_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  afx_attributes_soa at;
+  memset(&at, 0, sizeof at);
+  uint32_t nr = 0;
+  size_t count = 0, off = 0;
+  int rc = afx_issuance_wire_parse(blob, len, &at.n_attributes, at.kinds, &nr, &count, &off);
+  if (rc) return rc;
+  *count_out = count;
+  if (count == 0) return AFX_OK;
+  if (status_cap < count) { set_error("status buffer too small"); return AFX_E_BAD_ARGS; }
+  if (count > 0xffffffffu / 64) { set_error("batch too large for one call"); return AFX_E_BAD_ARGS; }
+  AFX_HIP(hipSetDevice(ctx->device));
+  const uint32_t n = at.n_attributes, cells = 4 + nr + n;
+  std::vector<uint32_t> row_of_cell(cells);
+  for (uint32_t r = 0; r < cells; r++) row_of_cell[r] = r;   // SoA rows in record order: t U V challenge responses[] values[]
+  Stager st(ctx);
+  const size_t o_rec = st.add(blob + off, (size_t)count * cells * 32), o_map = st.add((const uint8_t*)row_of_cell.data(), 4 * (size_t)cells),
+               o_soa = st.add(nullptr, (size_t)count * cells * 32), o_st = st.add(nullptr, count);
+  if ((rc = st.upload())) return rc;
+  AFX_HIP(afxk_aos_to_soa(ctx->stream, st.dev(o_rec), st.dev(o_soa), (const uint32_t*)st.dev(o_map), cells, (uint32_t)count));
+  auto rowp = [&](uint32_t r) { return (uint8_t*)st.dev(o_soa) + (size_t)r * count * 32; };
+  at.values = rowp(4 + nr);
+  const afx_issuance_soa iss = { rowp(0), rowp(1), rowp(2), rowp(3), rowp(4) };
+  if ((rc = afx_verify_issuances_dev(ctx, &at, &iss, nr, count, st.dev(o_st)))) return rc;
+  AFX_HIP(hipMemcpyAsync(status, st.dev(o_st), count, hipMemcpyDeviceToHost, ctx->stream));
+  AFX_HIP(hipStreamSynchronize(ctx->stream));
+  return AFX_OK;
+}
+extern "C" int afx_ctx_issuer_parameters(afx_ctx* c, uint8_t out[64]) {
+  if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  memcpy(out, c->gen_enc[c->id_CW()].data(), 32);
+  memcpy(out + 32, c->gen_enc[c->id_I()].data(), 32);
+  return AFX_OK;
+}

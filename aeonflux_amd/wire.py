@@ -67,3 +67,31 @@ def unpack_presentations(blob):
     for _ in range(ne):
         p["enc"].append({f: (take(6) if f == "responses" else take(1)[0]) for f in ENC_ORDER})
     return shape, p
+
+
+# ---- CredentialIssuance batches ("AFXI" v1) -------------------------------------------------------
+def pack_issuances(kinds, values, iss):
+    """kinds: AFX_ATTR_* per position; values [n,count,32]; iss: dict t,U,V,challenge [count,32], responses [nr,count,32]"""
+    n = len(kinds)
+    values = np.asarray(values, dtype=np.uint8).reshape(n, -1, 32) if n else np.zeros((0, iss["t"].shape[0], 32), np.uint8)
+    count, nr = iss["t"].shape[0], iss["responses"].shape[0]
+    cols = [iss["t"][None], iss["U"][None], iss["V"][None], iss["challenge"][None], iss["responses"], values]
+    soa = np.concatenate([np.asarray(c, dtype=np.uint8) for c in cols], axis=0)
+    cells = 4 + nr + n
+    assert soa.shape == (cells, count, 32)
+    h = b"AFXI" + struct.pack("<5I", 1, count, cells, n, nr) + bytes(kinds)
+    h += bytes(-len(h) % 32)
+    return h + np.ascontiguousarray(soa.transpose(1, 0, 2)).tobytes()
+
+
+def unpack_issuances(blob):
+    """wire bytes -> (kinds, values [n,count,32], issuance dict)"""
+    assert blob[:4] == b"AFXI"
+    ver, count, cells, n, nr = struct.unpack("<5I", blob[4:24])
+    assert ver == 1 and cells == 4 + nr + n
+    kinds = list(blob[24:24 + n])
+    o = (24 + n + 31) & ~31
+    rec = np.frombuffer(blob, dtype=np.uint8, offset=o).reshape(count, cells, 32).transpose(1, 0, 2)
+    c = lambda a: np.ascontiguousarray(a)
+    iss = {"t": c(rec[0]), "U": c(rec[1]), "V": c(rec[2]), "challenge": c(rec[3]), "responses": c(rec[4:4 + nr])}
+    return kinds, c(rec[4 + nr:]), iss

@@ -195,6 +195,24 @@ int afx_wire_parse(const uint8_t* blob, size_t len, afx_shape* shape_out, size_t
  * kernel, and verified.  status must hold `count` bytes (status_cap >= count). */
 int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out);
 
+/* A batch of CredentialIssuance messages of one attribute layout (issuer.rs:42-45: proof + credential{amac, attributes};
+ * the reference has no to_bytes for it either), same style:
+ *   header : "AFXI" | u32le version (1) | u32le count | u32le cells_per_record | u32le n_attributes | u32le n_responses
+ *            | kinds[n_attributes] (u8, AFX_ATTR_*) | zero pad to 32 B
+ *   records: count x cells_per_record x 32 bytes, each record =
+ *            t | U | V | challenge | responses[n_responses] | value of every attribute (Sc, or Pt = M1), position order
+ * cells_per_record = 4 + n_responses + n_attributes. */
+size_t afx_issuance_wire_header_bytes(uint32_t n_attributes);
+int afx_issuance_wire_parse(const uint8_t* blob, size_t len, uint32_t* n_attributes_out, uint8_t kinds_out[AFX_MAX_ATTRIBUTES],
+                            uint32_t* n_responses_out, size_t* count_out, size_t* records_offset_out);
+/* CredentialIssuance::verify (issuer.rs:48-57) over a serialized batch; the context needs no issuer key. */
+int afx_verify_issuances_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out);
+
+/* IssuerParameters in the byte form the crate intends (C_W || I, 64 bytes; issuer.rs:155,163 - its own
+ * to_bytes/from_bytes are unimplemented!(), parameters.rs:365-372): what afx_ctx_create was given, or what an
+ * issuer context derived from its key. */
+int afx_ctx_issuer_parameters(afx_ctx* ctx, uint8_t out[64]);
+
 /* ProofOfEncryption::verify alone (src/nizk/encryption.rs:154-210); `index` = ProofOfEncryption.index */
 int afx_verify_encryption_proofs(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* batch, size_t count,
                                  uint8_t* status);

@@ -64,6 +64,8 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     except afx.AfxError as e:
         assert e.rc == afx.E_BAD_ARGS
     ctx.set_challenge_trace(0, 0)
+    iblob = wire.pack_issuances(kinds, values, iss)
+    assert len(ctx.verify_issuances_wire(iblob)) == 3 and len(ctx.issuer_parameters()) == 64
     blob = wire.pack_presentations(shape, pres)
     stt, cnt = np.zeros(3, np.uint8), C.c_size_t(0)
     assert afx.lib().afx_verify_presentations_wire(ctx.h, blob, len(blob), stt.ctypes.data, 3, C.byref(cnt)) == 0 and cnt.value == 3

@@ -68,3 +68,62 @@ def test_wire_verify_matches_oracle(n, layout, hide, count):
     afx.check(afx.lib().afx_verify_presentations_wire(ctx.h, blob, len(blob), status.ctypes.data, count, C.byref(cnt)))
     ctx.close()
     assert cnt.value == count and status.tolist() == want
+
+
+def test_issuance_wire_roundtrip_and_c_parser():
+    import aeonflux_amd as afx
+    from aeonflux_amd import wire
+    rng = np.random.default_rng(11)
+    rb = lambda *s: rng.integers(0, 256, size=s, dtype=np.uint8)
+    kinds, count = [0, 0, 2, 3], 7
+    values = rb(4, count, 32)
+    iss = {"t": rb(count, 32), "U": rb(count, 32), "V": rb(count, 32), "challenge": rb(count, 32), "responses": rb(9, count, 32)}
+    blob = wire.pack_issuances(kinds, values, iss)
+    assert len(blob) == 32 + count * (4 + 9 + 4) * 32
+    k2, v2, i2 = wire.unpack_issuances(blob)
+    assert k2 == kinds and np.array_equal(v2, values) and all(np.array_equal(iss[f], i2[f]) for f in iss)
+    lib = afx.lib()
+    n, kk, nr, cnt, off = C.c_uint32(0), (C.c_uint8 * 32)(), C.c_uint32(0), C.c_size_t(0), C.c_size_t(0)
+    args = (C.byref(n), kk, C.byref(nr), C.byref(cnt), C.byref(off))
+    assert lib.afx_issuance_wire_parse(blob, len(blob), *args) == 0
+    assert (n.value, list(kk[:4]), nr.value, cnt.value, off.value) == (4, kinds, 9, count, 32)
+    assert lib.afx_issuance_wire_header_bytes(4) == 32 and lib.afx_issuance_wire_header_bytes(16) == 64 and lib.afx_issuance_wire_header_bytes(33) == 0
+    bad = [blob[:-1], blob + b"\0", b"AFXP" + blob[4:], blob[:4] + struct.pack("<I", 2) + blob[8:], blob[:12] + struct.pack("<I", 16) + blob[16:],
+           blob[:16] + struct.pack("<I", 40) + blob[20:], blob[:8] + struct.pack("<I", 1 << 30) + blob[12:], blob[:20], blob[:24] + b"\x09" + blob[25:]]
+    for b in bad:
+        assert lib.afx_issuance_wire_parse(b, len(b), *args) == afx.E_BAD_ARGS
+
+
+@pytest.mark.gpu
+def test_issuance_wire_verify_matches_oracle_and_issuer_parameters():
+    import aeonflux_amd as afx
+    from aeonflux_amd import wire
+    from tests.helpers import make_credentials
+    n, cnt = 4, 40
+    d = make_credentials(n, "SSPE", cnt, b"wire-iss")
+    kinds = list(d["creds"][0]["kinds"])
+    values = np.zeros((n, cnt, 32), np.uint8)
+    iss = {k: np.zeros((cnt, 32), np.uint8) for k in ("t", "U", "V", "challenge")}
+    iss["responses"] = np.zeros((n + 5, cnt, 32), np.uint8)
+    want = []
+    for i, cr in enumerate(d["creds"]):
+        t, V, resp = bytearray(cr["t"]), bytearray(cr["V"]), [bytearray(r) for r in cr["responses"]]
+        if i % 5 == 1:
+            resp[2][7] ^= 1
+        if i % 5 == 3:
+            V = bytearray(d["creds"][(i + 1) % cnt]["V"])
+        want.append(d["user"].issuance_verify(kinds, cr["values"], bytes(t), cr["U"], bytes(V), cr["challenge"], [bytes(r) for r in resp]))
+        for k in range(n):
+            values[k, i] = np.frombuffer(cr["values"][k][:32], np.uint8)
+        for name, v in (("t", bytes(t)), ("U", cr["U"]), ("V", bytes(V)), ("challenge", cr["challenge"])):
+            iss[name][i] = np.frombuffer(v, np.uint8)
+        for k in range(n + 5):
+            iss["responses"][k, i] = np.frombuffer(bytes(resp[k]), np.uint8)
+    blob = wire.pack_issuances(kinds, values, iss)
+    user = afx.Context(d["params"], None, d["ip"])
+    assert user.verify_issuances_wire(blob).tolist() == want and 0 in want and 1 in want
+    assert user.issuer_parameters() == d["ip"]
+    user.close()
+    issuer = afx.Context(d["params"], d["key"], d["ip"])
+    assert issuer.issuer_parameters() == d["ip"]
+    issuer.close()
