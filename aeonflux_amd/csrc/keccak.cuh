@@ -1,6 +1,10 @@
 // Keccak-f[1600] for gfx950: 25 x 64-bit lanes in registers, one sponge per GPU lane.
 // Underlies the STROBE-128 / merlin transcript hashing the reference reaches through zkp::Transcript
 // [3P] (/root/reference/src/nizk/presentation.rs:355, encryption.rs:160, issuance.rs:142).
+//
+// Written on 32-bit halves: a 64-bit rotation is two v_alignbit_b32 (none when the amount is 32), chi is one
+// v_xor + one v_bfi per half.  Left to the compiler as uint64_t shifts, the same round came out 3.5 times longer
+// (64-bit shift/add and multiply forms of the rotations plus ~260 register moves per round).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -12,32 +16,61 @@ __device__ __constant__ const uint64_t KECCAK_RC[24] = {
   0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
   0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL };
 
-__device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+// low 32 bits of ((hi:lo) >> s), 0 < s < 32
+__device__ __forceinline__ uint32_t kk_align(uint32_t hi, uint32_t lo, int s) {
+#if defined(__HIPCC__)
+  return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)s);
+#else
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> s);
+#endif
+}
+struct kk_lane { uint32_t lo, hi; };
+template <int N>
+__device__ __forceinline__ kk_lane kk_rotl(const kk_lane& x) {
+  kk_lane r;
+  if constexpr (N == 0) { r = x; }
+  else if constexpr (N == 32) { r.lo = x.hi; r.hi = x.lo; }
+  else if constexpr (N < 32) { r.lo = kk_align(x.lo, x.hi, 32 - N); r.hi = kk_align(x.hi, x.lo, 32 - N); }
+  else { r.lo = kk_align(x.hi, x.lo, 64 - N); r.hi = kk_align(x.lo, x.hi, 64 - N); }
+  return r;
+}
+__device__ __forceinline__ kk_lane kk_xor(const kk_lane& a, const kk_lane& b) { return { a.lo ^ b.lo, a.hi ^ b.hi }; }
+// a ^ (~b & c)
+__device__ __forceinline__ kk_lane kk_chi(const kk_lane& a, const kk_lane& b, const kk_lane& c) {
+  return { a.lo ^ (~b.lo & c.lo), a.hi ^ (~b.hi & c.hi) };
+}
 
 // state index = x + 5*y
-__device__ __forceinline__ void keccak_f1600(uint64_t a[25]) {
+__device__ __forceinline__ void keccak_f1600(uint64_t st[25]) {
+  kk_lane a[25];
+#pragma unroll
+  for (int i = 0; i < 25; i++) { a[i].lo = (uint32_t)st[i]; a[i].hi = (uint32_t)(st[i] >> 32); }
 #pragma unroll 1
   for (int round = 0; round < 24; round++) {
-    uint64_t c[5], d[5];
+    kk_lane c[5], d[5];
 #pragma unroll
-    for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+    for (int x = 0; x < 5; x++) c[x] = kk_xor(kk_xor(kk_xor(a[x], a[x + 5]), kk_xor(a[x + 10], a[x + 15])), a[x + 20]);
 #pragma unroll
-    for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
+    for (int x = 0; x < 5; x++) d[x] = kk_xor(c[(x + 4) % 5], kk_rotl<1>(c[(x + 1) % 5]));
 #pragma unroll
-    for (int i = 0; i < 25; i++) a[i] ^= d[i % 5];
+    for (int i = 0; i < 25; i++) a[i] = kk_xor(a[i], d[i % 5]);
     // rho + pi: b[y + 5*((2x+3y)%5)] = rotl(a[x+5y], r[x][y])
-    uint64_t b[25];
+    kk_lane b[25];
     b[0] = a[0];
-    b[10] = rotl64(a[1], 1);   b[20] = rotl64(a[2], 62);  b[5] = rotl64(a[3], 28);   b[15] = rotl64(a[4], 27);
-    b[16] = rotl64(a[5], 36);  b[1] = rotl64(a[6], 44);   b[11] = rotl64(a[7], 6);   b[21] = rotl64(a[8], 55);  b[6] = rotl64(a[9], 20);
-    b[7] = rotl64(a[10], 3);   b[17] = rotl64(a[11], 10); b[2] = rotl64(a[12], 43);  b[12] = rotl64(a[13], 25); b[22] = rotl64(a[14], 39);
-    b[23] = rotl64(a[15], 41); b[8] = rotl64(a[16], 45);  b[18] = rotl64(a[17], 15); b[3] = rotl64(a[18], 21);  b[13] = rotl64(a[19], 8);
-    b[14] = rotl64(a[20], 18); b[24] = rotl64(a[21], 2);  b[9] = rotl64(a[22], 61);  b[19] = rotl64(a[23], 56); b[4] = rotl64(a[24], 14);
+    b[10] = kk_rotl<1>(a[1]);   b[20] = kk_rotl<62>(a[2]);  b[5] = kk_rotl<28>(a[3]);   b[15] = kk_rotl<27>(a[4]);
+    b[16] = kk_rotl<36>(a[5]);  b[1] = kk_rotl<44>(a[6]);   b[11] = kk_rotl<6>(a[7]);   b[21] = kk_rotl<55>(a[8]);  b[6] = kk_rotl<20>(a[9]);
+    b[7] = kk_rotl<3>(a[10]);   b[17] = kk_rotl<10>(a[11]); b[2] = kk_rotl<43>(a[12]);  b[12] = kk_rotl<25>(a[13]); b[22] = kk_rotl<39>(a[14]);
+    b[23] = kk_rotl<41>(a[15]); b[8] = kk_rotl<45>(a[16]);  b[18] = kk_rotl<15>(a[17]); b[3] = kk_rotl<21>(a[18]);  b[13] = kk_rotl<8>(a[19]);
+    b[14] = kk_rotl<18>(a[20]); b[24] = kk_rotl<2>(a[21]);  b[9] = kk_rotl<61>(a[22]);  b[19] = kk_rotl<56>(a[23]); b[4] = kk_rotl<14>(a[24]);
 #pragma unroll
     for (int y = 0; y < 25; y += 5) {
 #pragma unroll
-      for (int x = 0; x < 5; x++) a[y + x] = b[y + x] ^ (~b[y + (x + 1) % 5] & b[y + (x + 2) % 5]);
+      for (int x = 0; x < 5; x++) a[y + x] = kk_chi(b[y + x], b[y + (x + 1) % 5], b[y + (x + 2) % 5]);
     }
-    a[0] ^= KECCAK_RC[round];
+    const uint64_t rc = KECCAK_RC[round];
+    a[0].lo ^= (uint32_t)rc;
+    a[0].hi ^= (uint32_t)(rc >> 32);
   }
+#pragma unroll
+  for (int i = 0; i < 25; i++) st[i] = (uint64_t)a[i].lo | ((uint64_t)a[i].hi << 32);
 }
