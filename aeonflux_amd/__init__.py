@@ -124,6 +124,7 @@ def lib():
         _LIB.afx_verify_presentations_wire.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _LIB.afx_ctx_set_pipelining.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_get_plan_stats.argtypes = [C.c_void_p, C.c_void_p]
+        _LIB.afx_ctx_set_strict.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_issuer_parameters.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.afx_issuance_wire_header_bytes.restype = C.c_size_t
         _LIB.afx_issuance_wire_header_bytes.argtypes = [C.c_uint32]
@@ -166,6 +167,10 @@ class Context:
 
     def __del__(self):
         self.close()
+
+    def set_strict(self, enable):
+        """opt-in strict mode (not the reference's behaviour): see afx_ctx_set_strict in include/aeonflux_gpu.h"""
+        check(lib().afx_ctx_set_strict(self.h, 1 if enable else 0))
 
     def issuer_parameters(self):
         """IssuerParameters as C_W || I (64 bytes)"""

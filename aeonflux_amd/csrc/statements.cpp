@@ -89,6 +89,12 @@ extern "C" int afx_ctx_get_challenge_trace(afx_ctx* c, uint8_t* host_out) {
   AFX_HIP(hipMemcpy(host_out, c->trace, c->trace_rows * c->trace_count * 32, hipMemcpyDeviceToHost));
   return AFX_OK;
 }
+extern "C" int afx_ctx_set_strict(afx_ctx* c, int enable) {
+  if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  c->strict = enable != 0;
+  return AFX_OK;
+}
 extern "C" int afx_ctx_get_plan_stats(afx_ctx* c, afx_plan_stats* out) {
   if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
@@ -309,7 +315,7 @@ static void add_encproof_verify(Assembler& as, JobSets& js, uint16_t index, cons
 // per-item array is touched.  Also yields the compact C_y list and, per compact index, which hidden-scalar slot
 // constraint #3 looks up (presentation.rs:427-433 uses the compact index as an original position).
 static bool presentation_shape_rejects(const afx_ctx* c, const afx_shape& sh, uint32_t keep[AFX_MAX_ATTRIBUTES], uint32_t* k_out,
-                                       int hidden_slot[AFX_MAX_ATTRIBUTES]) {
+                                       int hidden_slot[AFX_MAX_ATTRIBUTES], uint32_t pos[AFX_MAX_ATTRIBUTES]) {
   const uint32_t n = sh.n_attributes, hs = sh.n_hidden_scalars;
   if (n > c->n || n > AFX_MAX_ATTRIBUTES || hs > AFX_MAX_ATTRIBUTES || sh.n_enc_proofs > AFX_MAX_ATTRIBUTES ||
       sh.n_responses != 3 + hs /* verify_compact: responses.len() != num_scalars */)
@@ -323,13 +329,27 @@ static bool presentation_shape_rejects(const afx_ctx* c, const afx_shape& sh, ui
   uint32_t k = 0;
   for (uint32_t i = 0; i < n; i++)
     if (sh.kinds[i] != AFX_ENC_SECRET_POINT) keep[k++] = i;
+  if (c->strict) {
+    // one proof of encryption per hidden group element, in position order
+    uint32_t e = 0;
+    for (uint32_t i = 0; i < n; i++)
+      if (sh.kinds[i] == AFX_ENC_SECRET_POINT) {
+        if (e >= sh.n_enc_proofs || sh.enc_indices[e] != i) return true;
+        e++;
+      }
+    if (e != sh.n_enc_proofs) return true;
+  }
+  // pos[j]: the attribute position whose kind and generators constraint #3 uses for the j-th kept commitment: j itself
+  // in the reference (presentation.rs:427-433, the compact index used as an original position), keep[j] in strict mode
   for (uint32_t j = 0; j < k; j++) {
+    const uint32_t p = c->strict ? keep[j] : j;
+    pos[j] = p;
     hidden_slot[j] = -1;
-    if (sh.kinds[j] == AFX_ENC_SECRET_POINT) continue;
-    if (j >= c->g) return true;
-    if (sh.kinds[j] == AFX_ENC_SECRET_SCALAR) {
+    if (sh.kinds[p] == AFX_ENC_SECRET_POINT) continue;
+    if (p >= c->g) return true;
+    if (sh.kinds[p] == AFX_ENC_SECRET_SCALAR) {
       for (uint32_t h = 0; h < hs; h++)
-        if (sh.hidden_scalar_indices[h] == j) { hidden_slot[j] = (int)h; break; }
+        if (sh.hidden_scalar_indices[h] == p) { hidden_slot[j] = (int)h; break; }
       if (hidden_slot[j] < 0) return true;   // H_s[i] / G_m[i] lookup panics (:81, :100)
     }
   }
@@ -344,9 +364,9 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
   JobSets js;
   auto row = [&](const uint8_t* base, size_t k) { return base + (k * total + off) * 32; };
   const uint32_t n = sh.n_attributes, hs = sh.n_hidden_scalars;
-  uint32_t keep[AFX_MAX_ATTRIBUTES], k = 0;
+  uint32_t keep[AFX_MAX_ATTRIBUTES], pos[AFX_MAX_ATTRIBUTES], k = 0;
   int hidden_slot[AFX_MAX_ATTRIBUTES];
-  if (presentation_shape_rejects(c, sh, keep, &k, hidden_slot)) as.fail_all = true;
+  if (presentation_shape_rejects(c, sh, keep, &k, hidden_slot, pos)) as.fail_all = true;
   if (as.fail_all) { emit(as, js, status_dev, AFX_ST_VERIFICATION_FAILURE); return; }
 
   js.sccheck.push_back({ row(b.challenge, 0) });
@@ -415,9 +435,10 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
   v.constrain(Z, { { z, I } });
   v.constrain(C_x_1, { { t, C_x_0 }, { z_0, G_x_0 }, { z, G_x_1 } });
   for (uint32_t j = 0; j < k; j++) {
-    if (sh.kinds[j] == AFX_ENC_SECRET_POINT) continue;
-    if (sh.kinds[j] == AFX_ENC_SECRET_SCALAR) v.constrain(C_y[j], { { z, G_y[j] }, { H_s[hidden_slot[j]], G_m[hidden_slot[j]] } });
-    else v.constrain(C_y[j], { { z, G_y[j] } });
+    const uint32_t p = pos[j];
+    if (sh.kinds[p] == AFX_ENC_SECRET_POINT) continue;
+    if (sh.kinds[p] == AFX_ENC_SECRET_SCALAR) v.constrain(C_y[j], { { z, G_y[p] }, { H_s[hidden_slot[j]], G_m[hidden_slot[j]] } });
+    else v.constrain(C_y[j], { { z, G_y[p] } });
   }
   // one launch for everything: the lane that finishes Z goes straight on to constraint #1 (Z = z*I), the only job that needs it
   const size_t first_constraint = js.msm1.size();
@@ -482,9 +503,9 @@ extern "C" int afx_verify_presentations(afx_ctx* ctx, const afx_shape* shape, co
   AFX_HIP(hipSetDevice(ctx->device));
   {
     // a shape every item fails on says nothing reliable about the arrays' extents: answer without reading them
-    uint32_t keep[AFX_MAX_ATTRIBUTES], k = 0;
+    uint32_t keep[AFX_MAX_ATTRIBUTES], pos[AFX_MAX_ATTRIBUTES], k = 0;
     int slot[AFX_MAX_ATTRIBUTES];
-    if (presentation_shape_rejects(ctx, *shape, keep, &k, slot)) { memset(status, AFX_ST_VERIFICATION_FAILURE, count); return AFX_OK; }
+    if (presentation_shape_rejects(ctx, *shape, keep, &k, slot, pos)) { memset(status, AFX_ST_VERIFICATION_FAILURE, count); return AFX_OK; }
   }
   const uint32_t n = shape->n_attributes, nr = shape->n_responses, ne = shape->n_enc_proofs;
   if (!b->challenge || !b->C_x_0 || !b->C_x_1 || !b->C_V || (n && !b->C_y) || (nr && !b->responses) || (ne && !b->enc)) { set_error("null batch array"); return AFX_E_BAD_ARGS; }

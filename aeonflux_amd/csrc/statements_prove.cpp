@@ -310,22 +310,25 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
     const int G_x_0 = p.allocate_point("G_x_0", PointVar::Const(c->id_Gx0()));
     const int G_x_1 = p.allocate_point("G_x_1", PointVar::Const(c->id_Gx1()));
     int C_y[AFX_MAX_ATTRIBUTES], G_y[AFX_MAX_ATTRIBUTES], G_m[AFX_MAX_ATTRIBUTES];
-    uint32_t k = 0;
+    uint32_t k = 0, keep[AFX_MAX_ATTRIBUTES];
     for (uint32_t i = 0; i < na; i++)
-      if (cr.kinds[i] != AFX_ATTR_SECRET_POINT) C_y[k++] = p.allocate_point("C_y", PointVar::Var(v_Cy[i], orow(o.C_y, i)));
+      if (cr.kinds[i] != AFX_ATTR_SECRET_POINT) { keep[k] = i; C_y[k++] = p.allocate_point("C_y", PointVar::Var(v_Cy[i], orow(o.C_y, i))); }
     for (uint32_t i = 0; i < c->g; i++) G_y[i] = p.allocate_point("G_y", PointVar::Const(c->id_Gy(i)));
     for (uint32_t j = 0; j < hs; j++) G_m[j] = p.allocate_point("G_m", PointVar::Const(c->id_Gm(sh.hidden_scalar_indices[j])));
     const int Z = p.allocate_point("Z", PointVar::Var(v_Z, e_Z));
     p.constrain(Z, { { zv, I } });
     p.constrain(C_x_1, { { tv, C_x_0 }, { z_0v, G_x_0 }, { zv, G_x_1 } });
-    for (uint32_t j = 0; j < k; j++) {   // compact index used as an original position, literally (:267-273)
-      if (cr.kinds[j] == AFX_ATTR_SECRET_POINT) continue;
-      if (cr.kinds[j] == AFX_ATTR_SECRET_SCALAR) {
+    for (uint32_t j = 0; j < k; j++) {
+      // the reference uses the compact index j as an original position, literally (:267-273); strict mode uses the
+      // commitment's own position (afx_ctx_set_strict)
+      const uint32_t q = c->strict ? keep[j] : j;
+      if (cr.kinds[q] == AFX_ATTR_SECRET_POINT) continue;
+      if (cr.kinds[q] == AFX_ATTR_SECRET_SCALAR) {
         int slot = -1;
-        for (uint32_t h = 0; h < hs; h++) if (sh.hidden_scalar_indices[h] == j) slot = (int)h;
-        p.constrain(C_y[j], { { zv, G_y[j] }, { H_s[slot], G_m[slot] } });
+        for (uint32_t h = 0; h < hs; h++) if (sh.hidden_scalar_indices[h] == q) slot = (int)h;
+        p.constrain(C_y[j], { { zv, G_y[q] }, { H_s[slot], G_m[slot] } });
       } else {
-        p.constrain(C_y[j], { { zv, G_y[j] } });
+        p.constrain(C_y[j], { { zv, G_y[q] } });
       }
     }
     std::vector<afx_hash_program> rng_hash, chal_hash;

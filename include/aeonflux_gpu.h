@@ -131,6 +131,18 @@ void* afx_ctx_stream(const afx_ctx* ctx);
 int afx_ctx_set_pipelining(afx_ctx* ctx, int enable);
 int afx_ctx_synchronize(afx_ctx* ctx);
 
+/* Strict mode (opt-in, off by default, NOT bit-compatible with the reference):
+ *  - constraint #3 of the presentation proof (presentation.rs:267-273 prover, :427-433 verifier) pairs the j-th kept
+ *    commitment with the generators and kind of its OWN attribute position instead of position j, in afx_show and in
+ *    afx_verify_presentations; with hidden group elements only in trailing positions both modes give the same bytes,
+ *    otherwise only strict-mode presentations verify, and only under a strict-mode verifier;
+ *  - afx_verify_presentations requires exactly one proof of encryption per SECRET_POINT attribute, with
+ *    enc_indices equal to those positions in increasing order (the reference verifies whatever is attached,
+ *    presentation.rs:438-440).
+ * The DLEQ between C_y[i] and its proof of encryption that the reference's README.md:121-122 lists as TODO is not
+ * part of this mode: no such statement exists in the reference to restate. */
+int afx_ctx_set_strict(afx_ctx* ctx, int enable);
+
 /* Challenge trace (parity aid; off by default).  set(rows, count) allocates a device array [rows][count][32]; while it
  * exists, every verification call (presentations, proofs of encryption, issuances) of at most `count` items also
  * stores the challenge it RECOMPUTES for item i of proof r in cell (r, i): r = 0 for the main proof (or the only

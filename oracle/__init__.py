@@ -62,6 +62,7 @@ def load(native=False):
     lib.afxo_ctx_new.restype = C.c_void_p
     lib.afxo_ctx_new.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p]
     lib.afxo_ctx_free.argtypes = [C.c_void_p]
+    lib.afxo_ctx_set_strict.argtypes = [C.c_void_p, C.c_int]
     lib.afxo_ctx_n.argtypes = [C.c_void_p]
     lib.afxo_ctx_n.restype = C.c_uint32
     lib.afxo_sizeof_system_parameters.restype = C.c_size_t
@@ -207,6 +208,9 @@ class Ctx:
         if getattr(self, "h", None):
             lib().afxo_ctx_free(self.h)
             self.h = None
+
+    def set_strict(self, strict):
+        lib().afxo_ctx_set_strict(self.h, 1 if strict else 0)
 
     def keypair_derive(self, master_secret):
         o = _buf(128)

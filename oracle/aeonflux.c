@@ -22,6 +22,7 @@ struct afxo_ctx {
   ge W;
   int has_issuer_params;
   ge C_W, I;
+  int strict; /* SURVEY.md section 8f rank 4 (NOT the reference's behaviour): see afxo_ctx_set_strict */
 };
 
 static uint32_t rd32(const uint8_t* b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); }
@@ -577,6 +578,27 @@ static int presentation_statement(zkp_cs* z, const afxo_ctx* c, int prover, uint
   zkp_constrain(z, Zv, 1, s, q);
   s[0] = t; q[0] = Cx0; s[1] = z0; q[1] = Gx0; s[2] = zz; q[2] = Gx1;
   zkp_constrain(z, Cx1, 3, s, q);
+  if (c->strict) {
+    /* strict mode: the statement the scheme intends - the j-th kept commitment is checked against the generators and
+     * the kind of ITS OWN position */
+    uint32_t j = 0;
+    for (uint32_t i = 0; i < n_attrs; i++) {
+      if (kinds[i] == AFX_ENC_SECRET_POINT) continue;
+      if (kinds[i] == AFX_ENC_SECRET_SCALAR) {
+        int found = -1;
+        for (uint32_t h = 0; h < hs; h++)
+          if (hidx[h] == i) { found = (int)h; break; }
+        if (found < 0) return 0;
+        s[0] = zz; q[0] = Gy[i]; s[1] = Hs[found]; q[1] = Gm[found];
+        zkp_constrain(z, Cy[j], 2, s, q);
+      } else {
+        s[0] = zz; q[0] = Gy[i];
+        zkp_constrain(z, Cy[j], 1, s, q);
+      }
+      j++;
+    }
+    return 1;
+  }
   /* constraint #3, restated literally (compact index used as original position) */
   for (uint32_t j = 0; j < k; j++) {
     if (j >= n_attrs) return 0;       /* encrypted_attributes[i] out of range */
@@ -677,9 +699,26 @@ int afxo_show(const afxo_ctx* c, uint32_t n_attrs, const uint8_t* kinds, const u
 }
 
 /* Issuer::verify, src/issuer.rs:141-147 -> ProofOfValidCredential::verify, presentation.rs:324-443 */
+/* Strict mode (opt-in, off by default, NOT bit-compatible with the reference):
+ *  - constraint #3 of the presentation proof uses each kept commitment's own position (prover and verifier), so
+ *    presentations with hidden group elements anywhere verify (the reference only handles trailing ones, App. B);
+ *  - the verifier requires exactly one proof of encryption per hidden group element, in position order
+ *    (the reference verifies whatever is attached, presentation.rs:438-440).
+ * The DLEQ between C_y[i] and the proof of encryption that README.md:121-122 lists as TODO is NOT part of it. */
+void afxo_ctx_set_strict(afxo_ctx* c, int strict) { c->strict = strict != 0; }
+
 int afxo_verify_presentation(const afxo_ctx* c, const afxo_presentation* p) {
   if (!c->has_key || !c->has_issuer_params) return -1;
   uint32_t n_attrs = p->n_attributes;
+  if (c->strict && n_attrs <= AFX_MAX_ATTRIBUTES && p->n_enc_proofs <= AFX_MAX_ATTRIBUTES) {
+    uint32_t e = 0;
+    for (uint32_t i = 0; i < n_attrs; i++)
+      if (p->kinds[i] == AFX_ENC_SECRET_POINT) {
+        if (e >= p->n_enc_proofs || p->enc[e].index != i) return AFX_ST_VERIFICATION_FAILURE;
+        e++;
+      }
+    if (e != p->n_enc_proofs) return AFX_ST_VERIFICATION_FAILURE;
+  }
   if (n_attrs > AFX_MAX_ATTRIBUTES || n_attrs > c->n) return AFX_ST_VERIFICATION_FAILURE; /* y[i]/G_m[i] index panic */
   if (p->n_responses > 3 + AFX_MAX_ATTRIBUTES || p->n_hidden_scalars > AFX_MAX_ATTRIBUTES || p->n_enc_proofs > AFX_MAX_ATTRIBUTES)
     return AFX_ST_VERIFICATION_FAILURE;
