@@ -57,12 +57,11 @@ size_t Assembler::blob_alloc(size_t bytes, size_t align) {
   return off;
 }
 template <class T>
-void Assembler::add_jobs(LaunchKind k, const std::vector<T>& jobs, uint32_t max_fixed) {
+void Assembler::add_jobs(LaunchKind k, const std::vector<T>& jobs) {
   if (jobs.empty()) return;
   Launch l;
   l.kind = k;
   l.njobs = (uint32_t)jobs.size();
-  l.max_fixed = max_fixed;
   l.jobs_off = blob_alloc(sizeof(T) * jobs.size(), 16);
   memcpy(blob_.data() + l.jobs_off, jobs.data(), sizeof(T) * jobs.size());
   launches.push_back(l);
@@ -71,9 +70,9 @@ void Assembler::decode(const std::vector<afx_decode_job>& jobs) {
   stats.decodings += jobs.size();
   stats.field_mul += AFX_DECODE_MUL * jobs.size();
   stats.field_sq += AFX_DECODE_SQ * jobs.size();
-  add_jobs(L_DECODE, jobs, 0);
+  add_jobs(L_DECODE, jobs);
 }
-void Assembler::sccheck(const std::vector<afx_sccheck_job>& jobs) { add_jobs(L_SCCHECK, jobs, 0); }
+void Assembler::sccheck(const std::vector<afx_sccheck_job>& jobs) { add_jobs(L_SCCHECK, jobs); }
 void Assembler::pointop(const std::vector<afx_pointop_job>& jobs) {
   for (const afx_pointop_job& j : jobs) {
     stats.var_additions += j.sb != 0;
@@ -81,12 +80,12 @@ void Assembler::pointop(const std::vector<afx_pointop_job>& jobs) {
     stats.field_mul += (j.sb != 0 ? 9 : 0) + (j.out_enc ? AFX_ENCODE_MUL : 0);
     stats.field_sq += j.out_enc ? AFX_ENCODE_SQ : 0;
   }
-  add_jobs(L_POINTOP, jobs, 0);
+  add_jobs(L_POINTOP, jobs);
 }
-void Assembler::scalarop(const std::vector<afx_scalarop_job>& jobs) { add_jobs(L_SCALAROP, jobs, 0); }
+void Assembler::scalarop(const std::vector<afx_scalarop_job>& jobs) { add_jobs(L_SCALAROP, jobs); }
 void Assembler::hash(const std::vector<afx_hash_program>& progs) {
   for (const afx_hash_program& p : progs) stats.keccak_permutations += p.n_records;
-  add_jobs(L_HASH, progs, 0);
+  add_jobs(L_HASH, progs);
 }
 // Width-5 NAF of a canonical scalar (little-endian 32 bytes): digits in {0, +-1, +-3, ..., +-15}, at most one
 // nonzero digit in any 5 consecutive positions; returns the position of the highest nonzero digit (-1 for zero).
@@ -188,9 +187,9 @@ static std::vector<size_t> balanced_row_order(const std::vector<size_t>& heads, 
 void Assembler::msm(std::vector<afx_msm_job> jobs) {
   if (jobs.empty()) return;
   // kilo-cycles of VALU issue per wave (profiles/r01_fe_rates_ubench.txt): 63 windows of 4 doublings + the final
-  // encoding; 64 additions + the 9-entry table per variable base; 32 additions per fixed base
+  // encoding; 64 additions + the 9-entry table per variable base; AFX_POS_WINDOWS additions per fixed base
   auto cost = [](const afx_msm_job& j) {
-    return (j.n_var ? 1320u : 160u) + j.n_uni * (330u + 45u /* more conversions to p3 */) + (j.n_var - j.n_uni) * 470u + (j.n_terms - j.n_var) * 175u;
+    return (j.n_var ? 1320u : 160u) + j.n_uni * (330u + 45u /* more conversions to p3 */) + (j.n_var - j.n_uni) * 470u + (j.n_terms - j.n_var) * ((AFX_POS_WINDOWS * 175u) / 32u);
   };
   const size_t n = jobs.size();
   // a job named as another's successor (chain_to) is run by that job's lanes, not by grid rows of its own
@@ -242,13 +241,14 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
       stats.table_additions += 7 * j.n_uni + (AFX_TABLE_ENTRIES - 2) * nl;
       for (int b = j.top_bit; b >= 0; b--) {
         const uint64_t nuni = nafc_of[ji][b];
-        const uint64_t nadd = nuni + ((b & 3) == 0 ? nl : 0) + ((b & 7) == 0 ? nf : 0);
+        const uint64_t nadd = nuni + ((b & 3) == 0 ? nl : 0);
         if (b != j.top_bit) { stats.doublings++; S += 4; M += (nadd != 0 || b == 0) ? 4 : 3; }
-        stats.var_additions += nuni + ((b & 3) == 0 ? nl : 0);
-        stats.fixed_additions += (b & 7) == 0 ? nf : 0;
-        M += (nuni + ((b & 3) == 0 ? nl : 0)) * 4 + ((b & 7) == 0 ? nf : 0) * 3;
+        stats.var_additions += nadd;
+        M += nadd * 4;
         M += nadd * 4 - ((nadd != 0 && b != 0) ? 1 : 0);
       }
+      stats.fixed_additions += nf * AFX_POS_WINDOWS;
+      M += nf * AFX_POS_WINDOWS * 7;
       stats.encodings += j.out_enc ? 1 : 0;
       stats.var_additions += j.addend ? 1 : 0;
       if (j.addend) M += 9;
@@ -259,7 +259,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     }
     stats.doublings += nv ? 252 : 0;
     stats.var_additions += 64 * nv;
-    stats.fixed_additions += 32 * nf;
+    stats.fixed_additions += AFX_POS_WINDOWS * nf;
     stats.table_additions += (AFX_TABLE_ENTRIES - 2) * nv;
     stats.encodings += j.out_enc ? 1 : 0;
     stats.var_additions += j.addend ? 1 : 0;
@@ -268,14 +268,12 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     if (nv) {
       M += nv * (1 + (AFX_TABLE_ENTRIES - 2) * 9);            // tables: 2dT of P, then (add 4M + to p3 4M + 2dT 1M) per entry
       for (int w = 63; w >= 0; w--) {
-        const uint64_t nadd = nv + ((w & 1) == 0 ? nf : 0);
         if (w != 63) { S += 16; M += 3 * 3 + 4; }             // three doublings to p2, the fourth to p3
-        M += nv * 4 + (nadd - nv) * 3;                        // cached / niels additions
-        M += nadd * 4 - (w != 0 ? 1 : 0);                     // back to p3; the window's last one skips T
+        M += nv * 4;                                          // additions of window-table entries
+        M += nv * 4 - (w != 0 ? 1 : 0);                       // back to p3; the window's last one skips T
       }
-    } else {
-      M += 32 * nf * 7;                                       // positional tables: niels addition + to p3
     }
+    M += AFX_POS_WINDOWS * nf * 7;                            // fixed bases: positional tables, niels addition + to p3
     if (j.addend) M += 9;
     if (j.out_enc) { M += AFX_ENCODE_MUL; S += AFX_ENCODE_SQ; }
     stats.field_mul += M;
@@ -298,7 +296,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   std::vector<uint32_t> new_index(n);
   for (size_t k = 0; k < n; k++) new_index[order[k]] = (uint32_t)k;
   std::vector<afx_msm_job> out(n);
-  uint32_t dslot = 0, tslot = 0, max_fixed = 0;
+  uint32_t dslot = 0, tslot = 0;
   for (size_t k = 0; k < n; k++) {
     afx_msm_job j = jobs[order[k]];
     j.next_job = j.chain_to >= 0 ? new_index[j.chain_to] + 1 : 0;
@@ -308,7 +306,6 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
       j.naf = put(naf_of[order[k]].data(), naf_of[order[k]].size());
       j.naf_count = put(nafc_of[order[k]].data(), nafc_of[order[k]].size());
     }
-    if (j.n_var != 0 && j.n_terms - j.n_var <= AFX_FIXED_LDS_MAX) max_fixed = std::max(max_fixed, j.n_terms - j.n_var);
     out[k] = j;
   }
   max_digit_slots = std::max<size_t>(max_digit_slots, dslot);
@@ -317,7 +314,6 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   Launch l;
   l.kind = L_MSM;
   l.njobs = (uint32_t)heads.size();
-  l.max_fixed = max_fixed;
   l.jobs_off = blob_alloc(sizeof(afx_msm_job) * n, 16);
   memcpy(blob_.data() + l.jobs_off, out.data(), sizeof(afx_msm_job) * n);
   launches.push_back(l);
@@ -342,7 +338,7 @@ size_t Assembler::total_ws_bytes() const {
   size_t off = (ws_off_ + 255) & ~size_t(255);
   off += max_table_slots * (size_t)count * AFX_VAR_TABLE_DWORDS * sizeof(int32_t);
   off = (off + 255) & ~size_t(255);
-  off += max_digit_slots * 8 * (size_t)count * sizeof(uint32_t);
+  off += max_digit_slots * AFX_DIGIT_WORDS * (size_t)count * sizeof(uint32_t);
   return off + 256;
 }
 
@@ -352,7 +348,7 @@ int Assembler::run() {
   ctx->last_stats = stats;
   if (total_ws_bytes() > L.ws.cap) { set_error("workspace smaller than the sized plan"); return AFX_E_BAD_ARGS; }
   int32_t* table_ws = (int32_t*)ws_alloc(max_table_slots * (size_t)count * AFX_VAR_TABLE_DWORDS * sizeof(int32_t));
-  uint32_t* digit_ws = (uint32_t*)ws_alloc(max_digit_slots * 8 * (size_t)count * sizeof(uint32_t));
+  uint32_t* digit_ws = (uint32_t*)ws_alloc(max_digit_slots * AFX_DIGIT_WORDS * (size_t)count * sizeof(uint32_t));
   hipStream_t s = L.stream;
   const int slot = L.blob_next;
   if (blob_.size() > L.blob_dev[slot].cap || blob_.size() > L.blob_host_cap[slot]) { set_error("plan blob too large"); return AFX_E_BAD_ARGS; }
@@ -362,7 +358,6 @@ int Assembler::run() {
   if (!blob_.empty()) AFX_HIP(hipMemcpyAsync(L.blob_dev[slot].p, L.blob_host[slot], blob_.size(), hipMemcpyHostToDevice, s));
   AFX_HIP(hipEventRecord(L.blob_event[slot], s));
   L.blob_next ^= 1;
-  const int32_t* ft = (const int32_t*)ctx->d_fixed_tables.p;
   for (const Launch& l : launches) {
     const uint8_t* jobs = blob_base_ + l.jobs_off;
     afx_ctx::TimedLaunch tl = { (int)l.kind, nullptr, nullptr };
@@ -384,7 +379,7 @@ int Assembler::run() {
         // overlap it), which keeps per-launch timings meaningful and the VALU free of two competing table working sets
         afx_ctx::Lane& other = ctx->lane[lane ^ 1];
         if (ctx->pipelining && other.msm_recorded) AFX_HIP(hipStreamWaitEvent(s, other.msm_done, 0));
-        AFX_HIP(afxk_msm(s, (const afx_msm_job*)jobs, l.njobs, l.max_fixed, ft, (const int32_t*)ctx->d_pos_tables.p, table_ws, digit_ws, bad_, count));
+        AFX_HIP(afxk_msm(s, (const afx_msm_job*)jobs, l.njobs, (const int32_t*)ctx->d_pos_tables.p, table_ws, digit_ws, bad_, count));
         if (ctx->pipelining) { AFX_HIP(hipEventRecord(L.msm_done, s)); L.msm_recorded = true; }
         break;
       }

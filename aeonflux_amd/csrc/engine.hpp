@@ -62,7 +62,7 @@ struct afx_ctx {
   uint32_t id_W() const { return 11 + g + n; }
   std::vector<afx::Enc> gen_enc, gen_neg_enc;   // host copies of compress(G), compress(-G)
   // device residents
-  afx::DevBuf d_gen_enc, d_fixed_tables, d_pos_tables, d_gen_ext, d_key, d_consts;
+  afx::DevBuf d_gen_enc, d_pos_tables, d_gen_ext, d_key, d_consts;
   // key scalar slots in d_key ([k][32]): w, w', x0, x1, y[0..n), then constants one, zero
   const uint8_t* key_w() const { return (const uint8_t*)d_key.p; }
   const uint8_t* key_wp() const { return (const uint8_t*)d_key.p + 32; }
@@ -117,7 +117,6 @@ struct Launch {
   LaunchKind kind;
   size_t jobs_off = 0;      // offset of the job array in the blob
   uint32_t njobs = 0;
-  uint32_t max_fixed = 0;   // L_MSM: LDS sizing
   // L_FROM_UNIFORM / L_REDUCE_WIDE / L_FINISH direct arguments
   const uint8_t* in = nullptr;
   uint8_t* out = nullptr;
@@ -175,7 +174,7 @@ class Assembler {
  private:
   uint8_t* ws_alloc(size_t bytes);
   template <class T>
-  void add_jobs(LaunchKind k, const std::vector<T>& jobs, uint32_t max_fixed);
+  void add_jobs(LaunchKind k, const std::vector<T>& jobs);
   bool sizing_ = false;
   std::vector<uint8_t> blob_;
   uint8_t* blob_base_ = nullptr;   // device address the blob will live at

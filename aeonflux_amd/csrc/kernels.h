@@ -3,14 +3,14 @@
 #include <hip/hip_runtime_api.h>
 #include "plan.h"
 
-hipError_t afxk_setup_generators(hipStream_t s, const uint8_t* enc, uint32_t ngen, int32_t* fixed_tables, int32_t* ext, uint8_t* neg_enc, uint32_t* ok);
+hipError_t afxk_setup_generators(hipStream_t s, const uint8_t* enc, uint32_t ngen, int32_t* ext, uint8_t* neg_enc, uint32_t* ok);
 hipError_t afxk_decode(hipStream_t s, const afx_decode_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count);
 hipError_t afxk_sccheck(hipStream_t s, const afx_sccheck_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count);
 hipError_t afxk_pointop(hipStream_t s, const afx_pointop_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count);
 hipError_t afxk_scalarop(hipStream_t s, const afx_scalarop_job* jobs, uint32_t njobs, uint32_t count);
-hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen, int32_t* postab);
-hipError_t afxk_msm(hipStream_t s, const afx_msm_job* jobs, uint32_t njobs, uint32_t max_fixed, const int32_t* fixed_tables, const int32_t* pos_tables,
-                    int32_t* table_ws, uint32_t* digit_ws, uint32_t* bad, uint32_t count);
+hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen, int32_t* base_scratch, int32_t* postab);
+hipError_t afxk_msm(hipStream_t s, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, int32_t* table_ws, uint32_t* digit_ws,
+                    uint32_t* bad, uint32_t count);
 hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count);
 hipError_t afxk_finish(hipStream_t s, const uint32_t* bad, uint8_t* status, uint32_t count, uint32_t fail_all, uint8_t fail_code);
 hipError_t afxk_fill_u32(hipStream_t s, uint32_t* p, uint32_t v, uint32_t n);

@@ -2,13 +2,13 @@
 // proof) per lane; all control flow is uniform across a wave because the statement shape is batch-uniform.
 //
 // Kernel inventory (SURVEY.md §8a row K* -> kernel):
-//   k_setup_generators  decompress SystemParameters generators once, build affine window tables
+//   k_setup_generators, k_setup_posbase, k_setup_postables   decompress the generators once, build their positional tables
 //   k_decode            CompressedRistretto::decompress, coalesced 32-byte loads          (P4 ii, E1)
 //   k_sccheck           Scalar canonicity
 //   k_pointop           +-P +-Q (+ compress): C_V - W, C_y+M, C_y_1-E2, -E1               (P1, E1)
 //   k_scalarop          a*b+c mod l: y_i*m_i, -t*z, responses s*c+b                       (P1, S1, I2)
-//   k_msm               R = sum s_k P_k (+-addend) -> compress.  Fixed bases from LDS window tables,
-//                       variable bases from per-lane window tables in HBM, shared doublings  (P1, P4 iii, I1)
+//   k_msm               R = sum s_k P_k (+-addend) -> compress.  Fixed bases from positional tables (L2 / Infinity
+//                       Cache), variable bases from per-lane window tables in HBM, shared doublings (P1, P4 iii, I1)
 //   k_hash              STROBE-128/merlin transcript over Keccak-f[1600] driven by a precompiled byte
 //                       schedule; squeezes challenges / blinding factors                   (P2, P4 iv-v)
 //   k_finish            per-item status byte
@@ -99,10 +99,10 @@ AFX_DEV ge_cached cached_load(const int32_t* p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// setup: generators -> extended coords, 0..8 multiples as affine niels, encoding of the negation
+// setup (context creation): generators -> extended coords + encoding of the negation; positional tables
 // ---------------------------------------------------------------------------------------------
-__global__ void k_setup_generators(const uint8_t* __restrict__ enc, uint32_t ngen, int32_t* __restrict__ fixed_tables,
-                                   int32_t* __restrict__ ext, uint8_t* __restrict__ neg_enc, uint32_t* __restrict__ ok) {
+__global__ void k_setup_generators(const uint8_t* __restrict__ enc, uint32_t ngen, int32_t* __restrict__ ext, uint8_t* __restrict__ neg_enc,
+                                   uint32_t* __restrict__ ok) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ngen) return;
   uint32_t w[8];
@@ -117,42 +117,64 @@ __global__ void k_setup_generators(const uint8_t* __restrict__ enc, uint32_t nge
   uint32_t nw[8];
   ristretto_encode(nw, ge_neg(P));
   enc_store(neg_enc, g, nw);
-  int32_t* tab = fixed_tables + (size_t)g * AFX_FIXED_TABLE_DWORDS;
-  const fe d2 = fe_const(FEC_D2);
-  ge_p3 Q = ge_identity();
-  const ge_cached cP = ge_p3_to_cached(P);
-#pragma unroll 1
-  for (int k = 0; k < AFX_FIXED_ENTRIES; k++) {
-    const fe zinv = fe_invert(Q.Z);
-    const fe x = fe_mul(Q.X, zinv), y = fe_mul(Q.Y, zinv);
-    const fe ypx = fe_carry(fe_add(y, x)), ymx = fe_carry(fe_sub(y, x)), xy2d = fe_mul(fe_mul(x, y), d2);
-#pragma unroll
-    for (int l = 0; l < 10; l++) { tab[k * 30 + l] = ypx.v[l]; tab[k * 30 + 10 + l] = ymx.v[l]; tab[k * 30 + 20 + l] = xy2d.v[l]; }
-    Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
-  }
 }
 
-// positional tables for jobs made of fixed bases only (no doubling chain at all): thread (g, j) writes
-// d * 256^j * G_g for d = 0..128 as affine niels.  One-time work at context creation.
-__global__ void k_setup_postables(const int32_t* __restrict__ ext, uint32_t ngen, int32_t* __restrict__ postab) {
+// Positional tables: for generator g and window position j, the entries d * 2^(AFX_POS_BITS*j) * G_g for
+// d = 0 .. 2^(AFX_POS_BITS-1) as affine niels (y+x, y-x, 2dxy).  Two kernels: the window bases B_{g,j} = 2^(BITS*j) G_g
+// (thread per (g, j)), then thread (g, j, c) writes the 16 entries 16c .. 16c+15 with ONE field inversion
+// (Montgomery's trick over the 16 Z coordinates).
+__global__ void k_setup_posbase(const int32_t* __restrict__ ext, uint32_t ngen, int32_t* __restrict__ base) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ngen * 32) return;
-  const uint32_t g = t / 32, j = t % 32;
+  if (t >= ngen * AFX_POS_WINDOWS) return;
+  const uint32_t g = t / AFX_POS_WINDOWS, j = t % AFX_POS_WINDOWS;
   ge_p3 P = p3_load_uniform(ext + (size_t)g * AFX_VAR_DWORDS);
 #pragma unroll 1
-  for (uint32_t k = 0; k < 8 * j; k++) P = ge_double(P);
-  int32_t* tab = postab + (size_t)g * AFX_POS_TABLE_DWORDS + (size_t)j * AFX_FIXED_TABLE_DWORDS;
-  const fe d2 = fe_const(FEC_D2);
-  const ge_cached cP = ge_p3_to_cached(P);
+  for (uint32_t k = 0; k < AFX_POS_BITS * j; k++) P = ge_double(P);
+  int32_t* e = base + (size_t)t * AFX_VAR_DWORDS;
+#pragma unroll
+  for (int l = 0; l < 10; l++) { e[l] = P.X.v[l]; e[10 + l] = P.Y.v[l]; e[20 + l] = P.Z.v[l]; e[30 + l] = P.T.v[l]; }
+}
+#define AFX_POS_CHUNK 16
+#define AFX_POS_CHUNKS ((AFX_POS_ENTRIES + AFX_POS_CHUNK - 1) / AFX_POS_CHUNK)
+__global__ void k_setup_postables(const int32_t* __restrict__ base, uint32_t ngen, int32_t* __restrict__ postab) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ngen * AFX_POS_WINDOWS * AFX_POS_CHUNKS) return;
+  const uint32_t gj = t / AFX_POS_CHUNKS, c = t % AFX_POS_CHUNKS;
+  const ge_p3 B = p3_load_uniform(base + (size_t)gj * AFX_VAR_DWORDS);
+  const ge_cached cB = ge_p3_to_cached(B);
+  // Q = (16 c) * B by double-and-add over the bits of c (c < 64), then four doublings
   ge_p3 Q = ge_identity();
 #pragma unroll 1
-  for (int k = 0; k < AFX_FIXED_ENTRIES; k++) {
-    const fe zinv = fe_invert(Q.Z);
-    const fe x = fe_mul(Q.X, zinv), y = fe_mul(Q.Y, zinv);
+  for (int bit = 5; bit >= 0; bit--) {
+    Q = ge_double(Q);
+    if ((c >> bit) & 1u) Q = ge_p1p1_to_p3(ge_add_cached(Q, cB, false));
+  }
+#pragma unroll 1
+  for (int k = 0; k < 4; k++) Q = ge_double(Q);
+  int32_t* tab = postab + (size_t)(gj / AFX_POS_WINDOWS) * AFX_POS_TABLE_DWORDS + (size_t)(gj % AFX_POS_WINDOWS) * AFX_POS_WINDOW_DWORDS;
+  const uint32_t first = c * AFX_POS_CHUNK, n = min((uint32_t)AFX_POS_CHUNK, (uint32_t)AFX_POS_ENTRIES - first);
+  // pass 1: the chunk's points (kept in per-thread scratch: this kernel runs once per context) and the running
+  // products of their Z coordinates
+  fe X[AFX_POS_CHUNK], Y[AFX_POS_CHUNK], Z[AFX_POS_CHUNK], pre[AFX_POS_CHUNK];
+  fe prod = fe_one();
+#pragma unroll 1
+  for (uint32_t k = 0; k < n; k++) {
+    X[k] = Q.X; Y[k] = Q.Y; Z[k] = Q.Z; pre[k] = prod;
+    prod = fe_mul(prod, Q.Z);
+    if (k + 1 < n) Q = ge_p1p1_to_p3(ge_add_cached(Q, cB, false));
+  }
+  // pass 2, backwards: inv = 1 / (Z_0 ... Z_k), so 1/Z_k = inv * (Z_0 ... Z_{k-1}); then inv *= Z_k
+  fe inv = fe_invert(prod);
+  const fe d2 = fe_const(FEC_D2);
+#pragma unroll 1
+  for (int k = (int)n - 1; k >= 0; k--) {
+    const fe zinv = fe_mul(inv, pre[k]);
+    inv = fe_mul(inv, Z[k]);
+    const fe x = fe_mul(X[k], zinv), y = fe_mul(Y[k], zinv);
     const fe ypx = fe_carry(fe_add(y, x)), ymx = fe_carry(fe_sub(y, x)), xy2d = fe_mul(fe_mul(x, y), d2);
+    int32_t* e = tab + (size_t)(first + k) * AFX_NIELS_DWORDS;
 #pragma unroll
-    for (int l = 0; l < 10; l++) { tab[k * 30 + l] = ypx.v[l]; tab[k * 30 + 10 + l] = ymx.v[l]; tab[k * 30 + 20 + l] = xy2d.v[l]; }
-    Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
+    for (int l = 0; l < 10; l++) { e[l] = ypx.v[l]; e[10 + l] = ymx.v[l]; e[20 + l] = xy2d.v[l]; }
   }
 }
 
@@ -222,15 +244,21 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_scalarop(const afx_scalarop_job* 
 // ---------------------------------------------------------------------------------------------
 // k_msm: one small multiscalar multiplication per lane
 // ---------------------------------------------------------------------------------------------
-// Straus with a shared doubling chain.  Scalars are recoded without carries (s + 0x88..88 for 4-bit signed
-// digits in [-8,7], s + 0x80..80 for 8-bit signed digits in [-128,127]), so every lane adds at every window:
+// Straus with a shared doubling chain.  Per-item scalars are recoded without carries (s + 0x88..88 for 4-bit
+// signed digits in [-8,7], s + 0x80..80 for 8-bit signed digits in [-128,127]), so every lane adds at every window:
 // no divergence; a zero digit adds table entry 0 = the identity.
-//   variable bases: 4-bit windows, 9-entry cached tables built per lane into HBM workspace (1440 B per base per
-//                   item), gathered back as 10 x 16-byte loads per addition
-//   fixed bases   : 8-bit windows (an addition every second 4-bit window), 129-entry affine-niels tables built at
-//                   context creation; staged in LDS when the job has <= 4 of them (15.1 KB each), else read from L2
-// Field work per 4-bit window: 4 doublings (4 x 4S + 3 x 3M + 4M), 8M per variable term, 7M per fixed term (every
-// other window); the last addition of a window skips the T coordinate (-1M).
+//   variable bases, per-item scalar : 4-bit windows, 9-entry cached tables built per lane into HBM workspace (9 x 128 B
+//                   per base per item, entries in canonical 32-byte form), one entry = eight 16-byte loads
+//   variable bases, batch-constant scalar (the issuer key): width-5 NAF computed on the host, identical for every lane,
+//                   odd multiples 1..15 in the same table slots; bit-serial chain with uniform branches
+//   fixed bases   : positional tables built at context creation: for every window position j the affine-niels
+//                   entries d * 2^(AFX_POS_BITS*j) * G, d = 0 .. 2^(AFX_POS_BITS-1).  A fixed base costs AFX_POS_WINDOWS
+//                   (26 at 10 bits) additions and takes no part in the doubling chain: they are added after it.
+//                   (Round 1 first ran them inside the chain with 8-bit windows from LDS-staged tables; reading the
+//                   same tables from L2 measured equally fast, and 10-bit positional tables beat both.)
+// Field work per 4-bit window: 4 doublings (4 x 4S + 3 x 3M + 4M), 8M per variable term (the last addition of a
+// window skips the T coordinate, -1M); 7M per fixed-base addition.  Assembler::msm (engine.cpp) counts the same
+// schedule for afx_ctx_get_plan_stats.
 AFX_DEV ge_p3 msm_finish_add(const ge_p1p1& r, bool want_t) {
   ge_p3 o;
   o.X = fe_mul(r.T, r.X); o.Y = fe_mul(r.Y, r.Z); o.Z = fe_mul(r.T, r.Z);
@@ -242,76 +270,59 @@ AFX_DEV ge_p3 msm_finish_add(const ge_p1p1& r, bool want_t) {
 // per-lane context of one job inside k_msm
 struct msm_env {
   const afx_msm_job* job;
-  const int32_t* fixed_tables;
-  const int32_t* lds_tab;
   const int32_t* table_ws;
   const uint32_t* digit_ws;
-  uint32_t count, item, dslot, tslot, nv;
-  bool in_lds;
+  uint32_t count, item, dslot, tslot;
 };
 // acc += (4-bit signed digit of window w) * (variable base t), from the lane's own window table
 AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w, bool want_t) {
-  const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * 8 + ((uint32_t)w >> 3)) * e.count + e.item];
+  const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + ((uint32_t)w >> 3)) * e.count + e.item];
   const int d = (int)((word >> (((uint32_t)w & 7) * 4)) & 15u) - 8;
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
   const bool neg = (d < 0) != (e.job->term[t].negate != 0);
   const int32_t* tab = e.table_ws + ((size_t)(e.tslot + t) * e.count + e.item) * AFX_VAR_TABLE_DWORDS;
   return msm_finish_add(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), neg), want_t);
 }
-// acc += (8-bit signed digit at window w, w even) * (generator of term t), from the LDS or L2 copy of its table
-AFX_DEV ge_p3 msm_add_fixed(const msm_env& e, const ge_p3& acc, uint32_t t, int w, bool want_t) {
-  const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * 8 + ((uint32_t)w >> 3)) * e.count + e.item];
-  const int d = (int)((word >> (((uint32_t)w & 6) * 4)) & 255u) - 128;
+// acc += (AFX_POS_BITS-bit signed digit j) * 2^(AFX_POS_BITS*j) * (generator of term t), from the positional tables
+AFX_DEV ge_p3 msm_add_positional(const msm_env& e, const int32_t* __restrict__ pos_tables, const ge_p3& acc, uint32_t t, uint32_t j) {
+  const uint32_t o = AFX_POS_BITS * j, k = o >> 5, sh = o & 31u;
+  const uint32_t* dw = e.digit_ws + ((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + k) * e.count + e.item;
+  uint64_t w = dw[0];
+  if (sh + AFX_POS_BITS > 32) w |= (uint64_t)dw[e.count] << 32;   // uniform condition (j is uniform); k + 1 <= 8
+  const int d = (int)((uint32_t)(w >> sh) & ((1u << AFX_POS_BITS) - 1)) - (1 << (AFX_POS_BITS - 1));
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
   const bool neg = (d < 0) != (e.job->term[t].negate != 0);
+  const int2* p = reinterpret_cast<const int2*>(pos_tables + (size_t)e.job->term[t].fixed_idx * AFX_POS_TABLE_DWORDS +
+                                                (size_t)j * AFX_POS_WINDOW_DWORDS + idx * AFX_NIELS_DWORDS);
+  int32_t v[30];
+#pragma unroll
+  for (int l = 0; l < 15; l++) { const int2 x = p[l]; v[2 * l] = x.x; v[2 * l + 1] = x.y; }
   ge_niels q;
-  if (e.in_lds) {
-    const int32_t* p = e.lds_tab + (t - e.nv) * AFX_FIXED_TABLE_DWORDS + idx * AFX_NIELS_DWORDS;
 #pragma unroll
-    for (int l = 0; l < 10; l++) { q.ypx.v[l] = p[l]; q.ymx.v[l] = p[10 + l]; q.xy2d.v[l] = p[20 + l]; }
-  } else {
-    const int2* p = reinterpret_cast<const int2*>(e.fixed_tables + (size_t)e.job->term[t].fixed_idx * AFX_FIXED_TABLE_DWORDS + idx * AFX_NIELS_DWORDS);
-    int32_t v[30];
-#pragma unroll
-    for (int l = 0; l < 15; l++) { const int2 x = p[l]; v[2 * l] = x.x; v[2 * l + 1] = x.y; }
-#pragma unroll
-    for (int l = 0; l < 10; l++) { q.ypx.v[l] = v[l]; q.ymx.v[l] = v[10 + l]; q.xy2d.v[l] = v[20 + l]; }
-  }
-  return msm_finish_add(ge_madd(acc, q, neg), want_t);
+  for (int l = 0; l < 10; l++) { q.ypx.v[l] = v[l]; q.ymx.v[l] = v[10 + l]; q.xy2d.v[l] = v[20 + l]; }
+  return ge_p1p1_to_p3(ge_madd(acc, q, neg));
 }
 
 __global__ void __launch_bounds__(AFX_BLOCK, 2)
-k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_tables, const int32_t* __restrict__ pos_tables,
-      int32_t* __restrict__ table_ws, uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count) {
-  extern __shared__ int32_t lds_tab[];
-  const uint32_t tid = threadIdx.x;
-  // lanes past the end of the batch shadow the last item (identical values, identical stores): every lane of the
-  // block reaches every barrier
-  const uint32_t item = min(blockIdx.x * AFX_BLOCK + tid, count - 1);
+k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tables, int32_t* __restrict__ table_ws,
+      uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count) {
+  // lanes past the end of the batch shadow the last item (identical values, identical stores)
+  const uint32_t item = min(blockIdx.x * AFX_BLOCK + threadIdx.x, count - 1);
   const afx_msm_job* job = &jobs[blockIdx.y];
 #pragma unroll 1
   for (;;) {
   const uint32_t nt = job->n_terms, nv = job->n_var, nf = nt - nv, nu = job->n_uni;
-  const bool in_lds = nf <= AFX_FIXED_LDS_MAX && nv != 0;
-  __syncthreads();   // the previous job of this chain is done with the LDS tables
-  if (in_lds) {
-    for (uint32_t t = nv; t < nt; t++) {
-      const int4* src = reinterpret_cast<const int4*>(fixed_tables + (size_t)job->term[t].fixed_idx * AFX_FIXED_TABLE_DWORDS);
-      int4* dst = reinterpret_cast<int4*>(lds_tab + (t - nv) * AFX_FIXED_TABLE_DWORDS);
-      for (uint32_t i = tid; i < AFX_FIXED_TABLE_DWORDS / 4; i += AFX_BLOCK) dst[i] = src[i];
-    }
-  }
-  __syncthreads();
-
   // recode the per-item scalars, stored [slot][8][count] (batch-constant NAF terms need none)
   const uint32_t dslot = job->digit_slot;
 #pragma unroll 1
   for (uint32_t t = nu; t < nt; t++) {
     const sc s = sc_load_item(job->term[t].scalar, job->term[t].scalar_stride, item);
-    uint32_t b[8];
-    sc_bias(b, s, t < nv ? 0x88888888u : 0x80808080u);
+    uint32_t b[9];
+    b[8] = 0;
+    if (t < nv) sc_bias(b, s, 0x88888888u);
+    else sc_bias_wide<AFX_POS_BITS, AFX_POS_WINDOWS>(b, s);
 #pragma unroll
-    for (int i = 0; i < 8; i++) digit_ws[((size_t)(dslot + t) * 8 + i) * count + item] = b[i];
+    for (int i = 0; i < AFX_DIGIT_WORDS; i++) digit_ws[((size_t)(dslot + t) * AFX_DIGIT_WORDS + i) * count + item] = b[i];
   }
   // per-lane window tables for the variable bases: multiples 0..8 for 4-bit signed windows, or the odd multiples
   // 1, 3, ..., 15 for the terms that run a width-5 NAF
@@ -342,29 +353,15 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_ta
   }
 
   msm_env env;
-  env.job = job; env.fixed_tables = fixed_tables; env.lds_tab = lds_tab; env.table_ws = table_ws; env.digit_ws = digit_ws;
-  env.count = count; env.item = item; env.dslot = dslot; env.tslot = tslot; env.nv = nv; env.in_lds = in_lds;
+  env.job = job; env.table_ws = table_ws; env.digit_ws = digit_ws;
+  env.count = count; env.item = item; env.dslot = dslot; env.tslot = tslot;
   ge_p3 acc = ge_identity();
   if (nv == 0) {
-    // fixed bases only: sum over byte positions of positional-table entries, no doublings (32 additions per base)
+    // fixed bases only: sum over window positions of positional-table entries, no doublings
 #pragma unroll 1
-    for (uint32_t j = 0; j < 32; j++) {
+    for (uint32_t j = 0; j < AFX_POS_WINDOWS; j++) {
 #pragma unroll 1
-      for (uint32_t t = 0; t < nt; t++) {
-        const uint32_t word = digit_ws[((size_t)(dslot + t) * 8 + (j >> 2)) * count + item];
-        const int d = (int)((word >> ((j & 3) * 8)) & 255u) - 128;
-        const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
-        const bool neg = (d < 0) != (job->term[t].negate != 0);
-        const int2* e = reinterpret_cast<const int2*>(pos_tables + (size_t)job->term[t].fixed_idx * AFX_POS_TABLE_DWORDS +
-                                                      (size_t)j * AFX_FIXED_TABLE_DWORDS + idx * AFX_NIELS_DWORDS);
-        int32_t v[30];
-#pragma unroll
-        for (int l = 0; l < 15; l++) { const int2 x = e[l]; v[2 * l] = x.x; v[2 * l + 1] = x.y; }
-        ge_niels q;
-#pragma unroll
-        for (int l = 0; l < 10; l++) { q.ypx.v[l] = v[l]; q.ymx.v[l] = v[10 + l]; q.xy2d.v[l] = v[20 + l]; }
-        acc = ge_p1p1_to_p3(ge_madd(acc, q, neg));
-      }
+      for (uint32_t t = 0; t < nt; t++) acc = msm_add_positional(env, pos_tables, acc, t, j);
     }
   } else if (nu != 0) {
     // some scalars are batch constants: bit-serial chain, their width-5 NAF digits (the same for every lane, so the
@@ -375,7 +372,7 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_ta
 #pragma unroll 1
     for (int bit = top; bit >= 0; bit--) {
       const uint32_t nuni = nafc[bit];
-      const uint32_t nadd = nuni + ((bit & 3) == 0 ? nv - nu : 0u) + ((bit & 7) == 0 ? nf : 0u);
+      const uint32_t nadd = nuni + ((bit & 3) == 0 ? nv - nu : 0u);
       if (bit != top) acc = msm_finish_add(ge_p2_dbl(ge_p3_to_p2(acc)), nadd != 0 || bit == 0);
       uint32_t done = 0;
       if (nuni != 0) {
@@ -393,30 +390,27 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ fixed_ta
 #pragma unroll 1
         for (uint32_t t = nu; t < nv; t++) { done++; acc = msm_add_var(env, acc, t, bit >> 2, done != nadd || bit == 0); }
       }
-      if ((bit & 7) == 0) {
-#pragma unroll 1
-        for (uint32_t t = nv; t < nt; t++) { done++; acc = msm_add_fixed(env, acc, t, bit >> 2, done != nadd || bit == 0); }
-      }
     }
   } else {
 #pragma unroll 1
   for (int w = 63; w >= 0; w--) {
-    const bool fixed_now = ((w & 1) == 0) && nf != 0;
-    const uint32_t nadd = nv + (fixed_now ? nf : 0);
     if (w != 63) {
       ge_p2 a2 = ge_p3_to_p2(acc);
 #pragma unroll 1
       for (int k = 0; k < 3; k++) a2 = ge_p1p1_to_p2(ge_p2_dbl(a2));
-      acc = msm_finish_add(ge_p2_dbl(a2), nadd != 0);
+      acc = msm_finish_add(ge_p2_dbl(a2), true);
     }
-    uint32_t done = 0;
 #pragma unroll 1
-    for (uint32_t t = 0; t < nv; t++) { done++; acc = msm_add_var(env, acc, t, w, done != nadd || w == 0); }
-    if (fixed_now) {
-#pragma unroll 1
-      for (uint32_t t = nv; t < nt; t++) { done++; acc = msm_add_fixed(env, acc, t, w, done != nadd || w == 0); }
-    }
+    for (uint32_t t = 0; t < nv; t++) acc = msm_add_var(env, acc, t, w, t + 1 != nv || w == 0);
   }
+  }
+  if (nv != 0 && nf != 0) {
+    // the fixed bases of a job with variable bases: positional tables, after the chain (any order gives the same sum)
+#pragma unroll 1
+    for (uint32_t j = 0; j < AFX_POS_WINDOWS; j++) {
+#pragma unroll 1
+      for (uint32_t t = nv; t < nt; t++) acc = msm_add_positional(env, pos_tables, acc, t, j);
+    }
   }
   if (job->addend) {
     const ge_p3 A = var_load(job->addend, count, item);
@@ -576,8 +570,8 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_aos_to_soa(const uint8_t* __restr
 #include "kernels.h"
 static inline dim3 grid_for(uint32_t count, uint32_t njobs) { return dim3((count + AFX_BLOCK - 1) / AFX_BLOCK, njobs, 1); }
 
-hipError_t afxk_setup_generators(hipStream_t s, const uint8_t* enc, uint32_t ngen, int32_t* fixed_tables, int32_t* ext, uint8_t* neg_enc, uint32_t* ok) {
-  hipLaunchKernelGGL(k_setup_generators, dim3((ngen + 63) / 64), dim3(64), 0, s, enc, ngen, fixed_tables, ext, neg_enc, ok);
+hipError_t afxk_setup_generators(hipStream_t s, const uint8_t* enc, uint32_t ngen, int32_t* ext, uint8_t* neg_enc, uint32_t* ok) {
+  hipLaunchKernelGGL(k_setup_generators, dim3((ngen + 63) / 64), dim3(64), 0, s, enc, ngen, ext, neg_enc, ok);
   return hipGetLastError();
 }
 hipError_t afxk_decode(hipStream_t s, const afx_decode_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count) {
@@ -596,15 +590,15 @@ hipError_t afxk_scalarop(hipStream_t s, const afx_scalarop_job* jobs, uint32_t n
   hipLaunchKernelGGL(k_scalarop, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, count);
   return hipGetLastError();
 }
-hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen, int32_t* postab) {
-  hipLaunchKernelGGL(k_setup_postables, dim3((ngen * 32 + 63) / 64), dim3(64), 0, s, ext, ngen, postab);
+// base: scratch for ngen * AFX_POS_WINDOWS extended points (AFX_VAR_DWORDS each)
+hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen, int32_t* base, int32_t* postab) {
+  hipLaunchKernelGGL(k_setup_posbase, dim3((ngen * AFX_POS_WINDOWS + 63) / 64), dim3(64), 0, s, ext, ngen, base);
+  hipLaunchKernelGGL(k_setup_postables, dim3((ngen * AFX_POS_WINDOWS * AFX_POS_CHUNKS + 63) / 64), dim3(64), 0, s, base, ngen, postab);
   return hipGetLastError();
 }
-hipError_t afxk_msm(hipStream_t s, const afx_msm_job* jobs, uint32_t njobs, uint32_t max_fixed, const int32_t* fixed_tables, const int32_t* pos_tables,
-                    int32_t* table_ws, uint32_t* digit_ws, uint32_t* bad, uint32_t count) {
-  // max_fixed = the largest fixed-term count among the jobs that stage their tables in LDS (<= AFX_FIXED_LDS_MAX)
-  const size_t lds = (size_t)max_fixed * AFX_FIXED_TABLE_DWORDS * sizeof(int32_t);
-  hipLaunchKernelGGL(k_msm, grid_for(count, njobs), dim3(AFX_BLOCK), lds, s, jobs, fixed_tables, pos_tables, table_ws, digit_ws, bad, count);
+hipError_t afxk_msm(hipStream_t s, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, int32_t* table_ws, uint32_t* digit_ws,
+                    uint32_t* bad, uint32_t count) {
+  hipLaunchKernelGGL(k_msm, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count);
   return hipGetLastError();
 }
 hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count) {

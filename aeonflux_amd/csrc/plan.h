@@ -8,14 +8,18 @@
 
 #define AFX_MSM_MAX_TERMS 72   /* Z job: 2 + n + #public scalars <= 2 + 2n; issuance: n + 4 */
 #define AFX_TABLE_ENTRIES 9            /* variable bases: 0*P (identity) .. 8*P, signed 4-bit windows */
-#define AFX_FIXED_ENTRIES 129         /* fixed bases: 0*G .. 128*G, signed 8-bit windows          */
-#define AFX_POS_TABLE_DWORDS (32 * AFX_FIXED_TABLE_DWORDS) /* positional tables: for every byte position j, d * 256^j * G */
-#ifndef AFX_FIXED_LDS_MAX
-#define AFX_FIXED_LDS_MAX 4
-#endif /* a job stages its fixed tables in LDS when it has at most this many */
+/* positional tables: for every window position j, d * 2^(AFX_POS_BITS * j) * G for d = 0 .. 2^(AFX_POS_BITS-1), affine
+ * niels.  A fixed-base term costs AFX_POS_WINDOWS additions and no doubling, wherever in the job it is added. */
+#ifndef AFX_POS_BITS
+#define AFX_POS_BITS 10
+#endif
+#define AFX_POS_WINDOWS ((253 + AFX_POS_BITS - 1) / AFX_POS_BITS)
+#define AFX_POS_ENTRIES ((1 << (AFX_POS_BITS - 1)) + 1)
+#define AFX_POS_WINDOW_DWORDS ((AFX_POS_ENTRIES * 30 + 3) & ~3)   /* 16-byte multiple */
+#define AFX_POS_TABLE_DWORDS (AFX_POS_WINDOWS * AFX_POS_WINDOW_DWORDS)
+#define AFX_DIGIT_WORDS 9              /* recoded scalar: up to 260 bits (253 + one window of bias) */
 #define AFX_VAR_DWORDS 40              /* extended point: X,Y,Z,T x 10 limbs */
 #define AFX_NIELS_DWORDS 30            /* affine niels: y+x, y-x, 2dxy */
-#define AFX_FIXED_TABLE_DWORDS 3872    /* AFX_FIXED_ENTRIES * AFX_NIELS_DWORDS = 3870, padded to a 16-byte multiple */
 #define AFX_TABLE_ENTRY_DWORDS 32       /* a window-table entry: 4 field elements as canonical 256-bit words = 128 B = 2 HBM sectors */
 #define AFX_VAR_TABLE_DWORDS (AFX_TABLE_ENTRIES * AFX_TABLE_ENTRY_DWORDS)
 #define AFX_BLOCK 256
@@ -69,7 +73,7 @@ typedef struct {
 typedef struct {
   const uint8_t* scalar;   /* [count][32] per item, or one 32-byte scalar when scalar_stride == 0 */
   uint32_t scalar_stride;  /* 32 or 0 */
-  int32_t fixed_idx;       /* >= 0: generator id with an LDS window table; -1: variable point      */
+  int32_t fixed_idx;       /* >= 0: generator id (positional tables); -1: variable point           */
   const int32_t* var;      /* variable point (SoA) when fixed_idx < 0                              */
   uint32_t negate;         /* subtract the term                                                    */
 } afx_msm_term;

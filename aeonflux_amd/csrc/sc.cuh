@@ -164,6 +164,24 @@ AFX_DEV void sc_store(uint8_t* p, const sc& a) {
 // Signed fixed-window recoding without carries: with s' = s + 0x88..88, digit_i = nibble_i(s') - 8 in [-8, 7]
 // and sum digit_i 16^i = s; with s' = s + 0x80..80, digit_i = byte_i(s') - 128 in [-128, 127] and
 // sum digit_i 256^i = s.  Needs s < 2^255 (any canonical scalar).
+// The same for windows of B bits that do not divide 32: bias = sum over windows of 2^(B-1) * 2^(B*j); the result
+// has up to 253 + B bits (9 words).  digit_j = ((s' >> B*j) & (2^B - 1)) - 2^(B-1).
+template <int B, int WINDOWS>
+AFX_DEV void sc_bias_wide(uint32_t out[9], const sc& s) {
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    uint32_t bias = 0;
+#pragma unroll
+    for (int j = 0; j < WINDOWS; j++) {
+      const int bit = B * j + B - 1;
+      if (bit / 32 == i) bias |= 1u << (bit % 32);
+    }
+    c += (uint64_t)(i < 8 ? s.v[i] : 0u) + bias;
+    out[i] = (uint32_t)c;
+    c >>= 32;
+  }
+}
 AFX_DEV void sc_bias(uint32_t out[8], const sc& s, uint32_t bias) {
   uint64_t c = 0;
 #pragma unroll

@@ -138,7 +138,6 @@ extern "C" void afx_ctx_destroy(afx_ctx* c) {
   for (auto& L : c->lane) L.ws.release(true);
   c->staging.release(true);
   c->trace_buf.release(false);
-  c->d_fixed_tables.release(true);
   c->d_pos_tables.release(true);
   c->d_gen_ext.release(true);
   c->d_gen_enc.release(false);
@@ -208,7 +207,7 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
     c->has_key = true;
   }
   int rc;
-  if ((rc = c->d_gen_enc.ensure(32 * (size_t)c->ngen)) || (rc = c->d_fixed_tables.ensure(sizeof(int32_t) * AFX_FIXED_TABLE_DWORDS * (size_t)c->ngen)) ||
+  if ((rc = c->d_gen_enc.ensure(32 * (size_t)c->ngen)) ||
       (rc = c->d_pos_tables.ensure(sizeof(int32_t) * AFX_POS_TABLE_DWORDS * (size_t)c->ngen)) ||
       (rc = c->d_gen_ext.ensure(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)c->ngen)) || (rc = c->d_key.ensure(32 * (size_t)(4 + n))) ||
       (rc = c->d_consts.ensure(64)) || (rc = c->staging.ensure(32 * (size_t)c->ngen + 4 * (size_t)c->ngen)))
@@ -226,8 +225,10 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   AFX_HIP(hipMemcpyAsync(c->d_gen_enc.p, flat.data(), flat.size(), hipMemcpyHostToDevice, c->stream));
   uint8_t* d_neg = (uint8_t*)c->staging.p;
   uint32_t* d_ok = (uint32_t*)((uint8_t*)c->staging.p + 32 * (size_t)c->ngen);
-  AFX_HIP(afxk_setup_generators(c->stream, (const uint8_t*)c->d_gen_enc.p, c->ngen, (int32_t*)c->d_fixed_tables.p, (int32_t*)c->d_gen_ext.p, d_neg, d_ok));
-  AFX_HIP(afxk_setup_postables(c->stream, (const int32_t*)c->d_gen_ext.p, c->ngen, (int32_t*)c->d_pos_tables.p));
+  AFX_HIP(afxk_setup_generators(c->stream, (const uint8_t*)c->d_gen_enc.p, c->ngen, (int32_t*)c->d_gen_ext.p, d_neg, d_ok));
+  // window bases 2^(AFX_POS_BITS*j) * G go through lane 0's workspace (free at this point), then the tables
+  if ((rc = c->lane[0].ws.ensure(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)c->ngen * AFX_POS_WINDOWS))) return rc;
+  AFX_HIP(afxk_setup_postables(c->stream, (const int32_t*)c->d_gen_ext.p, c->ngen, (int32_t*)c->lane[0].ws.p, (int32_t*)c->d_pos_tables.p));
   std::vector<uint8_t> neg(32 * (size_t)c->ngen);
   std::vector<uint32_t> ok(c->ngen);
   AFX_HIP(hipMemcpyAsync(neg.data(), d_neg, neg.size(), hipMemcpyDeviceToHost, c->stream));

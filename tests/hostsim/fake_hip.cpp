@@ -34,7 +34,7 @@ const char* hipGetErrorString(hipError_t) { return "fake"; }
 
 // walk the job arrays like the kernels would, touching every pointer-sized field (ASan catches bad blobs)
 static volatile uintptr_t sink;
-hipError_t afxk_setup_generators(hipStream_t, const uint8_t*, uint32_t ngen, int32_t*, int32_t*, uint8_t*, uint32_t* ok) {
+hipError_t afxk_setup_generators(hipStream_t, const uint8_t*, uint32_t ngen, int32_t*, uint8_t*, uint32_t* ok) {
   for (uint32_t i = 0; i < ngen; i++) ok[i] = 1;
   return hipSuccess;
 }
@@ -42,10 +42,15 @@ hipError_t afxk_decode(hipStream_t, const afx_decode_job* j, uint32_t n, uint32_
 hipError_t afxk_sccheck(hipStream_t, const afx_sccheck_job* j, uint32_t n, uint32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].sc; return hipSuccess; }
 hipError_t afxk_pointop(hipStream_t, const afx_pointop_job* j, uint32_t n, uint32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
 hipError_t afxk_scalarop(hipStream_t, const afx_scalarop_job* j, uint32_t n, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
-hipError_t afxk_setup_postables(hipStream_t, const int32_t*, uint32_t, int32_t*) { return hipSuccess; }
-hipError_t afxk_msm(hipStream_t, const afx_msm_job* j, uint32_t n, uint32_t, const int32_t*, const int32_t*, int32_t*, uint32_t*, uint32_t*, uint32_t) {
-  for (uint32_t i = 0; i < n; i++)
+hipError_t afxk_setup_postables(hipStream_t, const int32_t*, uint32_t, int32_t*, int32_t*) { return hipSuccess; }
+hipError_t afxk_msm(hipStream_t, const afx_msm_job* j, uint32_t n, const int32_t*, int32_t*, uint32_t*, uint32_t*, uint32_t) {
+  for (uint32_t i = 0; i < n; i++) {
     for (uint32_t t = 0; t < j[i].n_terms; t++) sink += (uintptr_t)j[i].term[t].scalar;
+    if (j[i].n_uni) {   // the NAF arrays live in the plan blob: read them end to end
+      for (uint32_t b = 0; b < 256 * j[i].n_uni; b++) sink += (uintptr_t)j[i].naf[b];
+      for (uint32_t b = 0; b < 256; b++) sink += j[i].naf_count[b];
+    }
+  }
   return hipSuccess;
 }
 hipError_t afxk_hash(hipStream_t, const afx_hash_program* p, uint32_t n, uint32_t*, uint32_t) {
