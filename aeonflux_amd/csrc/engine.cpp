@@ -33,6 +33,11 @@ void DevBuf::release(bool wipe) {
 // ------------------------------------------------------------------------------------------------
 // Assembler
 // ------------------------------------------------------------------------------------------------
+static void secure_zero(void* p, size_t n) {
+  volatile uint8_t* q = (volatile uint8_t*)p;
+  for (size_t i = 0; i < n; i++) q[i] = 0;
+}
+Assembler::~Assembler() { secure_zero(blob_.data(), blob_.size()); }
 Assembler::Assembler(afx_ctx* c, uint32_t cnt, bool sizing, int ln) : ctx(c), lane(ln), count(cnt), sizing_(sizing) {
   blob_.reserve(1 << 16);
   afx_ctx::Lane& L = ctx->lane[lane];
@@ -305,6 +310,8 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     if (j.n_uni) {
       j.naf = put(naf_of[order[k]].data(), naf_of[order[k]].size());
       j.naf_count = put(nafc_of[order[k]].data(), nafc_of[order[k]].size());
+      secure_zero(naf_of[order[k]].data(), naf_of[order[k]].size());   // digits of the issuer key
+      secure_zero(nafc_of[order[k]].data(), nafc_of[order[k]].size());
     }
     out[k] = j;
   }

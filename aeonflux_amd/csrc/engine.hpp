@@ -130,6 +130,9 @@ class Assembler {
  public:
   // sizing == true: dry run that only measures workspace / blob needs (device addresses are meaningless)
   Assembler(afx_ctx* ctx, uint32_t count, bool sizing, int lane = 0);
+  ~Assembler();   // the plan can hold key material (prover witnesses in transcript constants, NAF digits of the key): wiped
+  Assembler(const Assembler&) = delete;
+  Assembler& operator=(const Assembler&) = delete;
   afx_ctx* ctx;
   int lane;
   uint32_t count;
