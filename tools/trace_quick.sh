@@ -1,5 +1,5 @@
 #!/bin/bash
-# quick kernel trace of one workload, grouped by kernel and grid.y:  tools/pmc_quick.sh c5
+# quick kernel trace of one workload, grouped by kernel and grid.y:  tools/trace_quick.sh c5
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 w=${1:-c5}
