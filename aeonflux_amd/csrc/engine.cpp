@@ -224,7 +224,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     j.n_uni = (uint32_t)uni.size();
     naf_of[ji].assign(256 * uni.size(), 0);
     nafc_of[ji].assign(256, 0);
-    int top = (lane.empty() && j.n_terms == j.n_var) ? 0 : 252;   // per-item windows start at bit 252
+    int top = lane.empty() ? 0 : 252;   // per-item windows start at bit 252
     for (size_t u = 0; u < uni.size(); u++) {
       int8_t* d = naf_of[ji].data() + 256 * u;
       top = std::max(top, naf5(d, hs[u]));

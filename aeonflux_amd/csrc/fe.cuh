@@ -110,6 +110,32 @@ AFX_DEV fe fe_carry(const fe& f) {
 #define AFX_PIN(x) ((void)0)   // host build of this header (tests/hostsim/arith_host.cpp)
 #endif
 // operation counters for the host build (the per-item counts DESIGN.md publishes are measured with them)
+// AFX_CHECK_BOUNDS (host build only): every multiplication / squaring checks what its code relies on - the int32
+// premultiplications and the 64-bit column sums - on the actual operands, and reports a violation.
+#ifdef AFX_CHECK_BOUNDS
+extern "C" void afx_bounds_violation(const char* what);
+static inline void afx_check_products(const int32_t* f, const int32_t* g, bool square) {
+  for (int i = 0; i < 10; i++) {
+    const int64_t ag = g[i] < 0 ? -(int64_t)g[i] : g[i], af = f[i] < 0 ? -(int64_t)f[i] : f[i];
+    if (ag * (square && (i & 1) ? 38 : 19) >= (1LL << 31)) afx_bounds_violation("19x/38x premultiplication overflows int32");
+    if (af * 2 >= (1LL << 31)) afx_bounds_violation("2x premultiplication overflows int32");
+  }
+  for (int k = 0; k < 10; k++) {
+    unsigned __int128 sum = 0;
+    for (int i = 0; i < 10; i++) {
+      const int j = (k - i + 10) % 10;
+      const unsigned __int128 af = f[i] < 0 ? -(int64_t)f[i] : f[i], ag = g[j] < 0 ? -(int64_t)g[j] : g[j];
+      sum += af * ag * (((i & 1) && (j & 1)) ? 2 : 1) * (i > k ? 19 : 1);
+    }
+    if (sum >= ((unsigned __int128)1 << 62)) afx_bounds_violation("column sum beyond 2^62");
+  }
+}
+#define AFX_CHECK_MUL(f, g) afx_check_products((f).v, (g).v, false)
+#define AFX_CHECK_SQ(f) afx_check_products((f).v, (f).v, true)
+#else
+#define AFX_CHECK_MUL(f, g) ((void)0)
+#define AFX_CHECK_SQ(f) ((void)0)
+#endif
 #ifdef AFX_COUNT_OPS
 extern thread_local uint64_t afx_n_mul, afx_n_sq;
 #define AFX_COUNT(x) (++(x))
@@ -118,11 +144,14 @@ extern thread_local uint64_t afx_n_mul, afx_n_sq;
 #endif
 
 // Schoolbook product, columns in order 0..9: column k's mad chain starts from the carry out of column k-1 (the
-// mad's 64-bit addend), so the carry chain needs no 64-bit additions.  Each carry arrives with the next limb's
-// rounding constant already in it (2^50 added to the high dword before the shift), which makes every limb come out
-// centred: r_k = (H_k mod 2^b) - 2^(b-1).
-AFX_DEV fe fe_mul(const fe& f, const fe& g) {
+// mad's 64-bit addend), so the carry chain needs no 64-bit additions.  CENTRED: each carry arrives with the next
+// limb's rounding constant already in it (2^50 added to the high dword before the shift), which makes every limb
+// come out centred: r_k = (H_k mod 2^b) - 2^(b-1), |r_k| <= 2^(b-1).  Not CENTRED ("raw"): floor carries, limbs in
+// [0, 2^b): 18 fewer additions, for results whose consumer is known to tolerate twice the magnitude (below).
+template <bool CENTRED>
+AFX_DEV fe fe_mul_impl(const fe& f, const fe& g) {
   AFX_COUNT(afx_n_mul);
+  AFX_CHECK_MUL(f, g);
   int32_t g19[10], f2[10];
 #pragma unroll
   for (int i = 0; i < 10; i++) {
@@ -130,7 +159,7 @@ AFX_DEV fe fe_mul(const fe& f, const fe& g) {
     f2[i] = (int32_t)(2u * (uint32_t)f.v[i]);
   }
   fe r;
-  int64_t c = 1LL << 25;  // rounding constant of limb 0; later carries arrive with the next limb's constant folded in
+  int64_t c = CENTRED ? (1LL << 25) : 0;  // rounding constant of limb 0; later carries arrive with the next limb's folded in
   uint32_t u0 = 0;
 #pragma unroll
   for (int k = 0; k < 10; k++) {
@@ -146,19 +175,27 @@ AFX_DEV fe fe_mul(const fe& f, const fe& g) {
     }
     const int bits = (k & 1) ? 25 : 26;
     const uint32_t lo = (uint32_t)H & ((1u << bits) - 1);
-    if (k == 0) u0 = lo; else r.v[k] = (int32_t)lo - (1 << (bits - 1));
-    c = (k < 9) ? ((H + (1LL << 50)) >> bits) : (H >> bits);
+    if (k == 0) u0 = lo; else r.v[k] = CENTRED ? (int32_t)lo - (1 << (bits - 1)) : (int32_t)lo;
+    c = (CENTRED && k < 9) ? ((H + (1LL << 50)) >> bits) : (H >> bits);
   }
-  // wrap: limb 0 gets 19 * carry(limb 9); u0 still holds limb 0 with its rounding constant
+  // wrap: limb 0 gets 19 * carry(limb 9); u0 still holds limb 0 (with its rounding constant when CENTRED)
   int64_t H0 = (int64_t)u0 + c * 19;
   const int32_t c0 = (int32_t)(H0 >> 26);
-  r.v[0] = (int32_t)((uint32_t)H0 & 0x3ffffffu) - (1 << 25);
+  r.v[0] = CENTRED ? (int32_t)((uint32_t)H0 & 0x3ffffffu) - (1 << 25) : (int32_t)((uint32_t)H0 & 0x3ffffffu);
   r.v[1] += c0;
   return r;
 }
+AFX_DEV fe fe_mul(const fe& f, const fe& g) { return fe_mul_impl<true>(f, g); }
+// Raw result: limbs in [0, 2^26) / [0, 2^25) ("1 unit" where a centred result is 1/2 unit).  Valid as either operand
+// of a multiplication or as the input of a squaring; sums of two raw values (2 units) only as a FIRST operand; a
+// difference of two raw values (+-1 unit) anywhere.  ge.cuh documents, at each use, why the consumer qualifies.
+AFX_DEV fe fe_mul_raw(const fe& f, const fe& g) { return fe_mul_impl<false>(f, g); }
 
-AFX_DEV fe fe_sq(const fe& f) {
+// The same two flavours for the squaring (raw: the squaring chains of the inversions, and Z^2 of the doubling).
+template <bool CENTRED>
+AFX_DEV fe fe_sq_impl(const fe& f) {
   AFX_COUNT(afx_n_sq);
+  AFX_CHECK_SQ(f);
   int32_t f2[10], f19[10], f38[10];
 #pragma unroll
   for (int i = 0; i < 10; i++) {
@@ -167,7 +204,7 @@ AFX_DEV fe fe_sq(const fe& f) {
     f38[i] = (int32_t)(38u * (uint32_t)f.v[i]);
   }
   fe r;
-  int64_t c = 1LL << 25;
+  int64_t c = CENTRED ? (1LL << 25) : 0;
   uint32_t u0 = 0;
 #pragma unroll
   for (int k = 0; k < 10; k++) {
@@ -185,20 +222,22 @@ AFX_DEV fe fe_sq(const fe& f) {
     }
     const int bits = (k & 1) ? 25 : 26;
     const uint32_t lo = (uint32_t)H & ((1u << bits) - 1);
-    if (k == 0) u0 = lo; else r.v[k] = (int32_t)lo - (1 << (bits - 1));
-    c = (k < 9) ? ((H + (1LL << 50)) >> bits) : (H >> bits);
+    if (k == 0) u0 = lo; else r.v[k] = CENTRED ? (int32_t)lo - (1 << (bits - 1)) : (int32_t)lo;
+    c = (CENTRED && k < 9) ? ((H + (1LL << 50)) >> bits) : (H >> bits);
   }
   int64_t H0 = (int64_t)u0 + c * 19;
   const int32_t c0 = (int32_t)(H0 >> 26);
-  r.v[0] = (int32_t)((uint32_t)H0 & 0x3ffffffu) - (1 << 25);
+  r.v[0] = CENTRED ? (int32_t)((uint32_t)H0 & 0x3ffffffu) - (1 << 25) : (int32_t)((uint32_t)H0 & 0x3ffffffu);
   r.v[1] += c0;
   return r;
 }
+AFX_DEV fe fe_sq(const fe& f) { return fe_sq_impl<true>(f); }
+AFX_DEV fe fe_sq_raw(const fe& f) { return fe_sq_impl<false>(f); }
 
-// f^(2^n), n >= 1, rolled loop (keeps the inversion chains small in code size)
+// f^(2^n), n >= 1, rolled loop (keeps the inversion chains small in code size); every consumer multiplies the result
 AFX_DEV fe fe_sqn(fe f, int n) {
 #pragma unroll 1
-  for (int i = 0; i < n; i++) f = fe_sq(f);
+  for (int i = 0; i < n; i++) f = fe_sq_raw(f);
   return f;
 }
 

@@ -46,7 +46,46 @@ AFX_DEV ge_p2 ge_p1p1_to_p2(const ge_p1p1& p) {
 }
 AFX_DEV ge_p3 ge_p1p1_to_p3(const ge_p1p1& p) {
   ge_p3 r;
-  r.X = fe_mul(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul(p.T, p.Z); r.T = fe_mul(p.X, p.Y);
+  r.X = fe_mul(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul(p.T, p.Z); r.T = fe_mul(p.Y, p.X);   // Y (up to 2 units) must be a first operand; X and Z are the second operands
+  return r;
+}
+// Conversions inside a doubling/addition chain, where the consumer of every coordinate is known (units: a centred
+// product is 1/2, a raw one 1; fe_mul takes <= 4 as first and <= 1.65 as second operand, fe_sq <= 1.65):
+//   GE_FOR_DBL   before a doubling (ge_p2_dbl): X, Y centred because (X+Y)^2 squares their sum (1 unit); Z raw (it
+//                is only squared); T not computed.
+//   GE_FOR_ADD   before an addition of a cached entry (ge_add_cached): X, Y, Z, T raw - Y+-X (2 units) and Z are
+//                first operands, T (1 unit) is a second operand.
+//   GE_FOR_MADD  before an addition of a niels entry (ge_madd): X, Y, T raw; Z centred because 2Z enters
+//                Z3 = 2Z + C, a second operand of the next conversion (a raw Z would make it 2.5 units).
+//   GE_FOR_ANY   everything centred (stores, encodings, table building, any other consumer).
+// The completed point's own bounds hold for every producer in this file: |X| <= 1.5, |Y| <= 2, |Z| <= 1.5, |T| <= 3,
+// so X and Z are the second operands of the four products and Y, T the first.  tests/test_device_arith_on_host.py
+// runs random chains of these steps on the host build with every operand bound asserted (AFX_CHECK_BOUNDS).
+enum { GE_FOR_DBL = 0, GE_FOR_ADD = 1, GE_FOR_MADD = 2, GE_FOR_ANY = 3 };
+template <int NEXT>
+AFX_DEV ge_p3 ge_p1p1_to_p3_for(const ge_p1p1& p) {
+  ge_p3 r;
+  if constexpr (NEXT == GE_FOR_DBL) {
+    r.X = fe_mul(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul_raw(p.T, p.Z); r.T = r.X;
+  } else if constexpr (NEXT == GE_FOR_ADD) {
+    r.X = fe_mul_raw(p.T, p.X); r.Y = fe_mul_raw(p.Y, p.Z); r.Z = fe_mul_raw(p.T, p.Z); r.T = fe_mul_raw(p.Y, p.X);
+  } else if constexpr (NEXT == GE_FOR_MADD) {
+    r.X = fe_mul_raw(p.T, p.X); r.Y = fe_mul_raw(p.Y, p.Z); r.Z = fe_mul(p.T, p.Z); r.T = fe_mul_raw(p.Y, p.X);
+  } else {
+    r = ge_p1p1_to_p3(p);
+  }
+  return r;
+}
+// the same with a (wave-uniform) run-time consumer
+AFX_DEV ge_p3 ge_p1p1_to_p3_next(const ge_p1p1& p, int next) {
+  if (next == GE_FOR_DBL) return ge_p1p1_to_p3_for<GE_FOR_DBL>(p);
+  if (next == GE_FOR_ADD) return ge_p1p1_to_p3_for<GE_FOR_ADD>(p);
+  if (next == GE_FOR_MADD) return ge_p1p1_to_p3_for<GE_FOR_MADD>(p);
+  return ge_p1p1_to_p3(p);
+}
+AFX_DEV ge_p2 ge_p1p1_to_p2_before_dbl(const ge_p1p1& p) {
+  ge_p2 r;
+  r.X = fe_mul(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul_raw(p.T, p.Z);
   return r;
 }
 AFX_DEV ge_p2 ge_p3_to_p2(const ge_p3& p) {
@@ -67,7 +106,8 @@ AFX_DEV ge_cached ge_p3_to_cached_reduced(const ge_p3& p) {
 }
 AFX_DEV ge_p1p1 ge_p2_dbl(const ge_p2& p) {
   ge_p1p1 r;
-  fe XX = fe_sq(p.X), YY = fe_sq(p.Y), ZZ = fe_sq(p.Z);
+  // Z^2 uncentred: it only reaches T = 2ZZ - (YY - XX), which is fe_mul's wide first operand in both conversions
+  fe XX = fe_sq(p.X), YY = fe_sq(p.Y), ZZ = fe_sq_raw(p.Z);
   fe B = fe_add(ZZ, ZZ);
   fe A = fe_add(p.X, p.Y);
   fe AA = fe_sq(A);
@@ -82,8 +122,9 @@ AFX_DEV ge_p1p1 ge_add_cached(const ge_p3& p, const ge_cached& q, bool neg) {
   ge_p1p1 r;
   fe qp = q.YpX, qm = q.YmX;
   fe_cswap(qp, qm, neg);
-  fe A = fe_mul(fe_add(p.Y, p.X), qp);
-  fe B = fe_mul(fe_sub(p.Y, p.X), qm);
+  // A, B raw: they only meet in X3 = A - B (+-1 unit, a second operand) and Y3 = A + B (2 units, a first operand)
+  fe A = fe_mul_raw(fe_add(p.Y, p.X), qp);
+  fe B = fe_mul_raw(fe_sub(p.Y, p.X), qm);
   fe C = fe_cneg(fe_mul(q.T2d, p.T), neg);
   fe ZZ = fe_mul(p.Z, q.Z);
   fe D = fe_add(ZZ, ZZ);
@@ -97,8 +138,8 @@ AFX_DEV ge_p1p1 ge_madd(const ge_p3& p, const ge_niels& q, bool neg) {
   ge_p1p1 r;
   fe qp = q.ypx, qm = q.ymx;
   fe_cswap(qp, qm, neg);
-  fe A = fe_mul(fe_add(p.Y, p.X), qp);
-  fe B = fe_mul(fe_sub(p.Y, p.X), qm);
+  fe A = fe_mul_raw(fe_add(p.Y, p.X), qp);   // raw: see ge_add_cached
+  fe B = fe_mul_raw(fe_sub(p.Y, p.X), qm);
   fe C = fe_cneg(fe_mul(q.xy2d, p.T), neg);
   fe D = fe_add(p.Z, p.Z);
   r.X = fe_sub(A, B);

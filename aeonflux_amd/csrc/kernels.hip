@@ -259,14 +259,6 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_scalarop(const afx_scalarop_job* 
 // Field work per 4-bit window: 4 doublings (4 x 4S + 3 x 3M + 4M), 8M per variable term (the last addition of a
 // window skips the T coordinate, -1M); 7M per fixed-base addition.  Assembler::msm (engine.cpp) counts the same
 // schedule for afx_ctx_get_plan_stats.
-AFX_DEV ge_p3 msm_finish_add(const ge_p1p1& r, bool want_t) {
-  ge_p3 o;
-  o.X = fe_mul(r.T, r.X); o.Y = fe_mul(r.Y, r.Z); o.Z = fe_mul(r.T, r.Z);
-  if (want_t) o.T = fe_mul(r.X, r.Y);
-  else o.T = o.X;   // unused by the doublings that follow
-  return o;
-}
-
 // per-lane context of one job inside k_msm
 struct msm_env {
   const afx_msm_job* job;
@@ -275,16 +267,17 @@ struct msm_env {
   uint32_t count, item, dslot, tslot;
 };
 // acc += (4-bit signed digit of window w) * (variable base t), from the lane's own window table
-AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w, bool want_t) {
+// `next` (wave-uniform): what consumes the result, GE_FOR_* (ge.cuh)
+AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w, int next) {
   const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + ((uint32_t)w >> 3)) * e.count + e.item];
   const int d = (int)((word >> (((uint32_t)w & 7) * 4)) & 15u) - 8;
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
   const bool neg = (d < 0) != (e.job->term[t].negate != 0);
   const int32_t* tab = e.table_ws + ((size_t)(e.tslot + t) * e.count + e.item) * AFX_VAR_TABLE_DWORDS;
-  return msm_finish_add(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), neg), want_t);
+  return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), neg), next);
 }
 // acc += (AFX_POS_BITS-bit signed digit j) * 2^(AFX_POS_BITS*j) * (generator of term t), from the positional tables
-AFX_DEV ge_p3 msm_add_positional(const msm_env& e, const int32_t* __restrict__ pos_tables, const ge_p3& acc, uint32_t t, uint32_t j) {
+AFX_DEV ge_p3 msm_add_positional(const msm_env& e, const int32_t* __restrict__ pos_tables, const ge_p3& acc, uint32_t t, uint32_t j, int next) {
   const uint32_t o = AFX_POS_BITS * j, k = o >> 5, sh = o & 31u;
   const uint32_t* dw = e.digit_ws + ((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + k) * e.count + e.item;
   uint64_t w = dw[0];
@@ -300,7 +293,7 @@ AFX_DEV ge_p3 msm_add_positional(const msm_env& e, const int32_t* __restrict__ p
   ge_niels q;
 #pragma unroll
   for (int l = 0; l < 10; l++) { q.ypx.v[l] = v[l]; q.ymx.v[l] = v[10 + l]; q.xy2d.v[l] = v[20 + l]; }
-  return ge_p1p1_to_p3(ge_madd(acc, q, neg));
+  return ge_p1p1_to_p3_next(ge_madd(acc, q, neg), next);
 }
 
 __global__ void __launch_bounds__(AFX_BLOCK, 2)
@@ -361,7 +354,8 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
 #pragma unroll 1
     for (uint32_t j = 0; j < AFX_POS_WINDOWS; j++) {
 #pragma unroll 1
-      for (uint32_t t = 0; t < nt; t++) acc = msm_add_positional(env, pos_tables, acc, t, j);
+      for (uint32_t t = 0; t < nt; t++)
+        acc = msm_add_positional(env, pos_tables, acc, t, j, (j + 1 == AFX_POS_WINDOWS && t + 1 == nt) ? GE_FOR_ANY : GE_FOR_MADD);
     }
   } else if (nu != 0) {
     // some scalars are batch constants: bit-serial chain, their width-5 NAF digits (the same for every lane, so the
@@ -373,7 +367,9 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
     for (int bit = top; bit >= 0; bit--) {
       const uint32_t nuni = nafc[bit];
       const uint32_t nadd = nuni + ((bit & 3) == 0 ? nv - nu : 0u);
-      if (bit != top) acc = msm_finish_add(ge_p2_dbl(ge_p3_to_p2(acc)), nadd != 0 || bit == 0);
+      // what follows the last step at this bit position: the next doubling, or (bit 0) whatever comes after the chain
+      const int after = bit == 0 ? GE_FOR_ANY : GE_FOR_DBL;
+      if (bit != top) acc = ge_p1p1_to_p3_next(ge_p2_dbl(ge_p3_to_p2(acc)), nadd != 0 ? GE_FOR_ADD : after);
       uint32_t done = 0;
       if (nuni != 0) {
 #pragma unroll 1
@@ -383,12 +379,12 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
           const uint32_t idx = (uint32_t)((d < 0 ? -d : d) - 1) >> 1;
           const int32_t* tab = table_ws + ((size_t)(tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
           done++;
-          acc = msm_finish_add(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), d < 0), done != nadd || bit == 0);
+          acc = ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), d < 0), done != nadd ? GE_FOR_ADD : after);
         }
       }
       if ((bit & 3) == 0) {
 #pragma unroll 1
-        for (uint32_t t = nu; t < nv; t++) { done++; acc = msm_add_var(env, acc, t, bit >> 2, done != nadd || bit == 0); }
+        for (uint32_t t = nu; t < nv; t++) { done++; acc = msm_add_var(env, acc, t, bit >> 2, done != nadd ? GE_FOR_ADD : after); }
       }
     }
   } else {
@@ -397,11 +393,12 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
     if (w != 63) {
       ge_p2 a2 = ge_p3_to_p2(acc);
 #pragma unroll 1
-      for (int k = 0; k < 3; k++) a2 = ge_p1p1_to_p2(ge_p2_dbl(a2));
-      acc = msm_finish_add(ge_p2_dbl(a2), true);
+      for (int k = 0; k < 3; k++) a2 = ge_p1p1_to_p2_before_dbl(ge_p2_dbl(a2));
+      acc = ge_p1p1_to_p3_for<GE_FOR_ADD>(ge_p2_dbl(a2));
     }
 #pragma unroll 1
-    for (uint32_t t = 0; t < nv; t++) acc = msm_add_var(env, acc, t, w, t + 1 != nv || w == 0);
+    for (uint32_t t = 0; t + 1 < nv; t++) acc = msm_add_var(env, acc, t, w, GE_FOR_ADD);
+    acc = msm_add_var(env, acc, nv - 1, w, w == 0 ? GE_FOR_ANY : GE_FOR_DBL);   // the window's last addition
   }
   }
   if (nv != 0 && nf != 0) {
@@ -409,7 +406,8 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
 #pragma unroll 1
     for (uint32_t j = 0; j < AFX_POS_WINDOWS; j++) {
 #pragma unroll 1
-      for (uint32_t t = nv; t < nt; t++) acc = msm_add_positional(env, pos_tables, acc, t, j);
+      for (uint32_t t = nv; t < nt; t++)
+        acc = msm_add_positional(env, pos_tables, acc, t, j, (j + 1 == AFX_POS_WINDOWS && t + 1 == nt) ? GE_FOR_ANY : GE_FOR_MADD);
     }
   }
   if (job->addend) {

@@ -5,6 +5,11 @@
 #include <string.h>
 thread_local uint64_t afx_n_mul = 0, afx_n_sq = 0;
 #define AFX_COUNT_OPS 1
+// every fe_mul / fe_sq of this build checks its operand bounds on the actual values (fe.cuh, AFX_CHECK_BOUNDS)
+#define AFX_CHECK_BOUNDS 1
+static uint64_t n_violations = 0;
+static const char* last_violation = "";
+extern "C" void afx_bounds_violation(const char* what) { n_violations++; last_violation = what; }
 #include "../../aeonflux_amd/csrc/ge.cuh"
 #include "../../aeonflux_amd/csrc/sc.cuh"
 
@@ -12,6 +17,89 @@ static void load8(uint32_t w[8], const uint8_t* p) { memcpy(w, p, 32); }
 static sc sc_from(const uint8_t* p) { sc s; memcpy(s.v, p, 32); return s; }
 
 extern "C" {
+
+uint64_t arith_bounds_violations(void) { return n_violations; }
+// self-test of the checker: a second operand of three reduced terms' magnitude times two must trip it; returns the
+// number of violations it caused and leaves the global count as it was
+uint64_t arith_bounds_checker_selftest(void) {
+  const uint64_t before = n_violations;
+  fe big;
+  for (int i = 0; i < 10; i++) big.v[i] = (i & 1) ? (3 << 25) : (3 << 26);
+  (void)fe_mul(fe_one(), big);     // 19 * 3 * 2^26 does not fit int32
+  (void)fe_sq(big);
+  const uint64_t caused = n_violations - before;
+  n_violations = before;
+  return caused;
+}
+const char* arith_last_violation(void) { return last_violation; }
+
+// The doubling/addition chain of k_msm, step for step, with the same consumer-aware conversions (ge.cuh GE_FOR_*):
+// out = sum_t s[t] * P[t] (nv variable bases, signed 4-bit windows, per-"lane" tables as the kernel builds them)
+//       + sum_u f[u] * Q[u] (nf points added as affine niels entries after the chain, bit by bit, standing in for the
+//       positional tables).  Returns 0 if a point does not decode.
+int arith_msm_chain(uint8_t out[32], uint32_t nv, const uint8_t* s, const uint8_t* p, uint32_t nf, const uint8_t* f, const uint8_t* q) {
+  if (nv == 0 || nv > 8 || nf > 4) return 0;
+  ge_cached tab[8][9];
+  uint32_t digits[8][8];
+  for (uint32_t t = 0; t < nv; t++) {
+    uint32_t w[8];
+    load8(w, p + 32 * t);
+    ge_p3 P;
+    if (!ristretto_decode(P, w)) return 0;
+    const ge_cached cP = ge_p3_to_cached_reduced(P);
+    tab[t][0] = ge_cached_identity();
+    tab[t][1] = cP;
+    ge_p3 Q = P;
+    for (int k = 2; k < 9; k++) { Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false)); tab[t][k] = ge_p3_to_cached_reduced(Q); }
+    // the kernel stores entries in canonical 32-byte form and reloads them: do the same round trip
+    for (int k = 0; k < 9; k++) {
+      uint32_t b[8];
+      fe_tobytes(b, tab[t][k].YpX); tab[t][k].YpX = fe_frombytes(b);
+      fe_tobytes(b, tab[t][k].YmX); tab[t][k].YmX = fe_frombytes(b);
+      fe_tobytes(b, tab[t][k].Z); tab[t][k].Z = fe_frombytes(b);
+      fe_tobytes(b, tab[t][k].T2d); tab[t][k].T2d = fe_frombytes(b);
+    }
+    sc_bias(digits[t], sc_from(s + 32 * t), 0x88888888u);
+  }
+  ge_p3 acc = ge_identity();
+  for (int w = 63; w >= 0; w--) {
+    if (w != 63) {
+      ge_p2 a2 = ge_p3_to_p2(acc);
+      for (int k = 0; k < 3; k++) a2 = ge_p1p1_to_p2_before_dbl(ge_p2_dbl(a2));
+      acc = ge_p1p1_to_p3_for<GE_FOR_ADD>(ge_p2_dbl(a2));
+    }
+    for (uint32_t t = 0; t < nv; t++) {
+      const int d = (int)((digits[t][w >> 3] >> ((w & 7) * 4)) & 15u) - 8;
+      const int idx = d < 0 ? -d : d;
+      const int next = t + 1 < nv ? GE_FOR_ADD : (w == 0 ? GE_FOR_ANY : GE_FOR_DBL);
+      acc = ge_p1p1_to_p3_next(ge_add_cached(acc, tab[t][idx], d < 0), next);
+    }
+  }
+  // niels additions after the chain: f[u] * Q[u] bit by bit with 2^bit * Q[u] made affine on the fly
+  for (uint32_t u = 0; u < nf; u++) {
+    uint32_t w[8];
+    load8(w, q + 32 * u);
+    ge_p3 B;
+    if (!ristretto_decode(B, w)) return 0;
+    const fe d2 = fe_const(FEC_D2);
+    for (int bit = 0; bit < 253; bit++) {
+      if ((f[32 * u + (bit >> 3)] >> (bit & 7)) & 1) {
+        const fe zinv = fe_invert(B.Z);
+        const fe x = fe_mul(B.X, zinv), y = fe_mul(B.Y, zinv);
+        ge_niels nq;
+        nq.ypx = fe_carry(fe_add(y, x)); nq.ymx = fe_carry(fe_sub(y, x)); nq.xy2d = fe_mul(fe_mul(x, y), d2);
+        const bool last = u + 1 == nf && bit == 252;
+        acc = ge_p1p1_to_p3_next(ge_madd(acc, nq, (bit & 1) != 0 ? false : false), last ? GE_FOR_ANY : GE_FOR_MADD);
+      }
+      B = ge_double(B);
+    }
+  }
+  acc = ge_carry(acc);   // whatever the last consumer annotation was, the encoder takes any reduced point
+  uint32_t o[8];
+  ristretto_encode(o, acc);
+  memcpy(out, o, 32);
+  return 1;
+}
 
 void arith_counters(uint64_t out[2], int reset) {
   out[0] = afx_n_mul; out[1] = afx_n_sq;

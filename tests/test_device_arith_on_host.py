@@ -21,7 +21,10 @@ def arith(tmp_path_factory):
            os.path.join(ROOT, "tests", "hostsim", "arith_host.cpp")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    return C.CDLL(out)
+    lib = C.CDLL(out)
+    lib.arith_bounds_violations.restype = C.c_uint64
+    lib.arith_last_violation.restype = C.c_char_p
+    return lib
 
 
 def stream(seed, n):
@@ -105,6 +108,41 @@ def test_scalar_ops_against_python_integers(arith):
         assert int.from_bytes(bytes(ng), "little") == (-av) % L
         arith.arith_sc(red, ma, ng, C.byref(can), wide, a, b_r, c_r)
         assert can.value == (1 if ai < L else 0)
+
+
+def test_msm_chain_with_consumer_aware_conversions(arith):
+    """k_msm's chain, step for step (raw / centred conversions chosen by what consumes them), against the oracle's
+    multiscalar multiplication; every fe_mul / fe_sq of the host build asserts its operand bounds on the way"""
+    import oracle
+    s = stream(b"chain-host", 64 * 12 * 12)
+    out = (C.c_uint8 * 32)()
+    pos = 0
+    for case in range(12):
+        nv, nf = 1 + case % 6, case % 3
+        pts = [oracle.point_from_uniform(s[pos + 64 * i:pos + 64 * i + 64]) for i in range(nv + nf)]
+        pos += 64 * (nv + nf)
+        scs = [oracle.scalar_reduce_wide(hashlib.sha512(b"k%d-%d" % (case, i)).digest()) for i in range(nv + nf)]
+        if case == 3:
+            scs[0] = bytes(32)                                          # all-zero digits: identity entries only
+        if case == 4:
+            scs[0] = (L - 1).to_bytes(32, "little")
+        if case == 5:
+            pts[0] = bytes(32)                                          # the identity as a base
+        assert arith.arith_msm_chain(out, nv, b"".join(scs[:nv]), b"".join(pts[:nv]), nf, b"".join(scs[nv:]), b"".join(pts[nv:])) == 1
+        assert bytes(out) == oracle.multiscalar(scs, pts), case
+    assert arith.arith_bounds_violations() == 0, arith.arith_last_violation()
+
+
+def test_the_bounds_checker_fires(arith):
+    arith.arith_bounds_checker_selftest.restype = C.c_uint64
+    assert arith.arith_bounds_checker_selftest() >= 2
+
+
+def test_no_bound_was_violated_anywhere(arith):
+    """runs last in this module: all the field operations of the tests above stayed within their operand bounds"""
+    arith.arith_bounds_violations.restype = C.c_uint64
+    arith.arith_last_violation.restype = C.c_char_p
+    assert arith.arith_bounds_violations() == 0, arith.arith_last_violation()
 
 
 def test_signed_digit_recoding(arith):
