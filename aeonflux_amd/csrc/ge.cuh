@@ -20,8 +20,9 @@ AFX_DEV fe fe_const(const int32_t* c) {
 struct ge_p3 { fe X, Y, Z, T; };        // extended: x = X/Z, y = Y/Z, xy = T/Z
 struct ge_p2 { fe X, Y, Z; };           // projective
 struct ge_p1p1 { fe X, Y, Z, T; };      // completed: ((X:Z), (Y:T))
-struct ge_cached { fe YpX, YmX, Z, T2d; };
-struct ge_niels { fe ypx, ymx, xy2d; }; // affine precomputed (Z = 1)
+struct ge_cached { fe YpX, YmX, Z2, T2d; };   // Y+X, Y-X, 2Z, 2dT: the addition needs 2*Z1*Z2 and gets it in one product
+struct ge_niels { fe ypx, ymx, xyd; };         // affine precomputed, HALVED: (y+x)/2, (y-x)/2, d*x*y.  Halving every entry
+                                               // scales the completed sum by 1/2 (same point) and saves doubling Z
 
 AFX_DEV ge_p3 ge_identity() {
   ge_p3 r;
@@ -30,12 +31,19 @@ AFX_DEV ge_p3 ge_identity() {
 }
 AFX_DEV ge_cached ge_cached_identity() {
   ge_cached r;
-  r.YpX = fe_one(); r.YmX = fe_one(); r.Z = fe_one(); r.T2d = fe_zero();
+  r.YpX = fe_one(); r.YmX = fe_one(); r.Z2 = fe_one(); r.Z2.v[0] = 2; r.T2d = fe_zero();
   return r;
 }
 AFX_DEV ge_niels ge_niels_identity() {
   ge_niels r;
-  r.ypx = fe_one(); r.ymx = fe_one(); r.xy2d = fe_zero();
+  r.ypx = fe_const(FEC_INV2); r.ymx = fe_const(FEC_INV2); r.xyd = fe_zero();
+  return r;
+}
+// affine point (x, y) -> halved niels form
+AFX_DEV ge_niels ge_niels_from_affine(const fe& x, const fe& y) {
+  ge_niels r;
+  const fe inv2 = fe_const(FEC_INV2);
+  r.ypx = fe_mul(fe_add(y, x), inv2); r.ymx = fe_mul(fe_sub(y, x), inv2); r.xyd = fe_mul(fe_mul(x, y), fe_const(FEC_D));
   return r;
 }
 AFX_DEV ge_p2 ge_p1p1_to_p2(const ge_p1p1& p) {
@@ -51,26 +59,23 @@ AFX_DEV ge_p3 ge_p1p1_to_p3(const ge_p1p1& p) {
 }
 // Conversions inside a doubling/addition chain, where the consumer of every coordinate is known (units: a centred
 // product is 1/2, a raw one 1; fe_mul takes <= 4 as first and <= 1.65 as second operand, fe_sq <= 1.65):
-//   GE_FOR_DBL   before a doubling (ge_p2_dbl): X, Y centred because (X+Y)^2 squares their sum (1 unit); Z raw (it
-//                is only squared); T not computed.
-//   GE_FOR_ADD   before an addition of a cached entry (ge_add_cached): X, Y, Z, T raw - Y+-X (2 units) and Z are
-//                first operands, T (1 unit) is a second operand.
-//   GE_FOR_MADD  before an addition of a niels entry (ge_madd): X, Y, T raw; Z centred because 2Z enters
-//                Z3 = 2Z + C, a second operand of the next conversion (a raw Z would make it 2.5 units).
+//   GE_FOR_DBL   before a doubling (ge_p2_dbl): Y centred, X and Z raw - (X+Y)^2 squares a sum within 1.5 units, X
+//                and Z are otherwise only squared; T not computed.
+//   GE_FOR_ADD   before an addition (ge_add_cached, ge_madd): X, Y, Z, T raw - Y+-X (2 units) and Z are first
+//                operands, T (1 unit) is a second operand; Z1*Z2' (cached, Z2' = 2 Z2) or Z itself (halved niels) is
+//                added to a centred product, so Z3 and T3 stay within 1.5 units.
 //   GE_FOR_ANY   everything centred (stores, encodings, table building, any other consumer).
 // The completed point's own bounds hold for every producer in this file: |X| <= 1.5, |Y| <= 2, |Z| <= 1.5, |T| <= 3,
 // so X and Z are the second operands of the four products and Y, T the first.  tests/test_device_arith_on_host.py
-// runs random chains of these steps on the host build with every operand bound asserted (AFX_CHECK_BOUNDS).
-enum { GE_FOR_DBL = 0, GE_FOR_ADD = 1, GE_FOR_MADD = 2, GE_FOR_ANY = 3 };
+// runs chains of these steps on the host build with every operand bound asserted (AFX_CHECK_BOUNDS).
+enum { GE_FOR_DBL = 0, GE_FOR_ADD = 1, GE_FOR_ANY = 3 };
 template <int NEXT>
 AFX_DEV ge_p3 ge_p1p1_to_p3_for(const ge_p1p1& p) {
   ge_p3 r;
   if constexpr (NEXT == GE_FOR_DBL) {
-    r.X = fe_mul(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul_raw(p.T, p.Z); r.T = r.X;
+    r.X = fe_mul_raw(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul_raw(p.T, p.Z); r.T = r.X;
   } else if constexpr (NEXT == GE_FOR_ADD) {
     r.X = fe_mul_raw(p.T, p.X); r.Y = fe_mul_raw(p.Y, p.Z); r.Z = fe_mul_raw(p.T, p.Z); r.T = fe_mul_raw(p.Y, p.X);
-  } else if constexpr (NEXT == GE_FOR_MADD) {
-    r.X = fe_mul_raw(p.T, p.X); r.Y = fe_mul_raw(p.Y, p.Z); r.Z = fe_mul(p.T, p.Z); r.T = fe_mul_raw(p.Y, p.X);
   } else {
     r = ge_p1p1_to_p3(p);
   }
@@ -80,12 +85,11 @@ AFX_DEV ge_p3 ge_p1p1_to_p3_for(const ge_p1p1& p) {
 AFX_DEV ge_p3 ge_p1p1_to_p3_next(const ge_p1p1& p, int next) {
   if (next == GE_FOR_DBL) return ge_p1p1_to_p3_for<GE_FOR_DBL>(p);
   if (next == GE_FOR_ADD) return ge_p1p1_to_p3_for<GE_FOR_ADD>(p);
-  if (next == GE_FOR_MADD) return ge_p1p1_to_p3_for<GE_FOR_MADD>(p);
   return ge_p1p1_to_p3(p);
 }
 AFX_DEV ge_p2 ge_p1p1_to_p2_before_dbl(const ge_p1p1& p) {
   ge_p2 r;
-  r.X = fe_mul(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul_raw(p.T, p.Z);
+  r.X = fe_mul_raw(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul_raw(p.T, p.Z);
   return r;
 }
 AFX_DEV ge_p2 ge_p3_to_p2(const ge_p3& p) {
@@ -95,7 +99,7 @@ AFX_DEV ge_p2 ge_p3_to_p2(const ge_p3& p) {
 }
 AFX_DEV ge_cached ge_p3_to_cached(const ge_p3& p) {
   ge_cached r;
-  r.YpX = fe_add(p.Y, p.X); r.YmX = fe_sub(p.Y, p.X); r.Z = p.Z; r.T2d = fe_mul(p.T, fe_const(FEC_D2));
+  r.YpX = fe_add(p.Y, p.X); r.YmX = fe_sub(p.Y, p.X); r.Z2 = fe_add(p.Z, p.Z); r.T2d = fe_mul(p.T, fe_const(FEC_D2));
   return r;
 }
 // cached form with (YpX, YmX) carried so the entry can itself be added to lazily (tables in memory)
@@ -126,8 +130,7 @@ AFX_DEV ge_p1p1 ge_add_cached(const ge_p3& p, const ge_cached& q, bool neg) {
   fe A = fe_mul_raw(fe_add(p.Y, p.X), qp);
   fe B = fe_mul_raw(fe_sub(p.Y, p.X), qm);
   fe C = fe_cneg(fe_mul(q.T2d, p.T), neg);
-  fe ZZ = fe_mul(p.Z, q.Z);
-  fe D = fe_add(ZZ, ZZ);
+  fe D = fe_mul_raw(p.Z, q.Z2);   // 2 Z1 Z2, raw: D +- C (C centred) stays within 1.5 units
   r.X = fe_sub(A, B);
   r.Y = fe_add(A, B);
   r.Z = fe_add(D, C);
@@ -140,8 +143,8 @@ AFX_DEV ge_p1p1 ge_madd(const ge_p3& p, const ge_niels& q, bool neg) {
   fe_cswap(qp, qm, neg);
   fe A = fe_mul_raw(fe_add(p.Y, p.X), qp);   // raw: see ge_add_cached
   fe B = fe_mul_raw(fe_sub(p.Y, p.X), qm);
-  fe C = fe_cneg(fe_mul(q.xy2d, p.T), neg);
-  fe D = fe_add(p.Z, p.Z);
+  fe C = fe_cneg(fe_mul(q.xyd, p.T), neg);
+  const fe& D = p.Z;   // entries are halved: no doubling of Z
   r.X = fe_sub(A, B);
   r.Y = fe_add(A, B);
   r.Z = fe_add(D, C);

@@ -76,7 +76,7 @@ AFX_DEV void cached_store(int32_t* p, const ge_cached& q) {
   uint32_t w[32];
   fe_tobytes(w, q.YpX);
   fe_tobytes(w + 8, q.YmX);
-  fe_tobytes(w + 16, q.Z);
+  fe_tobytes(w + 16, q.Z2);
   fe_tobytes(w + 24, q.T2d);
   uint4* d = reinterpret_cast<uint4*>(p);
 #pragma unroll
@@ -93,7 +93,7 @@ AFX_DEV ge_cached cached_load(const int32_t* p) {
   ge_cached q;
   q.YpX = fe_frombytes(w);
   q.YmX = fe_frombytes(w + 8);
-  q.Z = fe_frombytes(w + 16);
+  q.Z2 = fe_frombytes(w + 16);
   q.T2d = fe_frombytes(w + 24);
   return q;
 }
@@ -120,7 +120,7 @@ __global__ void k_setup_generators(const uint8_t* __restrict__ enc, uint32_t nge
 }
 
 // Positional tables: for generator g and window position j, the entries d * 2^(AFX_POS_BITS*j) * G_g for
-// d = 0 .. 2^(AFX_POS_BITS-1) as affine niels (y+x, y-x, 2dxy).  Two kernels: the window bases B_{g,j} = 2^(BITS*j) G_g
+// d = 0 .. 2^(AFX_POS_BITS-1) as halved affine niels ((y+x)/2, (y-x)/2, dxy; ge.cuh).  Two kernels: the window bases B_{g,j} = 2^(BITS*j) G_g
 // (thread per (g, j)), then thread (g, j, c) writes the 16 entries 16c .. 16c+15 with ONE field inversion
 // (Montgomery's trick over the 16 Z coordinates).
 __global__ void k_setup_posbase(const int32_t* __restrict__ ext, uint32_t ngen, int32_t* __restrict__ base) {
@@ -165,16 +165,14 @@ __global__ void k_setup_postables(const int32_t* __restrict__ base, uint32_t nge
   }
   // pass 2, backwards: inv = 1 / (Z_0 ... Z_k), so 1/Z_k = inv * (Z_0 ... Z_{k-1}); then inv *= Z_k
   fe inv = fe_invert(prod);
-  const fe d2 = fe_const(FEC_D2);
 #pragma unroll 1
   for (int k = (int)n - 1; k >= 0; k--) {
     const fe zinv = fe_mul(inv, pre[k]);
     inv = fe_mul(inv, Z[k]);
-    const fe x = fe_mul(X[k], zinv), y = fe_mul(Y[k], zinv);
-    const fe ypx = fe_carry(fe_add(y, x)), ymx = fe_carry(fe_sub(y, x)), xy2d = fe_mul(fe_mul(x, y), d2);
+    const ge_niels q = ge_niels_from_affine(fe_mul(X[k], zinv), fe_mul(Y[k], zinv));
     int32_t* e = tab + (size_t)(first + k) * AFX_NIELS_DWORDS;
 #pragma unroll
-    for (int l = 0; l < 10; l++) { e[l] = ypx.v[l]; e[10 + l] = ymx.v[l]; e[20 + l] = xy2d.v[l]; }
+    for (int l = 0; l < 10; l++) { e[l] = q.ypx.v[l]; e[10 + l] = q.ymx.v[l]; e[20 + l] = q.xyd.v[l]; }
   }
 }
 
@@ -292,7 +290,7 @@ AFX_DEV ge_p3 msm_add_positional(const msm_env& e, const int32_t* __restrict__ p
   for (int l = 0; l < 15; l++) { const int2 x = p[l]; v[2 * l] = x.x; v[2 * l + 1] = x.y; }
   ge_niels q;
 #pragma unroll
-  for (int l = 0; l < 10; l++) { q.ypx.v[l] = v[l]; q.ymx.v[l] = v[10 + l]; q.xy2d.v[l] = v[20 + l]; }
+  for (int l = 0; l < 10; l++) { q.ypx.v[l] = v[l]; q.ymx.v[l] = v[10 + l]; q.xyd.v[l] = v[20 + l]; }
   return ge_p1p1_to_p3_next(ge_madd(acc, q, neg), next);
 }
 
@@ -355,7 +353,7 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
     for (uint32_t j = 0; j < AFX_POS_WINDOWS; j++) {
 #pragma unroll 1
       for (uint32_t t = 0; t < nt; t++)
-        acc = msm_add_positional(env, pos_tables, acc, t, j, (j + 1 == AFX_POS_WINDOWS && t + 1 == nt) ? GE_FOR_ANY : GE_FOR_MADD);
+        acc = msm_add_positional(env, pos_tables, acc, t, j, (j + 1 == AFX_POS_WINDOWS && t + 1 == nt) ? GE_FOR_ANY : GE_FOR_ADD);
     }
   } else if (nu != 0) {
     // some scalars are batch constants: bit-serial chain, their width-5 NAF digits (the same for every lane, so the
@@ -407,7 +405,7 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
     for (uint32_t j = 0; j < AFX_POS_WINDOWS; j++) {
 #pragma unroll 1
       for (uint32_t t = nv; t < nt; t++)
-        acc = msm_add_positional(env, pos_tables, acc, t, j, (j + 1 == AFX_POS_WINDOWS && t + 1 == nt) ? GE_FOR_ANY : GE_FOR_MADD);
+        acc = msm_add_positional(env, pos_tables, acc, t, j, (j + 1 == AFX_POS_WINDOWS && t + 1 == nt) ? GE_FOR_ANY : GE_FOR_ADD);
     }
   }
   if (job->addend) {

@@ -56,7 +56,7 @@ int arith_msm_chain(uint8_t out[32], uint32_t nv, const uint8_t* s, const uint8_
       uint32_t b[8];
       fe_tobytes(b, tab[t][k].YpX); tab[t][k].YpX = fe_frombytes(b);
       fe_tobytes(b, tab[t][k].YmX); tab[t][k].YmX = fe_frombytes(b);
-      fe_tobytes(b, tab[t][k].Z); tab[t][k].Z = fe_frombytes(b);
+      fe_tobytes(b, tab[t][k].Z2); tab[t][k].Z2 = fe_frombytes(b);
       fe_tobytes(b, tab[t][k].T2d); tab[t][k].T2d = fe_frombytes(b);
     }
     sc_bias(digits[t], sc_from(s + 32 * t), 0x88888888u);
@@ -81,15 +81,12 @@ int arith_msm_chain(uint8_t out[32], uint32_t nv, const uint8_t* s, const uint8_
     load8(w, q + 32 * u);
     ge_p3 B;
     if (!ristretto_decode(B, w)) return 0;
-    const fe d2 = fe_const(FEC_D2);
     for (int bit = 0; bit < 253; bit++) {
       if ((f[32 * u + (bit >> 3)] >> (bit & 7)) & 1) {
         const fe zinv = fe_invert(B.Z);
-        const fe x = fe_mul(B.X, zinv), y = fe_mul(B.Y, zinv);
-        ge_niels nq;
-        nq.ypx = fe_carry(fe_add(y, x)); nq.ymx = fe_carry(fe_sub(y, x)); nq.xy2d = fe_mul(fe_mul(x, y), d2);
+        const ge_niels nq = ge_niels_from_affine(fe_mul(B.X, zinv), fe_mul(B.Y, zinv));
         const bool last = u + 1 == nf && bit == 252;
-        acc = ge_p1p1_to_p3_next(ge_madd(acc, nq, (bit & 1) != 0 ? false : false), last ? GE_FOR_ANY : GE_FOR_MADD);
+        acc = ge_p1p1_to_p3_next(ge_madd(acc, nq, false), last ? GE_FOR_ANY : GE_FOR_ADD);
       }
       B = ge_double(B);
     }
