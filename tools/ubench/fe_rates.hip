@@ -1,5 +1,5 @@
 // Field-multiplication throughput on gfx950 at the occupancy k_msm runs at (256 threads x 2 blocks per CU).
-// Build twice:  hipcc -O3 --offload-arch=gfx950 [-DAFX_FE_SEQ] fe_rates.hip -o fe_rates[_seq]
+// Build:  hipcc -O3 --offload-arch=gfx950 fe_rates.hip -o build/fe_rates
 #include "../../aeonflux_amd/csrc/fe.cuh"
 #include <cstdio>
 #include <vector>
@@ -15,6 +15,8 @@ __global__ void __launch_bounds__(256, 2) k_fe(int32_t* p) {
   for (int it = 0; it < ITERS; ++it) {
     if constexpr (MODE == 0) { a = fe_mul(a, b); }
     else if constexpr (MODE == 1) { a = fe_sq(a); }
+    else if constexpr (MODE == 3) { a = fe_mul_raw(a, b); }
+    else if constexpr (MODE == 4) { a = fe_sq_raw(a); }
     else {  // the shape of a doubling: 4 squarings, sums, 3 products
       fe xx = fe_sq(a), yy = fe_sq(b), s = fe_sq(fe_add(a, b)), zz = fe_sq(fe_sub(a, b));
       fe h = fe_add(yy, xx), g = fe_sub(yy, xx), e = fe_sub(s, h), f = fe_sub(fe_add(zz, zz), g);
@@ -49,13 +51,11 @@ int main() {
   std::vector<int32_t> h(10 * 512 * 256);
   for (size_t i = 0; i < h.size(); i++) h[i] = (int32_t)(i * 2654435761u >> 4);
   hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-#ifdef AFX_FE_SEQ
-  printf("sequential-carry fe_mul/fe_sq, %d CUs\n", ncu);
-#else
-  printf("interleaved-carry fe_mul/fe_sq, %d CUs\n", ncu);
-#endif
+  printf("fe_mul / fe_sq (centred) and their raw variants, %d CUs\n", ncu);
   run<0>(d, "mul", 1, ncu);
   run<1>(d, "sq", 1, ncu);
+  run<3>(d, "mul raw", 1, ncu);
+  run<4>(d, "sq raw", 1, ncu);
   run<2>(d, "dbl-mix", 6, ncu);
   return 0;
 }
