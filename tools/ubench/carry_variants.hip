@@ -2,6 +2,7 @@
 //   0 raw (floor carry, masked limb)            1 shipped centred form (2^50 into the high dword, limb - 2^(b-1))
 //   2 floor carry, limb - 2^(b-1) only          3 2^50 into the high dword only (limb masked)
 //   4 rounding constant added by a mad (H = 1 * R + H), limb - 2^(b-1)
+//   5 floor carries on the serial path, limbs centred afterwards with 32-bit operations off that path
 // Results are not all meaningful field products; only the instruction mix matters.
 // Build: hipcc -O3 --offload-arch=gfx950 carry_variants.hip -o build/carry_variants
 #include "../../aeonflux_amd/csrc/fe.cuh"
@@ -38,6 +39,17 @@ AFX_DEV fe mul_v(const fe& f, const fe& g) {
   int64_t H0 = (int64_t)u0 + c * 19;
   r.v[0] = (int32_t)((uint32_t)H0 & 0x3ffffffu);
   r.v[1] += (int32_t)(H0 >> 26);
+  if (V == 5) {
+    // post-hoc centring: t_k = top bit of limb k; limb k -= t_k << b_k; limb k+1 += t_k (limb 0 += 19 t_9)
+    int32_t t[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) { const int bits = (k & 1) ? 25 : 26; t[k] = (int32_t)((uint32_t)r.v[k] >> (bits - 1)) & 1; }
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      const int bits = (k & 1) ? 25 : 26;
+      r.v[k] = r.v[k] - (t[k] << bits) + (k == 0 ? 19 * t[9] : t[k - 1]);
+    }
+  }
   return r;
 }
 template <int V>
@@ -67,5 +79,6 @@ int main() {
   run<2>(d, "2 floor carry, limb - 2^(b-1)", pr.multiProcessorCount);
   run<3>(d, "3 +2^50 on the high dword, masked limb", pr.multiProcessorCount);
   run<4>(d, "4 rounding constant through a mad, limb - 2^(b-1)", pr.multiProcessorCount);
+  run<5>(d, "5 floor carries, limbs centred afterwards (32-bit, off the serial path)", pr.multiProcessorCount);
   return 0;
 }
