@@ -117,7 +117,8 @@ extern "C" void afx_bounds_violation(const char* what);
 static inline void afx_check_products(const int32_t* f, const int32_t* g, bool square) {
   for (int i = 0; i < 10; i++) {
     const int64_t ag = g[i] < 0 ? -(int64_t)g[i] : g[i], af = f[i] < 0 ? -(int64_t)f[i] : f[i];
-    if (ag * (square && (i & 1) ? 38 : 19) >= (1LL << 31)) afx_bounds_violation("19x/38x premultiplication overflows int32");
+    // limb 0 is never a wrapped term's second factor: its 19-fold is computed but not consumed
+    if (i != 0 && ag * (square && (i & 1) ? 38 : 19) >= (1LL << 31)) afx_bounds_violation("19x/38x premultiplication overflows int32");
     if (af * 2 >= (1LL << 31)) afx_bounds_violation("2x premultiplication overflows int32");
   }
   for (int k = 0; k < 10; k++) {
@@ -148,7 +149,8 @@ extern thread_local uint64_t afx_n_mul, afx_n_sq;
 // limb's rounding constant already in it (2^50 added to the high dword before the shift), which makes every limb
 // come out centred: r_k = (H_k mod 2^b) - 2^(b-1), |r_k| <= 2^(b-1).  Not CENTRED ("raw"): floor carries, limbs in
 // [0, 2^b): 18 fewer additions, for results whose consumer is known to tolerate twice the magnitude (below).
-template <bool CENTRED>
+// CMASK: bit k set = limb k comes out centred (its rounding constant travels in the carry of column k-1), clear = raw.
+template <uint32_t CMASK>
 AFX_DEV fe fe_mul_impl(const fe& f, const fe& g) {
   AFX_COUNT(afx_n_mul);
   AFX_CHECK_MUL(f, g);
@@ -159,7 +161,7 @@ AFX_DEV fe fe_mul_impl(const fe& f, const fe& g) {
     f2[i] = (int32_t)(2u * (uint32_t)f.v[i]);
   }
   fe r;
-  int64_t c = CENTRED ? (1LL << 25) : 0;  // rounding constant of limb 0; later carries arrive with the next limb's folded in
+  int64_t c = (CMASK & 1u) ? (1LL << 25) : 0;  // rounding constant of limb 0; later carries arrive with the next limb's folded in
   uint32_t u0 = 0;
 #pragma unroll
   for (int k = 0; k < 10; k++) {
@@ -175,24 +177,31 @@ AFX_DEV fe fe_mul_impl(const fe& f, const fe& g) {
     }
     const int bits = (k & 1) ? 25 : 26;
     const uint32_t lo = (uint32_t)H & ((1u << bits) - 1);
-    if (k == 0) u0 = lo; else r.v[k] = CENTRED ? (int32_t)lo - (1 << (bits - 1)) : (int32_t)lo;
-    c = (CENTRED && k < 9) ? ((H + (1LL << 50)) >> bits) : (H >> bits);
+    if (k == 0) u0 = lo; else r.v[k] = ((CMASK >> k) & 1u) ? (int32_t)lo - (1 << (bits - 1)) : (int32_t)lo;
+    c = (k < 9 && ((CMASK >> (k + 1)) & 1u)) ? ((H + (1LL << 50)) >> bits) : (H >> bits);
   }
-  // wrap: limb 0 gets 19 * carry(limb 9); u0 still holds limb 0 (with its rounding constant when CENTRED)
+  // wrap: limb 0 gets 19 * carry(limb 9); u0 still holds limb 0 (with its rounding constant when centred)
   int64_t H0 = (int64_t)u0 + c * 19;
   const int32_t c0 = (int32_t)(H0 >> 26);
-  r.v[0] = CENTRED ? (int32_t)((uint32_t)H0 & 0x3ffffffu) - (1 << 25) : (int32_t)((uint32_t)H0 & 0x3ffffffu);
+  r.v[0] = (CMASK & 1u) ? (int32_t)((uint32_t)H0 & 0x3ffffffu) - (1 << 25) : (int32_t)((uint32_t)H0 & 0x3ffffffu);
   r.v[1] += c0;
   return r;
 }
-AFX_DEV fe fe_mul(const fe& f, const fe& g) { return fe_mul_impl<true>(f, g); }
+#define AFX_CENTRE_ALL 0x3ffu
+#define AFX_CENTRE_EVEN 0x154u   /* limbs 2, 4, 6, 8 */
+AFX_DEV fe fe_mul(const fe& f, const fe& g) { return fe_mul_impl<AFX_CENTRE_ALL>(f, g); }
 // Raw result: limbs in [0, 2^26) / [0, 2^25) ("1 unit" where a centred result is 1/2 unit).  Valid as either operand
 // of a multiplication or as the input of a squaring; sums of two raw values (2 units) only as a FIRST operand; a
 // difference of two raw values (+-1 unit) anywhere.  ge.cuh documents, at each use, why the consumer qualifies.
-AFX_DEV fe fe_mul_raw(const fe& f, const fe& g) { return fe_mul_impl<false>(f, g); }
+AFX_DEV fe fe_mul_raw(const fe& f, const fe& g) { return fe_mul_impl<0u>(f, g); }
+// Only the limbs whose 19-fold must fit int32 when the value is a SECOND operand - the even limbs 2, 4, 6, 8 (limb 0 is
+// never premultiplied, odd limbs have a bit to spare) - come out centred.  For values that are combined with one or
+// two others of their kind and then used as a second operand, never squared: X3 = AA - (YY + XX) and Z3 = YY - XX of
+// the doubling, Z3 = D + C of the additions.
+AFX_DEV fe fe_mul_even(const fe& f, const fe& g) { return fe_mul_impl<AFX_CENTRE_EVEN>(f, g); }
 
 // The same two flavours for the squaring (raw: the squaring chains of the inversions, and Z^2 of the doubling).
-template <bool CENTRED>
+template <uint32_t CMASK>
 AFX_DEV fe fe_sq_impl(const fe& f) {
   AFX_COUNT(afx_n_sq);
   AFX_CHECK_SQ(f);
@@ -204,7 +213,7 @@ AFX_DEV fe fe_sq_impl(const fe& f) {
     f38[i] = (int32_t)(38u * (uint32_t)f.v[i]);
   }
   fe r;
-  int64_t c = CENTRED ? (1LL << 25) : 0;
+  int64_t c = (CMASK & 1u) ? (1LL << 25) : 0;
   uint32_t u0 = 0;
 #pragma unroll
   for (int k = 0; k < 10; k++) {
@@ -222,17 +231,18 @@ AFX_DEV fe fe_sq_impl(const fe& f) {
     }
     const int bits = (k & 1) ? 25 : 26;
     const uint32_t lo = (uint32_t)H & ((1u << bits) - 1);
-    if (k == 0) u0 = lo; else r.v[k] = CENTRED ? (int32_t)lo - (1 << (bits - 1)) : (int32_t)lo;
-    c = (CENTRED && k < 9) ? ((H + (1LL << 50)) >> bits) : (H >> bits);
+    if (k == 0) u0 = lo; else r.v[k] = ((CMASK >> k) & 1u) ? (int32_t)lo - (1 << (bits - 1)) : (int32_t)lo;
+    c = (k < 9 && ((CMASK >> (k + 1)) & 1u)) ? ((H + (1LL << 50)) >> bits) : (H >> bits);
   }
   int64_t H0 = (int64_t)u0 + c * 19;
   const int32_t c0 = (int32_t)(H0 >> 26);
-  r.v[0] = CENTRED ? (int32_t)((uint32_t)H0 & 0x3ffffffu) - (1 << 25) : (int32_t)((uint32_t)H0 & 0x3ffffffu);
+  r.v[0] = (CMASK & 1u) ? (int32_t)((uint32_t)H0 & 0x3ffffffu) - (1 << 25) : (int32_t)((uint32_t)H0 & 0x3ffffffu);
   r.v[1] += c0;
   return r;
 }
-AFX_DEV fe fe_sq(const fe& f) { return fe_sq_impl<true>(f); }
-AFX_DEV fe fe_sq_raw(const fe& f) { return fe_sq_impl<false>(f); }
+AFX_DEV fe fe_sq(const fe& f) { return fe_sq_impl<AFX_CENTRE_ALL>(f); }
+AFX_DEV fe fe_sq_raw(const fe& f) { return fe_sq_impl<0u>(f); }
+AFX_DEV fe fe_sq_even(const fe& f) { return fe_sq_impl<AFX_CENTRE_EVEN>(f); }
 
 // f^(2^n), n >= 1, rolled loop (keeps the inversion chains small in code size); every consumer multiplies the result
 AFX_DEV fe fe_sqn(fe f, int n) {

@@ -111,10 +111,12 @@ AFX_DEV ge_cached ge_p3_to_cached_reduced(const ge_p3& p) {
 AFX_DEV ge_p1p1 ge_p2_dbl(const ge_p2& p) {
   ge_p1p1 r;
   // Z^2 uncentred: it only reaches T = 2ZZ - (YY - XX), which is fe_mul's wide first operand in both conversions
-  fe XX = fe_sq(p.X), YY = fe_sq(p.Y), ZZ = fe_sq_raw(p.Z);
+  // XX, YY, (X+Y)^2 centred on the even limbs only: they reach X3 = AA - (YY + XX) and Z3 = YY - XX, second operands
+  // that are never squared (fe.cuh, fe_mul_even)
+  fe XX = fe_sq_even(p.X), YY = fe_sq_even(p.Y), ZZ = fe_sq_raw(p.Z);
   fe B = fe_add(ZZ, ZZ);
   fe A = fe_add(p.X, p.Y);
-  fe AA = fe_sq(A);
+  fe AA = fe_sq_even(A);
   r.Y = fe_add(YY, XX);
   r.Z = fe_sub(YY, XX);
   r.X = fe_sub(AA, r.Y);
@@ -129,8 +131,8 @@ AFX_DEV ge_p1p1 ge_add_cached(const ge_p3& p, const ge_cached& q, bool neg) {
   // A, B raw: they only meet in X3 = A - B (+-1 unit, a second operand) and Y3 = A + B (2 units, a first operand)
   fe A = fe_mul_raw(fe_add(p.Y, p.X), qp);
   fe B = fe_mul_raw(fe_sub(p.Y, p.X), qm);
-  fe C = fe_cneg(fe_mul(q.T2d, p.T), neg);
-  fe D = fe_mul_raw(p.Z, q.Z2);   // 2 Z1 Z2, raw: D +- C (C centred) stays within 1.5 units
+  fe C = fe_cneg(fe_mul_even(q.T2d, p.T), neg);
+  fe D = fe_mul_raw(p.Z, q.Z2);   // 2 Z1 Z2, raw: D +- C (C centred where it matters) stays within 1.5 / 2 units
   r.X = fe_sub(A, B);
   r.Y = fe_add(A, B);
   r.Z = fe_add(D, C);
@@ -143,7 +145,7 @@ AFX_DEV ge_p1p1 ge_madd(const ge_p3& p, const ge_niels& q, bool neg) {
   fe_cswap(qp, qm, neg);
   fe A = fe_mul_raw(fe_add(p.Y, p.X), qp);   // raw: see ge_add_cached
   fe B = fe_mul_raw(fe_sub(p.Y, p.X), qm);
-  fe C = fe_cneg(fe_mul(q.xyd, p.T), neg);
+  fe C = fe_cneg(fe_mul_even(q.xyd, p.T), neg);
   const fe& D = p.Z;   // entries are halved: no doubling of Z
   r.X = fe_sub(A, B);
   r.Y = fe_add(A, B);
