@@ -210,7 +210,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   std::vector<std::vector<uint8_t>> nafc_of(jobs.size());
   for (size_t ji = 0; ji < jobs.size(); ji++) {
     afx_msm_job& j = jobs[ji];
-    j.n_uni = 0; j.top_bit = 0; j.naf = nullptr; j.naf_count = nullptr;
+    j.n_uni = 0; j.top_bit = 0; j.naf_sched = nullptr;
     std::vector<afx_msm_term> uni, lane;
     std::vector<const uint8_t*> hs;
     for (uint32_t t = 0; t < j.n_var; t++) {
@@ -308,9 +308,17 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     j.digit_slot = dslot; dslot += j.n_terms;
     j.table_slot = tslot; tslot += j.n_var;
     if (j.n_uni) {
-      j.naf = put(naf_of[order[k]].data(), naf_of[order[k]].size());
-      j.naf_count = put(nafc_of[order[k]].data(), nafc_of[order[k]].size());
-      secure_zero(naf_of[order[k]].data(), naf_of[order[k]].size());   // digits of the issuer key
+      std::vector<uint32_t> sched;
+      const std::vector<int8_t>& nd = naf_of[order[k]];
+      for (int b = j.top_bit; b >= 0; b--)
+        for (uint32_t u = 0; u < j.n_uni; u++) {
+          const int d = nd[256 * u + b];
+          if (d) sched.push_back(((uint32_t)b << 16) | (u << 8) | (d < 0 ? 0x80u : 0u) | (uint32_t)(((d < 0 ? -d : d) - 1) >> 1));
+        }
+      sched.push_back(0xffffffffu);
+      j.naf_sched = put(sched.data(), sched.size());
+      secure_zero(sched.data(), 4 * sched.size());                     // digits of the issuer key
+      secure_zero(naf_of[order[k]].data(), naf_of[order[k]].size());
       secure_zero(nafc_of[order[k]].data(), nafc_of[order[k]].size());
     }
     out[k] = j;

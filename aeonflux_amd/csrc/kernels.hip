@@ -358,31 +358,29 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
   } else if (nu != 0) {
     // some scalars are batch constants: bit-serial chain, their width-5 NAF digits (the same for every lane, so the
     // branches are uniform) add odd multiples at ~1/6 of the bit positions; per-item terms keep their windows
-    const int8_t* naf = job->naf;
-    const uint8_t* nafc = job->naf_count;
+    const uint32_t* sched = job->naf_sched;   // uniform: scalar loads
     const int top = job->top_bit;
+    const uint32_t nvl = nv - nu;
+    uint32_t ei = 0, ev = sched[0];
 #pragma unroll 1
     for (int bit = top; bit >= 0; bit--) {
-      const uint32_t nuni = nafc[bit];
-      const uint32_t nadd = nuni + ((bit & 3) == 0 ? nv - nu : 0u);
+      const bool lane_adds = (bit & 3) == 0 && nvl != 0;
+      const bool any_adds = lane_adds || (ev >> 16) == (uint32_t)bit;
       // what follows the last step at this bit position: the next doubling, or (bit 0) whatever comes after the chain
       const int after = bit == 0 ? GE_FOR_ANY : GE_FOR_DBL;
-      if (bit != top) acc = ge_p1p1_to_p3_next(ge_p2_dbl(ge_p3_to_p2(acc)), nadd != 0 ? GE_FOR_ADD : after);
-      uint32_t done = 0;
-      if (nuni != 0) {
+      if (bit != top) acc = ge_p1p1_to_p3_next(ge_p2_dbl(ge_p3_to_p2(acc)), any_adds ? GE_FOR_ADD : after);
 #pragma unroll 1
-        for (uint32_t t = 0; t < nu; t++) {
-          const int d = naf[t * 256 + bit];
-          if (d == 0) continue;
-          const uint32_t idx = (uint32_t)((d < 0 ? -d : d) - 1) >> 1;
-          const int32_t* tab = table_ws + ((size_t)(tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
-          done++;
-          acc = ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), d < 0), done != nadd ? GE_FOR_ADD : after);
-        }
+      while ((ev >> 16) == (uint32_t)bit) {
+        const uint32_t t = (ev >> 8) & 0xffu, idx = ev & 7u;
+        const bool neg = (ev & 0x80u) != 0;
+        ev = sched[++ei];
+        const bool last = !lane_adds && (ev >> 16) != (uint32_t)bit;
+        const int32_t* tab = table_ws + ((size_t)(tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
+        acc = ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), neg), last ? after : GE_FOR_ADD);
       }
-      if ((bit & 3) == 0) {
+      if (lane_adds) {
 #pragma unroll 1
-        for (uint32_t t = nu; t < nv; t++) { done++; acc = msm_add_var(env, acc, t, bit >> 2, done != nadd ? GE_FOR_ADD : after); }
+        for (uint32_t t = nu; t < nv; t++) acc = msm_add_var(env, acc, t, bit >> 2, t + 1 != nv ? GE_FOR_ADD : after);
       }
     }
   } else {

@@ -84,8 +84,9 @@ typedef struct {
   uint32_t n_uni;                       /* the first n_uni variable terms have a batch-constant scalar known to the host:
                                            width-5 NAF digits, identical schedule for every lane (Assembler::msm sets these four) */
   int32_t top_bit;                      /* n_uni != 0: highest bit position at which anything is added            */
-  const int8_t* naf;                    /* [n_uni][256] digits in {0, +-1, +-3, ..., +-15}, sign of `negate` folded in */
-  const uint8_t* naf_count;             /* [256] number of nonzero NAF digits per bit position                   */
+  const uint32_t* naf_sched;            /* the nonzero NAF digits as a list of additions, highest bit position first:
+                                           (bit << 16) | (term << 8) | (negative << 7) | table index 0..7 (digit = +-(2 idx + 1),
+                                           sign of `negate` folded in); terminated by 0xffffffff.  Uniform => scalar loads */
   afx_msm_term term[AFX_MSM_MAX_TERMS];
   const int32_t* addend;                /* optional variable point added at the end               */
   uint32_t addend_negate;

@@ -46,9 +46,8 @@ hipError_t afxk_setup_postables(hipStream_t, const int32_t*, uint32_t, int32_t*,
 hipError_t afxk_msm(hipStream_t, const afx_msm_job* j, uint32_t n, const int32_t*, int32_t*, uint32_t*, uint32_t*, uint32_t) {
   for (uint32_t i = 0; i < n; i++) {
     for (uint32_t t = 0; t < j[i].n_terms; t++) sink += (uintptr_t)j[i].term[t].scalar;
-    if (j[i].n_uni) {   // the NAF arrays live in the plan blob: read them end to end
-      for (uint32_t b = 0; b < 256 * j[i].n_uni; b++) sink += (uintptr_t)j[i].naf[b];
-      for (uint32_t b = 0; b < 256; b++) sink += j[i].naf_count[b];
+    if (j[i].n_uni) {   // the NAF schedule lives in the plan blob: read it to its terminator
+      for (const uint32_t* e = j[i].naf_sched; ; e++) { sink += *e; if (*e == 0xffffffffu) break; }
     }
   }
   return hipSuccess;
