@@ -198,3 +198,32 @@ def test_recomputed_challenges_equal_the_oracles():
             proof_challenge = bytes(pres[i].challenge) if r == 0 else bytes(pres[i].enc[r - 1].challenge)
             failing_reached += want[r][i] != proof_challenge
     assert reached > (1 + ne) * n_items * 0.8 and failing_reached >= 10
+
+
+def test_concurrent_calls_from_threads():
+    """two contexts used from two host threads at once, and two threads sharing one context (calls serialise on the
+    context's mutex): every call returns the single-threaded answer"""
+    import threading
+    import aeonflux_amd as afx
+    params, key, ip, issuer, pres = make_batch(4, "SSPE", [0, 3], 48, b"gpu-threads")
+    corrupt(pres, b"threads-corrupt")
+    want = [issuer.verify_presentation(p) for p in pres]
+    a, b = afx.Context(params, key, ip), afx.Context(params, key, ip)
+    results, errors = {}, []
+
+    def work(name, ctx, rounds):
+        try:
+            for r in range(rounds):
+                results[(name, r)] = gpu_verify(afx, ctx, pres)
+        except Exception as e:   # noqa: BLE001 - reported below
+            errors.append((name, repr(e)))
+    threads = [threading.Thread(target=work, args=("a1", a, 4)), threading.Thread(target=work, args=("b1", b, 4)),
+               threading.Thread(target=work, args=("a2", a, 4))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    a.close()
+    b.close()
+    assert not errors, errors
+    assert len(results) == 12 and all(v == want for v in results.values())
