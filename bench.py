@@ -68,6 +68,16 @@ def usable_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def load_fixture(name):
     with open(os.path.join(ROOT, "tests", "golden", "flows.json")) as f:
         flows = json.load(f)["flows"]
@@ -207,7 +217,7 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
         for i in range(S):
             vals = [bytes(hin["values"][k, i]) + bytes(64) for k in range(n)]
             octx.issue(kinds, vals, bytes(hin["t_wide"][i]), bytes(hin["U_wide"][i]), bytes(hin["seed"][i]))
-        cpu = {"value": S / (time.perf_counter() - t0), "unit": "credentials/s", "cores": 1, "kind": "port",
+        cpu = {"value": S / (time.perf_counter() - t0), "unit": "credentials/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
                "sample": "first %d issuances of the same batch through the oracle (one thread, called from python)" % S}
     if rank == 0:
         ab = 32 * n + n + 160 + 96 + 32 * (n + 6)
@@ -498,7 +508,7 @@ def main():
         olib.afxo_verify_presentations_soa(octx, C.byref(oshape), C.byref(osoa1), S1, ost1.ctypes.data, 1)
         cpu1_s = time.perf_counter() - t0
         assert np.array_equal(ost1, got[:S1])
-        cpu = {"value": S / cpu_s, "unit": "presentations/s", "cores": threads, "kind": "port",
+        cpu = {"value": S / cpu_s, "unit": "presentations/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
                "sample": "first %d presentations of the same batch, oracle/ restated CPU path (gcc -O3 -march=native, 5x51 limbs, "
                          "NAF-5 Straus), %d threads; statuses equal to the GPU's" % (S, threads),
                "single_thread_value": S1 / cpu1_s}
