@@ -5,6 +5,25 @@ import sqlite3
 import sys
 
 
+def last_dispatches(path, kernel, n):
+    """per counter: sum over the last n dispatches of `kernel` (e.g. the timed launches of a bench run)"""
+    db = sqlite3.connect(path)
+    tables = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
+    kd = next(t for t in tables if "kernel_dispatch" in t)
+    ks = next(t for t in tables if "kernel_symbol" in t)
+    pe = next(t for t in tables if "rocpd_pmc_event" in t)
+    pi = next(t for t in tables if "rocpd_info_pmc" in t)
+    icols = [r[1] for r in db.execute(f"pragma table_info('{pi}')")]
+    namecol = "symbol" if "symbol" in icols else "name"
+    ids = [r[0] for r in db.execute(f"""select d.dispatch_id from {kd} d join {ks} s on d.kernel_id = s.id
+                                        where s.display_name like '{kernel}%' order by d.dispatch_id""")][-n:]
+    q = f"""select i.{namecol}, sum(p.value) from {pe} p join {pi} i on p.pmc_id = i.id join {kd} d on p.event_id = d.event_id
+            where d.dispatch_id in ({",".join(str(i) for i in ids)}) group by i.{namecol}"""
+    print("# %s: sums over the last %d dispatches of %s" % (path, len(ids), kernel))
+    for name, v in db.execute(q):
+        print("%-24s %18.0f   per dispatch %16.0f" % (name, v, v / max(1, len(ids))))
+
+
 def main(path, flt=None):
     db = sqlite3.connect(path)
     tables = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
@@ -27,5 +46,7 @@ def main(path, flt=None):
         print("%-28s %-24s %7d %18.0f %18.1f %10.4f" % (name[:28], r[1], r[2], r[3], r[4], r[5] / 1e6))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 5 and sys.argv[2] == "--last":
+    last_dispatches(sys.argv[1], sys.argv[4], int(sys.argv[3]))
+elif __name__ == "__main__":
     main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
