@@ -59,8 +59,7 @@ AFX_DEV ge_p3 ge_p1p1_to_p3(const ge_p1p1& p) {
 }
 // Conversions inside a doubling/addition chain, where the consumer of every coordinate is known (units: a centred
 // product is 1/2, a raw one 1; fe_mul takes <= 4 as first and <= 1.65 as second operand, fe_sq <= 1.65):
-//   GE_FOR_DBL   before a doubling (ge_p2_dbl): Y centred, X and Z raw - (X+Y)^2 squares a sum within 1.5 units, X
-//                and Z are otherwise only squared; T not computed.
+//   GE_FOR_DBL   before a doubling (ge_p2_dbl): X, Y, Z raw - they are squared, and so is Y - X (1 unit); T not computed.
 //   GE_FOR_ADD   before an addition (ge_add_cached, ge_madd): X, Y, Z, T raw - Y+-X (2 units) and Z are first
 //                operands, T (1 unit) is a second operand; Z1*Z2' (cached, Z2' = 2 Z2) or Z itself (halved niels) is
 //                added to a centred product, so Z3 and T3 stay within 1.5 units.
@@ -73,7 +72,7 @@ template <int NEXT>
 AFX_DEV ge_p3 ge_p1p1_to_p3_for(const ge_p1p1& p) {
   ge_p3 r;
   if constexpr (NEXT == GE_FOR_DBL) {
-    r.X = fe_mul_raw(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul_raw(p.T, p.Z); r.T = r.X;
+    r.X = fe_mul_raw(p.T, p.X); r.Y = fe_mul_raw(p.Y, p.Z); r.Z = fe_mul_raw(p.T, p.Z); r.T = r.X;
   } else if constexpr (NEXT == GE_FOR_ADD) {
     r.X = fe_mul_raw(p.T, p.X); r.Y = fe_mul_raw(p.Y, p.Z); r.Z = fe_mul_raw(p.T, p.Z); r.T = fe_mul_raw(p.Y, p.X);
   } else {
@@ -89,7 +88,7 @@ AFX_DEV ge_p3 ge_p1p1_to_p3_next(const ge_p1p1& p, int next) {
 }
 AFX_DEV ge_p2 ge_p1p1_to_p2_before_dbl(const ge_p1p1& p) {
   ge_p2 r;
-  r.X = fe_mul_raw(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul_raw(p.T, p.Z);
+  r.X = fe_mul_raw(p.T, p.X); r.Y = fe_mul_raw(p.Y, p.Z); r.Z = fe_mul_raw(p.T, p.Z);
   return r;
 }
 AFX_DEV ge_p2 ge_p3_to_p2(const ge_p3& p) {
@@ -110,16 +109,18 @@ AFX_DEV ge_cached ge_p3_to_cached_reduced(const ge_p3& p) {
 }
 AFX_DEV ge_p1p1 ge_p2_dbl(const ge_p2& p) {
   ge_p1p1 r;
-  // Z^2 uncentred: it only reaches T = 2ZZ - (YY - XX), which is fe_mul's wide first operand in both conversions
-  // XX, YY, (X+Y)^2 centred on the even limbs only: they reach X3 = AA - (YY + XX) and Z3 = YY - XX, second operands
-  // that are never squared (fe.cuh, fe_mul_even)
+  // 2XY is taken from (Y - X)^2 = XX + YY - 2XY rather than from (X + Y)^2: the difference of two raw coordinates is
+  // within 1 unit, so X and Y may both be raw when they come here (their sum would not be a valid squaring input).
+  // Z^2 uncentred: it only reaches T = 2ZZ - (YY - XX), which is fe_mul's wide first operand in both conversions.
+  // XX, YY, (Y-X)^2 centred on the even limbs only: they reach X3 = (YY + XX) - (Y-X)^2 and Z3 = YY - XX, second
+  // operands that are never squared (fe.cuh, fe_mul_even).
   fe XX = fe_sq_even(p.X), YY = fe_sq_even(p.Y), ZZ = fe_sq_raw(p.Z);
   fe B = fe_add(ZZ, ZZ);
-  fe A = fe_add(p.X, p.Y);
+  fe A = fe_sub(p.Y, p.X);
   fe AA = fe_sq_even(A);
   r.Y = fe_add(YY, XX);
   r.Z = fe_sub(YY, XX);
-  r.X = fe_sub(AA, r.Y);
+  r.X = fe_sub(r.Y, AA);
   r.T = fe_sub(B, r.Z);
   return r;
 }
