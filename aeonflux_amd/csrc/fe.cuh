@@ -194,11 +194,6 @@ AFX_DEV fe fe_mul(const fe& f, const fe& g) { return fe_mul_impl<AFX_CENTRE_ALL>
 // of a multiplication or as the input of a squaring; sums of two raw values (2 units) only as a FIRST operand; a
 // difference of two raw values (+-1 unit) anywhere.  ge.cuh documents, at each use, why the consumer qualifies.
 AFX_DEV fe fe_mul_raw(const fe& f, const fe& g) { return fe_mul_impl<0u>(f, g); }
-// Only the limbs whose 19-fold must fit int32 when the value is a SECOND operand - the even limbs 2, 4, 6, 8 (limb 0 is
-// never premultiplied, odd limbs have a bit to spare) - come out centred.  For values that are combined with one or
-// two others of their kind and then used as a second operand, never squared: X3 = AA - (YY + XX) and Z3 = YY - XX of
-// the doubling, Z3 = D + C of the additions.
-AFX_DEV fe fe_mul_even(const fe& f, const fe& g) { return fe_mul_impl<AFX_CENTRE_EVEN>(f, g); }
 
 // The same two flavours for the squaring (raw: the squaring chains of the inversions, and Z^2 of the doubling).
 template <uint32_t CMASK>
@@ -242,6 +237,10 @@ AFX_DEV fe fe_sq_impl(const fe& f) {
 }
 AFX_DEV fe fe_sq(const fe& f) { return fe_sq_impl<AFX_CENTRE_ALL>(f); }
 AFX_DEV fe fe_sq_raw(const fe& f) { return fe_sq_impl<0u>(f); }
+// Only the limbs whose 19-fold must fit int32 when the value is a SECOND operand - the even limbs 2, 4, 6, 8 (limb 0 is
+// never premultiplied, odd limbs have a bit to spare) - come out centred.  For values that are combined with one or
+// two others of their kind and then used as a second operand, never squared: XX, YY and (Y-X)^2 of the doubling, which
+// meet in X3 = (YY + XX) - (Y-X)^2 and Z3 = YY - XX.
 AFX_DEV fe fe_sq_even(const fe& f) { return fe_sq_impl<AFX_CENTRE_EVEN>(f); }
 
 // f^(2^n), n >= 1, rolled loop (keeps the inversion chains small in code size); every consumer multiplies the result

@@ -61,8 +61,7 @@ AFX_DEV ge_p3 ge_p1p1_to_p3(const ge_p1p1& p) {
 // product is 1/2, a raw one 1; fe_mul takes <= 4 as first and <= 1.65 as second operand, fe_sq <= 1.65):
 //   GE_FOR_DBL   before a doubling (ge_p2_dbl): X, Y, Z raw - they are squared, and so is Y - X (1 unit); T not computed.
 //   GE_FOR_ADD   before an addition (ge_add_cached, ge_madd): X, Y, Z, T raw - Y+-X (2 units) and Z are first
-//                operands, T (1 unit) is a second operand; Z1*Z2' (cached, Z2' = 2 Z2) or Z itself (halved niels) is
-//                added to a centred product, so Z3 and T3 stay within 1.5 units.
+//                operands, T (1 unit) is a second operand; Z3 is formed as a difference of two raw products.
 //   GE_FOR_ANY   everything centred (stores, encodings, table building, any other consumer).
 // The completed point's own bounds hold for every producer in this file: |X| <= 1.5, |Y| <= 2, |Z| <= 1.5, |T| <= 3,
 // so X and Z are the second operands of the four products and Y, T the first.  tests/test_device_arith_on_host.py
@@ -113,7 +112,7 @@ AFX_DEV ge_p1p1 ge_p2_dbl(const ge_p2& p) {
   // within 1 unit, so X and Y may both be raw when they come here (their sum would not be a valid squaring input).
   // Z^2 uncentred: it only reaches T = 2ZZ - (YY - XX), which is fe_mul's wide first operand in both conversions.
   // XX, YY, (Y-X)^2 centred on the even limbs only: they reach X3 = (YY + XX) - (Y-X)^2 and Z3 = YY - XX, second
-  // operands that are never squared (fe.cuh, fe_mul_even).
+  // operands that are never squared (fe.cuh, fe_sq_even).
   fe XX = fe_sq_even(p.X), YY = fe_sq_even(p.Y), ZZ = fe_sq_raw(p.Z);
   fe B = fe_add(ZZ, ZZ);
   fe A = fe_sub(p.Y, p.X);
@@ -132,12 +131,14 @@ AFX_DEV ge_p1p1 ge_add_cached(const ge_p3& p, const ge_cached& q, bool neg) {
   // A, B raw: they only meet in X3 = A - B (+-1 unit, a second operand) and Y3 = A + B (2 units, a first operand)
   fe A = fe_mul_raw(fe_add(p.Y, p.X), qp);
   fe B = fe_mul_raw(fe_sub(p.Y, p.X), qm);
-  fe C = fe_cneg(fe_mul_even(q.T2d, p.T), neg);
-  fe D = fe_mul_raw(p.Z, q.Z2);   // 2 Z1 Z2, raw: D +- C (C centred where it matters) stays within 1.5 / 2 units
+  // C' = -(2dT2) T1 (the sign flipped again when subtracting), raw: Z3 = D + C = D - C' is then a difference of raw
+  // values (+-1 unit, a second operand) and T3 = D - C = D + C' a sum (2 units, a first operand)
+  fe Cn = fe_mul_raw(fe_cneg(q.T2d, !neg), p.T);
+  fe D = fe_mul_raw(p.Z, q.Z2);   // 2 Z1 Z2
   r.X = fe_sub(A, B);
   r.Y = fe_add(A, B);
-  r.Z = fe_add(D, C);
-  r.T = fe_sub(D, C);
+  r.Z = fe_sub(D, Cn);
+  r.T = fe_add(D, Cn);
   return r;
 }
 AFX_DEV ge_p1p1 ge_madd(const ge_p3& p, const ge_niels& q, bool neg) {
@@ -146,12 +147,12 @@ AFX_DEV ge_p1p1 ge_madd(const ge_p3& p, const ge_niels& q, bool neg) {
   fe_cswap(qp, qm, neg);
   fe A = fe_mul_raw(fe_add(p.Y, p.X), qp);   // raw: see ge_add_cached
   fe B = fe_mul_raw(fe_sub(p.Y, p.X), qm);
-  fe C = fe_cneg(fe_mul_even(q.xyd, p.T), neg);
+  fe Cn = fe_mul_raw(fe_cneg(q.xyd, !neg), p.T);   // -C, raw: see ge_add_cached
   const fe& D = p.Z;   // entries are halved: no doubling of Z
   r.X = fe_sub(A, B);
   r.Y = fe_add(A, B);
-  r.Z = fe_add(D, C);
-  r.T = fe_sub(D, C);
+  r.Z = fe_sub(D, Cn);
+  r.T = fe_add(D, Cn);
   return r;
 }
 AFX_DEV ge_p3 ge_add(const ge_p3& p, const ge_p3& q) { return ge_p1p1_to_p3(ge_add_cached(p, ge_p3_to_cached(q), false)); }
