@@ -89,6 +89,12 @@ extern "C" int afx_ctx_get_challenge_trace(afx_ctx* c, uint8_t* host_out) {
   AFX_HIP(hipMemcpy(host_out, c->trace, c->trace_rows * c->trace_count * 32, hipMemcpyDeviceToHost));
   return AFX_OK;
 }
+extern "C" int afx_ctx_set_chunk_items(afx_ctx* c, uint32_t items) {
+  if (!c || (items != 0 && (items < 256 || items > (1u << 22)))) { set_error("chunk size out of range"); return AFX_E_BAD_ARGS; }
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  c->chunk_items = items;
+  return AFX_OK;
+}
 extern "C" int afx_ctx_set_strict(afx_ctx* c, int enable) {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);

@@ -9,7 +9,10 @@
 
 namespace afx {
 static constexpr size_t BLOB_CAP = size_t(4) << 20;
-static constexpr uint32_t CHUNK = 1u << 17;   // items per pass: bounds the window-table workspace (~35-80 KB per item => 5-10 GB)
+// Items per pass (afx_ctx_set_chunk_items).  Bounds the workspace: window tables + points in flight are ~25 KB (issue,
+// n = 16) to ~70 KB (C3 verification) per item, so the default 2^19 needs 13-37 GB of the 288 GB.  Measured on 2^20-item
+// batches: issue 6.21 M/s at 2^17, 6.45 at 2^18, 6.76 at 2^19, 6.84 at 2^20; C3 verification 2.42 / 2.45 / 2.45 / 2.44.
+static constexpr uint32_t CHUNK_DEFAULT = 1u << 19;
 }
 using namespace afx;
 
@@ -26,6 +29,7 @@ inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build) {
   AFX_HIP(hipSetDevice(c->device));
   // all chunks of one call run on one lane; calls alternate lanes only when the caller switched pipelining on
   const int lane = (c->pipelining && !c->force_lane0) ? (int)(c->lane_next++ & 1u) : 0;
+  const uint32_t CHUNK = c->chunk_items ? c->chunk_items : CHUNK_DEFAULT;
   for (size_t off = 0; off < count; off += CHUNK) {
     const uint32_t cc = (uint32_t)std::min<size_t>(CHUNK, count - off);
     try {

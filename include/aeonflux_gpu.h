@@ -143,6 +143,11 @@ int afx_ctx_synchronize(afx_ctx* ctx);
  * part of this mode: no such statement exists in the reference to restate. */
 int afx_ctx_set_strict(afx_ctx* ctx, int enable);
 
+/* Items per internal pass (tuning; 0 restores the default of 2^19).  A batch larger than this is processed in passes
+ * of this many items, which bounds the device workspace (about 25-70 KB per item and pass, depending on the
+ * statement); smaller values trade throughput for memory.  Accepted range 256 .. 2^22. */
+int afx_ctx_set_chunk_items(afx_ctx* ctx, uint32_t items);
+
 /* Challenge trace (parity aid; off by default).  set(rows, count) allocates a device array [rows][count][32]; while it
  * exists, every verification call (presentations, proofs of encryption, issuances) of at most `count` items also
  * stores the challenge it RECOMPUTES for item i of proof r in cell (r, i): r = 0 for the main proof (or the only

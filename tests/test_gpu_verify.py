@@ -102,8 +102,9 @@ def test_encryption_proofs_alone():
 
 
 def test_empty_and_chunk_boundary_batches():
-    """count == 0 is a no-op; a batch larger than the engine's internal chunk (2^17 items) crosses the chunk boundary
-    with a ragged last chunk.  The big batch is a tiling of 60 distinct presentations (some corrupted)."""
+    """count == 0 is a no-op; a batch larger than the engine's internal pass size crosses pass boundaries with a ragged
+    last pass (pass size set to 2^15 here; the default is 2^19).  The big batch is a tiling of 60 distinct
+    presentations (some corrupted)."""
     import ctypes as C
     import aeonflux_amd as afx
     from aeonflux_amd import batch
@@ -114,6 +115,7 @@ def test_empty_and_chunk_boundary_batches():
     a = presentation_arrays(pres)
     sh = afx.Shape.from_buffer_copy(bytes(shape_of(pres[0])))
     ctx = afx.Context(params, key, ip)
+    ctx.set_chunk_items(1 << 15)
     soa, keep = batch.presentation_soa(a)
     st = np.full(4, 77, np.uint8)
     afx.check(afx.lib().afx_verify_presentations(ctx.h, C.byref(sh), C.byref(soa), 0, st.ctypes.data))
