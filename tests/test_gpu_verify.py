@@ -229,3 +229,20 @@ def test_concurrent_calls_from_threads():
     b.close()
     assert not errors, errors
     assert len(results) == 12 and all(v == want for v in results.values())
+
+
+@pytest.mark.parametrize("layout,hide", [("E" * 32, list(range(32))), ("S" * 32, list(range(32))), ("P" * 32, [])])
+def test_extreme_shapes_at_the_attribute_limit(layout, hide):
+    """32 attributes, all of one kind: 32 proofs of encryption attached (the plan's largest: 1 + 2 + 32 * 5 multiscalar
+    jobs), 32 hidden scalars (35 responses), 32 revealed points.  Status parity with the oracle, corrupted items included."""
+    import aeonflux_amd as afx
+    params, key, ip, issuer, pres = make_batch(32, layout, hide, 6, b"gpu-extreme-" + layout[:1].encode())
+    pres[1].responses[0][9] ^= 8
+    if pres[2].n_enc_proofs:
+        pres[2].enc[31].C_y_2[4] ^= 1
+    pres[4].C_y[17][0] ^= 2
+    want = [issuer.verify_presentation(p) for p in pres]
+    ctx = afx.Context(params, key, ip)
+    got = gpu_verify(afx, ctx, pres)
+    ctx.close()
+    assert got == want and want[0] == 0 and want[1] == 1 and want[4] == 1
