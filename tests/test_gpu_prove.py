@@ -170,6 +170,8 @@ def gpu_show(afx, ctx, kinds, creds, keypairs, z_wide, seeds, enc_seeds):
     (6, "SSSPSE", [0, 2, 4, 5], 33),
     (1, "S", [], 2),
     (3, "ESS", [0], 5),
+    (32, "E" * 32, list(range(32)), 2),     # 32 proofs of encryption per presentation
+    (32, "S" * 32, list(range(32)), 2),     # 32 hidden scalars
 ])
 def test_show_matches_oracle_bytes_and_gpu_verifies(n, layout, hide, count):
     import aeonflux_amd as afx
