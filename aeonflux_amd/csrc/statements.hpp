@@ -29,15 +29,21 @@ inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build) {
   AFX_HIP(hipSetDevice(c->device));
   // all chunks of one call run on one lane; calls alternate lanes only when the caller switched pipelining on
   const int lane = (c->pipelining && !c->force_lane0) ? (int)(c->lane_next++ & 1u) : 0;
-  const uint32_t CHUNK = c->chunk_items ? c->chunk_items : CHUNK_DEFAULT;
-  for (size_t off = 0; off < count; off += CHUNK) {
-    const uint32_t cc = (uint32_t)std::min<size_t>(CHUNK, count - off);
+  uint32_t chunk = c->chunk_items ? c->chunk_items : CHUNK_DEFAULT;
+  for (size_t off = 0; off < count;) {
+    const uint32_t cc = (uint32_t)std::min<size_t>(chunk, count - off);
     try {
       Assembler sizing(c, cc, true, lane);
       build(sizing, off, cc);
       if (!sizing.plan_error.empty()) { set_error(sizing.plan_error); return AFX_E_BAD_ARGS; }
       int rc = c->lane[lane].ws.ensure(sizing.total_ws_bytes());
-      if (rc) return rc;
+      if (rc) {
+        // the device cannot hold this pass's workspace: take smaller passes (an engine on a shared or smaller GPU still works)
+        if (chunk <= 4096 || cc <= 4096) return rc;
+        (void)hipGetLastError();
+        chunk >>= 1;
+        continue;
+      }
       if (sizing.blob_bytes() > BLOB_CAP) { set_error("plan blob exceeds its fixed capacity"); return AFX_E_BAD_ARGS; }
       Assembler as(c, cc, false, lane);
       build(as, off, cc);
@@ -46,6 +52,7 @@ inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build) {
       set_error(std::string("plan assembly: ") + e.what());
       return AFX_E_BAD_ARGS;
     }
+    off += cc;
   }
   return AFX_OK;
 }

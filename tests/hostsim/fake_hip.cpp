@@ -11,7 +11,14 @@ extern "C" {
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
-hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+// AFX_FAKE_HIP_MAX_ALLOC (bytes) makes larger single allocations fail, to exercise the engine's out-of-memory handling
+hipError_t hipMalloc(void** p, size_t n) {
+  const char* lim = getenv("AFX_FAKE_HIP_MAX_ALLOC");
+  if (lim && n > strtoull(lim, nullptr, 10)) { *p = nullptr; return hipErrorOutOfMemory; }
+  *p = calloc(1, n ? n : 1);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipGetLastError(void) { return hipSuccess; }
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return hipSuccess; }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }

@@ -82,6 +82,29 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     o = [rb(3, 32) for _ in range(4)]
     assert afx.lib().afx_keypairs_derive(ctx.h, ms.ctypes.data, 3, *(x.ctypes.data for x in o)) == 0
     ctx.close()
+# a device too small for the default pass: the engine halves the pass size until the workspace fits
+d = make_credentials(4, "SSPE", 1, b"hostsim-oom")
+ctx = afx.Context(d["params"], d["key"], d["ip"])
+cnt = 20000
+zero = lambda *s: np.zeros(s, np.uint8)
+shape = afx.Shape()
+shape.n_attributes, shape.n_responses, shape.n_hidden_scalars, shape.n_enc_proofs = 4, 4, 1, 1
+for i, k in enumerate((1, 0, 2, 3)):
+    shape.kinds[i] = k
+shape.hidden_scalar_indices[0], shape.enc_indices[0] = 0, 3
+big = {"challenge": zero(cnt, 32), "responses": zero(4, cnt, 32), "C_x_0": zero(cnt, 32), "C_x_1": zero(cnt, 32), "C_V": zero(cnt, 32),
+       "C_y": zero(4, cnt, 32), "attr_values": zero(4, cnt, 32),
+       "enc": [{f: (zero(6, cnt, 32) if f == "responses" else zero(cnt, 32)) for f in batch.ENC_FIELDS}]}
+os.environ["AFX_FAKE_HIP_MAX_ALLOC"] = str(256 << 20)
+assert len(batch.verify_presentations(ctx, shape, big)) == cnt
+os.environ["AFX_FAKE_HIP_MAX_ALLOC"] = str(8 << 20)      # not even the smallest pass fits: a clean error
+try:
+    batch.verify_presentations(ctx, shape, big)
+    raise SystemExit("out-of-memory not reported")
+except afx.AfxError as e:
+    assert e.rc == afx.E_HIP, e.rc
+del os.environ["AFX_FAKE_HIP_MAX_ALLOC"]
+ctx.close()
 # bad parameters / keys are rejected on the host
 d = make_credentials(2, "SP", 1, b"hostsim-bad")
 for params, key in ((d["params"][:-1], d["key"]), (d["params"], d["key"][:-1]), (b"\x09" + d["params"][1:], d["key"]), (d["params"], d["key"][:4] + b"\xff" * 32 + d["key"][36:])):
