@@ -197,13 +197,8 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     return (j.n_var ? 1320u : 160u) + j.n_uni * (330u + 45u /* more conversions to p3 */) + (j.n_var - j.n_uni) * 470u + (j.n_terms - j.n_var) * ((AFX_POS_WINDOWS * 175u) / 32u);
   };
   const size_t n = jobs.size();
-  // a job named as another's successor (chain_to) is run by that job's lanes, not by grid rows of its own
-  std::vector<int> is_successor(n, 0);
   for (size_t i = 0; i < n; i++)
-    if (jobs[i].chain_to >= 0) {
-      if ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i) throw std::logic_error("bad msm chain");
-      is_successor[jobs[i].chain_to] = 1;
-    }
+    if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
   // variable bases whose scalar is a batch constant the host knows (the issuer key in Z and in the tag) go first
   // and run a width-5 NAF: ~43 additions each instead of 64, same schedule for every lane
   std::vector<std::vector<int8_t>> naf_of(jobs.size());
@@ -284,54 +279,78 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     stats.field_mul += M;
     stats.field_sq += S;
   }
-  std::vector<uint32_t> total(n);
-  for (size_t i = 0; i < n; i++) {
-    total[i] = 0;
-    for (int32_t k = (int32_t)i, guard = 0; k >= 0; k = jobs[k].chain_to) {
-      total[i] += cost(jobs[k]);
-      if (++guard > (int)n) throw std::logic_error("msm chain cycle");
-    }
-  }
-  // grid rows: chain heads (blockIdx.y is the job and low block ids are dispatched first)
-  std::vector<size_t> heads, order;
-  for (size_t i = 0; i < n; i++) if (!is_successor[i]) heads.push_back(i);
+  // Launch list.  One kernel per job class (kernels.hip MSM_*), and a job that consumes another job's out_var
+  // (chain_to) must sit in a later launch than its producer.  Greedy over the classes in the order NAF, WINDOW,
+  // FIXED: launch every pending job of the class whose producer (if any) has been launched; repeat until none is left.
+  // For Issuer::verify that is: tables + NAF {Z}, then tables + WINDOW {every constraint, #1 (Z = z*I) included}.
+  std::vector<int> producer(n, -1);
+  for (size_t i = 0; i < n; i++)
+    if (jobs[i].chain_to >= 0) producer[jobs[i].chain_to] = (int)i;
+  auto kind_of = [](const afx_msm_job& j) { return j.n_var == 0 ? 0 : (j.n_uni ? 2 : 1); };
+  std::vector<char> done(n, 0);
   const uint32_t blocks_per_row = (count + AFX_BLOCK - 1) / AFX_BLOCK, resident = 2 * ctx->n_cu;
-  order = balanced_row_order(heads, total, blocks_per_row >= resident ? 1u : (resident + blocks_per_row / 2) / blocks_per_row);
-  for (size_t i = 0; i < n; i++) if (is_successor[i]) order.push_back(i);
-  std::vector<uint32_t> new_index(n);
-  for (size_t k = 0; k < n; k++) new_index[order[k]] = (uint32_t)k;
-  std::vector<afx_msm_job> out(n);
   uint32_t dslot = 0, tslot = 0;
-  for (size_t k = 0; k < n; k++) {
-    afx_msm_job j = jobs[order[k]];
-    j.next_job = j.chain_to >= 0 ? new_index[j.chain_to] + 1 : 0;
-    j.digit_slot = dslot; dslot += j.n_terms;
-    j.table_slot = tslot; tslot += j.n_var;
-    if (j.n_uni) {
-      std::vector<uint32_t> sched;
-      const std::vector<int8_t>& nd = naf_of[order[k]];
-      for (int b = j.top_bit; b >= 0; b--)
-        for (uint32_t u = 0; u < j.n_uni; u++) {
-          const int d = nd[256 * u + b];
-          if (d) sched.push_back(((uint32_t)b << 16) | (u << 8) | (d < 0 ? 0x80u : 0u) | (uint32_t)(((d < 0 ? -d : d) - 1) >> 1));
-        }
-      sched.push_back(0xffffffffu);
-      j.naf_sched = put(sched.data(), sched.size());
-      secure_zero(sched.data(), 4 * sched.size());                     // digits of the issuer key
-      secure_zero(naf_of[order[k]].data(), naf_of[order[k]].size());
-      secure_zero(nafc_of[order[k]].data(), nafc_of[order[k]].size());
+  size_t left = n;
+  static const int class_order[3] = { 2, 1, 0 };
+  static const LaunchKind class_launch[3] = { L_MSM_FIXED, L_MSM_WINDOW, L_MSM_NAF };
+  for (int guard = 0; left; guard++) {
+    if (guard > (int)(3 * n + 3)) throw std::logic_error("msm chain cycle");
+    const int kind = class_order[guard % 3];
+    std::vector<size_t> rows;
+    for (size_t i = 0; i < n; i++)
+      if (!done[i] && kind_of(jobs[i]) == kind && (producer[i] < 0 || done[producer[i]])) rows.push_back(i);
+    if (rows.empty()) continue;
+    std::vector<uint32_t> c(n, 0);
+    for (size_t i : rows) c[i] = cost(jobs[i]);
+    rows = balanced_row_order(rows, c, blocks_per_row >= resident ? 1u : (resident + blocks_per_row / 2) / blocks_per_row);
+    std::vector<afx_msm_job> out;
+    std::vector<afx_table_job> odd_rows, plain_rows;
+    for (size_t i : rows) {
+      afx_msm_job j = jobs[i];
+      j.next_job = 0;
+      j.digit_slot = dslot; dslot += j.n_terms;
+      j.table_slot = tslot; tslot += j.n_var;
+      for (uint32_t t = 0; t < j.n_var; t++) {
+        afx_table_job tj = { j.term[t].var, j.table_slot + t, 0 };
+        (t < j.n_uni ? odd_rows : plain_rows).push_back(tj);
+      }
+      if (j.n_uni) {
+        std::vector<uint32_t> sched;
+        const std::vector<int8_t>& nd = naf_of[i];
+        for (int b = j.top_bit; b >= 0; b--)
+          for (uint32_t u = 0; u < j.n_uni; u++) {
+            const int d = nd[256 * u + b];
+            if (d) sched.push_back(((uint32_t)b << 16) | (u << 8) | (d < 0 ? 0x80u : 0u) | (uint32_t)(((d < 0 ? -d : d) - 1) >> 1));
+          }
+        sched.push_back(0xffffffffu);
+        j.naf_sched = put(sched.data(), sched.size());
+        secure_zero(sched.data(), 4 * sched.size());                     // digits of the issuer key
+        secure_zero(naf_of[i].data(), naf_of[i].size());
+        secure_zero(nafc_of[i].data(), nafc_of[i].size());
+      }
+      out.push_back(j);
     }
-    out[k] = j;
+    for (size_t i : rows) { done[i] = 1; left--; }   // launched: consumers may go into any later launch
+    for (int odd = 1; odd >= 0; odd--) {
+      const std::vector<afx_table_job>& tr = odd ? odd_rows : plain_rows;
+      if (tr.empty()) continue;
+      Launch tl;
+      tl.kind = L_MSM_TABLES;
+      tl.odd = odd;
+      tl.njobs = (uint32_t)tr.size();
+      tl.jobs_off = blob_alloc(sizeof(afx_table_job) * tr.size(), 16);
+      memcpy(blob_.data() + tl.jobs_off, tr.data(), sizeof(afx_table_job) * tr.size());
+      launches.push_back(tl);
+    }
+    Launch l;
+    l.kind = class_launch[kind];
+    l.njobs = (uint32_t)out.size();
+    l.jobs_off = blob_alloc(sizeof(afx_msm_job) * out.size(), 16);
+    memcpy(blob_.data() + l.jobs_off, out.data(), sizeof(afx_msm_job) * out.size());
+    launches.push_back(l);
   }
   max_digit_slots = std::max<size_t>(max_digit_slots, dslot);
   max_table_slots = std::max<size_t>(max_table_slots, tslot);
-  // the launch has one grid row per chain head; successors sit behind them in the same array
-  Launch l;
-  l.kind = L_MSM;
-  l.njobs = (uint32_t)heads.size();
-  l.jobs_off = blob_alloc(sizeof(afx_msm_job) * n, 16);
-  memcpy(blob_.data() + l.jobs_off, out.data(), sizeof(afx_msm_job) * n);
-  launches.push_back(l);
 }
 void Assembler::from_uniform(const uint8_t* wide, uint8_t* out_enc, int32_t* out_var) {
   Launch l; l.kind = L_FROM_UNIFORM; l.in = wide; l.out = out_enc; l.out_var = out_var;
@@ -389,12 +408,14 @@ int Assembler::run() {
       case L_SCCHECK: AFX_HIP(afxk_sccheck(s, (const afx_sccheck_job*)jobs, l.njobs, bad_, count)); break;
       case L_POINTOP: AFX_HIP(afxk_pointop(s, (const afx_pointop_job*)jobs, l.njobs, bad_, count)); break;
       case L_SCALAROP: AFX_HIP(afxk_scalarop(s, (const afx_scalarop_job*)jobs, l.njobs, count)); break;
-      case L_MSM: {
+      case L_MSM_TABLES: AFX_HIP(afxk_msm_tables(s, l.odd, (const afx_table_job*)jobs, l.njobs, table_ws, count)); break;
+      case L_MSM_FIXED: case L_MSM_WINDOW: case L_MSM_NAF: {
         // pipelined lanes: the heavy kernel of one lane never runs beside the other lane's (only the light kernels
         // overlap it), which keeps per-launch timings meaningful and the VALU free of two competing table working sets
         afx_ctx::Lane& other = ctx->lane[lane ^ 1];
         if (ctx->pipelining && other.msm_recorded) AFX_HIP(hipStreamWaitEvent(s, other.msm_done, 0));
-        AFX_HIP(afxk_msm(s, (const afx_msm_job*)jobs, l.njobs, (const int32_t*)ctx->d_pos_tables.p, table_ws, digit_ws, bad_, count));
+        AFX_HIP(afxk_msm(s, l.kind == L_MSM_FIXED ? 0 : l.kind == L_MSM_WINDOW ? 1 : 2, (const afx_msm_job*)jobs, l.njobs,
+                         (const int32_t*)ctx->d_pos_tables.p, table_ws, digit_ws, bad_, count));
         if (ctx->pipelining) { AFX_HIP(hipEventRecord(L.msm_done, s)); L.msm_recorded = true; }
         break;
       }
@@ -403,6 +424,7 @@ int Assembler::run() {
       case L_REDUCE_WIDE: AFX_HIP(afxk_reduce_wide(s, l.in, l.out, count)); break;
       case L_COPY: AFX_HIP(hipMemcpyAsync(l.out, l.in, l.bytes, hipMemcpyDeviceToDevice, s)); break;
       case L_FINISH: AFX_HIP(afxk_finish(s, bad_, l.out, count, 0, l.fail_code)); break;
+      case L_KINDS: break;
     }
     if (ctx->timing) {
       AFX_HIP(hipEventRecord(tl.stop, s));

@@ -112,7 +112,9 @@ struct afx_ctx {
 
 namespace afx {
 
-enum LaunchKind { L_FILL_BAD, L_DECODE, L_SCCHECK, L_POINTOP, L_SCALAROP, L_MSM, L_HASH, L_FROM_UNIFORM, L_REDUCE_WIDE, L_COPY, L_FINISH };
+// L_MSM_WINDOW keeps the slot the single k_msm kernel had (timing names: statements.cpp KIND_NAMES)
+enum LaunchKind { L_FILL_BAD, L_DECODE, L_SCCHECK, L_POINTOP, L_SCALAROP, L_MSM_WINDOW, L_HASH, L_FROM_UNIFORM, L_REDUCE_WIDE, L_COPY, L_FINISH,
+                  L_MSM_FIXED, L_MSM_NAF, L_MSM_TABLES, L_KINDS };
 
 struct Launch {
   LaunchKind kind;
@@ -124,6 +126,7 @@ struct Launch {
   int32_t* out_var = nullptr;
   uint8_t fail_code = AFX_ST_VERIFICATION_FAILURE;
   size_t bytes = 0;         // L_COPY
+  int odd = 0;              // L_MSM_TABLES: odd multiples (NAF terms) or multiples 0..8
 };
 
 // Builds one call's kernel launch list over a chunk of `count` items.

@@ -9,7 +9,9 @@ hipError_t afxk_sccheck(hipStream_t s, const afx_sccheck_job* jobs, uint32_t njo
 hipError_t afxk_pointop(hipStream_t s, const afx_pointop_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count);
 hipError_t afxk_scalarop(hipStream_t s, const afx_scalarop_job* jobs, uint32_t njobs, uint32_t count);
 hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen, int32_t* base_scratch, int32_t* postab);
-hipError_t afxk_msm(hipStream_t s, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, int32_t* table_ws, uint32_t* digit_ws,
+// kind: 0 fixed bases only, 1 per-item windows, 2 uniform NAF terms (kernels.hip MSM_*)
+hipError_t afxk_msm_tables(hipStream_t s, int odd, const afx_table_job* rows, uint32_t nrows, int32_t* table_ws, uint32_t count);
+hipError_t afxk_msm(hipStream_t s, int kind, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, int32_t* table_ws, uint32_t* digit_ws,
                     uint32_t* bad, uint32_t count);
 hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count);
 hipError_t afxk_finish(hipStream_t s, const uint32_t* bad, uint8_t* status, uint32_t count, uint32_t fail_all, uint8_t fail_code);

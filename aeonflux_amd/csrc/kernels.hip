@@ -294,19 +294,21 @@ AFX_DEV ge_p3 msm_add_positional(const msm_env& e, const int32_t* __restrict__ p
   return ge_p1p1_to_p3_next(ge_madd(acc, q, neg), next);
 }
 
-__global__ void __launch_bounds__(AFX_BLOCK, 2)
-k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tables, int32_t* __restrict__ table_ws,
-      uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count) {
-  // lanes past the end of the batch shadow the last item (identical values, identical stores)
-  const uint32_t item = min(blockIdx.x * AFX_BLOCK + threadIdx.x, count - 1);
-  const afx_msm_job* job = &jobs[blockIdx.y];
-#pragma unroll 1
-  for (;;) {
-  const uint32_t nt = job->n_terms, nv = job->n_var, nf = nt - nv, nu = job->n_uni;
-  // recode the per-item scalars, stored [slot][8][count] (batch-constant NAF terms need none)
+// One kernel per job class (the host sorts a launch list's jobs by class, engine.cpp Assembler::msm), so that each
+// class gets a register allocation of its own: the three chain variants, table building and the ristretto encoding in
+// one loop body had the allocator pay for their union (round 1: 68 VGPRs spilled, 276 B/lane of scratch).
+//   MSM_FIXED   fixed bases only: positional tables, no doubling chain
+//   MSM_WINDOW  variable bases with per-item scalars: signed 4-bit windows, 63 x 4 doublings
+//   MSM_NAF     some variable bases carry a batch-constant scalar (the issuer key): bit-serial chain with their width-5
+//               NAF digits as a uniform schedule; per-item terms keep their windows
+// A job that consumes another job's out_var (Z -> constraint #1 of the presentation proof) sits in a later launch.
+enum { MSM_FIXED = 0, MSM_WINDOW = 1, MSM_NAF = 2 };
+
+// recode the per-item scalars of terms [from, nt), stored [slot][AFX_DIGIT_WORDS][count]
+AFX_DEV void msm_recode(const afx_msm_job* job, uint32_t* __restrict__ digit_ws, uint32_t count, uint32_t item, uint32_t from, uint32_t nv, uint32_t nt) {
   const uint32_t dslot = job->digit_slot;
 #pragma unroll 1
-  for (uint32_t t = nu; t < nt; t++) {
+  for (uint32_t t = from; t < nt; t++) {
     const sc s = sc_load_item(job->term[t].scalar, job->term[t].scalar_stride, item);
     uint32_t b[9];
     b[8] = 0;
@@ -315,97 +317,43 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
 #pragma unroll
     for (int i = 0; i < AFX_DIGIT_WORDS; i++) digit_ws[((size_t)(dslot + t) * AFX_DIGIT_WORDS + i) * count + item] = b[i];
   }
-  // per-lane window tables for the variable bases: multiples 0..8 for 4-bit signed windows, or the odd multiples
-  // 1, 3, ..., 15 for the terms that run a width-5 NAF
-  const uint32_t tslot = job->table_slot;
+}
+// per-lane window table of one variable base: multiples 0..8 (signed 4-bit windows), or the odd multiples
+// 1, 3, ..., 15 (ODD: the terms that run a width-5 NAF)
+template <bool ODD>
+AFX_DEV void msm_build_table(int32_t* __restrict__ tab, const ge_p3& P) {
+  ge_p3 Q = P;
+  if (ODD) {
+    const ge_cached c2 = ge_p3_to_cached(ge_double(P));
+    cached_store(tab, ge_p3_to_cached_reduced(P));
 #pragma unroll 1
-  for (uint32_t t = 0; t < nv; t++) {
-    int32_t* tab = table_ws + ((size_t)(tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
-    const ge_p3 P = var_load(job->term[t].var, count, item);
-    ge_p3 Q = P;
-    if (t < nu) {
-      const ge_cached c2 = ge_p3_to_cached(ge_double(P));
-      cached_store(tab, ge_p3_to_cached_reduced(P));
-#pragma unroll 1
-      for (int k = 1; k < 8; k++) {
-        Q = ge_p1p1_to_p3(ge_add_cached(Q, c2, false));
-        cached_store(tab + k * AFX_TABLE_ENTRY_DWORDS, ge_p3_to_cached_reduced(Q));
-      }
-    } else {
-      const ge_cached cP = ge_p3_to_cached_reduced(P);
-      cached_store(tab, ge_cached_identity());
-      cached_store(tab + AFX_TABLE_ENTRY_DWORDS, cP);
-#pragma unroll 1
-      for (int k = 2; k < AFX_TABLE_ENTRIES; k++) {
-        Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
-        cached_store(tab + k * AFX_TABLE_ENTRY_DWORDS, ge_p3_to_cached_reduced(Q));
-      }
-    }
-  }
-
-  msm_env env;
-  env.job = job; env.table_ws = table_ws; env.digit_ws = digit_ws;
-  env.count = count; env.item = item; env.dslot = dslot; env.tslot = tslot;
-  ge_p3 acc = ge_identity();
-  if (nv == 0) {
-    // fixed bases only: sum over window positions of positional-table entries, no doublings
-#pragma unroll 1
-    for (uint32_t j = 0; j < AFX_POS_WINDOWS; j++) {
-#pragma unroll 1
-      for (uint32_t t = 0; t < nt; t++)
-        acc = msm_add_positional(env, pos_tables, acc, t, j, (j + 1 == AFX_POS_WINDOWS && t + 1 == nt) ? GE_FOR_ANY : GE_FOR_ADD);
-    }
-  } else if (nu != 0) {
-    // some scalars are batch constants: bit-serial chain, their width-5 NAF digits (the same for every lane, so the
-    // branches are uniform) add odd multiples at ~1/6 of the bit positions; per-item terms keep their windows
-    const uint32_t* sched = job->naf_sched;   // uniform: scalar loads
-    const int top = job->top_bit;
-    const uint32_t nvl = nv - nu;
-    uint32_t ei = 0, ev = sched[0];
-#pragma unroll 1
-    for (int bit = top; bit >= 0; bit--) {
-      const bool lane_adds = (bit & 3) == 0 && nvl != 0;
-      const bool any_adds = lane_adds || (ev >> 16) == (uint32_t)bit;
-      // what follows the last step at this bit position: the next doubling, or (bit 0) whatever comes after the chain
-      const int after = bit == 0 ? GE_FOR_ANY : GE_FOR_DBL;
-      if (bit != top) acc = ge_p1p1_to_p3_next(ge_p2_dbl(ge_p3_to_p2(acc)), any_adds ? GE_FOR_ADD : after);
-#pragma unroll 1
-      while ((ev >> 16) == (uint32_t)bit) {
-        const uint32_t t = (ev >> 8) & 0xffu, idx = ev & 7u;
-        const bool neg = (ev & 0x80u) != 0;
-        ev = sched[++ei];
-        const bool last = !lane_adds && (ev >> 16) != (uint32_t)bit;
-        const int32_t* tab = table_ws + ((size_t)(tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
-        acc = ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), neg), last ? after : GE_FOR_ADD);
-      }
-      if (lane_adds) {
-#pragma unroll 1
-        for (uint32_t t = nu; t < nv; t++) acc = msm_add_var(env, acc, t, bit >> 2, t + 1 != nv ? GE_FOR_ADD : after);
-      }
+    for (int k = 1; k < 8; k++) {
+      Q = ge_p1p1_to_p3(ge_add_cached(Q, c2, false));
+      cached_store(tab + k * AFX_TABLE_ENTRY_DWORDS, ge_p3_to_cached_reduced(Q));
     }
   } else {
+    const ge_cached cP = ge_p3_to_cached_reduced(P);
+    cached_store(tab, ge_cached_identity());
+    cached_store(tab + AFX_TABLE_ENTRY_DWORDS, cP);
 #pragma unroll 1
-  for (int w = 63; w >= 0; w--) {
-    if (w != 63) {
-      ge_p2 a2 = ge_p3_to_p2(acc);
-#pragma unroll 1
-      for (int k = 0; k < 3; k++) a2 = ge_p1p1_to_p2_before_dbl(ge_p2_dbl(a2));
-      acc = ge_p1p1_to_p3_for<GE_FOR_ADD>(ge_p2_dbl(a2));
-    }
-#pragma unroll 1
-    for (uint32_t t = 0; t + 1 < nv; t++) acc = msm_add_var(env, acc, t, w, GE_FOR_ADD);
-    acc = msm_add_var(env, acc, nv - 1, w, w == 0 ? GE_FOR_ANY : GE_FOR_DBL);   // the window's last addition
-  }
-  }
-  if (nv != 0 && nf != 0) {
-    // the fixed bases of a job with variable bases: positional tables, after the chain (any order gives the same sum)
-#pragma unroll 1
-    for (uint32_t j = 0; j < AFX_POS_WINDOWS; j++) {
-#pragma unroll 1
-      for (uint32_t t = nv; t < nt; t++)
-        acc = msm_add_positional(env, pos_tables, acc, t, j, (j + 1 == AFX_POS_WINDOWS && t + 1 == nt) ? GE_FOR_ANY : GE_FOR_ADD);
+    for (int k = 2; k < AFX_TABLE_ENTRIES; k++) {
+      Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
+      cached_store(tab + k * AFX_TABLE_ENTRY_DWORDS, ge_p3_to_cached_reduced(Q));
     }
   }
+}
+// the fixed bases of a job (terms [from, nt)): positional tables, no doubling; the sum's last step leaves acc centred
+AFX_DEV ge_p3 msm_fixed_terms(const msm_env& e, const int32_t* __restrict__ pos_tables, ge_p3 acc, uint32_t from, uint32_t nt) {
+#pragma unroll 1
+  for (uint32_t j = 0; j < AFX_POS_WINDOWS; j++) {
+#pragma unroll 1
+    for (uint32_t t = from; t < nt; t++)
+      acc = msm_add_positional(e, pos_tables, acc, t, j, (j + 1 == AFX_POS_WINDOWS && t + 1 == nt) ? GE_FOR_ANY : GE_FOR_ADD);
+  }
+  return acc;
+}
+// addend, extended-coordinate output, compressed output
+AFX_DEV void msm_finish(const afx_msm_job* job, ge_p3 acc, uint32_t* __restrict__ bad, uint32_t count, uint32_t item) {
   if (job->addend) {
     const ge_p3 A = var_load(job->addend, count, item);
     acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_p3_to_cached(A), job->addend_negate != 0));
@@ -417,9 +365,81 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
     enc_store(job->out_enc, item, wenc);
     if (job->reject_identity && is_identity_encoding(wenc)) atomicOr(&bad[item], AFX_BAD_IDENTITY);
   }
-  if (job->next_job == 0) break;
-  job = &jobs[job->next_job - 1];
+}
+
+// window tables of the variable bases of one k_msm launch, one (job, term) pair per grid row: the chain kernels only read them
+template <bool ODD>
+__global__ void __launch_bounds__(AFX_BLOCK, 2)
+k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table_ws, uint32_t count) {
+  const uint32_t item = min(blockIdx.x * AFX_BLOCK + threadIdx.x, count - 1);
+  const afx_table_job row = rows[blockIdx.y];
+  int32_t* tab = table_ws + ((size_t)row.table_slot * count + item) * AFX_VAR_TABLE_DWORDS;
+  const ge_p3 P = var_load(row.var, count, item);
+  msm_build_table<ODD>(tab, P);
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(AFX_BLOCK, 2)
+k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tables, int32_t* __restrict__ table_ws,
+      uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count) {
+  // lanes past the end of the batch shadow the last item (identical values, identical stores)
+  const uint32_t item = min(blockIdx.x * AFX_BLOCK + threadIdx.x, count - 1);
+  const afx_msm_job* job = &jobs[blockIdx.y];
+  const uint32_t nt = job->n_terms, nv = job->n_var, nu = job->n_uni;
+  msm_env env;
+  env.job = job; env.table_ws = table_ws; env.digit_ws = digit_ws;
+  env.count = count; env.item = item; env.dslot = job->digit_slot; env.tslot = job->table_slot;
+  msm_recode(job, digit_ws, count, item, nu, nv, nt);   // batch-constant NAF terms need no digits
+  ge_p3 acc = ge_identity();
+  if constexpr (KIND == MSM_FIXED) {
+    acc = msm_fixed_terms(env, pos_tables, acc, 0, nt);
+  } else {
+    if constexpr (KIND == MSM_NAF) {
+      // bit-serial chain: the batch-constant scalars' width-5 NAF digits (the same for every lane, so the branches are
+      // uniform) add odd multiples at ~1/6 of the bit positions; per-item terms keep their 4-bit windows
+      const uint32_t* sched = job->naf_sched;   // uniform: scalar loads
+      const int top = job->top_bit;
+      const uint32_t nvl = nv - nu;
+      uint32_t ei = 0, ev = sched[0];
+#pragma unroll 1
+      for (int bit = top; bit >= 0; bit--) {
+        const bool lane_adds = (bit & 3) == 0 && nvl != 0;
+        const bool any_adds = lane_adds || (ev >> 16) == (uint32_t)bit;
+        // what follows the last step at this bit position: the next doubling, or (bit 0) whatever comes after the chain
+        const int after = bit == 0 ? GE_FOR_ANY : GE_FOR_DBL;
+        if (bit != top) acc = ge_p1p1_to_p3_next(ge_p2_dbl(ge_p3_to_p2(acc)), any_adds ? GE_FOR_ADD : after);
+#pragma unroll 1
+        while ((ev >> 16) == (uint32_t)bit) {
+          const uint32_t t = (ev >> 8) & 0xffu, idx = ev & 7u;
+          const bool neg = (ev & 0x80u) != 0;
+          ev = sched[++ei];
+          const bool last = !lane_adds && (ev >> 16) != (uint32_t)bit;
+          const int32_t* tab = table_ws + ((size_t)(env.tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
+          acc = ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), neg), last ? after : GE_FOR_ADD);
+        }
+        if (lane_adds) {
+#pragma unroll 1
+          for (uint32_t t = nu; t < nv; t++) acc = msm_add_var(env, acc, t, bit >> 2, t + 1 != nv ? GE_FOR_ADD : after);
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int w = 63; w >= 0; w--) {
+        if (w != 63) {
+          ge_p2 a2 = ge_p3_to_p2(acc);
+#pragma unroll 1
+          for (int k = 0; k < 3; k++) a2 = ge_p1p1_to_p2_before_dbl(ge_p2_dbl(a2));
+          acc = ge_p1p1_to_p3_for<GE_FOR_ADD>(ge_p2_dbl(a2));
+        }
+#pragma unroll 1
+        for (uint32_t t = 0; t + 1 < nv; t++) acc = msm_add_var(env, acc, t, w, GE_FOR_ADD);
+        acc = msm_add_var(env, acc, nv - 1, w, w == 0 ? GE_FOR_ANY : GE_FOR_DBL);   // the window's last addition
+      }
+    }
+    // the fixed bases of a job with variable bases: after the chain (any order gives the same sum)
+    if (nt != nv) acc = msm_fixed_terms(env, pos_tables, acc, nv, nt);
   }
+  msm_finish(job, acc, bad, count, item);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -590,9 +610,19 @@ hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen
   hipLaunchKernelGGL(k_setup_postables, dim3((ngen * AFX_POS_WINDOWS * AFX_POS_CHUNKS + 63) / 64), dim3(64), 0, s, base, ngen, postab);
   return hipGetLastError();
 }
-hipError_t afxk_msm(hipStream_t s, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, int32_t* table_ws, uint32_t* digit_ws,
+hipError_t afxk_msm(hipStream_t s, int kind, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, int32_t* table_ws, uint32_t* digit_ws,
                     uint32_t* bad, uint32_t count) {
-  hipLaunchKernelGGL(k_msm, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count);
+  switch (kind) {
+    case MSM_FIXED: hipLaunchKernelGGL(k_msm<MSM_FIXED>, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count); break;
+    case MSM_WINDOW: hipLaunchKernelGGL(k_msm<MSM_WINDOW>, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count); break;
+    case MSM_NAF: hipLaunchKernelGGL(k_msm<MSM_NAF>, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t afxk_msm_tables(hipStream_t s, int odd, const afx_table_job* rows, uint32_t nrows, int32_t* table_ws, uint32_t count) {
+  if (odd) hipLaunchKernelGGL(k_msm_tables<true>, grid_for(count, nrows), dim3(AFX_BLOCK), 0, s, rows, table_ws, count);
+  else hipLaunchKernelGGL(k_msm_tables<false>, grid_for(count, nrows), dim3(AFX_BLOCK), 0, s, rows, table_ws, count);
   return hipGetLastError();
 }
 hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count) {

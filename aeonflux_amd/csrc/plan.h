@@ -93,12 +93,20 @@ typedef struct {
   uint8_t* out_enc;                     /* [count][32] compressed result, may be null             */
   afx_var_t out_var;                    /* extended result, may be null                           */
   uint32_t reject_identity;
-  uint32_t next_job;                    /* 1 + index of a job the same lane runs right after this one (it may
-                                           consume this job's out_var); 0 = none.  Successors are not grid rows */
-  int32_t chain_to;                     /* host only: index (in the vector handed to Assembler::msm) of the successor, -1 none */
+  uint32_t next_job;                    /* unused (round 1 chained a successor job inside the lane) */
+  int32_t chain_to;                     /* host only: index (in the vector handed to Assembler::msm) of a job that consumes this
+                                           job's out_var and therefore goes into a later launch; -1 none */
   uint32_t digit_slot;                  /* first recoded-scalar slot of this job in digit_ws (one per term)   */
   uint32_t table_slot;                  /* first window-table slot of this job in table_ws (one per var term) */
 } afx_msm_job;
+
+/* one window table to build (k_msm_tables<ODD>): the base and where the table goes.  ODD = the odd multiples 1, 3, .., 15
+ * (terms that run a width-5 NAF), else the multiples 0..8 (signed 4-bit windows) */
+typedef struct {
+  const int32_t* var;      /* variable point (SoA)                                                  */
+  uint32_t table_slot;     /* slot in table_ws                                                      */
+  uint32_t pad;
+} afx_table_job;
 
 /* one 8-byte word of a STROBE rate block: st = (st & keep) ^ c ^ (field_word & fmask) */
 typedef struct {

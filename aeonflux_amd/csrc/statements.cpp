@@ -35,8 +35,10 @@ extern "C" const char* afx_last_error(void) { return afx::last_error(); }
 extern "C" uint32_t afx_ctx_n_attributes(const afx_ctx* ctx) { return ctx ? ctx->n : 0; }
 extern "C" void* afx_ctx_stream(const afx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
-static const char* const KIND_NAMES[] = { "k_fill_u32", "k_decode", "k_sccheck", "k_pointop", "k_scalarop", "k_msm", "k_hash",
-                                          "k_from_uniform", "k_reduce_wide", "copy", "k_finish" };
+// indexed by afx::LaunchKind.  "k_msm" (afx_ctx_get_timing) = the three chain kernels + the table kernel together
+static const char* const KIND_NAMES[] = { "k_fill_u32", "k_decode", "k_sccheck", "k_pointop", "k_scalarop", "k_msm_window", "k_hash",
+                                          "k_from_uniform", "k_reduce_wide", "copy", "k_finish", "k_msm_fixed", "k_msm_naf", "k_msm_tables" };
+static_assert(sizeof KIND_NAMES / sizeof KIND_NAMES[0] == afx::L_KINDS, "one name per launch kind");
 static int drain_timing(afx_ctx* c) {
   for (auto& L : c->lane)
     if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
@@ -109,6 +111,7 @@ extern "C" int afx_ctx_get_plan_stats(afx_ctx* c, afx_plan_stats* out) {
 }
 extern "C" int afx_ctx_synchronize(afx_ctx* c) {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
   AFX_HIP(hipSetDevice(c->device));
   for (auto& L : c->lane)
     if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
@@ -116,6 +119,7 @@ extern "C" int afx_ctx_synchronize(afx_ctx* c) {
 }
 extern "C" int afx_ctx_set_timing(afx_ctx* c, int enable) {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
   AFX_HIP(hipSetDevice(c->device));
   int rc = drain_timing(c);
   if (rc) return rc;
@@ -125,9 +129,15 @@ extern "C" int afx_ctx_set_timing(afx_ctx* c, int enable) {
 }
 extern "C" int afx_ctx_get_timing(afx_ctx* c, const char* kernel, double* total_ms, uint64_t* launches) {
   if (!c || !kernel || !total_ms || !launches) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
   AFX_HIP(hipSetDevice(c->device));
   int rc = drain_timing(c);
   if (rc) return rc;
+  if (strcmp(kernel, "k_msm") == 0) {
+    *total_ms = 0; *launches = 0;
+    for (int k : { (int)L_MSM_WINDOW, (int)L_MSM_FIXED, (int)L_MSM_NAF, (int)L_MSM_TABLES }) { *total_ms += c->kind_ms[k]; *launches += c->kind_launches[k]; }
+    return AFX_OK;
+  }
   for (size_t k = 0; k < sizeof KIND_NAMES / sizeof KIND_NAMES[0]; k++)
     if (strcmp(kernel, KIND_NAMES[k]) == 0) { *total_ms = c->kind_ms[k]; *launches = c->kind_launches[k]; return AFX_OK; }
   set_error("unknown kernel name");

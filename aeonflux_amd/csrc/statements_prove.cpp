@@ -550,10 +550,13 @@ extern "C" int afx_issuer_keygen(int device, const uint8_t* sysparams, size_t sy
   afx_ctx* c = nullptr;
   int rc = afx_ctx_create_impl(&c, device, sysparams, sysparams_len, nullptr, 0, key_scalars, nullptr);
   if (rc) return rc;
+  uint8_t buf[96];
+  {
+  // the Stager refers to the context: it must be gone before afx_ctx_destroy(c)
   Stager st(c);
   const size_t o_out = st.add(nullptr, 96), o_st = st.add(nullptr, 1);
-  if ((rc = st.upload())) { afx_ctx_destroy(c); return rc; }
-  rc = run_chunked(c, 1, [&](Assembler& as, size_t, uint32_t) {
+  rc = st.upload();
+  if (!rc) rc = run_chunked(c, 1, [&](Assembler& as, size_t, uint32_t) {
     std::vector<afx_msm_job> jobs;
     jobs.push_back(mk_job({ mk_term(c->key_w(), 0, nullptr, (int32_t)c->id_Gw(), false) }, nullptr, nullptr, st.dev(o_out), false));   // W (amacs.rs:104)
     jobs.push_back(mk_job({ mk_term(c->key_w(), 0, nullptr, (int32_t)c->id_Gw(), false), mk_term(c->key_wp(), 0, nullptr, (int32_t)c->id_Gwp(), false) },
@@ -565,11 +568,11 @@ extern "C" int afx_issuer_keygen(int device, const uint8_t* sysparams, size_t sy
     as.msm(jobs);
     as.finish(st.dev(o_st), 1);
   });
-  uint8_t buf[96];
   if (!rc) {
     hipError_t e = hipMemcpyAsync(buf, st.dev(o_out), 96, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = AFX_E_HIP; }
+  }
   }
   if (!rc) {
     memcpy(W_out, buf, 32);
