@@ -257,6 +257,14 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_scalarop(const afx_scalarop_job* 
 // Field work per 4-bit window: 4 doublings (4 x 4S + 3 x 3M + 4M), 8M per variable term (the last addition of a
 // window skips the T coordinate, -1M); 7M per fixed-base addition.  Assembler::msm (engine.cpp) counts the same
 // schedule for afx_ctx_get_plan_stats.
+// Experiment switch (never in the shipped build; results are wrong with it): every lane gathers item 0's window table,
+// so the gathers hit L1/L2 and the chain runs as if table traffic were free - the upper bound on what any table-layout
+// or table-size change can gain (profiles/r02_traffic_experiments.txt).
+#ifdef AFX_EXPERIMENT_ALIAS_TABLES
+#define AFX_TABLE_ITEM(item) ((item) & 0u)
+#else
+#define AFX_TABLE_ITEM(item) (item)
+#endif
 // per-lane context of one job inside k_msm
 struct msm_env {
   const afx_msm_job* job;
@@ -271,7 +279,7 @@ AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w,
   const int d = (int)((word >> (((uint32_t)w & 7) * 4)) & 15u) - 8;
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
   const bool neg = (d < 0) != (e.job->term[t].negate != 0);
-  const int32_t* tab = e.table_ws + ((size_t)(e.tslot + t) * e.count + e.item) * AFX_VAR_TABLE_DWORDS;
+  const int32_t* tab = e.table_ws + ((size_t)(e.tslot + t) * e.count + AFX_TABLE_ITEM(e.item)) * AFX_VAR_TABLE_DWORDS;
   return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), neg), next);
 }
 // acc += (AFX_POS_BITS-bit signed digit j) * 2^(AFX_POS_BITS*j) * (generator of term t), from the positional tables
@@ -320,8 +328,11 @@ AFX_DEV void msm_recode(const afx_msm_job* job, uint32_t* __restrict__ digit_ws,
 }
 // per-lane window table of one variable base: multiples 0..8 (signed 4-bit windows), or the odd multiples
 // 1, 3, ..., 15 (ODD: the terms that run a width-5 NAF)
+// Layout inside a slot's AFX_VAR_TABLE_DWORDS * count dwords: 4-bit-window tables are item-major ([item][entry]: a lane's 9
+// entries are contiguous, its digit picks one), NAF tables entry-major ([entry][item]: every lane of a wave reads the SAME
+// entry, so the wave's gather is 64 x 128 contiguous bytes).  `stride` = dwords between consecutive entries.
 template <bool ODD>
-AFX_DEV void msm_build_table(int32_t* __restrict__ tab, const ge_p3& P) {
+AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, const ge_p3& P) {
   ge_p3 Q = P;
   if (ODD) {
     const ge_cached c2 = ge_p3_to_cached(ge_double(P));
@@ -329,16 +340,16 @@ AFX_DEV void msm_build_table(int32_t* __restrict__ tab, const ge_p3& P) {
 #pragma unroll 1
     for (int k = 1; k < 8; k++) {
       Q = ge_p1p1_to_p3(ge_add_cached(Q, c2, false));
-      cached_store(tab + k * AFX_TABLE_ENTRY_DWORDS, ge_p3_to_cached_reduced(Q));
+      cached_store(tab + k * stride, ge_p3_to_cached_reduced(Q));
     }
   } else {
     const ge_cached cP = ge_p3_to_cached_reduced(P);
     cached_store(tab, ge_cached_identity());
-    cached_store(tab + AFX_TABLE_ENTRY_DWORDS, cP);
+    cached_store(tab + stride, cP);
 #pragma unroll 1
     for (int k = 2; k < AFX_TABLE_ENTRIES; k++) {
       Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
-      cached_store(tab + k * AFX_TABLE_ENTRY_DWORDS, ge_p3_to_cached_reduced(Q));
+      cached_store(tab + k * stride, ge_p3_to_cached_reduced(Q));
     }
   }
 }
@@ -373,9 +384,10 @@ __global__ void __launch_bounds__(AFX_BLOCK, 2)
 k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table_ws, uint32_t count) {
   const uint32_t item = min(blockIdx.x * AFX_BLOCK + threadIdx.x, count - 1);
   const afx_table_job row = rows[blockIdx.y];
-  int32_t* tab = table_ws + ((size_t)row.table_slot * count + item) * AFX_VAR_TABLE_DWORDS;
+  int32_t* slot = table_ws + (size_t)row.table_slot * count * AFX_VAR_TABLE_DWORDS;
   const ge_p3 P = var_load(row.var, count, item);
-  msm_build_table<ODD>(tab, P);
+  if (ODD) msm_build_table<true>(slot + (size_t)item * AFX_TABLE_ENTRY_DWORDS, (size_t)count * AFX_TABLE_ENTRY_DWORDS, P);
+  else msm_build_table<false>(slot + (size_t)item * AFX_VAR_TABLE_DWORDS, AFX_TABLE_ENTRY_DWORDS, P);
 }
 
 template <int KIND>
@@ -414,8 +426,8 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
           const bool neg = (ev & 0x80u) != 0;
           ev = sched[++ei];
           const bool last = !lane_adds && (ev >> 16) != (uint32_t)bit;
-          const int32_t* tab = table_ws + ((size_t)(env.tslot + t) * count + item) * AFX_VAR_TABLE_DWORDS;
-          acc = ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), neg), last ? after : GE_FOR_ADD);
+          const int32_t* ent = table_ws + (size_t)(env.tslot + t) * count * AFX_VAR_TABLE_DWORDS + ((size_t)idx * count + AFX_TABLE_ITEM(item)) * AFX_TABLE_ENTRY_DWORDS;
+          acc = ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent), neg), last ? after : GE_FOR_ADD);
         }
         if (lane_adds) {
 #pragma unroll 1

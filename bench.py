@@ -40,14 +40,52 @@ def algorithmic_bytes(shape):
     return 32 * (4 + hs) + 96 + 32 * n + 32 * pub + 448 * hp + (n + 2 * hs + 4 * hp) + 1
 
 
-def measured_traffic(workload):
-    """HBM bytes per k_msm launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json; collected with
-    tools/collect_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH §HBM)"""
+TRAFFIC_FILE = "r02_traffic.json"
+# timing experiments with deliberately wrong kernels (tools/ab_bench.sh with an experiment build): skip the result checks
+# and say so in the output line.  Never set for a reported number.
+UNCHECKED = os.environ.get("AFX_BENCH_UNCHECKED") == "1"
+
+
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r02_traffic.json; collected with tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes,
+    FETCH doubled per MI355X_MICROARCH §HBM).  PMC counters cannot be read from inside the process, so the figure is the
+    committed measurement of the same workload, not a live one.  C4 launches are C3 launches (2^19-item passes)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            return json.load(f).get(workload)
+        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
+            d = json.load(f).get({"c4": "c3"}.get(workload, workload))
+        return d.get(kernel) if isinstance(d, dict) else d
     except (OSError, ValueError):
         return None
+
+
+MSM_KERNELS = ("k_msm_window", "k_msm_naf", "k_msm_fixed", "k_msm_tables")
+OTHER_KERNELS = ("k_decode", "k_pointop", "k_hash", "k_scalarop", "k_sccheck", "k_from_uniform", "k_reduce_wide", "k_finish", "k_fill_u32")
+
+
+def kernel_times(ctx, steps):
+    """per-kernel totals of the timed steps, measured by the engine with HIP events on its own stream"""
+    out = {}
+    for k in MSM_KERNELS + OTHER_KERNELS:
+        ms, n = ctx.get_timing(k)
+        if n:
+            out[k] = {"ms_per_step": ms / steps, "launches_per_step": n / steps, "avg_launch_ms": ms / n}
+    return out
+
+
+def roofline_of(kt, workload, ab, items_per_step):
+    """the contract's roofline object for the dominant kernel of the step (the largest ms_per_step)"""
+    dom = max((k for k in kt if k in MSM_KERNELS), key=lambda k: kt[k]["ms_per_step"])
+    d = kt[dom]
+    items_per_launch = items_per_step / d["launches_per_step"]
+    achieved = ab * items_per_launch / (d["avg_launch_ms"] / 1e3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "traffic": measured_traffic(workload, dom), "kernel": dom, "launches_per_step": d["launches_per_step"],
+            "avg_launch_ms": d["avg_launch_ms"], "items_per_launch": items_per_launch, "algorithmic_bytes_per_launch": ab * items_per_launch,
+            "kernel_ms_per_step": sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS),
+            "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in kt.items()},
+            "kernel_launches_per_step": {k: v["launches_per_step"] for k, v in kt.items()},
+            "note": "integer-ALU bound path: the compute-side figure is in \"valu\""}
 
 
 def usable_cores():
@@ -182,9 +220,9 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    assert not status.cpu().numpy().any(), "issue failed"
+    assert UNCHECKED or not status.cpu().numpy().any(), "issue failed"
     # parity spot check of the first 64 credentials against the CPU oracle (checker only)
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and not UNCHECKED:
         import oracle
         octx = oracle.Ctx(params, key, ip)
         h = {k: v[..., :64, :].cpu().numpy() for k, v in d_out.items()}
@@ -201,9 +239,8 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    msm_ms, msm_launches = issuer.get_timing("k_msm")
-    valu = valu_side(issuer, count, (msm_ms + issuer.get_timing("k_decode")[0] + issuer.get_timing("k_pointop")[0]) / args.steps)
-    hash_ms, _ = issuer.get_timing("k_hash")
+    kt = kernel_times(issuer, args.steps)
+    valu = valu_side(issuer, count, sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS + ("k_decode", "k_pointop", "k_from_uniform")))
     issuer.set_timing(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
@@ -221,17 +258,13 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
                "sample": "first %d issuances of the same batch through the oracle (one thread, called from python)" % S}
     if rank == 0:
         ab = 32 * n + n + 160 + 96 + 32 * (n + 6)
-        per_step = msm_ms / 1e3 / args.steps
-        achieved = ab * count / per_step / 1e9 if per_step > 0 else 0.0
         print(json.dumps({
             "metric": "credentials issued/sec (secondary; aMAC tag + issuance NIZK)", "value": count * world * args.steps / elapsed,
             "unit": "credentials/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic (random attribute values)",
             "config": {"workload": "C5: batch issue 2^20 credentials, 16 attributes (S x8, P x4, E x4)", "credentials_per_gpu": count,
                        "algorithmic_bytes_per_credential": ab, "parallelism": "host-sharded x%d, no collective" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                         "kernel": "k_msm", "launches_per_step": msm_launches / args.steps, "avg_launch_ms": msm_ms / max(1, msm_launches),
-                         "kernel_ms_per_step": msm_ms / args.steps, "other_kernels_ms_per_step": {"k_hash": hash_ms / args.steps}},
+            "roofline": roofline_of(kt, "c5", ab, count),
             "valu": valu, "cpu_baseline": cpu}))
     issuer.close()
     if dist is not None:
@@ -323,9 +356,8 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    msm_ms, msm_launches = user.get_timing("k_msm")
-    valu = valu_side(user, count, (msm_ms + user.get_timing("k_decode")[0] + user.get_timing("k_pointop")[0]) / args.steps)
-    hash_ms, _ = user.get_timing("k_hash")
+    kt = kernel_times(user, args.steps)
+    valu = valu_side(user, count, sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS + ("k_decode", "k_pointop", "k_from_uniform")))
     user.set_timing(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
@@ -333,17 +365,13 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
         elapsed = float(t.item())
     if rank == 0:
         ab = 32 * n + n + 96 + 32 + 128 + 96 + 64 + 32 + 32 + 907   # credential + keypair + randomness read, presentation written
-        per_step = msm_ms / 1e3 / args.steps
-        achieved = ab * count / per_step / 1e9 if per_step > 0 else 0.0
         print(json.dumps({
             "metric": "credential presentations created/sec (secondary; AnonymousCredential::show)", "value": count * world * args.steps / elapsed,
             "unit": "presentations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic (GPU-issued credentials)",
             "config": {"workload": "show 2^16 credentials, 4 attributes (s S P e)", "credentials_per_gpu": count, "algorithmic_bytes_per_presentation": ab,
                        "parallelism": "host-sharded x%d, no collective" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "kernel": "k_msm",
-                         "launches_per_step": msm_launches / args.steps, "avg_launch_ms": msm_ms / max(1, msm_launches),
-                         "kernel_ms_per_step": msm_ms / args.steps, "other_kernels_ms_per_step": {"k_hash": hash_ms / args.steps}},
+            "roofline": roofline_of(kt, "show", ab, count),
             "valu": valu, "cpu_baseline": None}))
     issuer.close()
     user.close()
@@ -366,7 +394,7 @@ def valu_side(ctx, items_per_step, field_kernel_ms_per_step):
     achieved = mads * items_per_step / (field_kernel_ms_per_step / 1e3) / 1e12 if field_kernel_ms_per_step > 0 else 0.0
     return {"unit": "T multiply-adds/s (v_mad_i64_i32)", "achieved": achieved, "peak": MAD_PEAK_T, "frac": achieved / MAD_PEAK_T,
             "peak_source": "tools/ubench/valu_rates.hip on this GPU (no published figure)", "per_item": dict(st, mads=mads),
-            "time_base": "summed durations of the kernels doing field arithmetic (k_msm, k_decode, k_pointop)"}
+            "time_base": "summed durations of the kernels doing field arithmetic (k_msm_*, k_decode, k_pointop, k_from_uniform)"}
 
 
 def main():
@@ -374,7 +402,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["c5", "show"])
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS) + ["c5", "show"],
+                    help="default: c3 on one GPU (the largest single-GPU configuration of BASELINE.json), c4 (2^22 presentations split "
+                         "over the ranks) on several")
     ap.add_argument("--batch", type=int, default=0, help="presentations per GPU (default: the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -386,6 +416,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("AFX_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if args.workload is None:
+        args.workload = "c3" if world == 1 else "c4"
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
@@ -445,7 +477,7 @@ def main():
         step()
     torch.cuda.synchronize()
     got = status.cpu().numpy()
-    if not np.array_equal(got, want):
+    if not np.array_equal(got, want) and not UNCHECKED:
         bad = np.nonzero(got != want)[0]
         raise SystemExit("status mismatch at %d items, first %s" % (bad.size, bad[:8]))
     issuer.set_pipelining(args.pipelining)
@@ -456,11 +488,8 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    msm_ms, msm_launches = issuer.get_timing("k_msm")
-    hash_ms, _ = issuer.get_timing("k_hash")
-    dec_ms, _ = issuer.get_timing("k_decode")
-    pop_ms, _ = issuer.get_timing("k_pointop")
-    valu = valu_side(issuer, count, (msm_ms + dec_ms + pop_ms) / args.steps)
+    kt = kernel_times(issuer, args.steps)
+    valu = valu_side(issuer, count, sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS + ("k_decode", "k_pointop")))
     issuer.set_timing(False)
     issuer.set_pipelining(False)
     if dist is not None:
@@ -468,7 +497,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     got = status.cpu().numpy()
-    assert np.array_equal(got, want), "status mismatch after the timed steps"
+    assert UNCHECKED or np.array_equal(got, want), "status mismatch after the timed steps"
     # PCIe-inclusive rate through the host-pointer entry point (never `value`; DESIGN.md quotes it)
     pcie = None
     if rank == 0:
@@ -478,7 +507,7 @@ def main():
         t0 = time.perf_counter()
         afx.check(afx.lib().afx_verify_presentations(issuer.h, C.byref(shape), C.byref(hsoa), count, hst.ctypes.data))
         pcie = count / (time.perf_counter() - t0)
-        assert np.array_equal(hst, want)
+        assert UNCHECKED or np.array_equal(hst, want)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is an N=1 figure
@@ -516,8 +545,6 @@ def main():
     if rank == 0:
         total = count * world * args.steps
         ab = algorithmic_bytes(shape)
-        per_step_msm_s = msm_ms / 1e3 / args.steps
-        achieved = ab * count / per_step_msm_s / 1e9 if per_step_msm_s > 0 else 0.0
         out = {
             "metric": "credential presentations verified/sec", "value": total / elapsed, "unit": "presentations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -527,14 +554,12 @@ def main():
                        "algorithmic_bytes_per_presentation": ab, "parallelism": "host-sharded x%d, no collective" % world,
                        "step_pipelining": "2 streams" if args.pipelining else "off",
                        "input_generation_s": round(gen_s, 2), "host_pointer_api_presentations_per_s": pcie},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": measured_traffic(args.workload),
-                         "kernel": "k_msm", "launches_per_step": msm_launches / args.steps,
-                         "avg_launch_ms": msm_ms / max(1, msm_launches), "kernel_ms_per_step": msm_ms / args.steps,
-                         "other_kernels_ms_per_step": {"k_hash": hash_ms / args.steps, "k_decode": dec_ms / args.steps},
-                         "note": "integer-ALU bound path: the compute-side figure is in \"valu\""},
+            "roofline": roofline_of(kt, args.workload, ab, count),
             "valu": valu,
             "cpu_baseline": cpu,
         }
+        if UNCHECKED:
+            out["unchecked_experiment"] = True
         print(json.dumps(out))
     issuer.close()
     if dist is not None:

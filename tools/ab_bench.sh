@@ -8,12 +8,12 @@ cp $LIB /tmp/ab_default.so
 for r in $(seq $ROUNDS); do
   for which in /tmp/ab_default.so "$@"; do
     cp $which $LIB
-    python bench.py --workload $WL --steps 10 --warmup 2 2>/dev/null | python -c "
+    python bench.py --workload $WL --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); r = d['roofline']
-        print('%-50s' % '$which', round(d['value']), 'ms/step', round(d['ms_per_step'], 3), 'k_msm', round(r['kernel_ms_per_step'], 3), r['other_kernels_ms_per_step'])"
+        print('%-40s' % '$which', round(d['value']), 'ms/step', round(d['ms_per_step'], 3), 'k_msm*', round(r['kernel_ms_per_step'], 3), r.get('kernels_ms_per_step', r.get('other_kernels_ms_per_step')))"
   done
 done
 cp /tmp/ab_default.so $LIB

@@ -1,32 +1,50 @@
 #!/usr/bin/env python3
-"""profiles/r01_traffic.json from the PMC databases written by tools/collect_traffic.sh.
-traffic per launch = 2 x FETCH_SIZE (gfx950 reports half the bytes of wide reads, MI355X_MICROARCH §HBM) + WRITE_SIZE,
-both counters in KB, averaged over the k_msm launches of the timed steps (the last `launches` dispatches)."""
+"""profiles/rNN_traffic.json from the PMC databases written by tools/collect_profiles.sh.
+Per kernel: HBM bytes per launch = 2 x FETCH_SIZE (gfx950 reports half the bytes of wide reads, MI355X_MICROARCH §HBM)
++ WRITE_SIZE, both counters in KB, averaged over the launches of the TIMED steps of the bench run under the profiler:
+the last steps x launches_per_step dispatches of the kernel (launches_per_step from the bench's own JSON line).
+Usage: traffic_json.py out.json workload:fetch_db:write_db:bench_log ..."""
 import json
 import sqlite3
 import sys
 
+KERNELS = {"k_msm_window": "%k_msm<1>%", "k_msm_naf": "%k_msm<2>%", "k_msm_fixed": "%k_msm<0>%", "k_msm_tables": "%k_msm_tables%",
+           "k_decode": "%k_decode%", "k_hash": "%k_hash%"}
 
-def per_dispatch(path, kernel="k_msm"):
+
+def per_dispatch(path, like):
     db = sqlite3.connect(path)
     t = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
     kd = next(x for x in t if "kernel_dispatch" in x); ks = next(x for x in t if "kernel_symbol" in x)
     pe = next(x for x in t if "rocpd_pmc_event" in x)
-    q = f"""select d.dispatch_id, sum(p.value), max(d.grid_size_x) from {pe} p join {kd} d on p.event_id = d.event_id
-            join {ks} s on d.kernel_id = s.id where s.display_name like '{kernel}%' group by d.dispatch_id order by d.dispatch_id"""
-    return db.execute(q).fetchall()
+    q = f"""select d.dispatch_id, sum(p.value) from {pe} p join {kd} d on p.event_id = d.event_id
+            join {ks} s on d.kernel_id = s.id where s.display_name like ? group by d.dispatch_id order by d.dispatch_id"""
+    return [r[1] for r in db.execute(q, (like,))]
 
 
 def main(out, *specs):
     res = {}
-    for spec in specs:   # workload:fetch_db:write_db:launches
-        w, f, wr, n = spec.split(":")
-        n = int(n)
-        fe = [r[1] for r in per_dispatch(f)][-n:]
-        wb = [r[1] for r in per_dispatch(wr)][-n:]
-        res[w] = (2 * sum(fe) / len(fe) + sum(wb) / len(wb)) * 1024.0
-        print(w, "FETCH_SIZE avg KB", sum(fe) / len(fe), "WRITE_SIZE avg KB", sum(wb) / len(wb), "-> bytes/launch", res[w])
-    json.dump(res, open(out, "w"))
+    for spec in specs:
+        w, f, wr, log = spec.split(":")
+        line = [l for l in open(log) if l.startswith("{")][-1]
+        bench = json.loads(line)
+        steps = bench["steps"]
+        res[w] = {}
+        for k, like in KERNELS.items():
+            per_step = bench["roofline"]["kernel_launches_per_step"].get(k)
+            if per_step is None:
+                continue
+            fe, wb = per_dispatch(f, like), per_dispatch(wr, like)
+            if not fe or not wb:
+                continue
+            # the timed steps are the run's last launches of this kernel (the verification bench adds a host-pointer pass of
+            # the same statement after them: identical launches)
+            n = min(int(round(steps * per_step)), len(fe), len(wb))
+            fe, wb = fe[-n:], wb[-n:]
+            res[w][k] = (2 * sum(fe) / len(fe) + sum(wb) / len(wb)) * 1024.0
+            print("%s %-14s launches averaged %3d  FETCH_SIZE avg KB %14.1f  WRITE_SIZE avg KB %14.1f  -> bytes/launch %.4g" %
+                  (w, k, n, sum(fe) / len(fe), sum(wb) / len(wb), res[w][k]))
+    json.dump(res, open(out, "w"), indent=1)
 
 
 if __name__ == "__main__":
