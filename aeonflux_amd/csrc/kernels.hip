@@ -257,9 +257,13 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_scalarop(const afx_scalarop_job* 
 // Field work per 4-bit window: 4 doublings (4 x 4S + 3 x 3M + 4M), 8M per variable term (the last addition of a
 // window skips the T coordinate, -1M); 7M per fixed-base addition.  Assembler::msm (engine.cpp) counts the same
 // schedule for afx_ctx_get_plan_stats.
-// Experiment switch (never in the shipped build; results are wrong with it): every lane gathers item 0's window table,
-// so the gathers hit L1/L2 and the chain runs as if table traffic were free - the upper bound on what any table-layout
-// or table-size change can gain (profiles/r02_traffic_experiments.txt).
+// Experiment switches (never in the shipped build; most give wrong results, bench.py runs them with AFX_BENCH_UNCHECKED=1;
+// DESIGN.md §4, profiles/r02_traffic_experiments.txt):
+//   AFX_EXPERIMENT_ALIAS_TABLES        every lane gathers item 0's window table: the gathers hit L1/L2 and the chain runs as
+//                                      if table traffic were free - the upper bound on any table-layout or -size change
+//   AFX_EXPERIMENT_WINDOW_ENTRY_MAJOR  4-bit-window tables laid out [entry][item] like the NAF tables (results stay right)
+//   AFX_EXPERIMENT_NO_IDENTITY_ENTRY   entry 0 (the identity) is not written (1/9 of the table bytes)
+//   AFX_EXPERIMENT_W3                  cost/traffic emulation of signed 3-bit windows: 85 windows x 3 doublings, 5-entry tables
 #ifdef AFX_EXPERIMENT_ALIAS_TABLES
 #define AFX_TABLE_ITEM(item) ((item) & 0u)
 #else
@@ -279,8 +283,17 @@ AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w,
   const int d = (int)((word >> (((uint32_t)w & 7) * 4)) & 15u) - 8;
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
   const bool neg = (d < 0) != (e.job->term[t].negate != 0);
-  const int32_t* tab = e.table_ws + ((size_t)(e.tslot + t) * e.count + AFX_TABLE_ITEM(e.item)) * AFX_VAR_TABLE_DWORDS;
-  return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(tab + idx * AFX_TABLE_ENTRY_DWORDS), neg), next);
+#ifdef AFX_EXPERIMENT_W3
+  const uint32_t idx3 = idx > 4 ? idx - 4 : idx;   // cost/traffic emulation of signed 3-bit windows: 5-entry tables (results are wrong)
+#else
+  const uint32_t idx3 = idx;
+#endif
+#ifdef AFX_EXPERIMENT_WINDOW_ENTRY_MAJOR
+  const int32_t* ent = e.table_ws + (size_t)(e.tslot + t) * e.count * AFX_VAR_TABLE_DWORDS + ((size_t)idx3 * e.count + AFX_TABLE_ITEM(e.item)) * AFX_TABLE_ENTRY_DWORDS;
+#else
+  const int32_t* ent = e.table_ws + ((size_t)(e.tslot + t) * e.count + AFX_TABLE_ITEM(e.item)) * AFX_VAR_TABLE_DWORDS + idx3 * AFX_TABLE_ENTRY_DWORDS;
+#endif
+  return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent), neg), next);
 }
 // acc += (AFX_POS_BITS-bit signed digit j) * 2^(AFX_POS_BITS*j) * (generator of term t), from the positional tables
 AFX_DEV ge_p3 msm_add_positional(const msm_env& e, const int32_t* __restrict__ pos_tables, const ge_p3& acc, uint32_t t, uint32_t j, int next) {
@@ -344,10 +357,17 @@ AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, const ge_
     }
   } else {
     const ge_cached cP = ge_p3_to_cached_reduced(P);
+#ifndef AFX_EXPERIMENT_NO_IDENTITY_ENTRY
     cached_store(tab, ge_cached_identity());
+#endif
     cached_store(tab + stride, cP);
+#ifdef AFX_EXPERIMENT_W3
+    const int entries = 5;
+#else
+    const int entries = AFX_TABLE_ENTRIES;
+#endif
 #pragma unroll 1
-    for (int k = 2; k < AFX_TABLE_ENTRIES; k++) {
+    for (int k = 2; k < entries; k++) {
       Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
       cached_store(tab + k * stride, ge_p3_to_cached_reduced(Q));
     }
@@ -386,8 +406,12 @@ k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table
   const afx_table_job row = rows[blockIdx.y];
   int32_t* slot = table_ws + (size_t)row.table_slot * count * AFX_VAR_TABLE_DWORDS;
   const ge_p3 P = var_load(row.var, count, item);
+#ifdef AFX_EXPERIMENT_WINDOW_ENTRY_MAJOR
+  msm_build_table<ODD>(slot + (size_t)item * AFX_TABLE_ENTRY_DWORDS, (size_t)count * AFX_TABLE_ENTRY_DWORDS, P);
+#else
   if (ODD) msm_build_table<true>(slot + (size_t)item * AFX_TABLE_ENTRY_DWORDS, (size_t)count * AFX_TABLE_ENTRY_DWORDS, P);
   else msm_build_table<false>(slot + (size_t)item * AFX_VAR_TABLE_DWORDS, AFX_TABLE_ENTRY_DWORDS, P);
+#endif
 }
 
 template <int KIND>
@@ -435,17 +459,23 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
         }
       }
     } else {
+#ifdef AFX_EXPERIMENT_W3
+      const int top_w = 84, dbl_to_p2 = 2;   // 85 windows of 3 bits (digits re-read from the 4-bit stream: wrong results, right cost)
+#else
+      const int top_w = 63, dbl_to_p2 = 3;
+#endif
 #pragma unroll 1
-      for (int w = 63; w >= 0; w--) {
-        if (w != 63) {
+      for (int wi = top_w; wi >= 0; wi--) {
+        const int w = wi & 63;
+        if (wi != top_w) {
           ge_p2 a2 = ge_p3_to_p2(acc);
 #pragma unroll 1
-          for (int k = 0; k < 3; k++) a2 = ge_p1p1_to_p2_before_dbl(ge_p2_dbl(a2));
+          for (int k = 0; k < dbl_to_p2; k++) a2 = ge_p1p1_to_p2_before_dbl(ge_p2_dbl(a2));
           acc = ge_p1p1_to_p3_for<GE_FOR_ADD>(ge_p2_dbl(a2));
         }
 #pragma unroll 1
         for (uint32_t t = 0; t + 1 < nv; t++) acc = msm_add_var(env, acc, t, w, GE_FOR_ADD);
-        acc = msm_add_var(env, acc, nv - 1, w, w == 0 ? GE_FOR_ANY : GE_FOR_DBL);   // the window's last addition
+        acc = msm_add_var(env, acc, nv - 1, w, wi == 0 ? GE_FOR_ANY : GE_FOR_DBL);   // the window's last addition
       }
     }
     // the fixed bases of a job with variable bases: after the chain (any order gives the same sum)
