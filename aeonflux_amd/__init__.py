@@ -136,6 +136,20 @@ def lib():
         _LIB.afx_ctx_synchronize.argtypes = [C.c_void_p]
         _LIB.afx_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_get_timing.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        _LIB.afx_verify_presentations_range.argtypes = [C.c_void_p, C.POINTER(Shape), C.POINTER(PresentationSoA), C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+        _LIB.afx_issue_range.argtypes = [C.c_void_p, C.POINTER(AttributesSoA), C.POINTER(IssueRandomness), C.c_size_t, C.c_size_t, C.c_size_t,
+                                         C.POINTER(IssuanceSoA), C.c_void_p]
+        _LIB.afx_group_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_uint32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p]
+        _LIB.afx_group_destroy.argtypes = [C.c_void_p]
+        _LIB.afx_group_destroy.restype = None
+        _LIB.afx_group_size.argtypes = [C.c_void_p]
+        _LIB.afx_group_size.restype = C.c_uint32
+        _LIB.afx_group_member.argtypes = [C.c_void_p, C.c_uint32]
+        _LIB.afx_group_member.restype = C.c_void_p
+        _LIB.afx_shard_bounds.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        _LIB.afx_shard_bounds.restype = None
+        _LIB.afx_group_verify_presentations.argtypes = [C.c_void_p, C.POINTER(Shape), C.POINTER(PresentationSoA), C.c_size_t, C.c_void_p]
+        _LIB.afx_group_issue.argtypes = [C.c_void_p, C.POINTER(AttributesSoA), C.POINTER(IssueRandomness), C.c_size_t, C.POINTER(IssuanceSoA), C.c_void_p]
         if hasattr(_LIB, "afx_issuer_keygen"):
             _LIB.afx_issuer_keygen.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p]
     return _LIB
@@ -149,12 +163,15 @@ def check(rc):
 class Context:
     """An issuer-side (key given) or user-side (key=None) engine context on one GPU."""
 
-    def __init__(self, sysparams, amacs_key, issuer_params, device=0):
-        h = C.c_void_p()
-        check(lib().afx_ctx_create(C.byref(h), device, sysparams, len(sysparams), amacs_key, len(amacs_key) if amacs_key else 0,
-                                   issuer_params))
-        self.h = h
-        self.n = lib().afx_ctx_n_attributes(h)
+    def __init__(self, sysparams, amacs_key, issuer_params, device=0, _borrowed=None):
+        if _borrowed is not None:   # a member of a Group: owned by the group
+            self.h, self._owned = _borrowed, False
+        else:
+            h = C.c_void_p()
+            check(lib().afx_ctx_create(C.byref(h), device, sysparams, len(sysparams), amacs_key, len(amacs_key) if amacs_key else 0,
+                                       issuer_params))
+            self.h, self._owned = h, True
+        self.n = lib().afx_ctx_n_attributes(self.h)
         self.device = device
 
     @property
@@ -163,7 +180,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().afx_ctx_destroy(self.h)
+            if self._owned:
+                lib().afx_ctx_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -234,3 +252,41 @@ class Context:
     def verify_encryption_proofs(self, index, soa, count, status_ptr, device_pointers=False):
         fn = lib().afx_verify_encryption_proofs_dev if device_pointers else lib().afx_verify_encryption_proofs
         check(fn(self.h, index, C.byref(soa), count, status_ptr))
+
+
+class Group:
+    """The issuer on several GPUs of one node (afx_group_*): one context per listed device, batches split contiguously,
+    one host thread per member, no collective.  The same device may be listed more than once."""
+
+    def __init__(self, sysparams, amacs_key, issuer_params, devices):
+        h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        check(lib().afx_group_create(C.byref(h), devs, len(devices), sysparams, len(sysparams), amacs_key, len(amacs_key) if amacs_key else 0,
+                                     issuer_params))
+        self.h = h
+        self.devices = list(devices)
+        self.n = self.member(0).n
+
+    def __len__(self):
+        return lib().afx_group_size(self.h)
+
+    def member(self, i):
+        m = lib().afx_group_member(self.h, i)
+        if not m:
+            raise IndexError(i)
+        return Context(None, None, None, device=self.devices[i], _borrowed=C.c_void_p(m))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().afx_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def shard_bounds(count, members, index):
+    """(first, n) of member `index`: the library's contiguous split (afx_shard_bounds)"""
+    first, n = C.c_size_t(0), C.c_size_t(0)
+    lib().afx_shard_bounds(count, members, index, C.byref(first), C.byref(n))
+    return first.value, n.value

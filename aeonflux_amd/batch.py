@@ -29,9 +29,10 @@ def _attrs(kinds, values):
     return s
 
 
-def issue(ctx, kinds, values, t_wide, U_wide, rng_seed):
+def issue(ctx, kinds, values, t_wide, U_wide, rng_seed, first=None, n=None):
     """Issuer::issue over a batch.  values [n,count,32], t_wide/U_wide [count,64], rng_seed [count,32].
-    Returns (dict(t,U,V,challenge,responses[n+5,count,32]), status[count])."""
+    Returns (dict(t,U,V,challenge,responses[n+5,count,32]), status[count]).  ctx may be a Group (all its GPUs); with
+    first/n only that range of the batch is issued (afx_issue_range; the other output rows stay zero / status 255)."""
     values, t_wide, U_wide, rng_seed = map(_u8, (values, t_wide, U_wide, rng_seed))
     cnt = t_wide.shape[0]
     req = _attrs(kinds, values)
@@ -40,7 +41,12 @@ def issue(ctx, kinds, values, t_wide, U_wide, rng_seed):
     o["responses"] = np.zeros((ctx.n + 5, cnt, 32), np.uint8)
     out = IssuanceSoA(*(o[k].ctypes.data for k in ("t", "U", "V", "challenge", "responses")))
     status = np.full(cnt, 255, np.uint8)
-    check(lib().afx_issue(ctx.h, C.byref(req), C.byref(rnd), cnt, C.byref(out), status.ctypes.data))
+    if first is not None:
+        check(lib().afx_issue_range(ctx.h, C.byref(req), C.byref(rnd), cnt, first, n, C.byref(out), status.ctypes.data))
+    elif hasattr(ctx, "member"):
+        check(lib().afx_group_issue(ctx.h, C.byref(req), C.byref(rnd), cnt, C.byref(out), status.ctypes.data))
+    else:
+        check(lib().afx_issue(ctx.h, C.byref(req), C.byref(rnd), cnt, C.byref(out), status.ctypes.data))
     return o, status
 
 
@@ -118,13 +124,19 @@ def presentation_soa(p, ptr=lambda a: a.ctypes.data):
     return soa, encs
 
 
-def verify_presentations(ctx, shape, p):
-    """Issuer::verify over a batch of presentations held in host numpy arrays."""
+def verify_presentations(ctx, shape, p, first=None, n=None):
+    """Issuer::verify over a batch of presentations held in host numpy arrays.  ctx may be a Group (all its GPUs); with
+    first/n only that range is verified (afx_verify_presentations_range; the other status bytes stay 255)."""
     p = dict(p, **{f: _u8(p[f]) for f in PRES_FIELDS}, enc=[{f: _u8(d[f]) for f in ENC_FIELDS} for d in p["enc"]])
     cnt = p["challenge"].shape[0]
     soa, keep = presentation_soa(p)
     status = np.full(cnt, 255, np.uint8)
-    check(lib().afx_verify_presentations(ctx.h, C.byref(shape), C.byref(soa), cnt, status.ctypes.data))
+    if first is not None:
+        check(lib().afx_verify_presentations_range(ctx.h, C.byref(shape), C.byref(soa), cnt, first, n, status.ctypes.data))
+    elif hasattr(ctx, "member"):
+        check(lib().afx_group_verify_presentations(ctx.h, C.byref(shape), C.byref(soa), cnt, status.ctypes.data))
+    else:
+        check(lib().afx_verify_presentations(ctx.h, C.byref(shape), C.byref(soa), cnt, status.ctypes.data))
     return status
 
 

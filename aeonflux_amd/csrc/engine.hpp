@@ -72,8 +72,6 @@ struct afx_ctx {
   const uint8_t* const_one() const { return (const uint8_t*)d_consts.p; }
   std::vector<afx::Enc> host_key;               // w, w', x0, x1, y...; wiped on destroy
   const int32_t* gen_ext(uint32_t id) const { return (const int32_t*)d_gen_ext.p + (size_t)id * AFX_VAR_DWORDS; }
-  // per-call scratch (grow-only; zeroed on destroy)
-  afx::DevBuf staging;
   // Execution lanes.  A lane = one HIP stream + its own workspace + a two-deep ring of (pinned host, device) plan
   // blobs (`blob_event[i]` marks the end of the copy that last used slot i, so a call can be assembled while the
   // previous one still runs).  Lane 0's stream is `stream`.  With pipelining off (default) every call runs on lane 0,
@@ -89,6 +87,9 @@ struct afx_ctx {
     int blob_next = 0;
     hipEvent_t msm_done = nullptr;   // end of this lane's latest k_msm launch
     bool msm_recorded = false;
+    afx::DevBuf staging;             // host-pointer front ends: the call's inputs and outputs in HBM (grow-only; zeroed on destroy)
+    void* pin = nullptr;             // pinned bounce buffer for results (a device-to-host copy into pageable memory would
+    size_t pin_cap = 0;              // block the host until the kernels end and serialise the two lanes)
   } lane[2];
   bool pipelining = false;
   bool strict = false;   // afx_ctx_set_strict
@@ -100,7 +101,7 @@ struct afx_ctx {
   size_t trace_rows = 0, trace_count = 0;
   afx::DevBuf trace_buf;
   unsigned lane_next = 0;
-  int force_lane0 = 0;   // host-pointer front ends stay on lane 0 (they read results back on `stream`)
+  int force_lane = -1;   // >= 0: every *_dev call runs on this lane (host-pointer front ends pick the lane they staged on)
   // optional per-launch HIP-event timing on `stream` (bench.py's roofline figure)
   bool timing = false;
   struct TimedLaunch { int kind; hipEvent_t start, stop; };

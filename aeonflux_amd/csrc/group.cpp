@@ -1,0 +1,83 @@
+// Several devices behind one call: a group holds one context per device, each with its own copy of the
+// parameters, key and generator tables.  A batch call splits [0, count) into contiguous ranges, one per member, runs
+// the members' range calls (afx_*_range: staging slices on two streams, results through pinned buffers) on one host thread
+// per member, and every member writes its part of the caller's arrays: no data moves between devices and there is no
+// collective.  This is what one `&self` method of the reference (Issuer::verify, /root/reference/src/issuer.rs:141-147;
+// Issuer::issue, :111-124) becomes when the issuer owns a node of GPUs.
+#include <string>
+#include <thread>
+#include <vector>
+#include "statements.hpp"
+
+struct afx_group {
+  std::vector<afx_ctx*> members;
+};
+
+extern "C" int afx_group_create(afx_group** out, const int* devices, uint32_t n_devices, const uint8_t* sysparams, size_t sysparams_len,
+                                const uint8_t* amacs_key, size_t amacs_key_len, const uint8_t issuer_params[64]) {
+  if (!out || !devices || n_devices == 0 || n_devices > 64) { set_error("bad device list"); return AFX_E_BAD_ARGS; }
+  *out = nullptr;
+  afx_group* g = new afx_group();
+  for (uint32_t i = 0; i < n_devices; i++) {
+    afx_ctx* c = nullptr;
+    const int rc = afx_ctx_create(&c, devices[i], sysparams, sysparams_len, amacs_key, amacs_key_len, issuer_params);
+    if (rc) {
+      const std::string why = afx_last_error();
+      for (afx_ctx* m : g->members) afx_ctx_destroy(m);
+      delete g;
+      set_error("member " + std::to_string(i) + " (device " + std::to_string(devices[i]) + "): " + why);
+      return rc;
+    }
+    g->members.push_back(c);
+  }
+  *out = g;
+  return AFX_OK;
+}
+extern "C" void afx_group_destroy(afx_group* g) {
+  if (!g) return;
+  for (afx_ctx* m : g->members) afx_ctx_destroy(m);
+  delete g;
+}
+extern "C" uint32_t afx_group_size(const afx_group* g) { return g ? (uint32_t)g->members.size() : 0; }
+extern "C" afx_ctx* afx_group_member(afx_group* g, uint32_t i) { return (g && i < g->members.size()) ? g->members[i] : nullptr; }
+
+// contiguous split of [0, count) over m members: the first count % m members take one item more
+extern "C" void afx_shard_bounds(size_t count, uint32_t members, uint32_t index, size_t* first, size_t* n) {
+  if (!first || !n) return;
+  if (members == 0 || index >= members) { *first = 0; *n = 0; return; }
+  const size_t base = count / members, extra = count % members;
+  *first = (size_t)index * base + (index < extra ? index : extra);
+  *n = base + (index < extra ? 1 : 0);
+}
+
+// one host thread per member; the first failure (lowest member index) is reported, with its message
+template <class F>
+static int run_members(afx_group* g, size_t count, F&& call) {
+  const uint32_t m = (uint32_t)g->members.size();
+  std::vector<int> rcs(m, AFX_OK);
+  std::vector<std::string> errs(m);
+  std::vector<std::thread> threads;
+  auto body = [&](uint32_t i) {
+    size_t first = 0, n = 0;
+    afx_shard_bounds(count, m, i, &first, &n);
+    if (n == 0) return;
+    rcs[i] = call(g->members[i], first, n);
+    if (rcs[i]) errs[i] = afx_last_error();   // the error string is per thread
+  };
+  for (uint32_t i = 1; i < m; i++) threads.emplace_back(body, i);
+  body(0);
+  for (std::thread& t : threads) t.join();
+  for (uint32_t i = 0; i < m; i++)
+    if (rcs[i]) { set_error("member " + std::to_string(i) + ": " + errs[i]); return rcs[i]; }
+  return AFX_OK;
+}
+
+extern "C" int afx_group_verify_presentations(afx_group* g, const afx_shape* shape, const afx_presentation_soa* batch, size_t count, uint8_t* status) {
+  if (!g || g->members.empty() || !shape || !batch || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  return run_members(g, count, [&](afx_ctx* c, size_t first, size_t n) { return afx_verify_presentations_range(c, shape, batch, count, first, n, status); });
+}
+extern "C" int afx_group_issue(afx_group* g, const afx_attributes_soa* requests, const afx_issue_randomness* rnd, size_t count,
+                               const afx_issuance_soa* out, uint8_t* status) {
+  if (!g || g->members.empty() || !requests || !rnd || !out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  return run_members(g, count, [&](afx_ctx* c, size_t first, size_t n) { return afx_issue_range(c, requests, rnd, count, first, n, out, status); });
+}

@@ -152,7 +152,10 @@ extern "C" void afx_ctx_destroy(afx_ctx* c) {
   // Zeroize + Drop of amacs::SecretKey (src/amacs.rs:64-82): wipe every copy of the key and anything derived
   c->d_key.release(true);
   for (auto& L : c->lane) L.ws.release(true);
-  c->staging.release(true);
+  for (auto& L : c->lane) {
+    L.staging.release(true);
+    if (L.pin) { memset(L.pin, 0, L.pin_cap); (void)hipHostFree(L.pin); L.pin = nullptr; L.pin_cap = 0; }
+  }
   c->trace_buf.release(false);
   c->d_pos_tables.release(true);
   c->d_gen_ext.release(true);
@@ -226,7 +229,7 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   if ((rc = c->d_gen_enc.ensure(32 * (size_t)c->ngen)) ||
       (rc = c->d_pos_tables.ensure(sizeof(int32_t) * AFX_POS_TABLE_DWORDS * (size_t)c->ngen)) ||
       (rc = c->d_gen_ext.ensure(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)c->ngen)) || (rc = c->d_key.ensure(32 * (size_t)(4 + n))) ||
-      (rc = c->d_consts.ensure(64)) || (rc = c->staging.ensure(32 * (size_t)c->ngen + 4 * (size_t)c->ngen)))
+      (rc = c->d_consts.ensure(64)) || (rc = c->lane[0].staging.ensure(32 * (size_t)c->ngen + 4 * (size_t)c->ngen)))
     return rc;
   for (auto& L : c->lane)
     for (int i = 0; i < 2; i++) {
@@ -239,8 +242,8 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   std::vector<uint8_t> flat(32 * (size_t)c->ngen);
   for (uint32_t i = 0; i < c->ngen; i++) memcpy(flat.data() + 32 * (size_t)i, c->gen_enc[i].data(), 32);
   AFX_HIP(hipMemcpyAsync(c->d_gen_enc.p, flat.data(), flat.size(), hipMemcpyHostToDevice, c->stream));
-  uint8_t* d_neg = (uint8_t*)c->staging.p;
-  uint32_t* d_ok = (uint32_t*)((uint8_t*)c->staging.p + 32 * (size_t)c->ngen);
+  uint8_t* d_neg = (uint8_t*)c->lane[0].staging.p;
+  uint32_t* d_ok = (uint32_t*)((uint8_t*)c->lane[0].staging.p + 32 * (size_t)c->ngen);
   AFX_HIP(afxk_setup_generators(c->stream, (const uint8_t*)c->d_gen_enc.p, c->ngen, (int32_t*)c->d_gen_ext.p, d_neg, d_ok));
   // window bases 2^(AFX_POS_BITS*j) * G go through lane 0's workspace (free at this point), then the tables
   if ((rc = c->lane[0].ws.ensure(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)c->ngen * AFX_POS_WINDOWS))) return rc;
@@ -502,9 +505,9 @@ extern "C" int afx_verify_encryption_proofs_dev(afx_ctx* ctx, uint16_t index, co
 // host-pointer front ends: stage the SoA batch into HBM, run the *_dev form, fetch the status bytes
 // ------------------------------------------------------------------------------------------------
 
-static void stage_encproof(Stager& st, const afx_encproof_soa& e, size_t count, size_t offs[9]) {
+static void stage_encproof(Stager& st, const afx_encproof_soa& e, size_t total, size_t first, size_t n, size_t offs[9]) {
   const uint8_t* f[9] = { e.challenge, e.responses, e.pk, e.E1, e.E2, e.C_y_1, e.C_y_2, e.C_y_3, e.C_y_2p };
-  for (int i = 0; i < 9; i++) offs[i] = st.add(f[i], 32 * count * (i == 1 ? 6 : 1));
+  for (int i = 0; i < 9; i++) offs[i] = st.add_rows(f[i], i == 1 ? 6 : 1, 32, total, first, n);
 }
 static afx_encproof_soa dev_encproof(const Stager& st, const size_t offs[9]) {
   afx_encproof_soa d = { st.dev(offs[0]), st.dev(offs[1]), st.dev(offs[2]), st.dev(offs[3]), st.dev(offs[4]),
@@ -512,36 +515,53 @@ static afx_encproof_soa dev_encproof(const Stager& st, const size_t offs[9]) {
   return d;
 }
 
-extern "C" int afx_verify_presentations(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* b, size_t count, uint8_t* status) {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
-  if (!ctx || !shape || !b || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  if (count == 0) return AFX_OK;
+// Items [first, first + n) of a batch of `total` presentations held in host memory; `status` is the batch's status array
+// (element first + i answers item first + i), so that callers sharding one batch over several contexts share every array.
+// The range is cut into slices that alternate between the context's two lanes: while one slice is verified, the next is
+// copied to HBM (">= 2 chunks per device to overlap H2D with compute").
+static int verify_presentations_host(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* b, size_t total, size_t first, size_t n,
+                                     uint8_t* status) {
+  if (n == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
+  if (!ctx->has_key) { set_error("Issuer::verify needs the issuer key"); return AFX_E_NO_KEY; }
   {
     // a shape every item fails on says nothing reliable about the arrays' extents: answer without reading them
     uint32_t keep[AFX_MAX_ATTRIBUTES], pos[AFX_MAX_ATTRIBUTES], k = 0;
     int slot[AFX_MAX_ATTRIBUTES];
-    if (presentation_shape_rejects(ctx, *shape, keep, &k, slot, pos)) { memset(status, AFX_ST_VERIFICATION_FAILURE, count); return AFX_OK; }
+    if (presentation_shape_rejects(ctx, *shape, keep, &k, slot, pos)) { memset(status + first, AFX_ST_VERIFICATION_FAILURE, n); return AFX_OK; }
   }
-  const uint32_t n = shape->n_attributes, nr = shape->n_responses, ne = shape->n_enc_proofs;
-  if (!b->challenge || !b->C_x_0 || !b->C_x_1 || !b->C_V || (n && !b->C_y) || (nr && !b->responses) || (ne && !b->enc)) { set_error("null batch array"); return AFX_E_BAD_ARGS; }
-  Stager st(ctx);
-  const size_t o_ch = st.add(b->challenge, 32 * count), o_rs = st.add(b->responses, 32 * count * nr), o_x0 = st.add(b->C_x_0, 32 * count),
-               o_x1 = st.add(b->C_x_1, 32 * count), o_cv = st.add(b->C_V, 32 * count), o_cy = st.add(b->C_y, 32 * count * n),
-               o_av = st.add(b->attr_values, b->attr_values ? 32 * count * n : 0);
-  std::vector<std::array<size_t, 9>> eo(ne);
-  for (uint32_t e = 0; e < ne; e++) stage_encproof(st, b->enc[e], count, eo[e].data());
-  const size_t o_st = st.add(nullptr, count);
-  int rc = st.upload();
-  if (rc) return rc;
-  std::vector<afx_encproof_soa> de(ne);
-  for (uint32_t e = 0; e < ne; e++) de[e] = dev_encproof(st, eo[e].data());
-  afx_presentation_soa d = { st.dev(o_ch), st.dev(o_rs), st.dev(o_x0), st.dev(o_x1), st.dev(o_cv), st.dev(o_cy), st.dev(o_av), de.data() };
-  if ((rc = afx_verify_presentations_dev(ctx, shape, &d, count, st.dev(o_st)))) return rc;
-  AFX_HIP(hipMemcpyAsync(status, st.dev(o_st), count, hipMemcpyDeviceToHost, ctx->stream));
-  AFX_HIP(hipStreamSynchronize(ctx->stream));
-  return AFX_OK;
+  const uint32_t na = shape->n_attributes, nr = shape->n_responses, ne = shape->n_enc_proofs;
+  if (!b->challenge || !b->C_x_0 || !b->C_x_1 || !b->C_V || (na && !b->C_y) || (nr && !b->responses) || (ne && !b->enc)) { set_error("null batch array"); return AFX_E_BAD_ARGS; }
+  return host_pipe(ctx, n, [&](Stager& st, size_t off, size_t sn) -> int {
+    const size_t f0 = first + off;
+    const size_t o_ch = st.add_rows(b->challenge, 1, 32, total, f0, sn), o_rs = st.add_rows(b->responses, nr, 32, total, f0, sn),
+                 o_x0 = st.add_rows(b->C_x_0, 1, 32, total, f0, sn), o_x1 = st.add_rows(b->C_x_1, 1, 32, total, f0, sn),
+                 o_cv = st.add_rows(b->C_V, 1, 32, total, f0, sn), o_cy = st.add_rows(b->C_y, na, 32, total, f0, sn),
+                 o_av = st.add_rows(b->attr_values, b->attr_values ? na : 0, 32, total, f0, sn);
+    std::vector<std::array<size_t, 9>> eo(ne);
+    for (uint32_t e = 0; e < ne; e++) stage_encproof(st, b->enc[e], total, f0, sn, eo[e].data());
+    const size_t o_st = st.add(nullptr, sn);
+    st.plan_fetch(status, o_st, 1, 1, total, f0, sn);
+    int rc = st.upload();
+    if (rc) return rc;
+    std::vector<afx_encproof_soa> de(ne);
+    for (uint32_t e = 0; e < ne; e++) de[e] = dev_encproof(st, eo[e].data());
+    afx_presentation_soa d = { st.dev(o_ch), st.dev(o_rs), st.dev(o_x0), st.dev(o_x1), st.dev(o_cv), st.dev(o_cy), st.dev(o_av), de.data() };
+    if ((rc = afx_verify_presentations_dev(ctx, shape, &d, sn, st.dev(o_st)))) return rc;
+    return st.fetch_all();
+  });
+}
+
+extern "C" int afx_verify_presentations_range(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* b, size_t total, size_t first,
+                                              size_t n, uint8_t* status) {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  if (!ctx || !shape || !b || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (first > total || n > total - first) { set_error("range outside the batch"); return AFX_E_BAD_ARGS; }
+  return verify_presentations_host(ctx, shape, b, total, first, n, status);
+}
+extern "C" int afx_verify_presentations(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* b, size_t count, uint8_t* status) {
+  return afx_verify_presentations_range(ctx, shape, b, count, 0, count, status);
 }
 
 extern "C" int afx_verify_encryption_proofs(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* b, size_t count, uint8_t* status) {
@@ -552,7 +572,7 @@ extern "C" int afx_verify_encryption_proofs(afx_ctx* ctx, uint16_t index, const 
   AFX_HIP(hipSetDevice(ctx->device));
   Stager st(ctx);
   size_t eo[9];
-  stage_encproof(st, *b, count, eo);
+  stage_encproof(st, *b, count, 0, count, eo);
   const size_t o_st = st.add(nullptr, count);
   int rc = st.upload();
   if (rc) return rc;

@@ -2,7 +2,9 @@
 // statements_prove.cpp: issuance and presentation provers).
 #pragma once
 #include <string.h>
+#include <algorithm>
 #include <functional>
+#include <memory>
 #include <stdexcept>
 #include <vector>
 #include "engine.hpp"
@@ -28,7 +30,7 @@ using BuildFn = std::function<void(Assembler&, size_t /*chunk offset*/, uint32_t
 inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build) {
   AFX_HIP(hipSetDevice(c->device));
   // all chunks of one call run on one lane; calls alternate lanes only when the caller switched pipelining on
-  const int lane = (c->pipelining && !c->force_lane0) ? (int)(c->lane_next++ & 1u) : 0;
+  const int lane = c->force_lane >= 0 ? c->force_lane : (c->pipelining ? (int)(c->lane_next++ & 1u) : 0);
   uint32_t chunk = c->chunk_items ? c->chunk_items : CHUNK_DEFAULT;
   for (size_t off = 0; off < count;) {
     const uint32_t cc = (uint32_t)std::min<size_t>(chunk, count - off);
@@ -96,16 +98,24 @@ inline void emit(Assembler& as, JobSets& js, uint8_t* status_dev, uint8_t fail_c
   as.finish(status_dev, fail_code);
 }
 
+// Host-pointer front ends: the call's arrays staged into HBM on one of the context's two lanes.  Inputs are copied on the
+// lane's stream; results come back through the lane's pinned buffer (fetch*/drain), so that a front end can keep one slice
+// of a batch computing on one lane while it stages the next slice on the other (statements.cpp, HostPipe).
 struct Stager {
   afx_ctx* c;
-  size_t bytes = 0;
+  int ln;
+  int prev_force;
+  size_t bytes = 0, pin_bytes = 0;
   struct Copy { size_t off; const uint8_t* src; size_t len; };
+  struct Out { uint8_t* dst; size_t pin_off, len; };
   std::vector<Copy> copies;
-  // a staged (host-pointer) call reads its results back on lane 0's stream: keep its device work on lane 0
-  explicit Stager(afx_ctx* ctx) : c(ctx) { c->force_lane0++; }
-  ~Stager() { c->force_lane0--; }
+  std::vector<Out> outs;
+  // the *_dev calls made while this object lives run on its lane
+  explicit Stager(afx_ctx* ctx, int lane = 0) : c(ctx), ln(lane), prev_force(ctx->force_lane) { c->force_lane = lane; }
+  ~Stager() { c->force_lane = prev_force; }
   Stager(const Stager&) = delete;
   Stager& operator=(const Stager&) = delete;
+  hipStream_t stream() const { return c->lane[ln].stream; }
   // reserve `len` bytes, to be filled from host `src` (or left for output when src == nullptr); returns offset
   size_t add(const uint8_t* src, size_t len) {
     const size_t off = (bytes + 255) & ~size_t(255);
@@ -113,11 +123,89 @@ struct Stager {
     if (src) copies.push_back({ off, src, len });
     return off;
   }
+  // items [first, first + n) of a [rows][total][elem] host array -> a contiguous [rows][n][elem] device array
+  size_t add_rows(const uint8_t* src, size_t rows, size_t elem, size_t total, size_t first, size_t n) {
+    const size_t off = (bytes + 255) & ~size_t(255);
+    bytes = off + rows * n * elem;
+    if (src)
+      for (size_t r = 0; r < rows; r++) copies.push_back({ off + r * n * elem, src + (r * total + first) * elem, n * elem });
+    return off;
+  }
   int upload() {
-    int rc = c->staging.ensure(bytes + 256);
+    afx_ctx::Lane& L = c->lane[ln];
+    int rc = L.staging.ensure(bytes + 256);
     if (rc) return rc;
-    for (const Copy& k : copies) AFX_HIP(hipMemcpyAsync((uint8_t*)c->staging.p + k.off, k.src, k.len, hipMemcpyHostToDevice, c->stream));
+    for (const Copy& k : copies) AFX_HIP(hipMemcpyAsync((uint8_t*)L.staging.p + k.off, k.src, k.len, hipMemcpyHostToDevice, L.stream));
     return AFX_OK;
   }
-  uint8_t* dev(size_t off) const { return (uint8_t*)c->staging.p + off; }
+  uint8_t* dev(size_t off) const { return (uint8_t*)c->lane[ln].staging.p + off; }
+  // results: the device array [rows][n][elem] at `off` goes to items [first, first + n) of the host array [rows][total][elem].
+  // plan_fetch() declares them (before reserve_pin); fetch_all() enqueues the copies into the pinned buffer after the
+  // kernels; drain() waits for the lane and scatters them to the caller's arrays.
+  void plan_fetch(uint8_t* dst, size_t off, size_t rows, size_t elem, size_t total, size_t first, size_t n) {
+    if (!dst || !rows || !n) return;
+    pend_.push_back({ off, pin_bytes, rows * n * elem });
+    for (size_t r = 0; r < rows; r++) outs.push_back({ dst + (r * total + first) * elem, pin_bytes + r * n * elem, n * elem });
+    pin_bytes += (rows * n * elem + 63) & ~size_t(63);
+  }
+  int fetch_all() {
+    afx_ctx::Lane& L = c->lane[ln];
+    if (pin_bytes > L.pin_cap) {
+      if (L.pin) { (void)hipHostFree(L.pin); L.pin = nullptr; L.pin_cap = 0; }
+      const size_t want = (pin_bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+      AFX_HIP(hipHostMalloc(&L.pin, want, hipHostMallocDefault));
+      L.pin_cap = want;
+    }
+    for (const Pend& p : pend_) AFX_HIP(hipMemcpyAsync((uint8_t*)L.pin + p.pin_off, dev(p.off), p.len, hipMemcpyDeviceToHost, L.stream));
+    return AFX_OK;
+  }
+  int drain() {
+    afx_ctx::Lane& L = c->lane[ln];
+    AFX_HIP(hipStreamSynchronize(L.stream));
+    for (const Out& o : outs) memcpy(o.dst, (const uint8_t*)L.pin + o.pin_off, o.len);
+    outs.clear();
+    pend_.clear();
+    return AFX_OK;
+  }
+
+ private:
+  struct Pend { size_t off, pin_off, len; };
+  std::vector<Pend> pend_;
 };
+
+// Items per slice of a host-pointer call: slices alternate between the two lanes, so the host-to-device copy of one
+// slice overlaps the kernels of the previous one.  2^17 items keep a pass within 1-2 % of the large-pass rate.
+static constexpr size_t HOST_SLICE_DEFAULT = size_t(1) << 17;
+inline size_t host_slice_items(const afx_ctx* c) {
+  if (c->trace) return ~size_t(0);   // the challenge trace is indexed by the item's position in ONE *_dev call
+  const size_t chunk = c->chunk_items ? c->chunk_items : CHUNK_DEFAULT;
+  return std::min(chunk, HOST_SLICE_DEFAULT);
+}
+// Runs `slice(lane, first, n)` over [0, count) in slices on alternating lanes; `slice` stages, launches and calls
+// fetch_all() on the Stager it is given; the pipe drains a lane before that lane is used again, and both at the end.
+inline int host_pipe(afx_ctx* c, size_t count, const std::function<int(Stager&, size_t, size_t)>& slice) {
+  const int entry_force = c->force_lane;
+  const size_t per = host_slice_items(c);
+  std::unique_ptr<Stager> st[2];
+  int rc = AFX_OK;
+  size_t i = 0;
+  for (size_t off = 0; off < count && !rc; i++) {
+    const size_t n = std::min(per, count - off);
+    const int lane = (int)(i & 1);
+    if (st[lane]) { rc = st[lane]->drain(); st[lane].reset(); }
+    if (rc) break;
+    st[lane].reset(new Stager(c, lane));
+    c->force_lane = lane;
+    rc = slice(*st[lane], off, n);
+    off += n;
+  }
+  for (int k = 0; k < 2; k++) {
+    const int lane = (int)((i + k) & 1);   // oldest first
+    if (st[lane]) { const int r2 = st[lane]->drain(); if (!rc) rc = r2; }
+  }
+  // a failed slice may leave work in flight on the other lane: wait before the Stagers (and the caller's arrays) go away
+  if (rc) for (auto& L : c->lane) if (L.stream) (void)hipStreamSynchronize(L.stream);
+  st[0].reset(); st[1].reset();
+  c->force_lane = entry_force;
+  return rc;
+}

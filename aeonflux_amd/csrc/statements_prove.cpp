@@ -416,8 +416,10 @@ static int fetch(afx_ctx* ctx, void* dst, const uint8_t* src_dev, size_t n) {
   return AFX_OK;
 }
 
-extern "C" int afx_issue(afx_ctx* ctx, const afx_attributes_soa* req, const afx_issue_randomness* rnd, size_t count,
-                         const afx_issuance_soa* out, uint8_t* status) {
+// Requests [first, first + n) of a batch of `total` held in host memory (outputs and status are indexed like the inputs:
+// item i of the batch lands in element i of every output array).  Slices alternate between the two lanes (statements.hpp).
+extern "C" int afx_issue_range(afx_ctx* ctx, const afx_attributes_soa* req, const afx_issue_randomness* rnd, size_t total, size_t first, size_t n,
+                               const afx_issuance_soa* out, uint8_t* status) {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !req || !rnd || !out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -425,29 +427,38 @@ extern "C" int afx_issue(afx_ctx* ctx, const afx_attributes_soa* req, const afx_
     set_error("null batch array");
     return AFX_E_BAD_ARGS;
   }
-  if (count == 0) return AFX_OK;
+  if (first > total || n > total - first) { set_error("range outside the batch"); return AFX_E_BAD_ARGS; }
+  if (n == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
+  if (!ctx->has_key) { set_error("Issuer::issue needs the issuer key"); return AFX_E_NO_KEY; }
   // wrong attribute count: every request is MacCreation (amacs.rs:285-287); the arrays' extents are not trusted then
-  if (req->n_attributes != ctx->n) { memset(status, AFX_ST_MAC_CREATION, count); return AFX_OK; }
+  if (req->n_attributes != ctx->n) { memset(status + first, AFX_ST_MAC_CREATION, n); return AFX_OK; }
   const uint32_t na = req->n_attributes, nr = ctx->n + 5;
-  Stager st(ctx);
-  const size_t o_val = st.add(req->values, 32 * count * na), o_tw = st.add(rnd->t_wide, 64 * count), o_uw = st.add(rnd->U_wide, 64 * count),
-               o_seed = st.add(rnd->rng_seed, 32 * count), o_t = st.add(nullptr, 32 * count), o_U = st.add(nullptr, 32 * count),
-               o_V = st.add(nullptr, 32 * count), o_ch = st.add(nullptr, 32 * count), o_rs = st.add(nullptr, 32 * count * nr),
-               o_st = st.add(nullptr, count);
-  int rc = st.upload();
-  if (rc) return rc;
-  afx_attributes_soa da = *req;
-  da.values = st.dev(o_val);
-  afx_issue_randomness dr = { st.dev(o_tw), st.dev(o_uw), st.dev(o_seed) };
-  afx_issuance_soa dout = { st.dev(o_t), st.dev(o_U), st.dev(o_V), st.dev(o_ch), st.dev(o_rs) };
-  if ((rc = afx_issue_dev(ctx, &da, &dr, count, &dout, st.dev(o_st)))) return rc;
-  if ((rc = fetch(ctx, out->t, st.dev(o_t), 32 * count)) || (rc = fetch(ctx, out->U, st.dev(o_U), 32 * count)) ||
-      (rc = fetch(ctx, out->V, st.dev(o_V), 32 * count)) || (rc = fetch(ctx, out->challenge, st.dev(o_ch), 32 * count)) ||
-      (rc = fetch(ctx, out->responses, st.dev(o_rs), 32 * count * nr)) || (rc = fetch(ctx, status, st.dev(o_st), count)))
-    return rc;
-  AFX_HIP(hipStreamSynchronize(ctx->stream));
-  return AFX_OK;
+  return host_pipe(ctx, n, [&](Stager& st, size_t off, size_t sn) -> int {
+    const size_t f0 = first + off;
+    const size_t o_val = st.add_rows(req->values, na, 32, total, f0, sn), o_tw = st.add_rows(rnd->t_wide, 1, 64, total, f0, sn),
+                 o_uw = st.add_rows(rnd->U_wide, 1, 64, total, f0, sn), o_seed = st.add_rows(rnd->rng_seed, 1, 32, total, f0, sn),
+                 o_t = st.add(nullptr, 32 * sn), o_U = st.add(nullptr, 32 * sn), o_V = st.add(nullptr, 32 * sn), o_ch = st.add(nullptr, 32 * sn),
+                 o_rs = st.add(nullptr, 32 * sn * nr), o_st = st.add(nullptr, sn);
+    st.plan_fetch(out->t, o_t, 1, 32, total, f0, sn);
+    st.plan_fetch(out->U, o_U, 1, 32, total, f0, sn);
+    st.plan_fetch(out->V, o_V, 1, 32, total, f0, sn);
+    st.plan_fetch(out->challenge, o_ch, 1, 32, total, f0, sn);
+    st.plan_fetch(out->responses, o_rs, nr, 32, total, f0, sn);
+    st.plan_fetch(status, o_st, 1, 1, total, f0, sn);
+    int rc = st.upload();
+    if (rc) return rc;
+    afx_attributes_soa da = *req;
+    da.values = st.dev(o_val);
+    afx_issue_randomness dr = { st.dev(o_tw), st.dev(o_uw), st.dev(o_seed) };
+    afx_issuance_soa dout = { st.dev(o_t), st.dev(o_U), st.dev(o_V), st.dev(o_ch), st.dev(o_rs) };
+    if ((rc = afx_issue_dev(ctx, &da, &dr, sn, &dout, st.dev(o_st)))) return rc;
+    return st.fetch_all();
+  });
+}
+extern "C" int afx_issue(afx_ctx* ctx, const afx_attributes_soa* req, const afx_issue_randomness* rnd, size_t count,
+                         const afx_issuance_soa* out, uint8_t* status) {
+  return afx_issue_range(ctx, req, rnd, count, 0, count, out, status);
 }
 
 extern "C" int afx_verify_issuances(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* iss, uint32_t n_responses,

@@ -179,8 +179,10 @@ int afx_ctx_get_plan_stats(afx_ctx* ctx, afx_plan_stats* out);
 
 /* Per-kernel device timing with HIP events on afx_ctx_stream(ctx) (measurement aid; off by default).
  * set_timing(ctx, 1) resets the counters and starts recording every launch; get_timing synchronises the
- * stream and returns the summed duration and launch count of one kernel ("k_msm", "k_hash", "k_decode",
- * "k_pointop", "k_scalarop", "k_sccheck", "k_finish", "k_from_uniform", "k_reduce_wide", "k_fill_u32"). */
+ * stream and returns the summed duration and launch count of one kernel: "k_msm_window", "k_msm_naf", "k_msm_fixed"
+ * (the three multiscalar kernels: per-item windows, uniform width-5 NAF terms, fixed bases only), "k_msm_tables", or
+ * "k_msm" for those four together; "k_hash", "k_decode", "k_pointop", "k_scalarop", "k_sccheck", "k_finish",
+ * "k_from_uniform", "k_reduce_wide", "k_fill_u32". */
 int afx_ctx_set_timing(afx_ctx* ctx, int enable);
 int afx_ctx_get_timing(afx_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
 
@@ -192,6 +194,31 @@ int afx_verify_presentations(afx_ctx* ctx, const afx_shape* shape, const afx_pre
 /* Same, all SoA arrays and `status` in device memory; asynchronous on afx_ctx_stream(ctx). */
 int afx_verify_presentations_dev(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* batch,
                                  size_t count, uint8_t* status_dev);
+
+/* Items [first, first + n) of a batch of `total` presentations.  Every array of `batch` and `status` is the whole batch's
+ * ([k][total][32], status[total]); the call reads and writes only the elements of its range, so several contexts (one per
+ * GPU) can work on one batch from several host threads.  The range is staged to HBM in slices that alternate between
+ * two streams: the copy of one slice overlaps the kernels of the previous one. */
+int afx_verify_presentations_range(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* batch, size_t total,
+                                   size_t first, size_t n, uint8_t* status);
+
+/* ---- several GPUs behind one call -------------------------------------------------------------------
+ * Issuer::verify and Issuer::issue are single `&self` methods in one process (src/issuer.rs:141-147, :111-124).  A group is
+ * that issuer on a node of GPUs: one context per listed device (the same device may be listed twice), each with its own
+ * copy of parameters, key and tables.  A group call splits [0, count) into contiguous ranges (afx_shard_bounds), one host
+ * thread per member runs afx_*_range on its range, and every member writes its part of the caller's arrays.  No data moves
+ * between devices; there is no collective.  Host pointers only.  Settings (strict mode, pass size ...) are per member:
+ * afx_group_member(). */
+typedef struct afx_group afx_group;
+int afx_group_create(afx_group** out, const int* devices, uint32_t n_devices, const uint8_t* sysparams, size_t sysparams_len,
+                     const uint8_t* amacs_key, size_t amacs_key_len, const uint8_t issuer_params[64]);
+void afx_group_destroy(afx_group* group);
+uint32_t afx_group_size(const afx_group* group);
+afx_ctx* afx_group_member(afx_group* group, uint32_t index);
+/* member `index` of `members` takes items [*first, *first + *n): contiguous, the first count % members ranges one item longer */
+void afx_shard_bounds(size_t count, uint32_t members, uint32_t index, size_t* first, size_t* n);
+int afx_group_verify_presentations(afx_group* group, const afx_shape* shape, const afx_presentation_soa* batch, size_t count,
+                                   uint8_t* status);
 
 /* ---- wire format (the reference defines none: presentation.rs:117-127 holds decoded
  *      points and has no to_bytes) ------------------------------------------------------------------
@@ -264,6 +291,12 @@ int afx_issue(afx_ctx* ctx, const afx_attributes_soa* requests, const afx_issue_
               const afx_issuance_soa* out, uint8_t* status);
 int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, const afx_issue_randomness* rnd, size_t count,
                   const afx_issuance_soa* out, uint8_t* status_dev);
+
+/* Requests [first, first + n) of a batch of `total`; arrays are the whole batch's, as for afx_verify_presentations_range. */
+int afx_issue_range(afx_ctx* ctx, const afx_attributes_soa* requests, const afx_issue_randomness* rnd, size_t total, size_t first,
+                    size_t n, const afx_issuance_soa* out, uint8_t* status);
+int afx_group_issue(afx_group* group, const afx_attributes_soa* requests, const afx_issue_randomness* rnd, size_t count,
+                    const afx_issuance_soa* out, uint8_t* status);
 
 /* CredentialIssuance::verify (src/issuer.rs:48-57 -> src/nizk/issuance.rs:132-218), user side. */
 int afx_verify_issuances(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* issuances,

@@ -8,7 +8,8 @@
 #include "../../aeonflux_amd/csrc/kernels.h"
 
 extern "C" {
-hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+// AFX_FAKE_HIP_DEVICES: how many devices the fake runtime reports (default 1)
+hipError_t hipGetDeviceCount(int* n) { const char* d = getenv("AFX_FAKE_HIP_DEVICES"); *n = d ? atoi(d) : 1; return hipSuccess; }
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
 // AFX_FAKE_HIP_MAX_ALLOC (bytes) makes larger single allocations fail, to exercise the engine's out-of-memory handling

@@ -66,3 +66,97 @@ def test_issue_show_verify_round_trip_at_full_size(name, n, layout, hide, count,
             for f in ("pk", "E1", "E2", "C_y_1", "C_y_2", "C_y_3", "C_y_2p"):
                 C.memmove(getattr(q, f), d[f][i].tobytes(), 32)
         assert octx.verify_presentation(p) == int(want[i]), (name, i)
+
+
+def _tile(a, reps):
+    return np.ascontiguousarray(np.concatenate([a] * reps, axis=-2))
+
+
+def test_c4_shards_of_a_2_22_batch_equal_the_unsharded_answer():
+    """BASELINE config 4: 2^22 presentations (C3 statement) host-sharded over 8 GPUs.  One GPU here: the shards of ranks 0
+    and 7 (afx_shard_bounds(2^22, 8, r): 2^19 items each) go through a second context as ranges of the whole batch, and must
+    equal both the expected statuses and the first context's unsharded answer on the same items.  The 2^22 presentations
+    are four copies of 2^20 distinct ones, corrupted independently after the copy (1 % of all items)."""
+    import aeonflux_amd as afx
+    import bench
+    from aeonflux_amd import batch
+    n, layout, hide, fixture = 8, "SSPPEEEE", [4, 5, 6, 7], "c3_8attrs_SSPPeeee"
+    params, key, ip = bench.load_fixture(fixture)
+    issuer = afx.Context(params, key, ip)
+    user = afx.Context(params, None, ip)
+    base, total, chunk = 1 << 20, 1 << 22, 1 << 16
+    parts = [bench.generate(afx, batch, issuer, user, params, n, layout, hide, chunk, 9000 + o) for o in range(0, base, chunk)]
+    shape = parts[0][1]
+    pres = {f: _tile(np.concatenate([p[0][f] for p in parts], axis=-2), total // base) for f in batch.PRES_FIELDS}
+    pres["enc"] = [{f: _tile(np.concatenate([p[0]["enc"][e][f] for p in parts], axis=-2), total // base) for f in batch.ENC_FIELDS}
+                   for e in range(shape.n_enc_proofs)]
+    del parts
+    user.close()
+    want = bench.corrupt(pres, total, 4)
+    assert want.sum() == total // 100
+    whole = batch.verify_presentations(issuer, shape, pres)          # unsharded, 2^22 items through one context
+    assert np.array_equal(whole, want)
+    second = afx.Context(params, key, ip)
+    for r in (0, 7):
+        first, cnt = afx.shard_bounds(total, 8, r)
+        assert cnt == 1 << 19 and first == r << 19
+        part = batch.verify_presentations(second, shape, pres, first=first, n=cnt)
+        assert np.array_equal(part[first:first + cnt], whole[first:first + cnt])
+        assert (part[:first] == 255).all() and (part[first + cnt:] == 255).all()
+    second.close()
+    issuer.close()
+
+
+def test_c5_issue_2_20_credentials_16_attributes():
+    """BASELINE config 5 at its full size on one GPU: 2^20 issuances, 16 attributes (S x8, P x4, E x4).  Every issuance verifies
+    on the user side (CredentialIssuance::verify), exactly the corrupted 1 % are rejected, and the first 64 are the oracle's bytes."""
+    import oracle
+    import aeonflux_amd as afx
+    import bench
+    from aeonflux_amd import batch
+    n, layout, count = 16, "SSSSSSSSPPPPEEEE", 1 << 20
+    params, key, ip = bench.load_fixture("c5_16attrs")
+    issuer = afx.Context(params, key, ip)
+    user = afx.Context(params, None, ip)
+    rng = np.random.default_rng(2020)
+    rb = lambda *s: rng.integers(0, 256, size=s, dtype=np.uint8)
+    kinds = [{"S": afx.ATTR_PUBLIC_SCALAR, "P": afx.ATTR_PUBLIC_POINT, "E": afx.ATTR_EITHER_POINT}[c] for c in layout]
+    values = np.zeros((n, count, 32), np.uint8)
+    for i, c in enumerate(layout):
+        for o in range(0, count, 1 << 18):
+            w = rb(1 << 18, 64)
+            values[i, o:o + (1 << 18)] = batch.scalars_from_wide(issuer, w) if c == "S" else batch.points_from_uniform(issuer, w)
+    tw, uw, seed = rb(count, 64), rb(count, 64), rb(count, 32)
+    iss, st = batch.issue(issuer, kinds, values, tw, uw, seed)
+    assert not st.any()
+    assert not batch.verify_issuances(user, kinds, values, iss).any()
+    octx = oracle.Ctx(params, key, ip)
+    for i in range(64):
+        vals = [bytes(values[k, i]) + bytes(64) for k in range(n)]
+        s, t, U, V, ch, resp = octx.issue(kinds, vals, bytes(tw[i]), bytes(uw[i]), bytes(seed[i]))
+        assert s == 0 and t == bytes(iss["t"][i]) and U == bytes(iss["U"][i]) and V == bytes(iss["V"][i]) and ch == bytes(iss["challenge"][i])
+        assert all(resp[k] == bytes(iss["responses"][k, i]) for k in range(n + 5))
+    # 1 % corrupted: a response bit, the tag's V, an attribute value, the identity as U
+    want = np.zeros(count, np.uint8)
+    idx = np.random.default_rng(3).choice(count, size=count // 100, replace=False)
+    for j, i in enumerate(idx):
+        mode = j % 4
+        if mode == 0:
+            iss["responses"][j % (n + 5), i, 2] ^= 0x20
+        elif mode == 1:
+            iss["V"][i, 9] ^= 0x01
+        elif mode == 2:
+            values[j % 8, i, 0] ^= 0x01       # a scalar attribute changed after issuance
+        else:
+            iss["U"][i, :] = 0
+        want[i] = 1
+    got = batch.verify_issuances(user, kinds, values, iss)
+    assert np.array_equal(got, want)
+    # a sample of the rejected ones through the oracle
+    uctx = oracle.Ctx(params, None, ip)
+    for i in sorted(int(x) for x in idx[:24]):
+        vals = [bytes(values[k, i]) + bytes(64) for k in range(n)]
+        assert uctx.issuance_verify(kinds, vals, bytes(iss["t"][i]), bytes(iss["U"][i]), bytes(iss["V"][i]), bytes(iss["challenge"][i]),
+                                    [bytes(iss["responses"][k, i]) for k in range(n + 5)]) == 1
+    user.close()
+    issuer.close()

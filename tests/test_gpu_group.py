@@ -1,0 +1,114 @@
+"""GPU: one batch over several contexts (include/aeonflux_gpu.h afx_group_*, afx_*_range).
+A two-member group (device 0 listed twice when the box has one GPU, devices 0 and 1 otherwise), explicit ranges and the
+sliced host-pointer pipeline must give the single-context answer, which must be the oracle's."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _devices():
+    import torch
+    return [0, 1] if torch.cuda.device_count() > 1 else [0, 0]
+
+
+def _oracle_statuses(params, key, ip, shape, pres, count):
+    import oracle
+    from aeonflux_amd import batch
+    olib = oracle.load(native=True)
+    olib.afxo_ctx_new.restype = C.c_void_p
+    octx = olib.afxo_ctx_new(params, len(params), key, len(key), ip)
+    osoa, keep = batch.presentation_soa(pres)
+    ost = np.full(count, 255, np.uint8)
+    olib.afxo_verify_presentations_soa(C.c_void_p(octx), C.byref(oracle.Shape.from_buffer_copy(bytes(shape))),
+                                       C.byref(oracle.PresentationSoA.from_buffer_copy(bytes(osoa))), count, ost.ctypes.data, 8)
+    return ost
+
+
+def test_group_ranges_and_slices_equal_one_context_and_the_oracle():
+    import aeonflux_amd as afx
+    import bench
+    from aeonflux_amd import batch
+    params, key, ip = bench.load_fixture("c3_8attrs_SSPPeeee")
+    issuer = afx.Context(params, key, ip)
+    user = afx.Context(params, None, ip)
+    count = 3001
+    pres, shape = bench.generate(afx, batch, issuer, user, params, 8, "SSPPEEEE", [4, 5, 6, 7], count, 2024)
+    user.close()
+    want = bench.corrupt(pres, count, 77)
+    pres["responses"][1, 2999, 4] ^= 2
+    want[2999] = 1
+    one = batch.verify_presentations(issuer, shape, pres)
+    assert np.array_equal(one, want)
+    assert np.array_equal(_oracle_statuses(params, key, ip, shape, pres, count), one)
+    # the group: every member its contiguous part, status concatenated in place
+    grp = afx.Group(params, key, ip, _devices())
+    assert len(grp) == 2
+    assert np.array_equal(batch.verify_presentations(grp, shape, pres), one)
+    # explicit ranges through a second context: three parts, written into one status array
+    other = afx.Context(params, key, ip)
+    merged = np.full(count, 255, np.uint8)
+    for r in range(3):
+        first, n = afx.shard_bounds(count, 3, r)
+        part = batch.verify_presentations(other if r % 2 else issuer, shape, pres, first=first, n=n)
+        assert (part[:first] == 255).all() and (part[first + n:] == 255).all()
+        merged[first:first + n] = part[first:first + n]
+    assert np.array_equal(merged, one)
+    # many small slices on alternating streams (the host-pointer pipeline), ragged tail included
+    other.set_chunk_items(256)
+    assert np.array_equal(batch.verify_presentations(other, shape, pres), one)
+    grp.member(0).set_chunk_items(512)
+    assert np.array_equal(batch.verify_presentations(grp, shape, pres), one)
+    # empty and one-item batches
+    assert len(batch.verify_presentations(grp, shape, {f: (v[..., :0, :] if f != "enc" else [{g: w[..., :0, :] for g, w in d.items()} for d in v])
+                                                       for f, v in pres.items()})) == 0
+    one_item = {f: (v[..., 5:6, :] if f != "enc" else [{g: w[..., 5:6, :] for g, w in d.items()} for d in v]) for f, v in pres.items()}
+    assert batch.verify_presentations(grp, shape, one_item).tolist() == [int(one[5])]
+    grp.close()
+    other.close()
+    issuer.close()
+
+
+def test_group_issue_equals_one_context_and_the_oracle():
+    import oracle
+    import aeonflux_amd as afx
+    import bench
+    from aeonflux_amd import batch
+    n, layout, count = 16, "SSSSSSSSPPPPEEEE", 1500
+    params, key, ip = bench.load_fixture("c5_16attrs")
+    issuer = afx.Context(params, key, ip)
+    rng = np.random.default_rng(11)
+    rb = lambda *s: rng.integers(0, 256, size=s, dtype=np.uint8)
+    kinds = [{"S": afx.ATTR_PUBLIC_SCALAR, "P": afx.ATTR_PUBLIC_POINT, "E": afx.ATTR_EITHER_POINT}[c] for c in layout]
+    values = np.stack([batch.scalars_from_wide(issuer, rb(count, 64)) if c == "S" else batch.points_from_uniform(issuer, rb(count, 64)) for c in layout])
+    values[3, 7] = 0xFF            # a non-canonical scalar attribute: that request fails alone
+    tw, uw, seed = rb(count, 64), rb(count, 64), rb(count, 32)
+    o1, s1 = batch.issue(issuer, kinds, values, tw, uw, seed)
+    assert s1[7] == afx.ST_MAC_CREATION and s1.sum() == afx.ST_MAC_CREATION
+    grp = afx.Group(params, key, ip, _devices())
+    grp.member(1).set_chunk_items(256)
+    o2, s2 = batch.issue(grp, kinds, values, tw, uw, seed)
+    assert np.array_equal(s1, s2)
+    ok = s1 == 0
+    for f in ("t", "U", "V", "challenge", "responses"):
+        assert np.array_equal(o1[f][..., ok, :], o2[f][..., ok, :]), f
+    # a range leaves everything outside it untouched
+    o3, s3 = batch.issue(issuer, kinds, values, tw, uw, seed, first=100, n=50)
+    assert (s3[:100] == 255).all() and (s3[150:] == 255).all() and not s3[100:150].any()
+    assert np.array_equal(o3["responses"][:, 100:150], o1["responses"][:, 100:150]) and not o3["responses"][:, :100].any() and not o3["V"][150:].any()
+    # the oracle's bytes for a few items
+    octx = oracle.Ctx(params, key, ip)
+    for i in (0, 1, 749, 750, 1499):
+        vals = [bytes(values[k, i]) + bytes(64) for k in range(n)]
+        st, t, U, V, ch, resp = octx.issue(kinds, vals, bytes(tw[i]), bytes(uw[i]), bytes(seed[i]))
+        assert st == 0 and t == bytes(o2["t"][i]) and U == bytes(o2["U"][i]) and V == bytes(o2["V"][i]) and ch == bytes(o2["challenge"][i])
+        assert all(resp[k] == bytes(o2["responses"][k, i]) for k in range(n + 5))
+    # and the issued credentials verify on the user side
+    user = afx.Context(params, None, ip)
+    sv = batch.verify_issuances(user, kinds, values, o2)
+    assert not sv[ok].any() and sv[7] == afx.ST_VERIFICATION_FAILURE
+    user.close()
+    grp.close()
+    issuer.close()

@@ -16,10 +16,10 @@ CSRC = os.path.join(ROOT, "aeonflux_amd", "csrc")
 @pytest.fixture(scope="module")
 def hostsim_lib(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("hostsim") / "libafx_hostsim.so")
-    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp")]
     srcs.append(os.path.join(ROOT, "tests", "hostsim", "fake_hip.cpp"))
     cmd = ["g++", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fPIC", "-std=c++17",
-           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-shared", "-o", out] + srcs
+           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-shared", "-pthread", "-o", out] + srcs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         pytest.skip("cannot build the host simulation: " + r.stderr[-400:])
@@ -81,7 +81,56 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     ms = rb(3, 64)
     o = [rb(3, 32) for _ in range(4)]
     assert afx.lib().afx_keypairs_derive(ctx.h, ms.ctypes.data, 3, *(x.ctypes.data for x in o)) == 0
+    # the cold-path entry points that build and destroy a context of their own
+    ks = d["key"][:4 + 32 * (4 + n)]
+    W, ipb = C.create_string_buffer(32), C.create_string_buffer(64)
+    assert afx.lib().afx_issuer_keygen(0, d["params"], len(d["params"]), ks, len(ks), W, ipb) == 0
+    assert afx.lib().afx_issuer_keygen(0, d["params"], len(d["params"]), ks[:-1], len(ks) - 1, W, ipb) == afx.E_BAD_PARAMS
+    stream = bytes(range(256)) * 8
+    pout, used = C.create_string_buffer(8192), C.c_size_t(0)
+    afx.lib().afx_system_parameters_generate(0, n, stream, len(stream), pout, 8192, C.byref(used))   # stub kernels: any rc, no bad access
+    kpsoa = afx.KeypairsSoA(*(x.ctypes.data for x in o))
+    e = [rb(3, 32) for _ in range(8)]
+    stx = rb(3)
+    assert afx.lib().afx_encrypt(ctx.h, C.byref(kpsoa), e[0].ctypes.data, e[1].ctypes.data, e[2].ctypes.data, 3, e[3].ctypes.data, e[4].ctypes.data, stx.ctypes.data) == 0
+    assert afx.lib().afx_decrypt(ctx.h, C.byref(kpsoa), e[3].ctypes.data, e[4].ctypes.data, 3, e[5].ctypes.data, e[6].ctypes.data, e[7].ctypes.data, None, stx.ctypes.data) == 0
+    # a range of a batch, and the same batch over a two-member group (two fake devices)
+    st_r = batch.verify_presentations(ctx, shape, pres, first=1, n=2)
+    assert st_r[0] == 255 and len(st_r) == 3
+    batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32), first=2, n=1)
+    os.environ["AFX_FAKE_HIP_DEVICES"] = "2"
+    grp = afx.Group(d["params"], d["key"], d["ip"], [0, 1])
+    assert len(grp) == 2 and grp.member(1).n == n
+    assert len(batch.verify_presentations(grp, shape, pres)) == 3
+    o2, st2 = batch.issue(grp, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
+    assert len(st2) == 3
+    try:
+        afx.Group(d["params"], d["key"], d["ip"], [0, 2])
+        raise SystemExit("group on a missing device accepted")
+    except afx.AfxError as ex:
+        assert ex.rc == afx.E_NO_DEVICE and b"member 1" in afx.lib().afx_last_error()
+    grp.close()
+    del os.environ["AFX_FAKE_HIP_DEVICES"]
     ctx.close()
+# several slices on alternating lanes (the host-pointer pipeline): 3 slices of 256 items + a tail
+d = make_credentials(4, "SSPE", 1, b"hostsim-pipe")
+ctx = afx.Context(d["params"], d["key"], d["ip"])
+ctx.set_chunk_items(256)
+cntp = 3 * 256 + 17
+zero = lambda *s: np.zeros(s, np.uint8)
+shape = afx.Shape()
+shape.n_attributes, shape.n_responses, shape.n_hidden_scalars, shape.n_enc_proofs = 4, 4, 1, 1
+for i, k in enumerate((1, 0, 2, 3)):
+    shape.kinds[i] = k
+shape.hidden_scalar_indices[0], shape.enc_indices[0] = 0, 3
+bigp = {"challenge": zero(cntp, 32), "responses": zero(4, cntp, 32), "C_x_0": zero(cntp, 32), "C_x_1": zero(cntp, 32), "C_V": zero(cntp, 32),
+        "C_y": zero(4, cntp, 32), "attr_values": zero(4, cntp, 32),
+        "enc": [{f: (zero(6, cntp, 32) if f == "responses" else zero(cntp, 32)) for f in batch.ENC_FIELDS}]}
+stp = batch.verify_presentations(ctx, shape, bigp)
+assert len(stp) == cntp and (stp == 0x5a).all(), stp[:8]      # every status byte came back through the pinned path
+stp = batch.verify_presentations(ctx, shape, bigp, first=300, n=400)
+assert (stp[:300] == 255).all() and (stp[300:700] == 0x5a).all() and (stp[700:] == 255).all()
+ctx.close()
 # a device too small for the default pass: the engine halves the pass size until the workspace fits
 d = make_credentials(4, "SSPE", 1, b"hostsim-oom")
 ctx = afx.Context(d["params"], d["key"], d["ip"])
