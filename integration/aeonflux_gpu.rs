@@ -2,16 +2,43 @@
 // toolchain, so this file has not been compiled here.  It is the `mod gpu` a maintainer would add to the aeonflux
 // crate (/root/reference/src/) together with `build.rs` emitting `cargo:rustc-link-lib=dylib=aeonflux_gpu`.
 //
-// It keeps the crate's own types at the surface: `GpuIssuer::verify_batch(&[ProofOfValidCredential])` has, per
-// item, exactly the result of `Issuer::verify(&presentation)` (src/issuer.rs:141-147).
+// It keeps the crate's own types at the surface, one batch method per call site of the drop-in boundary:
+//   GpuIssuer::verify_batch(&[ProofOfValidCredential])      per item = Issuer::verify            (src/issuer.rs:141-147)
+//   GpuIssuer::issue_batch(Vec<CredentialRequest>, csprng)   per item = Issuer::issue             (src/issuer.rs:111-124)
+//   GpuUser::show_batch(&[AnonymousCredential], ...)         per item = AnonymousCredential::show (src/credential.rs:37-46)
+//   GpuUser::verify_issuance_batch(Vec<CredentialIssuance>)  per item = CredentialIssuance::verify (src/issuer.rs:48-57)
+// and GpuIssuer::new_multi(issuer, &[devices]) puts the same issuer on several GPUs (afx_group_*).
+//
+// Randomness.  The engine takes every random draw as an input array, so the shim draws exactly what the reference draws,
+// in the reference's order:
+//   issue : per request, from the caller's csprng: 64 bytes for `Scalar::random` (t, src/amacs.rs:289), then 64 bytes for
+//           `RistrettoPoint::random` (U, src/amacs.rs:290); then 32 bytes from rand::thread_rng() - the draw zkp's
+//           `prove_compact` makes through merlin's `TranscriptRngBuilder::finalize(&mut thread_rng())` [3P].
+//   show  : per credential, from the caller's csprng: 64 bytes for `Scalar::random` (z, src/nizk/presentation.rs:162); then
+//           from rand::thread_rng(): 32 bytes for the presentation proof's own `prove_compact` (presentation.rs:284), then
+//           32 bytes per ProofOfEncryption, one per SecretPoint attribute in attribute order (presentation.rs:293-309 ->
+//           src/nizk/encryption.rs:141).
+// The #[repr(C)] structs below mirror include/aeonflux_gpu.h field for field; tests/test_integration_layouts.py checks
+// names, order and widths against the header without a Rust compiler.
 #![allow(non_snake_case)]
 
 use core::ffi::c_void;
 
-use crate::amacs::EncryptedAttribute;
+use curve25519_dalek::ristretto::{CompressedRistretto, RistrettoPoint};
+use curve25519_dalek::scalar::Scalar;
+use rand_core::{CryptoRng, RngCore};
+use zkp::CompactProof;
+
+use crate::amacs::{Amac, Attribute, EncryptedAttribute};
+use crate::credential::AnonymousCredential;
 use crate::errors::CredentialError;
-use crate::issuer::Issuer;
+use crate::issuer::{CredentialIssuance, Issuer};
+use crate::nizk::encryption::ProofOfEncryption;
+use crate::nizk::issuance::ProofOfIssuance;
 use crate::nizk::presentation::ProofOfValidCredential;
+use crate::parameters::{IssuerParameters, SystemParameters};
+use crate::symmetric::{Ciphertext, Keypair as SymmetricKeypair, PublicKey as SymmetricPublicKey};
+use crate::user::CredentialRequest;
 
 pub const AFX_MAX_ATTRIBUTES: usize = 32;
 
@@ -38,16 +65,110 @@ pub struct AfxPresentationSoa {
     pub C_y: *const u8, pub attr_values: *const u8, pub enc: *const AfxEncProofSoa,
 }
 
+#[repr(C)]
+pub struct AfxAttributesSoa {
+    pub n_attributes: u32,
+    pub kinds: [u8; AFX_MAX_ATTRIBUTES],
+    pub values: *const u8,
+}
+
+#[repr(C)]
+pub struct AfxIssueRandomness { pub t_wide: *const u8, pub U_wide: *const u8, pub rng_seed: *const u8 }
+
+#[repr(C)]
+pub struct AfxIssuanceSoa { pub t: *mut u8, pub U: *mut u8, pub V: *mut u8, pub challenge: *mut u8, pub responses: *mut u8 }
+
+#[repr(C)]
+pub struct AfxCredentialsSoa {
+    pub n_attributes: u32,
+    pub kinds: [u8; AFX_MAX_ATTRIBUTES],
+    pub values: *const u8, pub M2: *const u8, pub m3: *const u8, pub t: *const u8, pub U: *const u8, pub V: *const u8,
+}
+
+#[repr(C)]
+pub struct AfxKeypairsSoa { pub a: *const u8, pub a0: *const u8, pub a1: *const u8, pub pk: *const u8 }
+
+#[repr(C)]
+pub struct AfxShowRandomness { pub z_wide: *const u8, pub rng_seed: *const u8, pub enc_seeds: *const u8 }
+
+#[repr(C)]
+pub struct AfxEncProofOut {
+    pub challenge: *mut u8, pub responses: *mut u8, pub pk: *mut u8, pub E1: *mut u8, pub E2: *mut u8,
+    pub C_y_1: *mut u8, pub C_y_2: *mut u8, pub C_y_3: *mut u8, pub C_y_2p: *mut u8,
+}
+
+#[repr(C)]
+pub struct AfxPresentationOut {
+    pub challenge: *mut u8, pub responses: *mut u8, pub C_x_0: *mut u8, pub C_x_1: *mut u8, pub C_V: *mut u8,
+    pub C_y: *mut u8, pub attr_values: *mut u8, pub enc: *const AfxEncProofOut,
+}
+
+// per-item status bytes (AFX_ST_*) and amacs::Attribute kinds (AFX_ATTR_*) of include/aeonflux_gpu.h
+const ST_OK: u8 = 0;
+const ST_VERIFICATION_FAILURE: u8 = 1;
+const ST_MAC_CREATION: u8 = 2;
+const ST_NO_SYMMETRIC_KEY: u8 = 3;
+const ATTR_PUBLIC_SCALAR: u8 = 0;
+const ATTR_SECRET_SCALAR: u8 = 1;
+const ATTR_PUBLIC_POINT: u8 = 2;
+const ATTR_EITHER_POINT: u8 = 3;
+const ATTR_SECRET_POINT: u8 = 4;
+
 extern "C" {
     fn afx_ctx_create(out: *mut *mut c_void, device: i32, sysparams: *const u8, sysparams_len: usize,
                       amacs_key: *const u8, amacs_key_len: usize, issuer_params: *const u8) -> i32;
     fn afx_ctx_destroy(ctx: *mut c_void);
     fn afx_verify_presentations(ctx: *mut c_void, shape: *const AfxShape, batch: *const AfxPresentationSoa,
                                 count: usize, status: *mut u8) -> i32;
+    fn afx_issue(ctx: *mut c_void, requests: *const AfxAttributesSoa, rnd: *const AfxIssueRandomness, count: usize,
+                 out: *const AfxIssuanceSoa, status: *mut u8) -> i32;
+    fn afx_verify_issuances(ctx: *mut c_void, attrs: *const AfxAttributesSoa, issuances: *const AfxIssuanceSoa,
+                            n_responses: u32, count: usize, status: *mut u8) -> i32;
+    fn afx_show(ctx: *mut c_void, creds: *const AfxCredentialsSoa, keypairs: *const AfxKeypairsSoa,
+                rnd: *const AfxShowRandomness, count: usize, out: *const AfxPresentationOut, shape_out: *mut AfxShape,
+                status: *mut u8) -> i32;
+    fn afx_group_create(out: *mut *mut c_void, devices: *const i32, n_devices: u32, sysparams: *const u8, sysparams_len: usize,
+                        amacs_key: *const u8, amacs_key_len: usize, issuer_params: *const u8) -> i32;
+    fn afx_group_destroy(group: *mut c_void);
+    fn afx_group_verify_presentations(group: *mut c_void, shape: *const AfxShape, batch: *const AfxPresentationSoa,
+                                      count: usize, status: *mut u8) -> i32;
+    fn afx_group_issue(group: *mut c_void, requests: *const AfxAttributesSoa, rnd: *const AfxIssueRandomness, count: usize,
+                       out: *const AfxIssuanceSoa, status: *mut u8) -> i32;
 }
 
-/// `Issuer` with its parameters, tables and key resident on one MI355X.
-pub struct GpuIssuer { ctx: *mut c_void }
+/// `Issuer` with its parameters, tables and key resident on one MI355X (`ctx`) or on several (`group`: the batch is split
+/// contiguously over the devices inside the library, one host thread per device, no collective).
+pub struct GpuIssuer { ctx: *mut c_void, group: *mut c_void, n: usize }
+
+/// The user's side (no issuer key): `AnonymousCredential::show` and `CredentialIssuance::verify`.
+pub struct GpuUser { ctx: *mut c_void, n: usize }
+
+fn issuer_params_bytes(ip: &IssuerParameters) -> [u8; 64] {
+    let mut b = [0u8; 64];                                            // C_W || I (src/issuer.rs:155,163)
+    b[..32].copy_from_slice(ip.C_W.compress().as_bytes());
+    b[32..].copy_from_slice(ip.I.compress().as_bytes());
+    b
+}
+fn cell(col: &[u8], row: usize, count: usize, item: usize) -> [u8; 32] {
+    let mut b = [0u8; 32];
+    b.copy_from_slice(&col[32 * (row * count + item)..32 * (row * count + item) + 32]);
+    b
+}
+// outputs of the engine are canonical scalars / valid encodings by construction; a failure here is an engine bug
+fn sc(col: &[u8], row: usize, count: usize, item: usize) -> Scalar { Scalar::from_canonical_bytes(cell(col, row, count, item)).expect("engine returned a non-canonical scalar") }
+fn pt(col: &[u8], row: usize, count: usize, item: usize) -> RistrettoPoint { CompressedRistretto(cell(col, row, count, item)).decompress().expect("engine returned an invalid point") }
+
+/// amacs::Attribute (src/amacs.rs:168-179) -> kind byte + the 32-byte value the tag and the proofs use (Messages::from_attributes,
+/// src/amacs.rs:225-243: the scalar itself, the point, or a plaintext's M1) + (M2, m3) for plaintext kinds.
+fn attribute_cells(a: &Attribute) -> (u8, [u8; 32], Option<([u8; 32], [u8; 32])>) {
+    match a {
+        Attribute::PublicScalar(m) => (ATTR_PUBLIC_SCALAR, *m.as_bytes(), None),
+        Attribute::SecretScalar(m) => (ATTR_SECRET_SCALAR, *m.as_bytes(), None),
+        Attribute::PublicPoint(M)  => (ATTR_PUBLIC_POINT, *M.compress().as_bytes(), None),
+        Attribute::EitherPoint(p)  => (ATTR_EITHER_POINT, *p.M1.compress().as_bytes(), Some((*p.M2.compress().as_bytes(), *p.m3.as_bytes()))),
+        Attribute::SecretPoint(p)  => (ATTR_SECRET_POINT, *p.M1.compress().as_bytes(), Some((*p.M2.compress().as_bytes(), *p.m3.as_bytes()))),
+    }
+}
 
 /// Column-major staging of a batch: every field one `[count][32]` array, repeated fields `[k][count][32]`.
 struct Columns {
@@ -59,13 +180,67 @@ impl GpuIssuer {
     pub fn new(issuer: &Issuer, device: i32) -> Result<GpuIssuer, CredentialError> {
         let sp = issuer.system_parameters.to_bytes();                 // src/parameters.rs:155-184
         let key = issuer.amacs_key.to_bytes();                        // src/amacs.rs:110-125
-        let mut ip = [0u8; 64];                                       // C_W || I (src/issuer.rs:155,163)
-        ip[..32].copy_from_slice(issuer.issuer_parameters.C_W.compress().as_bytes());
-        ip[32..].copy_from_slice(issuer.issuer_parameters.I.compress().as_bytes());
+        let ip = issuer_params_bytes(&issuer.issuer_parameters);
         let mut ctx = core::ptr::null_mut();
         let rc = unsafe { afx_ctx_create(&mut ctx, device, sp.as_ptr(), sp.len(), key.as_ptr(), key.len(), ip.as_ptr()) };
         if rc != 0 { return Err(CredentialError::NoIssuerKey); }
-        Ok(GpuIssuer { ctx })
+        Ok(GpuIssuer { ctx, group: core::ptr::null_mut(), n: issuer.system_parameters.NUMBER_OF_ATTRIBUTES as usize })
+    }
+
+    /// The same issuer on several GPUs of one node: every batch call below is split contiguously over `devices`.
+    pub fn new_multi(issuer: &Issuer, devices: &[i32]) -> Result<GpuIssuer, CredentialError> {
+        let sp = issuer.system_parameters.to_bytes();
+        let key = issuer.amacs_key.to_bytes();
+        let ip = issuer_params_bytes(&issuer.issuer_parameters);
+        let mut group = core::ptr::null_mut();
+        let rc = unsafe { afx_group_create(&mut group, devices.as_ptr(), devices.len() as u32, sp.as_ptr(), sp.len(), key.as_ptr(), key.len(), ip.as_ptr()) };
+        if rc != 0 { return Err(CredentialError::NoIssuerKey); }
+        Ok(GpuIssuer { ctx: core::ptr::null_mut(), group, n: issuer.system_parameters.NUMBER_OF_ATTRIBUTES as usize })
+    }
+
+    /// Batch `Issuer::issue` (src/issuer.rs:111-124): consumes the requests like the reference does and returns one
+    /// `Result` per request, in order.  All requests must share one attribute layout (same kinds per position).
+    pub fn issue_batch<C: CryptoRng + RngCore>(&self, requests: Vec<CredentialRequest>, csprng: &mut C)
+        -> Vec<Result<CredentialIssuance, CredentialError>>
+    {
+        let count = requests.len();
+        if count == 0 { return Vec::new(); }
+        let na = requests[0].attributes.len();
+        let mut soa = AfxAttributesSoa { n_attributes: na as u32, kinds: [0; AFX_MAX_ATTRIBUTES], values: core::ptr::null() };
+        let mut values = vec![0u8; 32 * na * count];
+        for (i, r) in requests.iter().enumerate() {
+            assert!(r.attributes.len() == na, "issue_batch: mixed attribute counts; group requests by layout first");
+            for (k, a) in r.attributes.iter().enumerate() {
+                let (kind, v, _) = attribute_cells(a);
+                if i == 0 { soa.kinds[k] = kind; } else { assert!(soa.kinds[k] == kind, "issue_batch: mixed attribute kinds"); }
+                values[32 * (k * count + i)..32 * (k * count + i) + 32].copy_from_slice(&v);
+            }
+        }
+        soa.values = values.as_ptr();
+        // the reference's draws, in its order (see the header of this file)
+        let (mut t_wide, mut u_wide, mut seed) = (vec![0u8; 64 * count], vec![0u8; 64 * count], vec![0u8; 32 * count]);
+        for i in 0..count {
+            csprng.fill_bytes(&mut t_wide[64 * i..64 * i + 64]);      // Scalar::random          (src/amacs.rs:289)
+            csprng.fill_bytes(&mut u_wide[64 * i..64 * i + 64]);      // RistrettoPoint::random  (src/amacs.rs:290)
+        }
+        rand::thread_rng().fill_bytes(&mut seed);                     // zkp prove_compact's thread_rng() draw, 32 B per proof
+        let rnd = AfxIssueRandomness { t_wide: t_wide.as_ptr(), U_wide: u_wide.as_ptr(), rng_seed: seed.as_ptr() };
+        let nr = self.n + 5;                                          // w, w', x_0, x_1, y_0..y_{n-1}, "1" (src/nizk/issuance.rs:52-68)
+        let (mut t, mut u, mut v, mut ch, mut rs) = (vec![0u8; 32 * count], vec![0u8; 32 * count], vec![0u8; 32 * count], vec![0u8; 32 * count], vec![0u8; 32 * nr * count]);
+        let out = AfxIssuanceSoa { t: t.as_mut_ptr(), U: u.as_mut_ptr(), V: v.as_mut_ptr(), challenge: ch.as_mut_ptr(), responses: rs.as_mut_ptr() };
+        let mut status = vec![0u8; count];
+        let rc = unsafe {
+            if self.group.is_null() { afx_issue(self.ctx, &soa, &rnd, count, &out, status.as_mut_ptr()) }
+            else { afx_group_issue(self.group, &soa, &rnd, count, &out, status.as_mut_ptr()) }
+        };
+        assert!(rc == 0, "aeonflux_gpu: engine error {}", rc);
+        requests.into_iter().enumerate().map(|(i, request)| {
+            if status[i] == ST_MAC_CREATION { return Err(CredentialError::MacCreation); }   // amacs.rs:285-287 -> errors.rs:141-142
+            assert!(status[i] == ST_OK, "aeonflux_gpu: unexpected issue status {}", status[i]);
+            let amac = Amac { t: sc(&t, 0, count, i), U: pt(&u, 0, count, i), V: pt(&v, 0, count, i) };
+            let proof = CompactProof { challenge: sc(&ch, 0, count, i), responses: (0..nr).map(|k| sc(&rs, k, count, i)).collect() };
+            Ok(CredentialIssuance { proof: ProofOfIssuance(proof), credential: AnonymousCredential { amac, attributes: request.attributes } })
+        }).collect()
     }
 
     /// Batch `Issuer::verify`.  All presentations must share one shape (same attribute kinds, hidden indices and
@@ -82,14 +257,160 @@ impl GpuIssuer {
             C_x_1: cols.c_x_1.as_ptr(), C_V: cols.c_v.as_ptr(), C_y: cols.c_y.as_ptr(), attr_values: cols.attr_values.as_ptr(),
             enc: enc_soa.as_ptr() };
         let mut status = vec![0u8; count];
-        let rc = unsafe { afx_verify_presentations(self.ctx, &shape, &soa, count, status.as_mut_ptr()) };
+        let rc = unsafe {
+            if self.group.is_null() { afx_verify_presentations(self.ctx, &shape, &soa, count, status.as_mut_ptr()) }
+            else { afx_group_verify_presentations(self.group, &shape, &soa, count, status.as_mut_ptr()) }
+        };
         assert!(rc == 0, "aeonflux_gpu: engine error {}", rc);
         status.iter().map(|s| if *s == 0 { Ok(()) } else { Err(CredentialError::VerificationFailure) }).collect()
     }
 }
 
 impl Drop for GpuIssuer {
-    fn drop(&mut self) { unsafe { afx_ctx_destroy(self.ctx) } }   // wipes every key copy (src/amacs.rs:64-82)
+    // wipes every key copy, host and device (Zeroize + Drop of amacs::SecretKey, src/amacs.rs:64-82)
+    fn drop(&mut self) { unsafe { if self.group.is_null() { afx_ctx_destroy(self.ctx) } else { afx_group_destroy(self.group) } } }
+}
+
+impl GpuUser {
+    pub fn new(system_parameters: &SystemParameters, issuer_parameters: &IssuerParameters, device: i32) -> Result<GpuUser, CredentialError> {
+        let sp = system_parameters.to_bytes();
+        let ip = issuer_params_bytes(issuer_parameters);
+        let mut ctx = core::ptr::null_mut();
+        let rc = unsafe { afx_ctx_create(&mut ctx, device, sp.as_ptr(), sp.len(), core::ptr::null(), 0, ip.as_ptr()) };
+        if rc != 0 { return Err(CredentialError::NoSystemParameters); }
+        Ok(GpuUser { ctx, n: system_parameters.NUMBER_OF_ATTRIBUTES as usize })
+    }
+
+    /// Batch `AnonymousCredential::show` (src/credential.rs:37-46 -> src/nizk/presentation.rs:139-321).  One keypair per
+    /// credential (or `None`: a credential with a SecretPoint attribute then yields `NoSymmetricKey`, presentation.rs:150-157).
+    /// All credentials must share one layout after their hide_attribute / reveal_attribute calls.
+    pub fn show_batch<C: CryptoRng + RngCore>(&self, creds: &[AnonymousCredential], keypairs: Option<&[SymmetricKeypair]>, csprng: &mut C)
+        -> Vec<Result<ProofOfValidCredential, CredentialError>>
+    {
+        let count = creds.len();
+        if count == 0 { return Vec::new(); }
+        let na = creds[0].attributes.len();
+        let mut cs = AfxCredentialsSoa { n_attributes: na as u32, kinds: [0; AFX_MAX_ATTRIBUTES], values: core::ptr::null(), M2: core::ptr::null(),
+                                         m3: core::ptr::null(), t: core::ptr::null(), U: core::ptr::null(), V: core::ptr::null() };
+        let (mut values, mut m2, mut m3) = (vec![0u8; 32 * na * count], vec![0u8; 32 * na * count], vec![0u8; 32 * na * count]);
+        let (mut t, mut u, mut v) = (vec![0u8; 32 * count], vec![0u8; 32 * count], vec![0u8; 32 * count]);
+        for (i, c) in creds.iter().enumerate() {
+            assert!(c.attributes.len() == na, "show_batch: mixed attribute counts");
+            for (k, a) in c.attributes.iter().enumerate() {
+                let (kind, val, plain) = attribute_cells(a);
+                if i == 0 { cs.kinds[k] = kind; } else { assert!(cs.kinds[k] == kind, "show_batch: mixed attribute kinds"); }
+                let at = 32 * (k * count + i);
+                values[at..at + 32].copy_from_slice(&val);
+                if let Some((p2, s3)) = plain { m2[at..at + 32].copy_from_slice(&p2); m3[at..at + 32].copy_from_slice(&s3); }
+            }
+            t[32 * i..32 * i + 32].copy_from_slice(c.amac.t.as_bytes());
+            u[32 * i..32 * i + 32].copy_from_slice(c.amac.U.compress().as_bytes());
+            v[32 * i..32 * i + 32].copy_from_slice(c.amac.V.compress().as_bytes());
+        }
+        cs.values = values.as_ptr(); cs.M2 = m2.as_ptr(); cs.m3 = m3.as_ptr(); cs.t = t.as_ptr(); cs.U = u.as_ptr(); cs.V = v.as_ptr();
+        let hs = (0..na).filter(|k| cs.kinds[*k] == ATTR_SECRET_SCALAR).count();
+        let secret_points: Vec<usize> = (0..na).filter(|k| cs.kinds[*k] == ATTR_SECRET_POINT).collect();
+        let nsp = secret_points.len();
+        // keypairs (symmetric::Keypair, src/symmetric.rs:52-81)
+        let (mut ka, mut ka0, mut ka1, mut kpk) = (vec![0u8; 32 * count], vec![0u8; 32 * count], vec![0u8; 32 * count], vec![0u8; 32 * count]);
+        if let Some(kps) = keypairs {
+            assert!(kps.len() == count, "show_batch: one keypair per credential");
+            for (i, kp) in kps.iter().enumerate() {
+                ka[32 * i..32 * i + 32].copy_from_slice(kp.secret.a.as_bytes());
+                ka0[32 * i..32 * i + 32].copy_from_slice(kp.secret.a0.as_bytes());
+                ka1[32 * i..32 * i + 32].copy_from_slice(kp.secret.a1.as_bytes());
+                kpk[32 * i..32 * i + 32].copy_from_slice(kp.public.pk.compress().as_bytes());
+            }
+        }
+        let kp_soa = AfxKeypairsSoa { a: ka.as_ptr(), a0: ka0.as_ptr(), a1: ka1.as_ptr(), pk: kpk.as_ptr() };
+        // the reference's draws, in its order (see the header of this file)
+        let (mut z_wide, mut seed, mut enc_seeds) = (vec![0u8; 64 * count], vec![0u8; 32 * count], vec![0u8; 32 * count * nsp.max(1)]);
+        for i in 0..count { csprng.fill_bytes(&mut z_wide[64 * i..64 * i + 64]); }   // Scalar::random (presentation.rs:162)
+        rand::thread_rng().fill_bytes(&mut seed);                                     // the presentation proof's prove_compact (:284)
+        rand::thread_rng().fill_bytes(&mut enc_seeds);                                // then one per ProofOfEncryption (:301)
+        let rnd = AfxShowRandomness { z_wide: z_wide.as_ptr(), rng_seed: seed.as_ptr(), enc_seeds: enc_seeds.as_ptr() };
+        // outputs
+        let col = |k: usize| vec![0u8; 32 * k * count];
+        let (mut o_ch, mut o_rs, mut o_x0, mut o_x1, mut o_cv, mut o_cy, mut o_av) = (col(1), col(3 + hs), col(1), col(1), col(1), col(na), col(na));
+        let mut enc_cols: Vec<[Vec<u8>; 9]> = (0..nsp).map(|_| [col(1), col(6), col(1), col(1), col(1), col(1), col(1), col(1), col(1)]).collect();
+        let enc_out: Vec<AfxEncProofOut> = enc_cols.iter_mut().map(|e| AfxEncProofOut {
+            challenge: e[0].as_mut_ptr(), responses: e[1].as_mut_ptr(), pk: e[2].as_mut_ptr(), E1: e[3].as_mut_ptr(), E2: e[4].as_mut_ptr(),
+            C_y_1: e[5].as_mut_ptr(), C_y_2: e[6].as_mut_ptr(), C_y_3: e[7].as_mut_ptr(), C_y_2p: e[8].as_mut_ptr() }).collect();
+        let out = AfxPresentationOut { challenge: o_ch.as_mut_ptr(), responses: o_rs.as_mut_ptr(), C_x_0: o_x0.as_mut_ptr(), C_x_1: o_x1.as_mut_ptr(),
+                                       C_V: o_cv.as_mut_ptr(), C_y: o_cy.as_mut_ptr(), attr_values: o_av.as_mut_ptr(), enc: enc_out.as_ptr() };
+        let mut shape = AfxShape { n_attributes: 0, kinds: [0; 32], n_responses: 0, n_hidden_scalars: 0, hidden_scalar_indices: [0; 32],
+                                   n_enc_proofs: 0, enc_indices: [0; 32] };
+        let mut status = vec![0u8; count];
+        let rc = unsafe { afx_show(self.ctx, &cs, if keypairs.is_some() { &kp_soa } else { core::ptr::null() }, &rnd, count, &out, &mut shape, status.as_mut_ptr()) };
+        assert!(rc == 0, "aeonflux_gpu: engine error {}", rc);
+        // rebuild ProofOfValidCredential (src/nizk/presentation.rs:118-127) per item
+        (0..count).map(|i| {
+            match status[i] {
+                ST_OK => {}
+                ST_NO_SYMMETRIC_KEY => return Err(CredentialError::NoSymmetricKey),
+                ST_VERIFICATION_FAILURE | _ => return Err(CredentialError::VerificationFailure),
+            }
+            let proof = CompactProof { challenge: sc(&o_ch, 0, count, i), responses: (0..3 + hs).map(|k| sc(&o_rs, k, count, i)).collect() };
+            let encrypted_attributes = (0..na).map(|k| match shape.kinds[k] {
+                0 => EncryptedAttribute::PublicScalar(sc(&o_av, k, count, i)),
+                1 => EncryptedAttribute::SecretScalar,
+                2 => EncryptedAttribute::PublicPoint(pt(&o_av, k, count, i)),
+                _ => EncryptedAttribute::SecretPoint,
+            }).collect();
+            let proofs_of_encryption = (0..nsp).map(|e| {
+                let c = &enc_cols[e];
+                let index = shape.enc_indices[e];
+                (index, ProofOfEncryption {
+                    proof: CompactProof { challenge: sc(&c[0], 0, count, i), responses: (0..6).map(|k| sc(&c[1], k, count, i)).collect() },
+                    public_key: SymmetricPublicKey { pk: pt(&c[2], 0, count, i) },
+                    ciphertext: Ciphertext { E1: pt(&c[3], 0, count, i), E2: pt(&c[4], 0, count, i) },
+                    index,
+                    C_y_1: pt(&c[5], 0, count, i), C_y_2: pt(&c[6], 0, count, i), C_y_3: pt(&c[7], 0, count, i), C_y_2_prime: pt(&c[8], 0, count, i),
+                })
+            }).collect();
+            Ok(ProofOfValidCredential {
+                proof, proofs_of_encryption, encrypted_attributes,
+                hidden_scalar_indices: shape.hidden_scalar_indices[..shape.n_hidden_scalars as usize].to_vec(),
+                C_x_0: pt(&o_x0, 0, count, i), C_x_1: pt(&o_x1, 0, count, i), C_V: pt(&o_cv, 0, count, i),
+                C_y: (0..na).map(|k| pt(&o_cy, k, count, i)).collect(),
+            })
+        }).collect()
+    }
+
+    /// Batch `CredentialIssuance::verify` (src/issuer.rs:48-57): consumes the issuances and moves each credential out on success.
+    pub fn verify_issuance_batch(&self, issuances: Vec<CredentialIssuance>) -> Vec<Result<AnonymousCredential, CredentialError>> {
+        let count = issuances.len();
+        if count == 0 { return Vec::new(); }
+        let na = issuances[0].credential.attributes.len();
+        let nr = issuances[0].proof.0.responses.len();
+        let mut soa = AfxAttributesSoa { n_attributes: na as u32, kinds: [0; AFX_MAX_ATTRIBUTES], values: core::ptr::null() };
+        let mut values = vec![0u8; 32 * na * count];
+        let col = |k: usize| vec![0u8; 32 * k * count];
+        let (mut t, mut u, mut v, mut ch, mut rs) = (col(1), col(1), col(1), col(1), col(nr));
+        for (i, iss) in issuances.iter().enumerate() {
+            assert!(iss.credential.attributes.len() == na && iss.proof.0.responses.len() == nr, "verify_issuance_batch: mixed layouts");
+            for (k, a) in iss.credential.attributes.iter().enumerate() {
+                let (kind, val, _) = attribute_cells(a);
+                if i == 0 { soa.kinds[k] = kind; } else { assert!(soa.kinds[k] == kind, "verify_issuance_batch: mixed attribute kinds"); }
+                values[32 * (k * count + i)..32 * (k * count + i) + 32].copy_from_slice(&val);
+            }
+            t[32 * i..32 * i + 32].copy_from_slice(iss.credential.amac.t.as_bytes());
+            u[32 * i..32 * i + 32].copy_from_slice(iss.credential.amac.U.compress().as_bytes());
+            v[32 * i..32 * i + 32].copy_from_slice(iss.credential.amac.V.compress().as_bytes());
+            ch[32 * i..32 * i + 32].copy_from_slice(iss.proof.0.challenge.as_bytes());
+            for (k, r) in iss.proof.0.responses.iter().enumerate() { rs[32 * (k * count + i)..32 * (k * count + i) + 32].copy_from_slice(r.as_bytes()); }
+        }
+        soa.values = values.as_ptr();
+        let d = AfxIssuanceSoa { t: t.as_mut_ptr(), U: u.as_mut_ptr(), V: v.as_mut_ptr(), challenge: ch.as_mut_ptr(), responses: rs.as_mut_ptr() };
+        let mut status = vec![0u8; count];
+        let rc = unsafe { afx_verify_issuances(self.ctx, &soa, &d, nr as u32, count, status.as_mut_ptr()) };
+        assert!(rc == 0, "aeonflux_gpu: engine error {}", rc);
+        issuances.into_iter().enumerate().map(|(i, iss)| if status[i] == ST_OK { Ok(iss.credential) } else { Err(CredentialError::VerificationFailure) }).collect()
+    }
+}
+
+impl Drop for GpuUser {
+    fn drop(&mut self) { unsafe { afx_ctx_destroy(self.ctx) } }
 }
 
 /// ProofOfValidCredential (src/nizk/presentation.rs:118-127) -> shape + columns.  Lives inside the crate because the
