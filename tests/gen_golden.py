@@ -12,7 +12,9 @@ built or imported here, and holds no golden vectors of its own (SURVEY.md ยง4, ย
   flows.json        whole issue -> show -> verify transcripts for the reference's test layouts
                     (presentation.rs:461-638, issuance.rs:233-295, encryption.rs:222-244) computed by
                     the ORACLE after it passed the two files above: regression + GPU-parity inputs,
-                    NOT an independent pin ("parity unpinned" for the statement layer).
+                    NOT an independent pin ("parity unpinned" for the statement layer).  Before it is written, every
+                    flow is replayed through tests/pyref (a second restatement in pure Python, written
+                    independently of oracle/): all bytes and decisions must agree, or generation fails.
 """
 import ctypes as C
 import hashlib
@@ -273,6 +275,12 @@ def gen_flows():
 if __name__ == "__main__":
     os.makedirs(os.path.join(HERE, "golden"), exist_ok=True)
     for name, fn in (("primitives", gen_primitives), ("kat", gen_kat), ("flows", gen_flows)):
+        data = fn()
+        if name == "flows":
+            # the second restatement must reproduce every byte and decision before the fixture is accepted
+            from tests.test_pyref_cross_check import test_every_flow_replays_byte_for_byte
+            test_every_flow_replays_byte_for_byte(data["flows"])
+            data["_source"] += "; every flow cross-checked byte for byte against tests/pyref (independent pure-Python restatement)"
         with open(os.path.join(HERE, "golden", name + ".json"), "w") as f:
-            json.dump(fn(), f, indent=1)
+            json.dump(data, f, indent=1)
         print("wrote", name)

@@ -1,0 +1,97 @@
+"""CPU-only: tests/golden/flows.json (computed by the C oracle) replayed through the second, independently written
+restatement tests/pyref (pure Python).  Every output byte of issue and show - (t, U, V), challenges, responses, the
+prover's commitments - and every accept / reject decision with its recomputed commitments must be identical.
+The reference pins none of this (no vectors, not buildable here), so parity stays "unpinned by the
+reference"; what this test adds is that two restatements written apart from the Rust sources agree on all of it."""
+import pytest
+
+from tests.pyref import keccak, ristretto, statements as S
+
+H = bytes.fromhex
+
+
+def test_pyref_primitives_against_third_party_vectors(kat, primitives):
+    base = ristretto.decode(H("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76"))
+    assert ristretto.encode(ristretto.add(base, base)).hex() == "6a493210f7499cd17fecb510ae0cea23a110e8d5b901f8acadd3095c73a3b919"
+    t = keccak.Transcript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    # libsodium-computed vectors (tests/gen_golden.py): hash-to-group, scalar multiplication, validity
+    n = 0
+    for v in primitives["from_uniform"]:
+        assert ristretto.encode(ristretto.from_uniform_bytes(H(v["in"]))).hex() == v["out"]
+        n += 1
+    for v in primitives["scalarmult"]:
+        p = ristretto.decode(H(v["p"]))
+        k = int.from_bytes(H(v["s"]), "little")
+        if p is not None and v.get("out") and k < 2**255:   # libsodium clears bit 255 of the scalar
+            assert ristretto.encode(ristretto.mul(k, p)).hex() == v["out"]
+            n += 1
+    for v in primitives["add"]:
+        assert ristretto.encode(ristretto.add(ristretto.decode(H(v["p"])), ristretto.decode(H(v["q"])))).hex() == v["out"]
+    for v in primitives["sub"]:
+        assert ristretto.encode(ristretto.sub(ristretto.decode(H(v["p"])), ristretto.decode(H(v["q"])))).hex() == v["out"]
+    for v in primitives["validity"]:
+        assert (ristretto.decode(H(v["in"])) is not None) == bool(v["valid"]), v["in"]
+        n += 1
+    for v in primitives["scalar_reduce_wide"]:
+        assert ristretto.sc_bytes(ristretto.sc_from_wide(H(v["in"]))).hex() == v["out"]
+    assert n > 600
+
+
+def _values(rec):
+    return [H(v) for v in rec["values"]]
+
+
+def test_every_flow_replays_byte_for_byte(flows):
+    checked = {"issue": 0, "issuance_verify": 0, "show": 0, "verify": 0}
+    for f in flows:
+        params, key, ip = H(f["params"]), H(f["key"]), H(f["issuer_params"])
+        iss = f["issue"]
+        st, o = S.issue(params, key, ip, iss["kinds"], _values(iss), H(iss["t_wide"]), H(iss["U_wide"]), H(iss["rng_seed"]))
+        assert st == iss["status"], f["name"]
+        if st == 0:
+            for k in ("t", "U", "V", "challenge"):
+                assert o[k].hex() == iss[k], (f["name"], k)
+            assert [r.hex() for r in o["responses"]] == iss["responses"], f["name"]
+            assert [c.hex() for c in o["commitments"]] == f["issuance_commitments"], f["name"]
+            checked["issue"] += 1
+            vst, coms = S.issuance_verify(params, ip, iss["kinds"], _values(iss), H(iss["t"]), H(iss["U"]), H(iss["V"]), H(iss["challenge"]),
+                                          [H(r) for r in iss["responses"]])
+            assert vst == f["issuance_verify"], f["name"]
+            if vst == 0:
+                assert [c.hex() for c in coms] == f["issuance_commitments"], f["name"]   # the verifier recomputes the prover's commitments
+            checked["issuance_verify"] += 1
+        sh = f.get("show")
+        if not sh:
+            continue
+        kp = H(sh["keypair"]) if sh.get("keypair") else None
+        st, p = S.show(params, ip, sh["kinds"], _values(sh), H(iss["t"]), H(iss["U"]), H(iss["V"]), kp, H(sh["z_wide"]), H(sh["rng_seed"]),
+                       H(sh["enc_seeds"]))
+        assert st == sh["status"], f["name"]
+        checked["show"] += 1
+        if st != 0:
+            continue
+        want = f["presentation"]
+        for k in ("challenge", "C_x_0", "C_x_1", "C_V"):
+            assert p[k].hex() == want[k], (f["name"], k)
+        assert [r.hex() for r in p["responses"]] == want["responses"] and [c.hex() for c in p["C_y"]] == want["C_y"], f["name"]
+        assert p["kinds"] == want["kinds"] and p["hidden_scalar_indices"] == want["hidden_scalar_indices"], f["name"]
+        assert [v.hex() for v in p["attr_values"]] == want["attr_values"], f["name"]
+        assert len(p["enc"]) == len(want["enc"])
+        for e, we in zip(p["enc"], want["enc"]):
+            for k in ("challenge", "pk", "E1", "E2", "C_y_1", "C_y_2", "C_y_3", "C_y_2p"):
+                assert e[k].hex() == we[k], (f["name"], k)
+            assert [r.hex() for r in e["responses"]] == we["responses"] and e["index"] == we["index"], f["name"]
+        # Issuer::verify on the fixture's presentation (some fixtures are tampered with after show)
+        pres = dict(kinds=want["kinds"], attr_values=[H(v) for v in want["attr_values"]], hidden_scalar_indices=want["hidden_scalar_indices"],
+                    challenge=H(want["challenge"]), responses=[H(r) for r in want["responses"]], C_x_0=H(want["C_x_0"]), C_x_1=H(want["C_x_1"]),
+                    C_V=H(want["C_V"]), C_y=[H(c) for c in want["C_y"]],
+                    enc=[dict(index=we["index"], challenge=H(we["challenge"]), responses=[H(r) for r in we["responses"]],
+                              **{k: H(we[k]) for k in ("pk", "E1", "E2", "C_y_1", "C_y_2", "C_y_3", "C_y_2p")}) for we in want["enc"]])
+        vst, coms = S.verify_presentation(params, key, ip, pres)
+        assert vst == f["verify"], f["name"]
+        if vst == 0:
+            assert [c.hex() for c in coms] == f["verify_last_commitments"], f["name"]
+        checked["verify"] += 1
+    assert checked["issue"] >= 16 and checked["show"] >= 16 and checked["verify"] >= 15, checked
