@@ -13,6 +13,8 @@ const char* last_error() { return g_error.c_str(); }
 int DevBuf::ensure(size_t n) {
   if (n <= cap) return AFX_OK;
   if (p) {
+    // workspace / staging hold blindings, y_i*m_i products, staged user keys, key-derived tables: wipe first
+    if (sensitive) (void)hipMemset(p, 0, cap);
     hipError_t e = hipFree(p);
     p = nullptr; cap = 0;
     if (e != hipSuccess) { set_error(std::string("hipFree: ") + hipGetErrorString(e)); return AFX_E_HIP; }

@@ -30,6 +30,8 @@ const char* last_error();
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  bool sensitive = true;     // holds key-derived or prover-secret data at some point: zeroed before it is freed, also when it
+                             // is only being replaced by a larger (or, after an out-of-memory back-off, smaller) buffer
   int ensure(size_t n);      // grow-only; returns AFX_OK / AFX_E_HIP
   void release(bool wipe);
 };

@@ -193,6 +193,7 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   c->device = device;
   c->n = n;
   c->g = n < 3 ? 3 : n;
+  for (afx::DevBuf* pub : { &c->trace_buf, &c->d_gen_enc, &c->d_consts, &c->d_pos_tables, &c->d_gen_ext }) pub->sensitive = false;   // public data
   AFX_HIP(hipSetDevice(device));
   {
     int cus = 0;
@@ -479,6 +480,21 @@ extern "C" int afx_verify_presentations_dev(afx_ctx* ctx, const afx_shape* shape
   if (shape->n_enc_proofs && shape->n_enc_proofs <= AFX_MAX_ATTRIBUTES && !batch->enc) { set_error("enc proofs missing"); return AFX_E_BAD_ARGS; }
   const afx_shape sh = *shape;
   const afx_presentation_soa b = *batch;
+  {
+    // the arrays a well-formed request reads (a shape every item fails on reads none): a null one is a bad call, not a GPU fault
+    uint32_t keep[AFX_MAX_ATTRIBUTES], pos[AFX_MAX_ATTRIBUTES], k = 0;
+    int slot[AFX_MAX_ATTRIBUTES];
+    if (!presentation_shape_rejects(ctx, sh, keep, &k, slot, pos)) {
+      bool missing = !b.challenge || !b.C_x_0 || !b.C_x_1 || !b.C_V || (sh.n_attributes && !b.C_y) || (sh.n_responses && !b.responses);
+      for (uint32_t i = 0; i < sh.n_attributes; i++)
+        if ((sh.kinds[i] == AFX_ENC_PUBLIC_SCALAR || sh.kinds[i] == AFX_ENC_PUBLIC_POINT) && !b.attr_values) missing = true;
+      for (uint32_t e = 0; e < sh.n_enc_proofs; e++) {
+        const afx_encproof_soa& q = b.enc[e];
+        missing |= !q.challenge || !q.responses || !q.pk || !q.E1 || !q.E2 || !q.C_y_1 || !q.C_y_2 || !q.C_y_3 || !q.C_y_2p;
+      }
+      if (missing) { set_error("null batch array"); return AFX_E_BAD_ARGS; }
+    }
+  }
   std::vector<afx_encproof_soa> encs;
   if (b.enc && sh.n_enc_proofs <= AFX_MAX_ATTRIBUTES) encs.assign(b.enc, b.enc + sh.n_enc_proofs);
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
@@ -494,6 +510,10 @@ extern "C" int afx_verify_encryption_proofs_dev(afx_ctx* ctx, uint16_t index, co
   if (!ctx || !batch || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   const afx_encproof_soa e = *batch;
+  if (index < ctx->n && (!e.challenge || !e.responses || !e.pk || !e.E1 || !e.E2 || !e.C_y_1 || !e.C_y_2 || !e.C_y_3 || !e.C_y_2p)) {
+    set_error("null batch array");
+    return AFX_E_BAD_ARGS;
+  }
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
     JobSets js;
     add_encproof_verify(as, js, index, e, count, off, 0);

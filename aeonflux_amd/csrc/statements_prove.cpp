@@ -101,6 +101,9 @@ extern "C" int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* 
   if (count == 0) return AFX_OK;
   const afx_attributes_soa a = *attrs;
   const afx_issuance_soa s = *iss;
+  // the arrays a well-formed request reads (a request every item fails on reads none): a null one is a bad call, not a GPU fault
+  if (a.n_attributes <= ctx->n && n_responses == ctx->n + 5 &&
+      (!s.t || !s.U || !s.V || !s.challenge || !s.responses || (a.n_attributes && !a.values))) { set_error("null batch array"); return AFX_E_BAD_ARGS; }
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
     afx_ctx* c = as.ctx;
     JobSets js;
@@ -147,6 +150,10 @@ extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, c
   const afx_attributes_soa a = *requests;
   const afx_issue_randomness r = *rnd;
   const afx_issuance_soa o = *out;
+  if (a.n_attributes == ctx->n && (!a.values || !r.t_wide || !r.U_wide || !r.rng_seed || !o.t || !o.U || !o.V || !o.challenge || !o.responses)) {
+    set_error("null batch array");
+    return AFX_E_BAD_ARGS;
+  }
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
     afx_ctx* c = as.ctx;
     const uint32_t n = c->n;
@@ -248,6 +255,18 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
   if (count == 0) return AFX_OK;
   if (nsp && (!cr.M2 || !cr.m3 || !out->enc)) { set_error("hidden group elements need M2, m3 and enc outputs"); return AFX_E_BAD_ARGS; }
   const bool no_key = nsp && !keypairs;   // CredentialError::NoSymmetricKey (:150-157)
+  if (!no_key) {
+    bool missing = !cr.values || !cr.t || !cr.U || !cr.V || !rnd->z_wide || !rnd->rng_seed || !out->challenge || !out->responses || !out->C_x_0 ||
+                   !out->C_x_1 || !out->C_V || !out->C_y;
+    if (nsp) {
+      missing |= !rnd->enc_seeds || !keypairs->a || !keypairs->a0 || !keypairs->a1 || !keypairs->pk;
+      for (uint32_t e = 0; e < nsp; e++) {
+        const afx_encproof_out& q = out->enc[e];
+        missing |= !q.challenge || !q.responses || !q.pk || !q.E1 || !q.E2 || !q.C_y_1 || !q.C_y_2 || !q.C_y_3 || !q.C_y_2p;
+      }
+    }
+    if (missing) { set_error("null batch array"); return AFX_E_BAD_ARGS; }
+  }
   const afx_keypairs_soa kp = keypairs ? *keypairs : afx_keypairs_soa{ nullptr, nullptr, nullptr, nullptr };
   const afx_show_randomness r = *rnd;
   const afx_presentation_out o = *out;

@@ -20,6 +20,12 @@ static afx_msm_job mk_msm(const std::vector<afx_msm_term>& terms, const int32_t*
   j.addend = addend; j.out_var = out_var; j.out_enc = out_enc;
   return j;
 }
+// zeroes a host buffer that held secret-derived bytes when it goes out of scope (whatever the exit path)
+struct WipeOnExit {
+  std::vector<uint8_t>& v;
+  explicit WipeOnExit(std::vector<uint8_t>& b) : v(b) {}
+  ~WipeOnExit() { volatile uint8_t* q = v.data(); for (size_t i = 0; i < v.size(); i++) q[i] = 0; }
+};
 static int sync_fetch(afx_ctx* c, void* dst, const uint8_t* src, size_t n) {
   AFX_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->stream));
   AFX_HIP(hipStreamSynchronize(c->stream));
@@ -169,7 +175,8 @@ extern "C" int afx_keypairs_derive(afx_ctx* ctx, const uint8_t* master_secrets, 
   AFX_HIP(hipSetDevice(ctx->device));
   int rc;
   // a = H(master), a0 = H(a), a1 = H(a0)  (symmetric.rs:202-204)
-  std::vector<uint8_t> wide(64 * count);
+  std::vector<uint8_t> wide(64 * count);   // SHA-512 outputs that reduce to the secret keys
+  WipeOnExit wipe_wide(wide);
   uint8_t* outs[3] = { a, a0, a1 };
   for (int round = 0; round < 3; round++) {
     for (size_t i = 0; i < count; i++) {
@@ -236,6 +243,7 @@ extern "C" int afx_decrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8
   const size_t row = 32 * count;
   int rc;
   std::vector<uint8_t> bad1(count), bad2(count), e1p(row), wide(64 * count);
+  WipeOnExit wipe_wide(wide), wipe_e1p(e1p);   // hashes of the recovered plaintext, candidate E1
   // M1' = E2 - E1*a  (symmetric.rs:278)
   {
     Stager st(ctx);

@@ -126,6 +126,11 @@ shape.hidden_scalar_indices[0], shape.enc_indices[0] = 0, 3
 bigp = {"challenge": zero(cntp, 32), "responses": zero(4, cntp, 32), "C_x_0": zero(cntp, 32), "C_x_1": zero(cntp, 32), "C_V": zero(cntp, 32),
         "C_y": zero(4, cntp, 32), "attr_values": zero(4, cntp, 32),
         "enc": [{f: (zero(6, cntp, 32) if f == "responses" else zero(cntp, 32)) for f in batch.ENC_FIELDS}]}
+# a *_dev call with a null array that the shape needs is refused on the host (it would fault the GPU)
+null_soa, stn = afx.PresentationSoA(), np.zeros(4, np.uint8)
+assert afx.lib().afx_verify_presentations_dev(ctx.h, C.byref(shape), C.byref(null_soa), 4, stn.ctypes.data) == afx.E_BAD_ARGS
+null_enc = afx.EncProofSoA()
+assert afx.lib().afx_verify_encryption_proofs_dev(ctx.h, 3, C.byref(null_enc), 4, stn.ctypes.data) == afx.E_BAD_ARGS
 stp = batch.verify_presentations(ctx, shape, bigp)
 assert len(stp) == cntp and (stp == 0x5a).all(), stp[:8]      # every status byte came back through the pinned path
 stp = batch.verify_presentations(ctx, shape, bigp, first=300, n=400)
