@@ -219,7 +219,8 @@ __global__ void __launch_bounds__(AFX_BLOCK, 2) k_pointop(const afx_pointop_job*
     uint32_t w[8];
     ristretto_encode(w, R);
     enc_store(job.out_enc, item, w);
-    if (job.reject_identity && is_identity_encoding(w)) atomicOr(&bad[item], AFX_BAD_IDENTITY);
+    // 1: the point enters a transcript, the identity is rejected; 2: the point must BE the identity (strict-mode equality check)
+    if (job.reject_identity == 1 ? is_identity_encoding(w) : (job.reject_identity == 2 && !is_identity_encoding(w))) atomicOr(&bad[item], AFX_BAD_IDENTITY);
   }
 }
 

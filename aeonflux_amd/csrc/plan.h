@@ -58,7 +58,7 @@ typedef struct {
   int32_t sa, sb;
   afx_var_t out;           /* may be null                         */
   uint8_t* out_enc;        /* [count][32] compressed, may be null */
-  uint32_t reject_identity;
+  uint32_t reject_identity; /* 1: the identity fails the item; 2: anything BUT the identity fails it */
 } afx_pointop_job;
 
 /* out[i] = a[i or uniform] * b[i] (+ c[i])  mod l ; optionally negated */

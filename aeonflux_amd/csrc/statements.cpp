@@ -452,6 +452,22 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
   for (uint32_t j = 0; j < k; j++) C_y[j] = v.allocate_point("C_y", PointVar::Var(v_Cy[keep[j]], row(b.C_y, keep[j])));
   for (uint32_t i = 0; i < c->g; i++) G_y[i] = v.allocate_point("G_y", PointVar::Const(c->id_Gy(i)));
   for (uint32_t j = 0; j < hs; j++) G_m[j] = v.allocate_point("G_m", PointVar::Const(c->id_Gm(sh.hidden_scalar_indices[j])));
+  // strict mode: C_y[i] - C_y_1 = z*G_y[i] + z*(-G_y[0]) for every hidden group element i and the C_y_1 of its proof of encryption
+  // (the DLEQ of README.md:121-122; the oracle states the reason).  At position 0 the difference must be the identity.
+  int D[AFX_MAX_ATTRIBUTES], D_pos[AFX_MAX_ATTRIBUTES], nD = 0, neg_G_y_1 = -1;
+  if (c->strict)
+    for (uint32_t e = 0; e < sh.n_enc_proofs; e++) {   // presentation_shape_rejects: one proof per hidden group element, in position order
+      const uint32_t i = sh.enc_indices[e];
+      int32_t *v_C1 = as.new_var(), *v_D = as.new_var();
+      uint8_t* e_D = as.new_enc();
+      js.decode.push_back({ row(b.enc[e].C_y_1, 0), v_C1, 0 });
+      afx_pointop_job dj = { v_Cy[i], v_C1, nullptr, +1, -1, v_D, e_D, i == 0 ? 2u /* must BE the identity */ : 1u };
+      js.pointop.push_back(dj);
+      if (i == 0) continue;
+      if (neg_G_y_1 < 0) neg_G_y_1 = v.allocate_point("-G_y_1", PointVar::Const(c->id_Gy(0), true));
+      D[nD] = v.allocate_point("C_y-C_y_1", PointVar::Var(v_D, e_D));
+      D_pos[nD++] = (int)i;
+    }
   const int Z = v.allocate_point("Z", PointVar::Var(v_Z, e_Z));
   v.constrain(Z, { { z, I } });
   v.constrain(C_x_1, { { t, C_x_0 }, { z_0, G_x_0 }, { z, G_x_1 } });
@@ -461,6 +477,7 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
     if (sh.kinds[p] == AFX_ENC_SECRET_SCALAR) v.constrain(C_y[j], { { z, G_y[p] }, { H_s[hidden_slot[j]], G_m[hidden_slot[j]] } });
     else v.constrain(C_y[j], { { z, G_y[p] } });
   }
+  for (int d = 0; d < nD; d++) v.constrain(D[d], { { z, G_y[D_pos[d]] }, { z, neg_G_y_1 } });
   // one launch for everything: the lane that finishes Z goes straight on to constraint #1 (Z = z*I), the only job that needs it
   const size_t first_constraint = js.msm1.size();
   v.verify_compact(row(b.challenge, 0), 0, total, off, js.msm1, js.hash);

@@ -334,6 +334,20 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
       if (cr.kinds[i] != AFX_ATTR_SECRET_POINT) { keep[k] = i; C_y[k++] = p.allocate_point("C_y", PointVar::Var(v_Cy[i], orow(o.C_y, i))); }
     for (uint32_t i = 0; i < c->g; i++) G_y[i] = p.allocate_point("G_y", PointVar::Const(c->id_Gy(i)));
     for (uint32_t j = 0; j < hs; j++) G_m[j] = p.allocate_point("G_m", PointVar::Const(c->id_Gm(sh.hidden_scalar_indices[j])));
+    // strict mode: C_y[i] - C_y_1 = z*G_y[i] + z*(-G_y[0]) for every hidden group element i != 0 and the C_y_1 of its proof of
+    // encryption (the DLEQ of README.md:121-122; the oracle states the reason).  The prover knows the difference in closed form.
+    int D[AFX_MAX_ATTRIBUTES], D_pos[AFX_MAX_ATTRIBUTES], nD = 0, neg_G_y_1 = -1;
+    if (c->strict)
+      for (uint32_t e = 0; e < nsp; e++) {
+        const uint32_t i = sh.enc_indices[e];
+        if (i == 0) continue;   // the difference is the identity by construction
+        if (neg_G_y_1 < 0) neg_G_y_1 = p.allocate_point("-G_y_1", PointVar::Const(c->id_Gy(0), true));
+        int32_t* v_D = as.new_var();
+        uint8_t* e_D = as.new_enc();
+        msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gy(i), false), mk_term(z, 32, nullptr, (int32_t)c->id_Gy(0), true) }, nullptr, v_D, e_D, false));
+        D[nD] = p.allocate_point("C_y-C_y_1", PointVar::Var(v_D, e_D));
+        D_pos[nD++] = (int)i;
+      }
     const int Z = p.allocate_point("Z", PointVar::Var(v_Z, e_Z));
     p.constrain(Z, { { zv, I } });
     p.constrain(C_x_1, { { tv, C_x_0 }, { z_0v, G_x_0 }, { zv, G_x_1 } });
@@ -350,6 +364,7 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
         p.constrain(C_y[j], { { zv, G_y[q] } });
       }
     }
+    for (int d = 0; d < nD; d++) p.constrain(D[d], { { zv, G_y[D_pos[d]] }, { zv, neg_G_y_1 } });
     std::vector<afx_hash_program> rng_hash, chal_hash;
     std::vector<afx_msm_job> commit;
     std::vector<afx_scalarop_job> resp;

@@ -139,8 +139,10 @@ int afx_ctx_synchronize(afx_ctx* ctx);
  *  - afx_verify_presentations requires exactly one proof of encryption per SECRET_POINT attribute, with
  *    enc_indices equal to those positions in increasing order (the reference verifies whatever is attached,
  *    presentation.rs:438-440).
- * The DLEQ between C_y[i] and its proof of encryption that the reference's README.md:121-122 lists as TODO is not
- * part of this mode: no such statement exists in the reference to restate. */
+ *  - the DLEQ the reference's README.md:121-122 lists as TODO: for every hidden group element i the presentation proof also
+ *    shows, with its own nonce z, that C_y[i] - C_y_1 = z*(G_y[i] - G_y[0]), C_y_1 being the commitment inside that
+ *    attribute's proof of encryption (C_y[i] = z*G_y[i] + M1, presentation.rs:173; C_y_1 = z*G_y[0] + M1, encryption.rs:70):
+ *    the plaintext that is proven encrypted is the one the credential commits to.  Prover (afx_show) and verifier. */
 int afx_ctx_set_strict(afx_ctx* ctx, int enable);
 
 /* Items per internal pass (tuning; 0 restores the default of 2^19).  A batch larger than this is processed in passes

@@ -546,7 +546,8 @@ static int encryption_prove(afxo_encproof* out, const afxo_ctx* c, const attr_t*
  * kinds are EncryptedAttribute kinds.  Returns 0 where the reference would panic. */
 static int presentation_statement(zkp_cs* z, const afxo_ctx* c, int prover, uint32_t n_attrs, const uint8_t* kinds,
                                   uint32_t hs, const uint16_t* hidx, const sc* wit /* z, z_0, t, m... */, const ge* C_x_1,
-                                  const ge* C_x_0, const ge* C_y /* [n_attrs] */, const ge* Z) {
+                                  const ge* C_x_0, const ge* C_y /* [n_attrs] */, const ge* Z,
+                                  const ge* C_y_1 /* strict mode: per hidden group element, in position order, the C_y_1 of its proof of encryption */) {
   zkp_init(z, prover, "2019/1416 anonymous credential", "2019/1416 presentation proof");
   int zz = zkp_alloc_scalar(z, "z", prover ? &wit[0] : NULL);
   int z0 = zkp_alloc_scalar(z, "z_0", prover ? &wit[1] : NULL);
@@ -570,6 +571,34 @@ static int presentation_statement(zkp_cs* z, const afxo_ctx* c, int prover, uint
   for (uint32_t j = 0; j < hs; j++) {
     if (hidx[j] >= c->n) return 0; /* G_m[*i] out of range: panic at presentation.rs:407 */
     Gm[j] = PT("G_m", &c->G_m[hidx[j]]);
+  }
+  /* strict mode, the DLEQ the reference's README.md:121-122 lists as TODO: the plaintext committed to in C_y[i] is the one the
+   * proof of encryption is about.  C_y[i] = z G_y[i] + M1 (presentation.rs:173) and C_y_1 = z G_y[0] + M1 (encryption.rs:70), so
+   * C_y[i] - C_y_1 = z G_y[i] + z (-G_y[0]) with the presentation's own z.  For a hidden group element at position 0 the
+   * difference must be the identity, which is checked directly (an identity point cannot enter a zkp transcript). */
+  int Dv[AFX_MAX_ATTRIBUTES], Dpos[AFX_MAX_ATTRIBUTES], nD = 0, negGy1 = -1;
+  if (c->strict && C_y_1) {
+    uint32_t e = 0;
+    for (uint32_t i = 0; i < n_attrs; i++) {
+      if (kinds[i] != AFX_ENC_SECRET_POINT) continue;
+      ge D;
+      ge_sub(&D, &C_y[i], &C_y_1[e]);
+      e++;
+      if (i == 0) {
+        uint8_t de[32];
+        static const uint8_t zero[32] = { 0 };
+        ristretto_encode(de, &D);
+        if (memcmp(de, zero, 32) != 0) return 0;
+        continue;
+      }
+      if (negGy1 < 0) {
+        ge ng;
+        ge_neg(&ng, &c->G_y[0]);
+        negGy1 = PT("-G_y_1", &ng);
+      }
+      Dv[nD] = PT("C_y-C_y_1", &D);
+      Dpos[nD++] = (int)i;
+    }
   }
   int Zv = PT("Z", Z);
 #undef PT
@@ -596,6 +625,10 @@ static int presentation_statement(zkp_cs* z, const afxo_ctx* c, int prover, uint
         zkp_constrain(z, Cy[j], 1, s, q);
       }
       j++;
+    }
+    for (int d = 0; d < nD; d++) {
+      s[0] = zz; q[0] = Gy[Dpos[d]]; s[1] = zz; q[1] = negGy1;
+      zkp_constrain(z, Dv[d], 2, s, q);
     }
     return 1;
   }
@@ -664,8 +697,16 @@ int afxo_show(const afxo_ctx* c, uint32_t n_attrs, const uint8_t* kinds, const u
   ge_scalarmult(&C_x_1, &zn, &c->G_x1); ge_scalarmult(&tmp, &t, &U); ge_add(&C_x_1, &C_x_1, &tmp);
   ge_scalarmult(&C_V, &zn, &c->G_V); ge_add(&C_V, &C_V, &V);
   ge_scalarmult(&Z, &zn, &c->I);
+  ge C_y_1[AFX_MAX_ATTRIBUTES];
+  uint32_t nsp = 0;
+  for (uint32_t i = 0; i < n_attrs; i++)
+    if (ekinds[i] == AFX_ENC_SECRET_POINT) {   /* C_y_1 of the proof of encryption made below (encryption.rs:70) */
+      ge_scalarmult(&C_y_1[nsp], &zn, &c->G_y[0]);
+      ge_add(&C_y_1[nsp], &C_y_1[nsp], &a[i].M1);
+      nsp++;
+    }
   zkp_cs* z = (zkp_cs*)malloc(sizeof *z);
-  if (!presentation_statement(z, c, 1, n_attrs, ekinds, hs, hidx, wit, &C_x_1, &C_x_0, C_y, &Z)) { free(z); return -1; }
+  if (!presentation_statement(z, c, 1, n_attrs, ekinds, hs, hidx, wit, &C_x_1, &C_x_0, C_y, &Z, c->strict ? C_y_1 : NULL)) { free(z); return -1; }
   sc ch, resp[ZKP_MAX_SCALARS];
   zkp_prove_compact(z, rng_seed, &ch, resp);
   free(z);
@@ -704,7 +745,8 @@ int afxo_show(const afxo_ctx* c, uint32_t n_attrs, const uint8_t* kinds, const u
  *    presentations with hidden group elements anywhere verify (the reference only handles trailing ones, App. B);
  *  - the verifier requires exactly one proof of encryption per hidden group element, in position order
  *    (the reference verifies whatever is attached, presentation.rs:438-440).
- * The DLEQ between C_y[i] and the proof of encryption that README.md:121-122 lists as TODO is NOT part of it. */
+ *  - the presentation proof also shows, with its own z, that C_y[i] - C_y_1 = z (G_y[i] - G_y[0]) for every hidden group
+ *    element i and the C_y_1 of its proof of encryption: the DLEQ the reference's README.md:121-122 lists as TODO. */
 void afxo_ctx_set_strict(afxo_ctx* c, int strict) { c->strict = strict != 0; }
 
 int afxo_verify_presentation(const afxo_ctx* c, const afxo_presentation* p) {
@@ -756,8 +798,13 @@ int afxo_verify_presentation(const afxo_ctx* c, const afxo_presentation* p) {
     ge_scalarmult(&t, &c->y[i], &x);
     ge_sub(&Z, &Z, &t);
   }
+  ge C_y_1[AFX_MAX_ATTRIBUTES];
+  if (c->strict)
+    for (uint32_t e = 0; e < p->n_enc_proofs; e++)
+      if (!ristretto_decode(&C_y_1[e], p->enc[e].C_y_1)) return AFX_ST_VERIFICATION_FAILURE;
   zkp_cs* z = (zkp_cs*)malloc(sizeof *z);
-  int ok = presentation_statement(z, c, 0, n_attrs, p->kinds, p->n_hidden_scalars, p->hidden_scalar_indices, NULL, &C_x_1, &C_x_0, C_y, &Z);
+  int ok = presentation_statement(z, c, 0, n_attrs, p->kinds, p->n_hidden_scalars, p->hidden_scalar_indices, NULL, &C_x_1, &C_x_0, C_y, &Z,
+                                  c->strict ? C_y_1 : NULL);
   if (ok) ok = zkp_verify_compact(z, p->challenge, &p->responses[0][0], (int)p->n_responses);
   free(z);
   if (!ok) return AFX_ST_VERIFICATION_FAILURE;

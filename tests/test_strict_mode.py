@@ -1,5 +1,6 @@
-"""Strict mode (opt-in, NOT the reference's behaviour): constraint #3 by own position, and
-exactly one proof of encryption per hidden group element.  The oracle carries the same switch (oracle/aeonflux.c,
+"""Strict mode (opt-in, NOT the reference's behaviour): constraint #3 by own position, exactly one
+proof of encryption per hidden group element, and the DLEQ tying each hidden group element's commitment C_y[i] to the C_y_1
+of its proof of encryption (the TODO of the reference's README.md:121-122).  The oracle carries the same switch (oracle/aeonflux.c,
 afxo_ctx_set_strict), so the GPU path is compared with it byte for byte; the default mode must be unaffected."""
 import numpy as np
 import pytest
@@ -44,17 +45,34 @@ def test_oracle_strict_mode_semantics():
     issuer.set_strict(False)
     user.set_strict(False)
     assert [issuer.verify_presentation(p) for p in strict_pres] == [1, 1, 1]
-    # trailing hidden group elements: both modes produce the same bytes
+    # trailing hidden group element: constraint #3 coincides in both modes, so the commitments are the same bytes; the proof
+    # differs because the strict statement also carries the DLEQ (one more point variable and constraint in the transcript)
     d2 = make_credentials(4, "SSPE", 2, b"strict-oracle-2")
     k2 = [1, 0, 2, 4]
     a, rnd2 = _show_all(d2["user"], d2, k2, 2, d2["take"])
     d2["user"].set_strict(True)
+    strict2 = []
     for p, (c, kp, z, s, e) in zip(a, zip(d2["creds"], *rnd2)):
         st, ps = d2["user"].show(k2, c["values"], c["t"], c["U"], c["V"], kp, z, s, e)
-        assert st == 0 and bytes(ps) == bytes(p)
+        assert st == 0 and bytes(ps.C_x_0) == bytes(p.C_x_0) and bytes(ps.C_y[3]) == bytes(p.C_y[3]) and bytes(ps.enc[0].C_y_1) == bytes(p.enc[0].C_y_1)
+        assert bytes(ps.challenge) != bytes(p.challenge)
+        strict2.append(ps)
     q = oracle.Presentation.from_buffer_copy(bytes(a[0]))
     q.n_enc_proofs = 0
     assert d2["issuer"].verify_presentation(q) == 0    # the reference's behaviour: nothing ties the count to the hidden points
+    # what the DLEQ is for.  Take presentation 0 and attach presentation 1's (perfectly valid) proof of encryption: the
+    # reference accepts the pair although the ciphertext is about another plaintext; strict mode rejects it.
+    swapped = oracle.Presentation.from_buffer_copy(bytes(a[0]))
+    swapped.enc[0] = oracle.EncProof.from_buffer_copy(bytes(a[1].enc[0]))
+    assert d2["issuer"].verify_presentation(swapped) == 0
+    d2["issuer"].set_strict(True)
+    assert [d2["issuer"].verify_presentation(p) for p in strict2] == [0, 0]
+    swapped = oracle.Presentation.from_buffer_copy(bytes(strict2[0]))
+    swapped.enc[0] = oracle.EncProof.from_buffer_copy(bytes(strict2[1].enc[0]))
+    assert d2["issuer"].verify_presentation(swapped) == 1
+    assert [d2["issuer"].verify_presentation(p) for p in a] == [1, 1]     # default-mode proofs carry no DLEQ
+    d2["issuer"].set_strict(False)
+    assert [d2["issuer"].verify_presentation(p) for p in strict2] == [1, 1]
 
 
 @pytest.mark.gpu
@@ -95,13 +113,15 @@ def test_gpu_strict_mode_matches_strict_oracle(n, layout, hide):
         for q in stripped:
             q.n_enc_proofs = nsp - 1
         assert gpu_verify(afx, ictx, stripped) == [issuer.verify_presentation(q) for q in stripped] == [1, 1, 1]
+        # the DLEQ: another presentation's valid proof of encryption in place of the own one is rejected
+        swapped = [oracle.Presentation.from_buffer_copy(bytes(p)) for p in want[6:9]]
+        for q, donor in zip(swapped, want[7:10]):
+            q.enc[0] = oracle.EncProof.from_buffer_copy(bytes(donor.enc[0]))
+        assert gpu_verify(afx, ictx, swapped) == [issuer.verify_presentation(q) for q in swapped] == [1, 1, 1]
     # the same context back in the reference's mode gives the reference's answers again
     ictx.set_strict(False)
     issuer.set_strict(False)
     ref = [issuer.verify_presentation(p) for p in want]
     assert gpu_verify(afx, ictx, want) == ref
-    if layout == "SSPE":
-        assert ref == [0, 1, 1] + [0] * (count - 3)     # trailing hidden group element: the modes coincide
-    else:
-        assert ref == [1] * count                        # strict-mode proofs do not verify under the reference's statement
+    assert ref == [1] * count                            # strict-mode proofs do not verify under the reference's statement
     ictx.close()
