@@ -125,6 +125,7 @@ def lib():
         _LIB.afx_ctx_set_pipelining.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_get_plan_stats.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.afx_ctx_set_strict.argtypes = [C.c_void_p, C.c_int]
+        _LIB.afx_ctx_set_fixed_key_schedule.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_set_chunk_items.argtypes = [C.c_void_p, C.c_uint32]
         _LIB.afx_ctx_issuer_parameters.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.afx_issuance_wire_header_bytes.restype = C.c_size_t
@@ -194,6 +195,10 @@ class Context:
     def set_strict(self, enable):
         """opt-in strict mode (not the reference's behaviour): see afx_ctx_set_strict in include/aeonflux_gpu.h"""
         check(lib().afx_ctx_set_strict(self.h, 1 if enable else 0))
+
+    def set_fixed_key_schedule(self, enable):
+        """key scalars without NAF: running time independent of the issuer key (afx_ctx_set_fixed_key_schedule)"""
+        check(lib().afx_ctx_set_fixed_key_schedule(self.h, 1 if enable else 0))
 
     def issuer_parameters(self):
         """IssuerParameters as C_W || I (64 bytes)"""

@@ -211,7 +211,8 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     std::vector<afx_msm_term> uni, lane;
     std::vector<const uint8_t*> hs;
     for (uint32_t t = 0; t < j.n_var; t++) {
-      const uint8_t* h = j.term[t].scalar_stride == 0 ? host_scalar_of(ctx, j.term[t].scalar) : nullptr;
+      // afx_ctx_set_fixed_key_schedule: key scalars take the per-item window path (64 additions each, whatever the key)
+      const uint8_t* h = (j.term[t].scalar_stride == 0 && !ctx->fixed_key_schedule) ? host_scalar_of(ctx, j.term[t].scalar) : nullptr;
       if (h) { uni.push_back(j.term[t]); hs.push_back(h); } else lane.push_back(j.term[t]);
     }
     if (uni.empty()) continue;

@@ -95,6 +95,7 @@ struct afx_ctx {
   } lane[2];
   bool pipelining = false;
   bool strict = false;   // afx_ctx_set_strict
+  bool fixed_key_schedule = false;   // afx_ctx_set_fixed_key_schedule: no NAF for the issuer key's scalars
   uint32_t chunk_items = 0;   // afx_ctx_set_chunk_items; 0 = default
   afx_plan_stats last_stats = {};   // per-item operation counts of the most recent plan
   uint32_t n_cu = 256;   // compute units of the device (k_msm keeps 2 blocks resident on each)

@@ -103,6 +103,12 @@ extern "C" int afx_ctx_set_strict(afx_ctx* c, int enable) {
   c->strict = enable != 0;
   return AFX_OK;
 }
+extern "C" int afx_ctx_set_fixed_key_schedule(afx_ctx* c, int enable) {
+  if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  c->fixed_key_schedule = enable != 0;
+  return AFX_OK;
+}
 extern "C" int afx_ctx_get_plan_stats(afx_ctx* c, afx_plan_stats* out) {
   if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);

@@ -145,6 +145,15 @@ int afx_ctx_synchronize(afx_ctx* ctx);
  *    the plaintext that is proven encrypted is the one the credential commits to.  Prover (afx_show) and verifier. */
 int afx_ctx_set_strict(afx_ctx* ctx, int enable);
 
+/* Schedule of the issuer key's scalars (x0, x1, y_i in Issuer::verify's Z and in Amac::tag).  Default (0): the host recodes
+ * them to width-5 NAF and every lane runs that addition schedule - the fastest form, whose running time depends on the
+ * key's NAF weight (a per-key constant, the same for every batch under that key; nothing depends on the items).  1: the key
+ * scalars take the per-item window path instead (64 additions per term, whatever the key): running time independent of
+ * the key, 3-5 % slower.  The reference computes these products with dalek's constant-time `*` / `multiscalar_mul`
+ * (src/nizk/presentation.rs:342-351, src/amacs.rs:267-270); DESIGN.md "Documented divergences" has the threat model.
+ * Results are identical in both modes. */
+int afx_ctx_set_fixed_key_schedule(afx_ctx* ctx, int enable);
+
 /* Items per internal pass (tuning; 0 restores the default of 2^19).  A batch larger than this is processed in passes
  * of this many items, which bounds the device workspace (about 25-70 KB per item and pass, depending on the
  * statement); smaller values trade throughput for memory.  Accepted range 256 .. 2^22. */

@@ -112,3 +112,36 @@ def test_group_issue_equals_one_context_and_the_oracle():
     user.close()
     grp.close()
     issuer.close()
+
+
+def test_fixed_key_schedule_gives_identical_results():
+    """afx_ctx_set_fixed_key_schedule: the issuer key's scalars without NAF (running time independent of the key)"""
+    import aeonflux_amd as afx
+    import bench
+    from aeonflux_amd import batch
+    params, key, ip = bench.load_fixture("readme_4attrs_sSPe")
+    issuer = afx.Context(params, key, ip)
+    user = afx.Context(params, None, ip)
+    count = 700
+    pres, shape = bench.generate(afx, batch, issuer, user, params, 4, "SSPE", [0, 3], count, 606)
+    want = bench.corrupt(pres, count, 8)
+    assert np.array_equal(batch.verify_presentations(issuer, shape, pres), want)
+    naf = issuer.plan_stats()
+    issuer.set_fixed_key_schedule(True)
+    assert np.array_equal(batch.verify_presentations(issuer, shape, pres), want)
+    fixed = issuer.plan_stats()
+    assert fixed["var_additions"] > naf["var_additions"] and fixed["doublings"] >= naf["doublings"]
+    rng = np.random.default_rng(12)
+    rb = lambda *s: rng.integers(0, 256, size=s, dtype=np.uint8)
+    kinds = [afx.ATTR_PUBLIC_SCALAR, afx.ATTR_PUBLIC_SCALAR, afx.ATTR_PUBLIC_POINT, afx.ATTR_EITHER_POINT]
+    values = np.stack([batch.scalars_from_wide(issuer, rb(64, 64)), batch.scalars_from_wide(issuer, rb(64, 64)),
+                       batch.points_from_uniform(issuer, rb(64, 64)), batch.points_from_uniform(issuer, rb(64, 64))])
+    tw, uw, sd = rb(64, 64), rb(64, 64), rb(64, 32)
+    a, sa = batch.issue(issuer, kinds, values, tw, uw, sd)
+    issuer.set_fixed_key_schedule(False)
+    b, sb = batch.issue(issuer, kinds, values, tw, uw, sd)
+    assert not sa.any() and not sb.any()
+    for f in ("t", "U", "V", "challenge", "responses"):
+        assert np.array_equal(a[f], b[f]), f
+    user.close()
+    issuer.close()
