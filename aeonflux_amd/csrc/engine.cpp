@@ -381,6 +381,7 @@ size_t Assembler::total_ws_bytes() const {
 
 int Assembler::run() {
   if (sizing_) { set_error("run() on a sizing assembler"); return AFX_E_BAD_ARGS; }
+  if (!plan_error.empty()) { set_error(plan_error); return AFX_E_BAD_ARGS; }
   afx_ctx::Lane& L = ctx->lane[lane];
   ctx->last_stats = stats;
   if (total_ws_bytes() > L.ws.cap) { set_error("workspace smaller than the sized plan"); return AFX_E_BAD_ARGS; }

@@ -520,11 +520,14 @@ extern "C" int afx_verify_presentations_dev(afx_ctx* ctx, const afx_shape* shape
   }
   std::vector<afx_encproof_soa> encs;
   if (b.enc && sh.n_enc_proofs <= AFX_MAX_ATTRIBUTES) encs.assign(b.enc, b.enc + sh.n_enc_proofs);
+  // the plan's size depends on the shape and the mode, not on the arrays: remember it (the trace changes nothing in size,
+  // but a too-small trace buffer is a plan error that the sizing run reports, so traced calls are not cached)
+  const uint64_t key = ctx->trace ? 0 : plan_key("verify_presentations", &sh, sizeof sh, (ctx->strict ? 1u : 0u) | (ctx->fixed_key_schedule ? 2u : 0u));
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
     afx_presentation_soa bb = b;
     bb.enc = encs.data();
     build_presentation_verify(as, sh, bb, count, off, status_dev + off);
-  });
+  }, key);
 }
 
 extern "C" int afx_verify_encryption_proofs_dev(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* batch, size_t count, uint8_t* status_dev) {

@@ -27,7 +27,19 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
 // ------------------------------------------------------------------------------------------------
 using BuildFn = std::function<void(Assembler&, size_t /*chunk offset*/, uint32_t /*chunk count*/)>;
 
-inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build) {
+// FNV-1a over the bytes that determine a plan's SIZE (statement, shape, mode flags - never the data pointers)
+inline uint64_t plan_key(const char* statement, const void* shape, size_t shape_len, uint64_t flags) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; } };
+  mix((const uint8_t*)statement, strlen(statement));
+  mix((const uint8_t*)shape, shape_len);
+  mix((const uint8_t*)&flags, sizeof flags);
+  return h ? h : 1;
+}
+
+// key != 0: the plan's workspace and blob sizes are remembered per (key, pass size), so that repeated calls of one statement
+// on one shape assemble their plan once per pass instead of twice (the dry sizing run is skipped)
+inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, uint64_t key = 0) {
   AFX_HIP(hipSetDevice(c->device));
   // all chunks of one call run on one lane; calls alternate lanes only when the caller switched pipelining on
   const int lane = c->force_lane >= 0 ? c->force_lane : (c->pipelining ? (int)(c->lane_next++ & 1u) : 0);
@@ -35,10 +47,20 @@ inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build) {
   for (size_t off = 0; off < count;) {
     const uint32_t cc = (uint32_t)std::min<size_t>(chunk, count - off);
     try {
-      Assembler sizing(c, cc, true, lane);
-      build(sizing, off, cc);
-      if (!sizing.plan_error.empty()) { set_error(sizing.plan_error); return AFX_E_BAD_ARGS; }
-      int rc = c->lane[lane].ws.ensure(sizing.total_ws_bytes());
+      size_t ws_bytes = 0;
+      const std::pair<uint64_t, uint32_t> ck(key, cc);
+      auto hit = key ? c->plan_sizes.find(ck) : c->plan_sizes.end();
+      if (hit != c->plan_sizes.end()) {
+        ws_bytes = hit->second;
+      } else {
+        Assembler sizing(c, cc, true, lane);
+        build(sizing, off, cc);
+        if (!sizing.plan_error.empty()) { set_error(sizing.plan_error); return AFX_E_BAD_ARGS; }
+        if (sizing.blob_bytes() > BLOB_CAP) { set_error("plan blob exceeds its fixed capacity"); return AFX_E_BAD_ARGS; }
+        ws_bytes = sizing.total_ws_bytes();
+        if (key && c->plan_sizes.size() < 4096) c->plan_sizes[ck] = ws_bytes;
+      }
+      int rc = c->lane[lane].ws.ensure(ws_bytes);
       if (rc) {
         // the device cannot hold this pass's workspace: take smaller passes (an engine on a shared or smaller GPU still works)
         if (chunk <= 4096 || cc <= 4096) return rc;
@@ -46,7 +68,6 @@ inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build) {
         chunk >>= 1;
         continue;
       }
-      if (sizing.blob_bytes() > BLOB_CAP) { set_error("plan blob exceeds its fixed capacity"); return AFX_E_BAD_ARGS; }
       Assembler as(c, cc, false, lane);
       build(as, off, cc);
       if ((rc = as.run())) return rc;

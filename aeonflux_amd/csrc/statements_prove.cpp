@@ -104,6 +104,10 @@ extern "C" int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* 
   // the arrays a well-formed request reads (a request every item fails on reads none): a null one is a bad call, not a GPU fault
   if (a.n_attributes <= ctx->n && n_responses == ctx->n + 5 &&
       (!s.t || !s.U || !s.V || !s.challenge || !s.responses || (a.n_attributes && !a.values))) { set_error("null batch array"); return AFX_E_BAD_ARGS; }
+  struct { uint32_t n, nr; uint8_t kinds[AFX_MAX_ATTRIBUTES]; } kd__;
+  memset(&kd__, 0, sizeof kd__);
+  kd__.n = a.n_attributes; kd__.nr = n_responses; memcpy(kd__.kinds, a.kinds, AFX_MAX_ATTRIBUTES);
+  const uint64_t key__ = ctx->trace ? 0 : plan_key("verify_issuances", &kd__, sizeof kd__, 0);
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
     afx_ctx* c = as.ctx;
     JobSets js;
@@ -134,7 +138,7 @@ extern "C" int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* 
     issuance_statement(v, c, iv);
     v.verify_compact(row(s.challenge, 0), 0, count, off, js.msm2, js.hash, &js.scalarop);   // (resp_y * m_i) * G_m_i products: inputs only
     emit(as, js, status_dev + off, AFX_ST_VERIFICATION_FAILURE);
-  });
+  }, key__);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -154,6 +158,10 @@ extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, c
     set_error("null batch array");
     return AFX_E_BAD_ARGS;
   }
+  struct { uint32_t n; uint8_t kinds[AFX_MAX_ATTRIBUTES]; } kd__;
+  memset(&kd__, 0, sizeof kd__);
+  kd__.n = a.n_attributes; memcpy(kd__.kinds, a.kinds, AFX_MAX_ATTRIBUTES);
+  const uint64_t key__ = plan_key("issue", &kd__, sizeof kd__, ctx->fixed_key_schedule ? 2u : 0u);
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
     afx_ctx* c = as.ctx;
     const uint32_t n = c->n;
@@ -219,7 +227,7 @@ extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, c
     as.hash(chal_hash);
     as.scalarop(resp);
     as.finish(status_dev + off, AFX_ST_MAC_CREATION);
-  });
+  }, key__);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -272,6 +280,10 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
   const afx_presentation_out o = *out;
   std::vector<afx_encproof_out> eo;
   if (nsp) eo.assign(o.enc, o.enc + nsp);
+  struct { uint32_t n; uint8_t kinds[AFX_MAX_ATTRIBUTES]; } kd__;
+  memset(&kd__, 0, sizeof kd__);
+  kd__.n = na; memcpy(kd__.kinds, cr.kinds, AFX_MAX_ATTRIBUTES);
+  const uint64_t key__ = plan_key("show", &kd__, sizeof kd__, (ctx->strict ? 1u : 0u) | (no_key ? 4u : 0u));
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t cc) {
     afx_ctx* c = as.ctx;
     auto row = [&](const uint8_t* base, size_t k) { return base + (k * count + off) * 32; };
@@ -438,7 +450,7 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
     as.hash(chal_hash);
     as.scalarop(resp);
     as.finish(status_dev + off, AFX_ST_VERIFICATION_FAILURE);
-  });
+  }, key__);
 }
 
 // ------------------------------------------------------------------------------------------------
