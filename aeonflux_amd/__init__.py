@@ -137,6 +137,7 @@ def lib():
         _LIB.afx_ctx_synchronize.argtypes = [C.c_void_p]
         _LIB.afx_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_get_timing.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        _LIB.afx_ctx_get_core_clock_mhz.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         _LIB.afx_verify_presentations_range.argtypes = [C.c_void_p, C.POINTER(Shape), C.POINTER(PresentationSoA), C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
         _LIB.afx_issue_range.argtypes = [C.c_void_p, C.POINTER(AttributesSoA), C.POINTER(IssueRandomness), C.c_size_t, C.c_size_t, C.c_size_t,
                                          C.POINTER(IssuanceSoA), C.c_void_p]
@@ -248,6 +249,12 @@ class Context:
         ms, n = C.c_double(0), C.c_uint64(0)
         check(lib().afx_ctx_get_timing(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def core_clock_mhz(self):
+        """core clock the timed k_msm_window launches ran at (afx_ctx_get_core_clock_mhz)"""
+        mhz = C.c_double(0)
+        check(lib().afx_ctx_get_core_clock_mhz(self.h, C.byref(mhz)))
+        return mhz.value
 
     # ---- Issuer::verify ----
     def verify_presentations(self, shape, soa, count, status_ptr, device_pointers=False):

@@ -419,7 +419,8 @@ int Assembler::run() {
         afx_ctx::Lane& other = ctx->lane[lane ^ 1];
         if (ctx->pipelining && other.msm_recorded) AFX_HIP(hipStreamWaitEvent(s, other.msm_done, 0));
         AFX_HIP(afxk_msm(s, l.kind == L_MSM_FIXED ? 0 : l.kind == L_MSM_WINDOW ? 1 : 2, (const afx_msm_job*)jobs, l.njobs,
-                         (const int32_t*)ctx->d_pos_tables.p, table_ws, digit_ws, bad_, count));
+                         (const int32_t*)ctx->d_pos_tables.p, table_ws, digit_ws, bad_, count,
+                         (ctx->timing && l.kind == L_MSM_WINDOW) ? ctx->clock_probe() : nullptr));
         if (ctx->pipelining) { AFX_HIP(hipEventRecord(L.msm_done, s)); L.msm_recorded = true; }
         break;
       }

@@ -73,6 +73,7 @@ struct afx_ctx {
   const uint8_t* key_x1() const { return (const uint8_t*)d_key.p + 96; }
   const uint8_t* key_y(uint32_t i) const { return (const uint8_t*)d_key.p + 128 + 32 * i; }
   const uint8_t* const_one() const { return (const uint8_t*)d_consts.p; }
+  unsigned long long* clock_probe() const { return (unsigned long long*)((uint8_t*)d_consts.p + 1024); }   // k_msm's clock probe (2 counters)
   std::vector<afx::Enc> host_key;               // w, w', x0, x1, y...; wiped on destroy
   const int32_t* gen_ext(uint32_t id) const { return (const int32_t*)d_gen_ext.p + (size_t)id * AFX_VAR_DWORDS; }
   // Execution lanes.  A lane = one HIP stream + its own workspace + a two-deep ring of (pinned host, device) plan

@@ -418,7 +418,13 @@ k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table
 template <int KIND>
 __global__ void __launch_bounds__(AFX_BLOCK, 2)
 k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tables, int32_t* __restrict__ table_ws,
-      uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count) {
+      uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count, unsigned long long* __restrict__ clock_probe) {
+  // Clock probe (measurement aid): one lane of the launch's first block reads the shader-clock counter (s_memtime) and the
+  // constant 100 MHz counter (s_memrealtime) around its chain; their ratio is the core clock this kernel actually ran at
+  // (the kernels run at the socket power cap, below the nominal clock: DESIGN.md section 4).
+  const bool probe = clock_probe && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+  unsigned long long c0 = 0, r0 = 0;
+  if (probe) { c0 = clock64(); r0 = wall_clock64(); }
   // lanes past the end of the batch shadow the last item (identical values, identical stores)
   const uint32_t item = min(blockIdx.x * AFX_BLOCK + threadIdx.x, count - 1);
   const afx_msm_job* job = &jobs[blockIdx.y];
@@ -483,6 +489,10 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
     if (nt != nv) acc = msm_fixed_terms(env, pos_tables, acc, nv, nt);
   }
   msm_finish(job, acc, bad, count, item);
+  if (probe) {
+    atomicAdd(&clock_probe[0], (unsigned long long)clock64() - c0);
+    atomicAdd(&clock_probe[1], (unsigned long long)wall_clock64() - r0);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -654,11 +664,11 @@ hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen
   return hipGetLastError();
 }
 hipError_t afxk_msm(hipStream_t s, int kind, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, int32_t* table_ws, uint32_t* digit_ws,
-                    uint32_t* bad, uint32_t count) {
+                    uint32_t* bad, uint32_t count, unsigned long long* clock_probe) {
   switch (kind) {
-    case MSM_FIXED: hipLaunchKernelGGL(k_msm<MSM_FIXED>, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count); break;
-    case MSM_WINDOW: hipLaunchKernelGGL(k_msm<MSM_WINDOW>, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count); break;
-    case MSM_NAF: hipLaunchKernelGGL(k_msm<MSM_NAF>, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count); break;
+    case MSM_FIXED: hipLaunchKernelGGL(k_msm<MSM_FIXED>, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe); break;
+    case MSM_WINDOW: hipLaunchKernelGGL(k_msm<MSM_WINDOW>, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe); break;
+    case MSM_NAF: hipLaunchKernelGGL(k_msm<MSM_NAF>, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

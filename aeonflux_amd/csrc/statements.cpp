@@ -130,7 +130,19 @@ extern "C" int afx_ctx_set_timing(afx_ctx* c, int enable) {
   int rc = drain_timing(c);
   if (rc) return rc;
   for (int k = 0; k < 16; k++) { c->kind_ms[k] = 0; c->kind_launches[k] = 0; }
+  if (c->d_consts.p) AFX_HIP(hipMemsetAsync(c->clock_probe(), 0, 16, c->stream));
   c->timing = enable != 0;
+  return AFX_OK;
+}
+extern "C" int afx_ctx_get_core_clock_mhz(afx_ctx* c, double* mhz) {
+  if (!c || !mhz) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  AFX_HIP(hipSetDevice(c->device));
+  for (auto& L : c->lane)
+    if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
+  unsigned long long v[2] = { 0, 0 };
+  AFX_HIP(hipMemcpy(v, c->clock_probe(), sizeof v, hipMemcpyDeviceToHost));
+  *mhz = v[1] ? 100.0 * (double)v[0] / (double)v[1] : 0.0;
   return AFX_OK;
 }
 extern "C" int afx_ctx_get_timing(afx_ctx* c, const char* kernel, double* total_ms, uint64_t* launches) {
@@ -236,7 +248,7 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   if ((rc = c->d_gen_enc.ensure(32 * (size_t)c->ngen)) ||
       (rc = c->d_pos_tables.ensure(sizeof(int32_t) * AFX_POS_TABLE_DWORDS * (size_t)c->ngen)) ||
       (rc = c->d_gen_ext.ensure(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)c->ngen)) || (rc = c->d_key.ensure(32 * (size_t)(4 + n))) ||
-      (rc = c->d_consts.ensure(64)) || (rc = c->lane[0].staging.ensure(32 * (size_t)c->ngen + 4 * (size_t)c->ngen)))
+      (rc = c->d_consts.ensure(2048)) || (rc = c->lane[0].staging.ensure(32 * (size_t)c->ngen + 4 * (size_t)c->ngen)))
     return rc;
   for (auto& L : c->lane)
     for (int i = 0; i < 2; i++) {
@@ -267,10 +279,10 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
     volatile uint8_t* p = kflat.data();
     for (size_t i = 0; i < kflat.size(); i++) p[i] = 0;
   }
-  uint8_t consts[64];
+  uint8_t consts[2048];
   memset(consts, 0, sizeof consts);
   consts[0] = 1;   // Scalar::one()
-  AFX_HIP(hipMemcpyAsync(c->d_consts.p, consts, 64, hipMemcpyHostToDevice, c->stream));
+  AFX_HIP(hipMemcpyAsync(c->d_consts.p, consts, sizeof consts, hipMemcpyHostToDevice, c->stream));
   AFX_HIP(hipStreamSynchronize(c->stream));
   for (uint32_t i = 0; i < c->ngen; i++)
     if (!ok[i]) { set_error("generator / key point " + std::to_string(i) + " does not decompress"); return AFX_E_BAD_PARAMS; }   // parameters.rs:77-89

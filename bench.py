@@ -385,6 +385,9 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
 MAD_PEAK_T = 64 / 5.54 * 1024 * 2.4e9 / 1e12
 
 
+NOMINAL_MHZ = 2400.0
+
+
 def valu_side(ctx, items_per_step, field_kernel_ms_per_step):
     """compute-side figure beside the HBM roofline: 32x32->64-bit multiply-adds of the field arithmetic per second.
     Counts come from the engine's own plan of the last call (afx_ctx_get_plan_stats); a field multiplication is
@@ -392,7 +395,11 @@ def valu_side(ctx, items_per_step, field_kernel_ms_per_step):
     st = ctx.plan_stats()
     mads = 100 * st["field_mul"] + 55 * st["field_sq"]
     achieved = mads * items_per_step / (field_kernel_ms_per_step / 1e3) / 1e12 if field_kernel_ms_per_step > 0 else 0.0
+    mhz = ctx.core_clock_mhz()   # measured inside the timed k_msm_window launches (shader-clock counter / 100 MHz counter)
+    at_clock = MAD_PEAK_T * mhz / NOMINAL_MHZ if mhz > 0 else None
     return {"unit": "T multiply-adds/s (v_mad_i64_i32)", "achieved": achieved, "peak": MAD_PEAK_T, "frac": achieved / MAD_PEAK_T,
+            "core_clock_mhz_measured": mhz, "peak_at_measured_clock": at_clock, "frac_at_measured_clock": (achieved / at_clock) if at_clock else None,
+            "clock_note": "peak is at the nominal 2400 MHz; the kernels run at the socket power cap, below it",
             "peak_source": "tools/ubench/valu_rates.hip on this GPU (no published figure)", "per_item": dict(st, mads=mads),
             "time_base": "summed durations of the kernels doing field arithmetic (k_msm_*, k_decode, k_pointop, k_from_uniform)"}
 

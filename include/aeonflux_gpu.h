@@ -196,6 +196,10 @@ int afx_ctx_get_plan_stats(afx_ctx* ctx, afx_plan_stats* out);
  * "k_from_uniform", "k_reduce_wide", "k_fill_u32". */
 int afx_ctx_set_timing(afx_ctx* ctx, int enable);
 int afx_ctx_get_timing(afx_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
+/* The core clock the k_msm_window launches recorded since set_timing(ctx, 1) actually ran at, in MHz (0 if none ran): one
+ * lane per launch reads the shader-clock counter and the constant 100 MHz counter around its chain.  The path runs at
+ * the socket power cap, so this is below the nominal clock the multiply-add peak is usually quoted at. */
+int afx_ctx_get_core_clock_mhz(afx_ctx* ctx, double* mhz);
 
 /* ---- Issuer::verify (src/issuer.rs:141-147 -> src/nizk/presentation.rs:324-443) ------------- */
 
