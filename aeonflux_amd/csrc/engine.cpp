@@ -2,6 +2,7 @@
 #include "engine.hpp"
 #include <string.h>
 #include <algorithm>
+#include <map>
 #include <stdexcept>
 
 namespace afx {
@@ -293,6 +294,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   std::vector<char> done(n, 0);
   const uint32_t blocks_per_row = (count + AFX_BLOCK - 1) / AFX_BLOCK, resident = 2 * ctx->n_cu;
   uint32_t dslot = 0, tslot = 0;
+  std::map<std::pair<const int32_t*, bool>, uint32_t> table_of;   // (base, odd multiples?) -> table slot
   size_t left = n;
   static const int class_order[3] = { 2, 1, 0 };
   static const LaunchKind class_launch[3] = { L_MSM_FIXED, L_MSM_WINDOW, L_MSM_NAF };
@@ -312,10 +314,23 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
       afx_msm_job j = jobs[i];
       j.next_job = 0;
       j.digit_slot = dslot; dslot += j.n_terms;
-      j.table_slot = tslot; tslot += j.n_var;
+      // one window table per (base, kind of multiples) of this launch list: constraints that share a base share its table
+      // (a proof of encryption uses C_y_2 and C_y_2' in two constraints each, encryption.rs:197,204)
+      j.table_slot = 0;
       for (uint32_t t = 0; t < j.n_var; t++) {
-        afx_table_job tj = { j.term[t].var, j.table_slot + t, 0 };
-        (t < j.n_uni ? odd_rows : plain_rows).push_back(tj);
+        const bool odd = t < j.n_uni;
+        const std::pair<const int32_t*, bool> tk(j.term[t].var, odd);
+        auto hit = table_of.find(tk);
+        if (hit == table_of.end()) {
+          hit = table_of.emplace(tk, tslot++).first;
+          afx_table_job tj = { j.term[t].var, hit->second, 0 };
+          (odd ? odd_rows : plain_rows).push_back(tj);
+        } else {
+          stats.table_additions -= odd ? 7 : (AFX_TABLE_ENTRIES - 2);   // counted per term above; this one is shared
+          stats.field_mul -= odd ? (4 + 1 + 1 + 7 * 9) : (1 + (AFX_TABLE_ENTRIES - 2) * 9);
+          stats.field_sq -= odd ? 4 : 0;
+        }
+        j.term[t].table_slot = hit->second;
       }
       if (j.n_uni) {
         std::vector<uint32_t> sched;

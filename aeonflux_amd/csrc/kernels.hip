@@ -290,9 +290,9 @@ AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w,
   const uint32_t idx3 = idx;
 #endif
 #ifdef AFX_EXPERIMENT_WINDOW_ENTRY_MAJOR
-  const int32_t* ent = e.table_ws + (size_t)(e.tslot + t) * e.count * AFX_VAR_TABLE_DWORDS + ((size_t)idx3 * e.count + AFX_TABLE_ITEM(e.item)) * AFX_TABLE_ENTRY_DWORDS;
+  const int32_t* ent = e.table_ws + (size_t)e.job->term[t].table_slot * e.count * AFX_VAR_TABLE_DWORDS + ((size_t)idx3 * e.count + AFX_TABLE_ITEM(e.item)) * AFX_TABLE_ENTRY_DWORDS;
 #else
-  const int32_t* ent = e.table_ws + ((size_t)(e.tslot + t) * e.count + AFX_TABLE_ITEM(e.item)) * AFX_VAR_TABLE_DWORDS + idx3 * AFX_TABLE_ENTRY_DWORDS;
+  const int32_t* ent = e.table_ws + ((size_t)e.job->term[t].table_slot * e.count + AFX_TABLE_ITEM(e.item)) * AFX_VAR_TABLE_DWORDS + idx3 * AFX_TABLE_ENTRY_DWORDS;
 #endif
   return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent), neg), next);
 }
@@ -431,7 +431,7 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
   const uint32_t nt = job->n_terms, nv = job->n_var, nu = job->n_uni;
   msm_env env;
   env.job = job; env.table_ws = table_ws; env.digit_ws = digit_ws;
-  env.count = count; env.item = item; env.dslot = job->digit_slot; env.tslot = job->table_slot;
+  env.count = count; env.item = item; env.dslot = job->digit_slot; env.tslot = 0;
   msm_recode(job, digit_ws, count, item, nu, nv, nt);   // batch-constant NAF terms need no digits
   ge_p3 acc = ge_identity();
   if constexpr (KIND == MSM_FIXED) {
@@ -457,7 +457,7 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
           const bool neg = (ev & 0x80u) != 0;
           ev = sched[++ei];
           const bool last = !lane_adds && (ev >> 16) != (uint32_t)bit;
-          const int32_t* ent = table_ws + (size_t)(env.tslot + t) * count * AFX_VAR_TABLE_DWORDS + ((size_t)idx * count + AFX_TABLE_ITEM(item)) * AFX_TABLE_ENTRY_DWORDS;
+          const int32_t* ent = table_ws + (size_t)job->term[t].table_slot * count * AFX_VAR_TABLE_DWORDS + ((size_t)idx * count + AFX_TABLE_ITEM(item)) * AFX_TABLE_ENTRY_DWORDS;
           acc = ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent), neg), last ? after : GE_FOR_ADD);
         }
         if (lane_adds) {

@@ -76,6 +76,8 @@ typedef struct {
   int32_t fixed_idx;       /* >= 0: generator id (positional tables); -1: variable point           */
   const int32_t* var;      /* variable point (SoA) when fixed_idx < 0                              */
   uint32_t negate;         /* subtract the term                                                    */
+  uint32_t table_slot;     /* variable terms: slot of this base's window table in table_ws (Assembler::msm; terms of one
+                              launch list that share a base and a table kind share the table)              */
 } afx_msm_term;
 
 typedef struct {
@@ -97,7 +99,7 @@ typedef struct {
   int32_t chain_to;                     /* host only: index (in the vector handed to Assembler::msm) of a job that consumes this
                                            job's out_var and therefore goes into a later launch; -1 none */
   uint32_t digit_slot;                  /* first recoded-scalar slot of this job in digit_ws (one per term)   */
-  uint32_t table_slot;                  /* first window-table slot of this job in table_ws (one per var term) */
+  uint32_t table_slot;                  /* unused (slots are per term: afx_msm_term.table_slot) */
 } afx_msm_job;
 
 /* one window table to build (k_msm_tables<ODD>): the base and where the table goes.  ODD = the odd multiples 1, 3, .., 15
