@@ -1,17 +1,19 @@
 // GF(2^255-19) for gfx950, one field element per lane.
 //
 // Representation: 10 signed limbs, radix 2^25.5 (26,25,26,25,... bits).  Chosen by measurement
-// (profiles/r01_valu_rates_ubench.txt): v_mad_i64_i32 issues at ~5.4 cycles per wave-instruction,
-// v_fma_f64 at ~4.6, so the 100-mad schoolbook with 64-bit column accumulators and NO carry handling
-// inside the accumulation beats every fp64-split and saturated-limb variant priced against it.
+// (profiles/r01_valu_rates_ubench.txt, at the 2 waves per SIMD the kernels run at): v_mad_i64_i32 issues at ~5.5 cycles
+// per wave-instruction, v_fma_f64 at ~5.1, plain 32-bit VOP2 ops at ~2.8, VOP3 forms and 64-bit shifts at ~4.7, so the
+// 100-mad schoolbook with 64-bit column accumulators and NO carry handling inside the accumulation beats every
+// fp64-split and saturated-limb variant priced against it.
 // One fe = 10 VGPRs.  Replaces, for the reference's call sites, what curve25519-dalek's
 // FieldElement [3P] does (e.g. under /root/reference/src/nizk/presentation.rs:342-351); only canonical
 // encodings are contractual.
 //
 // The kernels built on this file are VALU-issue bound and their time is the sum of per-opcode issue costs
 // (profiles/r01_valu_rates_ubench.txt, profiles/r01_fe_rates_ubench.txt), so the code below is written against
-// that price list: 64-bit adds (v_lshl_add_u64, ~4.6-6.3 cycles) are avoided by feeding each column's carry into
-// the next column's mad chain as its addend.
+// that price list: 64-bit adds (v_lshl_add_u64, ~6.3 cycles) are avoided by feeding each column's carry into
+// the next column's mad chain as its addend.  Measured: fe_mul 753 cycles per wave-level operation (617 raw),
+// fe_sq 552 (488 raw; 56 mads + 40 other VALU instructions).
 //
 // Bounds discipline (same as the classic 10-limb schedule): fe_sq and fe_mul's SECOND operand accept
 // limbs up to 1.65*2^26 (even) / 1.65*2^25 (odd) in magnitude (the 19x / 38x premultiplications must

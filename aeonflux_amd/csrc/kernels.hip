@@ -7,8 +7,11 @@
 //   k_sccheck           Scalar canonicity
 //   k_pointop           +-P +-Q (+ compress): C_V - W, C_y+M, C_y_1-E2, -E1               (P1, E1)
 //   k_scalarop          a*b+c mod l: y_i*m_i, -t*z, responses s*c+b                       (P1, S1, I2)
-//   k_msm               R = sum s_k P_k (+-addend) -> compress.  Fixed bases from positional tables (L2 / Infinity
-//                       Cache), variable bases from per-lane window tables in HBM, shared doublings (P1, P4 iii, I1)
+//   k_msm_tables<ODD>   per-lane window tables of the variable bases of a launch list (multiples 0..8, or the odd
+//                       multiples 1..15 for width-5 NAF terms), one (base) per grid row, shared by the jobs that use it
+//   k_msm<KIND>         R = sum s_k P_k (+-addend) -> compress, one job class per kernel: MSM_FIXED (positional tables only),
+//                       MSM_WINDOW (per-item scalars: signed 4-bit windows over the per-lane tables, shared doublings),
+//                       MSM_NAF (batch-constant scalars - the issuer key - as a wave-uniform width-5 NAF schedule) (P1, P4 iii, I1)
 //   k_hash              STROBE-128/merlin transcript over Keccak-f[1600] driven by a precompiled byte
 //                       schedule; squeezes challenges / blinding factors                   (P2, P4 iv-v)
 //   k_finish            per-item status byte
