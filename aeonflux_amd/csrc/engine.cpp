@@ -508,7 +508,7 @@ afx_msm_term SchnorrBuilder::term_for(const uint8_t* scalar, uint32_t stride, co
   t.scalar = scalar;
   t.scalar_stride = stride;
   if (p.is_const) { t.fixed_idx = (int32_t)p.gen; t.var = nullptr; t.negate = (negate != p.neg) ? 1u : 0u; }
-  else { t.fixed_idx = -1; t.var = p.var; t.negate = negate ? 1u : 0u; }
+  else { t.fixed_idx = -1; t.var = p.var; t.negate = (negate != p.var_negated) ? 1u : 0u; }
   return t;
 }
 static void order_terms(afx_msm_job& j, const std::vector<afx_msm_term>& terms) {

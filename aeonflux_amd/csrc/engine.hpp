@@ -205,6 +205,8 @@ struct PointVar {
   uint32_t gen = 0;
   bool neg = false;
   const int32_t* var = nullptr;
+  bool var_negated = false;   // `var` holds the NEGATION of this point (its own encoding is still enc_dev): a term on it is the
+                              // negated term on `var`, and shares var's window table (-E1 beside E1 in a proof of encryption)
   const uint8_t* enc_dev = nullptr;
   // optional fixed-base form of a variable point: P = alt_scalar[item] * G_alt_gen (e.g. M_i = m_i * G_m_i,
   // src/amacs.rs:234-235).  A term s*P then runs as the fixed-base term (s*alt_scalar)*G, one scalar product away.
@@ -213,6 +215,7 @@ struct PointVar {
   const uint8_t* alt_scalar = nullptr;
   static PointVar Const(uint32_t gen, bool neg = false) { PointVar p; p.is_const = true; p.gen = gen; p.neg = neg; return p; }
   static PointVar Var(const int32_t* var, const uint8_t* enc) { PointVar p; p.is_const = false; p.var = var; p.enc_dev = enc; return p; }
+  static PointVar NegOf(const int32_t* var, const uint8_t* enc_of_negation) { PointVar p = Var(var, enc_of_negation); p.var_negated = true; return p; }
 };
 // A scalar variable: verifier side = the response array; prover side = the witness (per item, or a batch
 // constant such as the issuer key when stride == 0; `host` holds its bytes then).

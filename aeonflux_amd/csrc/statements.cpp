@@ -306,7 +306,7 @@ static void add_encproof_verify(Assembler& as, JobSets& js, uint16_t index, cons
   js.sccheck.push_back({ row(e.challenge, 0) });
   for (int k = 0; k < 6; k++) js.sccheck.push_back({ row(e.responses, k) });
   int32_t *v_pk = as.new_var(), *v_E1 = as.new_var(), *v_E2 = as.new_var(), *v_Cy1 = as.new_var(), *v_Cy2 = as.new_var(),
-          *v_Cy3 = as.new_var(), *v_Cy2p = as.new_var(), *v_D1 = as.new_var(), *v_D2 = as.new_var();
+          *v_Cy3 = as.new_var(), *v_Cy2p = as.new_var(), *v_D1 = as.new_var();
   uint8_t *e_D1 = as.new_enc(), *e_D2 = as.new_enc();
   js.decode.push_back({ row(e.pk, 0), v_pk, 1 });
   js.decode.push_back({ row(e.E1, 0), v_E1, 1 });
@@ -316,7 +316,7 @@ static void add_encproof_verify(Assembler& as, JobSets& js, uint16_t index, cons
   js.decode.push_back({ row(e.C_y_3, 0), v_Cy3, 1 });
   js.decode.push_back({ row(e.C_y_2p, 0), v_Cy2p, 1 });
   afx_pointop_job d1 = { v_Cy1, v_E2, nullptr, +1, -1, v_D1, e_D1, 1 };    // C_y_1 - E2   (:183)
-  afx_pointop_job d2 = { v_E1, nullptr, nullptr, -1, 0, v_D2, e_D2, 1 };   // -E1          (:185)
+  afx_pointop_job d2 = { v_E1, nullptr, nullptr, -1, 0, nullptr, e_D2, 1 };   // -E1 (:185): only its encoding is needed, see below
   js.pointop.push_back(d1);
   js.pointop.push_back(d2);
   auto resp = [&](int k) { ScalarVar s; s.dev = row(e.responses, k); s.stride = 32; return s; };
@@ -340,7 +340,7 @@ static void add_encproof_verify(Assembler& as, JobSets& js, uint16_t index, cons
   const int C_y_2p = v.allocate_point("C_y_2'", PointVar::Var(v_Cy2p, row(e.C_y_2p, 0)));
   const int C_y_1_minus_E2 = v.allocate_point("C_y_1-E2", PointVar::Var(v_D1, e_D1));
   const int E1 = v.allocate_point("E1", PointVar::Var(v_E1, row(e.E1, 0)));
-  const int minus_E1 = v.allocate_point("-E1", PointVar::Var(v_D2, e_D2));
+  const int minus_E1 = v.allocate_point("-E1", PointVar::NegOf(v_E1, e_D2));   // a*(-E1) runs as -(a*E1) on E1's window table
   v.constrain(pk, { { a, G_a }, { a0, G_a_0 }, { a1, G_a_1 } });
   v.constrain(C_y_1_minus_E2, { { z, G_y_1 }, { a, minus_E1 } });
   v.constrain(C_y_2p, { { a1, C_y_2 } });

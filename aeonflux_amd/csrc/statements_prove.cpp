@@ -396,7 +396,7 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
       sc1.push_back(mk_scalarop(a1, 32, m3, 32, a0, 32, false, kk));        // a0 + a1*m3
       sc2.push_back(mk_scalarop(z, 32, kk, 32, nullptr, 0, true, z1));      // z1 = -z(a0 + a1*m3) (encryption.rs:78)
       int32_t *v_E1 = as.new_var(), *v_E2 = as.new_var(), *v_C1 = as.new_var(), *v_C2 = as.new_var(), *v_C3 = as.new_var(),
-              *v_C2p = as.new_var(), *v_D1 = as.new_var(), *v_D2 = as.new_var();
+              *v_C2p = as.new_var(), *v_D1 = as.new_var();
       uint8_t *e_D1 = as.new_enc(), *e_D2 = as.new_enc();
       // Keypair::encrypt (symmetric.rs:252-261): E1 = M2*(a0 + a1*m3), E2 = E1*a + M1
       msm1.push_back(mk_job({ mk_term(kk, 32, v_M2, -1, false) }, nullptr, v_E1, orow(q.E1, 0), false));
@@ -407,7 +407,7 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
       msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gy(2), false), mk_term(m3, 32, nullptr, (int32_t)c->id_Gm(i), false) }, nullptr, v_C3, orow(q.C_y_3, 0), false));
       msm1b.push_back(mk_job({ mk_term(a1, 32, v_C2, -1, false) }, nullptr, v_C2p, orow(q.C_y_2p, 0), false));
       afx_pointop_job d1 = { v_C1, v_E2, nullptr, +1, -1, v_D1, e_D1, 0 };
-      afx_pointop_job d2 = { v_E1, nullptr, nullptr, -1, 0, v_D2, e_D2, 0 };
+      afx_pointop_job d2 = { v_E1, nullptr, nullptr, -1, 0, nullptr, e_D2, 0 };   // only the encoding of -E1 is needed
       pops.push_back(d1);
       pops.push_back(d2);
       SchnorrBuilder ep(as, "2019/1416 anonymous credentials", "2019/1416 proof of encryption");
@@ -430,7 +430,7 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
       const int C_y_2p = ep.allocate_point("C_y_2'", PointVar::Var(v_C2p, orow(q.C_y_2p, 0)));
       const int C_y_1_minus_E2 = ep.allocate_point("C_y_1-E2", PointVar::Var(v_D1, e_D1));
       const int E1 = ep.allocate_point("E1", PointVar::Var(v_E1, orow(q.E1, 0)));
-      const int minus_E1 = ep.allocate_point("-E1", PointVar::Var(v_D2, e_D2));
+      const int minus_E1 = ep.allocate_point("-E1", PointVar::NegOf(v_E1, e_D2));   // b_a*(-E1) runs as -(b_a*E1) on E1's window table
       ep.constrain(pk, { { sa, G_a }, { sa0, G_a_0 }, { sa1, G_a_1 } });
       ep.constrain(C_y_1_minus_E2, { { sz, G_y_1 }, { sa, minus_E1 } });
       ep.constrain(C_y_2p, { { sa1, C_y_2 } });
