@@ -266,13 +266,15 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_scalarop(const afx_scalarop_job* 
 //   AFX_EXPERIMENT_ALIAS_TABLES        every lane gathers item 0's window table: the gathers hit L1/L2 and the chain runs as
 //                                      if table traffic were free - the upper bound on any table-layout or -size change
 //   AFX_EXPERIMENT_WINDOW_ENTRY_MAJOR  4-bit-window tables laid out [entry][item] like the NAF tables (results stay right)
-//   AFX_EXPERIMENT_NO_IDENTITY_ENTRY   entry 0 (the identity) is not written (1/9 of the table bytes)
 //   AFX_EXPERIMENT_W3                  cost/traffic emulation of signed 3-bit windows: 85 windows x 3 doublings, 5-entry tables
 #ifdef AFX_EXPERIMENT_ALIAS_TABLES
 #define AFX_TABLE_ITEM(item) ((item) & 0u)
 #else
 #define AFX_TABLE_ITEM(item) (item)
 #endif
+// the identity in window-table entry form (Y+X = 1, Y-X = 1, 2Z = 2, 2dT = 0 as canonical 32-byte words): what digit 0 adds
+__device__ __attribute__((aligned(16))) const int32_t AFX_IDENTITY_ENTRY[AFX_TABLE_ENTRY_DWORDS] = {
+  1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 // per-lane context of one job inside k_msm
 struct msm_env {
   const afx_msm_job* job;
@@ -292,11 +294,14 @@ AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w,
 #else
   const uint32_t idx3 = idx;
 #endif
+  // multiples 1..8 are stored (at 0..7); digit 0 reads the one identity entry every lane shares (an address select, no table bytes)
+  const uint32_t stored = idx3 ? idx3 - 1 : 0;
 #ifdef AFX_EXPERIMENT_WINDOW_ENTRY_MAJOR
-  const int32_t* ent = e.table_ws + (size_t)e.job->term[t].table_slot * e.count * AFX_VAR_TABLE_DWORDS + ((size_t)idx3 * e.count + AFX_TABLE_ITEM(e.item)) * AFX_TABLE_ENTRY_DWORDS;
+  const int32_t* own = e.table_ws + (size_t)e.job->term[t].table_slot * e.count * AFX_VAR_TABLE_DWORDS + ((size_t)stored * e.count + AFX_TABLE_ITEM(e.item)) * AFX_TABLE_ENTRY_DWORDS;
 #else
-  const int32_t* ent = e.table_ws + ((size_t)e.job->term[t].table_slot * e.count + AFX_TABLE_ITEM(e.item)) * AFX_VAR_TABLE_DWORDS + idx3 * AFX_TABLE_ENTRY_DWORDS;
+  const int32_t* own = e.table_ws + ((size_t)e.job->term[t].table_slot * e.count + AFX_TABLE_ITEM(e.item)) * AFX_VAR_TABLE_DWORDS + stored * AFX_TABLE_ENTRY_DWORDS;
 #endif
+  const int32_t* ent = idx3 ? own : AFX_IDENTITY_ENTRY;
   return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent), neg), next);
 }
 // acc += (AFX_POS_BITS-bit signed digit j) * 2^(AFX_POS_BITS*j) * (generator of term t), from the positional tables
@@ -345,7 +350,7 @@ AFX_DEV void msm_recode(const afx_msm_job* job, uint32_t* __restrict__ digit_ws,
 }
 // per-lane window table of one variable base: multiples 0..8 (signed 4-bit windows), or the odd multiples
 // 1, 3, ..., 15 (ODD: the terms that run a width-5 NAF)
-// Layout inside a slot's AFX_VAR_TABLE_DWORDS * count dwords: 4-bit-window tables are item-major ([item][entry]: a lane's 9
+// Layout inside a slot's AFX_VAR_TABLE_DWORDS * count dwords: 4-bit-window tables are item-major ([item][entry]: a lane's 8 stored
 // entries are contiguous, its digit picks one), NAF tables entry-major ([entry][item]: every lane of a wave reads the SAME
 // entry, so the wave's gather is 64 x 128 contiguous bytes).  `stride` = dwords between consecutive entries.
 template <bool ODD>
@@ -361,10 +366,7 @@ AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, const ge_
     }
   } else {
     const ge_cached cP = ge_p3_to_cached_reduced(P);
-#ifndef AFX_EXPERIMENT_NO_IDENTITY_ENTRY
-    cached_store(tab, ge_cached_identity());
-#endif
-    cached_store(tab + stride, cP);
+    cached_store(tab, cP);   // k*P at entry k - 1; the identity (digit 0) is not stored
 #ifdef AFX_EXPERIMENT_W3
     const int entries = 5;
 #else
@@ -373,7 +375,7 @@ AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, const ge_
 #pragma unroll 1
     for (int k = 2; k < entries; k++) {
       Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
-      cached_store(tab + k * stride, ge_p3_to_cached_reduced(Q));
+      cached_store(tab + (k - 1) * stride, ge_p3_to_cached_reduced(Q));
     }
   }
 }

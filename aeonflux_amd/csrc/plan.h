@@ -8,6 +8,8 @@
 
 #define AFX_MSM_MAX_TERMS 72   /* Z job: 2 + n + #public scalars <= 2 + 2n; issuance: n + 4 */
 #define AFX_TABLE_ENTRIES 9            /* variable bases: 0*P (identity) .. 8*P, signed 4-bit windows */
+#define AFX_TABLE_STORED 8             /* entries kept per table: 1*P .. 8*P (digit 0 reads one shared identity entry), or the 8 odd
+                                          multiples of a width-5 NAF term */
 /* positional tables: for every window position j, d * 2^(AFX_POS_BITS * j) * G for d = 0 .. 2^(AFX_POS_BITS-1), affine
  * niels.  A fixed-base term costs AFX_POS_WINDOWS additions and no doubling, wherever in the job it is added. */
 #ifndef AFX_POS_BITS
@@ -21,7 +23,7 @@
 #define AFX_VAR_DWORDS 40              /* extended point: X,Y,Z,T x 10 limbs */
 #define AFX_NIELS_DWORDS 30            /* affine niels: y+x, y-x, 2dxy */
 #define AFX_TABLE_ENTRY_DWORDS 32       /* a window-table entry: 4 field elements as canonical 256-bit words = 128 B = 2 HBM sectors */
-#define AFX_VAR_TABLE_DWORDS (AFX_TABLE_ENTRIES * AFX_TABLE_ENTRY_DWORDS)
+#define AFX_VAR_TABLE_DWORDS (AFX_TABLE_STORED * AFX_TABLE_ENTRY_DWORDS)
 #define AFX_BLOCK 256
 /* field multiplications / squarings of one ristretto255 decoding / encoding as ge.cuh implements them
  * (measured on the host build of that header: tests/test_device_arith_on_host.py) */
