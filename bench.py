@@ -379,10 +379,13 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
         dist.destroy_process_group()
 
 
-# measured v_mad_i64_i32 issue rate at the occupancy the kernels run at (profiles/r01_valu_rates_ubench.txt, 2 waves
-# per SIMD: 5.54 cycles per wave-instruction): 64 lanes / 5.54 cycles x 1024 SIMDs x 2.4 GHz.  No published figure
-# exists for this opcode, so the "peak" of the compute-side figure is this microbenchmark's.
-MAD_PEAK_T = 64 / 5.54 * 1024 * 2.4e9 / 1e12
+# v_mad_i64_i32 issue cost at the occupancy the kernels run at (2 waves per SIMD), measured with a pure multiply-add loop
+# compiled from plain C (tools/ubench/mad_sustained.hip, profiles/r02_mad_sustained.txt): <= 4.68 cycles per wave-instruction;
+# that loop sustains 32.2 T mads/s at the ~2.29 GHz the power cap allows it.  (Round 1 priced the instruction at 5.54 cycles
+# from an inline-asm loop; that overstated every "valu" fraction by 18 %.)  No published figure exists for this opcode.
+MAD_CYCLES = 4.68
+MAD_PEAK_T = 64 / MAD_CYCLES * 1024 * 2.4e9 / 1e12      # at the nominal 2.4 GHz
+MAD_SUSTAINED_T = 32.2                                  # what a pure multiply-add stream sustains at the power cap
 
 
 NOMINAL_MHZ = 2400.0
@@ -400,7 +403,8 @@ def valu_side(ctx, items_per_step, field_kernel_ms_per_step):
     return {"unit": "T multiply-adds/s (v_mad_i64_i32)", "achieved": achieved, "peak": MAD_PEAK_T, "frac": achieved / MAD_PEAK_T,
             "core_clock_mhz_measured": mhz, "peak_at_measured_clock": at_clock, "frac_at_measured_clock": (achieved / at_clock) if at_clock else None,
             "clock_note": "peak is at the nominal 2400 MHz; the kernels run at the socket power cap, below it",
-            "peak_source": "tools/ubench/valu_rates.hip on this GPU (no published figure)", "per_item": dict(st, mads=mads),
+            "peak_source": "tools/ubench/mad_sustained.hip on this GPU (no published figure): %.2f cycles per wave-instruction" % MAD_CYCLES,
+            "peak_sustained_pure_mad_loop": MAD_SUSTAINED_T, "frac_of_sustained": achieved / MAD_SUSTAINED_T, "per_item": dict(st, mads=mads),
             "time_base": "summed durations of the kernels doing field arithmetic (k_msm_*, k_decode, k_pointop, k_from_uniform)"}
 
 
