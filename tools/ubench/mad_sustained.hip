@@ -8,6 +8,7 @@
 
 constexpr int NCH = 8;
 
+template <int SIGNED>
 __global__ void __launch_bounds__(256, 2) k_mad(uint64_t* out, unsigned long long* probe, uint32_t seed, int iters) {
   const uint32_t t = threadIdx.x + blockIdx.x * blockDim.x;
   const bool p = blockIdx.x == 0 && threadIdx.x == 0;
@@ -20,9 +21,9 @@ __global__ void __launch_bounds__(256, 2) k_mad(uint64_t* out, unsigned long lon
   for (int c = 0; c < NCH; ++c) {
     a[c] = ((uint64_t)(x + c) << 32) | (y + 3 * c);
     x ^= x << 13; x ^= x >> 17; x ^= x << 5;
-    xs[c] = (int32_t)(x & 0x3ffffff) - (1 << 25);    // 26-bit signed limbs, like the field elements' (fe.cuh)
+    xs[c] = (int32_t)(x & 0x3ffffff) - (SIGNED ? (1 << 25) : 0);    // 26-bit limbs: centred (signed) or raw (unsigned), as in fe.cuh
     y ^= y << 13; y ^= y >> 17; y ^= y << 5;
-    ys[c] = (int32_t)(y & 0x3ffffff) - (1 << 25);
+    ys[c] = (int32_t)(y & 0x3ffffff) - (SIGNED ? (1 << 25) : 0);
   }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -52,11 +53,15 @@ int main() {
   hipMalloc(&out, sizeof(uint64_t) * blocks * 256); hipMalloc(&probe, 16);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   printf("# v_mad_i64_i32, %d CUs, 2 waves per SIMD, 8 independent chains per lane, operands changing\n", ncu);
+  for (int mode = 0; mode < 4; mode++)
   for (int iters : { 2000, 20000, 200000, 600000 }) {
+    if (mode >= 1 && iters < 600000) continue;
+    const int sgn = mode == 0 || mode == 2;
     float best = 1e30f; unsigned long long pv[2] = { 0, 0 };
     for (int r = 0; r < 2; r++) {
       hipEventRecord(e0);
-      hipLaunchKernelGGL(k_mad, dim3(blocks), dim3(256), 0, 0, out, probe, 7u + r, iters);
+      if (sgn) hipLaunchKernelGGL(k_mad<1>, dim3(blocks), dim3(256), 0, 0, out, probe, 7u + r, iters);
+      else hipLaunchKernelGGL(k_mad<0>, dim3(blocks), dim3(256), 0, 0, out, probe, 7u + r, iters);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       if (ms < best) { best = ms; hipMemcpy(pv, probe, 16, hipMemcpyDeviceToHost); }
@@ -65,8 +70,8 @@ int main() {
     const double mhz = pv[1] ? 100.0 * pv[0] / pv[1] : 0;
     // per SIMD: 2 waves x iters*64 wave-instructions of mad (the ~2 scalar-ish VALU ops per 8 mads are counted out below)
     const double cyc = best * 1e-3 * mhz * 1e6 / (2.0 * iters * 8 * NCH);
-    printf("kernel %9.3f ms   %6.2f T mads/s   core clock %7.1f MHz   %.2f cycles per wave-instruction per SIMD at that clock\n",
-           best, mads / best / 1e9, mhz, cyc);
+    printf("%s limbs  kernel %9.3f ms   %6.2f T mads/s   core clock %7.1f MHz   %.2f cycles per wave-instruction per SIMD at that clock\n",
+           sgn ? "centred (signed) " : "raw (unsigned)   ", best, mads / best / 1e9, mhz, cyc);
   }
   return 0;
 }
