@@ -75,22 +75,23 @@ AFX_DEV ge_p3 p3_load_uniform(const int32_t* c40) {
 }
 // one window-table entry (cached form): four field elements in canonical 32-byte form, 128 contiguous bytes,
 // 16-byte aligned = exactly two 64-byte HBM sectors per gather (the 40-limb form straddled 3.5 on average)
-AFX_DEV void cached_store(int32_t* p, const ge_cached& q) {
+// `chunk` = dwords between the entry's consecutive 16-byte pieces: 4 (the 128 bytes contiguous: a lane's own entry of an
+// item-major table) or 4 * count (piece-major: the entries of neighbouring items interleaved piece by piece, so that each of the
+// eight loads of a wave that reads ONE entry index - a NAF table - is 1 KB contiguous instead of 64 pieces 128 bytes apart)
+AFX_DEV void cached_store(int32_t* p, size_t chunk, const ge_cached& q) {
   uint32_t w[32];
   fe_tobytes(w, q.YpX);
   fe_tobytes(w + 8, q.YmX);
   fe_tobytes(w + 16, q.Z2);
   fe_tobytes(w + 24, q.T2d);
-  uint4* d = reinterpret_cast<uint4*>(p);
 #pragma unroll
-  for (int i = 0; i < 8; i++) d[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+  for (int i = 0; i < 8; i++) *reinterpret_cast<uint4*>(p + i * chunk) = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-AFX_DEV ge_cached cached_load(const int32_t* p) {
-  const uint4* s = reinterpret_cast<const uint4*>(p);
+AFX_DEV ge_cached cached_load(const int32_t* p, size_t chunk) {
   uint32_t w[32];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    const uint4 t = s[i];
+    const uint4 t = *reinterpret_cast<const uint4*>(p + i * chunk);
     w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
   }
   ge_cached q;
@@ -302,7 +303,7 @@ AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w,
   const int32_t* own = e.table_ws + ((size_t)e.job->term[t].table_slot * e.count + AFX_TABLE_ITEM(e.item)) * AFX_VAR_TABLE_DWORDS + stored * AFX_TABLE_ENTRY_DWORDS;
 #endif
   const int32_t* ent = idx3 ? own : AFX_IDENTITY_ENTRY;
-  return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent), neg), next);
+  return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent, 4), neg), next);
 }
 // acc += (AFX_POS_BITS-bit signed digit j) * 2^(AFX_POS_BITS*j) * (generator of term t), from the positional tables
 AFX_DEV ge_p3 msm_add_positional(const msm_env& e, const int32_t* __restrict__ pos_tables, const ge_p3& acc, uint32_t t, uint32_t j, int next) {
@@ -352,21 +353,21 @@ AFX_DEV void msm_recode(const afx_msm_job* job, uint32_t* __restrict__ digit_ws,
 // 1, 3, ..., 15 (ODD: the terms that run a width-5 NAF)
 // Layout inside a slot's AFX_VAR_TABLE_DWORDS * count dwords: 4-bit-window tables are item-major ([item][entry]: a lane's 8 stored
 // entries are contiguous, its digit picks one), NAF tables entry-major ([entry][item]: every lane of a wave reads the SAME
-// entry, so the wave's gather is 64 x 128 contiguous bytes).  `stride` = dwords between consecutive entries.
+// entry; they are stored piece-major inside an entry, see cached_store).  `stride` = dwords between consecutive entries.
 template <bool ODD>
-AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, const ge_p3& P) {
+AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t chunk, const ge_p3& P) {
   ge_p3 Q = P;
   if (ODD) {
     const ge_cached c2 = ge_p3_to_cached(ge_double(P));
-    cached_store(tab, ge_p3_to_cached_reduced(P));
+    cached_store(tab, chunk, ge_p3_to_cached_reduced(P));
 #pragma unroll 1
     for (int k = 1; k < 8; k++) {
       Q = ge_p1p1_to_p3(ge_add_cached(Q, c2, false));
-      cached_store(tab + k * stride, ge_p3_to_cached_reduced(Q));
+      cached_store(tab + k * stride, chunk, ge_p3_to_cached_reduced(Q));
     }
   } else {
     const ge_cached cP = ge_p3_to_cached_reduced(P);
-    cached_store(tab, cP);   // k*P at entry k - 1; the identity (digit 0) is not stored
+    cached_store(tab, chunk, cP);   // k*P at entry k - 1; the identity (digit 0) is not stored
 #ifdef AFX_EXPERIMENT_W3
     const int entries = 5;
 #else
@@ -375,7 +376,7 @@ AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, const ge_
 #pragma unroll 1
     for (int k = 2; k < entries; k++) {
       Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
-      cached_store(tab + (k - 1) * stride, ge_p3_to_cached_reduced(Q));
+      cached_store(tab + (k - 1) * stride, chunk, ge_p3_to_cached_reduced(Q));
     }
   }
 }
@@ -413,11 +414,11 @@ k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table
   int32_t* slot = table_ws + (size_t)row.table_slot * count * AFX_VAR_TABLE_DWORDS;
   const ge_p3 P = var_load(row.var, count, item);
 #ifdef AFX_EXPERIMENT_WINDOW_ENTRY_MAJOR
-  msm_build_table<ODD>(slot + (size_t)item * AFX_TABLE_ENTRY_DWORDS, (size_t)count * AFX_TABLE_ENTRY_DWORDS, P);
-#else
-  if (ODD) msm_build_table<true>(slot + (size_t)item * AFX_TABLE_ENTRY_DWORDS, (size_t)count * AFX_TABLE_ENTRY_DWORDS, P);
-  else msm_build_table<false>(slot + (size_t)item * AFX_VAR_TABLE_DWORDS, AFX_TABLE_ENTRY_DWORDS, P);
+  if (!ODD) { msm_build_table<false>(slot + (size_t)item * AFX_TABLE_ENTRY_DWORDS, (size_t)count * AFX_TABLE_ENTRY_DWORDS, 4, P); return; }
 #endif
+  // NAF tables: [entry][piece][item][16 B]; window tables: [item][entry][128 B]
+  if (ODD) msm_build_table<true>(slot + (size_t)item * 4, (size_t)count * AFX_TABLE_ENTRY_DWORDS, (size_t)count * 4, P);
+  else msm_build_table<false>(slot + (size_t)item * AFX_VAR_TABLE_DWORDS, AFX_TABLE_ENTRY_DWORDS, 4, P);
 }
 
 template <int KIND>
@@ -462,8 +463,8 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
           const bool neg = (ev & 0x80u) != 0;
           ev = sched[++ei];
           const bool last = !lane_adds && (ev >> 16) != (uint32_t)bit;
-          const int32_t* ent = table_ws + (size_t)job->term[t].table_slot * count * AFX_VAR_TABLE_DWORDS + ((size_t)idx * count + AFX_TABLE_ITEM(item)) * AFX_TABLE_ENTRY_DWORDS;
-          acc = ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent), neg), last ? after : GE_FOR_ADD);
+          const int32_t* ent = table_ws + (size_t)job->term[t].table_slot * count * AFX_VAR_TABLE_DWORDS + (size_t)idx * count * AFX_TABLE_ENTRY_DWORDS + (size_t)AFX_TABLE_ITEM(item) * 4;
+          acc = ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent, (size_t)count * 4), neg), last ? after : GE_FOR_ADD);
         }
         if (lane_adds) {
 #pragma unroll 1
