@@ -1,0 +1,30 @@
+/* A C host of the engine: the smallest complete caller of the drop-in boundary (include/aeonflux_gpu.h).
+ * Verifies a batch of presentations held in host memory on every GPU of the node with one call, the way a C (or, through
+ * the same ABI, Rust / Go / Java) server would behind Issuer::verify (/root/reference/src/issuer.rs:141-147).
+ * Build: gcc -std=c99 -I include integration/example_verify.c -L aeonflux_amd/lib -laeonflux_gpu -o example_verify
+ * (tests/test_abi_and_host.py compiles it; it needs a GPU to run). */
+#include <stdio.h>
+#include <stdlib.h>
+#include "aeonflux_gpu.h"
+
+/* params/key/issuer_params: the byte forms the crate already defines (SystemParameters::to_bytes, amacs::SecretKey::to_bytes,
+ * C_W || I); shape + batch: same-shape presentations as struct-of-arrays, see the header. */
+int verify_on_all_gpus(const unsigned char* params, size_t params_len, const unsigned char* key, size_t key_len,
+                       const unsigned char issuer_params[64], const int* devices, unsigned n_devices, const afx_shape* shape,
+                       const afx_presentation_soa* batch, size_t count, unsigned char* status) {
+  afx_group* g = NULL;
+  int rc = afx_group_create(&g, devices, n_devices, params, params_len, key, key_len, issuer_params);
+  if (rc != AFX_OK) { fprintf(stderr, "afx_group_create: %d %s\n", rc, afx_last_error()); return rc; }
+  rc = afx_group_verify_presentations(g, shape, batch, count, status);   /* status[i]: AFX_ST_OK or AFX_ST_VERIFICATION_FAILURE */
+  if (rc != AFX_OK) fprintf(stderr, "afx_group_verify_presentations: %d %s\n", rc, afx_last_error());
+  afx_group_destroy(g);   /* wipes every copy of the key */
+  return rc;
+}
+
+/* the same with the caller's own threads: each thread takes a contiguous range of the batch on its own context */
+int verify_my_range(afx_ctx* ctx, unsigned members, unsigned index, const afx_shape* shape, const afx_presentation_soa* batch,
+                    size_t count, unsigned char* status) {
+  size_t first = 0, n = 0;
+  afx_shard_bounds(count, members, index, &first, &n);
+  return afx_verify_presentations_range(ctx, shape, batch, count, first, n, status);
+}

@@ -28,6 +28,26 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_header_is_valid_c_and_the_c_example_links(tmp_path):
+    """the boundary is a C ABI: the header must compile as C99 (not only as C++), and the C example must link against the library"""
+    hdr = os.path.join(ROOT, "include")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", hdr, "-x", "c", os.path.join(hdr, "aeonflux_gpu.h")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    import aeonflux_amd as afx
+    main = tmp_path / "main.c"
+    main.write_text('#include "aeonflux_gpu.h"\nint verify_my_range(afx_ctx*, unsigned, unsigned, const afx_shape*, const afx_presentation_soa*, size_t, unsigned char*);\n'
+                    'int main(void) { return verify_my_range(0, 1, 0, 0, 0, 0, 0) == AFX_E_BAD_ARGS ? 0 : 1; }\n')
+    exe = tmp_path / "example"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", hdr, os.path.join(ROOT, "integration", "example_verify.c"), str(main),
+                        "-L", os.path.dirname(afx.LIB_PATH), "-laeonflux_gpu", "-Wl,-rpath," + os.path.dirname(afx.LIB_PATH), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # null arguments are refused before any device is touched, so this runs without a GPU
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+
+
 def test_no_cpu_fallback_without_gpu():
     """on a box without a HIP device the engine must fail loudly, never compute on the CPU"""
     import torch
