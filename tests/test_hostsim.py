@@ -94,6 +94,13 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     stx = rb(3)
     assert afx.lib().afx_encrypt(ctx.h, C.byref(kpsoa), e[0].ctypes.data, e[1].ctypes.data, e[2].ctypes.data, 3, e[3].ctypes.data, e[4].ctypes.data, stx.ctypes.data) == 0
     assert afx.lib().afx_decrypt(ctx.h, C.byref(kpsoa), e[3].ctypes.data, e[4].ctypes.data, 3, e[5].ctypes.data, e[6].ctypes.data, e[7].ctypes.data, None, stx.ctypes.data) == 0
+    # the key-independent schedule: no NAF jobs, every launch list still assembles
+    assert afx.lib().afx_ctx_set_fixed_key_schedule(ctx.h, 1) == 0
+    batch.verify_presentations(ctx, shape, pres)
+    batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
+    assert afx.lib().afx_ctx_set_fixed_key_schedule(ctx.h, 0) == 0
+    mhz = C.c_double(-1)
+    assert afx.lib().afx_ctx_get_core_clock_mhz(ctx.h, C.byref(mhz)) == 0 and mhz.value >= 0
     # a range of a batch, and the same batch over a two-member group (two fake devices)
     st_r = batch.verify_presentations(ctx, shape, pres, first=1, n=2)
     assert st_r[0] == 255 and len(st_r) == 3
