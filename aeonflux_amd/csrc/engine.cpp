@@ -291,6 +291,23 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   for (size_t i = 0; i < n; i++)
     if (jobs[i].chain_to >= 0) producer[jobs[i].chain_to] = (int)i;
   auto kind_of = [](const afx_msm_job& j) { return j.n_var == 0 ? 0 : (j.n_uni ? 2 : 1); };
+  // Jobs whose result is only ever encoded (no consumer of the point itself, no addend): they run on halved scalars and leave
+  // half their sum in a workspace slot; one k_compress2x launch at the end of this list encodes the doubles with a single field
+  // inversion per item (kernels.hip).  That is every recomputed or fresh commitment of a Schnorr proof: 26 of the 35 encodings
+  // of a C3 presentation.  Jobs with batch-constant NAF scalars keep the plain encoding (their scalars are digits on the host).
+  std::vector<int32_t*> half_of(n, nullptr);
+  std::vector<afx_compress_job> cjobs;
+  for (size_t i = 0; i < n; i++) {
+    const afx_msm_job& j = jobs[i];
+    if (!j.out_enc || j.out_var || j.addend || j.n_uni || ctx->no_compress2x) continue;
+    half_of[i] = new_var();
+    afx_compress_job cj = { half_of[i], j.out_enc, j.reject_identity, 0 };
+    cjobs.push_back(cj);
+    // the plain encoding was counted above: replace it by this job's share of k_compress2x (two passes over e, f, g, h)
+    stats.field_mul += 22; stats.field_mul -= AFX_ENCODE_MUL;
+    stats.field_sq += 8; stats.field_sq -= AFX_ENCODE_SQ;
+  }
+  if (!cjobs.empty()) { stats.field_mul += 11; stats.field_sq += 254; }   // the one inversion
   std::vector<char> done(n, 0);
   const uint32_t blocks_per_row = (count + AFX_BLOCK - 1) / AFX_BLOCK, resident = 2 * ctx->n_cu;
   uint32_t dslot = 0, tslot = 0;
@@ -313,6 +330,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     for (size_t i : rows) {
       afx_msm_job j = jobs[i];
       j.next_job = 0;
+      j.half_var = half_of[i];
       j.digit_slot = dslot; dslot += j.n_terms;
       // one window table per (base, kind of multiples) of this launch list: constraints that share a base share its table
       // (a proof of encryption uses C_y_2 and C_y_2' in two constraints each, encryption.rs:197,204)
@@ -366,6 +384,15 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     l.jobs_off = blob_alloc(sizeof(afx_msm_job) * out.size(), 16);
     memcpy(blob_.data() + l.jobs_off, out.data(), sizeof(afx_msm_job) * out.size());
     launches.push_back(l);
+  }
+  if (!cjobs.empty()) {
+    Launch cl;
+    cl.kind = L_COMPRESS;
+    cl.njobs = (uint32_t)cjobs.size();
+    cl.jobs_off = blob_alloc(sizeof(afx_compress_job) * cjobs.size(), 16);
+    memcpy(blob_.data() + cl.jobs_off, cjobs.data(), sizeof(afx_compress_job) * cjobs.size());
+    cl.prefix_ws = (int32_t*)ws_alloc(sizeof(int32_t) * 10 * cjobs.size() * (size_t)count);
+    launches.push_back(cl);
   }
   max_digit_slots = std::max<size_t>(max_digit_slots, dslot);
   max_table_slots = std::max<size_t>(max_table_slots, tslot);
@@ -427,6 +454,7 @@ int Assembler::run() {
       case L_SCCHECK: AFX_HIP(afxk_sccheck(s, (const afx_sccheck_job*)jobs, l.njobs, bad_, count)); break;
       case L_POINTOP: AFX_HIP(afxk_pointop(s, (const afx_pointop_job*)jobs, l.njobs, bad_, count)); break;
       case L_SCALAROP: AFX_HIP(afxk_scalarop(s, (const afx_scalarop_job*)jobs, l.njobs, count)); break;
+      case L_COMPRESS: AFX_HIP(afxk_compress2x(s, (const afx_compress_job*)jobs, l.njobs, l.prefix_ws, bad_, count)); break;
       case L_MSM_TABLES: AFX_HIP(afxk_msm_tables(s, l.odd, (const afx_table_job*)jobs, l.njobs, table_ws, count)); break;
       case L_MSM_FIXED: case L_MSM_WINDOW: case L_MSM_NAF: {
         // pipelined lanes: the heavy kernel of one lane never runs beside the other lane's (only the light kernels

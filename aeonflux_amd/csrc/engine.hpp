@@ -98,6 +98,7 @@ struct afx_ctx {
   bool pipelining = false;
   bool strict = false;   // afx_ctx_set_strict
   bool fixed_key_schedule = false;   // afx_ctx_set_fixed_key_schedule: no NAF for the issuer key's scalars
+  bool no_compress2x = false;        // measurement switch (AFX_NO_COMPRESS2X=1 in the environment at context creation): every job encodes its own result
   uint32_t chunk_items = 0;   // afx_ctx_set_chunk_items; 0 = default
   afx_plan_stats last_stats = {};   // per-item operation counts of the most recent plan
   std::map<std::pair<uint64_t, uint32_t>, size_t> plan_sizes;   // (plan key, pass size) -> workspace bytes (statements.hpp run_chunked)
@@ -121,7 +122,7 @@ namespace afx {
 
 // L_MSM_WINDOW keeps the slot the single k_msm kernel had (timing names: statements.cpp KIND_NAMES)
 enum LaunchKind { L_FILL_BAD, L_DECODE, L_SCCHECK, L_POINTOP, L_SCALAROP, L_MSM_WINDOW, L_HASH, L_FROM_UNIFORM, L_REDUCE_WIDE, L_COPY, L_FINISH,
-                  L_MSM_FIXED, L_MSM_NAF, L_MSM_TABLES, L_KINDS };
+                  L_MSM_FIXED, L_MSM_NAF, L_MSM_TABLES, L_COMPRESS, L_KINDS };
 
 struct Launch {
   LaunchKind kind;
@@ -134,6 +135,7 @@ struct Launch {
   uint8_t fail_code = AFX_ST_VERIFICATION_FAILURE;
   size_t bytes = 0;         // L_COPY
   int odd = 0;              // L_MSM_TABLES: odd multiples (NAF terms) or multiples 0..8
+  int32_t* prefix_ws = nullptr;   // L_COMPRESS: scratch for the prefix products (njobs * 10 * count dwords)
 };
 
 // Builds one call's kernel launch list over a chunk of `count` items.

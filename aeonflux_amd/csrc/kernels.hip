@@ -340,7 +340,8 @@ AFX_DEV void msm_recode(const afx_msm_job* job, uint32_t* __restrict__ digit_ws,
   const uint32_t dslot = job->digit_slot;
 #pragma unroll 1
   for (uint32_t t = from; t < nt; t++) {
-    const sc s = sc_load_item(job->term[t].scalar, job->term[t].scalar_stride, item);
+    sc s = sc_load_item(job->term[t].scalar, job->term[t].scalar_stride, item);
+    if (job->half_var) s = sc_half(s);   // the job computes half of its sum; k_compress2x encodes the double
     uint32_t b[9];
     b[8] = 0;
     if (t < nv) sc_bias(b, s, 0x88888888u);
@@ -397,6 +398,7 @@ AFX_DEV void msm_finish(const afx_msm_job* job, ge_p3 acc, uint32_t* __restrict_
     acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_p3_to_cached(A), job->addend_negate != 0));
   }
   if (job->out_var) var_store(job->out_var, count, item, acc);
+  if (job->half_var) { var_store(job->half_var, count, item, acc); return; }   // encoded by k_compress2x
   if (job->out_enc) {
     uint32_t wenc[8];
     ristretto_encode(wenc, acc);
@@ -498,6 +500,69 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
   if (probe) {
     atomicAdd(&clock_probe[0], (unsigned long long)clock64() - c0);
     atomicAdd(&clock_probe[1], (unsigned long long)wall_clock64() - r0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_compress2x: the encodings of 2*P_j for all the points P_j an item's jobs left in half_var, with ONE field inversion per item
+// ---------------------------------------------------------------------------------------------
+// RistrettoPoint::compress needs an inverse square root per point (254 squarings).  The encoding of TWICE a point does not: with
+//   e = 2XY, f = Z^2 + dT^2, g = Y^2 + X^2, h = Z^2 - dT^2     (2P = (e*f : g*h : f*g : e*h) in extended coordinates)
+// it is |(h' - g') * magic * g' / (f*h)| after two sign/rotation decisions that only need 1/(e*g) and 1/(f*h) - plain inversions,
+// which Montgomery's trick shares (curve25519-dalek's RistrettoPoint::double_and_compress_batch [3P] is the same computation).
+// So a job whose result is only ever ENCODED (every recomputed / fresh commitment of a Schnorr proof) runs on halved scalars
+// (msm_recode) and leaves R/2 here; lane = item walks its jobs twice: prefix products of e*f*g*h forwards, one inversion, the
+// encodings backwards.  e*f*g*h = 0 exactly for the identity's representatives (X = 0 or Y = 0; f, g, h never vanish on the
+// even subgroup), whose encoding is all zeros; such a factor is left out of the product.  tests/: every byte-parity test of the
+// commitments and challenges goes through this kernel; tests/pyref checks the formula against encode(P + P).
+struct c2x_state { fe e, f, g, h, eg, fh, efgh; bool zero; };
+AFX_DEV c2x_state c2x_from(const ge_p3& P) {
+  c2x_state s;
+  const fe XX = fe_sq(P.X), YY = fe_sq(P.Y), ZZ = fe_sq(P.Z), dTT = fe_mul(fe_sq(P.T), fe_const(FEC_D));
+  s.e = fe_mul(fe_add(P.Y, P.Y), P.X);
+  s.f = fe_add(ZZ, dTT);
+  s.g = fe_add(YY, XX);
+  s.h = fe_sub(ZZ, dTT);
+  s.eg = fe_mul(s.g, s.e);
+  s.fh = fe_mul(s.f, s.h);
+  s.efgh = fe_mul(s.eg, s.fh);
+  s.zero = fe_is_zero(s.efgh);
+  fe_cmov(s.efgh, fe_one(), s.zero);
+  return s;
+}
+__global__ void __launch_bounds__(AFX_BLOCK, 2)
+k_compress2x(const afx_compress_job* __restrict__ jobs, uint32_t njobs, int32_t* __restrict__ prefix_ws, uint32_t* __restrict__ bad, uint32_t count) {
+  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  if (item >= count) return;
+  fe prod = fe_one();
+#pragma unroll 1
+  for (uint32_t j = 0; j < njobs; j++) {
+    const c2x_state s = c2x_from(var_load(jobs[j].var, count, item));
+    fe_store_soa(prefix_ws + (size_t)j * 10 * count, 0, count, item, prod);   // product of the factors before j
+    prod = fe_mul(prod, s.efgh);
+  }
+  fe inv = fe_invert(prod);
+#pragma unroll 1
+  for (uint32_t jj = njobs; jj > 0; jj--) {
+    const uint32_t j = jj - 1;
+    const c2x_state s = c2x_from(var_load(jobs[j].var, count, item));
+    const fe inv_j = fe_mul(inv, fe_load_soa(prefix_ws + (size_t)j * 10 * count, 0, count, item));   // 1 / (e f g h)_j
+    inv = fe_mul(inv, s.efgh);
+    const fe Zinv = fe_mul(s.eg, inv_j), Tinv = fe_mul(s.fh, inv_j);
+    const bool rotate = fe_is_negative(fe_mul(s.eg, Zinv));
+    fe e = s.e, g = s.g, h = s.h, magic = fe_const(FEC_INVSQRT_A_MINUS_D);
+    fe_cmov(e, s.g, rotate);
+    fe_cmov(g, fe_neg(s.e), rotate);
+    fe_cmov(h, fe_mul(s.f, fe_const(FEC_SQRT_M1)), rotate);
+    fe_cmov(magic, fe_const(FEC_SQRT_M1), rotate);
+    g = fe_cneg(g, fe_is_negative(fe_mul(fe_mul(h, e), Zinv)));
+    const fe sres = fe_abs(fe_mul(fe_sub(h, g), fe_mul(magic, fe_mul(g, Tinv))));
+    uint32_t w[8];
+    fe_tobytes(w, sres);
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = s.zero ? 0u : w[i];
+    enc_store(jobs[j].out_enc, item, w);
+    if (jobs[j].reject_identity && is_identity_encoding(w)) atomicOr(&bad[item], AFX_BAD_IDENTITY);
   }
 }
 
@@ -682,6 +747,10 @@ hipError_t afxk_msm(hipStream_t s, int kind, const afx_msm_job* jobs, uint32_t n
 hipError_t afxk_msm_tables(hipStream_t s, int odd, const afx_table_job* rows, uint32_t nrows, int32_t* table_ws, uint32_t count) {
   if (odd) hipLaunchKernelGGL(k_msm_tables<true>, grid_for(count, nrows), dim3(AFX_BLOCK), 0, s, rows, table_ws, count);
   else hipLaunchKernelGGL(k_msm_tables<false>, grid_for(count, nrows), dim3(AFX_BLOCK), 0, s, rows, table_ws, count);
+  return hipGetLastError();
+}
+hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, uint32_t njobs, int32_t* prefix_ws, uint32_t* bad, uint32_t count) {
+  hipLaunchKernelGGL(k_compress2x, dim3((count + AFX_BLOCK - 1) / AFX_BLOCK), dim3(AFX_BLOCK), 0, s, jobs, njobs, prefix_ws, bad, count);
   return hipGetLastError();
 }
 hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count) {

@@ -100,6 +100,9 @@ typedef struct {
   uint32_t next_job;                    /* unused (round 1 chained a successor job inside the lane) */
   int32_t chain_to;                     /* host only: index (in the vector handed to Assembler::msm) of a job that consumes this
                                            job's out_var and therefore goes into a later launch; -1 none */
+  afx_var_t half_var;                   /* non-null: the job runs on HALVED scalars (s/2 mod l for every term), stores the sum here and
+                                           does not encode; k_compress2x then encodes TWICE the stored point, which needs one field
+                                           inversion per item for all such jobs together instead of a square root each (Assembler::msm) */
   uint32_t digit_slot;                  /* first recoded-scalar slot of this job in digit_ws (one per term)   */
   uint32_t table_slot;                  /* unused (slots are per term: afx_msm_term.table_slot) */
 } afx_msm_job;
@@ -111,6 +114,14 @@ typedef struct {
   uint32_t table_slot;     /* slot in table_ws                                                      */
   uint32_t pad;
 } afx_table_job;
+
+/* k_compress2x: out_enc[item] = encoding of 2 * var[item] (ristretto255) */
+typedef struct {
+  const int32_t* var;      /* SoA extended point, the half of what is to be encoded                 */
+  uint8_t* out_enc;        /* [count][32]                                                            */
+  uint32_t reject_identity;
+  uint32_t pad;
+} afx_compress_job;
 
 /* one 8-byte word of a STROBE rate block: st = (st & keep) ^ c ^ (field_word & fmask) */
 typedef struct {

@@ -182,6 +182,24 @@ AFX_DEV void sc_bias_wide(uint32_t out[9], const sc& s) {
     c >>= 32;
   }
 }
+// s * 2^-1 mod l for canonical s: (s + l) / 2 when s is odd, s / 2 otherwise.  (A non-canonical s - its item has failed already -
+// just gives some 256-bit value.)
+AFX_DEV sc sc_half(const sc& s) {
+  const uint32_t odd = s.v[0] & 1u;
+  uint32_t t[9];
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (uint64_t)s.v[i] + (odd ? SC_L[i] : 0u);
+    t[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  t[8] = (uint32_t)c;
+  sc r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = (t[i] >> 1) | (t[i + 1] << 31);
+  return r;
+}
 AFX_DEV void sc_bias(uint32_t out[8], const sc& s, uint32_t bias) {
   uint64_t c = 0;
 #pragma unroll

@@ -37,7 +37,7 @@ extern "C" void* afx_ctx_stream(const afx_ctx* ctx) { return ctx ? (void*)ctx->s
 
 // indexed by afx::LaunchKind.  "k_msm" (afx_ctx_get_timing) = the three chain kernels + the table kernel together
 static const char* const KIND_NAMES[] = { "k_fill_u32", "k_decode", "k_sccheck", "k_pointop", "k_scalarop", "k_msm_window", "k_hash",
-                                          "k_from_uniform", "k_reduce_wide", "copy", "k_finish", "k_msm_fixed", "k_msm_naf", "k_msm_tables" };
+                                          "k_from_uniform", "k_reduce_wide", "copy", "k_finish", "k_msm_fixed", "k_msm_naf", "k_msm_tables", "k_compress2x" };
 static_assert(sizeof KIND_NAMES / sizeof KIND_NAMES[0] == afx::L_KINDS, "one name per launch kind");
 static int drain_timing(afx_ctx* c) {
   for (auto& L : c->lane)
@@ -211,6 +211,7 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   c->device = device;
   c->n = n;
   c->g = n < 3 ? 3 : n;
+  { const char* off = getenv("AFX_NO_COMPRESS2X"); c->no_compress2x = off && off[0] == '1'; }
   for (afx::DevBuf* pub : { &c->trace_buf, &c->d_gen_enc, &c->d_consts, &c->d_pos_tables, &c->d_gen_ext }) pub->sensitive = false;   // public data
   AFX_HIP(hipSetDevice(device));
   {
