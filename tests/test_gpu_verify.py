@@ -246,3 +246,35 @@ def test_extreme_shapes_at_the_attribute_limit(layout, hide):
     got = gpu_verify(afx, ctx, pres)
     ctx.close()
     assert got == want and want[0] == 0 and want[1] == 1 and want[4] == 1
+
+
+def test_identity_commitments_beside_ordinary_ones():
+    """Commitments are encoded by k_compress2x with one inversion per item (Montgomery's trick over all of an item's commitments):
+    a commitment that is the identity (zero factor in the product) must be rejected like zkp rejects it, and must not disturb
+    the encodings of the item's other commitments.  All-zero challenge and responses make every commitment of that proof the
+    identity; the proofs of encryption of the same item stay ordinary."""
+    import oracle
+    import aeonflux_amd as afx
+    params, key, ip, issuer, pres = make_batch(8, "SSPPEEEE", [4, 5, 6, 7], 6, b"identity-commitments")
+    assert [issuer.verify_presentation(p) for p in pres] == [0] * 6
+    z = bytes(32)
+    for k in range(32):
+        pres[1].challenge[k] = 0                    # main proof of item 1: all commitments are the identity
+        pres[3].enc[2].challenge[k] = 0             # third proof of encryption of item 3
+    for r in range(pres[1].n_responses):
+        for k in range(32):
+            pres[1].responses[r][k] = 0
+    for r in range(6):
+        for k in range(32):
+            pres[3].enc[2].responses[r][k] = 0
+    want = [issuer.verify_presentation(p) for p in pres]
+    assert want == [0, 1, 0, 1, 0, 0]
+    ctx = afx.Context(params, key, ip)
+    ctx.set_challenge_trace(5, 6)
+    assert gpu_verify(afx, ctx, pres) == want
+    # the untouched proofs of the two rejected items still recompute the challenges they carry (their encodings came out right)
+    tr = ctx.get_challenge_trace()
+    for e in range(4):
+        assert bytes(tr[1 + e, 1]) == bytes(pres[1].enc[e].challenge)
+    assert bytes(tr[0, 3]) == bytes(pres[3].challenge) and bytes(tr[1, 3]) == bytes(pres[3].enc[0].challenge)
+    ctx.close()

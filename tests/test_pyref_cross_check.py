@@ -95,3 +95,29 @@ def test_every_flow_replays_byte_for_byte(flows):
             assert [c.hex() for c in coms] == f["verify_last_commitments"], f["name"]
         checked["verify"] += 1
     assert checked["issue"] >= 16 and checked["show"] >= 16 and checked["verify"] >= 15, checked
+
+
+def test_double_and_compress_equals_encode_of_the_double():
+    """the formula behind the engine's k_compress2x (kernels.hip): the encoding of 2P without a square root, batched over one
+    inversion, against encode(P + P) - random points, random projective scalings, every representative of a coset (P + E[4]),
+    identities in between, and the halved-scalar identity the engine relies on: 2 * ((s/2 mod l) P) encodes like s P."""
+    import hashlib
+    R = ristretto
+    tors = [R.IDENTITY, (0, R.P - 1, 1, 0), (R.SQRT_M1, 0, 1, 0), ((-R.SQRT_M1) % R.P, 0, 1, 0)]
+    pts = []
+    for i in range(40):
+        p = R.from_uniform_bytes(hashlib.sha512(b"c2x-%d" % i).digest())
+        lam = int.from_bytes(hashlib.sha256(b"lam-%d" % i).digest(), "little") % R.P or 1
+        p = R.add(p, tors[i % 4])
+        pts.append(tuple(c * lam % R.P for c in p))
+        if i % 7 == 3:
+            pts.append(tors[(i // 7) % 4])          # a representative of the identity in the middle of the batch
+    got = R.double_and_compress(pts)
+    assert got == [R.encode(R.add(p, p)) for p in pts]
+    assert bytes(32) in got
+    inv2 = (R.L + 1) // 2
+    for i in range(8):
+        p = R.from_uniform_bytes(hashlib.sha512(b"half-%d" % i).digest())
+        s = int.from_bytes(hashlib.sha512(b"s-%d" % i).digest(), "little") % R.L
+        half = R.mul(s * inv2 % R.L, R.add(p, tors[i % 4]))
+        assert R.double_and_compress([half])[0] == R.encode(R.mul(s, p))
