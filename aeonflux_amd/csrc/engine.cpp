@@ -123,6 +123,21 @@ static int naf5(int8_t out[256], const uint8_t s[32]) {
   return top;
 }
 
+// s / 2 mod l for a canonical scalar (little-endian 32 bytes): (s + l) >> 1 when s is odd
+static void host_half(uint8_t out[32], const uint8_t in[32]) {
+  static const uint8_t L[32] = { 0xed, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x58, 0xd6, 0x9c, 0xf7, 0xa2, 0xde, 0xf9, 0xde, 0x14,
+                                 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x10 };
+  uint8_t t[33];
+  unsigned carry = 0;
+  for (int i = 0; i < 32; i++) {
+    const unsigned v = in[i] + ((in[0] & 1) ? L[i] : 0) + carry;
+    t[i] = (uint8_t)v;
+    carry = v >> 8;
+  }
+  t[32] = (uint8_t)carry;
+  for (int i = 0; i < 32; i++) out[i] = (uint8_t)((t[i] >> 1) | (t[i + 1] << 7));
+}
+
 // host copy of a batch-constant scalar that lives in the context's key block (w, w', x0, x1, y...), or null
 static const uint8_t* host_scalar_of(const afx_ctx* c, const uint8_t* dev) {
   const uint8_t* base = (const uint8_t*)c->d_key.p;
@@ -202,6 +217,9 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   const size_t n = jobs.size();
   for (size_t i = 0; i < n; i++)
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
+  // Jobs whose result is only ever encoded (no consumer of the point itself, no addend) run on halved scalars; k_compress2x
+  // encodes the doubles (below, and kernels.hip)
+  auto encoded_only = [&](const afx_msm_job& j) { return j.out_enc && !j.out_var && !j.addend && !ctx->no_compress2x; };
   // variable bases whose scalar is a batch constant the host knows (the issuer key in Z and in the tag) go first
   // and run a width-5 NAF: ~43 additions each instead of 64, same schedule for every lane
   std::vector<std::vector<int8_t>> naf_of(jobs.size());
@@ -226,7 +244,10 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     int top = lane.empty() ? 0 : 252;   // per-item windows start at bit 252
     for (size_t u = 0; u < uni.size(); u++) {
       int8_t* d = naf_of[ji].data() + 256 * u;
-      top = std::max(top, naf5(d, hs[u]));
+      uint8_t halved[32];
+      if (encoded_only(j)) host_half(halved, hs[u]);   // the device halves the per-item scalars of such a job (msm_recode)
+      top = std::max(top, naf5(d, encoded_only(j) ? halved : hs[u]));
+      secure_zero(halved, sizeof halved);
       for (int b = 0; b < 256; b++) {
         if (uni[u].negate) d[b] = (int8_t)-d[b];
         nafc_of[ji][b] += d[b] != 0;
@@ -293,13 +314,13 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   auto kind_of = [](const afx_msm_job& j) { return j.n_var == 0 ? 0 : (j.n_uni ? 2 : 1); };
   // Jobs whose result is only ever encoded (no consumer of the point itself, no addend): they run on halved scalars and leave
   // half their sum in a workspace slot; one k_compress2x launch at the end of this list encodes the doubles with a single field
-  // inversion per item (kernels.hip).  That is every recomputed or fresh commitment of a Schnorr proof: 26 of the 35 encodings
-  // of a C3 presentation.  Jobs with batch-constant NAF scalars keep the plain encoding (their scalars are digits on the host).
+  // inversion per item (kernels.hip).  That is every recomputed or fresh commitment of a Schnorr proof (26 of the 35 encodings
+  // of a C3 presentation), the tag's V and the scalar attributes' messages of an issuance.
   std::vector<int32_t*> half_of(n, nullptr);
   std::vector<afx_compress_job> cjobs;
   for (size_t i = 0; i < n; i++) {
     const afx_msm_job& j = jobs[i];
-    if (!j.out_enc || j.out_var || j.addend || j.n_uni || ctx->no_compress2x) continue;
+    if (!encoded_only(j)) continue;
     half_of[i] = new_var();
     afx_compress_job cj = { half_of[i], j.out_enc, j.reject_identity, 0 };
     cjobs.push_back(cj);
@@ -536,7 +557,10 @@ afx_msm_term SchnorrBuilder::term_for(const uint8_t* scalar, uint32_t stride, co
   t.scalar = scalar;
   t.scalar_stride = stride;
   if (p.is_const) { t.fixed_idx = (int32_t)p.gen; t.var = nullptr; t.negate = (negate != p.neg) ? 1u : 0u; }
-  else { t.fixed_idx = -1; t.var = p.var; t.negate = (negate != p.var_negated) ? 1u : 0u; }
+  else {
+    if (!p.var) throw std::logic_error("a term needs the coordinates of a point that was only encoded");
+    t.fixed_idx = -1; t.var = p.var; t.negate = (negate != p.var_negated) ? 1u : 0u;
+  }
   return t;
 }
 static void order_terms(afx_msm_job& j, const std::vector<afx_msm_term>& terms) {

@@ -76,14 +76,16 @@ static void messages_from_attributes(Assembler& as, const afx_attributes_soa& a,
   afx_ctx* c = as.ctx;
   for (uint32_t i = 0; i < a.n_attributes; i++) {
     const uint8_t* val = a.values + (i * total + off) * 32;
-    int32_t* v = as.new_var();
     if (is_scalar_kind(a.kinds[i])) {
+      // only the ENCODING of M_i = m_i*G_m_i is needed (it is hashed): every term on M_i runs as a fixed-base term on G_m_i
+      // (has_alt), so the job keeps no coordinates and its encoding comes from k_compress2x
       sccheck.push_back({ val });
       uint8_t* e = as.new_enc();
-      msm.push_back(mk_job({ mk_term(val, 32, nullptr, (int32_t)c->id_Gm(i), false) }, nullptr, v, e, reject_identity));
-      M[i] = PointVar::Var(v, e);
+      msm.push_back(mk_job({ mk_term(val, 32, nullptr, (int32_t)c->id_Gm(i), false) }, nullptr, nullptr, e, reject_identity));
+      M[i] = PointVar::Var(nullptr, e);
       M[i].has_alt = true; M[i].alt_gen = c->id_Gm(i); M[i].alt_scalar = val;   // M_i = m_i * G_m_i
     } else {
+      int32_t* v = as.new_var();
       decode.push_back({ val, v, reject_identity ? 1u : 0u });
       M[i] = PointVar::Var(v, val);
     }
@@ -194,16 +196,17 @@ extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, c
         vterms.push_back(mk_term(c->key_y(i), 0, iv.M[i].var, -1, false));
       }
     }
-    int32_t *v_Vp = as.new_var(), *v_V = as.new_var(), *v_tU = as.new_var();
+    // W joins as the fixed-base term 1*W: V is then a pure multiscalar sum of which only the encoding is needed (the prover
+    // never multiplies V), so it is encoded by k_compress2x like the commitments
+    vterms.push_back(mk_term(c->const_one(), 0, nullptr, (int32_t)c->id_W(), false));
+    int32_t* v_tU = as.new_var();
     uint8_t* e_tU = as.new_enc();
-    msm1.push_back(mk_job(vterms, nullptr, v_Vp, nullptr, false));
+    msm1.push_back(mk_job(vterms, nullptr, nullptr, orow(o.V, 0), false));
     msm1.push_back(mk_job({ mk_term(orow(o.t, 0), 32, v_U, -1, false) }, nullptr, v_tU, e_tU, false));   // t*U (issuance.rs:91)
-    afx_pointop_job pv = { v_Vp, nullptr, c->gen_ext(c->id_W()), +1, +1, v_V, orow(o.V, 0), 0 };
     as.sccheck(sccheck);
     as.decode(decode);
     as.scalarop(sc1);
     as.msm(msm1);
-    as.pointop({ pv });
     // ProofOfIssuance::prove
     iv.n_messages = n;
     Enc one{};
@@ -213,7 +216,7 @@ extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, c
     for (uint32_t i = 0; i < n; i++) iv.y[i] = sv_uniform(c->key_y(i), c->host_key[4 + i]);
     iv.one = sv_uniform(c->const_one(), one);
     iv.U = PointVar::Var(v_U, orow(o.U, 0));
-    iv.V = PointVar::Var(v_V, orow(o.V, 0));
+    iv.V = PointVar::Var(nullptr, orow(o.V, 0));   // left-hand side only: the prover needs its encoding, not its coordinates
     iv.tU = PointVar::Var(v_tU, e_tU);
     SchnorrBuilder p(as, "2019/1416 anonymous credential", "2019/1416 issuance proof");
     issuance_statement(p, c, iv);
