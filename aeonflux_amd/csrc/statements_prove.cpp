@@ -308,7 +308,9 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
     int32_t* v_Cy[AFX_MAX_ATTRIBUTES];
     int32_t* v_M1[AFX_MAX_ATTRIBUTES] = { nullptr };
     for (uint32_t i = 0; i < na; i++) {
-      v_Cy[i] = as.new_var();
+      // a commitment that is only a left-hand side of the statement (every C_y of a kind other than a hidden group element)
+      // needs no coordinates: the prover never multiplies it.  Without out_var its job is encoded by k_compress2x.
+      v_Cy[i] = cr.kinds[i] == AFX_ATTR_SECRET_POINT ? as.new_var() : nullptr;
       std::vector<afx_msm_term> t = { mk_term(z, 32, nullptr, (int32_t)c->id_Gy(i), false) };
       const int32_t* addend = nullptr;
       if (is_scalar_kind(cr.kinds[i])) {
@@ -324,7 +326,7 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
       if (cr.kinds[i] != AFX_ATTR_SECRET_SCALAR && cr.kinds[i] != AFX_ATTR_SECRET_POINT && o.attr_values)
         as.copy(orow(o.attr_values, i), row(cr.values, i), 32 * (size_t)cc);
     }
-    int32_t *v_Cx0 = as.new_var(), *v_Cx1 = as.new_var(), *v_Z = as.new_var();
+    int32_t *v_Cx0 = as.new_var(), *v_Cx1 = nullptr, *v_Z = nullptr;   // C_x_1 and Z are left-hand sides only
     uint8_t* e_Z = as.new_enc();
     msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gx0(), false) }, v_U, v_Cx0, orow(o.C_x_0, 0), false));
     msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gx1(), false), mk_term(row(cr.t, 0), 32, v_U, -1, false) }, nullptr, v_Cx1, orow(o.C_x_1, 0), false));
@@ -398,7 +400,7 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
       uint8_t *kk = as.new_enc(), *z1 = as.new_enc();
       sc1.push_back(mk_scalarop(a1, 32, m3, 32, a0, 32, false, kk));        // a0 + a1*m3
       sc2.push_back(mk_scalarop(z, 32, kk, 32, nullptr, 0, true, z1));      // z1 = -z(a0 + a1*m3) (encryption.rs:78)
-      int32_t *v_E1 = as.new_var(), *v_E2 = as.new_var(), *v_C1 = as.new_var(), *v_C2 = as.new_var(), *v_C3 = as.new_var(),
+      int32_t *v_E1 = as.new_var(), *v_E2 = as.new_var(), *v_C1 = as.new_var(), *v_C2 = as.new_var(), *v_C3 = nullptr /* left-hand side only */,
               *v_C2p = as.new_var(), *v_D1 = as.new_var();
       uint8_t *e_D1 = as.new_enc(), *e_D2 = as.new_enc();
       // Keypair::encrypt (symmetric.rs:252-261): E1 = M2*(a0 + a1*m3), E2 = E1*a + M1
