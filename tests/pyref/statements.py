@@ -199,8 +199,18 @@ def _lookup(pairs, i):
     raise ProofError("hidden-scalar lookup by a position that holds none (the reference panics)")
 
 
-def show(params, ip, kinds, values, t, U, V, keypair, z_wide, seed, enc_seeds):
-    """values[i]: 96 bytes = scalar or M1 | M2 | m3.  keypair: 128 bytes a|a0|a1|pk or None.  Returns (status, presentation dict)"""
+def _own_position_constraints(cs, kinds_at, secret_point, secret_scalar, C_y, keep, G_y, H_s, G_m, z):
+    """strict mode: the j-th kept commitment against the generators and the kind of ITS OWN attribute position"""
+    for j, i in enumerate(keep):
+        if kinds_at[i] == secret_scalar:
+            cs.constrain(C_y[j], [(z, G_y[i]), (_lookup(H_s, i), _lookup(G_m, i))])
+        else:
+            cs.constrain(C_y[j], [(z, G_y[i])])
+
+
+def show(params, ip, kinds, values, t, U, V, keypair, z_wide, seed, enc_seeds, strict=False):
+    """values[i]: 96 bytes = scalar or M1 | M2 | m3.  keypair: 128 bytes a|a0|a1|pk or None.  Returns (status, presentation dict).
+    strict: the engine's opt-in strict mode (own-position constraint #3 and the DLEQ with each proof of encryption's C_y_1)."""
     sp = Params(params)
     C_W, I = _issuer_params(ip)
     n = sp.n
@@ -241,11 +251,23 @@ def show(params, ip, kinds, values, t, U, V, keypair, z_wide, seed, enc_seeds):
     C_y = [pr.allocate_point(b"C_y", c) for i, c in enumerate(C_y_) if kinds[i] != SECRET_POINT]
     G_y = [pr.allocate_point(b"G_y", g) for g in sp.G_y]
     G_m = [(i, pr.allocate_point(b"G_m", g)) for i, g, _ in H_s_]
+    dleq, neg_G_y_1 = [], None
+    if strict:
+        # C_y[i] - C_y_1 = z*G_y[i] + z*(-G_y[0]) for every hidden group element i != 0 (C_y_1 = z*G_y[0] + M1, encryption.rs:70)
+        for i, k in enumerate(kinds):
+            if k == SECRET_POINT and i != 0:
+                if neg_G_y_1 is None:
+                    neg_G_y_1 = pr.allocate_point(b"-G_y_1", R.neg(sp.G_y[0]))
+                dleq.append((pr.allocate_point(b"C_y-C_y_1", R.sub(R.mul(z_, sp.G_y[i]), R.mul(z_, sp.G_y[0]))), i))
     Z = pr.allocate_point(b"Z", Z_)
     pr.constrain(Z, [(z, vI)])
     pr.constrain(C_x_1, [(tv, C_x_0), (z_0, G_x_0), (z, G_x_1)])
     try:
-        for i, C_y_i in enumerate(C_y):            # COMPACT index used as an attribute position (presentation.rs:267-273)
+        if strict:
+            _own_position_constraints(pr, kinds, SECRET_POINT, SECRET_SCALAR, C_y, [i for i in range(len(kinds)) if kinds[i] != SECRET_POINT], G_y, H_s, G_m, z)
+            for D, i in dleq:
+                pr.constrain(D, [(z, G_y[i]), (z, neg_G_y_1)])
+        for i, C_y_i in ([] if strict else list(enumerate(C_y))):            # COMPACT index used as an attribute position (presentation.rs:267-273)
             if kinds[i] == SECRET_POINT:
                 continue
             if kinds[i] == SECRET_SCALAR:
@@ -274,7 +296,7 @@ def show(params, ip, kinds, values, t, U, V, keypair, z_wide, seed, enc_seeds):
                     C_y=[R.encode(c) for c in C_y_], enc=enc, commitments=coms)
 
 
-def verify_presentation(params, key, ip, p):
+def verify_presentation(params, key, ip, p, strict=False):
     """p: dict with kinds (E_*), attr_values, hidden_scalar_indices, challenge, responses, C_x_0, C_x_1, C_V, C_y, enc[...]
     Returns (status, commitments of the last proof verified or None)"""
     sp, sk = Params(params), Key(key)
@@ -282,6 +304,9 @@ def verify_presentation(params, key, ip, p):
     try:
         kinds = p["kinds"]
         n = len(kinds)
+        if strict:   # exactly one proof of encryption per hidden group element, in position order
+            if [e["index"] for e in p["enc"]] != [i for i, k in enumerate(kinds) if k == E_SECRET_POINT]:
+                raise ProofError("proofs of encryption do not match the hidden group elements")
         if n > sp.n:
             raise ProofError("more attributes than the key has")
         ch = R.sc_canonical(p["challenge"])
@@ -324,10 +349,28 @@ def verify_presentation(params, key, ip, p):
             if i >= sp.n:
                 raise ProofError("G_m index out of range (the reference panics)")
             G_m.append((i, pt(b"G_m", sp.G_m[i])))
+        dleq, neg_G_y_1 = [], None
+        if strict:
+            for e, i in zip(p["enc"], [i for i, k in enumerate(kinds) if k == E_SECRET_POINT]):
+                C_y_1 = R.decode(e["C_y_1"])
+                if C_y_1 is None:
+                    raise ProofError("malformed")
+                D = R.sub(C_y[i], C_y_1)
+                if i == 0:
+                    if R.encode(D) != bytes(32):
+                        raise ProofError("C_y[0] differs from the C_y_1 of its proof of encryption")
+                    continue
+                if neg_G_y_1 is None:
+                    neg_G_y_1 = pt(b"-G_y_1", R.neg(sp.G_y[0]))
+                dleq.append((pt(b"C_y-C_y_1", D), i))
         Z = pt(b"Z", Z_)
         ve.constrain(Z, [(z, vI)])
         ve.constrain(vC_x_1, [(t, vC_x_0), (z_0, G_x_0), (z, G_x_1)])
-        for i, C_y_i in enumerate(vC_y):           # COMPACT index used as an attribute position (presentation.rs:427-433)
+        if strict:
+            _own_position_constraints(ve, kinds, E_SECRET_POINT, E_SECRET_SCALAR, vC_y, [i for i in range(n) if kinds[i] != E_SECRET_POINT], G_y, H_s, G_m, z)
+            for D, i in dleq:
+                ve.constrain(D, [(z, G_y[i]), (z, neg_G_y_1)])
+        for i, C_y_i in ([] if strict else list(enumerate(vC_y))):           # COMPACT index used as an attribute position (presentation.rs:427-433)
             if kinds[i] == E_SECRET_POINT:
                 continue
             if i >= len(G_y):

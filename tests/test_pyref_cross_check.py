@@ -121,3 +121,37 @@ def test_double_and_compress_equals_encode_of_the_double():
         s = int.from_bytes(hashlib.sha512(b"s-%d" % i).digest(), "little") % R.L
         half = R.mul(s * inv2 % R.L, R.add(p, tors[i % 4]))
         assert R.double_and_compress([half])[0] == R.encode(R.mul(s, p))
+
+
+def test_strict_mode_statement_agrees_with_the_oracle():
+    """the engine's opt-in strict mode (own-position constraint #3, one proof of encryption per hidden group element, the DLEQ with
+    its C_y_1) is not the reference's statement, so no reference pins it either: the two restatements must agree on it as well"""
+    from tests.helpers import make_credentials
+    for n, layout, hide in ((3, "ESS", [0]), (6, "SESPSE", [0, 1, 4, 5]), (4, "SSPE", [0, 3])):
+        d = make_credentials(n, layout, 3, b"pyref-strict-%d" % n)
+        user, issuer, take = d["user"], d["issuer"], d["take"]
+        user.set_strict(True)
+        issuer.set_strict(True)
+        kinds = list(d["creds"][0]["kinds"])
+        for i in hide:
+            kinds[i] = 1 if kinds[i] == 0 else 4
+        nsp = sum(1 for k in kinds if k == 4)
+        made = []
+        for c in d["creds"]:
+            kp, z, sd, es = user.keypair_derive(take(64)), take(64), take(32), take(32 * nsp)
+            st, p = user.show(kinds, c["values"], c["t"], c["U"], c["V"], kp, z, sd, es)
+            st2, q = S.show(d["params"], d["ip"], kinds, c["values"], c["t"], c["U"], c["V"], kp, z, sd, es, strict=True)
+            assert st == st2 == 0
+            assert q["challenge"] == bytes(p.challenge) and q["responses"] == [bytes(p.responses[k]) for k in range(p.n_responses)], layout
+            assert [e["challenge"] for e in q["enc"]] == [bytes(p.enc[e].challenge) for e in range(nsp)]
+            made.append((p, {k: q[k] for k in ("kinds", "attr_values", "hidden_scalar_indices", "challenge", "responses", "C_x_0", "C_x_1", "C_V", "C_y", "enc")}))
+        for p, q in made:
+            assert S.verify_presentation(d["params"], d["key"], d["ip"], q, strict=True)[0] == issuer.verify_presentation(p) == 0
+        issuer.set_strict(False)
+        for p, q in made:   # under the reference's statement a strict-mode proof is just a wrong proof
+            assert S.verify_presentation(d["params"], d["key"], d["ip"], q, strict=False)[0] == issuer.verify_presentation(p) == 1
+        issuer.set_strict(True)
+        # another presentation's (valid) proof of encryption in place of the own one: the DLEQ rejects it
+        if nsp:
+            q = dict(made[0][1], enc=[dict(made[1][1]["enc"][0])] + made[0][1]["enc"][1:])
+            assert S.verify_presentation(d["params"], d["key"], d["ip"], q, strict=True)[0] == 1
