@@ -41,7 +41,7 @@ const char* hipGetErrorString(hipError_t) { return "fake"; }
 }
 
 // walk the job arrays like the kernels would, touching every pointer-sized field (ASan catches bad blobs)
-static volatile uintptr_t sink;
+static thread_local volatile uintptr_t sink;   // per thread: the group tests drive several contexts from several threads
 hipError_t afxk_setup_generators(hipStream_t, const uint8_t*, uint32_t ngen, int32_t*, uint8_t*, uint32_t* ok) {
   for (uint32_t i = 0; i < ngen; i++) ok[i] = 1;
   return hipSuccess;

@@ -185,3 +185,56 @@ def test_every_entry_point_assembles_cleanly_under_asan(hostsim_lib, tmp_path):
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "hostsim ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+TSAN_DRIVER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import aeonflux_amd as afx
+afx.LIB_PATH = %(lib)r
+from aeonflux_amd import batch
+import bench
+os.environ["AFX_FAKE_HIP_DEVICES"] = "3"
+params, key, ip = bench.load_fixture("c3_8attrs_SSPPeeee")
+grp = afx.Group(params, key, ip, [0, 1, 2])
+shape = afx.Shape()
+shape.n_attributes, shape.n_responses, shape.n_hidden_scalars, shape.n_enc_proofs = 8, 3, 0, 4
+for i, k in enumerate((0, 0, 2, 2, 3, 3, 3, 3)):
+    shape.kinds[i] = k
+for e in range(4):
+    shape.enc_indices[e] = 4 + e
+cnt = 1500
+z = lambda *s: np.zeros(s, np.uint8)
+pres = {"challenge": z(cnt, 32), "responses": z(3, cnt, 32), "C_x_0": z(cnt, 32), "C_x_1": z(cnt, 32), "C_V": z(cnt, 32), "C_y": z(8, cnt, 32),
+        "attr_values": z(8, cnt, 32), "enc": [{f: (z(6, cnt, 32) if f == "responses" else z(cnt, 32)) for f in batch.ENC_FIELDS} for _ in range(4)]}
+for m in range(3):
+    grp.member(m).set_chunk_items(256)
+for _ in range(3):
+    assert (batch.verify_presentations(grp, shape, pres) == 0x5a).all()
+kinds = [0] * 8
+o, st = batch.issue(grp, kinds, z(8, cnt, 32), z(cnt, 64), z(cnt, 64), z(cnt, 32))
+assert len(st) == cnt
+grp.close()
+print("tsan drive ok")
+"""
+
+
+def test_group_calls_are_race_free_under_tsan(tmp_path):
+    """the multi-device path (one host thread per member, slices on two lanes each) under ThreadSanitizer, on the fake runtime"""
+    tsan = subprocess.run(["gcc", "-print-file-name=libtsan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(tsan) or not os.path.exists(tsan):
+        pytest.skip("no libtsan")
+    out = str(tmp_path / "libafx_tsan.so")
+    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp")]
+    srcs.append(os.path.join(ROOT, "tests", "hostsim", "fake_hip.cpp"))
+    r = subprocess.run(["g++", "-g", "-O1", "-fsanitize=thread", "-fPIC", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-shared",
+                        "-pthread", "-o", out] + srcs, capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("cannot build with -fsanitize=thread: " + r.stderr[-300:])
+    script = tmp_path / "drive.py"
+    script.write_text(TSAN_DRIVER % {"root": ROOT, "lib": out})
+    env = dict(os.environ, LD_PRELOAD=tsan, TSAN_OPTIONS="report_bugs=1 halt_on_error=0 exitcode=0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert "tsan drive ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
