@@ -241,6 +241,42 @@ AFX_DEV void ristretto_encode(uint32_t w[8], const ge_p3& p) {
   fe_tobytes(w, s);
 }
 
+// The encoding of TWICE a point without a square root (curve25519-dalek's double_and_compress_batch [3P]; kernels.hip
+// k_compress2x has the story): with e = 2XY, f = Z^2 + dT^2, g = Y^2 + X^2, h = Z^2 - dT^2, 2P = (e*f : g*h : f*g : e*h), and the
+// encoding needs only 1/(e*g) and 1/(f*h) - that is 1/(e*f*g*h), an inversion that can be shared among many points.
+// p: limbs reduced.  zero: e*f*g*h = 0, true exactly for the representatives of the identity; efgh is then set to 1 so that
+// the caller's running product is not spoilt.
+struct c2x_state { fe e, f, g, h, eg, fh, efgh; bool zero; };
+AFX_DEV c2x_state c2x_from(const ge_p3& P) {
+  c2x_state s;
+  const fe XX = fe_sq(P.X), YY = fe_sq(P.Y), ZZ = fe_sq(P.Z), dTT = fe_mul(fe_sq(P.T), fe_const(FEC_D));
+  s.e = fe_mul(fe_add(P.Y, P.Y), P.X);
+  s.f = fe_add(ZZ, dTT);
+  s.g = fe_add(YY, XX);
+  s.h = fe_sub(ZZ, dTT);
+  s.eg = fe_mul(s.g, s.e);
+  s.fh = fe_mul(s.f, s.h);
+  s.efgh = fe_mul(s.eg, s.fh);
+  s.zero = fe_is_zero(s.efgh);
+  fe_cmov(s.efgh, fe_one(), s.zero);
+  return s;
+}
+// w = encoding of 2P given inv = 1 / (e*f*g*h) of the same state (all zeros for the identity)
+AFX_DEV void c2x_finish(uint32_t w[8], const c2x_state& s, const fe& inv) {
+  const fe Zinv = fe_mul(s.eg, inv), Tinv = fe_mul(s.fh, inv);
+  const bool rotate = fe_is_negative(fe_mul(s.eg, Zinv));
+  fe e = s.e, g = s.g, h = s.h, magic = fe_const(FEC_INVSQRT_A_MINUS_D);
+  fe_cmov(e, s.g, rotate);
+  fe_cmov(g, fe_neg(s.e), rotate);
+  fe_cmov(h, fe_mul(s.f, fe_const(FEC_SQRT_M1)), rotate);
+  fe_cmov(magic, fe_const(FEC_SQRT_M1), rotate);
+  g = fe_cneg(g, fe_is_negative(fe_mul(fe_mul(h, e), Zinv)));
+  const fe sres = fe_abs(fe_mul(fe_sub(h, g), fe_mul(magic, fe_mul(g, Tinv))));
+  fe_tobytes(w, sres);
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = s.zero ? 0u : w[i];
+}
+
 // RFC 9496 §4.3.4 MAP
 AFX_DEV ge_p3 ristretto_elligator(const fe& r0) {
   const fe one = fe_one();

@@ -515,21 +515,6 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
 // encodings backwards.  e*f*g*h = 0 exactly for the identity's representatives (X = 0 or Y = 0; f, g, h never vanish on the
 // even subgroup), whose encoding is all zeros; such a factor is left out of the product.  tests/: every byte-parity test of the
 // commitments and challenges goes through this kernel; tests/pyref checks the formula against encode(P + P).
-struct c2x_state { fe e, f, g, h, eg, fh, efgh; bool zero; };
-AFX_DEV c2x_state c2x_from(const ge_p3& P) {
-  c2x_state s;
-  const fe XX = fe_sq(P.X), YY = fe_sq(P.Y), ZZ = fe_sq(P.Z), dTT = fe_mul(fe_sq(P.T), fe_const(FEC_D));
-  s.e = fe_mul(fe_add(P.Y, P.Y), P.X);
-  s.f = fe_add(ZZ, dTT);
-  s.g = fe_add(YY, XX);
-  s.h = fe_sub(ZZ, dTT);
-  s.eg = fe_mul(s.g, s.e);
-  s.fh = fe_mul(s.f, s.h);
-  s.efgh = fe_mul(s.eg, s.fh);
-  s.zero = fe_is_zero(s.efgh);
-  fe_cmov(s.efgh, fe_one(), s.zero);
-  return s;
-}
 __global__ void __launch_bounds__(AFX_BLOCK, 2)
 k_compress2x(const afx_compress_job* __restrict__ jobs, uint32_t njobs, int32_t* __restrict__ prefix_ws, uint32_t* __restrict__ bad, uint32_t count) {
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
@@ -548,19 +533,8 @@ k_compress2x(const afx_compress_job* __restrict__ jobs, uint32_t njobs, int32_t*
     const c2x_state s = c2x_from(var_load(jobs[j].var, count, item));
     const fe inv_j = fe_mul(inv, fe_load_soa(prefix_ws + (size_t)j * 10 * count, 0, count, item));   // 1 / (e f g h)_j
     inv = fe_mul(inv, s.efgh);
-    const fe Zinv = fe_mul(s.eg, inv_j), Tinv = fe_mul(s.fh, inv_j);
-    const bool rotate = fe_is_negative(fe_mul(s.eg, Zinv));
-    fe e = s.e, g = s.g, h = s.h, magic = fe_const(FEC_INVSQRT_A_MINUS_D);
-    fe_cmov(e, s.g, rotate);
-    fe_cmov(g, fe_neg(s.e), rotate);
-    fe_cmov(h, fe_mul(s.f, fe_const(FEC_SQRT_M1)), rotate);
-    fe_cmov(magic, fe_const(FEC_SQRT_M1), rotate);
-    g = fe_cneg(g, fe_is_negative(fe_mul(fe_mul(h, e), Zinv)));
-    const fe sres = fe_abs(fe_mul(fe_sub(h, g), fe_mul(magic, fe_mul(g, Tinv))));
     uint32_t w[8];
-    fe_tobytes(w, sres);
-#pragma unroll
-    for (int i = 0; i < 8; i++) w[i] = s.zero ? 0u : w[i];
+    c2x_finish(w, s, inv_j);
     enc_store(jobs[j].out_enc, item, w);
     if (jobs[j].reject_identity && is_identity_encoding(w)) atomicOr(&bad[item], AFX_BAD_IDENTITY);
   }

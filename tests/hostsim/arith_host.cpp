@@ -198,4 +198,35 @@ void arith_op_counts(uint64_t out[8][2]) {
   (void)p2;
 }
 
+// double-and-compress (ge.cuh c2x_*; the engine's k_compress2x): encodings of 2*P_j for n points given by their encodings, with
+// ONE inversion, every multiplication bound-checked.  Each P_j goes through a doubling and an addition first, so that the
+// state is fed the kind of limbs an MSM accumulator holds, not freshly decoded ones.  Returns 0 if a point does not decode.
+int arith_double_and_compress(uint8_t* out /* [n][32] */, uint32_t n, const uint8_t* pts /* [n][32] */, const uint8_t* shift /* 32 B point added to each */) {
+  if (n > 64) return 0;
+  c2x_state st[64];
+  fe pre[64], prod = fe_one();
+  uint32_t w[8];
+  load8(w, shift);
+  ge_p3 S;
+  if (!ristretto_decode(S, w)) return 0;
+  for (uint32_t j = 0; j < n; j++) {
+    load8(w, pts + 32 * j);
+    ge_p3 P;
+    if (!ristretto_decode(P, w)) return 0;
+    // (P + S) - S = P through the engine's own addition: limbs as an accumulator leaves them (ge_p1p1_to_p3: centred)
+    P = ge_sub(ge_add(P, S), S);
+    st[j] = c2x_from(P);
+    pre[j] = prod;
+    prod = fe_mul(prod, st[j].efgh);
+  }
+  fe inv = fe_invert(prod);
+  for (uint32_t jj = n; jj > 0; jj--) {
+    const uint32_t j = jj - 1;
+    const fe inv_j = fe_mul(inv, pre[j]);
+    inv = fe_mul(inv, st[j].efgh);
+    c2x_finish(w, st[j], inv_j);
+    memcpy(out + 32 * j, w, 32);
+  }
+  return 1;
+}
 }  // extern "C"

@@ -133,6 +133,25 @@ def test_msm_chain_with_consumer_aware_conversions(arith):
     assert arith.arith_bounds_violations() == 0, arith.arith_last_violation()
 
 
+def test_double_and_compress_against_the_oracle(arith):
+    """ge.cuh c2x_from / c2x_finish (k_compress2x): the encodings of 2P for a batch of points with one inversion equal the
+    oracle's encode(P + P) - identities in the batch included - with every multiplication's operand bounds checked"""
+    import ctypes as C
+    import hashlib
+    import oracle
+    rnd = hashlib.shake_256(b"c2x-host").digest(64 * 40)
+    pts = [oracle.point_from_uniform(rnd[64 * i:64 * i + 64]) for i in range(39)]
+    pts.insert(7, bytes(32))                     # the identity in the middle of the batch
+    pts.insert(20, bytes(32))
+    shift = oracle.point_from_uniform(hashlib.sha512(b"c2x-shift").digest())
+    out = C.create_string_buffer(32 * len(pts))
+    arith.arith_double_and_compress.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p]
+    assert arith.arith_double_and_compress(out, len(pts), b"".join(pts), shift) == 1
+    for j, p in enumerate(pts):
+        assert out.raw[32 * j:32 * j + 32] == oracle.point_add(p, p), j
+    assert out.raw[32 * 7:32 * 8] == bytes(32)
+
+
 def test_the_bounds_checker_fires(arith):
     arith.arith_bounds_checker_selftest.restype = C.c_uint64
     assert arith.arith_bounds_checker_selftest() >= 2
