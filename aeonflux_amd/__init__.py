@@ -151,6 +151,12 @@ def lib():
         _LIB.afx_shard_bounds.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         _LIB.afx_shard_bounds.restype = None
         _LIB.afx_group_verify_presentations.argtypes = [C.c_void_p, C.POINTER(Shape), C.POINTER(PresentationSoA), C.c_size_t, C.c_void_p]
+        _LIB.afx_verify_issuances_range.argtypes = [C.c_void_p, C.POINTER(AttributesSoA), C.POINTER(IssuanceSoA), C.c_uint32, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+        _LIB.afx_group_verify_issuances.argtypes = [C.c_void_p, C.POINTER(AttributesSoA), C.POINTER(IssuanceSoA), C.c_uint32, C.c_size_t, C.c_void_p]
+        _LIB.afx_show_range.argtypes = [C.c_void_p, C.POINTER(CredentialsSoA), C.POINTER(KeypairsSoA), C.POINTER(ShowRandomness), C.c_size_t, C.c_size_t, C.c_size_t,
+                                        C.POINTER(PresentationOut), C.POINTER(Shape), C.c_void_p]
+        _LIB.afx_group_show.argtypes = [C.c_void_p, C.POINTER(CredentialsSoA), C.POINTER(KeypairsSoA), C.POINTER(ShowRandomness), C.c_size_t,
+                                        C.POINTER(PresentationOut), C.POINTER(Shape), C.c_void_p]
         _LIB.afx_group_issue.argtypes = [C.c_void_p, C.POINTER(AttributesSoA), C.POINTER(IssueRandomness), C.c_size_t, C.POINTER(IssuanceSoA), C.c_void_p]
         if hasattr(_LIB, "afx_issuer_keygen"):
             _LIB.afx_issuer_keygen.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p]

@@ -50,8 +50,9 @@ def issue(ctx, kinds, values, t_wide, U_wide, rng_seed, first=None, n=None):
     return o, status
 
 
-def verify_issuances(ctx, kinds, values, issuance, n_responses=None):
-    """CredentialIssuance::verify over a batch; issuance = dict as returned by issue()."""
+def verify_issuances(ctx, kinds, values, issuance, n_responses=None, first=None, n=None):
+    """CredentialIssuance::verify over a batch; issuance = dict as returned by issue().  ctx may be a Group; with first/n only
+    that range is verified (afx_verify_issuances_range; the other status bytes stay 255)."""
     values = _u8(values)
     iss = {k: _u8(issuance[k]) for k in ("t", "U", "V", "challenge", "responses")}
     cnt = iss["t"].shape[0]
@@ -59,14 +60,20 @@ def verify_issuances(ctx, kinds, values, issuance, n_responses=None):
     s = IssuanceSoA(*(iss[k].ctypes.data for k in ("t", "U", "V", "challenge", "responses")))
     status = np.full(cnt, 255, np.uint8)
     nr = iss["responses"].shape[0] if n_responses is None else n_responses
-    check(lib().afx_verify_issuances(ctx.h, C.byref(req), C.byref(s), nr, cnt, status.ctypes.data))
+    if first is not None:
+        check(lib().afx_verify_issuances_range(ctx.h, C.byref(req), C.byref(s), nr, cnt, first, n, status.ctypes.data))
+    elif hasattr(ctx, "member"):
+        check(lib().afx_group_verify_issuances(ctx.h, C.byref(req), C.byref(s), nr, cnt, status.ctypes.data))
+    else:
+        check(lib().afx_verify_issuances(ctx.h, C.byref(req), C.byref(s), nr, cnt, status.ctypes.data))
     return status
 
 
-def show(ctx, kinds, values, t, U, V, keypairs, z_wide, rng_seed, enc_seeds=None, M2=None, m3=None):
+def show(ctx, kinds, values, t, U, V, keypairs, z_wide, rng_seed, enc_seeds=None, M2=None, m3=None, first=None, n_items=None):
     """AnonymousCredential::show over a batch.  kinds: AFX_ATTR_* after hide/reveal.  values/M2/m3 [n,count,32];
     keypairs: dict(a,a0,a1,pk -> [count,32]) or None; enc_seeds [#secret points, count, 32].
-    Returns (presentation dict incl. 'enc' list, Shape, status)."""
+    Returns (presentation dict incl. 'enc' list, Shape, status).  ctx may be a Group; with first/n_items only that range
+    of the batch is shown (afx_show_range; the other output rows stay zero / status 255)."""
     n = len(kinds)
     values, t, U, V, z_wide, rng_seed = map(_u8, (values, t, U, V, z_wide, rng_seed))
     cnt = t.shape[0]
@@ -105,8 +112,13 @@ def show(ctx, kinds, values, t, U, V, keypairs, z_wide, rng_seed, enc_seeds=None
     out.enc = C.cast(eouts, C.POINTER(EncProofOut))
     shape = Shape()
     status = np.full(cnt, 255, np.uint8)
-    check(lib().afx_show(ctx.h, C.byref(cs), C.byref(kp) if kp is not None else None, C.byref(rnd), cnt, C.byref(out),
-                         C.byref(shape), status.ctypes.data))
+    kpp = C.byref(kp) if kp is not None else None
+    if first is not None:
+        check(lib().afx_show_range(ctx.h, C.byref(cs), kpp, C.byref(rnd), cnt, first, n_items, C.byref(out), C.byref(shape), status.ctypes.data))
+    elif hasattr(ctx, "member"):
+        check(lib().afx_group_show(ctx.h, C.byref(cs), kpp, C.byref(rnd), cnt, C.byref(out), C.byref(shape), status.ctypes.data))
+    else:
+        check(lib().afx_show(ctx.h, C.byref(cs), kpp, C.byref(rnd), cnt, C.byref(out), C.byref(shape), status.ctypes.data))
     return o, shape, status
 
 

@@ -81,3 +81,20 @@ extern "C" int afx_group_issue(afx_group* g, const afx_attributes_soa* requests,
   if (!g || g->members.empty() || !requests || !rnd || !out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   return run_members(g, count, [&](afx_ctx* c, size_t first, size_t n) { return afx_issue_range(c, requests, rnd, count, first, n, out, status); });
 }
+extern "C" int afx_group_verify_issuances(afx_group* g, const afx_attributes_soa* attrs, const afx_issuance_soa* issuances, uint32_t n_responses,
+                                          size_t count, uint8_t* status) {
+  if (!g || g->members.empty() || !attrs || !issuances || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  return run_members(g, count, [&](afx_ctx* c, size_t first, size_t n) { return afx_verify_issuances_range(c, attrs, issuances, n_responses, count, first, n, status); });
+}
+// the shape is a function of the credentials' layout alone: member 0 reports it (an empty range still does), the other
+// members write theirs to a local
+extern "C" int afx_group_show(afx_group* g, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
+                              size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status) {
+  if (!g || g->members.empty() || !creds || !rnd || !out || !shape_out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  int rc = afx_show_range(g->members[0], creds, keypairs, rnd, count, 0, 0, out, shape_out, status);
+  if (rc) return rc;
+  return run_members(g, count, [&](afx_ctx* c, size_t first, size_t n) {
+    afx_shape local;
+    return afx_show_range(c, creds, keypairs, rnd, count, first, n, out, &local, status);
+  });
+}

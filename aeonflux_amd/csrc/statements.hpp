@@ -129,7 +129,7 @@ struct Stager {
   size_t bytes = 0, pin_bytes = 0;
   struct Copy { size_t off; const uint8_t* src; size_t len; };
   struct Out { uint8_t* dst; size_t pin_off, len; };
-  std::vector<Copy> copies;
+  std::vector<Copy> copies, blanks;
   std::vector<Out> outs;
   // the *_dev calls made while this object lives run on its lane
   explicit Stager(afx_ctx* ctx, int lane = 0) : c(ctx), ln(lane), prev_force(ctx->force_lane) { c->force_lane = lane; }
@@ -142,6 +142,7 @@ struct Stager {
     const size_t off = (bytes + 255) & ~size_t(255);
     bytes = off + len;
     if (src) copies.push_back({ off, src, len });
+    else if (len) blanks.push_back({ off, nullptr, len });
     return off;
   }
   // items [first, first + n) of a [rows][total][elem] host array -> a contiguous [rows][n][elem] device array
@@ -157,6 +158,9 @@ struct Stager {
     int rc = L.staging.ensure(bytes + 256);
     if (rc) return rc;
     for (const Copy& k : copies) AFX_HIP(hipMemcpyAsync((uint8_t*)L.staging.p + k.off, k.src, k.len, hipMemcpyHostToDevice, L.stream));
+    // result areas start from zero: the staging buffer is reused from call to call, and what a call does not write (the
+    // outputs of a failed item, the hidden rows of attr_values) must not hand an earlier call's bytes to this caller
+    for (const Copy& k : blanks) AFX_HIP(hipMemsetAsync((uint8_t*)L.staging.p + k.off, 0, k.len, L.stream));
     return AFX_OK;
   }
   uint8_t* dev(size_t off) const { return (uint8_t*)c->lane[ln].staging.p + off; }

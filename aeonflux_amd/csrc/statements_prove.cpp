@@ -512,8 +512,9 @@ extern "C" int afx_issue(afx_ctx* ctx, const afx_attributes_soa* req, const afx_
   return afx_issue_range(ctx, req, rnd, count, 0, count, out, status);
 }
 
-extern "C" int afx_verify_issuances(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* iss, uint32_t n_responses,
-                                    size_t count, uint8_t* status) {
+// Issuances [first, first + n) of a host batch of `total` (user side, CredentialIssuance::verify, /root/reference/src/issuer.rs:48-57)
+extern "C" int afx_verify_issuances_range(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* iss, uint32_t n_responses,
+                                          size_t total, size_t first, size_t n, uint8_t* status) {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !attrs || !iss || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -521,28 +522,37 @@ extern "C" int afx_verify_issuances(afx_ctx* ctx, const afx_attributes_soa* attr
     set_error("null batch array");
     return AFX_E_BAD_ARGS;
   }
-  if (count == 0) return AFX_OK;
+  if (first > total || n > total - first) { set_error("range outside the batch"); return AFX_E_BAD_ARGS; }
+  if (n == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
   // shapes every item fails on (zkp: responses.len() != num_scalars; G_m[i] out of range): answer without reading the arrays
-  if (attrs->n_attributes > ctx->n || n_responses != ctx->n + 5) { memset(status, AFX_ST_VERIFICATION_FAILURE, count); return AFX_OK; }
+  if (attrs->n_attributes > ctx->n || n_responses != ctx->n + 5) { memset(status + first, AFX_ST_VERIFICATION_FAILURE, n); return AFX_OK; }
   const uint32_t na = attrs->n_attributes, nr = n_responses;
-  Stager st(ctx);
-  const size_t o_val = st.add(attrs->values, 32 * count * na), o_t = st.add(iss->t, 32 * count), o_U = st.add(iss->U, 32 * count),
-               o_V = st.add(iss->V, 32 * count), o_ch = st.add(iss->challenge, 32 * count), o_rs = st.add(iss->responses, 32 * count * nr),
-               o_st = st.add(nullptr, count);
-  int rc = st.upload();
-  if (rc) return rc;
-  afx_attributes_soa da = *attrs;
-  da.values = st.dev(o_val);
-  afx_issuance_soa di = { st.dev(o_t), st.dev(o_U), st.dev(o_V), st.dev(o_ch), st.dev(o_rs) };
-  if ((rc = afx_verify_issuances_dev(ctx, &da, &di, n_responses, count, st.dev(o_st)))) return rc;
-  if ((rc = fetch(ctx, status, st.dev(o_st), count))) return rc;
-  AFX_HIP(hipStreamSynchronize(ctx->stream));
-  return AFX_OK;
+  return host_pipe(ctx, n, [&](Stager& st, size_t off, size_t sn) -> int {
+    const size_t f0 = first + off;
+    const size_t o_val = st.add_rows(attrs->values, na, 32, total, f0, sn), o_t = st.add_rows(iss->t, 1, 32, total, f0, sn),
+                 o_U = st.add_rows(iss->U, 1, 32, total, f0, sn), o_V = st.add_rows(iss->V, 1, 32, total, f0, sn),
+                 o_ch = st.add_rows(iss->challenge, 1, 32, total, f0, sn), o_rs = st.add_rows(iss->responses, nr, 32, total, f0, sn),
+                 o_st = st.add(nullptr, sn);
+    st.plan_fetch(status, o_st, 1, 1, total, f0, sn);
+    int rc = st.upload();
+    if (rc) return rc;
+    afx_attributes_soa da = *attrs;
+    da.values = st.dev(o_val);
+    afx_issuance_soa di = { st.dev(o_t), st.dev(o_U), st.dev(o_V), st.dev(o_ch), st.dev(o_rs) };
+    if ((rc = afx_verify_issuances_dev(ctx, &da, &di, n_responses, sn, st.dev(o_st)))) return rc;
+    return st.fetch_all();
+  });
+}
+extern "C" int afx_verify_issuances(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* iss, uint32_t n_responses,
+                                    size_t count, uint8_t* status) {
+  return afx_verify_issuances_range(ctx, attrs, iss, n_responses, count, 0, count, status);
 }
 
-extern "C" int afx_show(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
-                        size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status) {
+// Credentials [first, first + n) of a host batch of `total` (AnonymousCredential::show, /root/reference/src/credential.rs:37-46);
+// every output array is indexed like the inputs.  shape_out is the same for every range of one batch.
+extern "C" int afx_show_range(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
+                              size_t total, size_t first, size_t n, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status) {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !creds || !rnd || !out || !shape_out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -556,45 +566,53 @@ extern "C" int afx_show(afx_ctx* ctx, const afx_credentials_soa* creds, const af
     return AFX_E_BAD_ARGS;
   }
   if (keypairs && nsp && (!keypairs->a || !keypairs->a0 || !keypairs->a1 || !keypairs->pk)) { set_error("null keypair array"); return AFX_E_BAD_ARGS; }
+  if (first > total || n > total - first) { set_error("range outside the batch"); return AFX_E_BAD_ARGS; }
   AFX_HIP(hipSetDevice(ctx->device));
-  Stager st(ctx);
-  const size_t row = 32 * count;
-  const size_t o_val = st.add(creds->values, row * na), o_M2 = st.add(nsp ? creds->M2 : nullptr, nsp ? row * na : 0),
-               o_m3 = st.add(nsp ? creds->m3 : nullptr, nsp ? row * na : 0), o_t = st.add(creds->t, row), o_U = st.add(creds->U, row),
-               o_V = st.add(creds->V, row), o_zw = st.add(rnd->z_wide, 64 * count), o_seed = st.add(rnd->rng_seed, row),
-               o_es = st.add(nsp ? rnd->enc_seeds : nullptr, row * nsp);
-  size_t o_kp[4] = { 0, 0, 0, 0 };
-  if (keypairs && nsp) { o_kp[0] = st.add(keypairs->a, row); o_kp[1] = st.add(keypairs->a0, row); o_kp[2] = st.add(keypairs->a1, row); o_kp[3] = st.add(keypairs->pk, row); }
-  const size_t o_ch = st.add(nullptr, row), o_rs = st.add(nullptr, row * (3 + hs)), o_x0 = st.add(nullptr, row), o_x1 = st.add(nullptr, row),
-               o_cv = st.add(nullptr, row), o_cy = st.add(nullptr, row * na), o_av = st.add(nullptr, row * na), o_st = st.add(nullptr, count);
-  std::vector<std::array<size_t, 9>> oe(nsp);
-  for (uint32_t e = 0; e < nsp; e++)
-    for (int f = 0; f < 9; f++) oe[e][f] = st.add(nullptr, row * (f == 1 ? 6 : 1));
-  int rc = st.upload();
-  if (rc) return rc;
-  afx_credentials_soa dc = *creds;
-  dc.values = st.dev(o_val); dc.M2 = nsp ? st.dev(o_M2) : nullptr; dc.m3 = nsp ? st.dev(o_m3) : nullptr;
-  dc.t = st.dev(o_t); dc.U = st.dev(o_U); dc.V = st.dev(o_V);
-  afx_keypairs_soa dk = { st.dev(o_kp[0]), st.dev(o_kp[1]), st.dev(o_kp[2]), st.dev(o_kp[3]) };
-  afx_show_randomness dr = { st.dev(o_zw), st.dev(o_seed), st.dev(o_es) };
-  std::vector<afx_encproof_out> de(nsp);
-  for (uint32_t e = 0; e < nsp; e++)
-    de[e] = { st.dev(oe[e][0]), st.dev(oe[e][1]), st.dev(oe[e][2]), st.dev(oe[e][3]), st.dev(oe[e][4]), st.dev(oe[e][5]), st.dev(oe[e][6]), st.dev(oe[e][7]), st.dev(oe[e][8]) };
-  afx_presentation_out dout = { st.dev(o_ch), st.dev(o_rs), st.dev(o_x0), st.dev(o_x1), st.dev(o_cv), st.dev(o_cy), st.dev(o_av), de.data() };
-  if ((rc = afx_show_dev(ctx, &dc, (keypairs && nsp) ? &dk : nullptr, &dr, count, &dout, shape_out, st.dev(o_st)))) return rc;
-  if (count == 0) return AFX_OK;
-  if ((rc = fetch(ctx, out->challenge, st.dev(o_ch), row)) || (rc = fetch(ctx, out->responses, st.dev(o_rs), row * (3 + hs))) ||
-      (rc = fetch(ctx, out->C_x_0, st.dev(o_x0), row)) || (rc = fetch(ctx, out->C_x_1, st.dev(o_x1), row)) || (rc = fetch(ctx, out->C_V, st.dev(o_cv), row)) ||
-      (rc = fetch(ctx, out->C_y, st.dev(o_cy), row * na)) || (rc = fetch(ctx, out->attr_values, st.dev(o_av), row * na)) || (rc = fetch(ctx, status, st.dev(o_st), count)))
-    return rc;
-  for (uint32_t e = 0; e < nsp; e++) {
-    uint8_t* dst[9] = { out->enc[e].challenge, out->enc[e].responses, out->enc[e].pk, out->enc[e].E1, out->enc[e].E2,
-                        out->enc[e].C_y_1, out->enc[e].C_y_2, out->enc[e].C_y_3, out->enc[e].C_y_2p };
-    for (int f = 0; f < 9; f++)
-      if ((rc = fetch(ctx, dst[f], st.dev(oe[e][f]), row * (f == 1 ? 6 : 1)))) return rc;
+  const bool kp = keypairs && nsp;
+  if (n == 0) {   // the shape is still reported (an empty batch has one)
+    afx_credentials_soa dc = *creds;
+    afx_show_randomness dr = *rnd;
+    return afx_show_dev(ctx, &dc, kp ? keypairs : nullptr, &dr, 0, out, shape_out, status);
   }
-  AFX_HIP(hipStreamSynchronize(ctx->stream));
-  return AFX_OK;
+  return host_pipe(ctx, n, [&](Stager& st, size_t off, size_t sn) -> int {
+    const size_t f0 = first + off;
+    auto in = [&](const uint8_t* p, size_t rows, size_t elem) { return st.add_rows(p, rows, elem, total, f0, sn); };
+    auto res = [&](uint8_t* dst, size_t rows, size_t elem) {
+      const size_t o = st.add(nullptr, rows * sn * elem);
+      st.plan_fetch(dst, o, rows, elem, total, f0, sn);
+      return o;
+    };
+    const size_t o_val = in(creds->values, na, 32), o_M2 = in(nsp ? creds->M2 : nullptr, nsp ? na : 0, 32), o_m3 = in(nsp ? creds->m3 : nullptr, nsp ? na : 0, 32),
+                 o_t = in(creds->t, 1, 32), o_U = in(creds->U, 1, 32), o_V = in(creds->V, 1, 32), o_zw = in(rnd->z_wide, 1, 64),
+                 o_seed = in(rnd->rng_seed, 1, 32), o_es = in(nsp ? rnd->enc_seeds : nullptr, nsp, 32);
+    size_t o_kp[4] = { 0, 0, 0, 0 };
+    if (kp) { o_kp[0] = in(keypairs->a, 1, 32); o_kp[1] = in(keypairs->a0, 1, 32); o_kp[2] = in(keypairs->a1, 1, 32); o_kp[3] = in(keypairs->pk, 1, 32); }
+    const size_t o_ch = res(out->challenge, 1, 32), o_rs = res(out->responses, 3 + hs, 32), o_x0 = res(out->C_x_0, 1, 32), o_x1 = res(out->C_x_1, 1, 32),
+                 o_cv = res(out->C_V, 1, 32), o_cy = res(out->C_y, na, 32), o_av = res(out->attr_values, na, 32), o_st = res(status, 1, 1);
+    std::vector<std::array<size_t, 9>> oe(nsp);
+    for (uint32_t e = 0; e < nsp; e++) {
+      uint8_t* dst[9] = { out->enc[e].challenge, out->enc[e].responses, out->enc[e].pk, out->enc[e].E1, out->enc[e].E2,
+                          out->enc[e].C_y_1, out->enc[e].C_y_2, out->enc[e].C_y_3, out->enc[e].C_y_2p };
+      for (int f = 0; f < 9; f++) oe[e][f] = res(dst[f], f == 1 ? 6 : 1, 32);
+    }
+    int rc = st.upload();
+    if (rc) return rc;
+    afx_credentials_soa dc = *creds;
+    dc.values = st.dev(o_val); dc.M2 = nsp ? st.dev(o_M2) : nullptr; dc.m3 = nsp ? st.dev(o_m3) : nullptr;
+    dc.t = st.dev(o_t); dc.U = st.dev(o_U); dc.V = st.dev(o_V);
+    afx_keypairs_soa dk = { st.dev(o_kp[0]), st.dev(o_kp[1]), st.dev(o_kp[2]), st.dev(o_kp[3]) };
+    afx_show_randomness dr = { st.dev(o_zw), st.dev(o_seed), st.dev(o_es) };
+    std::vector<afx_encproof_out> de(nsp);
+    for (uint32_t e = 0; e < nsp; e++)
+      de[e] = { st.dev(oe[e][0]), st.dev(oe[e][1]), st.dev(oe[e][2]), st.dev(oe[e][3]), st.dev(oe[e][4]), st.dev(oe[e][5]), st.dev(oe[e][6]), st.dev(oe[e][7]), st.dev(oe[e][8]) };
+    afx_presentation_out dout = { st.dev(o_ch), st.dev(o_rs), st.dev(o_x0), st.dev(o_x1), st.dev(o_cv), st.dev(o_cy), st.dev(o_av), de.data() };
+    if ((rc = afx_show_dev(ctx, &dc, kp ? &dk : nullptr, &dr, sn, &dout, shape_out, st.dev(o_st)))) return rc;
+    return st.fetch_all();
+  });
+}
+extern "C" int afx_show(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
+                        size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status) {
+  return afx_show_range(ctx, creds, keypairs, rnd, count, 0, count, out, shape_out, status);
 }
 
 // ------------------------------------------------------------------------------------------------

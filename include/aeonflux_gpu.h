@@ -318,6 +318,11 @@ int afx_verify_issuances(afx_ctx* ctx, const afx_attributes_soa* attrs, const af
                          uint32_t n_responses, size_t count, uint8_t* status);
 int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* issuances,
                              uint32_t n_responses, size_t count, uint8_t* status_dev);
+/* Issuances [first, first + n) of a batch of `total`, and the whole batch over a group's devices. */
+int afx_verify_issuances_range(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* issuances,
+                               uint32_t n_responses, size_t total, size_t first, size_t n, uint8_t* status);
+int afx_group_verify_issuances(afx_group* group, const afx_attributes_soa* attrs, const afx_issuance_soa* issuances,
+                               uint32_t n_responses, size_t count, uint8_t* status);
 
 /* ---- AnonymousCredential::show (src/credential.rs:37-46 -> src/nizk/presentation.rs:139-321) - */
 
@@ -368,6 +373,15 @@ int afx_show(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_
 int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs,
                  const afx_show_randomness* rnd, size_t count, const afx_presentation_out* out, afx_shape* shape_out,
                  uint8_t* status_dev);
+/* Credentials [first, first + n) of a batch of `total` (every output array indexed like the inputs; shape_out is the same
+ * for every range of one batch), and the whole batch over a group's devices (a user-side group is created with
+ * amacs_key == NULL). */
+int afx_show_range(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs,
+                   const afx_show_randomness* rnd, size_t total, size_t first, size_t n, const afx_presentation_out* out,
+                   afx_shape* shape_out, uint8_t* status);
+int afx_group_show(afx_group* group, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs,
+                   const afx_show_randomness* rnd, size_t count, const afx_presentation_out* out, afx_shape* shape_out,
+                   uint8_t* status);
 
 /* ---- setup helpers (cold path; still GPU arithmetic) ---------------------------------------- */
 

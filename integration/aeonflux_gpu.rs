@@ -134,6 +134,11 @@ extern "C" {
                                       count: usize, status: *mut u8) -> i32;
     fn afx_group_issue(group: *mut c_void, requests: *const AfxAttributesSoa, rnd: *const AfxIssueRandomness, count: usize,
                        out: *const AfxIssuanceSoa, status: *mut u8) -> i32;
+    fn afx_group_verify_issuances(group: *mut c_void, attrs: *const AfxAttributesSoa, issuances: *const AfxIssuanceSoa,
+                                  n_responses: u32, count: usize, status: *mut u8) -> i32;
+    fn afx_group_show(group: *mut c_void, creds: *const AfxCredentialsSoa, keypairs: *const AfxKeypairsSoa,
+                      rnd: *const AfxShowRandomness, count: usize, out: *const AfxPresentationOut, shape_out: *mut AfxShape,
+                      status: *mut u8) -> i32;
 }
 
 /// `Issuer` with its parameters, tables and key resident on one MI355X (`ctx`) or on several (`group`: the batch is split
@@ -141,7 +146,7 @@ extern "C" {
 pub struct GpuIssuer { ctx: *mut c_void, group: *mut c_void, n: usize }
 
 /// The user's side (no issuer key): `AnonymousCredential::show` and `CredentialIssuance::verify`.
-pub struct GpuUser { ctx: *mut c_void, n: usize }
+pub struct GpuUser { ctx: *mut c_void, group: *mut c_void, n: usize }
 
 fn issuer_params_bytes(ip: &IssuerParameters) -> [u8; 64] {
     let mut b = [0u8; 64];                                            // C_W || I (src/issuer.rs:155,163)
@@ -278,7 +283,17 @@ impl GpuUser {
         let mut ctx = core::ptr::null_mut();
         let rc = unsafe { afx_ctx_create(&mut ctx, device, sp.as_ptr(), sp.len(), core::ptr::null(), 0, ip.as_ptr()) };
         if rc != 0 { return Err(CredentialError::NoSystemParameters); }
-        Ok(GpuUser { ctx, n: system_parameters.NUMBER_OF_ATTRIBUTES as usize })
+        Ok(GpuUser { ctx, group: core::ptr::null_mut(), n: system_parameters.NUMBER_OF_ATTRIBUTES as usize })
+    }
+
+    /// The same on several GPUs of the node: batches are split contiguously over `devices` inside the library.
+    pub fn new_multi_user(system_parameters: &SystemParameters, issuer_parameters: &IssuerParameters, devices: &[i32]) -> Result<GpuUser, CredentialError> {
+        let sp = system_parameters.to_bytes();
+        let ip = issuer_params_bytes(issuer_parameters);
+        let mut group = core::ptr::null_mut();
+        let rc = unsafe { afx_group_create(&mut group, devices.as_ptr(), devices.len() as u32, sp.as_ptr(), sp.len(), core::ptr::null(), 0, ip.as_ptr()) };
+        if rc != 0 { return Err(CredentialError::NoSystemParameters); }
+        Ok(GpuUser { ctx: core::ptr::null_mut(), group, n: system_parameters.NUMBER_OF_ATTRIBUTES as usize })
     }
 
     /// Batch `AnonymousCredential::show` (src/credential.rs:37-46 -> src/nizk/presentation.rs:139-321).  One keypair per
@@ -341,7 +356,11 @@ impl GpuUser {
         let mut shape = AfxShape { n_attributes: 0, kinds: [0; 32], n_responses: 0, n_hidden_scalars: 0, hidden_scalar_indices: [0; 32],
                                    n_enc_proofs: 0, enc_indices: [0; 32] };
         let mut status = vec![0u8; count];
-        let rc = unsafe { afx_show(self.ctx, &cs, if keypairs.is_some() { &kp_soa } else { core::ptr::null() }, &rnd, count, &out, &mut shape, status.as_mut_ptr()) };
+        let kp_ptr: *const AfxKeypairsSoa = if keypairs.is_some() { &kp_soa } else { core::ptr::null() };
+        let rc = unsafe {
+            if self.group.is_null() { afx_show(self.ctx, &cs, kp_ptr, &rnd, count, &out, &mut shape, status.as_mut_ptr()) }
+            else { afx_group_show(self.group, &cs, kp_ptr, &rnd, count, &out, &mut shape, status.as_mut_ptr()) }
+        };
         assert!(rc == 0, "aeonflux_gpu: engine error {}", rc);
         // rebuild ProofOfValidCredential (src/nizk/presentation.rs:118-127) per item
         (0..count).map(|i| {
@@ -403,14 +422,17 @@ impl GpuUser {
         soa.values = values.as_ptr();
         let d = AfxIssuanceSoa { t: t.as_mut_ptr(), U: u.as_mut_ptr(), V: v.as_mut_ptr(), challenge: ch.as_mut_ptr(), responses: rs.as_mut_ptr() };
         let mut status = vec![0u8; count];
-        let rc = unsafe { afx_verify_issuances(self.ctx, &soa, &d, nr as u32, count, status.as_mut_ptr()) };
+        let rc = unsafe {
+            if self.group.is_null() { afx_verify_issuances(self.ctx, &soa, &d, nr as u32, count, status.as_mut_ptr()) }
+            else { afx_group_verify_issuances(self.group, &soa, &d, nr as u32, count, status.as_mut_ptr()) }
+        };
         assert!(rc == 0, "aeonflux_gpu: engine error {}", rc);
         issuances.into_iter().enumerate().map(|(i, iss)| if status[i] == ST_OK { Ok(iss.credential) } else { Err(CredentialError::VerificationFailure) }).collect()
     }
 }
 
 impl Drop for GpuUser {
-    fn drop(&mut self) { unsafe { afx_ctx_destroy(self.ctx) } }
+    fn drop(&mut self) { unsafe { if self.group.is_null() { afx_ctx_destroy(self.ctx) } else { afx_group_destroy(self.group) } } }
 }
 
 /// ProofOfValidCredential (src/nizk/presentation.rs:118-127) -> shape + columns.  Lives inside the crate because the

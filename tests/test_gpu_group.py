@@ -114,6 +114,73 @@ def test_group_issue_equals_one_context_and_the_oracle():
     issuer.close()
 
 
+def test_group_show_and_verify_issuances_equal_one_context():
+    """afx_group_show / afx_group_verify_issuances and their _range forms (the user side on several GPUs): byte-equal to the
+    single-context calls, ragged slices and a range included; the presentations then verify"""
+    import aeonflux_amd as afx
+    import bench
+    from aeonflux_amd import batch
+    n, layout, hide, count = 4, "SSPE", [0, 3], 1203
+    params, key, ip = bench.load_fixture("readme_4attrs_sSPe")
+    issuer = afx.Context(params, key, ip)
+    user = afx.Context(params, None, ip)
+    rng = np.random.default_rng(31)
+    rb = lambda *s: rng.integers(0, 256, size=s, dtype=np.uint8)
+    kinds = [afx.ATTR_PUBLIC_SCALAR, afx.ATTR_PUBLIC_SCALAR, afx.ATTR_PUBLIC_POINT, afx.ATTR_EITHER_POINT]
+    values = np.stack([batch.scalars_from_wide(issuer, rb(count, 64)), batch.scalars_from_wide(issuer, rb(count, 64)),
+                       batch.points_from_uniform(issuer, rb(count, 64)), batch.points_from_uniform(issuer, rb(count, 64))])
+    M2, m3 = np.zeros((n, count, 32), np.uint8), np.zeros((n, count, 32), np.uint8)
+    M2[3], m3[3] = batch.points_from_uniform(issuer, rb(count, 64)), batch.scalars_from_wide(issuer, rb(count, 64))
+    iss, st = batch.issue(issuer, kinds, values, rb(count, 64), rb(count, 64), rb(count, 32))
+    assert not st.any()
+    bad = {k: v.copy() for k, v in iss.items()}
+    bad["responses"][2, 1100, 0] ^= 1
+    bad["V"][17] = bad["V"][18]
+    # user-side group (no issuer key)
+    grp = afx.Group(params, None, ip, _devices())
+    grp.member(1).set_chunk_items(256)
+    s1 = batch.verify_issuances(user, kinds, values, bad)
+    assert s1.sum() == 2 * afx.ST_VERIFICATION_FAILURE and s1[17] and s1[1100]
+    assert np.array_equal(batch.verify_issuances(grp, kinds, values, bad), s1)
+    part = batch.verify_issuances(user, kinds, values, bad, first=1000, n=203)
+    assert (part[:1000] == 255).all() and np.array_equal(part[1000:], s1[1000:])
+    # show
+    skinds = [afx.ATTR_SECRET_SCALAR, afx.ATTR_PUBLIC_SCALAR, afx.ATTR_PUBLIC_POINT, afx.ATTR_SECRET_POINT]
+    g = max(3, n)
+    gen = lambda idx: np.frombuffer(params[4 + 32 * idx:4 + 32 * idx + 32], np.uint8)
+    a, a0, a1 = (batch.scalars_from_wide(issuer, rb(count, 64)) for _ in range(3))
+    bases = np.stack([np.broadcast_to(gen(5 + g + n + 1 + k), (count, 32)) for k in range(3)])
+    pk, ok = batch.multiscalar_mul(issuer, np.stack([a, a0, a1]), bases)
+    kp = dict(a=a, a0=a0, a1=a1, pk=pk)
+    zw, seed, es = rb(count, 64), rb(count, 32), rb(1, count, 32)
+    p1, sh1, t1 = batch.show(user, skinds, values, iss["t"], iss["U"], iss["V"], kp, zw, seed, es, M2, m3)
+    assert not t1.any()
+    p2, sh2, t2 = batch.show(grp, skinds, values, iss["t"], iss["U"], iss["V"], kp, zw, seed, es, M2, m3)
+    assert bytes(sh1) == bytes(sh2) and np.array_equal(t1, t2)
+
+    def same(x, y, sel=slice(None)):
+        for f, v in x.items():
+            if f == "enc":
+                for d, e in zip(v, y["enc"]):
+                    for h, w in d.items():
+                        assert np.array_equal(w[..., sel, :], e[h][..., sel, :]), ("enc", h)
+            else:
+                assert np.array_equal(v[..., sel, :], y[f][..., sel, :]), f
+    same(p1, p2)
+    p3, sh3, t3 = batch.show(user, skinds, values, iss["t"], iss["U"], iss["V"], kp, zw, seed, es, M2, m3, first=300, n_items=77)
+    assert bytes(sh3) == bytes(sh1) and (t3[:300] == 255).all() and (t3[377:] == 255).all() and not t3[300:377].any()
+    same(p1, p3, slice(300, 377))
+    assert not p3["C_V"][:300].any() and not p3["enc"][0]["responses"][:, 377:].any()
+    # no keypair with a hidden group element: every status NoSymmetricKey, through the group as well
+    _, _, t4 = batch.show(grp, skinds, values, iss["t"], iss["U"], iss["V"], None, zw, seed, es, M2, m3)
+    assert (t4 == afx.ST_NO_SYMMETRIC_KEY).all()
+    # and what the group showed verifies
+    assert not batch.verify_presentations(issuer, sh2, p2).any()
+    grp.close()
+    user.close()
+    issuer.close()
+
+
 def test_fixed_key_schedule_gives_identical_results():
     """afx_ctx_set_fixed_key_schedule: the issuer key's scalars without NAF (running time independent of the key)"""
     import aeonflux_amd as afx

@@ -111,6 +111,14 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     assert len(batch.verify_presentations(grp, shape, pres)) == 3
     o2, st2 = batch.issue(grp, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
     assert len(st2) == 3
+    assert len(batch.verify_issuances(grp, kinds, values, iss)) == 3
+    assert batch.verify_issuances(ctx, kinds, values, iss, first=1, n=1)[0] == 255
+    pg, shg, stg = batch.show(grp, k2, values, iss["t"], iss["U"], iss["V"], kp, rb(3, 64), rb(3, 32), rb(max(nsp, 1), 3, 32), values, values)
+    assert bytes(shg) == bytes(shape) and len(stg) == 3
+    pr, shr, str_ = batch.show(ctx, k2, values, iss["t"], iss["U"], iss["V"], kp, rb(3, 64), rb(3, 32), rb(max(nsp, 1), 3, 32), values, values, first=2, n_items=1)
+    assert str_[0] == 255 and str_[1] == 255 and bytes(shr) == bytes(shape)
+    pe, she, ste = batch.show(ctx, k2, values, iss["t"], iss["U"], iss["V"], kp, rb(3, 64), rb(3, 32), rb(max(nsp, 1), 3, 32), values, values, first=3, n_items=0)
+    assert bytes(she) == bytes(shape) and (ste == 255).all()
     try:
         afx.Group(d["params"], d["key"], d["ip"], [0, 2])
         raise SystemExit("group on a missing device accepted")
@@ -215,6 +223,11 @@ for _ in range(3):
 kinds = [0] * 8
 o, st = batch.issue(grp, kinds, z(8, cnt, 32), z(cnt, 64), z(cnt, 64), z(cnt, 32))
 assert len(st) == cnt
+assert len(batch.verify_issuances(grp, kinds, z(8, cnt, 32), o)) == cnt
+kp = {f: z(cnt, 32) for f in ("a", "a0", "a1", "pk")}
+k2 = [1, 0, 2, 2, 4, 4, 3, 3]
+pg, shg, stg = batch.show(grp, k2, z(8, cnt, 32), o["t"], o["U"], o["V"], kp, z(cnt, 64), z(cnt, 32), z(2, cnt, 32), z(8, cnt, 32), z(8, cnt, 32))
+assert len(stg) == cnt and shg.n_enc_proofs == 2
 grp.close()
 print("tsan drive ok")
 """

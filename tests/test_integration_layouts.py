@@ -108,7 +108,7 @@ def rust_externs():
 def test_extern_declarations_match_the_header():
     cp, rx = c_prototypes(), rust_externs()
     assert {"afx_ctx_create", "afx_verify_presentations", "afx_issue", "afx_show", "afx_verify_issuances", "afx_group_create",
-            "afx_group_verify_presentations", "afx_group_issue"} <= set(rx)
+            "afx_group_verify_presentations", "afx_group_issue", "afx_group_show", "afx_group_verify_issuances"} <= set(rx)
     for name, (ret, kinds) in rx.items():
         assert name in cp, name
         cret, ckinds = cp[name]
