@@ -798,28 +798,31 @@ extern "C" int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, 
     if (sh.kinds[i] == AFX_ENC_PUBLIC_SCALAR || sh.kinds[i] == AFX_ENC_PUBLIC_POINT) row_of_cell.push_back(row_av + i);
   for (uint32_t r = row_enc; r < rows; r++) row_of_cell.push_back(r);
   if (row_of_cell.size() != cells) { set_error("internal: wire cell map"); return AFX_E_BAD_ARGS; }
-  Stager st(ctx);
-  const size_t o_rec = st.add(blob + off, (size_t)count * cells * 32), o_map = st.add((const uint8_t*)row_of_cell.data(), 4 * (size_t)cells),
-               o_soa = st.add(nullptr, (size_t)count * rows * 32), o_st = st.add(nullptr, count);
-  if ((rc = st.upload())) return rc;
-  AFX_HIP(afxk_aos_to_soa(ctx->stream, st.dev(o_rec), st.dev(o_soa), (const uint32_t*)st.dev(o_map), cells, (uint32_t)count));
-  auto rowp = [&](uint32_t r) { return (const uint8_t*)st.dev(o_soa) + (size_t)r * count * 32; };
-  afx_presentation_soa d;
-  d.challenge = rowp(0);
-  d.responses = rowp(row_resp);
-  d.C_x_0 = rowp(row_cx); d.C_x_1 = rowp(row_cx + 1); d.C_V = rowp(row_cx + 2);
-  d.C_y = rowp(row_cy);
-  d.attr_values = rowp(row_av);
-  std::vector<afx_encproof_soa> encs(sh.n_enc_proofs);
-  for (uint32_t e = 0; e < sh.n_enc_proofs; e++) {
-    const uint32_t r = row_enc + 14 * e;
-    encs[e] = { rowp(r), rowp(r + 1), rowp(r + 7), rowp(r + 8), rowp(r + 9), rowp(r + 10), rowp(r + 11), rowp(r + 12), rowp(r + 13) };
-  }
-  d.enc = encs.data();
-  if ((rc = afx_verify_presentations_dev(ctx, &sh, &d, count, st.dev(o_st)))) return rc;
-  AFX_HIP(hipMemcpyAsync(status, st.dev(o_st), count, hipMemcpyDeviceToHost, ctx->stream));
-  AFX_HIP(hipStreamSynchronize(ctx->stream));
-  return AFX_OK;
+  // records are contiguous: a slice of the batch is a byte range of the blob; slices alternate between the two lanes like
+  // those of the column-array calls (statements.hpp host_pipe), each transposed on the GPU into its own SoA scratch
+  return host_pipe(ctx, count, [&](Stager& st, size_t first, size_t sn) -> int {
+    const size_t o_rec = st.add(blob + off + first * cells * 32, sn * cells * 32), o_map = st.add((const uint8_t*)row_of_cell.data(), 4 * (size_t)cells),
+                 o_soa = st.reserve(sn * rows * 32), o_st = st.add(nullptr, sn);
+    st.plan_fetch(status, o_st, 1, 1, count, first, sn);
+    int rc2 = st.upload();
+    if (rc2) return rc2;
+    AFX_HIP(afxk_aos_to_soa(st.stream(), st.dev(o_rec), st.dev(o_soa), (const uint32_t*)st.dev(o_map), cells, (uint32_t)sn));
+    auto rowp = [&](uint32_t r) { return (const uint8_t*)st.dev(o_soa) + (size_t)r * sn * 32; };
+    afx_presentation_soa d;
+    d.challenge = rowp(0);
+    d.responses = rowp(row_resp);
+    d.C_x_0 = rowp(row_cx); d.C_x_1 = rowp(row_cx + 1); d.C_V = rowp(row_cx + 2);
+    d.C_y = rowp(row_cy);
+    d.attr_values = rowp(row_av);
+    std::vector<afx_encproof_soa> encs(sh.n_enc_proofs);
+    for (uint32_t e = 0; e < sh.n_enc_proofs; e++) {
+      const uint32_t r = row_enc + 14 * e;
+      encs[e] = { rowp(r), rowp(r + 1), rowp(r + 7), rowp(r + 8), rowp(r + 9), rowp(r + 10), rowp(r + 11), rowp(r + 12), rowp(r + 13) };
+    }
+    d.enc = encs.data();
+    if ((rc2 = afx_verify_presentations_dev(ctx, &sh, &d, sn, st.dev(o_st)))) return rc2;
+    return st.fetch_all();
+  });
 }
 
 // ---- CredentialIssuance batches ("AFXI" v1) -----------------------------------------------------
@@ -862,18 +865,20 @@ extern "C" int afx_verify_issuances_wire(afx_ctx* ctx, const uint8_t* blob, size
   const uint32_t n = at.n_attributes, cells = 4 + nr + n;
   std::vector<uint32_t> row_of_cell(cells);
   for (uint32_t r = 0; r < cells; r++) row_of_cell[r] = r;   // SoA rows in record order: t U V challenge responses[] values[]
-  Stager st(ctx);
-  const size_t o_rec = st.add(blob + off, (size_t)count * cells * 32), o_map = st.add((const uint8_t*)row_of_cell.data(), 4 * (size_t)cells),
-               o_soa = st.add(nullptr, (size_t)count * cells * 32), o_st = st.add(nullptr, count);
-  if ((rc = st.upload())) return rc;
-  AFX_HIP(afxk_aos_to_soa(ctx->stream, st.dev(o_rec), st.dev(o_soa), (const uint32_t*)st.dev(o_map), cells, (uint32_t)count));
-  auto rowp = [&](uint32_t r) { return (uint8_t*)st.dev(o_soa) + (size_t)r * count * 32; };
-  at.values = rowp(4 + nr);
-  const afx_issuance_soa iss = { rowp(0), rowp(1), rowp(2), rowp(3), rowp(4) };
-  if ((rc = afx_verify_issuances_dev(ctx, &at, &iss, nr, count, st.dev(o_st)))) return rc;
-  AFX_HIP(hipMemcpyAsync(status, st.dev(o_st), count, hipMemcpyDeviceToHost, ctx->stream));
-  AFX_HIP(hipStreamSynchronize(ctx->stream));
-  return AFX_OK;
+  return host_pipe(ctx, count, [&](Stager& st, size_t first, size_t sn) -> int {
+    const size_t o_rec = st.add(blob + off + first * cells * 32, sn * cells * 32), o_map = st.add((const uint8_t*)row_of_cell.data(), 4 * (size_t)cells),
+                 o_soa = st.reserve(sn * cells * 32), o_st = st.add(nullptr, sn);
+    st.plan_fetch(status, o_st, 1, 1, count, first, sn);
+    int rc2 = st.upload();
+    if (rc2) return rc2;
+    AFX_HIP(afxk_aos_to_soa(st.stream(), st.dev(o_rec), st.dev(o_soa), (const uint32_t*)st.dev(o_map), cells, (uint32_t)sn));
+    auto rowp = [&](uint32_t r) { return (uint8_t*)st.dev(o_soa) + (size_t)r * sn * 32; };
+    afx_attributes_soa as = at;
+    as.values = rowp(4 + nr);
+    const afx_issuance_soa iss = { rowp(0), rowp(1), rowp(2), rowp(3), rowp(4) };
+    if ((rc2 = afx_verify_issuances_dev(ctx, &as, &iss, nr, sn, st.dev(o_st)))) return rc2;
+    return st.fetch_all();
+  });
 }
 extern "C" int afx_ctx_issuer_parameters(afx_ctx* c, uint8_t out[64]) {
   if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }

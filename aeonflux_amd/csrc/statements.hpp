@@ -145,6 +145,12 @@ struct Stager {
     else if (len) blanks.push_back({ off, nullptr, len });
     return off;
   }
+  // scratch that the call's own kernels fill before anything reads it (not zeroed)
+  size_t reserve(size_t len) {
+    const size_t off = (bytes + 255) & ~size_t(255);
+    bytes = off + len;
+    return off;
+  }
   // items [first, first + n) of a [rows][total][elem] host array -> a contiguous [rows][n][elem] device array
   size_t add_rows(const uint8_t* src, size_t rows, size_t elem, size_t total, size_t first, size_t n) {
     const size_t off = (bytes + 255) & ~size_t(255);

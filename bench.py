@@ -513,7 +513,7 @@ def main():
     got = status.cpu().numpy()
     assert UNCHECKED or np.array_equal(got, want), "status mismatch after the timed steps"
     # PCIe-inclusive rate through the host-pointer entry point (never `value`; DESIGN.md quotes it)
-    pcie = None
+    pcie = wire_rate = None
     if rank == 0:
         hsoa, keep_h = batch.presentation_soa(pres)
         hst = np.full(count, 255, np.uint8)
@@ -522,6 +522,20 @@ def main():
         afx.check(afx.lib().afx_verify_presentations(issuer.h, C.byref(shape), C.byref(hsoa), count, hst.ctypes.data))
         pcie = count / (time.perf_counter() - t0)
         assert UNCHECKED or np.array_equal(hst, want)
+        # ... and as one serialized AFXP blob in pageable host memory (afx_verify_presentations_wire: the transposition to
+        # columns happens on the GPU, slice by slice); a quarter of the batch keeps the host-side packing short
+        from aeonflux_amd import wire as wire_mod
+        wn = min(count, 1 << 18)
+        wsub = {f: np.ascontiguousarray(pres[f][..., :wn, :]) for f in batch.PRES_FIELDS}
+        wsub["enc"] = [{f: np.ascontiguousarray(d[f][..., :wn, :]) for f in batch.ENC_FIELDS} for d in pres["enc"]]
+        blob = wire_mod.pack_presentations(shape, wsub)
+        wst, wcnt = np.full(wn, 255, np.uint8), C.c_size_t(0)
+        afx.check(afx.lib().afx_verify_presentations_wire(issuer.h, blob, len(blob), wst.ctypes.data, wn, C.byref(wcnt)))
+        t0 = time.perf_counter()
+        afx.check(afx.lib().afx_verify_presentations_wire(issuer.h, blob, len(blob), wst.ctypes.data, wn, C.byref(wcnt)))
+        wire_rate = wn / (time.perf_counter() - t0)
+        assert UNCHECKED or np.array_equal(wst, want[:wn])
+        del blob, wsub
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is an N=1 figure
@@ -567,7 +581,8 @@ def main():
             "config": {"workload": desc, "presentations_per_gpu": count, "attributes": n, "shape": layout, "hidden": hide,
                        "algorithmic_bytes_per_presentation": ab, "parallelism": "host-sharded x%d, no collective" % world,
                        "step_pipelining": "2 streams" if args.pipelining else "off",
-                       "input_generation_s": round(gen_s, 2), "host_pointer_api_presentations_per_s": pcie},
+                       "input_generation_s": round(gen_s, 2), "host_pointer_api_presentations_per_s": pcie,
+                       "wire_blob_api_presentations_per_s": wire_rate},
             "roofline": roofline_of(kt, args.workload, ab, count),
             "valu": valu,
             "cpu_baseline": cpu,

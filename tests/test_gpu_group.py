@@ -59,6 +59,12 @@ def test_group_ranges_and_slices_equal_one_context_and_the_oracle():
     # many small slices on alternating streams (the host-pointer pipeline), ragged tail included
     other.set_chunk_items(256)
     assert np.array_equal(batch.verify_presentations(other, shape, pres), one)
+    # the same batch as one serialized blob (AFXP): slices are byte ranges of the record area
+    from aeonflux_amd import wire
+    blob = wire.pack_presentations(shape, pres)
+    stw, cw = np.full(count, 9, np.uint8), C.c_size_t(0)
+    afx.check(afx.lib().afx_verify_presentations_wire(other.h, blob, len(blob), stw.ctypes.data, count, C.byref(cw)))
+    assert cw.value == count and np.array_equal(stw, one)
     grp.member(0).set_chunk_items(512)
     assert np.array_equal(batch.verify_presentations(grp, shape, pres), one)
     # empty and one-item batches
@@ -109,6 +115,12 @@ def test_group_issue_equals_one_context_and_the_oracle():
     user = afx.Context(params, None, ip)
     sv = batch.verify_issuances(user, kinds, values, o2)
     assert not sv[ok].any() and sv[7] == afx.ST_VERIFICATION_FAILURE
+    # ... also as one serialized blob (AFXI) in slices of 256 records
+    from aeonflux_amd import wire
+    o2["responses"][5, 1000, 1] ^= 4
+    sv[1000] = afx.ST_VERIFICATION_FAILURE
+    user.set_chunk_items(256)
+    assert np.array_equal(user.verify_issuances_wire(wire.pack_issuances(kinds, values, o2)), sv)
     user.close()
     grp.close()
     issuer.close()
