@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libaeonflux_gpu.so")
 MAX_ATTRIBUTES = 32
 
 OK, E_BAD_ARGS, E_BAD_PARAMS, E_NO_DEVICE, E_HIP, E_NO_KEY = 0, -1, -2, -3, -4, -5
+E_NO_MEMORY = -6
 ST_OK, ST_VERIFICATION_FAILURE, ST_MAC_CREATION, ST_NO_SYMMETRIC_KEY, ST_UNDECRYPTABLE = 0, 1, 2, 3, 4
 ATTR_PUBLIC_SCALAR, ATTR_SECRET_SCALAR, ATTR_PUBLIC_POINT, ATTR_EITHER_POINT, ATTR_SECRET_POINT = range(5)
 ENC_PUBLIC_SCALAR, ENC_SECRET_SCALAR, ENC_PUBLIC_POINT, ENC_SECRET_POINT = range(4)

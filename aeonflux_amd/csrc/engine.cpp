@@ -3,12 +3,30 @@
 #include <string.h>
 #include <algorithm>
 #include <map>
+#include <new>
+#include <system_error>
 #include <stdexcept>
 
 namespace afx {
 
 static thread_local std::string g_error;
 void set_error(const std::string& s) { g_error = s; }
+int exception_rc() noexcept {
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    try { set_error("out of host memory"); } catch (...) {}
+    return AFX_E_NO_MEMORY;
+  } catch (const std::system_error& e) {
+    try { set_error(std::string("system: ") + e.what()); } catch (...) {}
+    return AFX_E_NO_MEMORY;
+  } catch (const std::exception& e) {
+    try { set_error(std::string("internal: ") + e.what()); } catch (...) {}
+    return AFX_E_BAD_ARGS;
+  } catch (...) {
+    return AFX_E_BAD_ARGS;
+  }
+}
 const char* last_error() { return g_error.c_str(); }
 
 int DevBuf::ensure(size_t n) {

@@ -19,6 +19,9 @@ namespace afx {
 
 void set_error(const std::string& s);
 const char* last_error();
+// No exception leaves the library: every int-returning entry point is a function-try-block whose handler calls this
+// (inside a catch clause) to turn the exception in flight into a return code and an error string.
+int exception_rc() noexcept;
 #define AFX_HIP(call)                                                                                  \
   do {                                                                                                 \
     hipError_t e__ = (call);                                                                           \

@@ -4,40 +4,38 @@
 // per member, and every member writes its part of the caller's arrays: no data moves between devices and there is no
 // collective.  This is what one `&self` method of the reference (Issuer::verify, /root/reference/src/issuer.rs:141-147;
 // Issuer::issue, :111-124) becomes when the issuer owns a node of GPUs.
+#include <memory>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 #include "statements.hpp"
 
 struct afx_group {
   std::vector<afx_ctx*> members;
+  ~afx_group() { for (afx_ctx* m : members) afx_ctx_destroy(m); }   // wipes every member's copy of the key
 };
 
 extern "C" int afx_group_create(afx_group** out, const int* devices, uint32_t n_devices, const uint8_t* sysparams, size_t sysparams_len,
-                                const uint8_t* amacs_key, size_t amacs_key_len, const uint8_t issuer_params[64]) {
+                                const uint8_t* amacs_key, size_t amacs_key_len, const uint8_t issuer_params[64]) try {
   if (!out || !devices || n_devices == 0 || n_devices > 64) { set_error("bad device list"); return AFX_E_BAD_ARGS; }
   *out = nullptr;
-  afx_group* g = new afx_group();
+  std::unique_ptr<afx_group> g(new afx_group());
+  g->members.reserve(n_devices);
   for (uint32_t i = 0; i < n_devices; i++) {
     afx_ctx* c = nullptr;
     const int rc = afx_ctx_create(&c, devices[i], sysparams, sysparams_len, amacs_key, amacs_key_len, issuer_params);
     if (rc) {
       const std::string why = afx_last_error();
-      for (afx_ctx* m : g->members) afx_ctx_destroy(m);
-      delete g;
       set_error("member " + std::to_string(i) + " (device " + std::to_string(devices[i]) + "): " + why);
       return rc;
     }
     g->members.push_back(c);
   }
-  *out = g;
+  *out = g.release();
   return AFX_OK;
-}
-extern "C" void afx_group_destroy(afx_group* g) {
-  if (!g) return;
-  for (afx_ctx* m : g->members) afx_ctx_destroy(m);
-  delete g;
-}
+} catch (...) { return afx::exception_rc(); }
+extern "C" void afx_group_destroy(afx_group* g) { delete g; }
 extern "C" uint32_t afx_group_size(const afx_group* g) { return g ? (uint32_t)g->members.size() : 0; }
 extern "C" afx_ctx* afx_group_member(afx_group* g, uint32_t i) { return (g && i < g->members.size()) ? g->members[i] : nullptr; }
 
@@ -64,7 +62,11 @@ static int run_members(afx_group* g, size_t count, F&& call) {
     rcs[i] = call(g->members[i], first, n);
     if (rcs[i]) errs[i] = afx_last_error();   // the error string is per thread
   };
-  for (uint32_t i = 1; i < m; i++) threads.emplace_back(body, i);
+  // a member whose thread cannot be started runs on this one; the members' calls themselves do not throw (C entry points)
+  threads.reserve(m);
+  for (uint32_t i = 1; i < m; i++) {
+    try { threads.emplace_back(body, i); } catch (const std::system_error&) { body(i); }
+  }
   body(0);
   for (std::thread& t : threads) t.join();
   for (uint32_t i = 0; i < m; i++)
@@ -72,24 +74,24 @@ static int run_members(afx_group* g, size_t count, F&& call) {
   return AFX_OK;
 }
 
-extern "C" int afx_group_verify_presentations(afx_group* g, const afx_shape* shape, const afx_presentation_soa* batch, size_t count, uint8_t* status) {
+extern "C" int afx_group_verify_presentations(afx_group* g, const afx_shape* shape, const afx_presentation_soa* batch, size_t count, uint8_t* status) try {
   if (!g || g->members.empty() || !shape || !batch || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   return run_members(g, count, [&](afx_ctx* c, size_t first, size_t n) { return afx_verify_presentations_range(c, shape, batch, count, first, n, status); });
-}
+} catch (...) { return afx::exception_rc(); }
 extern "C" int afx_group_issue(afx_group* g, const afx_attributes_soa* requests, const afx_issue_randomness* rnd, size_t count,
-                               const afx_issuance_soa* out, uint8_t* status) {
+                               const afx_issuance_soa* out, uint8_t* status) try {
   if (!g || g->members.empty() || !requests || !rnd || !out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   return run_members(g, count, [&](afx_ctx* c, size_t first, size_t n) { return afx_issue_range(c, requests, rnd, count, first, n, out, status); });
-}
+} catch (...) { return afx::exception_rc(); }
 extern "C" int afx_group_verify_issuances(afx_group* g, const afx_attributes_soa* attrs, const afx_issuance_soa* issuances, uint32_t n_responses,
-                                          size_t count, uint8_t* status) {
+                                          size_t count, uint8_t* status) try {
   if (!g || g->members.empty() || !attrs || !issuances || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   return run_members(g, count, [&](afx_ctx* c, size_t first, size_t n) { return afx_verify_issuances_range(c, attrs, issuances, n_responses, count, first, n, status); });
-}
+} catch (...) { return afx::exception_rc(); }
 // the shape is a function of the credentials' layout alone: member 0 reports it (an empty range still does), the other
 // members write theirs to a local
 extern "C" int afx_group_show(afx_group* g, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
-                              size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status) {
+                              size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status) try {
   if (!g || g->members.empty() || !creds || !rnd || !out || !shape_out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   int rc = afx_show_range(g->members[0], creds, keypairs, rnd, count, 0, 0, out, shape_out, status);
   if (rc) return rc;
@@ -97,4 +99,4 @@ extern "C" int afx_group_show(afx_group* g, const afx_credentials_soa* creds, co
     afx_shape local;
     return afx_show_range(c, creds, keypairs, rnd, count, first, n, out, &local, status);
   });
-}
+} catch (...) { return afx::exception_rc(); }

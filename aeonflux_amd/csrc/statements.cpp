@@ -53,7 +53,7 @@ static int drain_timing(afx_ctx* c) {
   c->timed.clear();
   return AFX_OK;
 }
-extern "C" int afx_ctx_set_pipelining(afx_ctx* c, int enable) {
+extern "C" int afx_ctx_set_pipelining(afx_ctx* c, int enable) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
   AFX_HIP(hipSetDevice(c->device));
@@ -63,8 +63,8 @@ extern "C" int afx_ctx_set_pipelining(afx_ctx* c, int enable) {
   c->lane_next = 0;
   for (auto& L : c->lane) L.msm_recorded = false;
   return AFX_OK;
-}
-extern "C" int afx_ctx_set_challenge_trace(afx_ctx* c, size_t rows, size_t count) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_set_challenge_trace(afx_ctx* c, size_t rows, size_t count) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
   AFX_HIP(hipSetDevice(c->device));
@@ -80,8 +80,8 @@ extern "C" int afx_ctx_set_challenge_trace(afx_ctx* c, size_t rows, size_t count
   c->trace_rows = rows;
   c->trace_count = count;
   return AFX_OK;
-}
-extern "C" int afx_ctx_get_challenge_trace(afx_ctx* c, uint8_t* host_out) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_get_challenge_trace(afx_ctx* c, uint8_t* host_out) try {
   if (!c || !host_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
   if (!c->trace) { set_error("challenge trace is off"); return AFX_E_BAD_ARGS; }
@@ -90,40 +90,40 @@ extern "C" int afx_ctx_get_challenge_trace(afx_ctx* c, uint8_t* host_out) {
     if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
   AFX_HIP(hipMemcpy(host_out, c->trace, c->trace_rows * c->trace_count * 32, hipMemcpyDeviceToHost));
   return AFX_OK;
-}
-extern "C" int afx_ctx_set_chunk_items(afx_ctx* c, uint32_t items) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_set_chunk_items(afx_ctx* c, uint32_t items) try {
   if (!c || (items != 0 && (items < 256 || items > (1u << 22)))) { set_error("chunk size out of range"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
   c->chunk_items = items;
   return AFX_OK;
-}
-extern "C" int afx_ctx_set_strict(afx_ctx* c, int enable) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_set_strict(afx_ctx* c, int enable) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
   c->strict = enable != 0;
   return AFX_OK;
-}
-extern "C" int afx_ctx_set_fixed_key_schedule(afx_ctx* c, int enable) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_set_fixed_key_schedule(afx_ctx* c, int enable) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
   c->fixed_key_schedule = enable != 0;
   return AFX_OK;
-}
-extern "C" int afx_ctx_get_plan_stats(afx_ctx* c, afx_plan_stats* out) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_get_plan_stats(afx_ctx* c, afx_plan_stats* out) try {
   if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
   *out = c->last_stats;
   return AFX_OK;
-}
-extern "C" int afx_ctx_synchronize(afx_ctx* c) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_synchronize(afx_ctx* c) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
   AFX_HIP(hipSetDevice(c->device));
   for (auto& L : c->lane)
     if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
   return AFX_OK;
-}
-extern "C" int afx_ctx_set_timing(afx_ctx* c, int enable) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_set_timing(afx_ctx* c, int enable) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
   AFX_HIP(hipSetDevice(c->device));
@@ -133,8 +133,8 @@ extern "C" int afx_ctx_set_timing(afx_ctx* c, int enable) {
   if (c->d_consts.p) AFX_HIP(hipMemsetAsync(c->clock_probe(), 0, 16, c->stream));
   c->timing = enable != 0;
   return AFX_OK;
-}
-extern "C" int afx_ctx_get_core_clock_mhz(afx_ctx* c, double* mhz) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_get_core_clock_mhz(afx_ctx* c, double* mhz) try {
   if (!c || !mhz) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
   AFX_HIP(hipSetDevice(c->device));
@@ -144,8 +144,8 @@ extern "C" int afx_ctx_get_core_clock_mhz(afx_ctx* c, double* mhz) {
   AFX_HIP(hipMemcpy(v, c->clock_probe(), sizeof v, hipMemcpyDeviceToHost));
   *mhz = v[1] ? 100.0 * (double)v[0] / (double)v[1] : 0.0;
   return AFX_OK;
-}
-extern "C" int afx_ctx_get_timing(afx_ctx* c, const char* kernel, double* total_ms, uint64_t* launches) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_get_timing(afx_ctx* c, const char* kernel, double* total_ms, uint64_t* launches) try {
   if (!c || !kernel || !total_ms || !launches) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
   AFX_HIP(hipSetDevice(c->device));
@@ -160,7 +160,7 @@ extern "C" int afx_ctx_get_timing(afx_ctx* c, const char* kernel, double* total_
     if (strcmp(kernel, KIND_NAMES[k]) == 0) { *total_ms = c->kind_ms[k]; *launches = c->kind_launches[k]; return AFX_OK; }
   set_error("unknown kernel name");
   return AFX_E_BAD_ARGS;
-}
+} catch (...) { return afx::exception_rc(); }
 
 extern "C" void afx_ctx_destroy(afx_ctx* c) {
   if (!c) return;
@@ -294,10 +294,10 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
 }
 
 extern "C" int afx_ctx_create(afx_ctx** out, int device, const uint8_t* sysparams, size_t sysparams_len, const uint8_t* amacs_key,
-                              size_t amacs_key_len, const uint8_t issuer_params[64]) {
+                              size_t amacs_key_len, const uint8_t issuer_params[64]) try {
   if (!issuer_params) { set_error("issuer_params is required"); return AFX_E_BAD_ARGS; }
   return afx_ctx_create_impl(out, device, sysparams, sysparams_len, amacs_key, amacs_key_len, nullptr, issuer_params);
-}
+} catch (...) { return afx::exception_rc(); }
 
 // ProofOfEncryption::verify, src/nizk/encryption.rs:154-210
 static void add_encproof_verify(Assembler& as, JobSets& js, uint16_t index, const afx_encproof_soa& e, size_t total, size_t off, uint32_t trace_row) {
@@ -507,7 +507,7 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
 }
 
 extern "C" int afx_verify_presentations_dev(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* batch, size_t count,
-                                            uint8_t* status_dev) {
+                                            uint8_t* status_dev) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !shape || !batch || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -541,9 +541,9 @@ extern "C" int afx_verify_presentations_dev(afx_ctx* ctx, const afx_shape* shape
     bb.enc = encs.data();
     build_presentation_verify(as, sh, bb, count, off, status_dev + off);
   }, key);
-}
+} catch (...) { return afx::exception_rc(); }
 
-extern "C" int afx_verify_encryption_proofs_dev(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* batch, size_t count, uint8_t* status_dev) {
+extern "C" int afx_verify_encryption_proofs_dev(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* batch, size_t count, uint8_t* status_dev) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !batch || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -558,7 +558,7 @@ extern "C" int afx_verify_encryption_proofs_dev(afx_ctx* ctx, uint16_t index, co
     add_encproof_verify(as, js, index, e, count, off, 0);
     emit(as, js, status_dev + off, AFX_ST_VERIFICATION_FAILURE);
   });
-}
+} catch (...) { return afx::exception_rc(); }
 
 // ------------------------------------------------------------------------------------------------
 // host-pointer front ends: stage the SoA batch into HBM, run the *_dev form, fetch the status bytes
@@ -612,18 +612,18 @@ static int verify_presentations_host(afx_ctx* ctx, const afx_shape* shape, const
 }
 
 extern "C" int afx_verify_presentations_range(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* b, size_t total, size_t first,
-                                              size_t n, uint8_t* status) {
+                                              size_t n, uint8_t* status) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !shape || !b || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (first > total || n > total - first) { set_error("range outside the batch"); return AFX_E_BAD_ARGS; }
   return verify_presentations_host(ctx, shape, b, total, first, n, status);
-}
-extern "C" int afx_verify_presentations(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* b, size_t count, uint8_t* status) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_verify_presentations(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* b, size_t count, uint8_t* status) try {
   return afx_verify_presentations_range(ctx, shape, b, count, 0, count, status);
-}
+} catch (...) { return afx::exception_rc(); }
 
-extern "C" int afx_verify_encryption_proofs(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* b, size_t count, uint8_t* status) {
+extern "C" int afx_verify_encryption_proofs(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* b, size_t count, uint8_t* status) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !b || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -640,12 +640,12 @@ extern "C" int afx_verify_encryption_proofs(afx_ctx* ctx, uint16_t index, const 
   AFX_HIP(hipMemcpyAsync(status, st.dev(o_st), count, hipMemcpyDeviceToHost, ctx->stream));
   AFX_HIP(hipStreamSynchronize(ctx->stream));
   return AFX_OK;
-}
+} catch (...) { return afx::exception_rc(); }
 
 // ------------------------------------------------------------------------------------------------
 // batch primitives (K* rows): from_uniform_bytes, from_bytes_mod_order_wide, decompress/compress, MSM
 // ------------------------------------------------------------------------------------------------
-extern "C" int afx_points_from_uniform_bytes(afx_ctx* ctx, const uint8_t* wide, size_t count, uint8_t* out) {
+extern "C" int afx_points_from_uniform_bytes(afx_ctx* ctx, const uint8_t* wide, size_t count, uint8_t* out) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !wide || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -659,8 +659,8 @@ extern "C" int afx_points_from_uniform_bytes(afx_ctx* ctx, const uint8_t* wide, 
   AFX_HIP(hipMemcpyAsync(out, st.dev(o_out), 32 * count, hipMemcpyDeviceToHost, ctx->stream));
   AFX_HIP(hipStreamSynchronize(ctx->stream));
   return AFX_OK;
-}
-extern "C" int afx_scalars_from_wide_bytes(afx_ctx* ctx, const uint8_t* wide, size_t count, uint8_t* out) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_scalars_from_wide_bytes(afx_ctx* ctx, const uint8_t* wide, size_t count, uint8_t* out) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !wide || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -674,8 +674,8 @@ extern "C" int afx_scalars_from_wide_bytes(afx_ctx* ctx, const uint8_t* wide, si
   AFX_HIP(hipMemcpyAsync(out, st.dev(o_out), 32 * count, hipMemcpyDeviceToHost, ctx->stream));
   AFX_HIP(hipStreamSynchronize(ctx->stream));
   return AFX_OK;
-}
-extern "C" int afx_points_validate(afx_ctx* ctx, const uint8_t* pts, size_t count, uint8_t* ok, uint8_t* reencoded) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_points_validate(afx_ctx* ctx, const uint8_t* pts, size_t count, uint8_t* ok, uint8_t* reencoded) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !pts || !ok) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -690,8 +690,8 @@ extern "C" int afx_points_validate(afx_ctx* ctx, const uint8_t* pts, size_t coun
   if (reencoded) AFX_HIP(hipMemcpyAsync(reencoded, st.dev(o_re), 32 * count, hipMemcpyDeviceToHost, ctx->stream));
   AFX_HIP(hipStreamSynchronize(ctx->stream));
   return AFX_OK;
-}
-extern "C" int afx_multiscalar_mul(afx_ctx* ctx, uint32_t n_terms, const uint8_t* scalars, const uint8_t* points, size_t count, uint8_t* out, uint8_t* ok) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_multiscalar_mul(afx_ctx* ctx, uint32_t n_terms, const uint8_t* scalars, const uint8_t* points, size_t count, uint8_t* out, uint8_t* ok) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !scalars || !points || !out || !ok) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -726,7 +726,7 @@ extern "C" int afx_multiscalar_mul(afx_ctx* ctx, uint32_t n_terms, const uint8_t
   AFX_HIP(hipStreamSynchronize(ctx->stream));
   for (size_t i = 0; i < count; i++) ok[i] = bad[i] ? 0 : 1;
   return AFX_OK;
-}
+} catch (...) { return afx::exception_rc(); }
 
 // ------------------------------------------------------------------------------------------------
 // wire format: header parsing on the host, AoS -> SoA transposition on the GPU
@@ -750,7 +750,7 @@ extern "C" size_t afx_wire_header_bytes(const afx_shape* sh) {
   const size_t raw = 32 + sh->n_attributes + 2 * (size_t)sh->n_hidden_scalars + 2 * (size_t)sh->n_enc_proofs;
   return (raw + 31) & ~size_t(31);
 }
-extern "C" int afx_wire_parse(const uint8_t* blob, size_t len, afx_shape* shape_out, size_t* count_out, size_t* records_offset_out) {
+extern "C" int afx_wire_parse(const uint8_t* blob, size_t len, afx_shape* shape_out, size_t* count_out, size_t* records_offset_out) try {
   if (!blob || !shape_out || !count_out || !records_offset_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (len < 32 || memcmp(blob, "AFXP", 4) != 0 || rd32(blob + 4) != 1) { set_error("not an AFXP v1 batch"); return AFX_E_BAD_ARGS; }
   afx_shape sh;
@@ -773,8 +773,8 @@ extern "C" int afx_wire_parse(const uint8_t* blob, size_t len, afx_shape* shape_
   *count_out = count;
   *records_offset_out = hdr;
   return AFX_OK;
-}
-extern "C" int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !status || !count_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -823,7 +823,7 @@ extern "C" int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, 
     if ((rc2 = afx_verify_presentations_dev(ctx, &sh, &d, sn, st.dev(o_st)))) return rc2;
     return st.fetch_all();
   });
-}
+} catch (...) { return afx::exception_rc(); }
 
 // ---- CredentialIssuance batches ("AFXI" v1) -----------------------------------------------------
 extern "C" size_t afx_issuance_wire_header_bytes(uint32_t n_attributes) {
@@ -831,7 +831,7 @@ extern "C" size_t afx_issuance_wire_header_bytes(uint32_t n_attributes) {
   return (24 + (size_t)n_attributes + 31) & ~size_t(31);
 }
 extern "C" int afx_issuance_wire_parse(const uint8_t* blob, size_t len, uint32_t* n_out, uint8_t kinds_out[AFX_MAX_ATTRIBUTES], uint32_t* nr_out,
-                                       size_t* count_out, size_t* records_offset_out) {
+                                       size_t* count_out, size_t* records_offset_out) try {
   if (!blob || !n_out || !kinds_out || !nr_out || !count_out || !records_offset_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (len < 24 || memcmp(blob, "AFXI", 4) != 0 || rd32(blob + 4) != 1) { set_error("not an AFXI v1 batch"); return AFX_E_BAD_ARGS; }
   const uint32_t count = rd32(blob + 8), cells = rd32(blob + 12), n = rd32(blob + 16), nr = rd32(blob + 20);
@@ -846,8 +846,8 @@ extern "C" int afx_issuance_wire_parse(const uint8_t* blob, size_t len, uint32_t
   memcpy(kinds_out, blob + 24, n);
   *n_out = n; *nr_out = nr; *count_out = count; *records_offset_out = hdr;
   return AFX_OK;
-}
-extern "C" int afx_verify_issuances_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_verify_issuances_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !status || !count_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -879,11 +879,11 @@ extern "C" int afx_verify_issuances_wire(afx_ctx* ctx, const uint8_t* blob, size
     if ((rc2 = afx_verify_issuances_dev(ctx, &as, &iss, nr, sn, st.dev(o_st)))) return rc2;
     return st.fetch_all();
   });
-}
-extern "C" int afx_ctx_issuer_parameters(afx_ctx* c, uint8_t out[64]) {
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_issuer_parameters(afx_ctx* c, uint8_t out[64]) try {
   if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
   memcpy(out, c->gen_enc[c->id_CW()].data(), 32);
   memcpy(out + 32, c->gen_enc[c->id_I()].data(), 32);
   return AFX_OK;
-}
+} catch (...) { return afx::exception_rc(); }

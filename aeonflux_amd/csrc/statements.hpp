@@ -220,15 +220,24 @@ inline int host_pipe(afx_ctx* c, size_t count, const std::function<int(Stager&, 
   std::unique_ptr<Stager> st[2];
   int rc = AFX_OK;
   size_t i = 0;
-  for (size_t off = 0; off < count && !rc; i++) {
-    const size_t n = std::min(per, count - off);
-    const int lane = (int)(i & 1);
-    if (st[lane]) { rc = st[lane]->drain(); st[lane].reset(); }
-    if (rc) break;
-    st[lane].reset(new Stager(c, lane));
-    c->force_lane = lane;
-    rc = slice(*st[lane], off, n);
-    off += n;
+  try {
+    for (size_t off = 0; off < count && !rc; i++) {
+      const size_t n = std::min(per, count - off);
+      const int lane = (int)(i & 1);
+      if (st[lane]) { rc = st[lane]->drain(); st[lane].reset(); }
+      if (rc) break;
+      st[lane].reset(new Stager(c, lane));
+      c->force_lane = lane;
+      rc = slice(*st[lane], off, n);
+      off += n;
+    }
+  } catch (...) {
+    // copies from and to the caller's arrays may be in flight: wait for them before the exception goes on to the entry
+    // point's handler (which turns it into a return code)
+    for (auto& L : c->lane) if (L.stream) (void)hipStreamSynchronize(L.stream);
+    st[0].reset(); st[1].reset();
+    c->force_lane = entry_force;
+    throw;
   }
   for (int k = 0; k < 2; k++) {
     const int lane = (int)((i + k) & 1);   // oldest first

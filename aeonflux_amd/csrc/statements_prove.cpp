@@ -96,7 +96,7 @@ static void messages_from_attributes(Assembler& as, const afx_attributes_soa& a,
 // CredentialIssuance::verify
 // ------------------------------------------------------------------------------------------------
 extern "C" int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* iss, uint32_t n_responses,
-                                        size_t count, uint8_t* status_dev) {
+                                        size_t count, uint8_t* status_dev) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !attrs || !iss || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -141,13 +141,13 @@ extern "C" int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* 
     v.verify_compact(row(s.challenge, 0), 0, count, off, js.msm2, js.hash, &js.scalarop);   // (resp_y * m_i) * G_m_i products: inputs only
     emit(as, js, status_dev + off, AFX_ST_VERIFICATION_FAILURE);
   }, key__);
-}
+} catch (...) { return afx::exception_rc(); }
 
 // ------------------------------------------------------------------------------------------------
 // Issuer::issue
 // ------------------------------------------------------------------------------------------------
 extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, const afx_issue_randomness* rnd, size_t count,
-                             const afx_issuance_soa* out, uint8_t* status_dev) {
+                             const afx_issuance_soa* out, uint8_t* status_dev) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !requests || !rnd || !out || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -231,13 +231,13 @@ extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, c
     as.scalarop(resp);
     as.finish(status_dev + off, AFX_ST_MAC_CREATION);
   }, key__);
-}
+} catch (...) { return afx::exception_rc(); }
 
 // ------------------------------------------------------------------------------------------------
 // AnonymousCredential::show
 // ------------------------------------------------------------------------------------------------
 extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
-                            size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status_dev) {
+                            size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status_dev) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !creds || !rnd || !out || !shape_out || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -456,7 +456,7 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
     as.scalarop(resp);
     as.finish(status_dev + off, AFX_ST_VERIFICATION_FAILURE);
   }, key__);
-}
+} catch (...) { return afx::exception_rc(); }
 
 // ------------------------------------------------------------------------------------------------
 // host-pointer front ends
@@ -470,7 +470,7 @@ static int fetch(afx_ctx* ctx, void* dst, const uint8_t* src_dev, size_t n) {
 // Requests [first, first + n) of a batch of `total` held in host memory (outputs and status are indexed like the inputs:
 // item i of the batch lands in element i of every output array).  Slices alternate between the two lanes (statements.hpp).
 extern "C" int afx_issue_range(afx_ctx* ctx, const afx_attributes_soa* req, const afx_issue_randomness* rnd, size_t total, size_t first, size_t n,
-                               const afx_issuance_soa* out, uint8_t* status) {
+                               const afx_issuance_soa* out, uint8_t* status) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !req || !rnd || !out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -506,15 +506,15 @@ extern "C" int afx_issue_range(afx_ctx* ctx, const afx_attributes_soa* req, cons
     if ((rc = afx_issue_dev(ctx, &da, &dr, sn, &dout, st.dev(o_st)))) return rc;
     return st.fetch_all();
   });
-}
+} catch (...) { return afx::exception_rc(); }
 extern "C" int afx_issue(afx_ctx* ctx, const afx_attributes_soa* req, const afx_issue_randomness* rnd, size_t count,
-                         const afx_issuance_soa* out, uint8_t* status) {
+                         const afx_issuance_soa* out, uint8_t* status) try {
   return afx_issue_range(ctx, req, rnd, count, 0, count, out, status);
-}
+} catch (...) { return afx::exception_rc(); }
 
 // Issuances [first, first + n) of a host batch of `total` (user side, CredentialIssuance::verify, /root/reference/src/issuer.rs:48-57)
 extern "C" int afx_verify_issuances_range(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* iss, uint32_t n_responses,
-                                          size_t total, size_t first, size_t n, uint8_t* status) {
+                                          size_t total, size_t first, size_t n, uint8_t* status) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !attrs || !iss || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -543,16 +543,16 @@ extern "C" int afx_verify_issuances_range(afx_ctx* ctx, const afx_attributes_soa
     if ((rc = afx_verify_issuances_dev(ctx, &da, &di, n_responses, sn, st.dev(o_st)))) return rc;
     return st.fetch_all();
   });
-}
+} catch (...) { return afx::exception_rc(); }
 extern "C" int afx_verify_issuances(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* iss, uint32_t n_responses,
-                                    size_t count, uint8_t* status) {
+                                    size_t count, uint8_t* status) try {
   return afx_verify_issuances_range(ctx, attrs, iss, n_responses, count, 0, count, status);
-}
+} catch (...) { return afx::exception_rc(); }
 
 // Credentials [first, first + n) of a host batch of `total` (AnonymousCredential::show, /root/reference/src/credential.rs:37-46);
 // every output array is indexed like the inputs.  shape_out is the same for every range of one batch.
 extern "C" int afx_show_range(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
-                              size_t total, size_t first, size_t n, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status) {
+                              size_t total, size_t first, size_t n, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !creds || !rnd || !out || !shape_out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -609,17 +609,17 @@ extern "C" int afx_show_range(afx_ctx* ctx, const afx_credentials_soa* creds, co
     if ((rc = afx_show_dev(ctx, &dc, kp ? &dk : nullptr, &dr, sn, &dout, shape_out, st.dev(o_st)))) return rc;
     return st.fetch_all();
   });
-}
+} catch (...) { return afx::exception_rc(); }
 extern "C" int afx_show(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
-                        size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status) {
+                        size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status) try {
   return afx_show_range(ctx, creds, keypairs, rnd, count, 0, count, out, shape_out, status);
-}
+} catch (...) { return afx::exception_rc(); }
 
 // ------------------------------------------------------------------------------------------------
 // IssuerParameters::generate + W = w*G_w
 // ------------------------------------------------------------------------------------------------
 extern "C" int afx_issuer_keygen(int device, const uint8_t* sysparams, size_t sysparams_len, const uint8_t* key_scalars, size_t key_scalars_len,
-                                 uint8_t W_out[32], uint8_t issuer_params_out[64]) {
+                                 uint8_t W_out[32], uint8_t issuer_params_out[64]) try {
   if (!sysparams || !key_scalars || !W_out || !issuer_params_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (sysparams_len < 4) { set_error("SystemParameters too short"); return AFX_E_BAD_PARAMS; }
   const uint32_t n = (uint32_t)sysparams[0] | ((uint32_t)sysparams[1] << 8) | ((uint32_t)sysparams[2] << 16) | ((uint32_t)sysparams[3] << 24);
@@ -660,4 +660,4 @@ extern "C" int afx_issuer_keygen(int device, const uint8_t* sysparams, size_t sy
   }
   afx_ctx_destroy(c);
   return rc;
-}
+} catch (...) { return afx::exception_rc(); }

@@ -52,7 +52,7 @@ static int bare_ctx(afx_ctx** out, int device) {
 }
 
 extern "C" int afx_system_parameters_generate(int device, uint32_t n, const uint8_t* rng_stream, size_t stream_len, uint8_t* params_out,
-                                              size_t params_cap, size_t* consumed_out) {
+                                              size_t params_cap, size_t* consumed_out) try {
   if (!rng_stream || !params_out || !consumed_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (n == 0 || n > AFX_MAX_ATTRIBUTES) { set_error("number of attributes out of range"); return AFX_E_BAD_ARGS; }
   const uint32_t g = n < 3 ? 3 : n, total = 4 + g + n + 4;
@@ -112,9 +112,9 @@ extern "C" int afx_system_parameters_generate(int device, uint32_t n, const uint
   for (uint32_t k = 0; k < total; k++) { memcpy(p, gen[k], 32); p += 32; }
   *consumed_out = 32 * pos;
   return AFX_OK;
-}
+} catch (...) { return afx::exception_rc(); }
 
-extern "C" int afx_plaintexts_from_bytes(afx_ctx* ctx, const uint8_t* msgs, size_t count, uint8_t* M1, uint8_t* M2, uint8_t* m3, uint32_t* counters) {
+extern "C" int afx_plaintexts_from_bytes(afx_ctx* ctx, const uint8_t* msgs, size_t count, uint8_t* M1, uint8_t* M2, uint8_t* m3, uint32_t* counters) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !msgs || !M1 || !M2 || !m3) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -165,9 +165,9 @@ extern "C" int afx_plaintexts_from_bytes(afx_ctx* ctx, const uint8_t* msgs, size
   }
   if (!pending.empty()) { set_error("encode_to_group found no representative (the reference panics)"); return AFX_E_BAD_ARGS; }
   return AFX_OK;
-}
+} catch (...) { return afx::exception_rc(); }
 
-extern "C" int afx_keypairs_derive(afx_ctx* ctx, const uint8_t* master_secrets, size_t count, uint8_t* a, uint8_t* a0, uint8_t* a1, uint8_t* pk) {
+extern "C" int afx_keypairs_derive(afx_ctx* ctx, const uint8_t* master_secrets, size_t count, uint8_t* a, uint8_t* a0, uint8_t* a1, uint8_t* pk) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !master_secrets || !a || !a0 || !a1 || !pk) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -201,10 +201,10 @@ extern "C" int afx_keypairs_derive(afx_ctx* ctx, const uint8_t* master_secrets, 
   });
   if (rc) return rc;
   return sync_fetch(ctx, pk, st.dev(o_pk), 32 * count);
-}
+} catch (...) { return afx::exception_rc(); }
 
 extern "C" int afx_encrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8_t* M1, const uint8_t* M2, const uint8_t* m3, size_t count,
-                           uint8_t* E1, uint8_t* E2, uint8_t* status) {
+                           uint8_t* E1, uint8_t* E2, uint8_t* status) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !kp || !kp->a || !kp->a0 || !kp->a1 || !M1 || !M2 || !m3 || !E1 || !E2 || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -231,10 +231,10 @@ extern "C" int afx_encrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8
   AFX_HIP(hipMemcpyAsync(E1, st.dev(o_E1), row, hipMemcpyDeviceToHost, ctx->stream));
   AFX_HIP(hipMemcpyAsync(E2, st.dev(o_E2), row, hipMemcpyDeviceToHost, ctx->stream));
   return sync_fetch(ctx, status, st.dev(o_st), count);
-}
+} catch (...) { return afx::exception_rc(); }
 
 extern "C" int afx_decrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8_t* E1, const uint8_t* E2, size_t count, uint8_t* M1, uint8_t* M2,
-                           uint8_t* m3, uint8_t* messages, uint8_t* status) {
+                           uint8_t* m3, uint8_t* messages, uint8_t* status) try {
   std::unique_lock<std::recursive_mutex> lock__;
   if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (!ctx || !kp || !kp->a || !kp->a0 || !kp->a1 || !E1 || !E2 || !M1 || !M2 || !m3 || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -294,4 +294,4 @@ extern "C" int afx_decrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8
   for (size_t i = 0; i < count; i++)
     status[i] = (!bad1[i] && !bad2[i] && memcmp(e1p.data() + 32 * i, E1 + 32 * i, 32) == 0) ? AFX_ST_OK : AFX_ST_UNDECRYPTABLE;
   return AFX_OK;
-}
+} catch (...) { return afx::exception_rc(); }

@@ -43,6 +43,7 @@ extern "C" {
 #define AFX_E_NO_DEVICE (-3)   /* no usable HIP device / kernel image (there is no CPU fallback)  */
 #define AFX_E_HIP (-4)         /* a HIP runtime call failed; see afx_last_error()                 */
 #define AFX_E_NO_KEY (-5)      /* operation needs the issuer secret key but ctx has none          */
+#define AFX_E_NO_MEMORY (-6)   /* host allocation (or thread creation) failed inside the library    */
 
 /* per-item status == the reference's CredentialError outcome (src/errors.rs:73-89) */
 #define AFX_ST_OK 0
