@@ -430,7 +430,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     cl.njobs = (uint32_t)cjobs.size();
     cl.jobs_off = blob_alloc(sizeof(afx_compress_job) * cjobs.size(), 16);
     memcpy(blob_.data() + cl.jobs_off, cjobs.data(), sizeof(afx_compress_job) * cjobs.size());
-    cl.prefix_ws = (int32_t*)ws_alloc(sizeof(int32_t) * 10 * cjobs.size() * (size_t)count);
+    cl.prefix_ws = (int32_t*)ws_alloc(sizeof(int32_t) * 9 * cjobs.size() * (size_t)count);
     launches.push_back(cl);
   }
   max_digit_slots = std::max<size_t>(max_digit_slots, dslot);

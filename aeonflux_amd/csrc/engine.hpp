@@ -138,7 +138,7 @@ struct Launch {
   uint8_t fail_code = AFX_ST_VERIFICATION_FAILURE;
   size_t bytes = 0;         // L_COPY
   int odd = 0;              // L_MSM_TABLES: odd multiples (NAF terms) or multiples 0..8
-  int32_t* prefix_ws = nullptr;   // L_COMPRESS: scratch for the prefix products (njobs * 10 * count dwords)
+  int32_t* prefix_ws = nullptr;   // L_COMPRESS: scratch for the prefix products (njobs * 9 * count dwords)
 };
 
 // Builds one call's kernel launch list over a chunk of `count` items.

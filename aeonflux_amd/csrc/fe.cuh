@@ -1,40 +1,43 @@
 // GF(2^255-19) for gfx950, one field element per lane.
 //
-// Representation: 10 signed limbs, radix 2^25.5 (26,25,26,25,... bits).  Chosen by measurement
-// (profiles/r01_valu_rates_ubench.txt, at the 2 waves per SIMD the kernels run at): v_mad_i64_i32 issues at ~5.5 cycles
-// per wave-instruction, v_fma_f64 at ~5.1, plain 32-bit VOP2 ops at ~2.8, VOP3 forms and 64-bit shifts at ~4.7, so the
-// 100-mad schoolbook with 64-bit column accumulators and NO carry handling inside the accumulation beats every
-// fp64-split and saturated-limb variant priced against it.
-// One fe = 10 VGPRs.  Replaces, for the reference's call sites, what curve25519-dalek's
-// FieldElement [3P] does (e.g. under /root/reference/src/nizk/presentation.rs:342-351); only canonical
-// encodings are contractual.
+// Representation: 9 signed limbs of 29 bits (limb 8: 23 bits), value = sum v[i] * 2^(29 i).  One fe = 9 VGPRs.
+// Replaces, for the reference's call sites, what curve25519-dalek's FieldElement [3P] does (e.g. under
+// /root/reference/src/nizk/presentation.rs:342-351); only canonical encodings are contractual.
 //
-// The kernels built on this file are VALU-issue bound and their time is the sum of per-opcode issue costs
-// (profiles/r01_valu_rates_ubench.txt, profiles/r01_fe_rates_ubench.txt), so the code below is written against
-// that price list: 64-bit adds (v_lshl_add_u64, ~6.3 cycles) are avoided by feeding each column's carry into
-// the next column's mad chain as its addend.  Measured: fe_mul 753 cycles per wave-level operation (617 raw),
-// fe_sq 552 (488 raw; 56 mads + 40 other VALU instructions).
+// Why this form (tools/ubench/fe9_rates.hip, profiles/r02_fe9_rates.txt, against the 10 x 25.5-bit form of round 1,
+// tools/ubench/fe10_old.cuh): the kernels built on this file are bound by VALU issue, every VALU instruction costs about what a
+// v_mad_i64_i32 costs (profiles/r01_valu_rates_ubench.txt), so what counts is the number of instructions per product.  With a
+// uniform radix there are no doubled or 19-fold copies of the operands to prepare (14 instructions per product in the 25.5-bit
+// form): the product is 81 multiply-adds; its high columns 9..16 are accumulated on their own and folded into the low ones with
+// two multiply-adds each - 2^261 = 1216 (mod p) and 2^32 = 8 * 2^29, so column k+9 = hi * 2^32 + lo adds 1216 * lo to
+// column k and 9728 * hi to column k+1 - and the low columns run a sequential carry (the carry out of column k is the 64-bit
+// addend of column k+1's first multiply-add, so the chain needs no 64-bit additions).  Limb 8 is cut at 23 bits and what lies
+// above (weight 2^255 = 19) goes back to limb 0 with the last carry.  Measured: an addition's 8 products -9 %, a doubling's
+// 4 squarings + 3 products -4 %; a lone squaring +3 % (61 multiply-adds against 55).
 //
-// Bounds discipline (same as the classic 10-limb schedule): fe_sq and fe_mul's SECOND operand accept
-// limbs up to 1.65*2^26 (even) / 1.65*2^25 (odd) in magnitude (the 19x / 38x premultiplications must
-// fit int32); fe_mul's FIRST operand may be up to 4*2^26 / 4*2^25 (column sums stay < 2^63: worst
-// column = 124.5 * F * G * 2^52).  Results are within 1.01*2^25 / 1.01*2^24.
-// fe_add/fe_sub/fe_neg are limb-wise with no carry; at most one add/sub level of reduced operands
-// (or the documented three-term sums) may feed a multiplication.  fe_carry() re-normalises.
+// Bounds discipline, in units of 2^29 ("1 unit"; limb 8: 2^23).  A RAW result has limbs in [0, 1); a CENTRED one in
+// [-1/2, 1/2] (its rounding constants travel in the carries: 18 more additions, on the serial path).  fe_add/fe_sub/fe_neg
+// are limb-wise with no carry, so magnitudes add.  A product needs |f| * |g| <= 3.8 (column 7 holds 8 full products:
+// 8 * 3.8 * 2^58 plus the folds stays below 2^63), a squaring therefore |f| <= 1.9 (its doubled copy then fits int32).  ge.cuh states,
+// at each use, why the operands qualify; tests/test_device_arith_on_host.py runs the engine's chains on the host build of
+// this header with every column sum checked (AFX_CHECK_BOUNDS).  fe_carry() re-normalises to centred limbs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define AFX_DEV __device__ __forceinline__
+#define AFX_FE_LIMBS 9
+#define AFX_FE_MASK29 0x1fffffffu
+#define AFX_FE_MASK23 0x7fffffu
 
 struct fe {
-  int32_t v[10];
+  int32_t v[AFX_FE_LIMBS];
 };
 
 AFX_DEV fe fe_zero() {
   fe r;
 #pragma unroll
-  for (int i = 0; i < 10; i++) r.v[i] = 0;
+  for (int i = 0; i < AFX_FE_LIMBS; i++) r.v[i] = 0;
   return r;
 }
 AFX_DEV fe fe_one() {
@@ -45,61 +48,63 @@ AFX_DEV fe fe_one() {
 AFX_DEV fe fe_add(const fe& a, const fe& b) {
   fe r;
 #pragma unroll
-  for (int i = 0; i < 10; i++) r.v[i] = a.v[i] + b.v[i];
+  for (int i = 0; i < AFX_FE_LIMBS; i++) r.v[i] = a.v[i] + b.v[i];
   return r;
 }
 AFX_DEV fe fe_sub(const fe& a, const fe& b) {
   fe r;
 #pragma unroll
-  for (int i = 0; i < 10; i++) r.v[i] = a.v[i] - b.v[i];
+  for (int i = 0; i < AFX_FE_LIMBS; i++) r.v[i] = a.v[i] - b.v[i];
   return r;
 }
 AFX_DEV fe fe_neg(const fe& a) {
   fe r;
 #pragma unroll
-  for (int i = 0; i < 10; i++) r.v[i] = -a.v[i];
+  for (int i = 0; i < AFX_FE_LIMBS; i++) r.v[i] = -a.v[i];
+  return r;
+}
+// a - p, limb by limb (p = 2^255 - 19 has the limbs 2^29 - 19, 2^29 - 1 (x7), 2^23 - 1): the same field element, with the
+// limbs of a sum of two raw values, [0, 2), brought to (-1, 1)
+AFX_DEV fe fe_sub_p(const fe& a) {
+  fe r;
+  r.v[0] = a.v[0] - (int32_t)(AFX_FE_MASK29 - 18);
+#pragma unroll
+  for (int i = 1; i < 8; i++) r.v[i] = a.v[i] - (int32_t)AFX_FE_MASK29;
+  r.v[8] = a.v[8] - (int32_t)AFX_FE_MASK23;
   return r;
 }
 // f = b ? g : f
 AFX_DEV void fe_cmov(fe& f, const fe& g, bool b) {
 #pragma unroll
-  for (int i = 0; i < 10; i++) f.v[i] = b ? g.v[i] : f.v[i];
+  for (int i = 0; i < AFX_FE_LIMBS; i++) f.v[i] = b ? g.v[i] : f.v[i];
 }
 AFX_DEV void fe_cswap(fe& f, fe& g, bool b) {
 #pragma unroll
-  for (int i = 0; i < 10; i++) {
+  for (int i = 0; i < AFX_FE_LIMBS; i++) {
     int32_t x = f.v[i], y = g.v[i];
     f.v[i] = b ? y : x;
     g.v[i] = b ? x : y;
   }
 }
 
-// carry chain over 64-bit column sums -> reduced 32-bit limbs
-AFX_DEV fe fe_carry64(int64_t h[10]) {
+// carry chain over 64-bit limb values -> centred 32-bit limbs (|v[i]| <= 2^28, |v[8]| <= 2^22, v[1] a carry more)
+AFX_DEV fe fe_carry64(int64_t h[AFX_FE_LIMBS]) {
   int64_t c;
-  c = (h[0] + (1LL << 25)) >> 26; h[1] += c; h[0] -= c << 26;
-  c = (h[4] + (1LL << 25)) >> 26; h[5] += c; h[4] -= c << 26;
-  c = (h[1] + (1LL << 24)) >> 25; h[2] += c; h[1] -= c << 25;
-  c = (h[5] + (1LL << 24)) >> 25; h[6] += c; h[5] -= c << 25;
-  c = (h[2] + (1LL << 25)) >> 26; h[3] += c; h[2] -= c << 26;
-  c = (h[6] + (1LL << 25)) >> 26; h[7] += c; h[6] -= c << 26;
-  c = (h[3] + (1LL << 24)) >> 25; h[4] += c; h[3] -= c << 25;
-  c = (h[7] + (1LL << 24)) >> 25; h[8] += c; h[7] -= c << 25;
-  c = (h[4] + (1LL << 25)) >> 26; h[5] += c; h[4] -= c << 26;
-  c = (h[8] + (1LL << 25)) >> 26; h[9] += c; h[8] -= c << 26;
-  c = (h[9] + (1LL << 24)) >> 25; h[0] += c * 19; h[9] -= c << 25;
-  c = (h[0] + (1LL << 25)) >> 26; h[1] += c; h[0] -= c << 26;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c = (h[i] + (1LL << 28)) >> 29; h[i + 1] += c; h[i] -= c << 29; }
+  c = (h[8] + (1LL << 22)) >> 23; h[0] += c * 19; h[8] -= c << 23;
+  c = (h[0] + (1LL << 28)) >> 29; h[1] += c; h[0] -= c << 29;
   fe r;
 #pragma unroll
-  for (int i = 0; i < 10; i++) r.v[i] = (int32_t)h[i];
+  for (int i = 0; i < AFX_FE_LIMBS; i++) r.v[i] = (int32_t)h[i];
   return r;
 }
 
 // re-normalise a lazily added value (any limbs that fit int32)
 AFX_DEV fe fe_carry(const fe& f) {
-  int64_t h[10];
+  int64_t h[AFX_FE_LIMBS];
 #pragma unroll
-  for (int i = 0; i < 10; i++) h[i] = f.v[i];
+  for (int i = 0; i < AFX_FE_LIMBS; i++) h[i] = f.v[i];
   return fe_carry64(h);
 }
 
@@ -117,20 +122,34 @@ AFX_DEV fe fe_carry(const fe& f) {
 #ifdef AFX_CHECK_BOUNDS
 extern "C" void afx_bounds_violation(const char* what);
 static inline void afx_check_products(const int32_t* f, const int32_t* g, bool square) {
-  for (int i = 0; i < 10; i++) {
-    const int64_t ag = g[i] < 0 ? -(int64_t)g[i] : g[i], af = f[i] < 0 ? -(int64_t)f[i] : f[i];
-    // limb 0 is never a wrapped term's second factor: its 19-fold is computed but not consumed
-    if (i != 0 && ag * (square && (i & 1) ? 38 : 19) >= (1LL << 31)) afx_bounds_violation("19x/38x premultiplication overflows int32");
-    if (af * 2 >= (1LL << 31)) afx_bounds_violation("2x premultiplication overflows int32");
-  }
-  for (int k = 0; k < 10; k++) {
-    unsigned __int128 sum = 0;
-    for (int i = 0; i < 10; i++) {
-      const int j = (k - i + 10) % 10;
-      const unsigned __int128 af = f[i] < 0 ? -(int64_t)f[i] : f[i], ag = g[j] < 0 ? -(int64_t)g[j] : g[j];
-      sum += af * ag * (((i & 1) && (j & 1)) ? 2 : 1) * (i > k ? 19 : 1);
+  typedef __int128 i128;
+  if (square)
+    for (int i = 0; i < 9; i++) {
+      const int64_t af = f[i] < 0 ? -(int64_t)f[i] : f[i];
+      if (af * 2 >= (1LL << 31)) afx_bounds_violation("doubled limb of a squaring overflows int32");
     }
-    if (sum >= ((unsigned __int128)1 << 62)) afx_bounds_violation("column sum beyond 2^62");
+  // magnitudes, worst signs: high columns, then each low column with its own products, both folds and the carry
+  i128 hi[8];
+  for (int m = 0; m < 8; m++) {
+    i128 sum = 0;
+    for (int i = m + 1; i < 9; i++) {
+      const i128 af = f[i] < 0 ? -(i128)f[i] : f[i], ag = g[9 + m - i] < 0 ? -(i128)g[9 + m - i] : g[9 + m - i];
+      sum += af * ag;
+    }
+    if (sum >= ((i128)1 << 63) - ((i128)1 << 58)) afx_bounds_violation("high column sum beyond 2^63 - 2^58");
+    hi[m] = sum;
+  }
+  i128 carry = 0;
+  for (int k = 0; k < 9; k++) {
+    i128 sum = carry + ((i128)1 << 57);
+    for (int i = 0; i <= k; i++) {
+      const i128 af = f[i] < 0 ? -(i128)f[i] : f[i], ag = g[k - i] < 0 ? -(i128)g[k - i] : g[k - i];
+      sum += af * ag;
+    }
+    if (k < 8) sum += (i128)0xffffffffu * 1216;
+    if (k > 0) sum += ((hi[k - 1] >> 32) + 1) * 9728;
+    if (sum >= ((i128)1 << 63) - ((i128)1 << 58)) afx_bounds_violation("low column sum beyond 2^63 - 2^58");
+    carry = (sum >> (k < 8 ? 29 : 23)) + 1;
   }
 }
 #define AFX_CHECK_MUL(f, g) afx_check_products((f).v, (g).v, false)
@@ -146,104 +165,94 @@ extern thread_local uint64_t afx_n_mul, afx_n_sq;
 #define AFX_COUNT(x) ((void)0)
 #endif
 
-// Schoolbook product, columns in order 0..9: column k's mad chain starts from the carry out of column k-1 (the
-// mad's 64-bit addend), so the carry chain needs no 64-bit additions.  CENTRED: each carry arrives with the next
-// limb's rounding constant already in it (2^50 added to the high dword before the shift), which makes every limb
-// come out centred: r_k = (H_k mod 2^b) - 2^(b-1), |r_k| <= 2^(b-1).  Not CENTRED ("raw"): floor carries, limbs in
-// [0, 2^b): 18 fewer additions, for results whose consumer is known to tolerate twice the magnitude (below).
-// CMASK: bit k set = limb k comes out centred (its rounding constant travels in the carry of column k-1), clear = raw.
-template <uint32_t CMASK>
+// Low columns 0..8 of a product or a squaring, given its high columns: lowcol(k, H) adds column k's own products to H.
+// CENTRED: each carry arrives with the next limb's rounding constant already in it (2^57 added before the shift by 29;
+// 2^51 for limb 8), which makes every limb come out centred: r_k = (H_k mod 2^b) - 2^(b-1).  Not CENTRED ("raw"): floor
+// carries, limbs in [0, 2^b): 17 fewer additions, and none on the serial path (last multiply-add of column k -> shift ->
+// first multiply-add of column k+1).
+template <bool CENTRED, class LOW>
+AFX_DEV fe fe_reduce_columns(const int64_t (&hi)[8], LOW&& lowcol) {
+  fe r;
+  int64_t c = CENTRED ? (1LL << 28) : 0;  // rounding constant of limb 0; later carries arrive with the next limb's folded in
+  uint32_t u0 = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    int64_t H = lowcol(k, c);
+    if (k < 8) { H += (int64_t)((uint64_t)(uint32_t)hi[k] * 1216u); AFX_PIN(H); }        // column k+9, low dword
+    if (k > 0) { H += (int64_t)(int32_t)(hi[k - 1] >> 32) * 9728; AFX_PIN(H); }          // column k+8, high dword
+    if (k < 8) {
+      const uint32_t lo = (uint32_t)H & AFX_FE_MASK29;
+      if (k == 0) u0 = lo; else r.v[k] = CENTRED ? (int32_t)lo - (1 << 28) : (int32_t)lo;
+      c = CENTRED ? ((H + (k < 7 ? (1LL << 57) : (1LL << 51))) >> 29) : (H >> 29);
+    } else {
+      const uint32_t lo = (uint32_t)H & AFX_FE_MASK23;
+      r.v[8] = CENTRED ? (int32_t)lo - (1 << 22) : (int32_t)lo;
+      c = H >> 23;   // weight 2^255 = 19
+    }
+  }
+  // wrap: limb 0 gets 19 * (what lies above bit 255); u0 still holds limb 0 (with its rounding constant when centred)
+  int64_t H0 = (int64_t)u0 + c * 19;
+  const int32_t c0 = (int32_t)(H0 >> 29);
+  r.v[0] = CENTRED ? (int32_t)((uint32_t)H0 & AFX_FE_MASK29) - (1 << 28) : (int32_t)((uint32_t)H0 & AFX_FE_MASK29);
+  r.v[1] += c0;
+  return r;
+}
+template <bool CENTRED>
 AFX_DEV fe fe_mul_impl(const fe& f, const fe& g) {
   AFX_COUNT(afx_n_mul);
   AFX_CHECK_MUL(f, g);
-  int32_t g19[10], f2[10];
+  int64_t hi[8];
 #pragma unroll
-  for (int i = 0; i < 10; i++) {
-    g19[i] = (int32_t)(19u * (uint32_t)g.v[i]);
-    f2[i] = (int32_t)(2u * (uint32_t)f.v[i]);
+  for (int m = 0; m < 8; m++) {
+    int64_t H = 0;
+#pragma unroll
+    for (int i = m + 1; i < 9; i++) { H += (int64_t)f.v[i] * (int64_t)g.v[9 + m - i]; AFX_PIN(H); }
+    hi[m] = H;
   }
-  fe r;
-  int64_t c = (CMASK & 1u) ? (1LL << 25) : 0;  // rounding constant of limb 0; later carries arrive with the next limb's folded in
-  uint32_t u0 = 0;
+  return fe_reduce_columns<CENTRED>(hi, [&](int k, int64_t H) {
 #pragma unroll
-  for (int k = 0; k < 10; k++) {
-    int64_t H = c;
-#pragma unroll
-    for (int i = 0; i < 10; i++) {
-      const int j = (k - i + 10) % 10;
-      const bool wrap = i > k;
-      const int32_t a = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
-      const int32_t b = wrap ? g19[j] : g.v[j];
-      H += (int64_t)a * (int64_t)b;
-      AFX_PIN(H);
-    }
-    const int bits = (k & 1) ? 25 : 26;
-    const uint32_t lo = (uint32_t)H & ((1u << bits) - 1);
-    if (k == 0) u0 = lo; else r.v[k] = ((CMASK >> k) & 1u) ? (int32_t)lo - (1 << (bits - 1)) : (int32_t)lo;
-    c = (k < 9 && ((CMASK >> (k + 1)) & 1u)) ? ((H + (1LL << 50)) >> bits) : (H >> bits);
-  }
-  // wrap: limb 0 gets 19 * carry(limb 9); u0 still holds limb 0 (with its rounding constant when centred)
-  int64_t H0 = (int64_t)u0 + c * 19;
-  const int32_t c0 = (int32_t)(H0 >> 26);
-  r.v[0] = (CMASK & 1u) ? (int32_t)((uint32_t)H0 & 0x3ffffffu) - (1 << 25) : (int32_t)((uint32_t)H0 & 0x3ffffffu);
-  r.v[1] += c0;
-  return r;
+    for (int i = 0; i <= k; i++) { H += (int64_t)f.v[i] * (int64_t)g.v[k - i]; AFX_PIN(H); }
+    return H;
+  });
 }
-#define AFX_CENTRE_ALL 0x3ffu
-#define AFX_CENTRE_EVEN 0x154u   /* limbs 2, 4, 6, 8 */
-AFX_DEV fe fe_mul(const fe& f, const fe& g) { return fe_mul_impl<AFX_CENTRE_ALL>(f, g); }
-// Raw result: limbs in [0, 2^26) / [0, 2^25) ("1 unit" where a centred result is 1/2 unit).  Valid as either operand
-// of a multiplication or as the input of a squaring; sums of two raw values (2 units) only as a FIRST operand; a
-// difference of two raw values (+-1 unit) anywhere.  ge.cuh documents, at each use, why the consumer qualifies.
-AFX_DEV fe fe_mul_raw(const fe& f, const fe& g) { return fe_mul_impl<0u>(f, g); }
+AFX_DEV fe fe_mul(const fe& f, const fe& g) { return fe_mul_impl<true>(f, g); }
+// Raw result: limbs in [0, 1) instead of [-1/2, 1/2].  ge.cuh documents, at each use, why the consumer tolerates it.
+AFX_DEV fe fe_mul_raw(const fe& f, const fe& g) { return fe_mul_impl<false>(f, g); }
 
-// The same two flavours for the squaring (raw: the squaring chains of the inversions, and Z^2 of the doubling).
-template <uint32_t CMASK>
+// The same two flavours for the squaring: 45 products (cross terms from a doubled copy of the operand) + the 16 folds.
+template <bool CENTRED>
 AFX_DEV fe fe_sq_impl(const fe& f) {
   AFX_COUNT(afx_n_sq);
   AFX_CHECK_SQ(f);
-  int32_t f2[10], f19[10], f38[10];
+  int32_t f2[9];
 #pragma unroll
-  for (int i = 0; i < 10; i++) {
-    f2[i] = (int32_t)(2u * (uint32_t)f.v[i]);
-    f19[i] = (int32_t)(19u * (uint32_t)f.v[i]);
-    f38[i] = (int32_t)(38u * (uint32_t)f.v[i]);
-  }
-  fe r;
-  int64_t c = (CMASK & 1u) ? (1LL << 25) : 0;
-  uint32_t u0 = 0;
+  for (int i = 0; i < 9; i++) f2[i] = (int32_t)(2u * (uint32_t)f.v[i]);
+  int64_t hi[8];
 #pragma unroll
-  for (int k = 0; k < 10; k++) {
-    int64_t H = c;
+  for (int m = 0; m < 8; m++) {
+    int64_t H = 0;
 #pragma unroll
-    for (int i = 0; i < 10; i++) {
-      const int j = (k - i + 10) % 10;
+    for (int i = m + 1; i < 9; i++) {
+      const int j = 9 + m - i;
       if (j < i) continue;
-      const bool wrap = i + j >= 10;
-      const bool odd2 = (i & 1) && (j & 1);
-      const int32_t a = (i == j) ? f.v[i] : f2[i];
-      const int32_t b = wrap ? (odd2 ? f38[j] : f19[j]) : (odd2 ? f2[j] : f.v[j]);
-      H += (int64_t)a * (int64_t)b;
+      H += (int64_t)(i == j ? f.v[i] : f2[i]) * (int64_t)f.v[j];
       AFX_PIN(H);
     }
-    const int bits = (k & 1) ? 25 : 26;
-    const uint32_t lo = (uint32_t)H & ((1u << bits) - 1);
-    if (k == 0) u0 = lo; else r.v[k] = ((CMASK >> k) & 1u) ? (int32_t)lo - (1 << (bits - 1)) : (int32_t)lo;
-    c = (k < 9 && ((CMASK >> (k + 1)) & 1u)) ? ((H + (1LL << 50)) >> bits) : (H >> bits);
+    hi[m] = H;
   }
-  int64_t H0 = (int64_t)u0 + c * 19;
-  const int32_t c0 = (int32_t)(H0 >> 26);
-  r.v[0] = (CMASK & 1u) ? (int32_t)((uint32_t)H0 & 0x3ffffffu) - (1 << 25) : (int32_t)((uint32_t)H0 & 0x3ffffffu);
-  r.v[1] += c0;
-  return r;
+  return fe_reduce_columns<CENTRED>(hi, [&](int k, int64_t H) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) {
+      const int j = k - i;
+      if (j < i) continue;
+      H += (int64_t)(i == j ? f.v[i] : f2[i]) * (int64_t)f.v[j];
+      AFX_PIN(H);
+    }
+    return H;
+  });
 }
-AFX_DEV fe fe_sq(const fe& f) { return fe_sq_impl<AFX_CENTRE_ALL>(f); }
-AFX_DEV fe fe_sq_raw(const fe& f) { return fe_sq_impl<0u>(f); }
-// Only the limbs whose 19-fold must fit int32 when the value is a SECOND operand - the even limbs 2, 4, 6, 8 (limb 0 is
-// never premultiplied, odd limbs have a bit to spare) - come out centred.  For values that are combined with one or
-// two others of their kind and then used as a second operand, never squared: XX, YY and (Y-X)^2 of the doubling, which
-// meet in X3 = (YY + XX) - (Y-X)^2 and Z3 = YY - XX.
-AFX_DEV fe fe_sq_even(const fe& f) { return fe_sq_impl<AFX_CENTRE_EVEN>(f); }
+AFX_DEV fe fe_sq(const fe& f) { return fe_sq_impl<true>(f); }
+AFX_DEV fe fe_sq_raw(const fe& f) { return fe_sq_impl<false>(f); }
 
 // f^(2^n), n >= 1, rolled loop (keeps the inversion chains small in code size); every consumer multiplies the result
 AFX_DEV fe fe_sqn(fe f, int n) {
@@ -252,65 +261,45 @@ AFX_DEV fe fe_sqn(fe f, int n) {
   return f;
 }
 
-// multiply by a small constant limb-set given as a reduced fe in constant memory: just fe_mul.
-
-// Load from 8 little-endian dwords, ignoring bit 255 (dalek FieldElement::from_bytes).
-// Limbs come out unsigned (< 2^26 / 2^25): inside fe_mul's input bounds, no carry needed.
+// Load from 8 little-endian dwords, ignoring bit 255 (dalek FieldElement::from_bytes).  Limbs come out raw.
 AFX_DEV fe fe_frombytes(const uint32_t w[8]) {
   fe r;
-  const uint64_t w01 = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-  const uint64_t w12 = (uint64_t)w[1] | ((uint64_t)w[2] << 32);
-  const uint64_t w23 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
-  const uint64_t w34 = (uint64_t)w[3] | ((uint64_t)w[4] << 32);
-  const uint64_t w45 = (uint64_t)w[4] | ((uint64_t)w[5] << 32);
-  const uint64_t w56 = (uint64_t)w[5] | ((uint64_t)w[6] << 32);
-  const uint64_t w67 = (uint64_t)w[6] | ((uint64_t)w[7] << 32);
-  r.v[0] = (int32_t)(w01 & 0x3ffffff);                 // bits   0.. 25
-  r.v[1] = (int32_t)((w01 >> 26) & 0x1ffffff);         // bits  26.. 50
-  r.v[2] = (int32_t)((w12 >> 19) & 0x3ffffff);         // bits  51.. 76   (51-32 = 19)
-  r.v[3] = (int32_t)((w23 >> 13) & 0x1ffffff);         // bits  77..101   (77-64 = 13)
-  r.v[4] = (int32_t)((w34 >> 6) & 0x3ffffff);          // bits 102..127   (102-96 = 6)
-  r.v[5] = (int32_t)(w45 & 0x1ffffff);                 // bits 128..152
-  r.v[6] = (int32_t)((w45 >> 25) & 0x3ffffff);         // bits 153..178
-  r.v[7] = (int32_t)((w56 >> 19) & 0x1ffffff);         // bits 179..203   (179-160 = 19)
-  r.v[8] = (int32_t)((w67 >> 12) & 0x3ffffff);         // bits 204..229   (204-192 = 12)
-  r.v[9] = (int32_t)((w[7] >> 6) & 0x1ffffff);         // bits 230..254   (230-224 = 6), bit 255 dropped
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int o = 29 * i, k = o >> 5, sh = o & 31;
+    uint64_t x = w[k];
+    if (sh + 29 > 32 && k + 1 < 8) x |= (uint64_t)w[k + 1] << 32;
+    r.v[i] = (int32_t)((uint32_t)(x >> sh) & (i < 8 ? AFX_FE_MASK29 : AFX_FE_MASK23));   // limb 8: bits 232..254
+  }
   return r;
 }
 
 // Canonical little-endian encoding into 8 dwords.  Input: any limbs fe_carry accepts.
 AFX_DEV void fe_tobytes(uint32_t w[8], const fe& f) {
   fe t = fe_carry(f);
-  int32_t h0 = t.v[0], h1 = t.v[1], h2 = t.v[2], h3 = t.v[3], h4 = t.v[4];
-  int32_t h5 = t.v[5], h6 = t.v[6], h7 = t.v[7], h8 = t.v[8], h9 = t.v[9];
-  int32_t q = (19 * h9 + (1 << 24)) >> 25;
-  q = (h0 + q) >> 26; q = (h1 + q) >> 25; q = (h2 + q) >> 26; q = (h3 + q) >> 25; q = (h4 + q) >> 26;
-  q = (h5 + q) >> 25; q = (h6 + q) >> 26; q = (h7 + q) >> 25; q = (h8 + q) >> 26; q = (h9 + q) >> 25;
-  h0 += 19 * q;
+  int32_t h[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) h[i] = t.v[i];
+  // q = floor(value / p), -1 or 0 for the centred limbs fe_carry leaves (|value| < 2^254 * 1.01), by the classic estimate:
+  // floor(h / p) = floor((h + 19 h / 2^255 + 1/2) / 2^255), with 19 h / 2^255 taken from the top limb and rounded
+  int32_t q = (19 * h[8] + (1 << 22)) >> 23;
+#pragma unroll
+  for (int i = 0; i < 8; i++) q = (h[i] + q) >> 29;
+  q = (h[8] + q) >> 23;
+  h[0] += 19 * q;
   int32_t c;
-  c = h0 >> 26; h1 += c; h0 -= c << 26;
-  c = h1 >> 25; h2 += c; h1 -= c << 25;
-  c = h2 >> 26; h3 += c; h2 -= c << 26;
-  c = h3 >> 25; h4 += c; h3 -= c << 25;
-  c = h4 >> 26; h5 += c; h4 -= c << 26;
-  c = h5 >> 25; h6 += c; h5 -= c << 25;
-  c = h6 >> 26; h7 += c; h6 -= c << 26;
-  c = h7 >> 25; h8 += c; h7 -= c << 25;
-  c = h8 >> 26; h9 += c; h8 -= c << 26;
-  c = h9 >> 25; h9 -= c << 25;
-  // all limbs now in [0, 2^26) / [0, 2^25): pack at bit offsets 0,26,51,77,102,128,153,179,204,230
-  const uint64_t a = (uint64_t)(uint32_t)h0 | ((uint64_t)(uint32_t)h1 << 26) | ((uint64_t)(uint32_t)h2 << 51);  // bits 0..76 (overflowing part dropped)
-  w[0] = (uint32_t)a;
-  w[1] = (uint32_t)(a >> 32);
-  const uint64_t b = ((uint64_t)(uint32_t)h2 >> 13) | ((uint64_t)(uint32_t)h3 << 13) | ((uint64_t)(uint32_t)h4 << 38);  // bits 64..127
-  w[2] = (uint32_t)b;
-  w[3] = (uint32_t)(b >> 32);
-  const uint64_t d = (uint64_t)(uint32_t)h5 | ((uint64_t)(uint32_t)h6 << 25) | ((uint64_t)(uint32_t)h7 << 51);  // bits 128..191
-  w[4] = (uint32_t)d;
-  w[5] = (uint32_t)(d >> 32);
-  const uint64_t e = ((uint64_t)(uint32_t)h7 >> 13) | ((uint64_t)(uint32_t)h8 << 12) | ((uint64_t)(uint32_t)h9 << 38);  // bits 192..255
-  w[6] = (uint32_t)e;
-  w[7] = (uint32_t)(e >> 32);
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c = h[i] >> 29; h[i + 1] += c; h[i] -= c << 29; }
+  c = h[8] >> 23; h[8] -= c << 23;   // the dropped carry is q * 2^255: the output is value - q * p, in [0, p)
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    // dword k = bits 32k .. 32k+31: from limb i0 = floor(32k / 29) onwards
+    const int i0 = (32 * k) / 29, sh = 32 * k - 29 * i0;
+    uint64_t x = (uint64_t)(uint32_t)h[i0] >> sh;
+    if (i0 + 1 < 9) x |= (uint64_t)(uint32_t)h[i0 + 1] << (29 - sh);
+    if (58 - sh < 32 && i0 + 2 < 9) x |= (uint64_t)(uint32_t)h[i0 + 2] << (58 - sh);
+    w[k] = (uint32_t)x;
+  }
 }
 
 AFX_DEV bool fe_is_negative(const fe& f) {
@@ -327,7 +316,7 @@ AFX_DEV bool fe_eq(const fe& f, const fe& g) { return fe_is_zero(fe_sub(f, g)); 
 AFX_DEV fe fe_cneg(const fe& f, bool b) {
   fe r;
 #pragma unroll
-  for (int i = 0; i < 10; i++) r.v[i] = b ? -f.v[i] : f.v[i];
+  for (int i = 0; i < AFX_FE_LIMBS; i++) r.v[i] = b ? -f.v[i] : f.v[i];
   return r;
 }
 AFX_DEV fe fe_abs(const fe& f) { return fe_cneg(f, fe_is_negative(f)); }

@@ -13,7 +13,7 @@
 AFX_DEV fe fe_const(const int32_t* c) {
   fe r;
 #pragma unroll
-  for (int i = 0; i < 10; i++) r.v[i] = c[i];
+  for (int i = 0; i < AFX_FE_LIMBS; i++) r.v[i] = c[i];
   return r;
 }
 
@@ -46,26 +46,26 @@ AFX_DEV ge_niels ge_niels_from_affine(const fe& x, const fe& y) {
   r.ypx = fe_mul(fe_add(y, x), inv2); r.ymx = fe_mul(fe_sub(y, x), inv2); r.xyd = fe_mul(fe_mul(x, y), fe_const(FEC_D));
   return r;
 }
+// The completed point's bounds (units of fe.cuh: centred 1/2, raw 1; a product needs |f| * |g| <= 3.8, a squaring |f| <= 1.9),
+// for every producer in this file:  ge_p2_dbl  |X| < 1.5, |Y| < 1, |Z| < 1, |T| < 2;   ge_add_cached / ge_madd  |X| < 1,
+// 0 <= Y < 2, |Z| < 1, 0 <= T < 2.  The four products T*X, Y*Z, T*Z, Y*X therefore stay within 3.
 AFX_DEV ge_p2 ge_p1p1_to_p2(const ge_p1p1& p) {
   ge_p2 r;
-  // p.T may be four reduced terms deep (ge_p2_dbl): keep it in fe_mul's wide first operand
   r.X = fe_mul(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul(p.T, p.Z);
   return r;
 }
 AFX_DEV ge_p3 ge_p1p1_to_p3(const ge_p1p1& p) {
   ge_p3 r;
-  r.X = fe_mul(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul(p.T, p.Z); r.T = fe_mul(p.Y, p.X);   // Y (up to 2 units) must be a first operand; X and Z are the second operands
+  r.X = fe_mul(p.T, p.X); r.Y = fe_mul(p.Y, p.Z); r.Z = fe_mul(p.T, p.Z); r.T = fe_mul(p.Y, p.X);
   return r;
 }
-// Conversions inside a doubling/addition chain, where the consumer of every coordinate is known (units: a centred
-// product is 1/2, a raw one 1; fe_mul takes <= 4 as first and <= 1.65 as second operand, fe_sq <= 1.65):
-//   GE_FOR_DBL   before a doubling (ge_p2_dbl): X, Y, Z raw - they are squared, and so is Y - X (1 unit); T not computed.
-//   GE_FOR_ADD   before an addition (ge_add_cached, ge_madd): X, Y, Z, T raw - Y+-X (2 units) and Z are first
-//                operands, T (1 unit) is a second operand; Z3 is formed as a difference of two raw products.
+// Conversions inside a doubling/addition chain, where the consumer of every coordinate is known:
+//   GE_FOR_DBL   before a doubling (ge_p2_dbl): X, Y, Z raw - they are squared, and so is Y - X (within 1 unit); T not computed.
+//   GE_FOR_ADD   before an addition (ge_add_cached, ge_madd): X, Y, Z, T raw - Y + X (2 units), Y - X, Z and T (1 unit) each meet
+//                a table entry of 1 unit.
 //   GE_FOR_ANY   everything centred (stores, encodings, table building, any other consumer).
-// The completed point's own bounds hold for every producer in this file: |X| <= 1.5, |Y| <= 2, |Z| <= 1.5, |T| <= 3,
-// so X and Z are the second operands of the four products and Y, T the first.  tests/test_device_arith_on_host.py
-// runs chains of these steps on the host build with every operand bound asserted (AFX_CHECK_BOUNDS).
+// tests/test_device_arith_on_host.py runs chains of these steps on the host build with every column sum checked
+// (AFX_CHECK_BOUNDS).
 enum { GE_FOR_DBL = 0, GE_FOR_ADD = 1, GE_FOR_ANY = 3 };
 template <int NEXT>
 AFX_DEV ge_p3 ge_p1p1_to_p3_for(const ge_p1p1& p) {
@@ -95,6 +95,7 @@ AFX_DEV ge_p2 ge_p3_to_p2(const ge_p3& p) {
   r.X = p.X; r.Y = p.Y; r.Z = p.Z;
   return r;
 }
+// p: centred coordinates (then Y+X, Y-X and 2Z are within 1 unit, what ge_add_cached expects of an entry)
 AFX_DEV ge_cached ge_p3_to_cached(const ge_p3& p) {
   ge_cached r;
   r.YpX = fe_add(p.Y, p.X); r.YmX = fe_sub(p.Y, p.X); r.Z2 = fe_add(p.Z, p.Z); r.T2d = fe_mul(p.T, fe_const(FEC_D2));
@@ -109,15 +110,15 @@ AFX_DEV ge_cached ge_p3_to_cached_reduced(const ge_p3& p) {
 AFX_DEV ge_p1p1 ge_p2_dbl(const ge_p2& p) {
   ge_p1p1 r;
   // 2XY is taken from (Y - X)^2 = XX + YY - 2XY rather than from (X + Y)^2: the difference of two raw coordinates is
-  // within 1 unit, so X and Y may both be raw when they come here (their sum would not be a valid squaring input).
-  // Z^2 uncentred: it only reaches T = 2ZZ - (YY - XX), which is fe_mul's wide first operand in both conversions.
-  // XX, YY, (Y-X)^2 centred on the even limbs only: they reach X3 = (YY + XX) - (Y-X)^2 and Z3 = YY - XX, second
-  // operands that are never squared (fe.cuh, fe_sq_even).
-  fe XX = fe_sq_even(p.X), YY = fe_sq_even(p.Y), ZZ = fe_sq_raw(p.Z);
-  fe B = fe_add(ZZ, ZZ);
+  // within 1 unit, so X and Y may both be raw when they come here (their sum would be no valid squaring input).
+  // XX, YY, ZZ raw (their rounding would sit on the squarings' serial path); the two sums of raw values, YY + XX and 2 ZZ
+  // (limbs in [0, 2)), are brought to (-1, 1) by subtracting p limb by limb, which costs nine additions off that path;
+  // only (Y-X)^2 is centred.  Then |Y3| < 1, |Z3| < 1, |X3| = |Y3 - AA| < 1.5, |T3| = |2ZZ - p - Z3| < 2.
+  fe XX = fe_sq_raw(p.X), YY = fe_sq_raw(p.Y), ZZ = fe_sq_raw(p.Z);
+  fe B = fe_sub_p(fe_add(ZZ, ZZ));
   fe A = fe_sub(p.Y, p.X);
-  fe AA = fe_sq_even(A);
-  r.Y = fe_add(YY, XX);
+  fe AA = fe_sq(A);
+  r.Y = fe_sub_p(fe_add(YY, XX));
   r.Z = fe_sub(YY, XX);
   r.X = fe_sub(r.Y, AA);
   r.T = fe_sub(B, r.Z);
@@ -128,11 +129,11 @@ AFX_DEV ge_p1p1 ge_add_cached(const ge_p3& p, const ge_cached& q, bool neg) {
   ge_p1p1 r;
   fe qp = q.YpX, qm = q.YmX;
   fe_cswap(qp, qm, neg);
-  // A, B raw: they only meet in X3 = A - B (+-1 unit, a second operand) and Y3 = A + B (2 units, a first operand)
+  // A, B raw: they only meet in X3 = A - B (within 1 unit) and Y3 = A + B (2 units)
   fe A = fe_mul_raw(fe_add(p.Y, p.X), qp);
   fe B = fe_mul_raw(fe_sub(p.Y, p.X), qm);
   // C' = -(2dT2) T1 (the sign flipped again when subtracting), raw: Z3 = D + C = D - C' is then a difference of raw
-  // values (+-1 unit, a second operand) and T3 = D - C = D + C' a sum (2 units, a first operand)
+  // values (within 1 unit) and T3 = D - C = D + C' a sum (2 units)
   fe Cn = fe_mul_raw(fe_cneg(q.T2d, !neg), p.T);
   fe D = fe_mul_raw(p.Z, q.Z2);   // 2 Z1 Z2
   r.X = fe_sub(A, B);

@@ -46,7 +46,7 @@ AFX_DEV sc sc_load_item(const uint8_t* arr, uint32_t stride, uint32_t item) {
 AFX_DEV fe fe_load_soa(const int32_t* base, uint32_t c, uint32_t count, uint32_t item) {
   fe r;
 #pragma unroll
-  for (int l = 0; l < 10; l++) r.v[l] = base[(size_t)(c * 10 + l) * count + item];
+  for (int l = 0; l < AFX_FE_LIMBS; l++) r.v[l] = base[(size_t)(c * AFX_FE_LIMBS + l) * count + item];
   return r;
 }
 AFX_DEV ge_p3 var_load(const int32_t* base, uint32_t count, uint32_t item) {
@@ -59,7 +59,7 @@ AFX_DEV ge_p3 var_load(const int32_t* base, uint32_t count, uint32_t item) {
 }
 AFX_DEV void fe_store_soa(int32_t* base, uint32_t c, uint32_t count, uint32_t item, const fe& f) {
 #pragma unroll
-  for (int l = 0; l < 10; l++) base[(size_t)(c * 10 + l) * count + item] = f.v[l];
+  for (int l = 0; l < AFX_FE_LIMBS; l++) base[(size_t)(c * AFX_FE_LIMBS + l) * count + item] = f.v[l];
 }
 AFX_DEV void var_store(int32_t* base, uint32_t count, uint32_t item, const ge_p3& p) {
   fe_store_soa(base, 0, count, item, p.X);
@@ -67,14 +67,14 @@ AFX_DEV void var_store(int32_t* base, uint32_t count, uint32_t item, const ge_p3
   fe_store_soa(base, 2, count, item, p.Z);
   fe_store_soa(base, 3, count, item, p.T);
 }
-AFX_DEV ge_p3 p3_load_uniform(const int32_t* c40) {
+AFX_DEV ge_p3 p3_load_uniform(const int32_t* c36) {
   ge_p3 p;
 #pragma unroll
-  for (int l = 0; l < 10; l++) { p.X.v[l] = c40[l]; p.Y.v[l] = c40[10 + l]; p.Z.v[l] = c40[20 + l]; p.T.v[l] = c40[30 + l]; }
+  for (int l = 0; l < AFX_FE_LIMBS; l++) { p.X.v[l] = c36[l]; p.Y.v[l] = c36[9 + l]; p.Z.v[l] = c36[18 + l]; p.T.v[l] = c36[27 + l]; }
   return p;
 }
 // one window-table entry (cached form): four field elements in canonical 32-byte form, 128 contiguous bytes,
-// 16-byte aligned = exactly two 64-byte HBM sectors per gather (the 40-limb form straddled 3.5 on average)
+// 16-byte aligned = exactly two 64-byte HBM sectors per gather (the limb form straddled 3.5 on average)
 // `chunk` = dwords between the entry's consecutive 16-byte pieces: 4 (the 128 bytes contiguous: a lane's own entry of an
 // item-major table) or 4 * count (piece-major: the entries of neighbouring items interleaved piece by piece, so that each of the
 // eight loads of a wave that reads ONE entry index - a NAF table - is 1 KB contiguous instead of 64 pieces 128 bytes apart)
@@ -117,7 +117,7 @@ __global__ void k_setup_generators(const uint8_t* __restrict__ enc, uint32_t nge
   if (!good) P = ge_identity();
   int32_t* e = ext + (size_t)g * AFX_VAR_DWORDS;
 #pragma unroll
-  for (int l = 0; l < 10; l++) { e[l] = P.X.v[l]; e[10 + l] = P.Y.v[l]; e[20 + l] = P.Z.v[l]; e[30 + l] = P.T.v[l]; }
+  for (int l = 0; l < AFX_FE_LIMBS; l++) { e[l] = P.X.v[l]; e[9 + l] = P.Y.v[l]; e[18 + l] = P.Z.v[l]; e[27 + l] = P.T.v[l]; }
   uint32_t nw[8];
   ristretto_encode(nw, ge_neg(P));
   enc_store(neg_enc, g, nw);
@@ -136,7 +136,7 @@ __global__ void k_setup_posbase(const int32_t* __restrict__ ext, uint32_t ngen, 
   for (uint32_t k = 0; k < AFX_POS_BITS * j; k++) P = ge_double(P);
   int32_t* e = base + (size_t)t * AFX_VAR_DWORDS;
 #pragma unroll
-  for (int l = 0; l < 10; l++) { e[l] = P.X.v[l]; e[10 + l] = P.Y.v[l]; e[20 + l] = P.Z.v[l]; e[30 + l] = P.T.v[l]; }
+  for (int l = 0; l < AFX_FE_LIMBS; l++) { e[l] = P.X.v[l]; e[9 + l] = P.Y.v[l]; e[18 + l] = P.Z.v[l]; e[27 + l] = P.T.v[l]; }
 }
 #define AFX_POS_CHUNK 16
 #define AFX_POS_CHUNKS ((AFX_POS_ENTRIES + AFX_POS_CHUNK - 1) / AFX_POS_CHUNK)
@@ -176,7 +176,8 @@ __global__ void k_setup_postables(const int32_t* __restrict__ base, uint32_t nge
     const ge_niels q = ge_niels_from_affine(fe_mul(X[k], zinv), fe_mul(Y[k], zinv));
     int32_t* e = tab + (size_t)(first + k) * AFX_NIELS_DWORDS;
 #pragma unroll
-    for (int l = 0; l < 10; l++) { e[l] = q.ypx.v[l]; e[10 + l] = q.ymx.v[l]; e[20 + l] = q.xyd.v[l]; }
+    for (int l = 0; l < AFX_FE_LIMBS; l++) { e[l] = q.ypx.v[l]; e[9 + l] = q.ymx.v[l]; e[18 + l] = q.xyd.v[l]; }
+    e[27] = 0;
   }
 }
 
@@ -314,14 +315,14 @@ AFX_DEV ge_p3 msm_add_positional(const msm_env& e, const int32_t* __restrict__ p
   const int d = (int)((uint32_t)(w >> sh) & ((1u << AFX_POS_BITS) - 1)) - (1 << (AFX_POS_BITS - 1));
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
   const bool neg = (d < 0) != (e.job->term[t].negate != 0);
-  const int2* p = reinterpret_cast<const int2*>(pos_tables + (size_t)e.job->term[t].fixed_idx * AFX_POS_TABLE_DWORDS +
+  const int4* p = reinterpret_cast<const int4*>(pos_tables + (size_t)e.job->term[t].fixed_idx * AFX_POS_TABLE_DWORDS +
                                                 (size_t)j * AFX_POS_WINDOW_DWORDS + idx * AFX_NIELS_DWORDS);
-  int32_t v[30];
+  int32_t v[AFX_NIELS_DWORDS];   // 7 x 16 bytes: 27 limbs + padding
 #pragma unroll
-  for (int l = 0; l < 15; l++) { const int2 x = p[l]; v[2 * l] = x.x; v[2 * l + 1] = x.y; }
+  for (int l = 0; l < AFX_NIELS_DWORDS / 4; l++) { const int4 x = p[l]; v[4 * l] = x.x; v[4 * l + 1] = x.y; v[4 * l + 2] = x.z; v[4 * l + 3] = x.w; }
   ge_niels q;
 #pragma unroll
-  for (int l = 0; l < 10; l++) { q.ypx.v[l] = v[l]; q.ymx.v[l] = v[10 + l]; q.xyd.v[l] = v[20 + l]; }
+  for (int l = 0; l < AFX_FE_LIMBS; l++) { q.ypx.v[l] = v[l]; q.ymx.v[l] = v[9 + l]; q.xyd.v[l] = v[18 + l]; }
   return ge_p1p1_to_p3_next(ge_madd(acc, q, neg), next);
 }
 
@@ -423,6 +424,8 @@ k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table
   else msm_build_table<false>(slot + (size_t)item * AFX_VAR_TABLE_DWORDS, AFX_TABLE_ENTRY_DWORDS, 4, P);
 }
 
+// Two blocks per CU: three (168 registers) were measured too - the windowed chain 1.3 % faster, the step 0.8 %, for 76 bytes of
+// scratch per lane in the encoding epilogue; not taken.
 template <int KIND>
 __global__ void __launch_bounds__(AFX_BLOCK, 2)
 k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tables, int32_t* __restrict__ table_ws,
@@ -523,7 +526,7 @@ k_compress2x(const afx_compress_job* __restrict__ jobs, uint32_t njobs, int32_t*
 #pragma unroll 1
   for (uint32_t j = 0; j < njobs; j++) {
     const c2x_state s = c2x_from(var_load(jobs[j].var, count, item));
-    fe_store_soa(prefix_ws + (size_t)j * 10 * count, 0, count, item, prod);   // product of the factors before j
+    fe_store_soa(prefix_ws + (size_t)j * AFX_FE_LIMBS * count, 0, count, item, prod);   // product of the factors before j
     prod = fe_mul(prod, s.efgh);
   }
   fe inv = fe_invert(prod);
@@ -531,7 +534,7 @@ k_compress2x(const afx_compress_job* __restrict__ jobs, uint32_t njobs, int32_t*
   for (uint32_t jj = njobs; jj > 0; jj--) {
     const uint32_t j = jj - 1;
     const c2x_state s = c2x_from(var_load(jobs[j].var, count, item));
-    const fe inv_j = fe_mul(inv, fe_load_soa(prefix_ws + (size_t)j * 10 * count, 0, count, item));   // 1 / (e f g h)_j
+    const fe inv_j = fe_mul(inv, fe_load_soa(prefix_ws + (size_t)j * AFX_FE_LIMBS * count, 0, count, item));   // 1 / (e f g h)_j
     inv = fe_mul(inv, s.efgh);
     uint32_t w[8];
     c2x_finish(w, s, inv_j);

@@ -17,11 +17,11 @@
 #endif
 #define AFX_POS_WINDOWS ((253 + AFX_POS_BITS - 1) / AFX_POS_BITS)
 #define AFX_POS_ENTRIES ((1 << (AFX_POS_BITS - 1)) + 1)
-#define AFX_POS_WINDOW_DWORDS ((AFX_POS_ENTRIES * 30 + 3) & ~3)   /* 16-byte multiple */
+#define AFX_POS_WINDOW_DWORDS ((AFX_POS_ENTRIES * AFX_NIELS_DWORDS + 3) & ~3)   /* 16-byte multiple */
 #define AFX_POS_TABLE_DWORDS (AFX_POS_WINDOWS * AFX_POS_WINDOW_DWORDS)
 #define AFX_DIGIT_WORDS 9              /* recoded scalar: up to 260 bits (253 + one window of bias) */
-#define AFX_VAR_DWORDS 40              /* extended point: X,Y,Z,T x 10 limbs */
-#define AFX_NIELS_DWORDS 30            /* affine niels: y+x, y-x, 2dxy */
+#define AFX_VAR_DWORDS 36              /* extended point: X,Y,Z,T x 9 limbs */
+#define AFX_NIELS_DWORDS 28            /* affine niels: (y+x)/2, (y-x)/2, dxy x 9 limbs + 1 dword of padding = 7 x 16 bytes */
 #define AFX_TABLE_ENTRY_DWORDS 32       /* a window-table entry: 4 field elements as canonical 256-bit words = 128 B = 2 HBM sectors */
 #define AFX_VAR_TABLE_DWORDS (AFX_TABLE_STORED * AFX_TABLE_ENTRY_DWORDS)
 #define AFX_BLOCK 256
@@ -39,7 +39,7 @@
 #define AFX_BAD_CHALLENGE 8u
 #define AFX_BAD_SHAPE 16u
 
-/* variable point storage: struct-of-arrays, limb (c*10+l) of item i at base[(c*10+l)*count + i] */
+/* variable point storage: struct-of-arrays, limb (c*9+l) of item i at base[(c*9+l)*count + i] */
 typedef int32_t* afx_var_t;
 
 typedef struct {
@@ -52,11 +52,11 @@ typedef struct {
   const uint8_t* sc;       /* [count][32] scalar array to test for canonicity */
 } afx_sccheck_job;
 
-/* out = sa*A + sb*B, sa,sb in {-1,0,+1}; B may be a batch constant (extended coords, 40 dwords) */
+/* out = sa*A + sb*B, sa,sb in {-1,0,+1}; B may be a batch constant (extended coords, AFX_VAR_DWORDS dwords) */
 typedef struct {
   const int32_t* a;        /* var (SoA)                           */
   const int32_t* b;        /* var (SoA), or null                  */
-  const int32_t* b_const;  /* 40 dwords uniform, or null          */
+  const int32_t* b_const;  /* AFX_VAR_DWORDS uniform, or null     */
   int32_t sa, sb;
   afx_var_t out;           /* may be null                         */
   uint8_t* out_enc;        /* [count][32] compressed, may be null */

@@ -392,18 +392,20 @@ MAD_SUSTAINED_T = 32.2                                  # what a pure multiply-a
 
 
 NOMINAL_MHZ = 2400.0
+MADS_PER_MUL, MADS_PER_SQ = 98, 62
 
 
 def valu_side(ctx, items_per_step, field_kernel_ms_per_step):
     """compute-side figure beside the HBM roofline: 32x32->64-bit multiply-adds of the field arithmetic per second.
-    Counts come from the engine's own plan of the last call (afx_ctx_get_plan_stats); a field multiplication is
-    100 v_mad_i64_i32, a squaring 55 (aeonflux_amd/csrc/fe.cuh)."""
+    Counts come from the engine's own plan of the last call (afx_ctx_get_plan_stats); a field multiplication issues 98
+    multiply-adds (81 products, 16 to fold the high columns, 1 for the wrap), a squaring 62 (45 + 16 + 1): 9 x 29-bit limbs,
+    aeonflux_amd/csrc/fe.cuh."""
     st = ctx.plan_stats()
-    mads = 100 * st["field_mul"] + 55 * st["field_sq"]
+    mads = MADS_PER_MUL * st["field_mul"] + MADS_PER_SQ * st["field_sq"]
     achieved = mads * items_per_step / (field_kernel_ms_per_step / 1e3) / 1e12 if field_kernel_ms_per_step > 0 else 0.0
     mhz = ctx.core_clock_mhz()   # measured inside the timed k_msm_window launches (shader-clock counter / 100 MHz counter)
     at_clock = MAD_PEAK_T * mhz / NOMINAL_MHZ if mhz > 0 else None
-    return {"unit": "T multiply-adds/s (v_mad_i64_i32)", "achieved": achieved, "peak": MAD_PEAK_T, "frac": achieved / MAD_PEAK_T,
+    return {"unit": "T multiply-adds/s (v_mad_i64_i32 / v_mad_u64_u32)", "achieved": achieved, "peak": MAD_PEAK_T, "frac": achieved / MAD_PEAK_T,
             "core_clock_mhz_measured": mhz, "peak_at_measured_clock": at_clock, "frac_at_measured_clock": (achieved / at_clock) if at_clock else None,
             "clock_note": "peak is at the nominal 2400 MHz; the kernels run at the socket power cap, below it",
             "peak_source": "tools/ubench/mad_sustained.hip on this GPU (no published figure): %.2f cycles per wave-instruction" % MAD_CYCLES,

@@ -19,14 +19,15 @@ static sc sc_from(const uint8_t* p) { sc s; memcpy(s.v, p, 32); return s; }
 extern "C" {
 
 uint64_t arith_bounds_violations(void) { return n_violations; }
-// self-test of the checker: a second operand of three reduced terms' magnitude times two must trip it; returns the
-// number of violations it caused and leaves the global count as it was
+void arith_reset_violations(uint64_t to) { n_violations = to; }   // for tests that feed out-of-bounds operands on purpose
+// self-test of the checker: operands of three units' magnitude (column sums beyond 2^63; a doubled limb beyond int32) must
+// trip it; returns the number of violations it caused and leaves the global count as it was
 uint64_t arith_bounds_checker_selftest(void) {
   const uint64_t before = n_violations;
   fe big;
-  for (int i = 0; i < 10; i++) big.v[i] = (i & 1) ? (3 << 25) : (3 << 26);
-  (void)fe_mul(fe_one(), big);     // 19 * 3 * 2^26 does not fit int32
-  (void)fe_sq(big);
+  for (int i = 0; i < AFX_FE_LIMBS; i++) big.v[i] = 3 << (i < 8 ? 29 : 23);
+  (void)fe_mul(big, big);          // 8 * 9 * 2^58 > 2^63
+  (void)fe_sq(big);                // 2 * 3 * 2^29 does not fit int32
   const uint64_t caused = n_violations - before;
   n_violations = before;
   return caused;
@@ -123,6 +124,31 @@ void arith_fe_lazy(uint8_t out[2][32], const uint8_t a[4][32], const uint8_t b[2
   const fe s = fe_add(fe_add(x[0], x[1]), fe_add(x[2], x[3]));   // four reduced terms: fe_mul's first operand
   fe_tobytes(w, fe_mul(s, fe_sub(y[0], y[1]))); memcpy(out[0], w, 32);
   fe_tobytes(w, fe_sq(fe_sub(x[0], x[1]))); memcpy(out[1], w, 32);
+}
+
+// operands given limb by limb (any int32 values the caller likes): canonical bytes of f*g (raw and centred flavours), f^2
+// (both), and of f itself; every product goes through the bounds checker
+// which: 1 = the products, 2 = the squarings, 4 = f itself
+void arith_fe_limbs(uint8_t out[5][32], const int32_t f[AFX_FE_LIMBS], const int32_t g[AFX_FE_LIMBS], int which) {
+  fe x, y;
+  for (int i = 0; i < AFX_FE_LIMBS; i++) { x.v[i] = f[i]; y.v[i] = g[i]; }
+  uint32_t w[8];
+  if (which & 1) {
+    fe_tobytes(w, fe_mul(x, y)); memcpy(out[0], w, 32);
+    fe_tobytes(w, fe_mul_raw(x, y)); memcpy(out[1], w, 32);
+  }
+  if (which & 2) {
+    fe_tobytes(w, fe_sq(x)); memcpy(out[2], w, 32);
+    fe_tobytes(w, fe_sq_raw(x)); memcpy(out[3], w, 32);
+  }
+  if (which & 4) { fe_tobytes(w, x); memcpy(out[4], w, 32); }
+}
+// limbs of a raw / centred product, for range checks
+void arith_fe_mul_limbs(int32_t raw[AFX_FE_LIMBS], int32_t centred[AFX_FE_LIMBS], const int32_t f[AFX_FE_LIMBS], const int32_t g[AFX_FE_LIMBS]) {
+  fe x, y;
+  for (int i = 0; i < AFX_FE_LIMBS; i++) { x.v[i] = f[i]; y.v[i] = g[i]; }
+  const fe r = fe_mul_raw(x, y), c = fe_mul(x, y);
+  for (int i = 0; i < AFX_FE_LIMBS; i++) { raw[i] = r.v[i]; centred[i] = c.v[i]; }
 }
 
 int arith_decode_encode(uint8_t out[32], const uint8_t in[32]) {

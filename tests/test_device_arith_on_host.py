@@ -59,6 +59,70 @@ def test_lazily_added_operands_at_the_documented_bounds(arith):
         assert int.from_bytes(bytes(out[1]), "little") == (v[0] - v[1]) ** 2 % P
 
 
+def _limbs_value(l):
+    return sum(int(x) << (29 * i) for i, x in enumerate(l))
+
+
+def test_products_at_the_limits_of_the_bounds_discipline(arith):
+    """fe.cuh: a product needs |f| * |g| <= 3.8 units (1 unit = 2^29; limb 8: 2^23), a squaring |f| <= 1.9.  Operands with every limb at
+    the extreme of its range, all sign patterns that maximise a column, must come out right and must not trip the checker."""
+    import random
+    rnd = random.Random(9)
+    unit = [1 << 29] * 8 + [1 << 23]
+    out = ((C.c_uint8 * 32) * 5)()
+    raw, cen = (C.c_int32 * 9)(), (C.c_int32 * 9)()
+    before = arith.arith_bounds_violations()
+
+    def limbs(mag, mode):
+        v = []
+        for i in range(9):
+            top = int(unit[i] * mag) - 1
+            x = top if mode != "random" or rnd.random() < 0.5 else rnd.randrange(0, top + 1)
+            sign = {"pos": 1, "neg": -1, "alt": (-1) ** i, "random": rnd.choice((1, -1))}[mode]
+            v.append(sign * x)
+        return v
+    cases = []
+    for ma, mb in ((1, 1), (2, 1), (2, 1.9), (3.8, 1), (1, 3.8), (1.9, 1.99), (3, 1.25), (1.5, 2)):
+        for sa in ("pos", "neg", "alt", "random"):
+            for sb in ("pos", "neg", "alt", "random"):
+                cases.append((limbs(ma, sa), limbs(mb, sb)))
+    for _ in range(300):
+        ma = rnd.choice((1, 2, 3.8))
+        cases.append((limbs(ma, "random"), limbs(3.8 / ma if ma > 1 else 1, "random")))
+    for f, g in cases:
+        # the squaring takes |f| <= 1.9: scale f down for it when the case is a wider operand
+        fs = f if max(abs(x) / u for x, u in zip(f, unit)) <= 1.9 else [x // 2 for x in f]
+        arith.arith_fe_limbs(out, (C.c_int32 * 9)(*fs), (C.c_int32 * 9)(*g), 2 | 4)
+        vs = _limbs_value(fs)
+        assert int.from_bytes(bytes(out[2]), "little") == vs * vs % P and bytes(out[3]) == bytes(out[2])
+        assert int.from_bytes(bytes(out[4]), "little") == vs % P
+        arith.arith_fe_limbs(out, (C.c_int32 * 9)(*f), (C.c_int32 * 9)(*g), 1)
+        want = _limbs_value(f) * _limbs_value(g) % P
+        assert int.from_bytes(bytes(out[0]), "little") == want and int.from_bytes(bytes(out[1]), "little") == want
+        # ranges of the results: raw in [0, 1), centred in [-1/2, 1/2]; limb 1 takes the wrap's last carry (|.| < 2^15) on top
+        arith.arith_fe_mul_limbs(raw, cen, (C.c_int32 * 9)(*f), (C.c_int32 * 9)(*g))
+        for i in range(9):
+            slack = (1 << 17) if i == 1 else 0
+            assert -slack <= raw[i] < unit[i] + slack, (i, raw[i])
+            assert -(unit[i] >> 1) - slack <= cen[i] <= (unit[i] >> 1) + slack, (i, cen[i])
+    assert arith.arith_bounds_violations() == before, arith.arith_last_violation()
+
+
+def test_canonical_encoding_of_edge_values(arith):
+    """fe_tobytes on limb patterns around 0, p and 2^255, positive and negative, lazily added, up to the int32 range"""
+    out = ((C.c_uint8 * 32) * 5)()
+    p_limbs = [(1 << 29) - 19] + [(1 << 29) - 1] * 7 + [(1 << 23) - 1]
+    vals = [[0] * 9, [1] + [0] * 8, [-1] + [0] * 8, [-19] + [0] * 8, [-20] + [0] * 8, p_limbs, [x + (i == 0) for i, x in enumerate(p_limbs)],
+            [x - (i == 0) for i, x in enumerate(p_limbs)], [-x for x in p_limbs], [2 * x for x in p_limbs], [-2 * x for x in p_limbs],
+            [(1 << 29) - 1] * 8 + [(1 << 23) - 1], [18] + [0] * 8, [19] + [0] * 8, [0] * 8 + [1 << 23], [0] * 8 + [-(1 << 23)],
+            [3 * x for x in p_limbs], [(1 << 31) - 1] * 9, [-(1 << 31)] * 9, [(-1) ** i * ((1 << 31) - 1) for i in range(9)]]
+    zero = (C.c_int32 * 9)(*([0] * 9))
+    for v in vals:
+        arith.arith_fe_limbs(out, (C.c_int32 * 9)(*v), zero, 4)
+        got = int.from_bytes(bytes(out[4]), "little")
+        assert got == _limbs_value(v) % P and got < P, v
+
+
 def test_group_ops_against_the_oracle(arith, primitives):
     import oracle
     s = stream(b"ge-host", 64 * 3 * 40)

@@ -5,7 +5,7 @@
 //   5 floor carries on the serial path, limbs centred afterwards with 32-bit operations off that path
 // Results are not all meaningful field products; only the instruction mix matters.
 // Build: hipcc -O3 --offload-arch=gfx950 carry_variants.hip -o build/carry_variants
-#include "../../aeonflux_amd/csrc/fe.cuh"
+#include "fe10_old.cuh"   /* the 10 x 25.5-bit field arithmetic of round 1, frozen for these measurements */
 #include <cstdio>
 #include <vector>
 constexpr int ITERS = 2000;

@@ -19,23 +19,23 @@ constexpr int T = 16;
 
 __device__ __forceinline__ void p3_store(int32_t* p, const ge_p3& q) {
 #pragma unroll
-  for (int l = 0; l < 10; l++) { p[l] = q.X.v[l]; p[10 + l] = q.Y.v[l]; p[20 + l] = q.Z.v[l]; p[30 + l] = q.T.v[l]; }
+  for (int l = 0; l < AFX_FE_LIMBS; l++) { p[l] = q.X.v[l]; p[AFX_FE_LIMBS + l] = q.Y.v[l]; p[2 * AFX_FE_LIMBS + l] = q.Z.v[l]; p[3 * AFX_FE_LIMBS + l] = q.T.v[l]; }
 }
 __device__ __forceinline__ ge_p3 p3_load(const int32_t* p) {
   ge_p3 q;
 #pragma unroll
-  for (int l = 0; l < 10; l++) { q.X.v[l] = p[l]; q.Y.v[l] = p[10 + l]; q.Z.v[l] = p[20 + l]; q.T.v[l] = p[30 + l]; }
+  for (int l = 0; l < AFX_FE_LIMBS; l++) { q.X.v[l] = p[l]; q.Y.v[l] = p[AFX_FE_LIMBS + l]; q.Z.v[l] = p[2 * AFX_FE_LIMBS + l]; q.T.v[l] = p[3 * AFX_FE_LIMBS + l]; }
   return q;
 }
 // entry = cached form, 40 dwords (this benchmark does not pack to 128 B: both variants pay the same)
 __device__ __forceinline__ void cached_store40(int32_t* p, const ge_cached& q) {
 #pragma unroll
-  for (int l = 0; l < 10; l++) { p[l] = q.YpX.v[l]; p[10 + l] = q.YmX.v[l]; p[20 + l] = q.Z2.v[l]; p[30 + l] = q.T2d.v[l]; }
+  for (int l = 0; l < AFX_FE_LIMBS; l++) { p[l] = q.YpX.v[l]; p[AFX_FE_LIMBS + l] = q.YmX.v[l]; p[2 * AFX_FE_LIMBS + l] = q.Z2.v[l]; p[3 * AFX_FE_LIMBS + l] = q.T2d.v[l]; }
 }
 __device__ __forceinline__ ge_cached cached_load40(const int32_t* p) {
   ge_cached q;
 #pragma unroll
-  for (int l = 0; l < 10; l++) { q.YpX.v[l] = p[l]; q.YmX.v[l] = p[10 + l]; q.Z2.v[l] = p[20 + l]; q.T2d.v[l] = p[30 + l]; }
+  for (int l = 0; l < AFX_FE_LIMBS; l++) { q.YpX.v[l] = p[l]; q.YmX.v[l] = p[AFX_FE_LIMBS + l]; q.Z2.v[l] = p[2 * AFX_FE_LIMBS + l]; q.T2d.v[l] = p[3 * AFX_FE_LIMBS + l]; }
   return q;
 }
 
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256, 2) k_straus(const int32_t* __restrict__ p
 __device__ __forceinline__ ge_p3 shfl_xor_p3(const ge_p3& p, int mask) {
   ge_p3 r;
 #pragma unroll
-  for (int l = 0; l < 10; l++) {
+  for (int l = 0; l < AFX_FE_LIMBS; l++) {
     r.X.v[l] = __shfl_xor(p.X.v[l], mask, 16); r.Y.v[l] = __shfl_xor(p.Y.v[l], mask, 16);
     r.Z.v[l] = __shfl_xor(p.Z.v[l], mask, 16); r.T.v[l] = __shfl_xor(p.T.v[l], mask, 16);
   }

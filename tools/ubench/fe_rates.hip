@@ -1,6 +1,6 @@
 // Field-multiplication throughput on gfx950 at the occupancy k_msm runs at (256 threads x 2 blocks per CU).
 // Build:  hipcc -O3 --offload-arch=gfx950 fe_rates.hip -o build/fe_rates
-#include "../../aeonflux_amd/csrc/fe.cuh"
+#include "fe10_old.cuh"   /* the 10 x 25.5-bit field arithmetic of round 1, frozen for these measurements */
 #include <cstdio>
 #include <vector>
 

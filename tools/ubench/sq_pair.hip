@@ -6,7 +6,7 @@
 // (202 vs 242 units), but in the doubling chain itself all-limb centring is 1.5 % slower on C3 (same-box A/B) - chained
 // microbenchmarks of single operations do not predict the in-situ schedule; only in-situ A/Bs decide.
 // Build: hipcc -O3 --offload-arch=gfx950 tools/ubench/sq_pair.hip -o variants/sq_pair
-#include "../../aeonflux_amd/csrc/fe.cuh"
+#include "fe10_old.cuh"   /* the 10 x 25.5-bit field arithmetic of round 1, frozen for these measurements */
 #include <cstdio>
 #include <vector>
 
