@@ -94,6 +94,58 @@ FE9_DEV fe9 fe9_sq_impl(const fe9& f) {
     return H;
   });
 }
+
+// variant: the high columns accumulated operand by operand (consecutive multiply-adds go to different accumulators)
+template <bool CENTRED>
+FE9_DEV fe9 fe9_mul_rows(const fe9& f, const fe9& g) {
+  int64_t hi[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) hi[m] = 0;
+#pragma unroll
+  for (int i = 1; i < 9; i++) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int j = 9 + m - i;
+      if (j < 1 || j > 8) continue;
+      hi[m] += (int64_t)f.v[i] * (int64_t)g.v[j];
+      FE9_PIN(hi[m]);
+    }
+  }
+  return fe9_reduce<CENTRED>(hi, [&](int k, int64_t H) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) { H += (int64_t)f.v[i] * (int64_t)g.v[k - i]; FE9_PIN(H); }
+    return H;
+  });
+}
+// variant: no pins at all (the compiler schedules freely)
+template <bool CENTRED>
+FE9_DEV fe9 fe9_mul_nopin(const fe9& f, const fe9& g) {
+  int64_t hi[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    int64_t H = 0;
+#pragma unroll
+    for (int i = m + 1; i < 9; i++) H += (int64_t)f.v[i] * (int64_t)g.v[9 + m - i];
+    hi[m] = H;
+  }
+  fe9 r;
+  int64_t c = 0;
+  uint32_t u0 = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    int64_t H = c;
+#pragma unroll
+    for (int i = 0; i <= k; i++) H += (int64_t)f.v[i] * (int64_t)g.v[k - i];
+    if (k < 8) H += (int64_t)((uint64_t)(uint32_t)hi[k] * 1216u);
+    if (k > 0) H += (int64_t)(int32_t)(hi[k - 1] >> 32) * 9728;
+    if (k < 8) { const uint32_t lo = (uint32_t)H & FE9_MASK29; if (k == 0) u0 = lo; else r.v[k] = (int32_t)lo; c = H >> 29; }
+    else { r.v[8] = (int32_t)((uint32_t)H & FE9_MASK23); c = H >> 23; }
+  }
+  int64_t H0 = (int64_t)u0 + c * 19;
+  r.v[0] = (int32_t)((uint32_t)H0 & FE9_MASK29);
+  r.v[1] += (int32_t)(H0 >> 29);
+  return r;
+}
 FE9_DEV fe9 fe9_mul(const fe9& f, const fe9& g) { return fe9_mul_impl<true>(f, g); }
 FE9_DEV fe9 fe9_mul_raw(const fe9& f, const fe9& g) { return fe9_mul_impl<false>(f, g); }
 FE9_DEV fe9 fe9_sq(const fe9& f) { return fe9_sq_impl<true>(f); }

@@ -41,6 +41,19 @@ __global__ void __launch_bounds__(256, 2) k_fe(int32_t* p) {
     for (int it = 0; it < ITERS; ++it) {
       if constexpr (MODE == 10) { a = fe9_mul_raw(a, b); }
       else if constexpr (MODE == 11) { a = fe9_sq_raw(a); }
+      else if constexpr (MODE == 14) { a = fe9_mul_rows<false>(a, b); }
+      else if constexpr (MODE == 15) { a = fe9_mul_nopin<false>(a, b); }
+      else if constexpr (MODE == 16) {   // addition shape with the row-wise high columns
+        fe9 A = fe9_mul_rows<false>(fe9_add(b, a), b), B = fe9_mul_rows<false>(fe9_sub(b, a), a), Cn = fe9_mul_rows<false>(a, b), D = fe9_mul_rows<false>(b, b);
+        fe9 X3 = fe9_sub(A, B), Y3 = fe9_add(A, B), Z3 = fe9_sub(D, Cn), T3 = fe9_add(D, Cn);
+        a = fe9_mul_rows<false>(T3, X3); b = fe9_mul_rows<false>(Y3, Z3); fe9 z = fe9_mul_rows<false>(T3, Z3), tt = fe9_mul_rows<false>(Y3, X3);
+        a = fe9_sub(a, z); b = fe9_sub(b, tt);
+      } else if constexpr (MODE == 17) {
+        fe9 A = fe9_mul_nopin<false>(fe9_add(b, a), b), B = fe9_mul_nopin<false>(fe9_sub(b, a), a), Cn = fe9_mul_nopin<false>(a, b), D = fe9_mul_nopin<false>(b, b);
+        fe9 X3 = fe9_sub(A, B), Y3 = fe9_add(A, B), Z3 = fe9_sub(D, Cn), T3 = fe9_add(D, Cn);
+        a = fe9_mul_nopin<false>(T3, X3); b = fe9_mul_nopin<false>(Y3, Z3); fe9 z = fe9_mul_nopin<false>(T3, Z3), tt = fe9_mul_nopin<false>(Y3, X3);
+        a = fe9_sub(a, z); b = fe9_sub(b, tt);
+      }
       else if constexpr (MODE == 12) {   // doubling: three raw squarings, one centred, two offsets by p
         fe9 XX = fe9_sq_raw(a), YY = fe9_sq_raw(b), ZZ = fe9_sq_raw(fe9_sub(a, XX));
         fe9 B = fe9_sub_p(fe9_add(ZZ, ZZ)), A = fe9_sub(b, a), AA = fe9_sq(A);
@@ -88,6 +101,8 @@ int main() {
     const float s10 = run<1>(d, "10: sq raw", 1, ncu), s9 = run<11>(d, " 9: sq raw", 1, ncu);
     const float d10 = run<2>(d, "10: doubling (4S+3M)", 7, ncu), d9 = run<12>(d, " 9: doubling (4S+3M)", 7, ncu);
     const float a10 = run<3>(d, "10: addition (8M)", 8, ncu), a9 = run<13>(d, " 9: addition (8M)", 8, ncu);
+    run<16>(d, " 9: addition, row-wise high columns", 8, ncu);
+    run<17>(d, " 9: addition, no pins", 8, ncu);
     printf("  ratios 9/10: mul %.3f  sq %.3f  doubling %.3f  addition %.3f\n", m9 / m10, s9 / s10, d9 / d10, a9 / a10);
   }
   return 0;
