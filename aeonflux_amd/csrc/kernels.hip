@@ -146,10 +146,11 @@ __global__ void k_setup_postables(const int32_t* __restrict__ base, uint32_t nge
   const uint32_t gj = t / AFX_POS_CHUNKS, c = t % AFX_POS_CHUNKS;
   const ge_p3 B = p3_load_uniform(base + (size_t)gj * AFX_VAR_DWORDS);
   const ge_cached cB = ge_p3_to_cached(B);
-  // Q = (16 c) * B by double-and-add over the bits of c (c < 64), then four doublings
+  // Q = (16 c) * B by double-and-add over the bits of c (c < AFX_POS_CHUNKS), then four doublings
   ge_p3 Q = ge_identity();
+  constexpr int cbits = 32 - __builtin_clz((unsigned)(AFX_POS_CHUNKS - 1));
 #pragma unroll 1
-  for (int bit = 5; bit >= 0; bit--) {
+  for (int bit = cbits - 1; bit >= 0; bit--) {
     Q = ge_double(Q);
     if ((c >> bit) & 1u) Q = ge_p1p1_to_p3(ge_add_cached(Q, cB, false));
   }
@@ -257,9 +258,9 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_scalarop(const afx_scalarop_job* 
 //                   odd multiples 1..15 in the same table slots; bit-serial chain with uniform branches
 //   fixed bases   : positional tables built at context creation: for every window position j the affine-niels
 //                   entries d * 2^(AFX_POS_BITS*j) * G, d = 0 .. 2^(AFX_POS_BITS-1).  A fixed base costs AFX_POS_WINDOWS
-//                   (26 at 10 bits) additions and takes no part in the doubling chain: they are added after it.
+//                   (20 at 13 bits) additions and takes no part in the doubling chain: they are added after it.
 //                   (Round 1 first ran them inside the chain with 8-bit windows from LDS-staged tables; reading the
-//                   same tables from L2 measured equally fast, and 10-bit positional tables beat both.)
+//                   same tables from L2 measured equally fast, and positional tables beat both.)
 // Field work per 4-bit window: 4 doublings (4 x 4S + 3 x 3M + 4M), 8M per variable term (the last addition of a
 // window skips the T coordinate, -1M); 7M per fixed-base addition.  Assembler::msm (engine.cpp) counts the same
 // schedule for afx_ctx_get_plan_stats.
