@@ -194,7 +194,10 @@ class Context:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown: module globals may be gone already
+            pass
 
     def set_chunk_items(self, items):
         """items per internal pass (0 = default 2^19); bounds the device workspace"""
@@ -301,7 +304,10 @@ class Group:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_bounds(count, members, index):
