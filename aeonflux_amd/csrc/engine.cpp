@@ -417,8 +417,13 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
       memcpy(blob_.data() + tl.jobs_off, tr.data(), sizeof(afx_table_job) * tr.size());
       launches.push_back(tl);
     }
+    // a windowed launch none of whose jobs encodes inside the kernel (every launch of Issuer::verify: results that are only
+    // encoded go through k_compress2x) runs the kernel compiled without the encoder (kernels.hip, k_msm<KIND, ENC>).  Splitting
+    // a mixed launch in two was measured as well: -1.7 % on a 2^16-item show (fewer rows per launch), so mixed launches stay whole.
     Launch l;
     l.kind = class_launch[kind];
+    l.encodes = 0;
+    for (const afx_msm_job& j : out) if (j.out_enc && !j.half_var) l.encodes = 1;
     l.njobs = (uint32_t)out.size();
     l.jobs_off = blob_alloc(sizeof(afx_msm_job) * out.size(), 16);
     memcpy(blob_.data() + l.jobs_off, out.data(), sizeof(afx_msm_job) * out.size());
@@ -500,7 +505,7 @@ int Assembler::run() {
         // overlap it), which keeps per-launch timings meaningful and the VALU free of two competing table working sets
         afx_ctx::Lane& other = ctx->lane[lane ^ 1];
         if (ctx->pipelining && other.msm_recorded) AFX_HIP(hipStreamWaitEvent(s, other.msm_done, 0));
-        AFX_HIP(afxk_msm(s, l.kind == L_MSM_FIXED ? 0 : l.kind == L_MSM_WINDOW ? 1 : 2, (const afx_msm_job*)jobs, l.njobs,
+        AFX_HIP(afxk_msm(s, l.kind == L_MSM_FIXED ? 0 : l.kind == L_MSM_WINDOW ? 1 : 2, l.encodes, (const afx_msm_job*)jobs, l.njobs,
                          (const int32_t*)ctx->d_pos_tables.p, table_ws, digit_ws, bad_, count,
                          (ctx->timing && l.kind == L_MSM_WINDOW) ? ctx->clock_probe() : nullptr));
         if (ctx->pipelining) { AFX_HIP(hipEventRecord(L.msm_done, s)); L.msm_recorded = true; }

@@ -138,6 +138,7 @@ struct Launch {
   uint8_t fail_code = AFX_ST_VERIFICATION_FAILURE;
   size_t bytes = 0;         // L_COPY
   int odd = 0;              // L_MSM_TABLES: odd multiples (NAF terms) or multiples 0..8
+  int encodes = 1;          // L_MSM_*: some job of the launch encodes its result inside the kernel (kernels.hip k_msm<KIND, ENC>)
   int32_t* prefix_ws = nullptr;   // L_COMPRESS: scratch for the prefix products (njobs * 9 * count dwords)
 };
 

@@ -12,7 +12,7 @@ hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen
 // kind: 0 fixed bases only, 1 per-item windows, 2 uniform NAF terms (kernels.hip MSM_*)
 hipError_t afxk_msm_tables(hipStream_t s, int odd, const afx_table_job* rows, uint32_t nrows, int32_t* table_ws, uint32_t count);
 // clock_probe: two 64-bit counters (shader-clock cycles, 100 MHz ticks) one lane of the launch adds its chain's span to; may be null
-hipError_t afxk_msm(hipStream_t s, int kind, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, int32_t* table_ws, uint32_t* digit_ws,
+hipError_t afxk_msm(hipStream_t s, int kind, int encodes, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, int32_t* table_ws, uint32_t* digit_ws,
                     uint32_t* bad, uint32_t count, unsigned long long* clock_probe);
 // out_enc = encoding of twice each job's point; prefix_ws: njobs * 10 * count dwords of scratch
 hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, uint32_t njobs, int32_t* prefix_ws, uint32_t* bad, uint32_t count);

@@ -393,7 +393,8 @@ AFX_DEV ge_p3 msm_fixed_terms(const msm_env& e, const int32_t* __restrict__ pos_
   }
   return acc;
 }
-// addend, extended-coordinate output, compressed output
+// addend, extended-coordinate output, compressed output (ENC = false: a launch none of whose jobs encodes here)
+template <bool ENC>
 AFX_DEV void msm_finish(const afx_msm_job* job, ge_p3 acc, uint32_t* __restrict__ bad, uint32_t count, uint32_t item) {
   if (job->addend) {
     const ge_p3 A = var_load(job->addend, count, item);
@@ -401,7 +402,7 @@ AFX_DEV void msm_finish(const afx_msm_job* job, ge_p3 acc, uint32_t* __restrict_
   }
   if (job->out_var) var_store(job->out_var, count, item, acc);
   if (job->half_var) { var_store(job->half_var, count, item, acc); return; }   // encoded by k_compress2x
-  if (job->out_enc) {
+  if (ENC && job->out_enc) {
     uint32_t wenc[8];
     ristretto_encode(wenc, acc);
     enc_store(job->out_enc, item, wenc);
@@ -425,10 +426,12 @@ k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table
   else msm_build_table<false>(slot + (size_t)item * AFX_VAR_TABLE_DWORDS, AFX_TABLE_ENTRY_DWORDS, 4, P);
 }
 
-// Two blocks per CU: three (168 registers) were measured too - the windowed chain 1.3 % faster, the step 0.8 %, for 76 bytes of
-// scratch per lane in the encoding epilogue; not taken.
-template <int KIND>
-__global__ void __launch_bounds__(AFX_BLOCK, 2)
+// ENC: the launch has jobs that encode their result in this kernel (those with an addend or an extended-coordinate output as
+// well; results that are only encoded go through k_compress2x).  A windowed launch without such jobs - every one of
+// Issuer::verify - runs the instance compiled without the encoder's inversion, which fits three blocks per CU without
+// scratch (166 registers; 1.3 % faster than two blocks on that kernel, same box).
+template <int KIND, bool ENC>
+__global__ void __launch_bounds__(AFX_BLOCK, (KIND == MSM_WINDOW && !ENC) ? 3 : 2)
 k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tables, int32_t* __restrict__ table_ws,
       uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count, unsigned long long* __restrict__ clock_probe) {
   // Clock probe (measurement aid): one lane of the launch's first block reads the shader-clock counter (s_memtime) and the
@@ -500,7 +503,7 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
     // the fixed bases of a job with variable bases: after the chain (any order gives the same sum)
     if (nt != nv) acc = msm_fixed_terms(env, pos_tables, acc, nv, nt);
   }
-  msm_finish(job, acc, bad, count, item);
+  msm_finish<ENC>(job, acc, bad, count, item);
   if (probe) {
     atomicAdd(&clock_probe[0], (unsigned long long)clock64() - c0);
     atomicAdd(&clock_probe[1], (unsigned long long)wall_clock64() - r0);
@@ -712,12 +715,15 @@ hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen
   hipLaunchKernelGGL(k_setup_postables, dim3((ngen * AFX_POS_WINDOWS * AFX_POS_CHUNKS + 63) / 64), dim3(64), 0, s, base, ngen, postab);
   return hipGetLastError();
 }
-hipError_t afxk_msm(hipStream_t s, int kind, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, int32_t* table_ws, uint32_t* digit_ws,
-                    uint32_t* bad, uint32_t count, unsigned long long* clock_probe) {
+hipError_t afxk_msm(hipStream_t s, int kind, int encodes, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, int32_t* table_ws,
+                    uint32_t* digit_ws, uint32_t* bad, uint32_t count, unsigned long long* clock_probe) {
   switch (kind) {
-    case MSM_FIXED: hipLaunchKernelGGL(k_msm<MSM_FIXED>, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe); break;
-    case MSM_WINDOW: hipLaunchKernelGGL(k_msm<MSM_WINDOW>, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe); break;
-    case MSM_NAF: hipLaunchKernelGGL(k_msm<MSM_NAF>, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe); break;
+    case MSM_FIXED: hipLaunchKernelGGL((k_msm<MSM_FIXED, true>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe); break;
+    case MSM_WINDOW:
+      if (encodes) hipLaunchKernelGGL((k_msm<MSM_WINDOW, true>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe);
+      else hipLaunchKernelGGL((k_msm<MSM_WINDOW, false>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe);
+      break;
+    case MSM_NAF: hipLaunchKernelGGL((k_msm<MSM_NAF, true>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

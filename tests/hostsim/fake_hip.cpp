@@ -52,10 +52,11 @@ hipError_t afxk_pointop(hipStream_t, const afx_pointop_job* j, uint32_t n, uint3
 hipError_t afxk_scalarop(hipStream_t, const afx_scalarop_job* j, uint32_t n, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
 hipError_t afxk_setup_postables(hipStream_t, const int32_t*, uint32_t, int32_t*, int32_t*) { return hipSuccess; }
 hipError_t afxk_msm_tables(hipStream_t, int, const afx_table_job* r, uint32_t n, int32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)r[i].var + r[i].table_slot; return hipSuccess; }
-hipError_t afxk_msm(hipStream_t, int kind, const afx_msm_job* j, uint32_t n, const int32_t*, int32_t*, uint32_t*, uint32_t*, uint32_t, unsigned long long* probe) {
+hipError_t afxk_msm(hipStream_t, int kind, int encodes, const afx_msm_job* j, uint32_t n, const int32_t*, int32_t*, uint32_t*, uint32_t*, uint32_t, unsigned long long* probe) {
   if (probe) { probe[0] += 2250; probe[1] += 100; }
   if (kind < 0 || kind > 2) return hipErrorInvalidValue;
   for (uint32_t i = 0; i < n; i++) {
+    if (!encodes && j[i].out_enc && !j[i].half_var) return hipErrorInvalidValue;   // a job that encodes in the kernel needs the encoding launch
     if ((j[i].n_var == 0 ? 0 : j[i].n_uni ? 2 : 1) != kind) return hipErrorInvalidValue;   // every job in its own class's launch
     for (uint32_t t = 0; t < j[i].n_terms; t++) sink += (uintptr_t)j[i].term[t].scalar;
     if (j[i].n_uni) {   // the NAF schedule lives in the plan blob: read it to its terminator
