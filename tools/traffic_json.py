@@ -9,7 +9,7 @@ import json
 import sqlite3
 import sys
 
-KERNELS = {"k_msm_window": "%k_msm<1>%", "k_msm_naf": "%k_msm<2>%", "k_msm_fixed": "%k_msm<0>%", "k_msm_tables": "%k_msm_tables%",
+KERNELS = {"k_msm_window": "%k_msm<1,%", "k_msm_naf": "%k_msm<2,%", "k_msm_fixed": "%k_msm<0,%", "k_msm_tables": "%k_msm_tables%",
            "k_decode": "%k_decode%", "k_hash": "%k_hash%"}
 
 
