@@ -417,7 +417,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
       memcpy(blob_.data() + tl.jobs_off, tr.data(), sizeof(afx_table_job) * tr.size());
       launches.push_back(tl);
     }
-    // a windowed launch none of whose jobs encodes inside the kernel (every launch of Issuer::verify: results that are only
+    // a launch none of whose jobs encodes inside the kernel (every windowed launch of Issuer::verify: results that are only
     // encoded go through k_compress2x) runs the kernel compiled without the encoder (kernels.hip, k_msm<KIND, ENC>).  Splitting
     // a mixed launch in two was measured as well: -1.7 % on a 2^16-item show (fewer rows per launch), so mixed launches stay whole.
     Launch l;

@@ -427,11 +427,12 @@ k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table
 }
 
 // ENC: the launch has jobs that encode their result in this kernel (those with an addend or an extended-coordinate output as
-// well; results that are only encoded go through k_compress2x).  A windowed launch without such jobs - every one of
-// Issuer::verify - runs the instance compiled without the encoder's inversion, which fits three blocks per CU without
-// scratch (166 registers; 1.3 % faster than two blocks on that kernel, same box).
+// well; results that are only encoded go through k_compress2x).  A launch without such jobs - every windowed one of
+// Issuer::verify, every one of Issuer::issue - runs the instance compiled without the encoder's inversion, which fits three
+// blocks per CU without scratch (166 registers windowed and fixed, 146 NAF; the windowed chain 1.3 % faster than with two
+// blocks, the fixed-base sums 4.5 %, same box).
 template <int KIND, bool ENC>
-__global__ void __launch_bounds__(AFX_BLOCK, (KIND == MSM_WINDOW && !ENC) ? 3 : 2)
+__global__ void __launch_bounds__(AFX_BLOCK, !ENC ? 3 : 2)
 k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tables, int32_t* __restrict__ table_ws,
       uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count, unsigned long long* __restrict__ clock_probe) {
   // Clock probe (measurement aid): one lane of the launch's first block reads the shader-clock counter (s_memtime) and the
@@ -718,12 +719,18 @@ hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen
 hipError_t afxk_msm(hipStream_t s, int kind, int encodes, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, int32_t* table_ws,
                     uint32_t* digit_ws, uint32_t* bad, uint32_t count, unsigned long long* clock_probe) {
   switch (kind) {
-    case MSM_FIXED: hipLaunchKernelGGL((k_msm<MSM_FIXED, true>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe); break;
+    case MSM_FIXED:
+      if (encodes) hipLaunchKernelGGL((k_msm<MSM_FIXED, true>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe);
+      else hipLaunchKernelGGL((k_msm<MSM_FIXED, false>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe);
+      break;
     case MSM_WINDOW:
       if (encodes) hipLaunchKernelGGL((k_msm<MSM_WINDOW, true>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe);
       else hipLaunchKernelGGL((k_msm<MSM_WINDOW, false>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe);
       break;
-    case MSM_NAF: hipLaunchKernelGGL((k_msm<MSM_NAF, true>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe); break;
+    case MSM_NAF:
+      if (encodes) hipLaunchKernelGGL((k_msm<MSM_NAF, true>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe);
+      else hipLaunchKernelGGL((k_msm<MSM_NAF, false>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe);
+      break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
