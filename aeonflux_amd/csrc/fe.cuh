@@ -13,7 +13,7 @@
 // column k and 9728 * hi to column k+1 - and the low columns run a sequential carry (the carry out of column k is the 64-bit
 // addend of column k+1's first multiply-add, so the chain needs no 64-bit additions).  Limb 8 is cut at 23 bits and what lies
 // above (weight 2^255 = 19) goes back to limb 0 with the last carry.  Measured: an addition's 8 products -9 %, a doubling's
-// 4 squarings + 3 products -4 %; a lone squaring +3 % (61 multiply-adds against 55).
+// 4 squarings + 3 products -4 %; a lone squaring +3 % (62 multiply-adds against 56).
 //
 // Bounds discipline, in units of 2^29 ("1 unit"; limb 8: 2^23).  A RAW result has limbs in [0, 1); a CENTRED one in
 // [-1/2, 1/2] (its rounding constants travel in the carries: 18 more additions, on the serial path).  fe_add/fe_sub/fe_neg
