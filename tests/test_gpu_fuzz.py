@@ -4,6 +4,7 @@ every kind of corruption.  For each shape: show on the GPU must give the oracle'
 and the recomputed challenges (a hash over every recomputed commitment) the oracle's - in the reference's mode and in strict mode.
 This is the net under the engine's structural optimisations (shared window tables, commitments encoded as doubles by
 k_compress2x, per-class kernels): they depend on the shape of the launch list, which fixed-shape tests cannot vary."""
+import os
 import random
 
 import numpy as np
@@ -24,7 +25,8 @@ def _random_shape(rng):
     return n, layout, hide
 
 
-@pytest.mark.parametrize("seed", range(12))
+# AFX_FUZZ_SEEDS=n widens the sweep for soak runs (the suite runs the first 12)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AFX_FUZZ_SEEDS", "12"))))
 def test_random_shapes_show_and_verify_like_the_oracle(seed):
     import oracle
     import aeonflux_amd as afx
