@@ -362,14 +362,14 @@ AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t ch
   ge_p3 Q = P;
   if (ODD) {
     const ge_cached c2 = ge_p3_to_cached(ge_double(P));
-    cached_store(tab, chunk, ge_p3_to_cached_reduced(P));
+    cached_store(tab, chunk, ge_p3_to_cached(P));   // the canonical packing carries: no separate reduction
 #pragma unroll 1
     for (int k = 1; k < 8; k++) {
       Q = ge_p1p1_to_p3(ge_add_cached(Q, c2, false));
-      cached_store(tab + k * stride, chunk, ge_p3_to_cached_reduced(Q));
+      cached_store(tab + k * stride, chunk, ge_p3_to_cached(Q));
     }
   } else {
-    const ge_cached cP = ge_p3_to_cached_reduced(P);
+    const ge_cached cP = ge_p3_to_cached(P);   // P centred: Y+X, Y-X, 2Z within 1 unit, what ge_add_cached expects
     cached_store(tab, chunk, cP);   // k*P at entry k - 1; the identity (digit 0) is not stored
 #ifdef AFX_EXPERIMENT_W3
     const int entries = 5;
@@ -379,7 +379,7 @@ AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t ch
 #pragma unroll 1
     for (int k = 2; k < entries; k++) {
       Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
-      cached_store(tab + (k - 1) * stride, chunk, ge_p3_to_cached_reduced(Q));
+      cached_store(tab + (k - 1) * stride, chunk, ge_p3_to_cached(Q));
     }
   }
 }

@@ -47,11 +47,11 @@ int arith_msm_chain(uint8_t out[32], uint32_t nv, const uint8_t* s, const uint8_
     load8(w, p + 32 * t);
     ge_p3 P;
     if (!ristretto_decode(P, w)) return 0;
-    const ge_cached cP = ge_p3_to_cached_reduced(P);
+    const ge_cached cP = ge_p3_to_cached(P);   // as msm_build_table: the packing below is what reduces the entries
     tab[t][0] = ge_cached_identity();
     tab[t][1] = cP;
     ge_p3 Q = P;
-    for (int k = 2; k < 9; k++) { Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false)); tab[t][k] = ge_p3_to_cached_reduced(Q); }
+    for (int k = 2; k < 9; k++) { Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false)); tab[t][k] = ge_p3_to_cached(Q); }
     // the kernel stores entries in canonical 32-byte form and reloads them: do the same round trip
     for (int k = 0; k < 9; k++) {
       uint32_t b[8];
