@@ -172,9 +172,9 @@ def check(rc):
 class Context:
     """An issuer-side (key given) or user-side (key=None) engine context on one GPU."""
 
-    def __init__(self, sysparams, amacs_key, issuer_params, device=0, _borrowed=None):
-        if _borrowed is not None:   # a member of a Group: owned by the group
-            self.h, self._owned = _borrowed, False
+    def __init__(self, sysparams, amacs_key, issuer_params, device=0, _borrowed=None, _group=None):
+        if _borrowed is not None:   # a member of a Group: owned by the group, which clears self.h when it closes
+            self.h, self._owned, self._group = _borrowed, False, _group
         else:
             h = C.c_void_p()
             check(lib().afx_ctx_create(C.byref(h), device, sysparams, len(sysparams), amacs_key, len(amacs_key) if amacs_key else 0,
@@ -287,6 +287,7 @@ class Group:
                                      issuer_params))
         self.h = h
         self.devices = list(devices)
+        self._members = []   # weak references to the borrowed contexts handed out: invalidated by close()
         self.n = self.member(0).n
 
     def __len__(self):
@@ -296,10 +297,18 @@ class Group:
         m = lib().afx_group_member(self.h, i)
         if not m:
             raise IndexError(i)
-        return Context(None, None, None, device=self.devices[i], _borrowed=C.c_void_p(m))
+        import weakref
+        c = Context(None, None, None, device=self.devices[i], _borrowed=C.c_void_p(m), _group=self)   # keeps the group alive
+        self._members.append(weakref.ref(c))
+        return c
 
     def close(self):
         if getattr(self, "h", None):
+            for r in self._members:   # a member handle must not outlive the contexts the group owns
+                c = r()
+                if c is not None:
+                    c.h = None
+            self._members = []
             lib().afx_group_destroy(self.h)
             self.h = None
 

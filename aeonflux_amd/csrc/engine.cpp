@@ -32,9 +32,14 @@ const char* last_error() { return g_error.c_str(); }
 int DevBuf::ensure(size_t n) {
   if (n <= cap) return AFX_OK;
   if (p) {
+    // The buffer may still be in use: the *_dev entry points are asynchronous and the lanes' streams are non-blocking, so
+    // neither the null-stream memset below nor a later reuse of the freed range is ordered after their kernels.  Growing a
+    // buffer is rare (once per new high-water mark): wait for the whole device first.
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { set_error(std::string("hipDeviceSynchronize: ") + hipGetErrorString(e)); return AFX_E_HIP; }
     // workspace / staging hold blindings, y_i*m_i products, staged user keys, key-derived tables: wipe first
     if (sensitive) (void)hipMemset(p, 0, cap);
-    hipError_t e = hipFree(p);
+    e = hipFree(p);
     p = nullptr; cap = 0;
     if (e != hipSuccess) { set_error(std::string("hipFree: ") + hipGetErrorString(e)); return AFX_E_HIP; }
   }
@@ -237,7 +242,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
   // Jobs whose result is only ever encoded (no consumer of the point itself, no addend) run on halved scalars; k_compress2x
   // encodes the doubles (below, and kernels.hip)
-  auto encoded_only = [&](const afx_msm_job& j) { return j.out_enc && !j.out_var && !j.addend && !ctx->no_compress2x; };
+  auto encoded_only = [&](const afx_msm_job& j) { return j.out_enc && !j.out_var && !j.addend; };
   // variable bases whose scalar is a batch constant the host knows (the issuer key in Z and in the tag) go first
   // and run a width-5 NAF: ~43 additions each instead of 64, same schedule for every lane
   std::vector<std::vector<int8_t>> naf_of(jobs.size());

@@ -101,10 +101,10 @@ struct afx_ctx {
   bool pipelining = false;
   bool strict = false;   // afx_ctx_set_strict
   bool fixed_key_schedule = false;   // afx_ctx_set_fixed_key_schedule: no NAF for the issuer key's scalars
-  bool no_compress2x = false;        // measurement switch (AFX_NO_COMPRESS2X=1 in the environment at context creation): every job encodes its own result
+  bool secret_independent = false;   // afx_ctx_set_secret_independent_addressing: no memory address depends on a secret digit
   uint32_t chunk_items = 0;   // afx_ctx_set_chunk_items; 0 = default
   afx_plan_stats last_stats = {};   // per-item operation counts of the most recent plan
-  std::map<std::pair<uint64_t, uint32_t>, size_t> plan_sizes;   // (plan key, pass size) -> workspace bytes (statements.hpp run_chunked)
+  std::map<std::pair<std::string, uint32_t>, size_t> plan_sizes;   // (plan key bytes, pass size) -> workspace bytes (statements.hpp run_chunked)
   uint32_t n_cu = 256;   // compute units of the device (k_msm keeps 2 blocks resident on each)
   // parity aid (afx_ctx_set_challenge_trace): device array [trace_rows][trace_count][32] receiving every recomputed challenge
   uint8_t* trace = nullptr;

@@ -264,17 +264,6 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_scalarop(const afx_scalarop_job* 
 // Field work per 4-bit window: 4 doublings (4 x 4S + 3 x 3M + 4M), 8M per variable term (the last addition of a
 // window skips the T coordinate, -1M); 7M per fixed-base addition.  Assembler::msm (engine.cpp) counts the same
 // schedule for afx_ctx_get_plan_stats.
-// Experiment switches (never in the shipped build; most give wrong results, bench.py runs them with AFX_BENCH_UNCHECKED=1;
-// DESIGN.md §4, profiles/r02_traffic_experiments.txt):
-//   AFX_EXPERIMENT_ALIAS_TABLES        every lane gathers item 0's window table: the gathers hit L1/L2 and the chain runs as
-//                                      if table traffic were free - the upper bound on any table-layout or -size change
-//   AFX_EXPERIMENT_WINDOW_ENTRY_MAJOR  4-bit-window tables laid out [entry][item] like the NAF tables (results stay right)
-//   AFX_EXPERIMENT_W3                  cost/traffic emulation of signed 3-bit windows: 85 windows x 3 doublings, 5-entry tables
-#ifdef AFX_EXPERIMENT_ALIAS_TABLES
-#define AFX_TABLE_ITEM(item) ((item) & 0u)
-#else
-#define AFX_TABLE_ITEM(item) (item)
-#endif
 // the identity in window-table entry form (Y+X = 1, Y-X = 1, 2Z = 2, 2dT = 0 as canonical 32-byte words): what digit 0 adds
 __device__ __attribute__((aligned(16))) const int32_t AFX_IDENTITY_ENTRY[AFX_TABLE_ENTRY_DWORDS] = {
   1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -292,19 +281,10 @@ AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w,
   const int d = (int)((word >> (((uint32_t)w & 7) * 4)) & 15u) - 8;
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
   const bool neg = (d < 0) != (e.job->term[t].negate != 0);
-#ifdef AFX_EXPERIMENT_W3
-  const uint32_t idx3 = idx > 4 ? idx - 4 : idx;   // cost/traffic emulation of signed 3-bit windows: 5-entry tables (results are wrong)
-#else
-  const uint32_t idx3 = idx;
-#endif
   // multiples 1..8 are stored (at 0..7); digit 0 reads the one identity entry every lane shares (an address select, no table bytes)
-  const uint32_t stored = idx3 ? idx3 - 1 : 0;
-#ifdef AFX_EXPERIMENT_WINDOW_ENTRY_MAJOR
-  const int32_t* own = e.table_ws + (size_t)e.job->term[t].table_slot * e.count * AFX_VAR_TABLE_DWORDS + ((size_t)stored * e.count + AFX_TABLE_ITEM(e.item)) * AFX_TABLE_ENTRY_DWORDS;
-#else
-  const int32_t* own = e.table_ws + ((size_t)e.job->term[t].table_slot * e.count + AFX_TABLE_ITEM(e.item)) * AFX_VAR_TABLE_DWORDS + stored * AFX_TABLE_ENTRY_DWORDS;
-#endif
-  const int32_t* ent = idx3 ? own : AFX_IDENTITY_ENTRY;
+  const uint32_t stored = idx ? idx - 1 : 0;
+  const int32_t* own = e.table_ws + ((size_t)e.job->term[t].table_slot * e.count + e.item) * AFX_VAR_TABLE_DWORDS + stored * AFX_TABLE_ENTRY_DWORDS;
+  const int32_t* ent = idx ? own : AFX_IDENTITY_ENTRY;
   return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent, 4), neg), next);
 }
 // acc += (AFX_POS_BITS-bit signed digit j) * 2^(AFX_POS_BITS*j) * (generator of term t), from the positional tables
@@ -371,13 +351,8 @@ AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t ch
   } else {
     const ge_cached cP = ge_p3_to_cached(P);   // P centred: Y+X, Y-X, 2Z within 1 unit, what ge_add_cached expects
     cached_store(tab, chunk, cP);   // k*P at entry k - 1; the identity (digit 0) is not stored
-#ifdef AFX_EXPERIMENT_W3
-    const int entries = 5;
-#else
-    const int entries = AFX_TABLE_ENTRIES;
-#endif
 #pragma unroll 1
-    for (int k = 2; k < entries; k++) {
+    for (int k = 2; k < AFX_TABLE_ENTRIES; k++) {
       Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
       cached_store(tab + (k - 1) * stride, chunk, ge_p3_to_cached(Q));
     }
@@ -418,9 +393,6 @@ k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table
   const afx_table_job row = rows[blockIdx.y];
   int32_t* slot = table_ws + (size_t)row.table_slot * count * AFX_VAR_TABLE_DWORDS;
   const ge_p3 P = var_load(row.var, count, item);
-#ifdef AFX_EXPERIMENT_WINDOW_ENTRY_MAJOR
-  if (!ODD) { msm_build_table<false>(slot + (size_t)item * AFX_TABLE_ENTRY_DWORDS, (size_t)count * AFX_TABLE_ENTRY_DWORDS, 4, P); return; }
-#endif
   // NAF tables: [entry][piece][item][16 B]; window tables: [item][entry][128 B]
   if (ODD) msm_build_table<true>(slot + (size_t)item * 4, (size_t)count * AFX_TABLE_ENTRY_DWORDS, (size_t)count * 4, P);
   else msm_build_table<false>(slot + (size_t)item * AFX_VAR_TABLE_DWORDS, AFX_TABLE_ENTRY_DWORDS, 4, P);
@@ -473,7 +445,7 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
           const bool neg = (ev & 0x80u) != 0;
           ev = sched[++ei];
           const bool last = !lane_adds && (ev >> 16) != (uint32_t)bit;
-          const int32_t* ent = table_ws + (size_t)job->term[t].table_slot * count * AFX_VAR_TABLE_DWORDS + (size_t)idx * count * AFX_TABLE_ENTRY_DWORDS + (size_t)AFX_TABLE_ITEM(item) * 4;
+          const int32_t* ent = table_ws + (size_t)job->term[t].table_slot * count * AFX_VAR_TABLE_DWORDS + (size_t)idx * count * AFX_TABLE_ENTRY_DWORDS + (size_t)item * 4;
           acc = ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent, (size_t)count * 4), neg), last ? after : GE_FOR_ADD);
         }
         if (lane_adds) {
@@ -482,23 +454,17 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
         }
       }
     } else {
-#ifdef AFX_EXPERIMENT_W3
-      const int top_w = 84, dbl_to_p2 = 2;   // 85 windows of 3 bits (digits re-read from the 4-bit stream: wrong results, right cost)
-#else
-      const int top_w = 63, dbl_to_p2 = 3;
-#endif
 #pragma unroll 1
-      for (int wi = top_w; wi >= 0; wi--) {
-        const int w = wi & 63;
-        if (wi != top_w) {
+      for (int w = 63; w >= 0; w--) {
+        if (w != 63) {
           ge_p2 a2 = ge_p3_to_p2(acc);
 #pragma unroll 1
-          for (int k = 0; k < dbl_to_p2; k++) a2 = ge_p1p1_to_p2_before_dbl(ge_p2_dbl(a2));
+          for (int k = 0; k < 3; k++) a2 = ge_p1p1_to_p2_before_dbl(ge_p2_dbl(a2));
           acc = ge_p1p1_to_p3_for<GE_FOR_ADD>(ge_p2_dbl(a2));
         }
 #pragma unroll 1
         for (uint32_t t = 0; t + 1 < nv; t++) acc = msm_add_var(env, acc, t, w, GE_FOR_ADD);
-        acc = msm_add_var(env, acc, nv - 1, w, wi == 0 ? GE_FOR_ANY : GE_FOR_DBL);   // the window's last addition
+        acc = msm_add_var(env, acc, nv - 1, w, w == 0 ? GE_FOR_ANY : GE_FOR_DBL);   // the window's last addition
       }
     }
     // the fixed bases of a job with variable bases: after the chain (any order gives the same sum)

@@ -211,7 +211,6 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   c->device = device;
   c->n = n;
   c->g = n < 3 ? 3 : n;
-  { const char* off = getenv("AFX_NO_COMPRESS2X"); c->no_compress2x = off && off[0] == '1'; }
   for (afx::DevBuf* pub : { &c->trace_buf, &c->d_gen_enc, &c->d_consts, &c->d_pos_tables, &c->d_gen_ext }) pub->sensitive = false;   // public data
   AFX_HIP(hipSetDevice(device));
   {
@@ -535,7 +534,8 @@ extern "C" int afx_verify_presentations_dev(afx_ctx* ctx, const afx_shape* shape
   if (b.enc && sh.n_enc_proofs <= AFX_MAX_ATTRIBUTES) encs.assign(b.enc, b.enc + sh.n_enc_proofs);
   // the plan's size depends on the shape and the mode, not on the arrays: remember it (the trace changes nothing in size,
   // but a too-small trace buffer is a plan error that the sizing run reports, so traced calls are not cached)
-  const uint64_t key = ctx->trace ? 0 : plan_key("verify_presentations", &sh, sizeof sh, (ctx->strict ? 1u : 0u) | (ctx->fixed_key_schedule ? 2u : 0u));
+  const afx_shape csh = canonical_shape(sh);
+  const PlanKey key = ctx->trace ? PlanKey() : plan_key("verify_presentations", &csh, sizeof csh, mode_flags(ctx));
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
     afx_presentation_soa bb = b;
     bb.enc = encs.data();

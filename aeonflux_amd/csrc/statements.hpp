@@ -6,6 +6,7 @@
 #include <functional>
 #include <memory>
 #include <stdexcept>
+#include <string>
 #include <vector>
 #include "engine.hpp"
 
@@ -27,19 +28,36 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
 // ------------------------------------------------------------------------------------------------
 using BuildFn = std::function<void(Assembler&, size_t /*chunk offset*/, uint32_t /*chunk count*/)>;
 
-// FNV-1a over the bytes that determine a plan's SIZE (statement, shape, mode flags - never the data pointers)
-inline uint64_t plan_key(const char* statement, const void* shape, size_t shape_len, uint64_t flags) {
-  uint64_t h = 1469598103934665603ull;
-  auto mix = [&](const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; } };
-  mix((const uint8_t*)statement, strlen(statement));
-  mix((const uint8_t*)shape, shape_len);
-  mix((const uint8_t*)&flags, sizeof flags);
-  return h ? h : 1;
+// The bytes that determine a plan's SIZE (statement, shape, mode flags - never the data pointers), as the cache key itself:
+// no hash, so two requests share an entry only when these bytes are equal.  Callers pass a CANONICAL shape (unused array
+// tails zeroed: canonical_shape), because the shape of afx_verify_presentations_wire comes from the caller's blob.
+using PlanKey = std::string;   // empty: not cached
+inline PlanKey plan_key(const char* statement, const void* shape, size_t shape_len, uint64_t flags) {
+  PlanKey k(statement);
+  k.push_back('\0');
+  k.append((const char*)shape, shape_len);
+  k.append((const char*)&flags, sizeof flags);
+  return k;
+}
+inline afx_shape canonical_shape(const afx_shape& sh) {
+  afx_shape c;
+  memset(&c, 0, sizeof c);
+  c.n_attributes = sh.n_attributes; c.n_responses = sh.n_responses; c.n_hidden_scalars = sh.n_hidden_scalars; c.n_enc_proofs = sh.n_enc_proofs;
+  for (uint32_t i = 0; i < sh.n_attributes && i < AFX_MAX_ATTRIBUTES; i++) c.kinds[i] = sh.kinds[i];
+  for (uint32_t i = 0; i < sh.n_hidden_scalars && i < AFX_MAX_ATTRIBUTES; i++) c.hidden_scalar_indices[i] = sh.hidden_scalar_indices[i];
+  for (uint32_t i = 0; i < sh.n_enc_proofs && i < AFX_MAX_ATTRIBUTES; i++) c.enc_indices[i] = sh.enc_indices[i];
+  return c;
+}
+// mode flags that change a plan's size, for plan_key (every statement passes them all: a flag that does not matter to a
+// statement only costs it a second cache entry)
+inline uint64_t mode_flags(const afx_ctx* c) {
+  return (c->strict ? 1u : 0u) | (c->fixed_key_schedule ? 2u : 0u) | (c->secret_independent ? 8u : 0u);
 }
 
-// key != 0: the plan's workspace and blob sizes are remembered per (key, pass size), so that repeated calls of one statement
-// on one shape assemble their plan once per pass instead of twice (the dry sizing run is skipped)
-inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, uint64_t key = 0) {
+// key non-empty: the plan's workspace size is remembered per (key, pass size), so that repeated calls of one statement
+// on one shape assemble their plan once per pass instead of twice (the dry sizing run is skipped).  A remembered size that
+// turns out too small for the assembled plan is dropped and the pass is sized again.
+inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, const PlanKey& key = PlanKey()) {
   AFX_HIP(hipSetDevice(c->device));
   // all chunks of one call run on one lane; calls alternate lanes only when the caller switched pipelining on
   const int lane = c->force_lane >= 0 ? c->force_lane : (c->pipelining ? (int)(c->lane_next++ & 1u) : 0);
@@ -48,9 +66,10 @@ inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, uint64_t 
     const uint32_t cc = (uint32_t)std::min<size_t>(chunk, count - off);
     try {
       size_t ws_bytes = 0;
-      const std::pair<uint64_t, uint32_t> ck(key, cc);
-      auto hit = key ? c->plan_sizes.find(ck) : c->plan_sizes.end();
-      if (hit != c->plan_sizes.end()) {
+      const std::pair<PlanKey, uint32_t> ck(key, cc);
+      auto hit = !key.empty() ? c->plan_sizes.find(ck) : c->plan_sizes.end();
+      const bool cached = hit != c->plan_sizes.end();
+      if (cached) {
         ws_bytes = hit->second;
       } else {
         Assembler sizing(c, cc, true, lane);
@@ -58,7 +77,7 @@ inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, uint64_t 
         if (!sizing.plan_error.empty()) { set_error(sizing.plan_error); return AFX_E_BAD_ARGS; }
         if (sizing.blob_bytes() > BLOB_CAP) { set_error("plan blob exceeds its fixed capacity"); return AFX_E_BAD_ARGS; }
         ws_bytes = sizing.total_ws_bytes();
-        if (key && c->plan_sizes.size() < 4096) c->plan_sizes[ck] = ws_bytes;
+        if (!key.empty() && c->plan_sizes.size() < 4096) c->plan_sizes[ck] = ws_bytes;
       }
       int rc = c->lane[lane].ws.ensure(ws_bytes);
       if (rc) {
@@ -70,6 +89,10 @@ inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, uint64_t 
       }
       Assembler as(c, cc, false, lane);
       build(as, off, cc);
+      if (cached && (as.total_ws_bytes() > c->lane[lane].ws.cap || as.blob_bytes() > BLOB_CAP)) {
+        c->plan_sizes.erase(ck);   // the remembered size does not fit this plan: size the pass again
+        continue;
+      }
       if ((rc = as.run())) return rc;
     } catch (const std::exception& e) {
       set_error(std::string("plan assembly: ") + e.what());

@@ -108,8 +108,8 @@ extern "C" int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* 
       (!s.t || !s.U || !s.V || !s.challenge || !s.responses || (a.n_attributes && !a.values))) { set_error("null batch array"); return AFX_E_BAD_ARGS; }
   struct { uint32_t n, nr; uint8_t kinds[AFX_MAX_ATTRIBUTES]; } kd__;
   memset(&kd__, 0, sizeof kd__);
-  kd__.n = a.n_attributes; kd__.nr = n_responses; memcpy(kd__.kinds, a.kinds, AFX_MAX_ATTRIBUTES);
-  const uint64_t key__ = ctx->trace ? 0 : plan_key("verify_issuances", &kd__, sizeof kd__, 0);
+  kd__.n = a.n_attributes; kd__.nr = n_responses; memcpy(kd__.kinds, a.kinds, std::min<size_t>(a.n_attributes, AFX_MAX_ATTRIBUTES));
+  const PlanKey key__ = ctx->trace ? PlanKey() : plan_key("verify_issuances", &kd__, sizeof kd__, mode_flags(ctx));
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
     afx_ctx* c = as.ctx;
     JobSets js;
@@ -162,8 +162,8 @@ extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, c
   }
   struct { uint32_t n; uint8_t kinds[AFX_MAX_ATTRIBUTES]; } kd__;
   memset(&kd__, 0, sizeof kd__);
-  kd__.n = a.n_attributes; memcpy(kd__.kinds, a.kinds, AFX_MAX_ATTRIBUTES);
-  const uint64_t key__ = plan_key("issue", &kd__, sizeof kd__, ctx->fixed_key_schedule ? 2u : 0u);
+  kd__.n = a.n_attributes; memcpy(kd__.kinds, a.kinds, std::min<size_t>(a.n_attributes, AFX_MAX_ATTRIBUTES));
+  const PlanKey key__ = plan_key("issue", &kd__, sizeof kd__, mode_flags(ctx));
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
     afx_ctx* c = as.ctx;
     const uint32_t n = c->n;
@@ -285,8 +285,8 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
   if (nsp) eo.assign(o.enc, o.enc + nsp);
   struct { uint32_t n; uint8_t kinds[AFX_MAX_ATTRIBUTES]; } kd__;
   memset(&kd__, 0, sizeof kd__);
-  kd__.n = na; memcpy(kd__.kinds, cr.kinds, AFX_MAX_ATTRIBUTES);
-  const uint64_t key__ = plan_key("show", &kd__, sizeof kd__, (ctx->strict ? 1u : 0u) | (no_key ? 4u : 0u));
+  kd__.n = na; memcpy(kd__.kinds, cr.kinds, std::min<size_t>(na, AFX_MAX_ATTRIBUTES));
+  const PlanKey key__ = plan_key("show", &kd__, sizeof kd__, mode_flags(ctx) | (no_key ? 4u : 0u));
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t cc) {
     afx_ctx* c = as.ctx;
     auto row = [&](const uint8_t* base, size_t k) { return base + (k * count + off) * 32; };

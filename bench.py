@@ -413,6 +413,91 @@ def valu_side(ctx, items_per_step, field_kernel_ms_per_step):
             "time_base": "summed durations of the kernels doing field arithmetic (k_msm_*, k_compress2x, k_decode, k_pointop, k_from_uniform)"}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, worker=None, timeout_s=None):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh child processes, one rank per GPU, with the
+    environment torch.distributed.run would give them (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR/PORT), relay rank 0's
+    output line and return non-zero if any rank failed.  The parent never touches the GPU (children are new processes, not
+    an exec of one that initialised HIP).  `worker` is the child command (tests substitute a stub)."""
+    import subprocess
+    worker = worker or [sys.executable, os.path.abspath(__file__)]
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AFX_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(worker + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    t0 = time.time()
+    rc = 0
+    out0 = b""
+    import threading
+    def drain():
+        nonlocal out0
+        out0 = procs[0].stdout.read()
+    th = threading.Thread(target=drain, daemon=True)
+    th.start()
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
+                for o in live:
+                    procs[o].terminate()   # exactly the processes started above
+        if timeout_s is not None and time.time() - t0 > timeout_s and live:
+            sys.stderr.write("bench.py: ranks %s still running after %.0f s; stopping them\n" % (sorted(live), timeout_s))
+            for o in live:
+                procs[o].kill()
+            rc = rc or 124
+            timeout_s = None
+        if live:
+            time.sleep(0.05)
+    th.join(timeout=10)
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
+def tile_items(a, reps):
+    return a if reps == 1 else np.ascontiguousarray(np.concatenate([a] * reps, axis=-2))
+
+
+def group_api_rate(afx, batch, params, key, ip, shape, pres, want, devices, reps):
+    """What the single `&self` call Issuer::verify (/root/reference/src/issuer.rs:141-147) becomes on a node: ONE process, one
+    afx_group over `devices`, afx_group_verify_presentations on host arrays (contiguous split, one host thread and two
+    streams per member, no collective).  The batch is `reps` copies of this rank's (PCIe and staging inclusive, never
+    `value`).  Returns (presentations/s, items)."""
+    g = afx.Group(params, key, ip, devices)
+    try:
+        big = {f: tile_items(pres[f], reps) for f in batch.PRES_FIELDS}
+        big["enc"] = [{f: tile_items(d[f], reps) for f in batch.ENC_FIELDS} for d in pres["enc"]]
+        total = big["challenge"].shape[0]
+        exp = np.concatenate([want] * reps)
+        soa, keep = batch.presentation_soa(big)
+        st = np.full(total, 255, np.uint8)
+        fn = afx.lib().afx_group_verify_presentations
+        afx.check(fn(g.h, C.byref(shape), C.byref(soa), total, st.ctypes.data))   # warm-up: workspaces, staging, pinned buffers
+        st[:] = 255
+        t0 = time.perf_counter()
+        afx.check(fn(g.h, C.byref(shape), C.byref(soa), total, st.ctypes.data))
+        dt = time.perf_counter() - t0
+        assert UNCHECKED or np.array_equal(st, exp), "group API statuses differ from the expected ones"
+        return total / dt, total
+    finally:
+        g.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -424,13 +509,19 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="presentations per GPU (default: the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-group-api", action="store_true", help="skip the afx_group_verify_presentations leg (rank 0, after the timed steps)")
     ap.add_argument("--pipelining", action="store_true", help="alternate steps between the engine's two streams (measured slower: the "
                     "path is VALU-bound, overlap only adds contention; default off)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL; the driver's launch) or gloo (testing two ranks on one GPU)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around this process: be the launcher (before anything here touches the GPU)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks; reporting what runs\n" % (args.gpus, world))
     local_rank = int(os.environ.get("AFX_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     if args.workload is None:
         args.workload = "c3" if world == 1 else "c4"
@@ -514,8 +605,20 @@ def main():
         elapsed = float(t.item())
     got = status.cpu().numpy()
     assert UNCHECKED or np.array_equal(got, want), "status mismatch after the timed steps"
+    ranks_seen = 1
+    if dist is not None:
+        # the measurement is over: every rank leaves the process group here; rank 0 goes on alone with the host-side legs
+        ranks_seen = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
+        if rank != 0:
+            del dpres, soa, status
+            issuer.close()
+            return
     # PCIe-inclusive rate through the host-pointer entry point (never `value`; DESIGN.md quotes it)
     pcie = wire_rate = None
+    group_rate = group_items = group_err = None
     if rank == 0:
         hsoa, keep_h = batch.presentation_soa(pres)
         hst = np.full(count, 255, np.uint8)
@@ -538,6 +641,15 @@ def main():
         wire_rate = wn / (time.perf_counter() - t0)
         assert UNCHECKED or np.array_equal(wst, want[:wn])
         del blob, wsub
+        # ... and through ONE afx_group over the node's GPUs (one process, host arrays): the in-library split
+        if not args.no_group_api:
+            del dpres, soa, status
+            torch.cuda.empty_cache()
+            devices = [local_rank] * world if "AFX_BENCH_DEVICE" in os.environ else list(range(world))
+            try:
+                group_rate, group_items = group_api_rate(afx, batch, params, key, ip, shape, pres, want, devices, world)
+            except Exception as e:   # a missing device must not cost the headline line
+                group_err = "%s: %s" % (type(e).__name__, e)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is an N=1 figure
@@ -577,14 +689,20 @@ def main():
         ab = algorithmic_bytes(shape)
         out = {
             "metric": "credential presentations verified/sec", "value": total / elapsed, "unit": "presentations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "n_gpus": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if args.workload == "c4" else "weak", "vs_baseline": None, "dtype": "int64",
             "data": "synthetic (GPU-issued and GPU-shown credentials, random attribute values, 1% corrupted; all distinct)",
             "config": {"workload": desc, "presentations_per_gpu": count, "attributes": n, "shape": layout, "hidden": hide,
                        "algorithmic_bytes_per_presentation": ab, "parallelism": "host-sharded x%d, no collective" % world,
                        "step_pipelining": "2 streams" if args.pipelining else "off",
                        "input_generation_s": round(gen_s, 2), "host_pointer_api_presentations_per_s": pcie,
-                       "wire_blob_api_presentations_per_s": wire_rate},
+                       "wire_blob_api_presentations_per_s": wire_rate,
+                       "ranks_seen": ranks_seen, "launcher": "bench.py" if os.environ.get("AFX_BENCH_LAUNCHED") else
+                       ("external" if world > 1 else "none"),
+                       "group_api_presentations_per_s": group_rate, "group_api_items": group_items,
+                       "group_api_note": "one process, afx_group_verify_presentations over %d device(s) on host arrays (%d copies of "
+                                         "rank 0's batch), PCIe and staging inclusive" % (world, world),
+                       "group_api_error": group_err},
             "roofline": roofline_of(kt, args.workload, ab, count),
             "valu": valu,
             "cpu_baseline": cpu,
@@ -593,8 +711,6 @@ def main():
             out["unchecked_experiment"] = True
         print(json.dumps(out))
     issuer.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

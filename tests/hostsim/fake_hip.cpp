@@ -30,6 +30,7 @@ hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, 
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)0x1; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)0x1; return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)0x1; return hipSuccess; }
@@ -66,7 +67,7 @@ hipError_t afxk_msm(hipStream_t, int kind, int encodes, const afx_msm_job* j, ui
   return hipSuccess;
 }
 hipError_t afxk_compress2x(hipStream_t, const afx_compress_job* j, uint32_t n, int32_t* ws, uint32_t*, uint32_t count) {
-  for (uint32_t i = 0; i < n; i++) { sink += (uintptr_t)j[i].var + (uintptr_t)j[i].out_enc; ws[(size_t)i * 10 * count] = 1; ws[((size_t)i * 10 + 9) * count + count - 1] = 1; }
+  for (uint32_t i = 0; i < n; i++) { sink += (uintptr_t)j[i].var + (uintptr_t)j[i].out_enc; ws[(size_t)i * 9 * count] = 1; ws[((size_t)i * 9 + 8) * count + count - 1] = 1; }
   return hipSuccess;
 }
 hipError_t afxk_hash(hipStream_t, const afx_hash_program* p, uint32_t n, uint32_t*, uint32_t) {

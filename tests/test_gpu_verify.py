@@ -278,3 +278,43 @@ def test_identity_commitments_beside_ordinary_ones():
         assert bytes(tr[1 + e, 1]) == bytes(pres[1].enc[e].challenge)
     assert bytes(tr[0, 3]) == bytes(pres[3].challenge) and bytes(tr[1, 3]) == bytes(pres[3].enc[0].challenge)
     ctx.close()
+
+
+def test_workspace_growth_while_an_earlier_dev_call_is_in_flight():
+    """The *_dev calls are asynchronous.  A small call followed at once by one that needs a larger workspace must not have
+    its live workspace (bad[] flags, tables, digits) wiped or freed under it (round-2 advisor finding: a cleared bad[] flag
+    is a false accept).  Fresh contexts so that the second call really grows the buffer; repeated to give a race room."""
+    import ctypes as C
+    import torch
+    import aeonflux_amd as afx
+    from aeonflux_amd import batch
+    from tests.soa import presentation_arrays, shape_of
+    params, key, ip, issuer, pres = make_batch(4, "SSPE", [0, 3], 48, b"gpu-grow-race")
+    corrupt(pres, b"grow-race-corrupt")
+    want = np.array([issuer.verify_presentation(p) for p in pres], np.uint8)
+    assert want.any() and not want.all()
+    a = presentation_arrays(pres)
+    sh = afx.Shape.from_buffer_copy(bytes(shape_of(pres[0])))
+    reps = 1400   # 48 * 1400 = 67 200 items: a workspace some hundred times the small call's
+    big = {f: np.ascontiguousarray(np.concatenate([a[f]] * reps, axis=-2)) for f in batch.PRES_FIELDS}
+    big["enc"] = [{f: np.ascontiguousarray(np.concatenate([d[f]] * reps, axis=-2)) for f in batch.ENC_FIELDS} for d in a["enc"]]
+    dev = torch.device("cuda", 0)
+
+    def to_dev(p):
+        d = {f: torch.from_numpy(p[f]).to(dev) for f in batch.PRES_FIELDS}
+        d["enc"] = [{f: torch.from_numpy(e[f]).to(dev) for f in batch.ENC_FIELDS} for e in p["enc"]]
+        return d
+    d_small, d_big = to_dev(a), to_dev(big)
+    soa_s, keep_s = batch.presentation_soa(d_small, ptr=lambda t: t.data_ptr())
+    soa_b, keep_b = batch.presentation_soa(d_big, ptr=lambda t: t.data_ptr())
+    fn = afx.lib().afx_verify_presentations_dev
+    for _ in range(6):
+        ctx = afx.Context(params, key, ip)
+        st_s = torch.full((48,), 77, dtype=torch.uint8, device=dev)
+        st_b = torch.full((48 * reps,), 77, dtype=torch.uint8, device=dev)
+        afx.check(fn(ctx.h, C.byref(sh), C.byref(soa_s), 48, st_s.data_ptr()))
+        afx.check(fn(ctx.h, C.byref(sh), C.byref(soa_b), 48 * reps, st_b.data_ptr()))   # no synchronisation in between
+        ctx.synchronize()
+        assert np.array_equal(st_s.cpu().numpy(), want)
+        assert np.array_equal(st_b.cpu().numpy(), np.tile(want, reps))
+        ctx.close()

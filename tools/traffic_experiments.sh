@@ -1,6 +1,7 @@
 #!/bin/bash
-# Table-traffic experiments: for the shipped build and each experiment build in variants/ (built with
-# -DAFX_EXPERIMENT_*, see kernels.hip), the per-kernel time of C3 verification and C5 issuance and the HBM traffic of the MSM
+# Table-traffic experiments: for the shipped build and each experiment build in variants/ (built by tools/build_variant.sh from
+# tools/experiments/r02_table_traffic_switches.patch with
+# -DAFX_EXPERIMENT_*; the switches are not in the shipping sources), the per-kernel time of C3 verification and C5 issuance and the HBM traffic of the MSM
 # kernels (separate FETCH_SIZE / WRITE_SIZE passes).  Run on the GPU box:  bash tools/traffic_experiments.sh <variant.so>...
 # Output: gpurun_out/traffic_experiments.txt
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
