@@ -40,6 +40,11 @@ class PresentationSoA(C.Structure):
                [("enc", C.POINTER(EncProofSoA))]
 
 
+class PresentationGroup(C.Structure):
+    """afx_presentation_group: one same-shape group of a mixed request (afx_verify_presentations_mixed)"""
+    _fields_ = [("shape", Shape), ("batch", PresentationSoA), ("count", C.c_size_t), ("positions", C.POINTER(C.c_uint64))]
+
+
 class AttributesSoA(C.Structure):
     _fields_ = [("n_attributes", C.c_uint32), ("kinds", C.c_uint8 * MAX_ATTRIBUTES), ("values", C.c_void_p)]
 
@@ -123,6 +128,10 @@ def lib():
         _LIB.afx_wire_cells_per_record.argtypes = [C.POINTER(Shape)]
         _LIB.afx_wire_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Shape), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         _LIB.afx_verify_presentations_wire.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        _LIB.afx_wire_section_bytes.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        _LIB.afx_verify_presentations_mixed_wire.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        for name in ("afx_verify_presentations_mixed", "afx_group_verify_presentations_mixed"):
+            getattr(_LIB, name).argtypes = [C.c_void_p, C.POINTER(PresentationGroup), C.c_size_t, C.c_void_p, C.c_size_t]
         _LIB.afx_ctx_set_pipelining.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_get_plan_stats.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.afx_ctx_set_strict.argtypes = [C.c_void_p, C.c_int]

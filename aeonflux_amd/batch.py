@@ -183,19 +183,28 @@ def shape_key(shape):
 
 def verify_mixed(ctx, items):
     """Issuer::verify over presentations of different shapes: items = [(Shape, presentation dict with count 1 or more)].
-    Groups by shape on the host, runs one batch per group, returns the statuses in the order given."""
-    groups = {}
+    The items of one shape become one afx_presentation_group (arrays concatenated here: bytes only); the library runs one GPU
+    batch per group (afx_verify_presentations_mixed, or its afx_group_* form when ctx is a Group) and writes every status at
+    its presentation's place in the order given.  Returns the list of per-item status arrays."""
+    from . import PresentationGroup
+    groups, start, total = {}, [], 0
     for pos, (shape, p) in enumerate(items):
-        groups.setdefault(shape_key(shape), (shape, []))[1].append((pos, p))
-    out = [None] * len(items)
-    for shape, members in groups.values():
-        cat = {f: np.concatenate([_u8(p[f]) for _, p in members], axis=-2) for f in PRES_FIELDS}
-        cat["enc"] = [{f: np.concatenate([_u8(p["enc"][e][f]) for _, p in members], axis=-2) for f in ENC_FIELDS}
+        k = _u8(p["challenge"]).shape[0]
+        groups.setdefault(shape_key(shape), (shape, []))[1].append((total, k, p))
+        start.append((total, k))
+        total += k
+    arr = (PresentationGroup * max(1, len(groups)))()
+    keep = []
+    for g, (shape, members) in enumerate(groups.values()):
+        cat = {f: np.concatenate([_u8(p[f]) for _, _, p in members], axis=-2) for f in PRES_FIELDS}
+        cat["enc"] = [{f: np.concatenate([_u8(p["enc"][e][f]) for _, _, p in members], axis=-2) for f in ENC_FIELDS}
                       for e in range(shape.n_enc_proofs)]
-        st = verify_presentations(ctx, shape, cat)
-        o = 0
-        for pos, p in members:
-            k = _u8(p["challenge"]).shape[0]
-            out[pos] = st[o:o + k]
-            o += k
-    return out
+        soa, encs = presentation_soa(cat)
+        positions = np.concatenate([np.arange(o, o + k, dtype=np.uint64) for o, k, _ in members])
+        arr[g].shape, arr[g].batch, arr[g].count = shape, soa, positions.size
+        arr[g].positions = positions.ctypes.data_as(C.POINTER(C.c_uint64))
+        keep.append((cat, soa, encs, positions))
+    status = np.full(total, 255, np.uint8)
+    fn = lib().afx_group_verify_presentations_mixed if hasattr(ctx, "member") else lib().afx_verify_presentations_mixed
+    check(fn(ctx.h, arr, len(groups), status.ctypes.data, total))
+    return [status[o:o + k] for o, k in start]

@@ -1,0 +1,145 @@
+// Presentations of different shapes behind one call (include/aeonflux_gpu.h, "presentations of DIFFERENT shapes").
+// Issuer::verify (/root/reference/src/issuer.rs:141-147) accepts any presentation; its shape is per presentation
+// (src/nizk/presentation.rs:118-127, :293-309).  The GPU batch is shape-uniform, so a mixed stream is grouped here, on the
+// host, by the used part of the shape; each group is one ordinary batch call of this library and the status bytes go back to
+// the caller's order.  Only bytes move on the host (record copies when a shape's sections are not adjacent).
+#include <map>
+#include <string>
+#include <vector>
+#include "statements.hpp"
+
+namespace {
+
+std::string shape_key(const afx_shape& sh) {
+  const afx_shape c = canonical_shape(sh);
+  return std::string((const char*)&c, sizeof c);
+}
+uint32_t rd32(const uint8_t* b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); }
+
+// positions given: each < status_len and used once over all groups; not given: contiguous after the groups before
+int check_positions(const afx_presentation_group* groups, size_t n_groups, size_t status_len) {
+  std::vector<uint8_t> used(status_len, 0);
+  size_t next = 0;
+  for (size_t g = 0; g < n_groups; g++) {
+    const afx_presentation_group& G = groups[g];
+    for (size_t i = 0; i < G.count; i++) {
+      const uint64_t p = G.positions ? G.positions[i] : (uint64_t)(next + i);
+      if (p >= status_len) { set_error("group " + std::to_string(g) + ": position outside the status array"); return AFX_E_BAD_ARGS; }
+      if (used[p]) { set_error("group " + std::to_string(g) + ": a status position is used twice"); return AFX_E_BAD_ARGS; }
+      used[p] = 1;
+    }
+    next += G.count;
+  }
+  return AFX_OK;
+}
+
+template <class VerifyOne>
+int verify_groups(const afx_presentation_group* groups, size_t n_groups, uint8_t* status, size_t status_len, VerifyOne&& verify_one) {
+  if ((!groups && n_groups) || (!status && status_len)) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  int rc = check_positions(groups, n_groups, status_len);
+  if (rc) return rc;
+  std::vector<uint8_t> tmp;
+  size_t next = 0;
+  for (size_t g = 0; g < n_groups; g++) {
+    const afx_presentation_group& G = groups[g];
+    if (G.count) {
+      if (!G.positions) {
+        if ((rc = verify_one(G, status + next))) return rc;
+      } else {
+        tmp.assign(G.count, AFX_ST_VERIFICATION_FAILURE);
+        if ((rc = verify_one(G, tmp.data()))) return rc;
+        for (size_t i = 0; i < G.count; i++) status[G.positions[i]] = tmp[i];
+      }
+    }
+    next += G.count;
+  }
+  return AFX_OK;
+}
+
+}  // namespace
+
+extern "C" int afx_verify_presentations_mixed(afx_ctx* ctx, const afx_presentation_group* groups, size_t n_groups, uint8_t* status,
+                                              size_t status_len) try {
+  if (!ctx) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  return verify_groups(groups, n_groups, status, status_len, [&](const afx_presentation_group& G, uint8_t* st) {
+    return afx_verify_presentations(ctx, &G.shape, &G.batch, G.count, st);
+  });
+} catch (...) { return afx::exception_rc(); }
+
+extern "C" int afx_group_verify_presentations_mixed(afx_group* group, const afx_presentation_group* groups, size_t n_groups, uint8_t* status,
+                                                    size_t status_len) try {
+  if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  return verify_groups(groups, n_groups, status, status_len, [&](const afx_presentation_group& G, uint8_t* st) {
+    return afx_group_verify_presentations(group, &G.shape, &G.batch, G.count, st);
+  });
+} catch (...) { return afx::exception_rc(); }
+
+extern "C" int afx_wire_section_bytes(const uint8_t* blob, size_t len, size_t* section_len_out) try {
+  if (!blob || !section_len_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (len < 32 || memcmp(blob, "AFXP", 4) != 0 || rd32(blob + 4) != 1) { set_error("not an AFXP v1 section"); return AFX_E_BAD_ARGS; }
+  const uint64_t count = rd32(blob + 8), cells = rd32(blob + 12);
+  const uint32_t n = rd32(blob + 16), nr = rd32(blob + 20), hs = rd32(blob + 24), ne = rd32(blob + 28);
+  if (n > AFX_MAX_ATTRIBUTES || nr > 3 + AFX_MAX_ATTRIBUTES || hs > AFX_MAX_ATTRIBUTES || ne > AFX_MAX_ATTRIBUTES) { set_error("shape field out of range"); return AFX_E_BAD_ARGS; }
+  const size_t hdr = (32 + (size_t)n + 2 * (size_t)hs + 2 * (size_t)ne + 31) & ~size_t(31);
+  if (cells > 4 + 3 * (uint64_t)AFX_MAX_ATTRIBUTES + 14 * (uint64_t)AFX_MAX_ATTRIBUTES + 3) { set_error("cells_per_record out of range"); return AFX_E_BAD_ARGS; }
+  const uint64_t total = (uint64_t)hdr + count * cells * 32;   // < 2^32 * 2^10 * 2^5: no overflow
+  if (total > len) { set_error("section runs past the end of the blob"); return AFX_E_BAD_ARGS; }
+  *section_len_out = (size_t)total;
+  return AFX_OK;
+} catch (...) { return afx::exception_rc(); }
+
+extern "C" int afx_verify_presentations_mixed_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap,
+                                                   size_t* count_out) try {
+  if (!ctx || (!blob && len) || !count_out || (!status && status_cap)) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  struct Section { size_t off, len, hdr, count, first; };
+  struct Group { std::vector<Section> sections; size_t count = 0; };
+  std::map<std::string, Group> by_shape;
+  std::vector<std::string> order;   // groups in order of first appearance
+  size_t total = 0;
+  for (size_t off = 0; off < len;) {
+    size_t sl = 0;
+    int rc = afx_wire_section_bytes(blob + off, len - off, &sl);
+    if (rc) { set_error("section at byte " + std::to_string(off) + ": " + afx_last_error()); return rc; }
+    afx_shape sh;
+    size_t cnt = 0, rec = 0;
+    if ((rc = afx_wire_parse(blob + off, sl, &sh, &cnt, &rec))) { set_error("section at byte " + std::to_string(off) + ": " + afx_last_error()); return rc; }
+    const std::string key = shape_key(sh);
+    auto it = by_shape.find(key);
+    if (it == by_shape.end()) { it = by_shape.emplace(key, Group()).first; order.push_back(key); }
+    it->second.sections.push_back({ off, sl, rec, cnt, total });
+    it->second.count += cnt;
+    total += cnt;
+    off += sl;
+  }
+  *count_out = total;
+  if (total > status_cap) { set_error("status buffer too small"); return AFX_E_BAD_ARGS; }
+  std::vector<uint8_t> merged, st;
+  for (const std::string& key : order) {
+    const Group& G = by_shape[key];
+    if (G.count == 0) continue;
+    size_t got = 0;
+    if (G.sections.size() == 1) {   // the section as it lies in the caller's blob; its statuses are contiguous in the stream
+      const Section& S = G.sections[0];
+      const int rc = afx_verify_presentations_wire(ctx, blob + S.off, S.len, status + S.first, S.count, &got);
+      if (rc) return rc;
+      continue;
+    }
+    if (G.count > 0xffffffffu) { set_error("too many presentations of one shape"); return AFX_E_BAD_ARGS; }
+    // one header (the first section's, with the group's count) and every section's records behind it
+    const Section& S0 = G.sections[0];
+    size_t bytes = S0.hdr;
+    for (const Section& S : G.sections) bytes += S.len - S.hdr;
+    merged.resize(bytes);
+    memcpy(merged.data(), blob + S0.off, S0.hdr);
+    const uint32_t c32 = (uint32_t)G.count;
+    for (int b = 0; b < 4; b++) merged[8 + b] = (uint8_t)(c32 >> (8 * b));
+    size_t w = S0.hdr;
+    for (const Section& S : G.sections) { memcpy(merged.data() + w, blob + S.off + S.hdr, S.len - S.hdr); w += S.len - S.hdr; }
+    st.assign(G.count, AFX_ST_VERIFICATION_FAILURE);
+    const int rc = afx_verify_presentations_wire(ctx, merged.data(), merged.size(), st.data(), st.size(), &got);
+    if (rc) return rc;
+    size_t r = 0;
+    for (const Section& S : G.sections) { memcpy(status + S.first, st.data() + r, S.count); r += S.count; }
+  }
+  return AFX_OK;
+} catch (...) { return afx::exception_rc(); }

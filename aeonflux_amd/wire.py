@@ -69,6 +69,22 @@ def unpack_presentations(blob):
     return shape, p
 
 
+def pack_mixed(items):
+    """[(Shape, SoA presentation dict)] -> AFXP sections back to back, in the order given (a request stream of mixed shapes)"""
+    return b"".join(pack_presentations(shape, p) for shape, p in items)
+
+
+def verify_mixed_wire(ctx, blob):
+    """afx_verify_presentations_mixed_wire: statuses of a stream of AFXP sections, in stream order"""
+    import ctypes as C
+    from . import check, lib
+    n = C.c_size_t(0)
+    cap = max(1, len(blob) // 32)   # a record is at least one cell
+    status = np.full(cap, 255, np.uint8)
+    check(lib().afx_verify_presentations_mixed_wire(ctx.h, blob, len(blob), status.ctypes.data, cap, C.byref(n)))
+    return status[:n.value]
+
+
 # ---- CredentialIssuance batches ("AFXI" v1) -------------------------------------------------------
 def pack_issuances(kinds, values, iss):
     """kinds: AFX_ATTR_* per position; values [n,count,32]; iss: dict t,U,V,challenge [count,32], responses [nr,count,32]"""

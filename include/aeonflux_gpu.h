@@ -255,6 +255,38 @@ int afx_wire_parse(const uint8_t* blob, size_t len, afx_shape* shape_out, size_t
  * kernel, and verified.  status must hold `count` bytes (status_cap >= count). */
 int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out);
 
+/* ---- presentations of DIFFERENT shapes in one call ------------------------------------------------------------------
+ * Issuer::verify takes any presentation (src/issuer.rs:141-147): the shape - which attributes are hidden, how many proofs of
+ * encryption ride along - is per presentation (src/nizk/presentation.rs:118-127, :293-309), and a server's request stream
+ * mixes them.  The two entry points below group such a stream by shape inside the library, run one GPU batch per distinct
+ * shape and put every status byte where its presentation stood in the caller's order.  Two shapes are the same group when
+ * their used fields are equal (counts, kinds[0..n), hidden_scalar_indices[0..hs), enc_indices[0..ne)); array tails are ignored. */
+
+/* Length in bytes (header + records) of the AFXP v1 section that starts at `blob`, from its header alone; AFX_E_BAD_ARGS if the
+ * header is malformed or the section would run past `len`. */
+int afx_wire_section_bytes(const uint8_t* blob, size_t len, size_t* section_len_out);
+/* `blob` = AFXP v1 sections back to back, in arrival order; each section is a complete same-shape batch (count >= 1; one
+ * serialized presentation is a section with count = 1).  Sections of equal shape are merged into one batch whatever their
+ * position in the stream.  status[i] answers the i-th presentation of the stream; *count_out = their number.
+ * A section whose shape the reference would panic on fails its own items only.  Records are copied once on the host when
+ * a group spans several sections (bytes only; no arithmetic leaves the GPU). */
+int afx_verify_presentations_mixed_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out);
+
+/* The same over struct-of-arrays groups (host pointers).  `positions`, when not NULL, holds for each of the group's items its
+ * index in the caller's order: status[positions[i]] answers item i of the group (every index < status_len, each used once
+ * over all groups - checked before anything runs).  With positions == NULL the group's statuses are written contiguously,
+ * after those of the groups before it.  Groups may repeat a shape. */
+typedef struct {
+  afx_shape shape;
+  afx_presentation_soa batch;  /* the group's own arrays: [k][count][32]                        */
+  size_t count;
+  const uint64_t* positions;   /* [count] or NULL                                               */
+} afx_presentation_group;
+int afx_verify_presentations_mixed(afx_ctx* ctx, const afx_presentation_group* groups, size_t n_groups, uint8_t* status, size_t status_len);
+/* ... and over a group of GPUs: every shape group is split over the members like afx_group_verify_presentations. */
+int afx_group_verify_presentations_mixed(afx_group* group, const afx_presentation_group* groups, size_t n_groups, uint8_t* status,
+                                         size_t status_len);
+
 /* A batch of CredentialIssuance messages of one attribute layout (issuer.rs:42-45: proof + credential{amac, attributes};
  * the reference has no to_bytes for it either), same style:
  *   header : "AFXI" | u32le version (1) | u32le count | u32le cells_per_record | u32le n_attributes | u32le n_responses

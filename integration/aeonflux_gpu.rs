@@ -9,15 +9,18 @@
 //   GpuUser::verify_issuance_batch(Vec<CredentialIssuance>)  per item = CredentialIssuance::verify (src/issuer.rs:48-57)
 // and GpuIssuer::new_multi(issuer, &[devices]) puts the same issuer on several GPUs (afx_group_*).
 //
-// Randomness.  The engine takes every random draw as an input array, so the shim draws exactly what the reference draws,
-// in the reference's order:
-//   issue : per request, from the caller's csprng: 64 bytes for `Scalar::random` (t, src/amacs.rs:289), then 64 bytes for
-//           `RistrettoPoint::random` (U, src/amacs.rs:290); then 32 bytes from rand::thread_rng() - the draw zkp's
-//           `prove_compact` makes through merlin's `TranscriptRngBuilder::finalize(&mut thread_rng())` [3P].
-//   show  : per credential, from the caller's csprng: 64 bytes for `Scalar::random` (z, src/nizk/presentation.rs:162); then
-//           from rand::thread_rng(): 32 bytes for the presentation proof's own `prove_compact` (presentation.rs:284), then
-//           32 bytes per ProofOfEncryption, one per SecretPoint attribute in attribute order (presentation.rs:293-309 ->
+// Randomness.  The engine takes every random draw as an input array.  The shim draws, from the CALLER's csprng only:
+//   issue : per request, in the reference's order: 64 bytes for `Scalar::random` (t, src/amacs.rs:289), then 64 bytes for
+//           `RistrettoPoint::random` (U, src/amacs.rs:290); after all of those, 32 bytes per request that stand in for the draw
+//           zkp's `prove_compact` makes from thread_rng() through merlin's `TranscriptRngBuilder::finalize` [3P].
+//   show  : per credential 64 bytes for `Scalar::random` (z, src/nizk/presentation.rs:162); after all of those, 32 bytes per
+//           credential for the presentation proof's own `prove_compact` (presentation.rs:284), then 32 bytes per
+//           ProofOfEncryption, one per SecretPoint attribute in attribute order (presentation.rs:293-309 ->
 //           src/nizk/encryption.rs:141).
+// So a caller's deterministic csprng yields the reference's t, U and z, and the proofs' synthetic nonces come from the same
+// generator instead of the reference's hidden thread_rng() - `rand` is only a dev-dependency of the crate (Cargo.toml:42-45) and
+// the shim must not need it.  Every buffer that held such bytes (and the user's symmetric keys) is zeroized on drop, as the
+// crate does for what they become (src/amacs.rs:64-82, src/symmetric.rs:51-64).
 // The #[repr(C)] structs below mirror include/aeonflux_gpu.h field for field; tests/test_integration_layouts.py checks
 // names, order and widths against the header without a Rust compiler.
 #![allow(non_snake_case)]
@@ -27,6 +30,7 @@ use core::ffi::c_void;
 use curve25519_dalek::ristretto::{CompressedRistretto, RistrettoPoint};
 use curve25519_dalek::scalar::Scalar;
 use rand_core::{CryptoRng, RngCore};
+use zeroize::Zeroize;
 use zkp::CompactProof;
 
 use crate::amacs::{Amac, Attribute, EncryptedAttribute};
@@ -42,6 +46,7 @@ use crate::user::CredentialRequest;
 
 pub const AFX_MAX_ATTRIBUTES: usize = 32;
 
+#[derive(Clone, Copy)]
 #[repr(C)]
 pub struct AfxShape {
     pub n_attributes: u32,
@@ -103,6 +108,19 @@ pub struct AfxPresentationOut {
     pub C_y: *mut u8, pub attr_values: *mut u8, pub enc: *const AfxEncProofOut,
 }
 
+#[repr(C)]
+pub struct AfxPresentationGroup {
+    pub shape: AfxShape,
+    pub batch: AfxPresentationSoa,
+    pub count: usize,
+    pub positions: *const u64,
+}
+
+/// Bytes that must not outlive the call: randomness the proofs' nonces come from, staged symmetric keys.
+struct Wiped(Vec<u8>);
+impl Wiped { fn new(len: usize) -> Wiped { Wiped(vec![0u8; len]) } }
+impl Drop for Wiped { fn drop(&mut self) { self.0.zeroize(); } }
+
 // per-item status bytes (AFX_ST_*) and amacs::Attribute kinds (AFX_ATTR_*) of include/aeonflux_gpu.h
 const ST_OK: u8 = 0;
 const ST_VERIFICATION_FAILURE: u8 = 1;
@@ -120,6 +138,10 @@ extern "C" {
     fn afx_ctx_destroy(ctx: *mut c_void);
     fn afx_verify_presentations(ctx: *mut c_void, shape: *const AfxShape, batch: *const AfxPresentationSoa,
                                 count: usize, status: *mut u8) -> i32;
+    fn afx_verify_presentations_mixed(ctx: *mut c_void, groups: *const AfxPresentationGroup, n_groups: usize, status: *mut u8,
+                                      status_len: usize) -> i32;
+    fn afx_group_verify_presentations_mixed(group: *mut c_void, groups: *const AfxPresentationGroup, n_groups: usize, status: *mut u8,
+                                            status_len: usize) -> i32;
     fn afx_issue(ctx: *mut c_void, requests: *const AfxAttributesSoa, rnd: *const AfxIssueRandomness, count: usize,
                  out: *const AfxIssuanceSoa, status: *mut u8) -> i32;
     fn afx_verify_issuances(ctx: *mut c_void, attrs: *const AfxAttributesSoa, issuances: *const AfxIssuanceSoa,
@@ -211,6 +233,7 @@ impl GpuIssuer {
         let count = requests.len();
         if count == 0 { return Vec::new(); }
         let na = requests[0].attributes.len();
+        assert!(na <= AFX_MAX_ATTRIBUTES, "issue_batch: more than AFX_MAX_ATTRIBUTES attributes");
         let mut soa = AfxAttributesSoa { n_attributes: na as u32, kinds: [0; AFX_MAX_ATTRIBUTES], values: core::ptr::null() };
         let mut values = vec![0u8; 32 * na * count];
         for (i, r) in requests.iter().enumerate() {
@@ -223,13 +246,13 @@ impl GpuIssuer {
         }
         soa.values = values.as_ptr();
         // the reference's draws, in its order (see the header of this file)
-        let (mut t_wide, mut u_wide, mut seed) = (vec![0u8; 64 * count], vec![0u8; 64 * count], vec![0u8; 32 * count]);
+        let (mut t_wide, mut u_wide, mut seed) = (Wiped::new(64 * count), Wiped::new(64 * count), Wiped::new(32 * count));
         for i in 0..count {
-            csprng.fill_bytes(&mut t_wide[64 * i..64 * i + 64]);      // Scalar::random          (src/amacs.rs:289)
-            csprng.fill_bytes(&mut u_wide[64 * i..64 * i + 64]);      // RistrettoPoint::random  (src/amacs.rs:290)
+            csprng.fill_bytes(&mut t_wide.0[64 * i..64 * i + 64]);    // Scalar::random          (src/amacs.rs:289)
+            csprng.fill_bytes(&mut u_wide.0[64 * i..64 * i + 64]);    // RistrettoPoint::random  (src/amacs.rs:290)
         }
-        rand::thread_rng().fill_bytes(&mut seed);                     // zkp prove_compact's thread_rng() draw, 32 B per proof
-        let rnd = AfxIssueRandomness { t_wide: t_wide.as_ptr(), U_wide: u_wide.as_ptr(), rng_seed: seed.as_ptr() };
+        csprng.fill_bytes(&mut seed.0);                               // in place of zkp prove_compact's thread_rng() draw, 32 B per proof
+        let rnd = AfxIssueRandomness { t_wide: t_wide.0.as_ptr(), U_wide: u_wide.0.as_ptr(), rng_seed: seed.0.as_ptr() };
         let nr = self.n + 5;                                          // w, w', x_0, x_1, y_0..y_{n-1}, "1" (src/nizk/issuance.rs:52-68)
         let (mut t, mut u, mut v, mut ch, mut rs) = (vec![0u8; 32 * count], vec![0u8; 32 * count], vec![0u8; 32 * count], vec![0u8; 32 * count], vec![0u8; 32 * nr * count]);
         let out = AfxIssuanceSoa { t: t.as_mut_ptr(), U: u.as_mut_ptr(), V: v.as_mut_ptr(), challenge: ch.as_mut_ptr(), responses: rs.as_mut_ptr() };
@@ -248,26 +271,44 @@ impl GpuIssuer {
         }).collect()
     }
 
-    /// Batch `Issuer::verify`.  All presentations must share one shape (same attribute kinds, hidden indices and
-    /// number of proofs of encryption); group mixed traffic by shape first.
+    /// Batch `Issuer::verify` (src/issuer.rs:141-147) over ANY presentations: like the reference, which reads the shape from
+    /// each presentation's own fields (src/nizk/presentation.rs:293-309, :324-443), the batch is grouped by the full shape -
+    /// attribute kinds, hidden scalar indices, response count, the indices of the attached proofs of encryption - and every
+    /// group is verified under its own statement.  Results come back in the order given.  A presentation whose vectors do not
+    /// fit together (lengths the reference would index out of range on, `presentation.rs:346,351,407`; a proof of encryption
+    /// without its six responses, which zkp rejects) is answered with `VerificationFailure` without reaching the engine.
     pub fn verify_batch(&self, batch: &[ProofOfValidCredential]) -> Vec<Result<(), CredentialError>> {
-        if batch.is_empty() { return Vec::new(); }
-        let count = batch.len();
-        let (shape, cols) = marshal(batch);
-        let enc_soa: Vec<AfxEncProofSoa> = cols.enc.iter().map(|e| AfxEncProofSoa {
+        let total = batch.len();
+        if total == 0 { return Vec::new(); }
+        let mut status = vec![ST_VERIFICATION_FAILURE; total];
+        let mut by_shape: std::collections::BTreeMap<Vec<u8>, Vec<usize>> = std::collections::BTreeMap::new();
+        for (i, p) in batch.iter().enumerate() {
+            if let Some(key) = shape_key(p) { by_shape.entry(key).or_insert_with(Vec::new).push(i); }   // else: stays a failure
+        }
+        // the staged columns, position lists and struct arrays of every group live until the call returns
+        let staged: Vec<(AfxShape, Columns, Vec<u64>)> = by_shape.values().map(|members| {
+            let items: Vec<&ProofOfValidCredential> = members.iter().map(|i| &batch[*i]).collect();
+            let (shape, cols) = marshal(&items);
+            (shape, cols, members.iter().map(|i| *i as u64).collect())
+        }).collect();
+        let enc_soas: Vec<Vec<AfxEncProofSoa>> = staged.iter().map(|(_, cols, _)| cols.enc.iter().map(|e| AfxEncProofSoa {
             challenge: e[0].as_ptr(), responses: e[1].as_ptr(), pk: e[2].as_ptr(), E1: e[3].as_ptr(), E2: e[4].as_ptr(),
-            C_y_1: e[5].as_ptr(), C_y_2: e[6].as_ptr(), C_y_3: e[7].as_ptr(), C_y_2p: e[8].as_ptr() }).collect();
-        let soa = AfxPresentationSoa {
-            challenge: cols.challenge.as_ptr(), responses: cols.responses.as_ptr(), C_x_0: cols.c_x_0.as_ptr(),
-            C_x_1: cols.c_x_1.as_ptr(), C_V: cols.c_v.as_ptr(), C_y: cols.c_y.as_ptr(), attr_values: cols.attr_values.as_ptr(),
-            enc: enc_soa.as_ptr() };
-        let mut status = vec![0u8; count];
+            C_y_1: e[5].as_ptr(), C_y_2: e[6].as_ptr(), C_y_3: e[7].as_ptr(), C_y_2p: e[8].as_ptr() }).collect()).collect();
+        let groups: Vec<AfxPresentationGroup> = staged.iter().zip(enc_soas.iter()).map(|((shape, cols, positions), enc)| AfxPresentationGroup {
+            shape: *shape,
+            batch: AfxPresentationSoa {
+                challenge: cols.challenge.as_ptr(), responses: cols.responses.as_ptr(), C_x_0: cols.c_x_0.as_ptr(),
+                C_x_1: cols.c_x_1.as_ptr(), C_V: cols.c_v.as_ptr(), C_y: cols.c_y.as_ptr(), attr_values: cols.attr_values.as_ptr(),
+                enc: enc.as_ptr() },
+            count: positions.len(),
+            positions: positions.as_ptr(),
+        }).collect();
         let rc = unsafe {
-            if self.group.is_null() { afx_verify_presentations(self.ctx, &shape, &soa, count, status.as_mut_ptr()) }
-            else { afx_group_verify_presentations(self.group, &shape, &soa, count, status.as_mut_ptr()) }
+            if self.group.is_null() { afx_verify_presentations_mixed(self.ctx, groups.as_ptr(), groups.len(), status.as_mut_ptr(), total) }
+            else { afx_group_verify_presentations_mixed(self.group, groups.as_ptr(), groups.len(), status.as_mut_ptr(), total) }
         };
         assert!(rc == 0, "aeonflux_gpu: engine error {}", rc);
-        status.iter().map(|s| if *s == 0 { Ok(()) } else { Err(CredentialError::VerificationFailure) }).collect()
+        status.iter().map(|s| if *s == ST_OK { Ok(()) } else { Err(CredentialError::VerificationFailure) }).collect()
     }
 }
 
@@ -305,12 +346,15 @@ impl GpuUser {
         let count = creds.len();
         if count == 0 { return Vec::new(); }
         let na = creds[0].attributes.len();
+        assert!(na <= AFX_MAX_ATTRIBUTES, "show_batch: more than AFX_MAX_ATTRIBUTES attributes");
         let mut cs = AfxCredentialsSoa { n_attributes: na as u32, kinds: [0; AFX_MAX_ATTRIBUTES], values: core::ptr::null(), M2: core::ptr::null(),
                                          m3: core::ptr::null(), t: core::ptr::null(), U: core::ptr::null(), V: core::ptr::null() };
-        let (mut values, mut m2, mut m3) = (vec![0u8; 32 * na * count], vec![0u8; 32 * na * count], vec![0u8; 32 * na * count]);
+        // hidden attribute values are secrets of the user (amacs::Attribute zeroizes them, src/amacs.rs:184-200)
+        let (mut values_w, mut m2_w, mut m3_w) = (Wiped::new(32 * na * count), Wiped::new(32 * na * count), Wiped::new(32 * na * count));
+        let (values, m2, m3) = (&mut values_w.0, &mut m2_w.0, &mut m3_w.0);
         let (mut t, mut u, mut v) = (vec![0u8; 32 * count], vec![0u8; 32 * count], vec![0u8; 32 * count]);
         for (i, c) in creds.iter().enumerate() {
-            assert!(c.attributes.len() == na, "show_batch: mixed attribute counts");
+            assert!(c.attributes.len() == na, "show_batch: mixed attribute counts; group credentials by layout first");
             for (k, a) in c.attributes.iter().enumerate() {
                 let (kind, val, plain) = attribute_cells(a);
                 if i == 0 { cs.kinds[k] = kind; } else { assert!(cs.kinds[k] == kind, "show_batch: mixed attribute kinds"); }
@@ -327,23 +371,23 @@ impl GpuUser {
         let secret_points: Vec<usize> = (0..na).filter(|k| cs.kinds[*k] == ATTR_SECRET_POINT).collect();
         let nsp = secret_points.len();
         // keypairs (symmetric::Keypair, src/symmetric.rs:52-81)
-        let (mut ka, mut ka0, mut ka1, mut kpk) = (vec![0u8; 32 * count], vec![0u8; 32 * count], vec![0u8; 32 * count], vec![0u8; 32 * count]);
+        let (mut ka, mut ka0, mut ka1, mut kpk) = (Wiped::new(32 * count), Wiped::new(32 * count), Wiped::new(32 * count), vec![0u8; 32 * count]);
         if let Some(kps) = keypairs {
             assert!(kps.len() == count, "show_batch: one keypair per credential");
             for (i, kp) in kps.iter().enumerate() {
-                ka[32 * i..32 * i + 32].copy_from_slice(kp.secret.a.as_bytes());
-                ka0[32 * i..32 * i + 32].copy_from_slice(kp.secret.a0.as_bytes());
-                ka1[32 * i..32 * i + 32].copy_from_slice(kp.secret.a1.as_bytes());
+                ka.0[32 * i..32 * i + 32].copy_from_slice(kp.secret.a.as_bytes());
+                ka0.0[32 * i..32 * i + 32].copy_from_slice(kp.secret.a0.as_bytes());
+                ka1.0[32 * i..32 * i + 32].copy_from_slice(kp.secret.a1.as_bytes());
                 kpk[32 * i..32 * i + 32].copy_from_slice(kp.public.pk.compress().as_bytes());
             }
         }
-        let kp_soa = AfxKeypairsSoa { a: ka.as_ptr(), a0: ka0.as_ptr(), a1: ka1.as_ptr(), pk: kpk.as_ptr() };
-        // the reference's draws, in its order (see the header of this file)
-        let (mut z_wide, mut seed, mut enc_seeds) = (vec![0u8; 64 * count], vec![0u8; 32 * count], vec![0u8; 32 * count * nsp.max(1)]);
-        for i in 0..count { csprng.fill_bytes(&mut z_wide[64 * i..64 * i + 64]); }   // Scalar::random (presentation.rs:162)
-        rand::thread_rng().fill_bytes(&mut seed);                                     // the presentation proof's prove_compact (:284)
-        rand::thread_rng().fill_bytes(&mut enc_seeds);                                // then one per ProofOfEncryption (:301)
-        let rnd = AfxShowRandomness { z_wide: z_wide.as_ptr(), rng_seed: seed.as_ptr(), enc_seeds: enc_seeds.as_ptr() };
+        let kp_soa = AfxKeypairsSoa { a: ka.0.as_ptr(), a0: ka0.0.as_ptr(), a1: ka1.0.as_ptr(), pk: kpk.as_ptr() };
+        // the reference's csprng draws in its order, then the proofs' seeds (see the header of this file)
+        let (mut z_wide, mut seed, mut enc_seeds) = (Wiped::new(64 * count), Wiped::new(32 * count), Wiped::new(32 * count * nsp.max(1)));
+        for i in 0..count { csprng.fill_bytes(&mut z_wide.0[64 * i..64 * i + 64]); }   // Scalar::random (presentation.rs:162)
+        csprng.fill_bytes(&mut seed.0);                                               // in place of thread_rng() in the presentation proof's prove_compact (:284)
+        csprng.fill_bytes(&mut enc_seeds.0);                                          // ... and in each ProofOfEncryption's (:301), [secret point][credential]
+        let rnd = AfxShowRandomness { z_wide: z_wide.0.as_ptr(), rng_seed: seed.0.as_ptr(), enc_seeds: enc_seeds.0.as_ptr() };
         // outputs
         let col = |k: usize| vec![0u8; 32 * k * count];
         let (mut o_ch, mut o_rs, mut o_x0, mut o_x1, mut o_cv, mut o_cy, mut o_av) = (col(1), col(3 + hs), col(1), col(1), col(1), col(na), col(na));
@@ -402,6 +446,7 @@ impl GpuUser {
         if count == 0 { return Vec::new(); }
         let na = issuances[0].credential.attributes.len();
         let nr = issuances[0].proof.0.responses.len();
+        assert!(na <= AFX_MAX_ATTRIBUTES && nr <= AFX_MAX_ATTRIBUTES + 5, "verify_issuance_batch: layout beyond AFX_MAX_ATTRIBUTES");
         let mut soa = AfxAttributesSoa { n_attributes: na as u32, kinds: [0; AFX_MAX_ATTRIBUTES], values: core::ptr::null() };
         let mut values = vec![0u8; 32 * na * count];
         let col = |k: usize| vec![0u8; 32 * k * count];
@@ -435,21 +480,38 @@ impl Drop for GpuUser {
     fn drop(&mut self) { unsafe { if self.group.is_null() { afx_ctx_destroy(self.ctx) } else { afx_group_destroy(self.group) } } }
 }
 
-/// ProofOfValidCredential (src/nizk/presentation.rs:118-127) -> shape + columns.  Lives inside the crate because the
-/// struct's fields are private.
-fn marshal(batch: &[ProofOfValidCredential]) -> (AfxShape, Columns) {
+fn enc_kind(a: &EncryptedAttribute) -> u8 {
+    match a { EncryptedAttribute::PublicScalar(_) => 0, EncryptedAttribute::SecretScalar => 1,
+              EncryptedAttribute::PublicPoint(_) => 2, EncryptedAttribute::SecretPoint => 3 }
+}
+
+/// Everything of a presentation that is not a scalar or a point, as bytes: two presentations may share a GPU batch iff their
+/// keys are equal.  `None`: vectors that do not fit together or do not fit the ABI - the reference would index out of range
+/// (`self.C_y[i]`, `self.encrypted_attributes[i]`, presentation.rs:346,351,374) or zkp would reject the response count.
+fn shape_key(p: &ProofOfValidCredential) -> Option<Vec<u8>> {
+    let (n, nr, hs, ne) = (p.encrypted_attributes.len(), p.proof.responses.len(), p.hidden_scalar_indices.len(), p.proofs_of_encryption.len());
+    if n > AFX_MAX_ATTRIBUTES || hs > AFX_MAX_ATTRIBUTES || ne > AFX_MAX_ATTRIBUTES || nr > AFX_MAX_ATTRIBUTES + 3 || p.C_y.len() != n { return None; }
+    if p.proofs_of_encryption.iter().any(|(_, q)| q.proof.responses.len() != 6) { return None; }
+    let mut k = Vec::with_capacity(16 + n + 2 * (hs + ne));
+    for v in [n as u32, nr as u32, hs as u32, ne as u32].iter() { k.extend_from_slice(&v.to_le_bytes()); }
+    k.extend(p.encrypted_attributes.iter().map(enc_kind));
+    for h in p.hidden_scalar_indices.iter() { k.extend_from_slice(&h.to_le_bytes()); }
+    for (_, q) in p.proofs_of_encryption.iter() { k.extend_from_slice(&q.index.to_le_bytes()); }
+    Some(k)
+}
+
+/// Presentations of ONE shape (equal `shape_key`s) -> shape + columns.  Lives inside the crate because the struct's fields
+/// (src/nizk/presentation.rs:118-127) are private.
+fn marshal(batch: &[&ProofOfValidCredential]) -> (AfxShape, Columns) {
     let count = batch.len();
-    let p0 = &batch[0];
+    let p0 = batch[0];
     let n = p0.encrypted_attributes.len();
     let nr = p0.proof.responses.len();
     let ne = p0.proofs_of_encryption.len();
     let mut shape = AfxShape { n_attributes: n as u32, kinds: [0; 32], n_responses: nr as u32,
         n_hidden_scalars: p0.hidden_scalar_indices.len() as u32, hidden_scalar_indices: [0; 32],
         n_enc_proofs: ne as u32, enc_indices: [0; 32] };
-    for (i, a) in p0.encrypted_attributes.iter().enumerate() {
-        shape.kinds[i] = match a { EncryptedAttribute::PublicScalar(_) => 0, EncryptedAttribute::SecretScalar => 1,
-                                   EncryptedAttribute::PublicPoint(_) => 2, EncryptedAttribute::SecretPoint => 3 };
-    }
+    for (i, a) in p0.encrypted_attributes.iter().enumerate() { shape.kinds[i] = enc_kind(a); }
     for (i, h) in p0.hidden_scalar_indices.iter().enumerate() { shape.hidden_scalar_indices[i] = *h; }
     for (i, (_, e)) in p0.proofs_of_encryption.iter().enumerate() { shape.enc_indices[i] = e.index; }
     let col = |k: usize| vec![0u8; 32 * k * count];
@@ -457,6 +519,7 @@ fn marshal(batch: &[ProofOfValidCredential]) -> (AfxShape, Columns) {
                           attr_values: col(n), enc: (0..ne).map(|_| [col(1), col(6), col(1), col(1), col(1), col(1), col(1), col(1), col(1)]).collect() };
     let put = |dst: &mut Vec<u8>, row: usize, item: usize, src: &[u8; 32]| dst[32 * (row * count + item)..32 * (row * count + item) + 32].copy_from_slice(src);
     for (i, p) in batch.iter().enumerate() {
+        debug_assert!(shape_key(p) == shape_key(p0), "marshal: presentations of different shapes in one group");
         put(&mut c.challenge, 0, i, p.proof.challenge.as_bytes());
         for (k, r) in p.proof.responses.iter().enumerate() { put(&mut c.responses, k, i, r.as_bytes()); }
         put(&mut c.c_x_0, 0, i, p.C_x_0.compress().as_bytes());

@@ -143,3 +143,46 @@ def corrupt(pres, seed):
         else:
             for k in range(32):
                 tgt[k] = val[k]
+
+
+class DevMem:
+    """Device buffers for the *_dev entry points without PyTorch: ctypes over the HIP runtime the engine itself is linked
+    against (a second HIP runtime in the process - the one inside the torch wheel - does not initialise once this one has)."""
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            import ctypes as C
+            h = C.CDLL("/opt/rocm/lib/libamdhip64.so.7")
+            h.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            h.hipFree.argtypes = [C.c_void_p]
+            h.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            h.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+            cls._hip = h
+        return cls._hip
+
+    def __init__(self, array=None, nbytes=None, fill=None):
+        import ctypes as C
+        a = None if array is None else np.ascontiguousarray(array, dtype=np.uint8)
+        self.nbytes = a.nbytes if a is not None else nbytes
+        self.shape = a.shape if a is not None else (nbytes,)
+        p = C.c_void_p()
+        assert self.hip().hipMalloc(C.byref(p), max(1, self.nbytes)) == 0
+        self.ptr = p.value
+        if a is not None:
+            assert self.hip().hipMemcpy(self.ptr, a.ctypes.data, a.nbytes, 1) == 0      # hipMemcpyHostToDevice
+        elif fill is not None:
+            assert self.hip().hipMemset(self.ptr, fill, self.nbytes) == 0
+
+    def numpy(self):
+        out = np.zeros(self.shape, np.uint8)
+        assert self.hip().hipMemcpy(out.ctypes.data, self.ptr, self.nbytes, 2) == 0      # hipMemcpyDeviceToHost (synchronises)
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.hip().hipFree(self.ptr)
+            self.ptr = None
+
+    __del__ = free

@@ -285,7 +285,6 @@ def test_workspace_growth_while_an_earlier_dev_call_is_in_flight():
     its live workspace (bad[] flags, tables, digits) wiped or freed under it (round-2 advisor finding: a cleared bad[] flag
     is a false accept).  Fresh contexts so that the second call really grows the buffer; repeated to give a race room."""
     import ctypes as C
-    import torch
     import aeonflux_amd as afx
     from aeonflux_amd import batch
     from tests.soa import presentation_arrays, shape_of
@@ -298,23 +297,111 @@ def test_workspace_growth_while_an_earlier_dev_call_is_in_flight():
     reps = 1400   # 48 * 1400 = 67 200 items: a workspace some hundred times the small call's
     big = {f: np.ascontiguousarray(np.concatenate([a[f]] * reps, axis=-2)) for f in batch.PRES_FIELDS}
     big["enc"] = [{f: np.ascontiguousarray(np.concatenate([d[f]] * reps, axis=-2)) for f in batch.ENC_FIELDS} for d in a["enc"]]
-    dev = torch.device("cuda", 0)
+    from tests.helpers import DevMem
 
     def to_dev(p):
-        d = {f: torch.from_numpy(p[f]).to(dev) for f in batch.PRES_FIELDS}
-        d["enc"] = [{f: torch.from_numpy(e[f]).to(dev) for f in batch.ENC_FIELDS} for e in p["enc"]]
+        d = {f: DevMem(p[f]) for f in batch.PRES_FIELDS}
+        d["enc"] = [{f: DevMem(e[f]) for f in batch.ENC_FIELDS} for e in p["enc"]]
         return d
     d_small, d_big = to_dev(a), to_dev(big)
-    soa_s, keep_s = batch.presentation_soa(d_small, ptr=lambda t: t.data_ptr())
-    soa_b, keep_b = batch.presentation_soa(d_big, ptr=lambda t: t.data_ptr())
+    soa_s, keep_s = batch.presentation_soa(d_small, ptr=lambda t: t.ptr)
+    soa_b, keep_b = batch.presentation_soa(d_big, ptr=lambda t: t.ptr)
     fn = afx.lib().afx_verify_presentations_dev
     for _ in range(6):
         ctx = afx.Context(params, key, ip)
-        st_s = torch.full((48,), 77, dtype=torch.uint8, device=dev)
-        st_b = torch.full((48 * reps,), 77, dtype=torch.uint8, device=dev)
-        afx.check(fn(ctx.h, C.byref(sh), C.byref(soa_s), 48, st_s.data_ptr()))
-        afx.check(fn(ctx.h, C.byref(sh), C.byref(soa_b), 48 * reps, st_b.data_ptr()))   # no synchronisation in between
+        st_s, st_b = DevMem(nbytes=48, fill=77), DevMem(nbytes=48 * reps, fill=77)
+        afx.check(fn(ctx.h, C.byref(sh), C.byref(soa_s), 48, st_s.ptr))
+        afx.check(fn(ctx.h, C.byref(sh), C.byref(soa_b), 48 * reps, st_b.ptr))   # no synchronisation in between
         ctx.synchronize()
-        assert np.array_equal(st_s.cpu().numpy(), want)
-        assert np.array_equal(st_b.cpu().numpy(), np.tile(want, reps))
+        assert np.array_equal(st_s.numpy(), want)
+        assert np.array_equal(st_b.numpy(), np.tile(want, reps))
         ctx.close()
+        st_s.free()
+        st_b.free()
+
+
+def _mixed_stream(seed, n_creds=20):
+    """presentations of one issuer with different hide/reveal choices, in arrival order, two of them corrupted;
+    returns (ctx args, [(afx.Shape, arrays)], oracle statuses)"""
+    import aeonflux_amd as afx
+    from tests.helpers import make_credentials
+    from tests.soa import presentation_arrays, shape_of
+    d = make_credentials(4, "SSPE", n_creds, seed)
+    take, user, issuer = d["take"], d["user"], d["issuer"]
+    items, want = [], []
+    for i, cr in enumerate(d["creds"]):
+        hide = [[0, 3], [3], [0, 1], [], [1, 3]][(i * 3) % 5]   # shapes interleave: no two neighbours alike
+        kinds = list(cr["kinds"])
+        for j in hide:
+            kinds[j] = 1 if kinds[j] == 0 else 4
+        nsp = sum(1 for k in kinds if k == 4)
+        st, p = user.show(kinds, cr["values"], cr["t"], cr["U"], cr["V"], user.keypair_derive(take(64)), take(64), take(32), take(32 * nsp))
+        assert st == 0
+        if i in (4, 7, 13):
+            p.C_V[3] ^= 1
+        want.append(issuer.verify_presentation(p))
+        items.append((afx.Shape.from_buffer_copy(bytes(shape_of(p))), presentation_arrays([p])))
+    return d, items, want
+
+
+def test_mixed_shapes_through_the_c_entry_points():
+    """Issuer::verify takes any presentation (src/issuer.rs:141-147; the shape is per presentation, presentation.rs:293-309):
+    a stream of interleaved shapes goes through afx_verify_presentations_mixed (struct-of-arrays groups with positions),
+    through afx_verify_presentations_mixed_wire (AFXP sections back to back, grouped inside the library), and through the
+    group (multi-device) form; every status must be the oracle's, at the presentation's own place in the stream."""
+    import ctypes as C
+    import aeonflux_amd as afx
+    from aeonflux_amd import batch, wire
+    d, items, want = _mixed_stream(b"gpu-mixed-c")
+    assert sum(want) == 3 and len({bytes(s) for s, _ in items}) == 5
+    ctx = afx.Context(d["params"], d["key"], d["ip"])
+    got = batch.verify_mixed(ctx, items)
+    assert [int(g[0]) for g in got] == want
+    blob = wire.pack_mixed(items)
+    assert wire.verify_mixed_wire(ctx, blob).tolist() == want
+    # sections with count > 1, shapes repeating non-adjacently, garbage in the unused shape tails (must not split a group)
+    def cat(idx):
+        ps = [items[i][1] for i in idx]
+        out = {f: np.concatenate([p[f] for p in ps], axis=-2) for f in batch.PRES_FIELDS}
+        out["enc"] = [{f: np.concatenate([p["enc"][e][f] for p in ps], axis=-2) for f in batch.ENC_FIELDS} for e in range(len(ps[0]["enc"]))]
+        return out
+    by_shape = {}
+    for i, (s, _) in enumerate(items):
+        by_shape.setdefault(bytes(s), []).append(i)
+    sections, order = [], []
+    for idx in by_shape.values():
+        half = len(idx) // 2
+        sections.append((items[idx[0]][0], cat(idx[:half]), idx[:half]))
+        sections.append((items[idx[0]][0], cat(idx[half:]), idx[half:]))
+    sections = sections[::2] + sections[1::2]   # first halves of every shape, then second halves
+    for s, _, idx in sections:
+        order += idx
+    st = wire.verify_mixed_wire(ctx, b"".join(wire.pack_presentations(s, p) for s, p, _ in sections))
+    assert st.tolist() == [want[i] for i in order]
+    dirty = []
+    for s, p in items:
+        s2 = afx.Shape.from_buffer_copy(bytes(s))
+        for k in range(s2.n_attributes, 32):
+            s2.kinds[k] = 0xAB
+        for k in range(s2.n_enc_proofs, 32):
+            s2.enc_indices[k] = 0x7777
+        dirty.append((s2, p))
+    assert [int(g[0]) for g in batch.verify_mixed(ctx, dirty)] == want
+    # bad requests are refused before anything runs
+    n = C.c_size_t(0)
+    stb = np.zeros(64, np.uint8)
+    assert afx.lib().afx_verify_presentations_mixed_wire(ctx.h, blob[:-7], len(blob) - 7, stb.ctypes.data, 64, C.byref(n)) == afx.E_BAD_ARGS
+    assert afx.lib().afx_verify_presentations_mixed_wire(ctx.h, blob, len(blob), stb.ctypes.data, 3, C.byref(n)) == afx.E_BAD_ARGS and n.value == len(items)
+    assert afx.lib().afx_verify_presentations_mixed_wire(ctx.h, b"", 0, stb.ctypes.data, 64, C.byref(n)) == afx.OK and n.value == 0
+    g = (afx.PresentationGroup * 2)()
+    soa, keep = batch.presentation_soa(items[0][1])
+    pos = (C.c_uint64 * 1)(0)
+    for k in range(2):
+        g[k].shape, g[k].batch, g[k].count, g[k].positions = items[0][0], soa, 1, pos
+    assert afx.lib().afx_verify_presentations_mixed(ctx.h, g, 2, stb.ctypes.data, 2) == afx.E_BAD_ARGS   # position 0 twice
+    pos[0] = 5
+    assert afx.lib().afx_verify_presentations_mixed(ctx.h, g, 1, stb.ctypes.data, 2) == afx.E_BAD_ARGS   # outside the array
+    ctx.close()
+    grp = afx.Group(d["params"], d["key"], d["ip"], [0, 0])
+    assert [int(x[0]) for x in batch.verify_mixed(grp, items)] == want
+    grp.close()

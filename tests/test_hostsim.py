@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "aeonflux_amd", "csrc")
 @pytest.fixture(scope="module")
 def hostsim_lib(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("hostsim") / "libafx_hostsim.so")
-    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp", "mixed.cpp")]
     srcs.append(os.path.join(ROOT, "tests", "hostsim", "fake_hip.cpp"))
     cmd = ["g++", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fPIC", "-std=c++17",
            "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-shared", "-pthread", "-o", out] + srcs
@@ -70,6 +70,20 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     stt, cnt = np.zeros(3, np.uint8), C.c_size_t(0)
     assert afx.lib().afx_verify_presentations_wire(ctx.h, blob, len(blob), stt.ctypes.data, 3, C.byref(cnt)) == 0 and cnt.value == 3
     assert afx.lib().afx_verify_presentations_wire(ctx.h, blob[:-1], len(blob) - 1, stt.ctypes.data, 3, C.byref(cnt)) == afx.E_BAD_ARGS
+    # a stream of mixed shapes: this statement's shape twice around a second shape (hidden scalar revealed / nothing else),
+    # as back-to-back AFXP sections and as struct-of-arrays groups with positions; truncated streams are refused
+    sh2 = afx.Shape.from_buffer_copy(bytes(shape))
+    sh2.n_enc_proofs = 0
+    pres2 = dict(pres, enc=[])
+    stream = wire.pack_presentations(shape, pres) + wire.pack_presentations(sh2, pres2) + wire.pack_presentations(shape, pres)
+    assert wire.verify_mixed_wire(ctx, stream).tolist() == [0x5a] * 9
+    assert afx.lib().afx_verify_presentations_mixed_wire(ctx.h, stream[:-32], len(stream) - 32, stt.ctypes.data, 3, C.byref(cnt)) == afx.E_BAD_ARGS
+    assert afx.lib().afx_verify_presentations_mixed_wire(ctx.h, stream, len(stream), stt.ctypes.data, 3, C.byref(cnt)) == afx.E_BAD_ARGS and cnt.value == 9
+    sl = C.c_size_t(0)
+    assert afx.lib().afx_wire_section_bytes(stream, len(stream), C.byref(sl)) == 0 and sl.value == len(blob)
+    assert afx.lib().afx_wire_section_bytes(stream, len(blob) - 1, C.byref(sl)) == afx.E_BAD_ARGS
+    got = batch.verify_mixed(ctx, [(shape, pres), (sh2, pres2), (shape, pres)])
+    assert [g.tolist() for g in got] == [[0x5a] * 3] * 3
     # mis-shaped requests take the fail-all path
     bad = afx.Shape.from_buffer_copy(bytes(shape))
     bad.n_responses += 1   # claims a row the arrays do not have: must be rejected without reading them
@@ -109,6 +123,7 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     grp = afx.Group(d["params"], d["key"], d["ip"], [0, 1])
     assert len(grp) == 2 and grp.member(1).n == n
     assert len(batch.verify_presentations(grp, shape, pres)) == 3
+    assert [g.tolist() for g in batch.verify_mixed(grp, [(sh2, pres2), (shape, pres)])] == [[0x5a] * 3] * 2
     o2, st2 = batch.issue(grp, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
     assert len(st2) == 3
     assert len(batch.verify_issuances(grp, kinds, values, iss)) == 3
@@ -239,7 +254,7 @@ def test_group_calls_are_race_free_under_tsan(tmp_path):
     if not os.path.isabs(tsan) or not os.path.exists(tsan):
         pytest.skip("no libtsan")
     out = str(tmp_path / "libafx_tsan.so")
-    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp", "mixed.cpp")]
     srcs.append(os.path.join(ROOT, "tests", "hostsim", "fake_hip.cpp"))
     r = subprocess.run(["g++", "-g", "-O1", "-fsanitize=thread", "-fPIC", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-shared",
                         "-pthread", "-o", out] + srcs, capture_output=True, text=True)

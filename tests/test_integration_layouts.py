@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUST_TO_C = {"AfxShape": "afx_shape", "AfxEncProofSoa": "afx_encproof_soa", "AfxPresentationSoa": "afx_presentation_soa",
              "AfxAttributesSoa": "afx_attributes_soa", "AfxIssueRandomness": "afx_issue_randomness", "AfxIssuanceSoa": "afx_issuance_soa",
              "AfxCredentialsSoa": "afx_credentials_soa", "AfxKeypairsSoa": "afx_keypairs_soa", "AfxShowRandomness": "afx_show_randomness",
-             "AfxEncProofOut": "afx_encproof_out", "AfxPresentationOut": "afx_presentation_out"}
+             "AfxEncProofOut": "afx_encproof_out", "AfxPresentationOut": "afx_presentation_out",
+             "AfxPresentationGroup": "afx_presentation_group"}
 
 
 def strip_c_comments(s):
@@ -31,7 +32,8 @@ def c_structs():
             if ptr:
                 kind = "ptr"
             else:
-                kind = {"uint32_t": "u32", "uint16_t": "u16", "uint8_t": "u8", "uint64_t": "u64"}[ty]
+                # a scalar, or another struct of this header held by value
+                kind = {"uint32_t": "u32", "uint16_t": "u16", "uint8_t": "u8", "uint64_t": "u64", "size_t": "usize"}.get(ty, "struct " + ty)
                 if arr:
                     kind = "[%s;%s]" % (kind, {"AFX_MAX_ATTRIBUTES": "32"}.get(arr, arr))
             for fname in fnames.split(","):
@@ -56,7 +58,7 @@ def rust_structs():
                 kind = "ptr"
             else:
                 a = re.match(r"\[(\w+); (\w+)\]$", ty)
-                kind = "[%s;%s]" % (a.group(1), {"AFX_MAX_ATTRIBUTES": "32"}.get(a.group(2), a.group(2))) if a else ty
+                kind = "[%s;%s]" % (a.group(1), {"AFX_MAX_ATTRIBUTES": "32"}.get(a.group(2), a.group(2))) if a else ("struct " + RUST_TO_C[ty] if ty in RUST_TO_C else ty)
             fields.append((fname, kind))
         out[name] = fields
     return out
@@ -108,7 +110,8 @@ def rust_externs():
 def test_extern_declarations_match_the_header():
     cp, rx = c_prototypes(), rust_externs()
     assert {"afx_ctx_create", "afx_verify_presentations", "afx_issue", "afx_show", "afx_verify_issuances", "afx_group_create",
-            "afx_group_verify_presentations", "afx_group_issue", "afx_group_show", "afx_group_verify_issuances"} <= set(rx)
+            "afx_group_verify_presentations", "afx_group_issue", "afx_group_show", "afx_group_verify_issuances",
+            "afx_verify_presentations_mixed", "afx_group_verify_presentations_mixed"} <= set(rx)
     for name, (ret, kinds) in rx.items():
         assert name in cp, name
         cret, ckinds = cp[name]
@@ -119,8 +122,12 @@ def test_extern_declarations_match_the_header():
 def test_binding_covers_the_three_call_sites_and_documents_the_draw_order():
     src = open(os.path.join(ROOT, "integration", "aeonflux_gpu.rs")).read()
     for needle in ("pub fn verify_batch", "pub fn issue_batch", "pub fn show_batch", "pub fn verify_issuance_batch", "pub fn new_multi",
-                   "src/amacs.rs:289", "src/amacs.rs:290", "presentation.rs:162", "thread_rng()"):
+                   "src/amacs.rs:289", "src/amacs.rs:290", "presentation.rs:162", "thread_rng()", "fn shape_key", "zeroize"):
         assert needle in src, needle
+    # the shim draws from the caller's csprng only (`rand` is a dev-dependency of the crate) and never trusts batch[0]'s shape
+    code = re.sub(r"//.*", "", src)
+    assert "rand::" not in code and "thread_rng" not in code
+    assert "afx_verify_presentations_mixed" in code and "by_shape" in code
     # the draw order stated in the shim is the engine's input order: t_wide, U_wide, rng_seed / z_wide, rng_seed, enc_seeds
     cs = c_structs()
     assert [f for f, _ in cs["afx_issue_randomness"]] == ["t_wide", "U_wide", "rng_seed"]
