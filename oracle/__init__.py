@@ -81,6 +81,11 @@ def load(native=False):
     lib.afxo_verify_encryption_proof.argtypes = [C.c_void_p, C.POINTER(EncProof)]
     lib.afxo_verify_presentations_soa.argtypes = [C.c_void_p, C.POINTER(Shape), C.POINTER(PresentationSoA), C.c_size_t,
                                                   C.c_void_p, C.c_int]
+    lib.afxo_verify_presentations_soa_traced.argtypes = [C.c_void_p, C.POINTER(Shape), C.POINTER(PresentationSoA), C.c_size_t,
+                                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.afxo_issue_soa.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p] + [C.c_void_p] * 4 + [C.c_size_t] + [C.c_void_p] * 6 + [C.c_int]
+    lib.afxo_verify_issuances_soa_traced.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p] + [C.c_void_p] * 6 + [C.c_uint32, C.c_size_t] + \
+        [C.c_void_p] * 3 + [C.c_int]
     lib.afxo_sha512.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     lib.afxo_merlin_simple.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
                                        C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
@@ -282,3 +287,48 @@ def debug_last():
     ch = _buf(32)
     lib().afxo_debug_last(commits, C.byref(n), ch)
     return [commits.raw[32 * i:32 * i + 32] for i in range(n.value)], ch.raw
+
+
+# ---- batch forms over numpy struct-of-arrays (tests/test_gpu_full_size.py) ----
+
+def host_threads():
+    """cores this process may use (affinity mask): the oracle's batch forms split statically over that many threads"""
+    return max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+
+
+def verify_presentations_traced(ctx, shape, soa, count, threads=None):
+    """(status[count], trace[1 + n_enc_proofs, count, 32], reached[1 + n_enc_proofs, count]) from afxo_verify_presentations_soa_traced;
+    shape / soa: this module's Shape / PresentationSoA (or byte-compatible ctypes structures of the engine's mirror)"""
+    import numpy as np
+    rows = 1 + shape.n_enc_proofs
+    status, trace, reached = np.full(count, 255, np.uint8), np.zeros((rows, count, 32), np.uint8), np.zeros((rows, count), np.uint8)
+    rc = lib().afxo_verify_presentations_soa_traced(ctx.h, C.byref(Shape.from_buffer_copy(bytes(shape))), C.byref(PresentationSoA.from_buffer_copy(bytes(soa))),
+                                                    count, status.ctypes.data, trace.ctypes.data, reached.ctypes.data, threads or host_threads())
+    assert rc == 0
+    return status, trace, reached
+
+
+def issue_soa(ctx, kinds, values, t_wide, U_wide, seed, threads=None):
+    """Issuer::issue over a batch: values [n, count, 32], t_wide / U_wide [count, 64], seed [count, 32] -> (dict t U V challenge responses, status)"""
+    import numpy as np
+    n, count = values.shape[0], values.shape[1]
+    o = {k: np.zeros((count, 32), np.uint8) for k in ("t", "U", "V", "challenge")}
+    o["responses"] = np.zeros((ctx.n + 5, count, 32), np.uint8)
+    status = np.full(count, 255, np.uint8)
+    a = [np.ascontiguousarray(x, dtype=np.uint8) for x in (values, t_wide, U_wide, seed)]
+    rc = lib().afxo_issue_soa(ctx.h, n, bytes(kinds), *(x.ctypes.data for x in a), count, *(o[k].ctypes.data for k in ("t", "U", "V", "challenge", "responses")),
+                              status.ctypes.data, threads or host_threads())
+    assert rc == 0
+    return o, status
+
+
+def verify_issuances_traced(ctx, kinds, values, iss, threads=None):
+    """CredentialIssuance::verify over a batch -> (status[count], trace[count, 32], reached[count])"""
+    import numpy as np
+    n, count = values.shape[0], values.shape[1]
+    a = [np.ascontiguousarray(x, dtype=np.uint8) for x in (values, iss["t"], iss["U"], iss["V"], iss["challenge"], iss["responses"])]
+    status, trace, reached = np.full(count, 255, np.uint8), np.zeros((count, 32), np.uint8), np.zeros(count, np.uint8)
+    rc = lib().afxo_verify_issuances_soa_traced(ctx.h, n, bytes(kinds), *(x.ctypes.data for x in a), a[5].shape[0], count, status.ctypes.data,
+                                                trace.ctypes.data, reached.ctypes.data, threads or host_threads())
+    assert rc == 0
+    return status, trace, reached

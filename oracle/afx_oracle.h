@@ -64,6 +64,18 @@ int afxo_verify_encryption_proof(const afxo_ctx* c, const afxo_encproof* e);
 int afxo_verify_presentations_soa(const afxo_ctx* c, const afx_shape* shape, const afx_presentation_soa* batch, size_t count,
                                   uint8_t* status, int threads);
 
+/* the same with every proof's recomputed challenge (trace[(r * count + i) * 32], r = 0 main proof, 1 + e e-th proof of encryption;
+ * reached[r * count + i] = that verifier got to its commitments), and Issuer::issue / CredentialIssuance::verify over
+ * struct-of-arrays batches (values [n][count][32]); oracle/batch.c */
+int afxo_verify_presentations_soa_traced(const afxo_ctx* c, const afx_shape* shape, const afx_presentation_soa* batch, size_t count,
+                                         uint8_t* status, uint8_t* trace, uint8_t* reached, int threads);
+int afxo_issue_soa(const afxo_ctx* c, uint32_t n, const uint8_t* kinds, const uint8_t* values, const uint8_t* t_wide, const uint8_t* U_wide,
+                   const uint8_t* seed, size_t count, uint8_t* t, uint8_t* U, uint8_t* V, uint8_t* challenge, uint8_t* responses,
+                   uint8_t* status, int threads);
+int afxo_verify_issuances_soa_traced(const afxo_ctx* c, uint32_t n, const uint8_t* kinds, const uint8_t* values, const uint8_t* t,
+                                     const uint8_t* U, const uint8_t* V, const uint8_t* challenge, const uint8_t* responses, uint32_t nr,
+                                     size_t count, uint8_t* status, uint8_t* trace, uint8_t* reached, int threads);
+
 /* primitive wrappers for KATs */
 int afxo_point_decode_encode(const uint8_t in[32], uint8_t out[32]);
 void afxo_point_from_uniform(const uint8_t in[64], uint8_t out[32]);

@@ -8,6 +8,30 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+SAMPLE = 1 << 16   # "every recomputed commitment + challenge compared ... on a 2^16 sample for C3-C5"
+
+
+def _strided(count, offset):
+    """SAMPLE item indices spread over the whole batch (every count/SAMPLE-th item from `offset`), or all of a smaller batch"""
+    if count <= SAMPLE:
+        return np.arange(count)
+    return (np.arange(SAMPLE, dtype=np.int64) * (count // SAMPLE) + offset) % count
+
+
+def _oracle_agrees_on_sample(oracle, octx, shape, pres, idx, gpu_status, gpu_trace):
+    """The items `idx` of the batch through the oracle (all host cores): its status and, for every proof whose verifier reaches
+    its commitments, the challenge it recomputes - a hash over every recomputed commitment of that proof - must equal what the
+    GPU answered / recorded for the same items.  gpu_status [len(idx)], gpu_trace [1 + n_enc_proofs, len(idx), 32]."""
+    from aeonflux_amd import batch
+    sub = {f: np.ascontiguousarray(pres[f][..., idx, :]) for f in batch.PRES_FIELDS}
+    sub["enc"] = [{f: np.ascontiguousarray(d[f][..., idx, :]) for f in batch.ENC_FIELDS} for d in pres["enc"]]
+    soa, keep = batch.presentation_soa(sub)
+    st, trace, reached = oracle.verify_presentations_traced(octx, shape, soa, len(idx))
+    assert np.array_equal(st, gpu_status), np.nonzero(st != gpu_status)[0][:8]
+    r = reached.astype(bool)
+    assert np.array_equal(trace[r], gpu_trace[r]), "a recomputed challenge differs from the oracle's"
+    return int(r.sum()), int(st.sum())
+
 
 @pytest.mark.parametrize("name,n,layout,hide,count,fixture", [
     ("C2", 4, "SSPE", [0, 3], 1 << 16, "readme_4attrs_sSPe"),
@@ -34,15 +58,24 @@ def test_issue_show_verify_round_trip_at_full_size(name, n, layout, hide, count,
     want = bench.corrupt(pres, count, 31)
     got = batch.verify_presentations(issuer, shape, pres)
     assert np.array_equal(got, want) and want.sum() == count // 100
+    # the oracle on a strided 2^16-item sample (C2: the whole batch): statuses and every recomputed challenge
+    issuer.set_challenge_trace(1 + shape.n_enc_proofs, count)
+    assert np.array_equal(batch.verify_presentations(issuer, shape, pres), want)
+    trace = issuer.get_challenge_trace()
+    issuer.set_challenge_trace(0, 0)
+    idx = _strided(count, 5)
+    octx = oracle.Ctx(params, key, ip)
+    n_reached, n_rejected = _oracle_agrees_on_sample(oracle, octx, shape, pres, idx, got[idx], trace[:, idx])
+    assert n_reached > (1 + shape.n_enc_proofs) * len(idx) * 0.99 and n_rejected >= len(idx) // 200
+    del trace
     # verification is a function of the item alone: a permuted batch gives the permuted statuses
     perm = np.random.default_rng(5).permutation(count)
     shuffled = {f: np.ascontiguousarray(pres[f][..., perm, :]) for f in batch.PRES_FIELDS}
     shuffled["enc"] = [{f: np.ascontiguousarray(d[f][..., perm, :]) for f in batch.ENC_FIELDS} for d in pres["enc"]]
     assert np.array_equal(batch.verify_presentations(issuer, shape, shuffled), want[perm])
     issuer.close()
-    # a sample through the oracle (first items + every corrupted item among the first 4096)
+    # ... and item by item through the oracle's single-presentation entry point (first items + every corrupted item among the first 4096)
     sample = sorted(set(range(64)) | set(int(i) for i in np.nonzero(want[:4096])[0]))
-    octx = oracle.Ctx(params, key, ip)
     for i in sample:
         p = oracle.Presentation()
         p.n_attributes, p.n_responses, p.n_hidden_scalars, p.n_enc_proofs = shape.n_attributes, shape.n_responses, shape.n_hidden_scalars, shape.n_enc_proofs
@@ -96,13 +129,24 @@ def test_c4_shards_of_a_2_22_batch_equal_the_unsharded_answer():
     assert want.sum() == total // 100
     whole = batch.verify_presentations(issuer, shape, pres)          # unsharded, 2^22 items through one context
     assert np.array_equal(whole, want)
+    import oracle
     second = afx.Context(params, key, ip)
     for r in (0, 7):
         first, cnt = afx.shard_bounds(total, 8, r)
         assert cnt == 1 << 19 and first == r << 19
+        if r == 7:
+            second.set_challenge_trace(1 + shape.n_enc_proofs, cnt)   # indexed by the item's position inside the range call
         part = batch.verify_presentations(second, shape, pres, first=first, n=cnt)
         assert np.array_equal(part[first:first + cnt], whole[first:first + cnt])
         assert (part[:first] == 255).all() and (part[first + cnt:] == 255).all()
+    # rank 7's shard: a strided 2^16-item sample through the oracle, statuses and recomputed challenges
+    trace = second.get_challenge_trace()
+    second.set_challenge_trace(0, 0)
+    local = _strided(cnt, 3)
+    octx = oracle.Ctx(params, key, ip)
+    n_reached, n_rejected = _oracle_agrees_on_sample(oracle, octx, shape, pres, first + local, part[first + local], trace[:, local])
+    assert n_reached > 5 * len(local) * 0.99 and n_rejected >= len(local) // 200
+    del trace
     second.close()
     issuer.close()
 
@@ -136,6 +180,12 @@ def test_c5_issue_2_20_credentials_16_attributes():
         s, t, U, V, ch, resp = octx.issue(kinds, vals, bytes(tw[i]), bytes(uw[i]), bytes(seed[i]))
         assert s == 0 and t == bytes(iss["t"][i]) and U == bytes(iss["U"][i]) and V == bytes(iss["V"][i]) and ch == bytes(iss["challenge"][i])
         assert all(resp[k] == bytes(iss["responses"][k, i]) for k in range(n + 5))
+    # a strided 2^16-item sample re-issued by the oracle (all host cores): every output byte
+    idx = _strided(count, 11)
+    oi, ost = oracle.issue_soa(octx, kinds, np.ascontiguousarray(values[:, idx]), tw[idx], uw[idx], seed[idx])
+    assert not ost.any()
+    for f in ("t", "U", "V", "challenge", "responses"):
+        assert np.array_equal(oi[f], iss[f][..., idx, :]), f
     # 1 % corrupted: a response bit, the tag's V, an attribute value, the identity as U
     want = np.zeros(count, np.uint8)
     idx = np.random.default_rng(3).choice(count, size=count // 100, replace=False)
@@ -150,10 +200,19 @@ def test_c5_issue_2_20_credentials_16_attributes():
         else:
             iss["U"][i, :] = 0
         want[i] = 1
+    user.set_challenge_trace(1, count)
     got = batch.verify_issuances(user, kinds, values, iss)
     assert np.array_equal(got, want)
-    # a sample of the rejected ones through the oracle
+    trace = user.get_challenge_trace()[0]
+    user.set_challenge_trace(0, 0)
+    # the same strided sample through the oracle's CredentialIssuance::verify: statuses and recomputed challenges
     uctx = oracle.Ctx(params, None, ip)
+    sub = {f: np.ascontiguousarray(iss[f][..., idx, :]) for f in ("t", "U", "V", "challenge", "responses")}
+    vst, vtrace, vreached = oracle.verify_issuances_traced(uctx, kinds, np.ascontiguousarray(values[:, idx]), sub)
+    assert np.array_equal(vst, got[idx]) and vst.sum() >= len(idx) // 200
+    r = vreached.astype(bool)
+    assert r.sum() > 0.99 * len(idx) and np.array_equal(vtrace[r], trace[idx][r])
+    # a sample of the rejected ones through the oracle's single-issuance entry point
     for i in sorted(int(x) for x in idx[:24]):
         vals = [bytes(values[k, i]) + bytes(64) for k in range(n)]
         assert uctx.issuance_verify(kinds, vals, bytes(iss["t"][i]), bytes(iss["U"][i]), bytes(iss["V"][i]), bytes(iss["challenge"][i]),

@@ -194,3 +194,51 @@ def test_batch_soa_matches_per_item():
     for threads in (1, 3):
         oracle.lib().afxo_verify_presentations_soa(issuer.h, C.byref(shape), C.byref(soa), len(pres), status.ctypes.data, threads)
         assert status.tolist() == [issuer.verify_presentation(p) for p in pres] == [0, 0, 1, 0, 1, 0]
+
+
+def test_batch_forms_equal_the_per_item_calls():
+    """The oracle's threaded struct-of-arrays forms (oracle/batch.c: statuses + recomputed challenges for presentations and
+    issuances, batch issue), which the full-size GPU tests use on 2^16-item samples, against the per-item entry points the
+    golden flows pin."""
+    import numpy as np
+    import oracle
+    from tests.helpers import corrupt, make_batch, make_credentials
+    from tests.soa import pack_presentations
+    params, key, ip, issuer, pres = make_batch(4, "SSPE", [0, 3], 14, b"oracle-batch-forms")
+    corrupt(pres, b"oracle-batch-corrupt")
+    shape, soa, keep = pack_presentations(pres)
+    st, trace, reached = oracle.verify_presentations_traced(issuer, shape, soa, len(pres), threads=3)
+    assert st.tolist() == [issuer.verify_presentation(p) for p in pres] and 0 < st.sum() < len(pres)
+    for i, p in enumerate(pres):
+        q = oracle.Presentation.from_buffer_copy(bytes(p))
+        q.n_enc_proofs = 0
+        oracle.debug_reset()
+        issuer.verify_presentation(q)
+        commits, ch = oracle.debug_last()
+        assert bool(reached[0, i]) == bool(commits) and (not commits or bytes(trace[0, i]) == ch)
+        oracle.debug_reset()
+        issuer.verify_encryption_proof(p.enc[0])
+        commits, ch = oracle.debug_last()
+        assert bool(reached[1, i]) == bool(commits) and (not commits or bytes(trace[1, i]) == ch)
+    assert reached.sum() >= 2 * len(pres) - 6
+    d = make_credentials(5, "SSPES", 9, b"oracle-batch-issue")
+    creds, iss_ctx, user = d["creds"], d["issuer"], d["user"]
+    kinds = creds[0]["kinds"]
+    values = np.stack([np.stack([np.frombuffer(c["values"][k][:32], np.uint8) for c in creds]) for k in range(5)])
+    rnd = [np.stack([np.frombuffer(c["rnd"][j], np.uint8) for c in creds]) for j in range(3)]
+    o, st = oracle.issue_soa(iss_ctx, kinds, values, *rnd, threads=2)
+    assert not st.any()
+    for i, c in enumerate(creds):
+        assert (bytes(o["t"][i]), bytes(o["U"][i]), bytes(o["V"][i]), bytes(o["challenge"][i])) == (c["t"], c["U"], c["V"], c["challenge"])
+        assert [bytes(o["responses"][k, i]) for k in range(10)] == c["responses"]
+    o["V"][2, 5] ^= 1
+    o["responses"][3, 6, 0] ^= 2
+    st, trace, reached = oracle.verify_issuances_traced(user, kinds, values, o, threads=4)
+    assert st.tolist() == [0, 0, 1, 0, 0, 0, 1, 0, 0] and reached.sum() >= 8 and reached[6]   # item 2's V may no longer decode
+    for i in (0, 2, 6):
+        oracle.debug_reset()
+        vals = [bytes(values[k, i]) + bytes(64) for k in range(5)]
+        assert user.issuance_verify(kinds, vals, bytes(o["t"][i]), bytes(o["U"][i]), bytes(o["V"][i]), bytes(o["challenge"][i]),
+                                    [bytes(o["responses"][k, i]) for k in range(10)]) == int(st[i])
+        assert not reached[i] or oracle.debug_last()[1] == bytes(trace[i])
+    assert (bytes(trace[0]) == bytes(o["challenge"][0])) and bytes(trace[6]) != bytes(o["challenge"][6])
