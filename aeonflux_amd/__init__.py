@@ -136,6 +136,7 @@ def lib():
         _LIB.afx_ctx_get_plan_stats.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.afx_ctx_set_strict.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_set_fixed_key_schedule.argtypes = [C.c_void_p, C.c_int]
+        _LIB.afx_ctx_set_secret_independent_addressing.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_set_chunk_items.argtypes = [C.c_void_p, C.c_uint32]
         _LIB.afx_ctx_issuer_parameters.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.afx_issuance_wire_header_bytes.restype = C.c_size_t
@@ -219,6 +220,10 @@ class Context:
     def set_fixed_key_schedule(self, enable):
         """key scalars without NAF: running time independent of the issuer key (afx_ctx_set_fixed_key_schedule)"""
         check(lib().afx_ctx_set_fixed_key_schedule(self.h, 1 if enable else 0))
+
+    def set_secret_independent_addressing(self, enable):
+        """no memory address depends on a secret scalar's digits (afx_ctx_set_secret_independent_addressing); same bytes, slower"""
+        check(lib().afx_ctx_set_secret_independent_addressing(self.h, 1 if enable else 0))
 
     def issuer_parameters(self):
         """IssuerParameters as C_W || I (64 bytes)"""

@@ -235,9 +235,21 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   // kilo-cycles of VALU issue per wave (profiles/r01_fe_rates_ubench.txt): 63 windows of 4 doublings + the final
   // encoding; 64 additions + the 9-entry table per variable base; AFX_POS_WINDOWS additions per fixed base
   auto cost = [](const afx_msm_job& j) {
-    return (j.n_var ? 1320u : 160u) + j.n_uni * (330u + 45u /* more conversions to p3 */) + (j.n_var - j.n_uni) * 470u + (j.n_terms - j.n_var) * ((AFX_POS_WINDOWS * 175u) / 32u);
+    uint32_t c = (j.n_var ? 1320u : 160u) + j.n_uni * (330u + 45u /* more conversions to p3 */) + (j.n_var - j.n_uni) * 470u;
+    for (uint32_t t = j.n_var; t < j.n_terms; t++) c += ((j.term[t].secret ? AFX_SEC_WINDOWS * 200u : AFX_POS_WINDOWS * 175u)) / 32u;
+    for (uint32_t t = 0; t < j.n_var; t++) c += j.term[t].secret ? 120u : 0u;   // the table scans
+    return c;
   };
   const size_t n = jobs.size();
+  // Secret-independent addressing (afx_ctx_set_secret_independent_addressing): which terms carry a secret scalar.  In a prover-side
+  // plan every scalar but the constant 1; in a verifier-side plan the issuer key's (Z of Issuer::verify).  Such terms never run
+  // as a NAF schedule (whose table indices are the key's digits), read every entry of their window's table, and on a fixed base
+  // use the 4-bit positional tables.
+  const bool sec_mode = ctx->secret_independent;
+  auto is_key_scalar = [&](const afx_msm_term& t) { return t.scalar_stride == 0 && host_scalar_of(ctx, t.scalar) != nullptr; };
+  for (afx_msm_job& j : jobs)
+    for (uint32_t t = 0; t < j.n_terms; t++)
+      j.term[t].secret = (sec_mode && (secret_scalars ? j.term[t].scalar != ctx->const_one() : is_key_scalar(j.term[t]))) ? 1u : 0u;
   for (size_t i = 0; i < n; i++)
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
   // Jobs whose result is only ever encoded (no consumer of the point itself, no addend) run on halved scalars; k_compress2x
@@ -254,7 +266,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     std::vector<const uint8_t*> hs;
     for (uint32_t t = 0; t < j.n_var; t++) {
       // afx_ctx_set_fixed_key_schedule: key scalars take the per-item window path (64 additions each, whatever the key)
-      const uint8_t* h = (j.term[t].scalar_stride == 0 && !ctx->fixed_key_schedule) ? host_scalar_of(ctx, j.term[t].scalar) : nullptr;
+      const uint8_t* h = (j.term[t].scalar_stride == 0 && !ctx->fixed_key_schedule && !sec_mode) ? host_scalar_of(ctx, j.term[t].scalar) : nullptr;
       if (h) { uni.push_back(j.term[t]); hs.push_back(h); } else lane.push_back(j.term[t]);
     }
     if (uni.empty()) continue;
@@ -280,7 +292,9 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   }
   for (size_t ji = 0; ji < jobs.size(); ji++) {
     const afx_msm_job& j = jobs[ji];
-    const uint64_t nv = j.n_var, nf = j.n_terms - j.n_var;
+    const uint64_t nv = j.n_var;
+    uint64_t nfa = 0;   // additions of the fixed-base terms: AFX_POS_WINDOWS each, AFX_SEC_WINDOWS for a secret scalar
+    for (uint32_t t = j.n_var; t < j.n_terms; t++) nfa += j.term[t].secret ? AFX_SEC_WINDOWS : AFX_POS_WINDOWS;
     stats.msm_jobs++;
     if (j.n_uni) {
       // bit-serial schedule of k_msm's NAF branch
@@ -295,8 +309,8 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
         M += nadd * 4;
         M += nadd * 4 - ((nadd != 0 && b != 0) ? 1 : 0);
       }
-      stats.fixed_additions += nf * AFX_POS_WINDOWS;
-      M += nf * AFX_POS_WINDOWS * 7;
+      stats.fixed_additions += nfa;
+      M += nfa * 7;
       stats.encodings += j.out_enc ? 1 : 0;
       stats.var_additions += j.addend ? 1 : 0;
       if (j.addend) M += 9;
@@ -307,7 +321,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     }
     stats.doublings += nv ? 252 : 0;
     stats.var_additions += 64 * nv;
-    stats.fixed_additions += AFX_POS_WINDOWS * nf;
+    stats.fixed_additions += nfa;
     stats.table_additions += (AFX_TABLE_ENTRIES - 2) * nv;
     stats.encodings += j.out_enc ? 1 : 0;
     stats.var_additions += j.addend ? 1 : 0;
@@ -321,7 +335,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
         M += nv * 4 - (w != 0 ? 1 : 0);                       // back to p3; the window's last one skips T
       }
     }
-    M += AFX_POS_WINDOWS * nf * 7;                            // fixed bases: positional tables, niels addition + to p3
+    M += nfa * 7;                                             // fixed bases: positional tables, niels addition + to p3
     if (j.addend) M += 9;
     if (j.out_enc) { M += AFX_ENCODE_MUL; S += AFX_ENCODE_SQ; }
     stats.field_mul += M;
@@ -429,6 +443,8 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     l.kind = class_launch[kind];
     l.encodes = 0;
     for (const afx_msm_job& j : out) if (j.out_enc && !j.half_var) l.encodes = 1;
+    for (const afx_msm_job& j : out)
+      for (uint32_t t = 0; t < j.n_terms; t++) if (j.term[t].secret) l.secret = 1;
     l.njobs = (uint32_t)out.size();
     l.jobs_off = blob_alloc(sizeof(afx_msm_job) * out.size(), 16);
     memcpy(blob_.data() + l.jobs_off, out.data(), sizeof(afx_msm_job) * out.size());
@@ -510,8 +526,8 @@ int Assembler::run() {
         // overlap it), which keeps per-launch timings meaningful and the VALU free of two competing table working sets
         afx_ctx::Lane& other = ctx->lane[lane ^ 1];
         if (ctx->pipelining && other.msm_recorded) AFX_HIP(hipStreamWaitEvent(s, other.msm_done, 0));
-        AFX_HIP(afxk_msm(s, l.kind == L_MSM_FIXED ? 0 : l.kind == L_MSM_WINDOW ? 1 : 2, l.encodes, (const afx_msm_job*)jobs, l.njobs,
-                         (const int32_t*)ctx->d_pos_tables.p, table_ws, digit_ws, bad_, count,
+        AFX_HIP(afxk_msm(s, l.kind == L_MSM_FIXED ? 0 : l.kind == L_MSM_WINDOW ? 1 : 2, l.encodes, l.secret, (const afx_msm_job*)jobs, l.njobs,
+                         (const int32_t*)ctx->d_pos_tables.p, (const int32_t*)ctx->d_sec_tables.p, table_ws, digit_ws, bad_, count,
                          (ctx->timing && l.kind == L_MSM_WINDOW) ? ctx->clock_probe() : nullptr));
         if (ctx->pipelining) { AFX_HIP(hipEventRecord(L.msm_done, s)); L.msm_recorded = true; }
         break;

@@ -69,6 +69,7 @@ struct afx_ctx {
   std::vector<afx::Enc> gen_enc, gen_neg_enc;   // host copies of compress(G), compress(-G)
   // device residents
   afx::DevBuf d_gen_enc, d_pos_tables, d_gen_ext, d_key, d_consts;
+  afx::DevBuf d_sec_tables;   // 4-bit positional tables of the generators (AFX_SEC_*), built when secret-independent addressing is first switched on
   // key scalar slots in d_key ([k][32]): w, w', x0, x1, y[0..n), then constants one, zero
   const uint8_t* key_w() const { return (const uint8_t*)d_key.p; }
   const uint8_t* key_wp() const { return (const uint8_t*)d_key.p + 32; }
@@ -138,7 +139,8 @@ struct Launch {
   uint8_t fail_code = AFX_ST_VERIFICATION_FAILURE;
   size_t bytes = 0;         // L_COPY
   int odd = 0;              // L_MSM_TABLES: odd multiples (NAF terms) or multiples 0..8
-  int encodes = 1;          // L_MSM_*: some job of the launch encodes its result inside the kernel (kernels.hip k_msm<KIND, ENC>)
+  int encodes = 1;          // L_MSM_*: some job of the launch encodes its result inside the kernel (kernels.hip k_msm<KIND, ENC, SEC>)
+  int secret = 0;           // L_MSM_*: some term of the launch has a secret scalar under secret-independent addressing
   int32_t* prefix_ws = nullptr;   // L_COMPRESS: scratch for the prefix products (njobs * 9 * count dwords)
 };
 
@@ -154,6 +156,9 @@ class Assembler {
   int lane;
   uint32_t count;
   bool fail_all = false;      // statement-level failure for every item (reference would panic / reject all)
+  bool secret_scalars = false;   // a prover-side plan (issue, show, the symmetric-key helpers): every scalar of its multiscalar jobs
+                                 // but the constant 1 is a secret (blindings, witnesses, the key, nonces) - Assembler::msm marks the
+                                 // terms when the context runs with secret-independent addressing
   std::string plan_error;     // a request the plan cannot serve (reported as AFX_E_BAD_ARGS, nothing is launched)
   afx_plan_stats stats = {};  // per-item operation counts of this plan
 

@@ -8,12 +8,14 @@ hipError_t afxk_decode(hipStream_t s, const afx_decode_job* jobs, uint32_t njobs
 hipError_t afxk_sccheck(hipStream_t s, const afx_sccheck_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count);
 hipError_t afxk_pointop(hipStream_t s, const afx_pointop_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count);
 hipError_t afxk_scalarop(hipStream_t s, const afx_scalarop_job* jobs, uint32_t njobs, uint32_t count);
-hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen, int32_t* base_scratch, int32_t* postab);
+// secret != 0: the 4-bit tables of the secret-independent path (AFX_SEC_*) instead of the 13-bit ones
+hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen, int32_t* base_scratch, int32_t* postab, int secret);
 // kind: 0 fixed bases only, 1 per-item windows, 2 uniform NAF terms (kernels.hip MSM_*)
 hipError_t afxk_msm_tables(hipStream_t s, int odd, const afx_table_job* rows, uint32_t nrows, int32_t* table_ws, uint32_t count);
 // clock_probe: two 64-bit counters (shader-clock cycles, 100 MHz ticks) one lane of the launch adds its chain's span to; may be null
-hipError_t afxk_msm(hipStream_t s, int kind, int encodes, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, int32_t* table_ws, uint32_t* digit_ws,
-                    uint32_t* bad, uint32_t count, unsigned long long* clock_probe);
+// secret: some term of the launch has afx_msm_term.secret set (sec_tables must then be the context's 4-bit tables)
+hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, const int32_t* sec_tables,
+                    int32_t* table_ws, uint32_t* digit_ws, uint32_t* bad, uint32_t count, unsigned long long* clock_probe);
 // out_enc = encoding of twice each job's point; prefix_ws: njobs * 9 * count dwords of scratch (one 9-limb field element per job and item)
 hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, uint32_t njobs, int32_t* prefix_ws, uint32_t* bad, uint32_t count);
 hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count);

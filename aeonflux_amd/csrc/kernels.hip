@@ -87,13 +87,24 @@ AFX_DEV void cached_store(int32_t* p, size_t chunk, const ge_cached& q) {
 #pragma unroll
   for (int i = 0; i < 8; i++) *reinterpret_cast<uint4*>(p + i * chunk) = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-AFX_DEV ge_cached cached_load(const int32_t* p, size_t chunk) {
-  uint32_t w[32];
+AFX_DEV void cached_load_words(uint32_t w[32], const int32_t* p, size_t chunk) {
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const uint4 t = *reinterpret_cast<const uint4*>(p + i * chunk);
     w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
   }
+}
+AFX_DEV ge_cached cached_from_words(const uint32_t w[32]) {
+  ge_cached q;
+  q.YpX = fe_frombytes(w);
+  q.YmX = fe_frombytes(w + 8);
+  q.Z2 = fe_frombytes(w + 16);
+  q.T2d = fe_frombytes(w + 24);
+  return q;
+}
+AFX_DEV ge_cached cached_load(const int32_t* p, size_t chunk) {
+  uint32_t w[32];
+  cached_load_words(w, p, chunk);
   ge_cached q;
   q.YpX = fe_frombytes(w);
   q.YmX = fe_frombytes(w + 8);
@@ -123,32 +134,35 @@ __global__ void k_setup_generators(const uint8_t* __restrict__ enc, uint32_t nge
   enc_store(neg_enc, g, nw);
 }
 
-// Positional tables: for generator g and window position j, the entries d * 2^(AFX_POS_BITS*j) * G_g for
-// d = 0 .. 2^(AFX_POS_BITS-1) as halved affine niels ((y+x)/2, (y-x)/2, dxy; ge.cuh).  Two kernels: the window bases B_{g,j} = 2^(BITS*j) G_g
+// Positional tables: for generator g and window position j, the entries d * 2^(BITS*j) * G_g for
+// d = 0 .. 2^(BITS-1) as halved affine niels ((y+x)/2, (y-x)/2, dxy; ge.cuh).  Two kernels: the window bases B_{g,j} = 2^(BITS*j) G_g
 // (thread per (g, j)), then thread (g, j, c) writes the 16 entries 16c .. 16c+15 with ONE field inversion
 // (Montgomery's trick over the 16 Z coordinates).
-__global__ void k_setup_posbase(const int32_t* __restrict__ ext, uint32_t ngen, int32_t* __restrict__ base) {
+// The same two kernels build the 13-bit tables of the public path and the 4-bit tables of the secret-independent one
+// (AFX_SEC_*): `bits`, `windows`, `entries` (= 2^(bits-1) + 1) and the dword strides are launch arguments.
+__global__ void k_setup_posbase(const int32_t* __restrict__ ext, uint32_t ngen, int32_t* __restrict__ base, uint32_t bits, uint32_t windows) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ngen * AFX_POS_WINDOWS) return;
-  const uint32_t g = t / AFX_POS_WINDOWS, j = t % AFX_POS_WINDOWS;
+  if (t >= ngen * windows) return;
+  const uint32_t g = t / windows, j = t % windows;
   ge_p3 P = p3_load_uniform(ext + (size_t)g * AFX_VAR_DWORDS);
 #pragma unroll 1
-  for (uint32_t k = 0; k < AFX_POS_BITS * j; k++) P = ge_double(P);
+  for (uint32_t k = 0; k < bits * j; k++) P = ge_double(P);
   int32_t* e = base + (size_t)t * AFX_VAR_DWORDS;
 #pragma unroll
   for (int l = 0; l < AFX_FE_LIMBS; l++) { e[l] = P.X.v[l]; e[9 + l] = P.Y.v[l]; e[18 + l] = P.Z.v[l]; e[27 + l] = P.T.v[l]; }
 }
 #define AFX_POS_CHUNK 16
-#define AFX_POS_CHUNKS ((AFX_POS_ENTRIES + AFX_POS_CHUNK - 1) / AFX_POS_CHUNK)
-__global__ void k_setup_postables(const int32_t* __restrict__ base, uint32_t ngen, int32_t* __restrict__ postab) {
+__global__ void k_setup_postables(const int32_t* __restrict__ base, uint32_t ngen, int32_t* __restrict__ postab, uint32_t windows, uint32_t entries,
+                                  uint32_t window_dwords) {
+  const uint32_t chunks = (entries + AFX_POS_CHUNK - 1) / AFX_POS_CHUNK;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ngen * AFX_POS_WINDOWS * AFX_POS_CHUNKS) return;
-  const uint32_t gj = t / AFX_POS_CHUNKS, c = t % AFX_POS_CHUNKS;
+  if (t >= ngen * windows * chunks) return;
+  const uint32_t gj = t / chunks, c = t % chunks;
   const ge_p3 B = p3_load_uniform(base + (size_t)gj * AFX_VAR_DWORDS);
   const ge_cached cB = ge_p3_to_cached(B);
-  // Q = (16 c) * B by double-and-add over the bits of c (c < AFX_POS_CHUNKS), then four doublings
+  // Q = (16 c) * B by double-and-add over the bits of c (c < chunks), then four doublings
   ge_p3 Q = ge_identity();
-  constexpr int cbits = 32 - __builtin_clz((unsigned)(AFX_POS_CHUNKS - 1));
+  const int cbits = chunks > 1 ? 32 - __builtin_clz(chunks - 1) : 0;
 #pragma unroll 1
   for (int bit = cbits - 1; bit >= 0; bit--) {
     Q = ge_double(Q);
@@ -156,8 +170,8 @@ __global__ void k_setup_postables(const int32_t* __restrict__ base, uint32_t nge
   }
 #pragma unroll 1
   for (int k = 0; k < 4; k++) Q = ge_double(Q);
-  int32_t* tab = postab + (size_t)(gj / AFX_POS_WINDOWS) * AFX_POS_TABLE_DWORDS + (size_t)(gj % AFX_POS_WINDOWS) * AFX_POS_WINDOW_DWORDS;
-  const uint32_t first = c * AFX_POS_CHUNK, n = min((uint32_t)AFX_POS_CHUNK, (uint32_t)AFX_POS_ENTRIES - first);
+  int32_t* tab = postab + (size_t)(gj / windows) * windows * window_dwords + (size_t)(gj % windows) * window_dwords;
+  const uint32_t first = c * AFX_POS_CHUNK, n = min((uint32_t)AFX_POS_CHUNK, entries - first);
   // pass 1: the chunk's points (kept in per-thread scratch: this kernel runs once per context) and the running
   // products of their Z coordinates
   fe X[AFX_POS_CHUNK], Y[AFX_POS_CHUNK], Z[AFX_POS_CHUNK], pre[AFX_POS_CHUNK];
@@ -276,15 +290,36 @@ struct msm_env {
 };
 // acc += (4-bit signed digit of window w) * (variable base t), from the lane's own window table
 // `next` (wave-uniform): what consumes the result, GE_FOR_* (ge.cuh)
+// SEC (the launch has secret terms, afx_msm_term.secret): such a term reads ALL eight stored entries of its table, in order, and
+// keeps the digit's with selects (the identity for digit 0), so that no address depends on the digit - what dalek's constant-time
+// LookupTable::select does on the CPU (/root/reference/src/amacs.rs:267-270 multiplies by the key with it).  The branch on
+// `secret` is wave-uniform: it is a property of the term, not of the data.
+template <bool SEC>
 AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w, int next) {
   const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + ((uint32_t)w >> 3)) * e.count + e.item];
   const int d = (int)((word >> (((uint32_t)w & 7) * 4)) & 15u) - 8;
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
   const bool neg = (d < 0) != (e.job->term[t].negate != 0);
+  const int32_t* table = e.table_ws + ((size_t)e.job->term[t].table_slot * e.count + e.item) * AFX_VAR_TABLE_DWORDS;
+  if constexpr (SEC) {
+    if (e.job->term[t].secret) {
+      uint32_t sel[32];
+#pragma unroll
+      for (int i = 0; i < 32; i++) sel[i] = (uint32_t)AFX_IDENTITY_ENTRY[i];
+#pragma unroll 1
+      for (uint32_t k = 0; k < AFX_TABLE_STORED; k++) {
+        uint32_t ent[32];
+        cached_load_words(ent, table + k * AFX_TABLE_ENTRY_DWORDS, 4);
+        const bool hit = idx == k + 1;
+#pragma unroll
+        for (int i = 0; i < 32; i++) sel[i] = hit ? ent[i] : sel[i];
+      }
+      return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_from_words(sel), neg), next);
+    }
+  }
   // multiples 1..8 are stored (at 0..7); digit 0 reads the one identity entry every lane shares (an address select, no table bytes)
   const uint32_t stored = idx ? idx - 1 : 0;
-  const int32_t* own = e.table_ws + ((size_t)e.job->term[t].table_slot * e.count + e.item) * AFX_VAR_TABLE_DWORDS + stored * AFX_TABLE_ENTRY_DWORDS;
-  const int32_t* ent = idx ? own : AFX_IDENTITY_ENTRY;
+  const int32_t* ent = idx ? table + stored * AFX_TABLE_ENTRY_DWORDS : AFX_IDENTITY_ENTRY;
   return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent, 4), neg), next);
 }
 // acc += (AFX_POS_BITS-bit signed digit j) * 2^(AFX_POS_BITS*j) * (generator of term t), from the positional tables
@@ -301,6 +336,31 @@ AFX_DEV ge_p3 msm_add_positional(const msm_env& e, const int32_t* __restrict__ p
   int32_t v[AFX_NIELS_DWORDS];   // 7 x 16 bytes: 27 limbs + padding
 #pragma unroll
   for (int l = 0; l < AFX_NIELS_DWORDS / 4; l++) { const int4 x = p[l]; v[4 * l] = x.x; v[4 * l + 1] = x.y; v[4 * l + 2] = x.z; v[4 * l + 3] = x.w; }
+  ge_niels q;
+#pragma unroll
+  for (int l = 0; l < AFX_FE_LIMBS; l++) { q.ypx.v[l] = v[l]; q.ymx.v[l] = v[9 + l]; q.xyd.v[l] = v[18 + l]; }
+  return ge_p1p1_to_p3_next(ge_madd(acc, q, neg), next);
+}
+
+// acc += (signed 4-bit digit j) * 16^j * (generator of term t) for a SECRET scalar: the nine entries d = 0..8 of window j of the
+// generator's 4-bit positional table are all read (the addresses are wave-uniform and the same for every item) and the digit's
+// entry is kept with selects.  Digits as for a variable base (s + 0x88..88).
+AFX_DEV ge_p3 msm_add_positional_secret(const msm_env& e, const int32_t* __restrict__ sec_tables, const ge_p3& acc, uint32_t t, uint32_t j, int next) {
+  const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + (j >> 3)) * e.count + e.item];
+  const int d = (int)((word >> ((j & 7) * 4)) & 15u) - 8;
+  const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
+  const bool neg = (d < 0) != (e.job->term[t].negate != 0);
+  const int32_t* win = sec_tables + (size_t)e.job->term[t].fixed_idx * AFX_SEC_TABLE_DWORDS + (size_t)j * AFX_SEC_WINDOW_DWORDS;
+  int32_t v[27];
+#pragma unroll
+  for (int l = 0; l < 27; l++) v[l] = win[l];   // entry 0: the identity in niels form
+#pragma unroll 1
+  for (uint32_t k = 1; k < AFX_SEC_ENTRIES; k++) {
+    const int32_t* ent = win + k * AFX_NIELS_DWORDS;
+    const bool hit = idx == k;
+#pragma unroll
+    for (int l = 0; l < 27; l++) v[l] = hit ? ent[l] : v[l];
+  }
   ge_niels q;
 #pragma unroll
   for (int l = 0; l < AFX_FE_LIMBS; l++) { q.ypx.v[l] = v[l]; q.ymx.v[l] = v[9 + l]; q.xyd.v[l] = v[18 + l]; }
@@ -326,7 +386,7 @@ AFX_DEV void msm_recode(const afx_msm_job* job, uint32_t* __restrict__ digit_ws,
     if (job->half_var) s = sc_half(s);   // the job computes half of its sum; k_compress2x encodes the double
     uint32_t b[9];
     b[8] = 0;
-    if (t < nv) sc_bias(b, s, 0x88888888u);
+    if (t < nv || job->term[t].secret) sc_bias(b, s, 0x88888888u);   // signed 4-bit digits: variable bases, and secret scalars on fixed bases
     else sc_bias_wide<AFX_POS_BITS, AFX_POS_WINDOWS>(b, s);
 #pragma unroll
     for (int i = 0; i < AFX_DIGIT_WORDS; i++) digit_ws[((size_t)(dslot + t) * AFX_DIGIT_WORDS + i) * count + item] = b[i];
@@ -358,13 +418,32 @@ AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t ch
     }
   }
 }
-// the fixed bases of a job (terms [from, nt)): positional tables, no doubling; the sum's last step leaves acc centred
-AFX_DEV ge_p3 msm_fixed_terms(const msm_env& e, const int32_t* __restrict__ pos_tables, ge_p3 acc, uint32_t from, uint32_t nt) {
+// the fixed bases of a job (terms [from, nt)): positional tables, no doubling; the sum's last step leaves acc centred.
+// SEC: terms with a secret scalar take the 4-bit tables with all entries read (64 additions each), the others the 13-bit ones.
+template <bool SEC>
+AFX_DEV ge_p3 msm_fixed_terms(const msm_env& e, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables, ge_p3 acc, uint32_t from, uint32_t nt) {
+  int last_pub = -1, last_sec = -1;   // wave-uniform
+  if constexpr (SEC) {
+#pragma unroll 1
+    for (uint32_t t = from; t < nt; t++) { if (e.job->term[t].secret) last_sec = (int)t; else last_pub = (int)t; }
+#pragma unroll 1
+    for (uint32_t j = 0; j < AFX_SEC_WINDOWS && last_sec >= 0; j++) {
+#pragma unroll 1
+      for (uint32_t t = from; t < nt; t++)
+        if (e.job->term[t].secret)
+          acc = msm_add_positional_secret(e, sec_tables, acc, t, j, (last_pub < 0 && j + 1 == AFX_SEC_WINDOWS && (int)t == last_sec) ? GE_FOR_ANY : GE_FOR_ADD);
+    }
+    if (last_pub < 0) return acc;
+  } else {
+    last_pub = (int)nt - 1;
+  }
 #pragma unroll 1
   for (uint32_t j = 0; j < AFX_POS_WINDOWS; j++) {
 #pragma unroll 1
-    for (uint32_t t = from; t < nt; t++)
-      acc = msm_add_positional(e, pos_tables, acc, t, j, (j + 1 == AFX_POS_WINDOWS && t + 1 == nt) ? GE_FOR_ANY : GE_FOR_ADD);
+    for (uint32_t t = from; t < nt; t++) {
+      if (SEC && e.job->term[t].secret) continue;
+      acc = msm_add_positional(e, pos_tables, acc, t, j, (j + 1 == AFX_POS_WINDOWS && (int)t == last_pub) ? GE_FOR_ANY : GE_FOR_ADD);
+    }
   }
   return acc;
 }
@@ -403,9 +482,11 @@ k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table
 // Issuer::verify, every one of Issuer::issue - runs the instance compiled without the encoder's inversion, which fits three
 // blocks per CU without scratch (166 registers windowed and fixed, 146 NAF; the windowed chain 1.3 % faster than with two
 // blocks, the fixed-base sums 4.5 %, same box).
-template <int KIND, bool ENC>
-__global__ void __launch_bounds__(AFX_BLOCK, !ENC ? 3 : 2)
-k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tables, int32_t* __restrict__ table_ws,
+// SEC: the launch has terms with secret scalars under afx_ctx_set_secret_independent_addressing (the prover paths, the key's
+// terms of Issuer::verify): an instance of its own, so that the table scans cost the ordinary launches no registers.
+template <int KIND, bool ENC, bool SEC>
+__global__ void __launch_bounds__(AFX_BLOCK, (!ENC && !SEC) ? 3 : 2)
+k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables, int32_t* __restrict__ table_ws,
       uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count, unsigned long long* __restrict__ clock_probe) {
   // Clock probe (measurement aid): one lane of the launch's first block reads the shader-clock counter (s_memtime) and the
   // constant 100 MHz counter (s_memrealtime) around its chain; their ratio is the core clock this kernel actually ran at
@@ -423,7 +504,7 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
   msm_recode(job, digit_ws, count, item, nu, nv, nt);   // batch-constant NAF terms need no digits
   ge_p3 acc = ge_identity();
   if constexpr (KIND == MSM_FIXED) {
-    acc = msm_fixed_terms(env, pos_tables, acc, 0, nt);
+    acc = msm_fixed_terms<SEC>(env, pos_tables, sec_tables, acc, 0, nt);
   } else {
     if constexpr (KIND == MSM_NAF) {
       // bit-serial chain: the batch-constant scalars' width-5 NAF digits (the same for every lane, so the branches are
@@ -450,7 +531,7 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
         }
         if (lane_adds) {
 #pragma unroll 1
-          for (uint32_t t = nu; t < nv; t++) acc = msm_add_var(env, acc, t, bit >> 2, t + 1 != nv ? GE_FOR_ADD : after);
+          for (uint32_t t = nu; t < nv; t++) acc = msm_add_var<SEC>(env, acc, t, bit >> 2, t + 1 != nv ? GE_FOR_ADD : after);
         }
       }
     } else {
@@ -463,12 +544,12 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
           acc = ge_p1p1_to_p3_for<GE_FOR_ADD>(ge_p2_dbl(a2));
         }
 #pragma unroll 1
-        for (uint32_t t = 0; t + 1 < nv; t++) acc = msm_add_var(env, acc, t, w, GE_FOR_ADD);
-        acc = msm_add_var(env, acc, nv - 1, w, w == 0 ? GE_FOR_ANY : GE_FOR_DBL);   // the window's last addition
+        for (uint32_t t = 0; t + 1 < nv; t++) acc = msm_add_var<SEC>(env, acc, t, w, GE_FOR_ADD);
+        acc = msm_add_var<SEC>(env, acc, nv - 1, w, w == 0 ? GE_FOR_ANY : GE_FOR_DBL);   // the window's last addition
       }
     }
     // the fixed bases of a job with variable bases: after the chain (any order gives the same sum)
-    if (nt != nv) acc = msm_fixed_terms(env, pos_tables, acc, nv, nt);
+    if (nt != nv) acc = msm_fixed_terms<SEC>(env, pos_tables, sec_tables, acc, nv, nt);
   }
   msm_finish<ENC>(job, acc, bad, count, item);
   if (probe) {
@@ -676,27 +757,33 @@ hipError_t afxk_scalarop(hipStream_t s, const afx_scalarop_job* jobs, uint32_t n
   hipLaunchKernelGGL(k_scalarop, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, count);
   return hipGetLastError();
 }
-// base: scratch for ngen * AFX_POS_WINDOWS extended points (AFX_VAR_DWORDS each)
-hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen, int32_t* base, int32_t* postab) {
-  hipLaunchKernelGGL(k_setup_posbase, dim3((ngen * AFX_POS_WINDOWS + 63) / 64), dim3(64), 0, s, ext, ngen, base);
-  hipLaunchKernelGGL(k_setup_postables, dim3((ngen * AFX_POS_WINDOWS * AFX_POS_CHUNKS + 63) / 64), dim3(64), 0, s, base, ngen, postab);
+// base: scratch for ngen * windows extended points (AFX_VAR_DWORDS each); secret != 0: the 4-bit tables (AFX_SEC_*)
+hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen, int32_t* base, int32_t* postab, int secret) {
+  const uint32_t bits = secret ? AFX_SEC_BITS : AFX_POS_BITS, windows = secret ? AFX_SEC_WINDOWS : AFX_POS_WINDOWS;
+  const uint32_t entries = secret ? AFX_SEC_ENTRIES : AFX_POS_ENTRIES, wd = secret ? AFX_SEC_WINDOW_DWORDS : AFX_POS_WINDOW_DWORDS;
+  const uint32_t chunks = (entries + AFX_POS_CHUNK - 1) / AFX_POS_CHUNK;
+  hipLaunchKernelGGL(k_setup_posbase, dim3((ngen * windows + 63) / 64), dim3(64), 0, s, ext, ngen, base, bits, windows);
+  hipLaunchKernelGGL(k_setup_postables, dim3((ngen * windows * chunks + 63) / 64), dim3(64), 0, s, base, ngen, postab, windows, entries, wd);
   return hipGetLastError();
 }
-hipError_t afxk_msm(hipStream_t s, int kind, int encodes, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, int32_t* table_ws,
-                    uint32_t* digit_ws, uint32_t* bad, uint32_t count, unsigned long long* clock_probe) {
+template <int KIND>
+static void launch_msm(hipStream_t s, int encodes, int secret, dim3 grid, const afx_msm_job* jobs, const int32_t* pos_tables, const int32_t* sec_tables,
+                       int32_t* table_ws, uint32_t* digit_ws, uint32_t* bad, uint32_t count, unsigned long long* clock_probe) {
+  if (secret) {
+    if (encodes) hipLaunchKernelGGL((k_msm<KIND, true, true>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe);
+    else hipLaunchKernelGGL((k_msm<KIND, false, true>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe);
+  } else {
+    if (encodes) hipLaunchKernelGGL((k_msm<KIND, true, false>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe);
+    else hipLaunchKernelGGL((k_msm<KIND, false, false>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe);
+  }
+}
+hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables,
+                    const int32_t* sec_tables, int32_t* table_ws, uint32_t* digit_ws, uint32_t* bad, uint32_t count, unsigned long long* clock_probe) {
+  if (secret && !sec_tables) return hipErrorInvalidValue;
   switch (kind) {
-    case MSM_FIXED:
-      if (encodes) hipLaunchKernelGGL((k_msm<MSM_FIXED, true>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe);
-      else hipLaunchKernelGGL((k_msm<MSM_FIXED, false>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe);
-      break;
-    case MSM_WINDOW:
-      if (encodes) hipLaunchKernelGGL((k_msm<MSM_WINDOW, true>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe);
-      else hipLaunchKernelGGL((k_msm<MSM_WINDOW, false>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe);
-      break;
-    case MSM_NAF:
-      if (encodes) hipLaunchKernelGGL((k_msm<MSM_NAF, true>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe);
-      else hipLaunchKernelGGL((k_msm<MSM_NAF, false>), grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, pos_tables, table_ws, digit_ws, bad, count, clock_probe);
-      break;
+    case MSM_FIXED: launch_msm<MSM_FIXED>(s, encodes, secret, grid_for(count, njobs), jobs, pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe); break;
+    case MSM_WINDOW: launch_msm<MSM_WINDOW>(s, encodes, secret, grid_for(count, njobs), jobs, pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe); break;
+    case MSM_NAF: launch_msm<MSM_NAF>(s, encodes, secret, grid_for(count, njobs), jobs, pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

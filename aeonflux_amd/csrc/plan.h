@@ -21,6 +21,14 @@
 #define AFX_POS_ENTRIES ((1 << (AFX_POS_BITS - 1)) + 1)
 #define AFX_POS_WINDOW_DWORDS ((AFX_POS_ENTRIES * AFX_NIELS_DWORDS + 3) & ~3)   /* 16-byte multiple */
 #define AFX_POS_TABLE_DWORDS (AFX_POS_WINDOWS * AFX_POS_WINDOW_DWORDS)
+/* Positional tables for SECRET scalars on fixed bases (afx_ctx_set_secret_independent_addressing): 4-bit windows, so that all
+ * 9 entries d = 0..8 of a window are read for every addition and the one wanted is picked with selects - no address depends on a
+ * digit.  64 additions per term instead of AFX_POS_WINDOWS; 63 KB per generator, built when the mode is first switched on. */
+#define AFX_SEC_BITS 4
+#define AFX_SEC_WINDOWS 64
+#define AFX_SEC_ENTRIES 9
+#define AFX_SEC_WINDOW_DWORDS (AFX_SEC_ENTRIES * AFX_NIELS_DWORDS)
+#define AFX_SEC_TABLE_DWORDS (AFX_SEC_WINDOWS * AFX_SEC_WINDOW_DWORDS)
 #define AFX_DIGIT_WORDS 9              /* recoded scalar: up to 260 bits (253 + one window of bias) */
 #define AFX_VAR_DWORDS 36              /* extended point: X,Y,Z,T x 9 limbs */
 #define AFX_NIELS_DWORDS 28            /* affine niels: (y+x)/2, (y-x)/2, dxy x 9 limbs + 1 dword of padding = 7 x 16 bytes */
@@ -82,6 +90,10 @@ typedef struct {
   uint32_t negate;         /* subtract the term                                                    */
   uint32_t table_slot;     /* variable terms: slot of this base's window table in table_ws (Assembler::msm; terms of one
                               launch list that share a base and a table kind share the table)              */
+  uint32_t secret;         /* the scalar is a secret and the context runs with secret-independent addressing (Assembler::msm
+                              sets it): every entry of the window's table is read and the digit's entry selected; a fixed base
+                              uses the 4-bit positional tables (AFX_SEC_*), recoded like a variable term              */
+  uint32_t pad;
 } afx_msm_term;
 
 typedef struct {

@@ -109,6 +109,24 @@ extern "C" int afx_ctx_set_fixed_key_schedule(afx_ctx* c, int enable) try {
   c->fixed_key_schedule = enable != 0;
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_set_secret_independent_addressing(afx_ctx* c, int enable) try {
+  if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  if (enable && !c->d_sec_tables.p) {
+    // the generators' 4-bit positional tables, once per context: window bases through lane 0's workspace, like the 13-bit ones
+    AFX_HIP(hipSetDevice(c->device));
+    for (auto& L : c->lane)
+      if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
+    int rc;
+    if ((rc = c->d_sec_tables.ensure(sizeof(int32_t) * AFX_SEC_TABLE_DWORDS * (size_t)c->ngen)) ||
+        (rc = c->lane[0].ws.ensure(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)c->ngen * AFX_SEC_WINDOWS)))
+      return rc;
+    AFX_HIP(afxk_setup_postables(c->stream, (const int32_t*)c->d_gen_ext.p, c->ngen, (int32_t*)c->lane[0].ws.p, (int32_t*)c->d_sec_tables.p, 1));
+    AFX_HIP(hipStreamSynchronize(c->stream));
+  }
+  c->secret_independent = enable != 0;
+  return AFX_OK;
+} catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_get_plan_stats(afx_ctx* c, afx_plan_stats* out) try {
   if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
@@ -176,6 +194,7 @@ extern "C" void afx_ctx_destroy(afx_ctx* c) {
   }
   c->trace_buf.release(false);
   c->d_pos_tables.release(true);
+  c->d_sec_tables.release(false);
   c->d_gen_ext.release(true);
   c->d_gen_enc.release(false);
   c->d_consts.release(false);
@@ -211,7 +230,7 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   c->device = device;
   c->n = n;
   c->g = n < 3 ? 3 : n;
-  for (afx::DevBuf* pub : { &c->trace_buf, &c->d_gen_enc, &c->d_consts, &c->d_pos_tables, &c->d_gen_ext }) pub->sensitive = false;   // public data
+  for (afx::DevBuf* pub : { &c->trace_buf, &c->d_gen_enc, &c->d_consts, &c->d_pos_tables, &c->d_sec_tables, &c->d_gen_ext }) pub->sensitive = false;   // public data
   AFX_HIP(hipSetDevice(device));
   {
     int cus = 0;
@@ -266,7 +285,7 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   AFX_HIP(afxk_setup_generators(c->stream, (const uint8_t*)c->d_gen_enc.p, c->ngen, (int32_t*)c->d_gen_ext.p, d_neg, d_ok));
   // window bases 2^(AFX_POS_BITS*j) * G go through lane 0's workspace (free at this point), then the tables
   if ((rc = c->lane[0].ws.ensure(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)c->ngen * AFX_POS_WINDOWS))) return rc;
-  AFX_HIP(afxk_setup_postables(c->stream, (const int32_t*)c->d_gen_ext.p, c->ngen, (int32_t*)c->lane[0].ws.p, (int32_t*)c->d_pos_tables.p));
+  AFX_HIP(afxk_setup_postables(c->stream, (const int32_t*)c->d_gen_ext.p, c->ngen, (int32_t*)c->lane[0].ws.p, (int32_t*)c->d_pos_tables.p, 0));
   std::vector<uint8_t> neg(32 * (size_t)c->ngen);
   std::vector<uint32_t> ok(c->ngen);
   AFX_HIP(hipMemcpyAsync(neg.data(), d_neg, neg.size(), hipMemcpyDeviceToHost, c->stream));

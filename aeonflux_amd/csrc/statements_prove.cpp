@@ -166,6 +166,7 @@ extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, c
   const PlanKey key__ = plan_key("issue", &kd__, sizeof kd__, mode_flags(ctx));
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
     afx_ctx* c = as.ctx;
+    as.secret_scalars = true;   // the key, t, the proof's blindings: afx_ctx_set_secret_independent_addressing
     const uint32_t n = c->n;
     auto row = [&](const uint8_t* base, size_t k) { return base + (k * count + off) * 32; };
     auto orow = [&](uint8_t* base, size_t k) { return base + (k * count + off) * 32; };
@@ -289,6 +290,7 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
   const PlanKey key__ = plan_key("show", &kd__, sizeof kd__, mode_flags(ctx) | (no_key ? 4u : 0u));
   return run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t cc) {
     afx_ctx* c = as.ctx;
+    as.secret_scalars = true;   // z, the hidden attributes, the symmetric key, every blinding: afx_ctx_set_secret_independent_addressing
     auto row = [&](const uint8_t* base, size_t k) { return base + (k * count + off) * 32; };
     auto orow = [&](uint8_t* base, size_t k) { return base + (k * count + off) * 32; };
     if (no_key) { as.fail_all = true; as.finish(status_dev + off, AFX_ST_NO_SYMMETRIC_KEY); return; }

@@ -194,6 +194,7 @@ extern "C" int afx_keypairs_derive(afx_ctx* ctx, const uint8_t* master_secrets, 
   const size_t o_a = st.add(a, 32 * count), o_a0 = st.add(a0, 32 * count), o_a1 = st.add(a1, 32 * count), o_pk = st.add(nullptr, 32 * count), o_st = st.add(nullptr, count);
   if ((rc = st.upload())) return rc;
   rc = run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
+    as.secret_scalars = true;   // the user's symmetric key: afx_ctx_set_secret_independent_addressing
     afx_ctx* c = as.ctx;
     as.msm({ mk_msm({ mk_term(st.dev(o_a) + 32 * off, 32, nullptr, (int32_t)c->id_Ga(), false), mk_term(st.dev(o_a0) + 32 * off, 32, nullptr, (int32_t)c->id_Ga0(), false),
                       mk_term(st.dev(o_a1) + 32 * off, 32, nullptr, (int32_t)c->id_Ga1(), false) }, nullptr, nullptr, st.dev(o_pk) + 32 * off) });
@@ -217,6 +218,7 @@ extern "C" int afx_encrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8
   int rc = st.upload();
   if (rc) return rc;
   rc = run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
+    as.secret_scalars = true;   // the user's symmetric key: afx_ctx_set_secret_independent_addressing
     auto at = [&](size_t o) { return st.dev(o) + 32 * off; };
     int32_t *v_M1 = as.new_var(), *v_M2 = as.new_var(), *v_E1 = as.new_var();
     uint8_t* k = as.new_enc();
@@ -250,6 +252,7 @@ extern "C" int afx_decrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8
     const size_t o_a = st.add(kp->a, row), o_E1 = st.add(E1, row), o_E2 = st.add(E2, row), o_M1 = st.add(nullptr, row), o_st = st.add(nullptr, count);
     if ((rc = st.upload())) return rc;
     rc = run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
+    as.secret_scalars = true;   // the user's symmetric key: afx_ctx_set_secret_independent_addressing
       auto at = [&](size_t o) { return st.dev(o) + 32 * off; };
       int32_t *v_E1 = as.new_var(), *v_E2 = as.new_var();
       as.sccheck({ { at(o_a) } });
@@ -274,6 +277,7 @@ extern "C" int afx_decrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8
                  o_m3 = st.add(nullptr, row), o_E1p = st.add(nullptr, row), o_st = st.add(nullptr, count);
     if ((rc = st.upload())) return rc;
     rc = run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
+    as.secret_scalars = true;   // the user's symmetric key: afx_ctx_set_secret_independent_addressing
       auto at = [&](size_t o) { return st.dev(o) + 32 * off; };
       int32_t* v_M2 = as.new_var();
       uint8_t* k = as.new_enc();

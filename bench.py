@@ -190,6 +190,7 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
     n, layout, count = 16, "SSSSSSSSPPPPEEEE", (args.batch or (1 << 20))
     params, key, ip = load_fixture("c5_16attrs")
     issuer = afx.Context(params, key, ip, device=local_rank)
+    issuer.set_secret_independent_addressing(args.secret_independent)
     rng = np.random.default_rng(4242 + rank)
     rb = lambda *shape: rng.integers(0, 256, size=shape, dtype=np.uint8)
     dev = torch.device("cuda", local_rank)
@@ -266,6 +267,7 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
             "unit": "credentials/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic (random attribute values)",
             "config": {"workload": "C5: batch issue 2^20 credentials, 16 attributes (S x8, P x4, E x4)", "credentials_per_gpu": count,
+                       "secret_independent_addressing": bool(args.secret_independent),
                        "algorithmic_bytes_per_credential": ab, "parallelism": "host-sharded x%d, no collective" % world},
             "roofline": roofline_of(kt, "c5", ab, count),
             "valu": valu, "cpu_baseline": cpu}))
@@ -280,6 +282,7 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
     params, key, ip = load_fixture("readme_4attrs_sSPe")
     issuer = afx.Context(params, key, ip, device=local_rank)
     user = afx.Context(params, None, ip, device=local_rank)
+    user.set_secret_independent_addressing(args.secret_independent)
     rng = np.random.default_rng(99 + rank)
     rb = lambda *shape: rng.integers(0, 256, size=shape, dtype=np.uint8)
     dev = torch.device("cuda", local_rank)
@@ -373,6 +376,7 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
             "unit": "presentations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic (GPU-issued credentials)",
             "config": {"workload": "show 2^16 credentials, 4 attributes (s S P e)", "credentials_per_gpu": count, "algorithmic_bytes_per_presentation": ab,
+                       "secret_independent_addressing": bool(args.secret_independent),
                        "parallelism": "host-sharded x%d, no collective" % world},
             "roofline": roofline_of(kt, "show", ab, count),
             "valu": valu, "cpu_baseline": None}))
@@ -512,6 +516,8 @@ def main():
     ap.add_argument("--no-group-api", action="store_true", help="skip the afx_group_verify_presentations leg (rank 0, after the timed steps)")
     ap.add_argument("--pipelining", action="store_true", help="alternate steps between the engine's two streams (measured slower: the "
                     "path is VALU-bound, overlap only adds contention; default off)")
+    ap.add_argument("--secret-independent", action="store_true", help="afx_ctx_set_secret_independent_addressing on every context (cost "
+                    "measurement; results are the same bytes)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL; the driver's launch) or gloo (testing two ranks on one GPU)")
     args = ap.parse_args()
 
@@ -563,6 +569,7 @@ def main():
     want = corrupt(pres, count, 7 + rank)
     user.close()
     gen_s = time.time() - t0
+    issuer.set_secret_independent_addressing(args.secret_independent)   # after generation: only the timed verification pays
 
     # inputs resident in HBM before the timed region
     dev = torch.device("cuda", local_rank)
@@ -695,6 +702,7 @@ def main():
             "config": {"workload": desc, "presentations_per_gpu": count, "attributes": n, "shape": layout, "hidden": hide,
                        "algorithmic_bytes_per_presentation": ab, "parallelism": "host-sharded x%d, no collective" % world,
                        "step_pipelining": "2 streams" if args.pipelining else "off",
+                       "secret_independent_addressing": bool(args.secret_independent),
                        "input_generation_s": round(gen_s, 2), "host_pointer_api_presentations_per_s": pcie,
                        "wire_blob_api_presentations_per_s": wire_rate,
                        "ranks_seen": ranks_seen, "launcher": "bench.py" if os.environ.get("AFX_BENCH_LAUNCHED") else

@@ -155,6 +155,22 @@ int afx_ctx_set_strict(afx_ctx* ctx, int enable);
  * Results are identical in both modes. */
 int afx_ctx_set_fixed_key_schedule(afx_ctx* ctx, int enable);
 
+/* Secret-independent addressing (off by default).  The reference multiplies by secrets - the issuer key, the prover's nonces,
+ * blindings and witnesses - with dalek's constant-time `*` / `multiscalar_mul` (src/amacs.rs:267-270, src/nizk/presentation.rs:162-184,
+ * zkp's Prover), whose table lookups read every entry and select.  By default this engine's instruction stream is already
+ * independent of per-item secrets, but the window digit of a secret picks WHICH table entry a lane gathers from HBM.  With this
+ * mode on, no memory address depends on a secret digit either:
+ *   - afx_issue*, afx_show* and the symmetric-key helpers (afx_keypairs_derive, afx_encrypt, afx_decrypt, afx_issuer_keygen's
+ *     context): every scalar of every multiscalar job but the constant 1 is treated as a secret;
+ *   - afx_verify_presentations*: the issuer key's scalars in Z (which then also run the fixed schedule of
+ *     afx_ctx_set_fixed_key_schedule, whatever that setting says);
+ *   - a secret term on a per-item base reads all 8 entries of its lane's window table and keeps the digit's entry with selects;
+ *     a secret term on a generator uses 4-bit positional tables (63 KB per generator, built when the mode is first switched
+ *     on) whose 9 entries per window are all read: 64 additions per term instead of 20.
+ * Results are byte-identical in both modes.  Cost, measured: issue and show slower, verification a few
+ * per cent.  Everything else about timing is unchanged: kernels have no data-dependent branches in either mode. */
+int afx_ctx_set_secret_independent_addressing(afx_ctx* ctx, int enable);
+
 /* Items per internal pass (tuning; 0 restores the default of 2^19).  A batch larger than this is processed in passes
  * of this many items, which bounds the device workspace (about 25-70 KB per item and pass, depending on the
  * statement); smaller values trade throughput for memory.  Accepted range 256 .. 2^22. */

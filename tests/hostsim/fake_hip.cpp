@@ -51,10 +51,16 @@ hipError_t afxk_decode(hipStream_t, const afx_decode_job* j, uint32_t n, uint32_
 hipError_t afxk_sccheck(hipStream_t, const afx_sccheck_job* j, uint32_t n, uint32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].sc; return hipSuccess; }
 hipError_t afxk_pointop(hipStream_t, const afx_pointop_job* j, uint32_t n, uint32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
 hipError_t afxk_scalarop(hipStream_t, const afx_scalarop_job* j, uint32_t n, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
-hipError_t afxk_setup_postables(hipStream_t, const int32_t*, uint32_t, int32_t*, int32_t*) { return hipSuccess; }
+hipError_t afxk_setup_postables(hipStream_t, const int32_t*, uint32_t, int32_t*, int32_t*, int) { return hipSuccess; }
 hipError_t afxk_msm_tables(hipStream_t, int, const afx_table_job* r, uint32_t n, int32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)r[i].var + r[i].table_slot; return hipSuccess; }
-hipError_t afxk_msm(hipStream_t, int kind, int encodes, const afx_msm_job* j, uint32_t n, const int32_t*, int32_t*, uint32_t*, uint32_t*, uint32_t, unsigned long long* probe) {
+hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_msm_job* j, uint32_t n, const int32_t*, const int32_t* sec_tables, int32_t*, uint32_t*, uint32_t*, uint32_t,
+                    unsigned long long* probe) {
   if (probe) { probe[0] += 2250; probe[1] += 100; }
+  if (secret && !sec_tables) return hipErrorInvalidValue;
+  int any_secret = 0;
+  for (uint32_t i = 0; i < n; i++)
+    for (uint32_t t = 0; t < j[i].n_terms; t++) any_secret |= j[i].term[t].secret != 0;
+  if (any_secret != (secret != 0)) return hipErrorInvalidValue;   // the launch's flag is the OR of its terms' flags
   if (kind < 0 || kind > 2) return hipErrorInvalidValue;
   for (uint32_t i = 0; i < n; i++) {
     if (!encodes && j[i].out_enc && !j[i].half_var) return hipErrorInvalidValue;   // a job that encodes in the kernel needs the encoding launch

@@ -181,11 +181,11 @@ def test_c5_issue_2_20_credentials_16_attributes():
         assert s == 0 and t == bytes(iss["t"][i]) and U == bytes(iss["U"][i]) and V == bytes(iss["V"][i]) and ch == bytes(iss["challenge"][i])
         assert all(resp[k] == bytes(iss["responses"][k, i]) for k in range(n + 5))
     # a strided 2^16-item sample re-issued by the oracle (all host cores): every output byte
-    idx = _strided(count, 11)
-    oi, ost = oracle.issue_soa(octx, kinds, np.ascontiguousarray(values[:, idx]), tw[idx], uw[idx], seed[idx])
+    sidx = _strided(count, 11)
+    oi, ost = oracle.issue_soa(octx, kinds, np.ascontiguousarray(values[:, sidx]), tw[sidx], uw[sidx], seed[sidx])
     assert not ost.any()
     for f in ("t", "U", "V", "challenge", "responses"):
-        assert np.array_equal(oi[f], iss[f][..., idx, :]), f
+        assert np.array_equal(oi[f], iss[f][..., sidx, :]), f
     # 1 % corrupted: a response bit, the tag's V, an attribute value, the identity as U
     want = np.zeros(count, np.uint8)
     idx = np.random.default_rng(3).choice(count, size=count // 100, replace=False)
@@ -207,11 +207,11 @@ def test_c5_issue_2_20_credentials_16_attributes():
     user.set_challenge_trace(0, 0)
     # the same strided sample through the oracle's CredentialIssuance::verify: statuses and recomputed challenges
     uctx = oracle.Ctx(params, None, ip)
-    sub = {f: np.ascontiguousarray(iss[f][..., idx, :]) for f in ("t", "U", "V", "challenge", "responses")}
-    vst, vtrace, vreached = oracle.verify_issuances_traced(uctx, kinds, np.ascontiguousarray(values[:, idx]), sub)
-    assert np.array_equal(vst, got[idx]) and vst.sum() >= len(idx) // 200
+    sub = {f: np.ascontiguousarray(iss[f][..., sidx, :]) for f in ("t", "U", "V", "challenge", "responses")}
+    vst, vtrace, vreached = oracle.verify_issuances_traced(uctx, kinds, np.ascontiguousarray(values[:, sidx]), sub)
+    assert len(sidx) == SAMPLE and np.array_equal(vst, got[sidx]) and vst.sum() >= len(sidx) // 200
     r = vreached.astype(bool)
-    assert r.sum() > 0.99 * len(idx) and np.array_equal(vtrace[r], trace[idx][r])
+    assert r.sum() > 0.99 * len(sidx) and np.array_equal(vtrace[r], trace[sidx][r])
     # a sample of the rejected ones through the oracle's single-issuance entry point
     for i in sorted(int(x) for x in idx[:24]):
         vals = [bytes(values[k, i]) + bytes(64) for k in range(n)]

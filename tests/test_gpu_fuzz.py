@@ -36,6 +36,8 @@ def test_random_shapes_show_and_verify_like_the_oracle(seed):
         n, layout, hide = _random_shape(rng)
         strict = rng.random() < 0.3
         count = rng.choice((1, 7, 33, 65))
+        secret = random.Random(7700 + 4 * seed + case).random() < 0.4   # secret-independent addressing on both sides (its own stream:
+                                                                         # the shapes of earlier rounds' sweeps stay what they were)
         tag = b"fuzz-%d-%d" % (seed, case)
         d = make_credentials(n, layout, count, tag)
         user, issuer, take = d["user"], d["issuer"], d["take"]
@@ -55,6 +57,7 @@ def test_random_shapes_show_and_verify_like_the_oracle(seed):
         # AnonymousCredential::show on the GPU: the oracle's bytes
         uctx = afx.Context(d["params"], None, d["ip"])
         uctx.set_strict(strict)
+        uctx.set_secret_independent_addressing(secret)
         o, shape, status = gpu_show(afx, uctx, kinds, d["creds"], kps, zw, sd, es)
         uctx.close()
         assert status.tolist() == [0] * count, (layout, hide)
@@ -93,6 +96,7 @@ def test_random_shapes_show_and_verify_like_the_oracle(seed):
                     want_ch[1 + e][i] = ch
         ictx = afx.Context(d["params"], d["key"], d["ip"])
         ictx.set_strict(strict)
+        ictx.set_secret_independent_addressing(secret)
         ictx.set_challenge_trace(1 + nsp, count)
         got = gpu_verify(afx, ictx, pres)
         tr = ictx.get_challenge_trace()

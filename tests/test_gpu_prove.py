@@ -36,12 +36,15 @@ def gpu_issue(afx, ctx, kinds, values_rows, t_wide, U_wide, seeds, n_out=None):
     return o, status
 
 
+# secret: afx_ctx_set_secret_independent_addressing - every table entry read, 4-bit positional tables for the generators; same bytes
+@pytest.mark.parametrize("secret", [False, True])
 @pytest.mark.parametrize("n,layout,count", [(4, "SSPE", 70), (16, "SSSSSSSSPPPPEEEE", 20), (1, "P", 3), (3, "SSP", 65)])
-def test_issue_matches_oracle_bytes_and_verifies(n, layout, count):
+def test_issue_matches_oracle_bytes_and_verifies(n, layout, count, secret):
     import aeonflux_amd as afx
     d = make_credentials(n, layout, count, b"gpu-issue-%d" % n)
     creds = d["creds"]
     ctx = afx.Context(d["params"], d["key"], d["ip"])
+    ctx.set_secret_independent_addressing(secret)
     kinds = creds[0]["kinds"]
     values_rows = [[c["values"][i][:32] for c in creds] for i in range(n)]
     o, status = gpu_issue(afx, ctx, kinds, values_rows, [c["rnd"][0] for c in creds], [c["rnd"][1] for c in creds], [c["rnd"][2] for c in creds])
@@ -173,7 +176,8 @@ def gpu_show(afx, ctx, kinds, creds, keypairs, z_wide, seeds, enc_seeds):
     (32, "E" * 32, list(range(32)), 2),     # 32 proofs of encryption per presentation
     (32, "S" * 32, list(range(32)), 2),     # 32 hidden scalars
 ])
-def test_show_matches_oracle_bytes_and_gpu_verifies(n, layout, hide, count):
+@pytest.mark.parametrize("secret", [False, True])   # afx_ctx_set_secret_independent_addressing: same bytes
+def test_show_matches_oracle_bytes_and_gpu_verifies(n, layout, hide, count, secret):
     import aeonflux_amd as afx
     d = make_credentials(n, layout, count, b"gpu-show-%d" % n)
     take, user, issuer = d["take"], d["user"], d["issuer"]
@@ -191,6 +195,7 @@ def test_show_matches_oracle_bytes_and_gpu_verifies(n, layout, hide, count):
         assert st == 0
         want.append(p)
     uctx = afx.Context(d["params"], None, d["ip"])
+    uctx.set_secret_independent_addressing(secret)
     o, shape, status = gpu_show(afx, uctx, kinds, d["creds"], kps, zw, sd, es)
     uctx.close()
     assert status.tolist() == [0] * count
@@ -221,6 +226,7 @@ def test_show_matches_oracle_bytes_and_gpu_verifies(n, layout, hide, count):
     # and the issuer's GPU verify agrees with the oracle on the oracle-made twins
     from tests.helpers import gpu_verify
     ictx = afx.Context(d["params"], d["key"], d["ip"])
+    ictx.set_secret_independent_addressing(secret)   # the verifier's side of the mode: the key's terms of Z
     assert gpu_verify(afx, ictx, want) == [issuer.verify_presentation(p) for p in want]
     ictx.close()
 

@@ -113,6 +113,19 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     batch.verify_presentations(ctx, shape, pres)
     batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
     assert afx.lib().afx_ctx_set_fixed_key_schedule(ctx.h, 0) == 0
+    # secret-independent addressing: prover plans mark every term, the verifier's plan the key's terms; the fake launcher checks
+    # that each launch's flag is the OR of its terms' flags and that the 4-bit tables exist
+    ctx.set_secret_independent_addressing(True)
+    batch.verify_presentations(ctx, shape, pres)
+    batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
+    batch.show(ctx, k2, values, iss["t"], iss["U"], iss["V"], kp, rb(3, 64), rb(3, 32), rb(max(nsp, 1), 3, 32), values, values)
+    assert afx.lib().afx_encrypt(ctx.h, C.byref(kpsoa), e[0].ctypes.data, e[1].ctypes.data, e[2].ctypes.data, 3, e[3].ctypes.data, e[4].ctypes.data, stx.ctypes.data) == 0
+    assert ctx.plan_stats()["fixed_additions"] == 0   # E2 = a*E1 + M1: one variable base
+    batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
+    sec_fixed = ctx.plan_stats()["fixed_additions"]
+    ctx.set_secret_independent_addressing(False)
+    batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
+    assert sec_fixed > 2 * ctx.plan_stats()["fixed_additions"] > 0   # 64 additions per secret fixed-base term instead of 20
     mhz = C.c_double(-1)
     assert afx.lib().afx_ctx_get_core_clock_mhz(ctx.h, C.byref(mhz)) == 0 and mhz.value >= 0
     # a range of a batch, and the same batch over a two-member group (two fake devices)
