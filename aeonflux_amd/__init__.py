@@ -138,6 +138,7 @@ def lib():
         _LIB.afx_ctx_set_fixed_key_schedule.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_set_secret_independent_addressing.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_set_chunk_items.argtypes = [C.c_void_p, C.c_uint32]
+        _LIB.afx_ctx_set_small_batch_items.argtypes = [C.c_void_p, C.c_uint32]
         _LIB.afx_ctx_issuer_parameters.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.afx_issuance_wire_header_bytes.restype = C.c_size_t
         _LIB.afx_issuance_wire_header_bytes.argtypes = [C.c_uint32]
@@ -212,6 +213,10 @@ class Context:
     def set_chunk_items(self, items):
         """items per internal pass (0 = default 2^19); bounds the device workspace"""
         check(lib().afx_ctx_set_chunk_items(self.h, items))
+
+    def set_small_batch_items(self, items):
+        """passes of at most this many items take the latency plan (one chain per term); 0 = off (afx_ctx_set_small_batch_items)"""
+        check(lib().afx_ctx_set_small_batch_items(self.h, items))
 
     def set_strict(self, enable):
         """opt-in strict mode (not the reference's behaviour): see afx_ctx_set_strict in include/aeonflux_gpu.h"""

@@ -230,7 +230,103 @@ static std::vector<size_t> balanced_row_order(const std::vector<size_t>& heads, 
   return order;
 }
 
+// k_compress2x over `cjobs`, in `groups` grid rows: each row walks its share of an item's jobs with one field inversion
+void Assembler::compress(const std::vector<afx_compress_job>& cjobs, uint32_t groups) {
+  if (cjobs.empty()) return;
+  Launch cl;
+  cl.kind = L_COMPRESS;
+  cl.njobs = (uint32_t)cjobs.size();
+  cl.per_group = groups > 1 ? (cl.njobs + groups - 1) / groups : 0;
+  cl.jobs_off = blob_alloc(sizeof(afx_compress_job) * cjobs.size(), 16);
+  memcpy(blob_.data() + cl.jobs_off, cjobs.data(), sizeof(afx_compress_job) * cjobs.size());
+  cl.prefix_ws = (int32_t*)ws_alloc(sizeof(int32_t) * 9 * cjobs.size() * (size_t)count);
+  launches.push_back(cl);
+  // the plain encodings were counted job by job: replace them by k_compress2x's share (two passes over e, f, g, h per job, one
+  // inversion per row)
+  const uint64_t rows = cl.per_group ? (cl.njobs + cl.per_group - 1) / cl.per_group : 1;
+  stats.field_mul += 22 * cjobs.size() + 11 * rows; stats.field_mul -= AFX_ENCODE_MUL * cjobs.size();
+  stats.field_sq += 8 * cjobs.size() + 254 * rows; stats.field_sq -= AFX_ENCODE_SQ * cjobs.size();
+}
+
+// Multiscalar jobs of one statement stage.  Large passes: one lane per (job, item), every job a single chain (msm_list).  Small
+// passes (at most afx_ctx_set_small_batch_items items, default 2048): the device is mostly idle and a call's duration is the
+// LONGEST chain, so every variable-base term gets a chain of its own (msm_split).
 void Assembler::msm(std::vector<afx_msm_job> jobs) {
+  if (jobs.empty()) return;
+  std::vector<afx_compress_job> cjobs;
+  const bool small = ctx->small_batch_items != 0 && count <= ctx->small_batch_items;
+  if (small) msm_split(std::move(jobs), cjobs);
+  else msm_list(std::move(jobs), false, cjobs);
+  // small passes: the item's commitments are encoded in up to 8 rows, an inversion each, instead of one serial walk
+  compress(cjobs, small ? 8u : 1u);
+}
+
+// One chain per term.  A job with more than one part - each variable-base term, and its fixed-base terms together - becomes
+// that many single-part jobs writing partial sums, plus a k_pointsum row adding them (and the addend) up; a job that feeds
+// another (chain_to) is summed before the consumer's chains start, so stages run level by level.  No NAF schedules here: a
+// lone key term costs 64 additions instead of ~43, but shares the windowed launch with every other chain of its stage.
+void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compress_job>& cjobs) {
+  const size_t n = jobs.size();
+  for (size_t i = 0; i < n; i++)
+    if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
+  std::vector<int> level(n, 0);
+  for (size_t pass = 0; pass <= n; pass++) {
+    bool moved = false;
+    for (size_t i = 0; i < n; i++)
+      if (jobs[i].chain_to >= 0 && level[jobs[i].chain_to] < level[i] + 1) { level[jobs[i].chain_to] = level[i] + 1; moved = true; }
+    if (!moved) break;
+    if (pass == n) throw std::logic_error("msm chain cycle");
+  }
+  const int top = *std::max_element(level.begin(), level.end());
+  for (int lv = 0; lv <= top; lv++) {
+    std::vector<afx_msm_job> subs;
+    std::vector<afx_pointsum_job> sums;
+    for (size_t i = 0; i < n; i++) {
+      if (level[i] != lv) continue;
+      afx_msm_job j = jobs[i];
+      j.chain_to = -1;
+      const uint32_t parts = j.n_var + (j.n_terms > j.n_var ? 1u : 0u);
+      if (parts <= 1) { subs.push_back(j); continue; }   // a single chain already (its addend, if any, is added by its own lane)
+      const bool halved = j.out_enc && !j.out_var && !j.addend;   // only ever encoded: halved scalars, k_compress2x (msm_list)
+      std::vector<const int32_t*> part_vars;
+      auto sub_of = [&](uint32_t first, uint32_t nterms, uint32_t nvar) {
+        afx_msm_job s;
+        memset(&s, 0, sizeof s);
+        s.n_terms = nterms; s.n_var = nvar; s.chain_to = -1;
+        for (uint32_t t = 0; t < nterms; t++) s.term[t] = j.term[first + t];
+        int32_t* v = new_var();
+        if (halved) s.half_var = v; else s.out_var = v;
+        part_vars.push_back(v);
+        subs.push_back(s);
+      };
+      for (uint32_t t = 0; t < j.n_var; t++) sub_of(t, 1, 1);
+      if (j.n_terms > j.n_var) sub_of(j.n_var, j.n_terms - j.n_var, 0);
+      afx_pointsum_job sj;
+      memset(&sj, 0, sizeof sj);
+      sj.parts = put(part_vars.data(), part_vars.size());
+      sj.n_parts = (uint32_t)part_vars.size();
+      sj.addend = j.addend; sj.addend_negate = j.addend_negate;
+      sj.out_var = j.out_var;
+      sj.reject_identity = j.reject_identity;
+      if (halved) {
+        sj.half_var = new_var();
+        afx_compress_job cj = { sj.half_var, j.out_enc, j.reject_identity, 0 };
+        cjobs.push_back(cj);
+        stats.encodings++; stats.field_mul += AFX_ENCODE_MUL; stats.field_sq += AFX_ENCODE_SQ;   // compress() rewrites this share
+      } else {
+        sj.out_enc = j.out_enc;
+        if (j.out_enc) { stats.encodings++; stats.field_mul += AFX_ENCODE_MUL; stats.field_sq += AFX_ENCODE_SQ; }
+      }
+      stats.var_additions += sj.n_parts - 1 + (sj.addend ? 1 : 0);
+      stats.field_mul += 9 * (uint64_t)(sj.n_parts - 1 + (sj.addend ? 1 : 0));
+      sums.push_back(sj);
+    }
+    msm_list(std::move(subs), true, cjobs);
+    add_jobs(L_POINTSUM, sums);
+  }
+}
+
+void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector<afx_compress_job>& cjobs) {
   if (jobs.empty()) return;
   // kilo-cycles of VALU issue per wave (profiles/r01_fe_rates_ubench.txt): 63 windows of 4 doublings + the final
   // encoding; 64 additions + the 9-entry table per variable base; AFX_POS_WINDOWS additions per fixed base
@@ -254,7 +350,9 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
   // Jobs whose result is only ever encoded (no consumer of the point itself, no addend) run on halved scalars; k_compress2x
   // encodes the doubles (below, and kernels.hip)
-  auto encoded_only = [&](const afx_msm_job& j) { return j.out_enc && !j.out_var && !j.addend; };
+  auto encoded_only = [&](const afx_msm_job& j) { return j.out_enc && !j.out_var && !j.addend && !j.half_var; };
+  // ... and the parts of such a job that msm_split cut up arrive with their half_var set: halved scalars, no encoding of their own
+  auto halved = [&](const afx_msm_job& j) { return j.half_var != nullptr || encoded_only(j); };
   // variable bases whose scalar is a batch constant the host knows (the issuer key in Z and in the tag) go first
   // and run a width-5 NAF: ~43 additions each instead of 64, same schedule for every lane
   std::vector<std::vector<int8_t>> naf_of(jobs.size());
@@ -266,7 +364,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     std::vector<const uint8_t*> hs;
     for (uint32_t t = 0; t < j.n_var; t++) {
       // afx_ctx_set_fixed_key_schedule: key scalars take the per-item window path (64 additions each, whatever the key)
-      const uint8_t* h = (j.term[t].scalar_stride == 0 && !ctx->fixed_key_schedule && !sec_mode) ? host_scalar_of(ctx, j.term[t].scalar) : nullptr;
+      const uint8_t* h = (j.term[t].scalar_stride == 0 && !ctx->fixed_key_schedule && !sec_mode && !no_naf) ? host_scalar_of(ctx, j.term[t].scalar) : nullptr;
       if (h) { uni.push_back(j.term[t]); hs.push_back(h); } else lane.push_back(j.term[t]);
     }
     if (uni.empty()) continue;
@@ -279,10 +377,10 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     int top = lane.empty() ? 0 : 252;   // per-item windows start at bit 252
     for (size_t u = 0; u < uni.size(); u++) {
       int8_t* d = naf_of[ji].data() + 256 * u;
-      uint8_t halved[32];
-      if (encoded_only(j)) host_half(halved, hs[u]);   // the device halves the per-item scalars of such a job (msm_recode)
-      top = std::max(top, naf5(d, encoded_only(j) ? halved : hs[u]));
-      secure_zero(halved, sizeof halved);
+      uint8_t hbuf[32];
+      if (halved(j)) host_half(hbuf, hs[u]);   // the device halves the per-item scalars of such a job (msm_recode)
+      top = std::max(top, naf5(d, halved(j) ? hbuf : hs[u]));
+      secure_zero(hbuf, sizeof hbuf);
       for (int b = 0; b < 256; b++) {
         if (uni[u].negate) d[b] = (int8_t)-d[b];
         nafc_of[ji][b] += d[b] != 0;
@@ -354,18 +452,14 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   // inversion per item (kernels.hip).  That is every recomputed or fresh commitment of a Schnorr proof (26 of the 35 encodings
   // of a C3 presentation), the tag's V and the scalar attributes' messages of an issuance.
   std::vector<int32_t*> half_of(n, nullptr);
-  std::vector<afx_compress_job> cjobs;
   for (size_t i = 0; i < n; i++) {
     const afx_msm_job& j = jobs[i];
+    if (j.half_var) { half_of[i] = j.half_var; continue; }   // a part of a split job: summed, then encoded with its siblings
     if (!encoded_only(j)) continue;
     half_of[i] = new_var();
     afx_compress_job cj = { half_of[i], j.out_enc, j.reject_identity, 0 };
-    cjobs.push_back(cj);
-    // the plain encoding was counted above: replace it by this job's share of k_compress2x (two passes over e, f, g, h)
-    stats.field_mul += 22; stats.field_mul -= AFX_ENCODE_MUL;
-    stats.field_sq += 8; stats.field_sq -= AFX_ENCODE_SQ;
+    cjobs.push_back(cj);   // Assembler::compress rewrites the encoding's share of the operation counts
   }
-  if (!cjobs.empty()) { stats.field_mul += 11; stats.field_sq += 254; }   // the one inversion
   std::vector<char> done(n, 0);
   const uint32_t blocks_per_row = (count + AFX_BLOCK - 1) / AFX_BLOCK, resident = 2 * ctx->n_cu;
   uint32_t dslot = 0, tslot = 0;
@@ -450,15 +544,6 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     memcpy(blob_.data() + l.jobs_off, out.data(), sizeof(afx_msm_job) * out.size());
     launches.push_back(l);
   }
-  if (!cjobs.empty()) {
-    Launch cl;
-    cl.kind = L_COMPRESS;
-    cl.njobs = (uint32_t)cjobs.size();
-    cl.jobs_off = blob_alloc(sizeof(afx_compress_job) * cjobs.size(), 16);
-    memcpy(blob_.data() + cl.jobs_off, cjobs.data(), sizeof(afx_compress_job) * cjobs.size());
-    cl.prefix_ws = (int32_t*)ws_alloc(sizeof(int32_t) * 9 * cjobs.size() * (size_t)count);
-    launches.push_back(cl);
-  }
   max_digit_slots = std::max<size_t>(max_digit_slots, dslot);
   max_table_slots = std::max<size_t>(max_table_slots, tslot);
 }
@@ -519,7 +604,8 @@ int Assembler::run() {
       case L_SCCHECK: AFX_HIP(afxk_sccheck(s, (const afx_sccheck_job*)jobs, l.njobs, bad_, count)); break;
       case L_POINTOP: AFX_HIP(afxk_pointop(s, (const afx_pointop_job*)jobs, l.njobs, bad_, count)); break;
       case L_SCALAROP: AFX_HIP(afxk_scalarop(s, (const afx_scalarop_job*)jobs, l.njobs, count)); break;
-      case L_COMPRESS: AFX_HIP(afxk_compress2x(s, (const afx_compress_job*)jobs, l.njobs, l.prefix_ws, bad_, count)); break;
+      case L_COMPRESS: AFX_HIP(afxk_compress2x(s, (const afx_compress_job*)jobs, l.njobs, l.per_group, l.prefix_ws, bad_, count)); break;
+      case L_POINTSUM: AFX_HIP(afxk_pointsum(s, (const afx_pointsum_job*)jobs, l.njobs, bad_, count)); break;
       case L_MSM_TABLES: AFX_HIP(afxk_msm_tables(s, l.odd, (const afx_table_job*)jobs, l.njobs, table_ws, count)); break;
       case L_MSM_FIXED: case L_MSM_WINDOW: case L_MSM_NAF: {
         // pipelined lanes: the heavy kernel of one lane never runs beside the other lane's (only the light kernels

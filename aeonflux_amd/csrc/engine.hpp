@@ -104,6 +104,7 @@ struct afx_ctx {
   bool fixed_key_schedule = false;   // afx_ctx_set_fixed_key_schedule: no NAF for the issuer key's scalars
   bool secret_independent = false;   // afx_ctx_set_secret_independent_addressing: no memory address depends on a secret digit
   uint32_t chunk_items = 0;   // afx_ctx_set_chunk_items; 0 = default
+  uint32_t small_batch_items = 2048;   // afx_ctx_set_small_batch_items: passes of at most this many items take the latency plan
   afx_plan_stats last_stats = {};   // per-item operation counts of the most recent plan
   std::map<std::pair<std::string, uint32_t>, size_t> plan_sizes;   // (plan key bytes, pass size) -> workspace bytes (statements.hpp run_chunked)
   uint32_t n_cu = 256;   // compute units of the device (k_msm keeps 2 blocks resident on each)
@@ -118,15 +119,15 @@ struct afx_ctx {
   struct TimedLaunch { int kind; hipEvent_t start, stop; };
   std::vector<TimedLaunch> timed;          // recorded, not yet read back
   std::vector<hipEvent_t> event_pool;      // recycled events
-  double kind_ms[16] = { 0 };
-  uint64_t kind_launches[16] = { 0 };
+  double kind_ms[24] = { 0 };
+  uint64_t kind_launches[24] = { 0 };
 };
 
 namespace afx {
 
 // L_MSM_WINDOW keeps the slot the single k_msm kernel had (timing names: statements.cpp KIND_NAMES)
 enum LaunchKind { L_FILL_BAD, L_DECODE, L_SCCHECK, L_POINTOP, L_SCALAROP, L_MSM_WINDOW, L_HASH, L_FROM_UNIFORM, L_REDUCE_WIDE, L_COPY, L_FINISH,
-                  L_MSM_FIXED, L_MSM_NAF, L_MSM_TABLES, L_COMPRESS, L_KINDS };
+                  L_MSM_FIXED, L_MSM_NAF, L_MSM_TABLES, L_COMPRESS, L_POINTSUM, L_KINDS };
 
 struct Launch {
   LaunchKind kind;
@@ -142,6 +143,7 @@ struct Launch {
   int encodes = 1;          // L_MSM_*: some job of the launch encodes its result inside the kernel (kernels.hip k_msm<KIND, ENC, SEC>)
   int secret = 0;           // L_MSM_*: some term of the launch has a secret scalar under secret-independent addressing
   int32_t* prefix_ws = nullptr;   // L_COMPRESS: scratch for the prefix products (njobs * 9 * count dwords)
+  uint32_t per_group = 0;         // L_COMPRESS: jobs per grid row (each row shares one inversion per item); 0 = all in one row
 };
 
 // Builds one call's kernel launch list over a chunk of `count` items.
@@ -174,7 +176,7 @@ class Assembler {
   void sccheck(const std::vector<afx_sccheck_job>& jobs);
   void pointop(const std::vector<afx_pointop_job>& jobs);
   void scalarop(const std::vector<afx_scalarop_job>& jobs);
-  void msm(std::vector<afx_msm_job> jobs);   // assigns digit/table slots
+  void msm(std::vector<afx_msm_job> jobs);   // assigns digit/table slots; small batches: one chain per term (msm_split)
   void hash(const std::vector<afx_hash_program>& progs);
   void from_uniform(const uint8_t* wide, uint8_t* out_enc, int32_t* out_var);
   void reduce_wide(const uint8_t* wide, uint8_t* out);
@@ -198,6 +200,9 @@ class Assembler {
 
  private:
   uint8_t* ws_alloc(size_t bytes);
+  void msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector<afx_compress_job>& cjobs);
+  void msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compress_job>& cjobs);
+  void compress(const std::vector<afx_compress_job>& cjobs, uint32_t groups);
   template <class T>
   void add_jobs(LaunchKind k, const std::vector<T>& jobs);
   bool sizing_ = false;

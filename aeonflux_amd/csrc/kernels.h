@@ -17,7 +17,9 @@ hipError_t afxk_msm_tables(hipStream_t s, int odd, const afx_table_job* rows, ui
 hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables, const int32_t* sec_tables,
                     int32_t* table_ws, uint32_t* digit_ws, uint32_t* bad, uint32_t count, unsigned long long* clock_probe);
 // out_enc = encoding of twice each job's point; prefix_ws: njobs * 9 * count dwords of scratch (one 9-limb field element per job and item)
-hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, uint32_t njobs, int32_t* prefix_ws, uint32_t* bad, uint32_t count);
+// per_row: jobs per grid row, each row sharing one field inversion per item (0 = all jobs in one row)
+hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, uint32_t njobs, uint32_t per_row, int32_t* prefix_ws, uint32_t* bad, uint32_t count);
+hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count);
 hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count);
 hipError_t afxk_finish(hipStream_t s, const uint32_t* bad, uint8_t* status, uint32_t count, uint32_t fail_all, uint8_t fail_code);
 hipError_t afxk_fill_u32(hipStream_t s, uint32_t* p, uint32_t v, uint32_t n);

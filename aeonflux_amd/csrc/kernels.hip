@@ -570,10 +570,15 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
 // encodings backwards.  e*f*g*h = 0 exactly for the identity's representatives (X = 0 or Y = 0; f, g, h never vanish on the
 // even subgroup), whose encoding is all zeros; such a factor is left out of the product.  tests/: every byte-parity test of the
 // commitments and challenges goes through this kernel; tests/pyref checks the formula against encode(P + P).
+// Grid row y walks the jobs [y * per_row, (y + 1) * per_row) of the item: one row (and one inversion per item) for large passes;
+// small passes, where the serial walk is what a call waits for, spread an item's commitments over up to 8 rows.
 __global__ void __launch_bounds__(AFX_BLOCK, 2)
-k_compress2x(const afx_compress_job* __restrict__ jobs, uint32_t njobs, int32_t* __restrict__ prefix_ws, uint32_t* __restrict__ bad, uint32_t count) {
+k_compress2x(const afx_compress_job* __restrict__ jobs, uint32_t njobs_all, uint32_t per_row, int32_t* __restrict__ prefix_ws, uint32_t* __restrict__ bad, uint32_t count) {
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
   if (item >= count) return;
+  const uint32_t first = blockIdx.y * per_row, njobs = min(per_row, njobs_all - first);
+  jobs += first;
+  prefix_ws += (size_t)first * AFX_FE_LIMBS * count;
   fe prod = fe_one();
 #pragma unroll 1
   for (uint32_t j = 0; j < njobs; j++) {
@@ -592,6 +597,25 @@ k_compress2x(const afx_compress_job* __restrict__ jobs, uint32_t njobs, int32_t*
     c2x_finish(w, s, inv_j);
     enc_store(jobs[j].out_enc, item, w);
     if (jobs[j].reject_identity && is_identity_encoding(w)) atomicOr(&bad[item], AFX_BAD_IDENTITY);
+  }
+}
+
+// k_pointsum: out = sum of the partial results of a job that Assembler::msm_split cut into one chain per term (+- addend)
+__global__ void __launch_bounds__(AFX_BLOCK, 2) k_pointsum(const afx_pointsum_job* __restrict__ jobs, uint32_t* __restrict__ bad, uint32_t count) {
+  const afx_pointsum_job job = jobs[blockIdx.y];
+  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  if (item >= count) return;
+  ge_p3 acc = var_load(job.parts[0], count, item);
+#pragma unroll 1
+  for (uint32_t k = 1; k < job.n_parts; k++) acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_p3_to_cached(var_load(job.parts[k], count, item)), false));
+  if (job.addend) acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_p3_to_cached(var_load(job.addend, count, item)), job.addend_negate != 0));
+  if (job.out_var) var_store(job.out_var, count, item, acc);
+  if (job.half_var) { var_store(job.half_var, count, item, acc); return; }   // encoded by k_compress2x
+  if (job.out_enc) {
+    uint32_t w[8];
+    ristretto_encode(w, acc);
+    enc_store(job.out_enc, item, w);
+    if (job.reject_identity && is_identity_encoding(w)) atomicOr(&bad[item], AFX_BAD_IDENTITY);
   }
 }
 
@@ -793,8 +817,13 @@ hipError_t afxk_msm_tables(hipStream_t s, int odd, const afx_table_job* rows, ui
   else hipLaunchKernelGGL(k_msm_tables<false>, grid_for(count, nrows), dim3(AFX_BLOCK), 0, s, rows, table_ws, count);
   return hipGetLastError();
 }
-hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, uint32_t njobs, int32_t* prefix_ws, uint32_t* bad, uint32_t count) {
-  hipLaunchKernelGGL(k_compress2x, dim3((count + AFX_BLOCK - 1) / AFX_BLOCK), dim3(AFX_BLOCK), 0, s, jobs, njobs, prefix_ws, bad, count);
+hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, uint32_t njobs, uint32_t per_row, int32_t* prefix_ws, uint32_t* bad, uint32_t count) {
+  if (per_row == 0 || per_row > njobs) per_row = njobs;
+  hipLaunchKernelGGL(k_compress2x, dim3((count + AFX_BLOCK - 1) / AFX_BLOCK, (njobs + per_row - 1) / per_row), dim3(AFX_BLOCK), 0, s, jobs, njobs, per_row, prefix_ws, bad, count);
+  return hipGetLastError();
+}
+hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count) {
+  hipLaunchKernelGGL(k_pointsum, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, bad, count);
   return hipGetLastError();
 }
 hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count) {

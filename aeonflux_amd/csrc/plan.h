@@ -137,6 +137,20 @@ typedef struct {
   uint32_t pad;
 } afx_compress_job;
 
+/* k_pointsum (small batches: Assembler::msm splits a job into one chain per term and sums the partial results here):
+ * out = sum of parts (+- addend); stored to out_var and/or half_var (then encoded by k_compress2x), or encoded here */
+typedef struct {
+  const int32_t* const* parts;  /* device array of n_parts SoA extended points                     */
+  uint32_t n_parts;
+  uint32_t addend_negate;
+  const int32_t* addend;        /* optional                                                         */
+  afx_var_t out_var;            /* may be null                                                      */
+  afx_var_t half_var;           /* may be null: the parts were computed on halved scalars           */
+  uint8_t* out_enc;             /* [count][32], encoded in this kernel when half_var is null; may be null */
+  uint32_t reject_identity;
+  uint32_t pad;
+} afx_pointsum_job;
+
 /* one 8-byte word of a STROBE rate block: st = (st & keep) ^ c ^ (field_word & fmask) */
 typedef struct {
   uint64_t c;

@@ -37,7 +37,7 @@ extern "C" void* afx_ctx_stream(const afx_ctx* ctx) { return ctx ? (void*)ctx->s
 
 // indexed by afx::LaunchKind.  "k_msm" (afx_ctx_get_timing) = the three chain kernels + the table kernel together
 static const char* const KIND_NAMES[] = { "k_fill_u32", "k_decode", "k_sccheck", "k_pointop", "k_scalarop", "k_msm_window", "k_hash",
-                                          "k_from_uniform", "k_reduce_wide", "copy", "k_finish", "k_msm_fixed", "k_msm_naf", "k_msm_tables", "k_compress2x" };
+                                          "k_from_uniform", "k_reduce_wide", "copy", "k_finish", "k_msm_fixed", "k_msm_naf", "k_msm_tables", "k_compress2x", "k_pointsum" };
 static_assert(sizeof KIND_NAMES / sizeof KIND_NAMES[0] == afx::L_KINDS, "one name per launch kind");
 static int drain_timing(afx_ctx* c) {
   for (auto& L : c->lane)
@@ -97,6 +97,12 @@ extern "C" int afx_ctx_set_chunk_items(afx_ctx* c, uint32_t items) try {
   c->chunk_items = items;
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_set_small_batch_items(afx_ctx* c, uint32_t items) try {
+  if (!c || items > (1u << 16)) { set_error("small-batch threshold out of range"); return AFX_E_BAD_ARGS; }
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  c->small_batch_items = items;
+  return AFX_OK;
+} catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_set_strict(afx_ctx* c, int enable) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
@@ -147,7 +153,7 @@ extern "C" int afx_ctx_set_timing(afx_ctx* c, int enable) try {
   AFX_HIP(hipSetDevice(c->device));
   int rc = drain_timing(c);
   if (rc) return rc;
-  for (int k = 0; k < 16; k++) { c->kind_ms[k] = 0; c->kind_launches[k] = 0; }
+  for (int k = 0; k < (int)afx::L_KINDS; k++) { c->kind_ms[k] = 0; c->kind_launches[k] = 0; }
   if (c->d_consts.p) AFX_HIP(hipMemsetAsync(c->clock_probe(), 0, 16, c->stream));
   c->timing = enable != 0;
   return AFX_OK;

@@ -51,7 +51,7 @@ inline afx_shape canonical_shape(const afx_shape& sh) {
 // mode flags that change a plan's size, for plan_key (every statement passes them all: a flag that does not matter to a
 // statement only costs it a second cache entry)
 inline uint64_t mode_flags(const afx_ctx* c) {
-  return (c->strict ? 1u : 0u) | (c->fixed_key_schedule ? 2u : 0u) | (c->secret_independent ? 8u : 0u);
+  return (c->strict ? 1u : 0u) | (c->fixed_key_schedule ? 2u : 0u) | (c->secret_independent ? 8u : 0u) | ((uint64_t)c->small_batch_items << 8);
 }
 
 // key non-empty: the plan's workspace size is remembered per (key, pass size), so that repeated calls of one statement

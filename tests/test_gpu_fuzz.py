@@ -56,7 +56,9 @@ def test_random_shapes_show_and_verify_like_the_oracle(seed):
             pres.append(p)
         # AnonymousCredential::show on the GPU: the oracle's bytes
         uctx = afx.Context(d["params"], None, d["ip"])
+        latency_plan = random.Random(8800 + 4 * seed + case).random() < 0.5   # one chain per term (the default for small passes) or one per job
         uctx.set_strict(strict)
+        uctx.set_small_batch_items(2048 if latency_plan else 0)
         uctx.set_secret_independent_addressing(secret)
         o, shape, status = gpu_show(afx, uctx, kinds, d["creds"], kps, zw, sd, es)
         uctx.close()
@@ -96,6 +98,7 @@ def test_random_shapes_show_and_verify_like_the_oracle(seed):
                     want_ch[1 + e][i] = ch
         ictx = afx.Context(d["params"], d["key"], d["ip"])
         ictx.set_strict(strict)
+        ictx.set_small_batch_items(2048 if latency_plan else 0)
         ictx.set_secret_independent_addressing(secret)
         ictx.set_challenge_trace(1 + nsp, count)
         got = gpu_verify(afx, ictx, pres)

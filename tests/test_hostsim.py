@@ -113,6 +113,15 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     batch.verify_presentations(ctx, shape, pres)
     batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
     assert afx.lib().afx_ctx_set_fixed_key_schedule(ctx.h, 0) == 0
+    # the plan of large passes (one chain per job, NAF schedules for the key) at this size too: the default here is the latency plan
+    ctx.set_small_batch_items(0)
+    batch.verify_presentations(ctx, shape, pres)
+    big_jobs = ctx.plan_stats()["msm_jobs"]
+    batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
+    batch.show(ctx, k2, values, iss["t"], iss["U"], iss["V"], kp, rb(3, 64), rb(3, 32), rb(max(nsp, 1), 3, 32), values, values)
+    ctx.set_small_batch_items(2048)
+    batch.verify_presentations(ctx, shape, pres)
+    assert ctx.plan_stats()["msm_jobs"] >= big_jobs   # one chain per term
     # secret-independent addressing: prover plans mark every term, the verifier's plan the key's terms; the fake launcher checks
     # that each launch's flag is the OR of its terms' flags and that the 4-bit tables exist
     ctx.set_secret_independent_addressing(True)
