@@ -281,6 +281,12 @@ if __name__ == "__main__":
             from tests.test_pyref_cross_check import test_every_flow_replays_byte_for_byte
             test_every_flow_replays_byte_for_byte(data["flows"])
             data["_source"] += "; every flow cross-checked byte for byte against tests/pyref (independent pure-Python restatement)"
+            # ... and libsodium must recompute every group operation of that replay (tests/sodium_replay.py): the flows' group
+            # values are then pinned by a third implementation; labels / order / constraint lists by the two restatements only
+            from tests import sodium_replay
+            ops = sodium_replay.replay_flows(sod, data["flows"])
+            data["_source"] += "; every group operation of that replay recomputed with libsodium 1.0.18 (%d multiscalar sums, %d scalar " \
+                               "multiplications, %d additions/subtractions/negations)" % (ops["msm"], ops["mul"], ops["add"] + ops["sub"] + ops["neg"])
         with open(os.path.join(HERE, "golden", name + ".json"), "w") as f:
             json.dump(data, f, indent=1)
         print("wrote", name)

@@ -90,7 +90,37 @@ def encode(pt):
     return _abs(den_inv * (Z - y) % P).to_bytes(32, "little")
 
 
-def add(p, q):
+# TRACE: when a list, every top-level group operation of the statement code is recorded as (op, [scalars], [encodings of the
+# input points], encoding of the result) - tests/gen_golden.py and tests/test_pyref_cross_check.py replay the records through
+# libsodium, which pins the GROUP VALUES of every flow (tags, commitments, ciphertexts, recomputed commitments) to a third
+# implementation; the operations inside mul / msm / sub are not recorded on their own.
+TRACE = None
+_depth = 0
+
+
+def _traced(op):
+    def wrap(fn):
+        def inner(*args):
+            global _depth
+            if TRACE is None or _depth:
+                return fn(*args)
+            _depth += 1
+            try:
+                out = fn(*args)
+            finally:
+                _depth -= 1
+            if op == "mul":
+                TRACE.append((op, [args[0] % L], [encode(args[1])], encode(out)))
+            elif op == "msm":
+                TRACE.append((op, [k % L for k in args[0]], [encode(q) for q in args[1]], encode(out)))
+            else:
+                TRACE.append((op, [], [encode(q) for q in args], encode(out)))
+            return out
+        return inner
+    return wrap
+
+
+def _add(p, q):
     X1, Y1, Z1, T1 = p
     X2, Y2, Z2, T2 = q
     A = (Y1 - X1) * (Y2 - X2) % P
@@ -101,28 +131,37 @@ def add(p, q):
     return (E * F % P, G * H % P, F * G % P, E * H % P)
 
 
+add = _traced("add")(_add)
+
+
+@_traced("neg")
 def neg(p):
     return ((-p[0]) % P, p[1], p[2], (-p[3]) % P)
 
 
+@_traced("sub")
 def sub(p, q):
-    return add(p, neg(q))
+    return _add(p, ((-q[0]) % P, q[1], q[2], (-q[3]) % P))
 
 
-def mul(k, p):
+def _mul(k, p):
     k %= L
     acc = IDENTITY
     for bit in bin(k)[2:] if k else "":
-        acc = add(acc, acc)
+        acc = _add(acc, acc)
         if bit == "1":
-            acc = add(acc, p)
+            acc = _add(acc, p)
     return acc
 
 
+mul = _traced("mul")(_mul)
+
+
+@_traced("msm")
 def msm(scalars, points):
     acc = IDENTITY
     for k, p in zip(scalars, points):
-        acc = add(acc, mul(k, p))
+        acc = _add(acc, _mul(k, p))
     return acc
 
 

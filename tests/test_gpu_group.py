@@ -202,6 +202,7 @@ def test_fixed_key_schedule_gives_identical_results():
     issuer = afx.Context(params, key, ip)
     user = afx.Context(params, None, ip)
     count = 700
+    issuer.set_small_batch_items(0)   # the plan of large passes: that is where the key's scalars run as NAF schedules
     pres, shape = bench.generate(afx, batch, issuer, user, params, 4, "SSPE", [0, 3], count, 606)
     want = bench.corrupt(pres, count, 8)
     assert np.array_equal(batch.verify_presentations(issuer, shape, pres), want)

@@ -97,6 +97,21 @@ def test_every_flow_replays_byte_for_byte(flows):
     assert checked["issue"] >= 16 and checked["show"] >= 16 and checked["verify"] >= 15, checked
 
 
+def test_libsodium_recomputes_every_group_operation_of_every_flow(flows):
+    """A third implementation under the statement layer: every scalar multiplication, multiscalar sum, addition, subtraction and
+    negation that tests/pyref performs while replaying the golden flows - tags, messages, both provers' commitments, ciphertexts,
+    Z, every commitment a verifier recomputes - is recomputed with libsodium's ristretto255 from the recorded scalars and point
+    encodings.  With test_every_flow_replays_byte_for_byte (oracle == pyref on every byte) this pins the GROUP VALUES of the
+    flows to libsodium; what stays pinned only by the two restatements agreeing is the framing: transcript labels, the order of
+    allocations and constraints, which terms a constraint has.  libsodium exists in the build container only."""
+    from tests import sodium_replay
+    sod = sodium_replay.load()
+    if sod is None:
+        pytest.skip("no libsodium on this machine (it lives in the build container)")
+    n = sodium_replay.replay_flows(sod, flows)
+    assert n["msm"] >= 150 and n["mul"] >= 200 and n["sub"] >= 40 and n["neg"] >= 40, n
+
+
 def test_double_and_compress_equals_encode_of_the_double():
     """the formula behind the engine's k_compress2x (kernels.hip): the encoding of 2P without a square root, batched over one
     inversion, against encode(P + P) - random points, random projective scalings, every representative of a coset (P + E[4]),
