@@ -254,7 +254,7 @@ void Assembler::compress(const std::vector<afx_compress_job>& cjobs, uint32_t gr
 void Assembler::msm(std::vector<afx_msm_job> jobs) {
   if (jobs.empty()) return;
   std::vector<afx_compress_job> cjobs;
-  const bool small = ctx->small_batch_items != 0 && count <= ctx->small_batch_items;
+  const bool small = this->small();
   if (small) msm_split(std::move(jobs), cjobs);
   else msm_list(std::move(jobs), false, cjobs);
   // small passes: the item's commitments are encoded in up to 8 rows, an inversion each, instead of one serial walk
@@ -715,12 +715,33 @@ afx_hash_program SchnorrBuilder::make_program(const StrobeSim& sim) {
 }
 
 void SchnorrBuilder::verify_compact(const uint8_t* challenge_dev, uint32_t trace_row, size_t total, size_t off, std::vector<afx_msm_job>& msm_out, std::vector<afx_hash_program>& hash_out,
-                                    std::vector<afx_scalarop_job>* pre_ops) {
+                                    std::vector<afx_scalarop_job>* pre_ops, std::vector<afx_scalarop_job>* expand_ops) {
   // R_j = sum resp[s] * P  - c * LHS, appended as "blindcom"
   for (auto& cn : constraints_) {
     std::vector<afx_msm_term> terms;
     for (auto& sp : cn.second) terms.push_back(term_for(scalars_[sp.first].dev, scalars_[sp.first].stride, points_[sp.second], false, pre_ops));
-    terms.push_back(term_for(challenge_dev, 32, points_[cn.first], true, pre_ops));
+    const PointVar& lhs = points_[cn.first];
+    if (expand_ops && !lhs.parts.empty()) {
+      // -c * LHS over the parts of LHS: -c * (+-coef * base) = -+(c * coef) * base, so no term needs LHS's own coordinates
+      for (const PointVar::Part& pt : lhs.parts) {
+        afx_msm_term t;
+        memset(&t, 0, sizeof t);
+        if (pt.coef) {
+          uint8_t* prod = as_.new_enc();
+          afx_scalarop_job o;
+          memset(&o, 0, sizeof o);
+          o.a = pt.coef; o.a_stride = pt.coef_stride; o.b = challenge_dev; o.b_stride = 32; o.out = prod;
+          expand_ops->push_back(o);
+          t.scalar = prod;
+        } else {
+          t.scalar = challenge_dev;
+        }
+        t.scalar_stride = 32; t.var = pt.var; t.fixed_idx = pt.var ? -1 : pt.fixed; t.negate = pt.neg ? 0u : 1u;
+        terms.push_back(t);
+      }
+    } else {
+      terms.push_back(term_for(challenge_dev, 32, lhs, true, pre_ops));
+    }
     afx_msm_job j;
     memset(&j, 0, sizeof j);
     order_terms(j, terms);

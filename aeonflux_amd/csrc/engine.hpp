@@ -98,6 +98,9 @@ struct afx_ctx {
     afx::DevBuf staging;             // host-pointer front ends: the call's inputs and outputs in HBM (grow-only; zeroed on destroy)
     void* pin = nullptr;             // pinned bounce buffer for results (a device-to-host copy into pageable memory would
     size_t pin_cap = 0;              // block the host until the kernels end and serialise the two lanes)
+    void* pin_in = nullptr;          // pinned image of a SMALL call's whole staging area: its many short input rows are gathered
+    size_t pin_in_cap = 0;           // here on the host and go to HBM in one copy (statements.hpp Stager::upload); wiped on destroy
+    hipEvent_t pin_in_done = nullptr;   // end of the copy that last read pin_in
   } lane[2];
   bool pipelining = false;
   bool strict = false;   // afx_ctx_set_strict
@@ -193,6 +196,8 @@ class Assembler {
   size_t blob_alloc(size_t bytes, size_t align);
 
   uint32_t* bad() const { return bad_; }
+  // this pass takes the latency plan (afx_ctx_set_small_batch_items): one chain per term, statements avoid chains that wait for chains
+  bool small() const { return ctx->small_batch_items != 0 && count <= ctx->small_batch_items; }
   int run();   // upload blob, launch everything on ctx->stream (asynchronous)
 
   size_t max_digit_slots = 0, max_table_slots = 0;
@@ -229,6 +234,11 @@ struct PointVar {
   bool has_alt = false;
   uint32_t alt_gen = 0;
   const uint8_t* alt_scalar = nullptr;
+  // optional: the point as a sum of parts, P = sum +-coef_k * base_k (coef == nullptr: coefficient 1).  With it, a verifier's term
+  // -c * P can run as the independent terms -+(c * coef_k) * base_k, none of which waits for P itself to be computed (small
+  // passes: Z of Issuer::verify and the constraint Z = z*I, statements.cpp)
+  struct Part { const uint8_t* coef; uint32_t coef_stride; bool neg; const int32_t* var; int32_t fixed; };
+  std::vector<Part> parts;
   static PointVar Const(uint32_t gen, bool neg = false) { PointVar p; p.is_const = true; p.gen = gen; p.neg = neg; return p; }
   static PointVar Var(const int32_t* var, const uint8_t* enc) { PointVar p; p.is_const = false; p.var = var; p.enc_dev = enc; return p; }
   static PointVar NegOf(const int32_t* var, const uint8_t* enc_of_negation) { PointVar p = Var(var, enc_of_negation); p.var_negated = true; return p; }
@@ -251,8 +261,10 @@ class SchnorrBuilder {
   // Verifier::verify_compact over the batch: commitments, transcript, challenge comparison
   // `pre_ops` receives the scalar products that fixed-base forms of variable points need (run them before msm_out)
   // trace_row: which row of the context's challenge trace (afx_ctx_set_challenge_trace) this proof reports to
+  // `expand_ops` (optional): left-hand sides that carry `parts` have their -c * LHS term expanded over them; the products
+  // c * coef_k go here (run them before msm_out, after whatever computes the coefficients)
   void verify_compact(const uint8_t* challenge_dev, uint32_t trace_row, size_t total, size_t off, std::vector<afx_msm_job>& msm_out, std::vector<afx_hash_program>& hash_out,
-                      std::vector<afx_scalarop_job>* pre_ops = nullptr);
+                      std::vector<afx_scalarop_job>* pre_ops = nullptr, std::vector<afx_scalarop_job>* expand_ops = nullptr);
   // Prover::prove_compact over the batch.  Fills: rng hash program (blindings), commitment msm jobs,
   // challenge hash program, response scalar ops.  rng_seed_dev: [count][32].
   void prove_compact(const uint8_t* rng_seed_dev, uint8_t* challenge_out, uint8_t* responses_out /* [nsc][count][32] */,

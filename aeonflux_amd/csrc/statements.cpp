@@ -197,6 +197,8 @@ extern "C" void afx_ctx_destroy(afx_ctx* c) {
   for (auto& L : c->lane) {
     L.staging.release(true);
     if (L.pin) { memset(L.pin, 0, L.pin_cap); (void)hipHostFree(L.pin); L.pin = nullptr; L.pin_cap = 0; }
+    if (L.pin_in) { memset(L.pin_in, 0, L.pin_in_cap); (void)hipHostFree(L.pin_in); L.pin_in = nullptr; L.pin_in_cap = 0; }
+    if (L.pin_in_done) { (void)hipEventDestroy(L.pin_in_done); L.pin_in_done = nullptr; }
   }
   c->trace_buf.release(false);
   c->d_pos_tables.release(true);
@@ -511,7 +513,16 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
       D[nD] = v.allocate_point("C_y-C_y_1", PointVar::Var(v_D, e_D));
       D_pos[nD++] = (int)i;
     }
-  const int Z = v.allocate_point("Z", PointVar::Var(v_Z, e_Z));
+  // Small passes: constraint #1 recomputes R = z*I - c*Z, and a chain on Z itself could only start when Z's chains have ended -
+  // two chain latencies in a row, most of what a small call waits for.  Z is a sum the verifier knows term by term, so there
+  // -c*Z runs as c*x0*C_x_0 + c*x1*C_x_1 + sum c*y_i*X_i - c*(C_V - W): chains on the decoded inputs, beside Z's own.
+  PointVar pZ = PointVar::Var(v_Z, e_Z);
+  const bool expand_Z = as.small();
+  if (expand_Z) {
+    pZ.parts.push_back({ nullptr, 0, false, v_A, -1 });
+    for (const afx_msm_term& t : zterms) pZ.parts.push_back({ t.scalar, t.scalar_stride, true, t.var, t.fixed_idx });
+  }
+  const int Z = v.allocate_point("Z", pZ);
   v.constrain(Z, { { z, I } });
   v.constrain(C_x_1, { { t, C_x_0 }, { z_0, G_x_0 }, { z, G_x_1 } });
   for (uint32_t j = 0; j < k; j++) {
@@ -523,8 +534,8 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
   for (int d = 0; d < nD; d++) v.constrain(D[d], { { z, G_y[D_pos[d]] }, { z, neg_G_y_1 } });
   // one launch for everything: the lane that finishes Z goes straight on to constraint #1 (Z = z*I), the only job that needs it
   const size_t first_constraint = js.msm1.size();
-  v.verify_compact(row(b.challenge, 0), 0, total, off, js.msm1, js.hash);
-  js.msm1[z_index].chain_to = (int32_t)first_constraint;
+  v.verify_compact(row(b.challenge, 0), 0, total, off, js.msm1, js.hash, nullptr, expand_Z ? &js.scalarop2 : nullptr);
+  if (!expand_Z) js.msm1[z_index].chain_to = (int32_t)first_constraint;
   // proofs of encryption: verified independently, whatever their number (:438-440)
   for (uint32_t e = 0; e < sh.n_enc_proofs && !as.fail_all; e++) add_encproof_verify(as, js, sh.enc_indices[e], b.enc[e], total, off, 1 + e);
   emit(as, js, status_dev, AFX_ST_VERIFICATION_FAILURE);

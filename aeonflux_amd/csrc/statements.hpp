@@ -106,7 +106,7 @@ inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, const Pla
 struct JobSets {
   std::vector<afx_sccheck_job> sccheck;
   std::vector<afx_decode_job> decode;
-  std::vector<afx_scalarop_job> scalarop;
+  std::vector<afx_scalarop_job> scalarop, scalarop2;   // scalarop2 runs after scalarop (products of its results)
   std::vector<afx_pointop_job> pointop;
   std::vector<afx_msm_job> msm1, msm2;
   std::vector<afx_hash_program> hash;
@@ -134,6 +134,7 @@ inline void emit(Assembler& as, JobSets& js, uint8_t* status_dev, uint8_t fail_c
     as.sccheck(js.sccheck);
     as.decode(js.decode);
     as.scalarop(js.scalarop);
+    as.scalarop(js.scalarop2);
     as.pointop(js.pointop);
     as.msm(js.msm1);
     as.msm(js.msm2);
@@ -182,10 +183,31 @@ struct Stager {
       for (size_t r = 0; r < rows; r++) copies.push_back({ off + r * n * elem, src + (r * total + first) * elem, n * elem });
     return off;
   }
+  // Calls of few items are many short rows (75 arrays for a C3 presentation batch): each row as its own copy from pageable
+  // memory costs more than the kernels gain from the latency plan.  Up to PACK_LIMIT bytes the staging area's image is put
+  // together in a pinned buffer (inputs copied, result areas zeroed) and sent in ONE transfer.
+  static constexpr size_t PACK_LIMIT = size_t(4) << 20;
   int upload() {
     afx_ctx::Lane& L = c->lane[ln];
     int rc = L.staging.ensure(bytes + 256);
     if (rc) return rc;
+    if (bytes <= PACK_LIMIT && copies.size() > 2) {
+      if (bytes > L.pin_in_cap) {
+        if (L.pin_in) { AFX_HIP(hipEventSynchronize(L.pin_in_done)); memset(L.pin_in, 0, L.pin_in_cap); (void)hipHostFree(L.pin_in); L.pin_in = nullptr; L.pin_in_cap = 0; }
+        const size_t want = std::min(PACK_LIMIT, std::max<size_t>(size_t(1) << 18, (bytes + 65535) & ~size_t(65535)));
+        AFX_HIP(hipHostMalloc(&L.pin_in, want, hipHostMallocDefault));
+        L.pin_in_cap = want;
+        if (!L.pin_in_done) AFX_HIP(hipEventCreateWithFlags(&L.pin_in_done, hipEventDisableTiming));
+      } else {
+        AFX_HIP(hipEventSynchronize(L.pin_in_done));   // the previous call's transfer out of this buffer
+      }
+      uint8_t* img = (uint8_t*)L.pin_in;
+      for (const Copy& k : copies) memcpy(img + k.off, k.src, k.len);
+      for (const Copy& k : blanks) memset(img + k.off, 0, k.len);
+      AFX_HIP(hipMemcpyAsync(L.staging.p, img, bytes, hipMemcpyHostToDevice, L.stream));
+      AFX_HIP(hipEventRecord(L.pin_in_done, L.stream));
+      return AFX_OK;
+    }
     for (const Copy& k : copies) AFX_HIP(hipMemcpyAsync((uint8_t*)L.staging.p + k.off, k.src, k.len, hipMemcpyHostToDevice, L.stream));
     // result areas start from zero: the staging buffer is reused from call to call, and what a call does not write (the
     // outputs of a failed item, the hidden rows of attr_values) must not hand an earlier call's bytes to this caller
