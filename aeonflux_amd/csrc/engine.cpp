@@ -113,6 +113,14 @@ void Assembler::pointop(const std::vector<afx_pointop_job>& jobs) {
   }
   add_jobs(L_POINTOP, jobs);
 }
+void Assembler::negenc(const std::vector<afx_negenc_job>& jobs) {
+  if (jobs.empty()) return;
+  stats.encodings += jobs.size();
+  stats.field_mul += 11 + (2 * 3 + 2 + 17) * jobs.size();   // one inversion; per point: the value to invert twice, prefix products, the encoding's tail
+  stats.field_sq += 254 + 3 * jobs.size();
+  add_jobs(L_NEGENC, jobs);
+  launches.back().prefix_ws = (int32_t*)ws_alloc(sizeof(int32_t) * 9 * jobs.size() * (size_t)count);
+}
 void Assembler::scalarop(const std::vector<afx_scalarop_job>& jobs) { add_jobs(L_SCALAROP, jobs); }
 void Assembler::hash(const std::vector<afx_hash_program>& progs) {
   for (const afx_hash_program& p : progs) stats.keccak_permutations += p.n_records;
@@ -605,6 +613,7 @@ int Assembler::run() {
       case L_POINTOP: AFX_HIP(afxk_pointop(s, (const afx_pointop_job*)jobs, l.njobs, bad_, count)); break;
       case L_SCALAROP: AFX_HIP(afxk_scalarop(s, (const afx_scalarop_job*)jobs, l.njobs, count)); break;
       case L_COMPRESS: AFX_HIP(afxk_compress2x(s, (const afx_compress_job*)jobs, l.njobs, l.per_group, l.prefix_ws, bad_, count)); break;
+      case L_NEGENC: AFX_HIP(afxk_negenc(s, (const afx_negenc_job*)jobs, l.njobs, l.prefix_ws, bad_, count)); break;
       case L_POINTSUM: AFX_HIP(afxk_pointsum(s, (const afx_pointsum_job*)jobs, l.njobs, bad_, count)); break;
       case L_MSM_TABLES: AFX_HIP(afxk_msm_tables(s, l.odd, (const afx_table_job*)jobs, l.njobs, table_ws, count)); break;
       case L_MSM_FIXED: case L_MSM_WINDOW: case L_MSM_NAF: {

@@ -130,7 +130,7 @@ namespace afx {
 
 // L_MSM_WINDOW keeps the slot the single k_msm kernel had (timing names: statements.cpp KIND_NAMES)
 enum LaunchKind { L_FILL_BAD, L_DECODE, L_SCCHECK, L_POINTOP, L_SCALAROP, L_MSM_WINDOW, L_HASH, L_FROM_UNIFORM, L_REDUCE_WIDE, L_COPY, L_FINISH,
-                  L_MSM_FIXED, L_MSM_NAF, L_MSM_TABLES, L_COMPRESS, L_POINTSUM, L_KINDS };
+                  L_MSM_FIXED, L_MSM_NAF, L_MSM_TABLES, L_COMPRESS, L_POINTSUM, L_NEGENC, L_KINDS };
 
 struct Launch {
   LaunchKind kind;
@@ -145,7 +145,7 @@ struct Launch {
   int odd = 0;              // L_MSM_TABLES: odd multiples (NAF terms) or multiples 0..8
   int encodes = 1;          // L_MSM_*: some job of the launch encodes its result inside the kernel (kernels.hip k_msm<KIND, ENC, SEC>)
   int secret = 0;           // L_MSM_*: some term of the launch has a secret scalar under secret-independent addressing
-  int32_t* prefix_ws = nullptr;   // L_COMPRESS: scratch for the prefix products (njobs * 9 * count dwords)
+  int32_t* prefix_ws = nullptr;   // L_COMPRESS, L_NEGENC: scratch for the prefix products (njobs * 9 * count dwords)
   uint32_t per_group = 0;         // L_COMPRESS: jobs per grid row (each row shares one inversion per item); 0 = all in one row
 };
 
@@ -178,6 +178,7 @@ class Assembler {
   void decode(const std::vector<afx_decode_job>& jobs);
   void sccheck(const std::vector<afx_sccheck_job>& jobs);
   void pointop(const std::vector<afx_pointop_job>& jobs);
+  void negenc(const std::vector<afx_negenc_job>& jobs);   // encodings of the negations of decoded points, one inversion per item
   void scalarop(const std::vector<afx_scalarop_job>& jobs);
   void msm(std::vector<afx_msm_job> jobs);   // assigns digit/table slots; small batches: one chain per term (msm_split)
   void hash(const std::vector<afx_hash_program>& progs);

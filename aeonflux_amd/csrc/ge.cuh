@@ -219,12 +219,17 @@ AFX_DEV bool ristretto_decode(ge_p3& r, const uint32_t w[8]) {
 }
 
 // RFC 9496 §4.3.2 Encode (RistrettoPoint::compress).  p: limbs reduced (outputs of fe_mul / ge_carry).
+// the part of Encode after the inverse square root: u1 = (Z+Y)(Z-Y), u2 = XY, I = 1/sqrt(u1 u2^2) (the non-negative root)
+AFX_DEV void ristretto_encode_tail(uint32_t w[8], const ge_p3& p, const fe& u1, const fe& u2, const fe& I);
 AFX_DEV void ristretto_encode(uint32_t w[8], const ge_p3& p) {
   const fe one = fe_one();
   fe u1 = fe_mul(fe_add(p.Z, p.Y), fe_sub(p.Z, p.Y));
   fe u2 = fe_mul(p.X, p.Y);
   fe I;
   fe_sqrt_ratio_i(I, one, fe_mul(u1, fe_sq(u2)));
+  ristretto_encode_tail(w, p, u1, u2, I);
+}
+AFX_DEV void ristretto_encode_tail(uint32_t w[8], const ge_p3& p, const fe& u1, const fe& u2, const fe& I) {
   fe D1 = fe_mul(u1, I);
   fe D2 = fe_mul(u2, I);
   fe Zinv = fe_mul(fe_mul(D1, D2), p.T);
@@ -240,6 +245,25 @@ AFX_DEV void ristretto_encode(uint32_t w[8], const ge_p3& p) {
   y = fe_cneg(y, fe_is_negative(fe_mul(x, Zinv)));
   fe s = fe_abs(fe_mul(Dinv, fe_sub(p.Z, y)));
   fe_tobytes(w, s);
+}
+
+// The encoding of the NEGATION of a decoded point without a square root.  Decode(s) = (x, y) with y = u1/u2, u1 = 1 - s^2,
+// u2 = 1 + s^2, and x^2 = 4 s^2 / v for the v whose inverse square root Decode took.  Encode(-x, y) needs
+// 1/sqrt((1 - y^2) x^2 y^2), and (1 - y^2) x^2 y^2 = (2 x s u1 / u2^2)^2 - a perfect square of quantities at hand: the root is
+// +-u2^2 / (2 x s u1), ONE INVERSION, which a caller with several such points shares among them (Montgomery's trick,
+// k_negenc).  neg_den() is the value to invert; neg_finish() the encoding, given its inverse.  x = 0 or s = 0 (the identity,
+// or the placeholder of a failed decode) gives den = 0: the caller leaves such a factor out and the result is not used.
+AFX_DEV fe negenc_den(const fe& s, const ge_p3& P) {
+  const fe u1 = fe_sub(fe_one(), fe_sq(s));
+  return fe_mul(fe_mul(fe_add(P.X, P.X), s), u1);
+}
+AFX_DEV void negenc_finish(uint32_t w[8], const fe& s, const ge_p3& P, const fe& inv_den) {
+  fe u2d = fe_add(fe_one(), fe_sq(s));                       // 1 + s^2
+  const fe I = fe_abs(fe_mul(fe_sq(u2d), inv_den));          // the non-negative root, as SQRT_RATIO_M1 returns it
+  const ge_p3 N = ge_neg(P);                                 // (-x, y, 1, -xy)
+  const fe u1 = fe_mul(fe_add(N.Z, N.Y), fe_sub(N.Z, N.Y));
+  const fe u2 = fe_mul(N.X, N.Y);
+  ristretto_encode_tail(w, N, u1, u2, I);
 }
 
 // The encoding of TWICE a point without a square root (curve25519-dalek's double_and_compress_batch [3P]; kernels.hip

@@ -19,6 +19,8 @@ hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_
 // out_enc = encoding of twice each job's point; prefix_ws: njobs * 9 * count dwords of scratch (one 9-limb field element per job and item)
 // per_row: jobs per grid row, each row sharing one field inversion per item (0 = all jobs in one row)
 hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, uint32_t njobs, uint32_t per_row, int32_t* prefix_ws, uint32_t* bad, uint32_t count);
+// out_enc = encoding of the negation of each job's decoded point; prefix_ws: njobs * 9 * count dwords of scratch
+hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, uint32_t njobs, int32_t* prefix_ws, uint32_t* bad, uint32_t count);
 hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count);
 hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count);
 hipError_t afxk_finish(hipStream_t s, const uint32_t* bad, uint8_t* status, uint32_t count, uint32_t fail_all, uint8_t fail_code);

@@ -600,6 +600,46 @@ k_compress2x(const afx_compress_job* __restrict__ jobs, uint32_t njobs_all, uint
   }
 }
 
+// k_negenc: the encodings of -P_j for decoded points P_j (the "-E1" of every proof of encryption an item carries,
+// encryption.rs:185) with one field inversion per item instead of an inverse square root per point (ge.cuh negenc_*).  Same
+// two-pass walk as k_compress2x; a point whose factor is zero (the identity, or the placeholder of a failed decode - the item
+// is rejected either way) is left out of the product and encodes to zeros.
+__global__ void __launch_bounds__(AFX_BLOCK, 2)
+k_negenc(const afx_negenc_job* __restrict__ jobs, uint32_t njobs, int32_t* __restrict__ prefix_ws, uint32_t* __restrict__ bad, uint32_t count) {
+  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  if (item >= count) return;
+  fe prod = fe_one();
+#pragma unroll 1
+  for (uint32_t j = 0; j < njobs; j++) {
+    uint32_t w[8];
+    enc_load(w, jobs[j].enc, item);
+    fe den = negenc_den(fe_frombytes(w), var_load(jobs[j].var, count, item));
+    fe_cmov(den, fe_one(), fe_is_zero(den));
+    fe_store_soa(prefix_ws + (size_t)j * AFX_FE_LIMBS * count, 0, count, item, prod);
+    prod = fe_mul(prod, den);
+  }
+  fe inv = fe_invert(prod);
+#pragma unroll 1
+  for (uint32_t jj = njobs; jj > 0; jj--) {
+    const uint32_t j = jj - 1;
+    uint32_t w[8];
+    enc_load(w, jobs[j].enc, item);
+    const fe s = fe_frombytes(w);
+    const ge_p3 P = var_load(jobs[j].var, count, item);
+    fe den = negenc_den(s, P);
+    const bool zero = fe_is_zero(den);
+    fe_cmov(den, fe_one(), zero);
+    const fe inv_j = fe_mul(inv, fe_load_soa(prefix_ws + (size_t)j * AFX_FE_LIMBS * count, 0, count, item));
+    inv = fe_mul(inv, den);
+    uint32_t o[8];
+    negenc_finish(o, s, P, inv_j);
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = zero ? 0u : o[i];
+    enc_store(jobs[j].out_enc, item, o);
+    if (jobs[j].reject_identity && is_identity_encoding(o)) atomicOr(&bad[item], AFX_BAD_IDENTITY);
+  }
+}
+
 // k_pointsum: out = sum of the partial results of a job that Assembler::msm_split cut into one chain per term (+- addend)
 __global__ void __launch_bounds__(AFX_BLOCK, 2) k_pointsum(const afx_pointsum_job* __restrict__ jobs, uint32_t* __restrict__ bad, uint32_t count) {
   const afx_pointsum_job job = jobs[blockIdx.y];
@@ -820,6 +860,10 @@ hipError_t afxk_msm_tables(hipStream_t s, int odd, const afx_table_job* rows, ui
 hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, uint32_t njobs, uint32_t per_row, int32_t* prefix_ws, uint32_t* bad, uint32_t count) {
   if (per_row == 0 || per_row > njobs) per_row = njobs;
   hipLaunchKernelGGL(k_compress2x, dim3((count + AFX_BLOCK - 1) / AFX_BLOCK, (njobs + per_row - 1) / per_row), dim3(AFX_BLOCK), 0, s, jobs, njobs, per_row, prefix_ws, bad, count);
+  return hipGetLastError();
+}
+hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, uint32_t njobs, int32_t* prefix_ws, uint32_t* bad, uint32_t count) {
+  hipLaunchKernelGGL(k_negenc, dim3((count + AFX_BLOCK - 1) / AFX_BLOCK), dim3(AFX_BLOCK), 0, s, jobs, njobs, prefix_ws, bad, count);
   return hipGetLastError();
 }
 hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count) {

@@ -137,6 +137,16 @@ typedef struct {
   uint32_t pad;
 } afx_compress_job;
 
+/* k_negenc: out_enc[item] = encoding of -P, P = the point that `enc` decodes to (coordinates in `var`, Z = 1, as k_decode left
+ * them): no square root, one field inversion per item for all its jobs (ge.cuh negenc_*) */
+typedef struct {
+  const uint8_t* enc;      /* [count][32] the encoding P was decoded from                            */
+  const int32_t* var;      /* SoA extended P                                                          */
+  uint8_t* out_enc;        /* [count][32]                                                             */
+  uint32_t reject_identity;
+  uint32_t pad;
+} afx_negenc_job;
+
 /* k_pointsum (small batches: Assembler::msm splits a job into one chain per term and sums the partial results here):
  * out = sum of parts (+- addend); stored to out_var and/or half_var (then encoded by k_compress2x), or encoded here */
 typedef struct {

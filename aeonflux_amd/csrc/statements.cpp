@@ -37,7 +37,7 @@ extern "C" void* afx_ctx_stream(const afx_ctx* ctx) { return ctx ? (void*)ctx->s
 
 // indexed by afx::LaunchKind.  "k_msm" (afx_ctx_get_timing) = the three chain kernels + the table kernel together
 static const char* const KIND_NAMES[] = { "k_fill_u32", "k_decode", "k_sccheck", "k_pointop", "k_scalarop", "k_msm_window", "k_hash",
-                                          "k_from_uniform", "k_reduce_wide", "copy", "k_finish", "k_msm_fixed", "k_msm_naf", "k_msm_tables", "k_compress2x", "k_pointsum" };
+                                          "k_from_uniform", "k_reduce_wide", "copy", "k_finish", "k_msm_fixed", "k_msm_naf", "k_msm_tables", "k_compress2x", "k_pointsum", "k_negenc" };
 static_assert(sizeof KIND_NAMES / sizeof KIND_NAMES[0] == afx::L_KINDS, "one name per launch kind");
 static int drain_timing(afx_ctx* c) {
   for (auto& L : c->lane)
@@ -343,9 +343,10 @@ static void add_encproof_verify(Assembler& as, JobSets& js, uint16_t index, cons
   js.decode.push_back({ row(e.C_y_3, 0), v_Cy3, 1 });
   js.decode.push_back({ row(e.C_y_2p, 0), v_Cy2p, 1 });
   afx_pointop_job d1 = { v_Cy1, v_E2, nullptr, +1, -1, v_D1, e_D1, 1 };    // C_y_1 - E2   (:183)
-  afx_pointop_job d2 = { v_E1, nullptr, nullptr, -1, 0, nullptr, e_D2, 1 };   // -E1 (:185): only its encoding is needed, see below
   js.pointop.push_back(d1);
-  js.pointop.push_back(d2);
+  // -E1 (:185): only its encoding is needed (the term a*(-E1) runs as -(a*E1) on E1's table, below), and the encoding of the
+  // negation of a DECODED point needs no square root: one inversion per item for all its proofs of encryption (k_negenc)
+  js.negenc.push_back({ row(e.E1, 0), v_E1, e_D2, 1, 0 });
   auto resp = [&](int k) { ScalarVar s; s.dev = row(e.responses, k); s.stride = 32; return s; };
   SchnorrBuilder v(as, "2019/1416 anonymous credentials", "2019/1416 proof of encryption");
   const int a = v.allocate_scalar("a", resp(0));

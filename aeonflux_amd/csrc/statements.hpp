@@ -108,6 +108,7 @@ struct JobSets {
   std::vector<afx_decode_job> decode;
   std::vector<afx_scalarop_job> scalarop, scalarop2;   // scalarop2 runs after scalarop (products of its results)
   std::vector<afx_pointop_job> pointop;
+  std::vector<afx_negenc_job> negenc;
   std::vector<afx_msm_job> msm1, msm2;
   std::vector<afx_hash_program> hash;
 };
@@ -136,6 +137,7 @@ inline void emit(Assembler& as, JobSets& js, uint8_t* status_dev, uint8_t fail_c
     as.scalarop(js.scalarop);
     as.scalarop(js.scalarop2);
     as.pointop(js.pointop);
+    as.negenc(js.negenc);
     as.msm(js.msm1);
     as.msm(js.msm2);
     as.hash(js.hash);

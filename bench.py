@@ -60,7 +60,11 @@ def measured_traffic(workload, kernel):
 
 
 MSM_KERNELS = ("k_msm_window", "k_msm_naf", "k_msm_fixed", "k_msm_tables")
-OTHER_KERNELS = ("k_compress2x", "k_decode", "k_pointop", "k_hash", "k_scalarop", "k_sccheck", "k_from_uniform", "k_reduce_wide", "k_finish", "k_fill_u32")
+OTHER_KERNELS = ("k_compress2x", "k_negenc", "k_pointsum", "k_decode", "k_pointop", "k_hash", "k_scalarop", "k_sccheck", "k_from_uniform", "k_reduce_wide", "k_finish", "k_fill_u32")
+
+
+# the kernels doing field arithmetic beside the multiscalar ones (the time base of the "valu" figure)
+FIELD_KERNELS = ("k_compress2x", "k_negenc", "k_pointsum", "k_decode", "k_pointop", "k_from_uniform")
 
 
 def kernel_times(ctx, steps):
@@ -244,7 +248,7 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
     fence()
     elapsed = time.perf_counter() - t0
     kt = kernel_times(issuer, args.steps)
-    valu = valu_side(issuer, count, sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS + ("k_compress2x", "k_decode", "k_pointop", "k_from_uniform")))
+    valu = valu_side(issuer, count, sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS + FIELD_KERNELS))
     issuer.set_timing(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
@@ -363,7 +367,7 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
     fence()
     elapsed = time.perf_counter() - t0
     kt = kernel_times(user, args.steps)
-    valu = valu_side(user, count, sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS + ("k_compress2x", "k_decode", "k_pointop", "k_from_uniform")))
+    valu = valu_side(user, count, sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS + FIELD_KERNELS))
     user.set_timing(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
@@ -414,7 +418,7 @@ def valu_side(ctx, items_per_step, field_kernel_ms_per_step):
             "clock_note": "peak is at the nominal 2400 MHz; the kernels run at the socket power cap, below it",
             "peak_source": "tools/ubench/mad_sustained.hip on this GPU (no published figure): %.2f cycles per wave-instruction" % MAD_CYCLES,
             "peak_sustained_pure_mad_loop": MAD_SUSTAINED_T, "frac_of_sustained": achieved / MAD_SUSTAINED_T, "per_item": dict(st, mads=mads),
-            "time_base": "summed durations of the kernels doing field arithmetic (k_msm_*, k_compress2x, k_decode, k_pointop, k_from_uniform)"}
+            "time_base": "summed durations of the kernels doing field arithmetic (k_msm_*, k_compress2x, k_negenc, k_pointsum, k_decode, k_pointop, k_from_uniform)"}
 
 
 def free_port():
@@ -603,7 +607,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kt = kernel_times(issuer, args.steps)
-    valu = valu_side(issuer, count, sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS + ("k_compress2x", "k_decode", "k_pointop")))
+    valu = valu_side(issuer, count, sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS + FIELD_KERNELS))
     issuer.set_timing(False)
     issuer.set_pipelining(False)
     if dist is not None:

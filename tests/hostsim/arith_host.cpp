@@ -255,4 +255,35 @@ int arith_double_and_compress(uint8_t* out /* [n][32] */, uint32_t n, const uint
   }
   return 1;
 }
+
+// encodings of the NEGATIONS of n decoded points with one inversion (ge.cuh negenc_*; the engine's k_negenc), every multiplication
+// bound-checked.  A point with a zero factor (the identity) is left out of the product and encodes to zeros.  Returns 0 if a
+// point does not decode.
+int arith_negate_and_encode(uint8_t* out /* [n][32] */, uint32_t n, const uint8_t* pts /* [n][32] */) {
+  if (n > 64) return 0;
+  fe s[64], den[64], pre[64], prod = fe_one();
+  ge_p3 P[64];
+  bool zero[64];
+  uint32_t w[8];
+  for (uint32_t j = 0; j < n; j++) {
+    load8(w, pts + 32 * j);
+    if (!ristretto_decode(P[j], w)) return 0;
+    s[j] = fe_frombytes(w);
+    den[j] = negenc_den(s[j], P[j]);
+    zero[j] = fe_is_zero(den[j]);
+    fe_cmov(den[j], fe_one(), zero[j]);
+    pre[j] = prod;
+    prod = fe_mul(prod, den[j]);
+  }
+  fe inv = fe_invert(prod);
+  for (uint32_t jj = n; jj > 0; jj--) {
+    const uint32_t j = jj - 1;
+    const fe inv_j = fe_mul(inv, pre[j]);
+    inv = fe_mul(inv, den[j]);
+    negenc_finish(w, s[j], P[j], inv_j);
+    if (zero[j]) memset(w, 0, sizeof w);
+    memcpy(out + 32 * j, w, 32);
+  }
+  return 1;
+}
 }  // extern "C"

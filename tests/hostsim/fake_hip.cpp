@@ -72,6 +72,10 @@ hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_ms
   }
   return hipSuccess;
 }
+hipError_t afxk_negenc(hipStream_t, const afx_negenc_job* j, uint32_t n, int32_t* ws, uint32_t*, uint32_t count) {
+  for (uint32_t i = 0; i < n; i++) { sink += (uintptr_t)j[i].enc + (uintptr_t)j[i].var + (uintptr_t)j[i].out_enc; ws[(size_t)i * 9 * count] = 1; ws[((size_t)i * 9 + 8) * count + count - 1] = 1; }
+  return hipSuccess;
+}
 hipError_t afxk_pointsum(hipStream_t, const afx_pointsum_job* j, uint32_t n, uint32_t*, uint32_t) {
   for (uint32_t i = 0; i < n; i++) {
     if (j[i].n_parts < 2 || (!j[i].out_var && !j[i].half_var && !j[i].out_enc)) return hipErrorInvalidValue;

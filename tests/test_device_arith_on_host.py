@@ -216,6 +216,32 @@ def test_double_and_compress_against_the_oracle(arith):
     assert out.raw[32 * 7:32 * 8] == bytes(32)
 
 
+def test_negate_and_encode_against_the_oracle(arith, primitives):
+    """ge.cuh negenc_den / negenc_finish (k_negenc): the encodings of -P for a batch of DECODED points with one inversion and no
+    square root equal the oracle's encode(identity - P) - random points, small multiples of the base point, the libsodium-valid
+    encodings of the golden file (both parities of every decision inside Encode occur), the identity in the batch - with every
+    multiplication's operand bounds checked"""
+    import ctypes as C
+    import hashlib
+    import oracle
+    rnd = hashlib.shake_256(b"negenc-host").digest(64 * 30)
+    pts = [oracle.point_from_uniform(rnd[64 * i:64 * i + 64]) for i in range(30)]
+    pts += [bytes.fromhex(x) for x in primitives["base_multiples"][1:]]
+    pts += [bytes.fromhex(v["in"]) for v in primitives["validity"] if v["valid"]][:16]
+    pts.insert(5, bytes(32))                      # the identity in the middle of the batch
+    arith.arith_negate_and_encode.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p]
+    seen = set()
+    for lo in range(0, len(pts), 60):
+        chunk = pts[lo:lo + 60]
+        out = C.create_string_buffer(32 * len(chunk))
+        assert arith.arith_negate_and_encode(out, len(chunk), b"".join(chunk)) == 1
+        for j, p in enumerate(chunk):
+            want = oracle.point_sub(bytes(32), p)
+            assert out.raw[32 * j:32 * j + 32] == want, (lo + j, p.hex())
+            seen.add(want == p)
+    assert seen == {True, False} or len(pts) > 40   # 2-torsion-like fixed points are rare; most negations differ
+
+
 def test_the_bounds_checker_fires(arith):
     arith.arith_bounds_checker_selftest.restype = C.c_uint64
     assert arith.arith_bounds_checker_selftest() >= 2
