@@ -40,7 +40,13 @@ def algorithmic_bytes(shape):
     return 32 * (4 + hs) + 96 + 32 * n + 32 * pub + 448 * hp + (n + 2 * hs + 4 * hp) + 1
 
 
-TRAFFIC_FILE = "r02_traffic.json"
+def traffic_file():
+    """the newest committed traffic measurement, profiles/rNN_traffic.json"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+    return found[-1] if found else None
+
+
 # timing experiments with deliberately wrong kernels (tools/ab_bench.sh with an experiment build): skip the result checks
 # and say so in the output line.  Never set for a reported number.
 UNCHECKED = os.environ.get("AFX_BENCH_UNCHECKED") == "1"
@@ -48,14 +54,14 @@ UNCHECKED = os.environ.get("AFX_BENCH_UNCHECKED") == "1"
 
 def measured_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r02_traffic.json; collected with tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes,
+    (profiles/rNN_traffic.json, the newest round's; collected with tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes,
     FETCH doubled per MI355X_MICROARCH §HBM).  PMC counters cannot be read from inside the process, so the figure is the
     committed measurement of the same workload, not a live one.  C4 launches are C3 launches (2^19-item passes)."""
     try:
-        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
+        with open(traffic_file()) as f:
             d = json.load(f).get({"c4": "c3"}.get(workload, workload))
         return d.get(kernel) if isinstance(d, dict) else d
-    except (OSError, ValueError):
+    except (OSError, ValueError, TypeError):
         return None
 
 
@@ -692,7 +698,8 @@ def main():
         assert np.array_equal(ost1, got[:S1])
         cpu = {"value": S / cpu_s, "unit": "presentations/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
                "sample": "first %d presentations of the same batch, oracle/ restated CPU path (gcc -O3 -march=native, 5x51 limbs, "
-                         "NAF-5 Straus), %d threads; statuses equal to the GPU's" % (S, threads),
+                         "NAF-5 Straus), %d threads = the cores this process may use (scheduler affinity mask capped by the cgroup CPU "
+                         "quota; the machine reports %d hardware threads); statuses equal to the GPU's" % (S, threads, os.cpu_count() or 0),
                "single_thread_value": S1 / cpu1_s}
 
     if rank == 0:
