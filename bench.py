@@ -548,8 +548,15 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # the process group only carries the measurement's barrier and one MAX all-reduce of a double (the data path has no
+        # collective): RCCL as the contract asks; if it cannot start on this node, gloo serves the same purpose
         if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            except Exception as e:   # noqa: BLE001 - reported in the output line
+                sys.stderr.write("bench.py: rank %d: RCCL process group failed (%s); using gloo\n" % (rank, e))
+                args.dist_backend = "gloo (nccl failed to initialise)"
+                dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend=args.dist_backend)
     import aeonflux_amd as afx
@@ -716,7 +723,7 @@ def main():
                        "secret_independent_addressing": bool(args.secret_independent),
                        "input_generation_s": round(gen_s, 2), "host_pointer_api_presentations_per_s": pcie,
                        "wire_blob_api_presentations_per_s": wire_rate,
-                       "ranks_seen": ranks_seen, "launcher": "bench.py" if os.environ.get("AFX_BENCH_LAUNCHED") else
+                       "ranks_seen": ranks_seen, "dist_backend": args.dist_backend if world > 1 else None, "launcher": "bench.py" if os.environ.get("AFX_BENCH_LAUNCHED") else
                        ("external" if world > 1 else "none"),
                        "group_api_presentations_per_s": group_rate, "group_api_items": group_items,
                        "group_api_note": "one process, afx_group_verify_presentations over %d device(s) on host arrays (%d copies of "

@@ -1,0 +1,57 @@
+"""Latency of ONE synchronous host-pointer call of each operation at small batch sizes, for the two plans
+(afx_ctx_set_small_batch_items 0 / 2048): python tools/small_call_latency.py
+Shapes: issue n = 16 (C5's layout), show and verify the C3 shape (8 attributes, 4 hidden encrypted points)."""
+import sys
+import time
+sys.path.insert(0, ".")
+import numpy as np
+import aeonflux_amd as afx
+import bench
+from aeonflux_amd import batch
+
+
+def timed(fn, reps=20):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+rng = np.random.default_rng(1)
+rb = lambda *s: rng.integers(0, 256, size=s, dtype=np.uint8)
+p5, k5, i5 = bench.load_fixture("c5_16attrs")
+iss5 = afx.Context(p5, k5, i5)
+p3, k3, i3 = bench.load_fixture("c3_8attrs_SSPPeeee")
+iss3, usr3 = afx.Context(p3, k3, i3), afx.Context(p3, None, i3)
+print("%-8s %-28s %-28s %-28s" % ("items", "issue n=16  (0 / 2048) ms", "show C3  (0 / 2048) ms", "verify C3  (0 / 2048) ms"))
+for n in (1, 16, 256, 1024):
+    kinds5 = [afx.ATTR_PUBLIC_SCALAR] * 8 + [afx.ATTR_PUBLIC_POINT] * 4 + [afx.ATTR_EITHER_POINT] * 4
+    vals5 = np.stack([batch.scalars_from_wide(iss5, rb(n, 64)) if i < 8 else batch.points_from_uniform(iss5, rb(n, 64)) for i in range(16)])
+    tw, uw, sd = rb(n, 64), rb(n, 64), rb(n, 32)
+    # a C3-shape credential batch and what show needs
+    layout, hide = "SSPPEEEE", [4, 5, 6, 7]
+    kinds3 = [{"S": afx.ATTR_PUBLIC_SCALAR, "P": afx.ATTR_PUBLIC_POINT, "E": afx.ATTR_EITHER_POINT}[c] for c in layout]
+    vals3 = np.stack([batch.scalars_from_wide(iss3, rb(n, 64)) if c == "S" else batch.points_from_uniform(iss3, rb(n, 64)) for c in layout])
+    M2 = np.stack([batch.points_from_uniform(iss3, rb(n, 64)) for _ in layout])
+    m3 = np.stack([batch.scalars_from_wide(iss3, rb(n, 64)) for _ in layout])
+    cred, st = batch.issue(iss3, kinds3, vals3, rb(n, 64), rb(n, 64), rb(n, 32))
+    sk = [afx.ATTR_SECRET_POINT if i in hide else k for i, k in enumerate(kinds3)]
+    a, a0, a1 = (batch.scalars_from_wide(iss3, rb(n, 64)) for _ in range(3))
+    gen = lambda idx: np.frombuffer(p3[4 + 32 * idx:4 + 32 * idx + 32], np.uint8)
+    pk, ok = batch.multiscalar_mul(iss3, np.stack([a, a0, a1]), np.stack([np.broadcast_to(gen(5 + 8 + 8 + 1 + k), (n, 32)) for k in range(3)]))
+    kp = dict(a=a, a0=a0, a1=a1, pk=pk)
+    zw, ssd, es = rb(n, 64), rb(n, 32), rb(4, n, 32)
+    pres, shape, st = batch.show(usr3, sk, vals3, cred["t"], cred["U"], cred["V"], kp, zw, ssd, es, M2, m3)
+    assert not st.any() and not batch.verify_presentations(iss3, shape, pres).any()
+    cols = []
+    for name, ctx, fn in (("issue", iss5, lambda: batch.issue(iss5, kinds5, vals5, tw, uw, sd)),
+                          ("show", usr3, lambda: batch.show(usr3, sk, vals3, cred["t"], cred["U"], cred["V"], kp, zw, ssd, es, M2, m3)),
+                          ("verify", iss3, lambda: batch.verify_presentations(iss3, shape, pres))):
+        r = []
+        for thr in (0, 2048):
+            ctx.set_small_batch_items(thr)
+            r.append(timed(fn))
+        ctx.set_small_batch_items(2048)
+        cols.append("%8.3f / %8.3f" % tuple(r))
+    print("%-8d %-28s %-28s %-28s" % (n, *cols), flush=True)
