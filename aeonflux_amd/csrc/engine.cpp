@@ -261,6 +261,21 @@ void Assembler::compress(const std::vector<afx_compress_job>& cjobs, uint32_t gr
 // LONGEST chain, so every variable-base term gets a chain of its own (msm_split).
 void Assembler::msm(std::vector<afx_msm_job> jobs) {
   if (jobs.empty()) return;
+  // Secret-independent addressing (afx_ctx_set_secret_independent_addressing): which terms carry a secret scalar.  In a prover-side
+  // plan every scalar but the constant 1.  In a verifier-side plan every term of a job that multiplies by the issuer key (Z of
+  // Issuer::verify): the key's own terms, and beside them the per-item scalars DERIVED from it by a public factor (y_i * m_i for a
+  // revealed scalar attribute), whose digits would give the key away just the same.  Marked here, before a small pass splits the
+  // job into one chain per term.  Such terms never run as a NAF schedule (whose table indices are the key's digits), read every
+  // entry of their window's table, and on a fixed base use the 4-bit positional tables.
+  auto is_key_scalar = [&](const afx_msm_term& t) { return t.scalar_stride == 0 && host_scalar_of(ctx, t.scalar) != nullptr; };
+  for (afx_msm_job& j : jobs) {
+    bool key_job = false;
+    for (uint32_t t = 0; t < j.n_terms; t++) key_job |= is_key_scalar(j.term[t]);
+    for (uint32_t t = 0; t < j.n_terms; t++) {
+      j.term[t].secret = (ctx->secret_independent && (secret_scalars || key_job) && j.term[t].scalar != ctx->const_one()) ? 1u : 0u;
+      stats.secret_terms += j.term[t].secret;
+    }
+  }
   std::vector<afx_compress_job> cjobs;
   const bool small = this->small();
   if (small) msm_split(std::move(jobs), cjobs);
@@ -345,15 +360,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     return c;
   };
   const size_t n = jobs.size();
-  // Secret-independent addressing (afx_ctx_set_secret_independent_addressing): which terms carry a secret scalar.  In a prover-side
-  // plan every scalar but the constant 1; in a verifier-side plan the issuer key's (Z of Issuer::verify).  Such terms never run
-  // as a NAF schedule (whose table indices are the key's digits), read every entry of their window's table, and on a fixed base
-  // use the 4-bit positional tables.
-  const bool sec_mode = ctx->secret_independent;
-  auto is_key_scalar = [&](const afx_msm_term& t) { return t.scalar_stride == 0 && host_scalar_of(ctx, t.scalar) != nullptr; };
-  for (afx_msm_job& j : jobs)
-    for (uint32_t t = 0; t < j.n_terms; t++)
-      j.term[t].secret = (sec_mode && (secret_scalars ? j.term[t].scalar != ctx->const_one() : is_key_scalar(j.term[t]))) ? 1u : 0u;
+  const bool sec_mode = ctx->secret_independent;   // terms were marked by Assembler::msm, before any splitting
   for (size_t i = 0; i < n; i++)
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
   // Jobs whose result is only ever encoded (no consumer of the point itself, no addend) run on halved scalars; k_compress2x

@@ -518,7 +518,9 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
   // two chain latencies in a row, most of what a small call waits for.  Z is a sum the verifier knows term by term, so there
   // -c*Z runs as c*x0*C_x_0 + c*x1*C_x_1 + sum c*y_i*X_i - c*(C_V - W): chains on the decoded inputs, beside Z's own.
   PointVar pZ = PointVar::Var(v_Z, e_Z);
-  const bool expand_Z = as.small();
+  // (not with secret-independent addressing: the products c*x0 ... are the key times a public factor, and the expanded terms would
+  // have to scan their tables like Z's own do - the second chain is the cheaper price there)
+  const bool expand_Z = as.small() && !c->secret_independent;
   if (expand_Z) {
     pZ.parts.push_back({ nullptr, 0, false, v_A, -1 });
     for (const afx_msm_term& t : zterms) pZ.parts.push_back({ t.scalar, t.scalar_stride, true, t.var, t.fixed_idx });

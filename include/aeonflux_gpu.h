@@ -162,8 +162,9 @@ int afx_ctx_set_fixed_key_schedule(afx_ctx* ctx, int enable);
  * mode on, no memory address depends on a secret digit either:
  *   - afx_issue*, afx_show* and the symmetric-key helpers (afx_keypairs_derive, afx_encrypt, afx_decrypt, afx_issuer_keygen's
  *     context): every scalar of every multiscalar job but the constant 1 is treated as a secret;
- *   - afx_verify_presentations*: the issuer key's scalars in Z (which then also run the fixed schedule of
- *     afx_ctx_set_fixed_key_schedule, whatever that setting says);
+ *   - afx_verify_presentations*: every scalar of the job that computes Z - the issuer key's (which then also run the fixed
+ *     schedule of afx_ctx_set_fixed_key_schedule, whatever that setting says) and the per-item products y_i * m_i of the key with
+ *     revealed scalar attributes, whose digits would give the key away just the same;
  *   - a secret term on a per-item base reads all 8 entries of its lane's window table and keeps the digit's entry with selects;
  *     a secret term on a generator uses 4-bit positional tables (63 KB per generator, built when the mode is first switched
  *     on) whose 9 entries per window are all read: 64 additions per term instead of 20.
@@ -210,6 +211,8 @@ typedef struct afx_plan_stats {
   uint64_t keccak_permutations;
   uint64_t field_mul, field_sq; /* GF(2^255-19) multiplications / squarings of all of the above, from the kernels' own
                                   schedule (tests/test_device_arith_on_host.py pins the per-block counts)        */
+  uint64_t secret_terms;       /* terms of the multiscalar jobs that run with secret-independent addressing (0 unless
+                                  afx_ctx_set_secret_independent_addressing is on)                               */
 } afx_plan_stats;
 int afx_ctx_get_plan_stats(afx_ctx* ctx, afx_plan_stats* out);
 

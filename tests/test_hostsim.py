@@ -125,8 +125,15 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     # secret-independent addressing: prover plans mark every term, the verifier's plan the key's terms; the fake launcher checks
     # that each launch's flag is the OR of its terms' flags and that the 4-bit tables exist
     ctx.set_secret_independent_addressing(True)
-    batch.verify_presentations(ctx, shape, pres)
+    # the verifier's secrets: every term of Z - the key's own and the key-derived y_i * m_i of revealed scalars - in both plans
+    # (marked before a small pass splits Z into one chain per term); nothing else of Issuer::verify
+    z_terms = 2 + shape.n_attributes + sum(1 for k in list(shape.kinds)[:shape.n_attributes] if k == 0)
+    for thr in (0, 2048):
+        ctx.set_small_batch_items(thr)
+        batch.verify_presentations(ctx, shape, pres)
+        assert shape.n_attributes != n or ctx.plan_stats()["secret_terms"] == z_terms, (ctx.plan_stats(), z_terms)
     batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
+    assert ctx.plan_stats()["secret_terms"] > 3 * n
     batch.show(ctx, k2, values, iss["t"], iss["U"], iss["V"], kp, rb(3, 64), rb(3, 32), rb(max(nsp, 1), 3, 32), values, values)
     assert afx.lib().afx_encrypt(ctx.h, C.byref(kpsoa), e[0].ctypes.data, e[1].ctypes.data, e[2].ctypes.data, 3, e[3].ctypes.data, e[4].ctypes.data, stx.ctypes.data) == 0
     assert ctx.plan_stats()["fixed_additions"] == 0   # E2 = a*E1 + M1: one variable base
