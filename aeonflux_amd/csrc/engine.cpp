@@ -268,7 +268,15 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   // job into one chain per term.  Such terms never run as a NAF schedule (whose table indices are the key's digits), read every
   // entry of their window's table, and on a fixed base use the 4-bit positional tables.
   auto is_key_scalar = [&](const afx_msm_term& t) { return t.scalar_stride == 0 && host_scalar_of(ctx, t.scalar) != nullptr; };
+  // producers that leave their half (plan.h afx_msm_job.leave_half): known before the terms are marked, so that a consumer in this
+  // same call doubles its scalar too
   for (afx_msm_job& j : jobs) {
+    if (j.leave_half && !(j.out_var && j.out_enc && !j.addend && !j.half_var)) j.leave_half = 0;   // nothing to gain or not possible
+    if (j.leave_half) half_bases_.insert(j.out_var);
+  }
+  for (afx_msm_job& j : jobs) {
+    for (uint32_t t = 0; t < j.n_var; t++) j.term[t].dbl = half_bases_.count(j.term[t].var) ? 1u : 0u;
+    for (uint32_t t = j.n_var; t < j.n_terms; t++) j.term[t].dbl = 0;
     bool key_job = false;
     for (uint32_t t = 0; t < j.n_terms; t++) key_job |= is_key_scalar(j.term[t]);
     for (uint32_t t = 0; t < j.n_terms; t++) {
@@ -277,11 +285,18 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     }
   }
   std::vector<afx_compress_job> cjobs;
+  cjobs.swap(pending_cjobs_);   // compress_also()
   const bool small = this->small();
   if (small) msm_split(std::move(jobs), cjobs);
   else msm_list(std::move(jobs), false, cjobs);
   // small passes: the item's commitments are encoded in up to 8 rows, an inversion each, instead of one serial walk
   compress(cjobs, small ? 8u : 1u);
+}
+
+void Assembler::compress_also(const int32_t* var, uint8_t* out_enc, bool negate, uint32_t reject_identity) {
+  afx_compress_job cj = { var, out_enc, reject_identity, negate ? 1u : 0u };
+  pending_cjobs_.push_back(cj);
+  stats.encodings++; stats.field_mul += AFX_ENCODE_MUL; stats.field_sq += AFX_ENCODE_SQ;   // compress() rewrites this share
 }
 
 // One chain per term.  A job with more than one part - each variable-base term, and its fixed-base terms together - becomes
@@ -310,7 +325,7 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
       j.chain_to = -1;
       const uint32_t parts = j.n_var + (j.n_terms > j.n_var ? 1u : 0u);
       if (parts <= 1) { subs.push_back(j); continue; }   // a single chain already (its addend, if any, is added by its own lane)
-      const bool halved = j.out_enc && !j.out_var && !j.addend;   // only ever encoded: halved scalars, k_compress2x (msm_list)
+      const bool halved = j.out_enc && !j.addend && (!j.out_var || j.leave_half);   // only ever encoded, or leaving its half: halved scalars, k_compress2x (msm_list)
       std::vector<const int32_t*> part_vars;
       auto sub_of = [&](uint32_t first, uint32_t nterms, uint32_t nvar) {
         afx_msm_job s;
@@ -332,7 +347,8 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
       sj.out_var = j.out_var;
       sj.reject_identity = j.reject_identity;
       if (halved) {
-        sj.half_var = new_var();
+        sj.half_var = j.leave_half ? j.out_var : new_var();   // leave_half: the half IS what later terms find at out_var
+        if (j.leave_half) sj.out_var = nullptr;
         afx_compress_job cj = { sj.half_var, j.out_enc, j.reject_identity, 0 };
         cjobs.push_back(cj);
         stats.encodings++; stats.field_mul += AFX_ENCODE_MUL; stats.field_sq += AFX_ENCODE_SQ;   // compress() rewrites this share
@@ -365,7 +381,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
   // Jobs whose result is only ever encoded (no consumer of the point itself, no addend) run on halved scalars; k_compress2x
   // encodes the doubles (below, and kernels.hip)
-  auto encoded_only = [&](const afx_msm_job& j) { return j.out_enc && !j.out_var && !j.addend && !j.half_var; };
+  auto encoded_only = [&](const afx_msm_job& j) { return j.out_enc && !j.addend && !j.half_var && (!j.out_var || j.leave_half); };   // leave_half: msm() vetted it
   // ... and the parts of such a job that msm_split cut up arrive with their half_var set: halved scalars, no encoding of their own
   auto halved = [&](const afx_msm_job& j) { return j.half_var != nullptr || encoded_only(j); };
   // variable bases whose scalar is a batch constant the host knows (the issuer key in Z and in the tag) go first
@@ -379,7 +395,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     std::vector<const uint8_t*> hs;
     for (uint32_t t = 0; t < j.n_var; t++) {
       // afx_ctx_set_fixed_key_schedule: key scalars take the per-item window path (64 additions each, whatever the key)
-      const uint8_t* h = (j.term[t].scalar_stride == 0 && !ctx->fixed_key_schedule && !sec_mode && !no_naf) ? host_scalar_of(ctx, j.term[t].scalar) : nullptr;
+      const uint8_t* h = (j.term[t].scalar_stride == 0 && !ctx->fixed_key_schedule && !sec_mode && !no_naf && !j.term[t].dbl) ? host_scalar_of(ctx, j.term[t].scalar) : nullptr;
       if (h) { uni.push_back(j.term[t]); hs.push_back(h); } else lane.push_back(j.term[t]);
     }
     if (uni.empty()) continue;
@@ -471,7 +487,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     const afx_msm_job& j = jobs[i];
     if (j.half_var) { half_of[i] = j.half_var; continue; }   // a part of a split job: summed, then encoded with its siblings
     if (!encoded_only(j)) continue;
-    half_of[i] = new_var();
+    half_of[i] = j.leave_half ? j.out_var : new_var();   // leave_half: later terms on this base find the half where they look
     afx_compress_job cj = { half_of[i], j.out_enc, j.reject_identity, 0 };
     cjobs.push_back(cj);   // Assembler::compress rewrites the encoding's share of the operation counts
   }
@@ -496,8 +512,8 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     std::vector<afx_table_job> odd_rows, plain_rows;
     for (size_t i : rows) {
       afx_msm_job j = jobs[i];
-      j.next_job = 0;
       j.half_var = half_of[i];
+      if (j.leave_half) j.out_var = nullptr;   // one store: the half, through half_var
       j.digit_slot = dslot; dslot += j.n_terms;
       // one window table per (base, kind of multiples) of this launch list: constraints that share a base share its table
       // (a proof of encryption uses C_y_2 and C_y_2' in two constraints each, encryption.rs:197,204)

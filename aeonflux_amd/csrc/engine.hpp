@@ -7,6 +7,7 @@
 #include <array>
 #include <map>
 #include <memory>
+#include <set>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -181,6 +182,9 @@ class Assembler {
   void negenc(const std::vector<afx_negenc_job>& jobs);   // encodings of the negations of decoded points, one inversion per item
   void scalarop(const std::vector<afx_scalarop_job>& jobs);
   void msm(std::vector<afx_msm_job> jobs);   // assigns digit/table slots; small batches: one chain per term (msm_split)
+  // one more point for the NEXT msm() call's k_compress2x launch: out_enc = encoding of +-2 * var, where var is (or will be, by
+  // that call's chains) the half some job left (afx_msm_job.leave_half) - the "-E1" of a proof of encryption being created
+  void compress_also(const int32_t* var, uint8_t* out_enc, bool negate, uint32_t reject_identity);
   void hash(const std::vector<afx_hash_program>& progs);
   void from_uniform(const uint8_t* wide, uint8_t* out_enc, int32_t* out_var);
   void reduce_wide(const uint8_t* wide, uint8_t* out);
@@ -211,6 +215,8 @@ class Assembler {
   void compress(const std::vector<afx_compress_job>& cjobs, uint32_t groups);
   template <class T>
   void add_jobs(LaunchKind k, const std::vector<T>& jobs);
+  std::set<const int32_t*> half_bases_;            // variables that hold HALF their point (producers with leave_half)
+  std::vector<afx_compress_job> pending_cjobs_;    // compress_also()
   bool sizing_ = false;
   std::vector<uint8_t> blob_;
   uint8_t* blob_base_ = nullptr;   // device address the blob will live at

@@ -383,7 +383,11 @@ AFX_DEV void msm_recode(const afx_msm_job* job, uint32_t* __restrict__ digit_ws,
 #pragma unroll 1
   for (uint32_t t = from; t < nt; t++) {
     sc s = sc_load_item(job->term[t].scalar, job->term[t].scalar_stride, item);
-    if (job->half_var) s = sc_half(s);   // the job computes half of its sum; k_compress2x encodes the double
+    // the job computes half of its sum (k_compress2x encodes the double); the term's base holds half its point (leave_half):
+    // each alone changes the scalar, both together cancel
+    const bool halve = job->half_var != nullptr, twice = job->term[t].dbl != 0;
+    if (halve && !twice) s = sc_half(s);
+    if (twice && !halve) s = sc_dbl(s);
     uint32_t b[9];
     b[8] = 0;
     if (t < nv || job->term[t].secret) sc_bias(b, s, 0x88888888u);   // signed 4-bit digits: variable bases, and secret scalars on fixed bases
@@ -582,7 +586,9 @@ k_compress2x(const afx_compress_job* __restrict__ jobs, uint32_t njobs_all, uint
   fe prod = fe_one();
 #pragma unroll 1
   for (uint32_t j = 0; j < njobs; j++) {
-    const c2x_state s = c2x_from(var_load(jobs[j].var, count, item));
+    ge_p3 P = var_load(jobs[j].var, count, item);
+    if (jobs[j].negate) P = ge_neg(P);
+    const c2x_state s = c2x_from(P);
     fe_store_soa(prefix_ws + (size_t)j * AFX_FE_LIMBS * count, 0, count, item, prod);   // product of the factors before j
     prod = fe_mul(prod, s.efgh);
   }
@@ -590,7 +596,9 @@ k_compress2x(const afx_compress_job* __restrict__ jobs, uint32_t njobs_all, uint
 #pragma unroll 1
   for (uint32_t jj = njobs; jj > 0; jj--) {
     const uint32_t j = jj - 1;
-    const c2x_state s = c2x_from(var_load(jobs[j].var, count, item));
+    ge_p3 P = var_load(jobs[j].var, count, item);
+    if (jobs[j].negate) P = ge_neg(P);
+    const c2x_state s = c2x_from(P);
     const fe inv_j = fe_mul(inv, fe_load_soa(prefix_ws + (size_t)j * AFX_FE_LIMBS * count, 0, count, item));   // 1 / (e f g h)_j
     inv = fe_mul(inv, s.efgh);
     uint32_t w[8];

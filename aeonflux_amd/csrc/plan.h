@@ -93,7 +93,8 @@ typedef struct {
   uint32_t secret;         /* the scalar is a secret and the context runs with secret-independent addressing (Assembler::msm
                               sets it): every entry of the window's table is read and the digit's entry selected; a fixed base
                               uses the 4-bit positional tables (AFX_SEC_*), recoded like a variable term              */
-  uint32_t pad;
+  uint32_t dbl;            /* the base holds HALF the point the statement means (its producer left its half for k_compress2x,
+                              afx_msm_job.leave_half): the term's scalar counts twice (Assembler::msm sets it)           */
 } afx_msm_term;
 
 typedef struct {
@@ -111,7 +112,10 @@ typedef struct {
   uint8_t* out_enc;                     /* [count][32] compressed result, may be null             */
   afx_var_t out_var;                    /* extended result, may be null                           */
   uint32_t reject_identity;
-  uint32_t next_job;                    /* unused (round 1 chained a successor job inside the lane) */
+  uint32_t leave_half;                  /* host only, set by the statement code on a job whose result is BOTH encoded and used as a base
+                                           by later multiscalar terms (and by nothing else): the job runs on halved scalars, out_var
+                                           receives half the result, k_compress2x encodes the double, and every later term on that base
+                                           doubles its scalar instead (afx_msm_term.dbl) - one inverse square root less */
   int32_t chain_to;                     /* host only: index (in the vector handed to Assembler::msm) of a job that consumes this
                                            job's out_var and therefore goes into a later launch; -1 none */
   afx_var_t half_var;                   /* non-null: the job runs on HALVED scalars (s/2 mod l for every term), stores the sum here and
@@ -134,7 +138,7 @@ typedef struct {
   const int32_t* var;      /* SoA extended point, the half of what is to be encoded                 */
   uint8_t* out_enc;        /* [count][32]                                                            */
   uint32_t reject_identity;
-  uint32_t pad;
+  uint32_t negate;         /* encode -2 * var instead (the "-E1" beside an E1 that left its half)                            */
 } afx_compress_job;
 
 /* k_negenc: out_enc[item] = encoding of -P, P = the point that `enc` decodes to (coordinates in `var`, Z = 1, as k_decode left

@@ -200,6 +200,23 @@ AFX_DEV sc sc_half(const sc& s) {
   for (int i = 0; i < 8; i++) r.v[i] = (t[i] >> 1) | (t[i + 1] << 31);
   return r;
 }
+// 2 s mod l for canonical s (2 s < 2 l: one conditional subtraction)
+AFX_DEV sc sc_dbl(const sc& s) {
+  uint32_t t[9], u[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) t[i] = (i < 8 ? s.v[i] << 1 : 0u) | (i > 0 ? s.v[i - 1] >> 31 : 0u);
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const uint64_t d = (uint64_t)t[i] - (i < 8 ? SC_L[i] : 0u) - borrow;
+    u[i] = (uint32_t)d;
+    borrow = (uint32_t)(d >> 63);
+  }
+  sc r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = borrow ? t[i] : u[i];
+  return r;
+}
 AFX_DEV void sc_bias(uint32_t out[8], const sc& s, uint32_t bias) {
   uint64_t c = 0;
 #pragma unroll

@@ -27,6 +27,9 @@ static afx_msm_job mk_job(const std::vector<afx_msm_term>& terms, const int32_t*
   j.reject_identity = reject_identity ? 1u : 0u;
   return j;
 }
+// a job whose result is encoded AND is the base of later multiscalar terms, and nothing else: it leaves its half (plan.h
+// afx_msm_job.leave_half): no inverse square root for the encoding, the later terms double their scalars
+static afx_msm_job leaving_half(afx_msm_job j) { j.leave_half = 1; return j; }
 static ScalarVar sv_item(const uint8_t* dev) { ScalarVar s; s.dev = dev; s.stride = 32; return s; }
 static ScalarVar sv_uniform(const uint8_t* dev, const Enc& host) { ScalarVar s; s.dev = dev; s.stride = 0; s.host = host; return s; }
 
@@ -128,7 +131,7 @@ extern "C" int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* 
     js.decode.push_back({ row(s.U, 0), v_U, 1 });
     js.decode.push_back({ row(s.V, 0), v_V, 1 });
     messages_from_attributes(as, a, count, off, true, js.sccheck, js.decode, js.msm1, iv.M);
-    js.msm1.push_back(mk_job({ mk_term(row(s.t, 0), 32, v_U, -1, false) }, nullptr, v_tU, e_tU, true));   // t*U (:189)
+    js.msm1.push_back(leaving_half(mk_job({ mk_term(row(s.t, 0), 32, v_U, -1, false) }, nullptr, v_tU, e_tU, true)));   // t*U (:189): hashed, and x_1's base
     iv.n_messages = a.n_attributes;
     iv.w = sv_item(row(s.responses, 0)); iv.wp = sv_item(row(s.responses, 1)); iv.x0 = sv_item(row(s.responses, 2)); iv.x1 = sv_item(row(s.responses, 3));
     for (uint32_t i = 0; i < c->n; i++) iv.y[i] = sv_item(row(s.responses, 4 + i));
@@ -203,7 +206,7 @@ extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, c
     int32_t* v_tU = as.new_var();
     uint8_t* e_tU = as.new_enc();
     msm1.push_back(mk_job(vterms, nullptr, nullptr, orow(o.V, 0), false));
-    msm1.push_back(mk_job({ mk_term(orow(o.t, 0), 32, v_U, -1, false) }, nullptr, v_tU, e_tU, false));   // t*U (issuance.rs:91)
+    msm1.push_back(leaving_half(mk_job({ mk_term(orow(o.t, 0), 32, v_U, -1, false) }, nullptr, v_tU, e_tU, false)));   // t*U (issuance.rs:91): hashed, and x_1's base
     as.sccheck(sccheck);
     as.decode(decode);
     as.scalarop(sc1);
@@ -406,17 +409,17 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
               *v_C2p = as.new_var(), *v_D1 = as.new_var();
       uint8_t *e_D1 = as.new_enc(), *e_D2 = as.new_enc();
       // Keypair::encrypt (symmetric.rs:252-261): E1 = M2*(a0 + a1*m3), E2 = E1*a + M1
-      msm1.push_back(mk_job({ mk_term(kk, 32, v_M2, -1, false) }, nullptr, v_E1, orow(q.E1, 0), false));
+      // E1 and C_y_2' are outputs AND bases of later terms (E2 = a*E1 + M1, the proof's a*(-E1) and m3*C_y_2'): they leave their halves
+      msm1.push_back(leaving_half(mk_job({ mk_term(kk, 32, v_M2, -1, false) }, nullptr, v_E1, orow(q.E1, 0), false)));
       msm1b.push_back(mk_job({ mk_term(a, 32, v_E1, -1, false) }, v_M1[i], v_E2, orow(q.E2, 0), false));
       // C_y_1..3, C_y_2' (encryption.rs:70-75)
       msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gy(0), false) }, v_M1[i], v_C1, orow(q.C_y_1, 0), false));
       msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gy(1), false) }, v_M2, v_C2, orow(q.C_y_2, 0), false));
       msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gy(2), false), mk_term(m3, 32, nullptr, (int32_t)c->id_Gm(i), false) }, nullptr, v_C3, orow(q.C_y_3, 0), false));
-      msm1b.push_back(mk_job({ mk_term(a1, 32, v_C2, -1, false) }, nullptr, v_C2p, orow(q.C_y_2p, 0), false));
+      msm1b.push_back(leaving_half(mk_job({ mk_term(a1, 32, v_C2, -1, false) }, nullptr, v_C2p, orow(q.C_y_2p, 0), false)));
       afx_pointop_job d1 = { v_C1, v_E2, nullptr, +1, -1, v_D1, e_D1, 0 };
-      afx_pointop_job d2 = { v_E1, nullptr, nullptr, -1, 0, nullptr, e_D2, 0 };   // only the encoding of -E1 is needed
       pops.push_back(d1);
-      pops.push_back(d2);
+      as.compress_also(v_E1, e_D2, true, 0);   // only the encoding of -E1 is needed: from E1's half, with msm1's other commitments
       SchnorrBuilder ep(as, "2019/1416 anonymous credentials", "2019/1416 proof of encryption");
       const int sa = ep.allocate_scalar("a", sv_item(a));
       const int sa0 = ep.allocate_scalar("a0", sv_item(a0));

@@ -225,7 +225,9 @@ extern "C" int afx_encrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8
     as.sccheck({ { at(o_a) }, { at(o_a0) }, { at(o_a1) }, { at(o_m3) } });
     as.decode({ { at(o_M1), v_M1, 0 }, { at(o_M2), v_M2, 0 } });
     as.scalarop({ mk_sop(at(o_a1), 32, at(o_m3), 32, at(o_a0), 32, k) });                                   // a0 + a1*m3
-    as.msm({ mk_msm({ mk_term(k, 32, v_M2, -1, false) }, nullptr, v_E1, at(o_E1)) });                         // E1 = M2*(a0 + a1*m3)
+    afx_msm_job jE1 = mk_msm({ mk_term(k, 32, v_M2, -1, false) }, nullptr, v_E1, at(o_E1));                   // E1 = M2*(a0 + a1*m3)
+    jE1.leave_half = 1;   // an output and the base of E2's term: plan.h afx_msm_job.leave_half
+    as.msm({ jE1 });
     as.msm({ mk_msm({ mk_term(at(o_a), 32, v_E1, -1, false) }, v_M1, nullptr, at(o_E2)) });                   // E2 = E1*a + M1
     as.finish(st.dev(o_st) + off, AFX_ST_VERIFICATION_FAILURE);
   });

@@ -200,6 +200,12 @@ void arith_sc(uint8_t red[32], uint8_t muladd[32], uint8_t neg[32], int* canonic
   *canonical = sc_is_canonical(sc_from(a)) ? 1 : 0;
 }
 
+// s/2 and 2s mod l (k_msm's recoding of halved jobs and of terms on a half base)
+void arith_sc_half_dbl(uint8_t half[32], uint8_t dbl[32], const uint8_t a[32]) {
+  sc r = sc_half(sc_from(a)); memcpy(half, r.v, 32);
+  r = sc_dbl(sc_from(a)); memcpy(dbl, r.v, 32);
+}
+
 // signed-digit recoding used by k_msm: digits of s + bias; returns sum(d_i * radix^i) check value via the caller
 void arith_sc_bias(uint32_t out[8], const uint8_t s[32], uint32_t bias) { sc_bias(out, sc_from(s), bias); }
 

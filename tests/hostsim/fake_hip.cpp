@@ -65,6 +65,8 @@ hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_ms
   for (uint32_t i = 0; i < n; i++) {
     if (!encodes && j[i].out_enc && !j[i].half_var) return hipErrorInvalidValue;   // a job that encodes in the kernel needs the encoding launch
     if ((j[i].n_var == 0 ? 0 : j[i].n_uni ? 2 : 1) != kind) return hipErrorInvalidValue;   // every job in its own class's launch
+    if (j[i].leave_half && (j[i].out_var || !j[i].half_var)) return hipErrorInvalidValue;    // a job that leaves its half stores only the half
+    for (uint32_t t = 0; t < j[i].n_uni; t++) if (j[i].term[t].dbl) return hipErrorInvalidValue;   // NAF schedules never run on a half base
     for (uint32_t t = 0; t < j[i].n_terms; t++) sink += (uintptr_t)j[i].term[t].scalar;
     if (j[i].n_uni) {   // the NAF schedule lives in the plan blob: read it to its terminator
       for (const uint32_t* e = j[i].naf_sched; ; e++) { sink += *e; if (*e == 0xffffffffu) break; }

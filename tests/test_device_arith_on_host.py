@@ -172,6 +172,10 @@ def test_scalar_ops_against_python_integers(arith):
         assert int.from_bytes(bytes(ng), "little") == (-av) % L
         arith.arith_sc(red, ma, ng, C.byref(can), wide, a, b_r, c_r)
         assert can.value == (1 if ai < L else 0)
+        half, dbl = (C.c_uint8 * 32)(), (C.c_uint8 * 32)()
+        arith.arith_sc_half_dbl(half, dbl, a_r)
+        assert int.from_bytes(bytes(half), "little") * 2 % L == av and int.from_bytes(bytes(half), "little") < L
+        assert int.from_bytes(bytes(dbl), "little") == 2 * av % L
 
 
 def test_msm_chain_with_consumer_aware_conversions(arith):
