@@ -257,7 +257,7 @@ void Assembler::compress(const std::vector<afx_compress_job>& cjobs, uint32_t gr
 }
 
 // Multiscalar jobs of one statement stage.  Large passes: one lane per (job, item), every job a single chain (msm_list).  Small
-// passes (at most afx_ctx_set_small_batch_items items, default 2048): the device is mostly idle and a call's duration is the
+// passes (at most afx_ctx_set_small_batch_items items, default 8192): the device is mostly idle and a call's duration is the
 // LONGEST chain, so every variable-base term gets a chain of its own (msm_split).
 void Assembler::msm(std::vector<afx_msm_job> jobs) {
   if (jobs.empty()) return;
@@ -287,8 +287,31 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   std::vector<afx_compress_job> cjobs;
   cjobs.swap(pending_cjobs_);   // compress_also()
   const bool small = this->small();
-  if (small) msm_split(std::move(jobs), cjobs);
-  else msm_list(std::move(jobs), false, cjobs);
+  // Passes of up to four times that size: the device is full during the windowed launch but not during the one before it,
+  // which holds the ONE job that multiplies by the issuer key (Z: a single grid row of ten NAF terms, 16-128 blocks on 256
+  // compute units for 1.7 ms).  There that job alone is split into one NAF chain per term and summed, ahead of the others.
+  const bool mid = !small && ctx->small_batch_items != 0 && count <= 4 * (uint64_t)ctx->small_batch_items;
+  if (small) msm_split(std::move(jobs), cjobs, true);
+  else if (mid) {
+    auto naf_term = [&](const afx_msm_term& t) { return t.scalar_stride == 0 && !ctx->fixed_key_schedule && !ctx->secret_independent && !t.dbl && host_scalar_of(ctx, t.scalar) != nullptr; };
+    std::vector<afx_msm_job> first, rest;
+    std::vector<int> new_index(jobs.size(), -1);
+    bool ok = true;
+    for (size_t i = 0; i < jobs.size(); i++) {
+      uint32_t k = 0;
+      for (uint32_t t = 0; t < jobs[i].n_var; t++) k += naf_term(jobs[i].term[t]);
+      if (k >= 2) first.push_back(jobs[i]); else { new_index[i] = (int)rest.size(); rest.push_back(jobs[i]); }
+    }
+    for (size_t i = 0; i < jobs.size() && ok; i++)
+      if (jobs[i].chain_to >= 0 && new_index[i] >= 0 && new_index[jobs[i].chain_to] < 0) ok = false;   // a split job would wait for one that is not
+    if (first.empty() || !ok) msm_list(std::move(jobs), false, cjobs);
+    else {
+      for (afx_msm_job& j : first) j.chain_to = -1;   // their consumers are all in `rest`, which starts after their sums
+      for (afx_msm_job& j : rest) j.chain_to = j.chain_to >= 0 ? new_index[j.chain_to] : -1;
+      msm_split(std::move(first), cjobs, false);
+      msm_list(std::move(rest), false, cjobs);
+    }
+  } else msm_list(std::move(jobs), false, cjobs);
   // small passes: the item's commitments are encoded in up to 8 rows, an inversion each, instead of one serial walk
   compress(cjobs, small ? 8u : 1u);
 }
@@ -301,9 +324,9 @@ void Assembler::compress_also(const int32_t* var, uint8_t* out_enc, bool negate,
 
 // One chain per term.  A job with more than one part - each variable-base term, and its fixed-base terms together - becomes
 // that many single-part jobs writing partial sums, plus a k_pointsum row adding them (and the addend) up; a job that feeds
-// another (chain_to) is summed before the consumer's chains start, so stages run level by level.  No NAF schedules here: a
-// lone key term costs 64 additions instead of ~43, but shares the windowed launch with every other chain of its stage.
-void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compress_job>& cjobs) {
+// another (chain_to) is summed before the consumer's chains start, so stages run level by level.  no_naf (small passes): no NAF
+// schedules - a lone key term costs 64 additions instead of ~43, but shares the windowed launch with every other chain of its stage.
+void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compress_job>& cjobs, bool no_naf) {
   const size_t n = jobs.size();
   for (size_t i = 0; i < n; i++)
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
@@ -360,7 +383,7 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
       stats.field_mul += 9 * (uint64_t)(sj.n_parts - 1 + (sj.addend ? 1 : 0));
       sums.push_back(sj);
     }
-    msm_list(std::move(subs), true, cjobs);
+    msm_list(std::move(subs), no_naf, cjobs);
     add_jobs(L_POINTSUM, sums);
   }
 }

@@ -405,3 +405,33 @@ def test_mixed_shapes_through_the_c_entry_points():
     grp = afx.Group(d["params"], d["key"], d["ip"], [0, 0])
     assert [int(x[0]) for x in batch.verify_mixed(grp, items)] == want
     grp.close()
+
+
+def test_the_three_plans_agree():
+    """One batch of 9000 presentations (60 distinct ones tiled, a third corrupted) under the plan of large passes (one chain per
+    job), the latency plan (one chain per term, -c*Z over Z's terms) and the plan in between (only the job that multiplies by
+    the issuer key split into NAF chains): the same statuses - the oracle's - and the same recomputed challenges."""
+    import aeonflux_amd as afx
+    from aeonflux_amd import batch
+    from tests.soa import presentation_arrays, shape_of
+    params, key, ip, issuer, pres = make_batch(8, "SSPPEEEE", [4, 5, 6, 7], 60, b"gpu-three-plans")
+    corrupt(pres, b"three-plans-corrupt")
+    want = np.array([issuer.verify_presentation(p) for p in pres], np.uint8)
+    a = presentation_arrays(pres)
+    sh = afx.Shape.from_buffer_copy(bytes(shape_of(pres[0])))
+    reps, total = 150, 9000
+    big = {f: np.ascontiguousarray(np.concatenate([a[f]] * reps, axis=-2)) for f in batch.PRES_FIELDS}
+    big["enc"] = [{f: np.ascontiguousarray(np.concatenate([d[f]] * reps, axis=-2)) for f in batch.ENC_FIELDS} for d in a["enc"]]
+    ctx = afx.Context(params, key, ip)
+    seen = {}
+    for name, thr in (("one chain per job", 0), ("one chain per term", 16384), ("key job split", 4096)):
+        ctx.set_small_batch_items(thr)
+        ctx.set_challenge_trace(5, total)
+        st = batch.verify_presentations(ctx, sh, big)
+        tr = ctx.get_challenge_trace()
+        ctx.set_challenge_trace(0, 0)
+        assert np.array_equal(st, np.tile(want, reps)), name
+        seen[name] = (tr, ctx.plan_stats()["msm_jobs"])
+    ctx.close()
+    assert np.array_equal(seen["one chain per job"][0], seen["one chain per term"][0]) and np.array_equal(seen["one chain per job"][0], seen["key job split"][0])
+    assert seen["one chain per job"][1] < seen["key job split"][1] < seen["one chain per term"][1]   # 27 < 27 - 1 + 11 < 86
