@@ -257,7 +257,7 @@ void Assembler::compress(const std::vector<afx_compress_job>& cjobs, uint32_t gr
 }
 
 // Multiscalar jobs of one statement stage.  Large passes: one lane per (job, item), every job a single chain (msm_list).  Small
-// passes (at most afx_ctx_set_small_batch_items items, default 8192): the device is mostly idle and a call's duration is the
+// passes (at most afx_ctx_set_small_batch_items items, default 4096): the device is mostly idle and a call's duration is the
 // LONGEST chain, so every variable-base term gets a chain of its own (msm_split).
 void Assembler::msm(std::vector<afx_msm_job> jobs) {
   if (jobs.empty()) return;

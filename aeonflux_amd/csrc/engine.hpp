@@ -108,7 +108,7 @@ struct afx_ctx {
   bool fixed_key_schedule = false;   // afx_ctx_set_fixed_key_schedule: no NAF for the issuer key's scalars
   bool secret_independent = false;   // afx_ctx_set_secret_independent_addressing: no memory address depends on a secret digit
   uint32_t chunk_items = 0;   // afx_ctx_set_chunk_items; 0 = default
-  uint32_t small_batch_items = 8192;   // afx_ctx_set_small_batch_items: passes of at most this many items take the latency plan
+  uint32_t small_batch_items = 4096;   // afx_ctx_set_small_batch_items: passes of at most this many items take the latency plan
   afx_plan_stats last_stats = {};   // per-item operation counts of the most recent plan
   std::map<std::pair<std::string, uint32_t>, size_t> plan_sizes;   // (plan key bytes, pass size) -> workspace bytes (statements.hpp run_chunked)
   uint32_t n_cu = 256;   // compute units of the device (k_msm keeps 2 blocks resident on each)

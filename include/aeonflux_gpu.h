@@ -177,14 +177,14 @@ int afx_ctx_set_secret_independent_addressing(afx_ctx* ctx, int enable);
  * statement); smaller values trade throughput for memory.  Accepted range 256 .. 2^22. */
 int afx_ctx_set_chunk_items(afx_ctx* ctx, uint32_t items);
 
-/* Small passes (default 8192 items; 0 switches the latency plans off, at most 2^16).  A call of few items leaves most of the
+/* Small passes (default 4096 items; 0 switches the latency plans off, at most 2^16).  A call of few items leaves most of the
  * device idle, and its duration is that of its LONGEST chain of field operations - one Issuer::verify of the reference is one
  * presentation (src/issuer.rs:141-147).  Passes of at most this many items therefore give every variable-base term of every
  * multiscalar multiplication a chain of its own (a 3-term commitment becomes 3 lanes with 64 additions each instead of one
  * with 192), add the partial sums up afterwards, and encode an item's commitments in several rows.  More work in all, less
- * time per call (measured crossover with the throughput plan: 2^13 items).  Passes of up to FOUR times this many items split
+ * time per call (measured, C3 shape: 3.2 ms against 4.3 ms at 2^12 items, level at 2^13).  Passes of up to FOUR times this many items split
  * only the job that multiplies by the issuer key (Z: one grid row that cannot fill the device at such sizes) into one NAF
- * chain per term.  Results are identical under every plan. */
+ * chain per term (5.0 ms against 5.8 ms at 2^13 items, 8.7 against 9.0 at 2^14).  Results are identical under every plan. */
 int afx_ctx_set_small_batch_items(afx_ctx* ctx, uint32_t items);
 
 /* Challenge trace (parity aid; off by default).  set(rows, count) allocates a device array [rows][count][32]; while it
