@@ -1,5 +1,5 @@
 """Time per call of Issuer::verify against batch size (C3 shape), for the two plans (afx_ctx_set_small_batch_items 0 = one chain
-per job, 2048 = one chain per term for small passes):
+per job, 4096 = the default: one chain per term up to 2^12 items, the key job split up to 2^14):
   dev   afx_verify_presentations_dev, inputs resident in HBM, calls queued back to back on the context's stream
   host  afx_verify_presentations, host pointers, one synchronous call (staging, kernels, status back): what a caller of the
         reference's one-presentation Issuer::verify (src/issuer.rs:141-147) waits for
@@ -23,7 +23,7 @@ shape = parts[0][1]
 pres = {f: np.concatenate([p[0][f] for p in parts], axis=-2) for f in batch.PRES_FIELDS}
 pres["enc"] = [{f: np.concatenate([p[0]["enc"][e][f] for p in parts], axis=-2) for f in batch.ENC_FIELDS} for e in range(shape.n_enc_proofs)]
 dev = torch.device("cuda", 0)
-print("%-10s %s" % ("items", "  ".join("%-26s" % ("small_batch_items=%d: dev / host ms" % t) for t in (0, 2048))))
+print("%-10s %s" % ("items", "  ".join("%-26s" % ("small_batch_items=%d: dev / host ms" % t) for t in (0, 4096))))
 for lg in range(0, top + 1):
     n = 1 << lg
     hsub = {f: np.ascontiguousarray(pres[f][..., :n, :]) for f in batch.PRES_FIELDS}
@@ -35,7 +35,7 @@ for lg in range(0, top + 1):
     st = torch.zeros(n, dtype=torch.uint8, device=dev)
     hst = np.zeros(n, np.uint8)
     cols = []
-    for thr in (0, 2048):
+    for thr in (0, 4096):
         issuer.set_small_batch_items(thr)
         call = lambda: afx.check(afx.lib().afx_verify_presentations_dev(issuer.h, C.byref(shape), C.byref(soa), n, st.data_ptr()))
         hcall = lambda: afx.check(afx.lib().afx_verify_presentations(issuer.h, C.byref(shape), C.byref(hsoa), n, hst.ctypes.data))

@@ -1,5 +1,5 @@
 """Latency of ONE synchronous host-pointer call of each operation at small batch sizes, for the two plans
-(afx_ctx_set_small_batch_items 0 / 2048): python tools/small_call_latency.py
+(afx_ctx_set_small_batch_items 0 / 4096 (the default)): python tools/small_call_latency.py
 Shapes: issue n = 16 (C5's layout), show and verify the C3 shape (8 attributes, 4 hidden encrypted points)."""
 import sys
 import time
@@ -24,7 +24,7 @@ p5, k5, i5 = bench.load_fixture("c5_16attrs")
 iss5 = afx.Context(p5, k5, i5)
 p3, k3, i3 = bench.load_fixture("c3_8attrs_SSPPeeee")
 iss3, usr3 = afx.Context(p3, k3, i3), afx.Context(p3, None, i3)
-print("%-8s %-28s %-28s %-28s" % ("items", "issue n=16  (0 / 2048) ms", "show C3  (0 / 2048) ms", "verify C3  (0 / 2048) ms"))
+print("%-8s %-28s %-28s %-28s" % ("items", "issue n=16  (0 / 4096) ms", "show C3  (0 / 4096) ms", "verify C3  (0 / 4096) ms"))
 for n in (1, 16, 256, 1024):
     kinds5 = [afx.ATTR_PUBLIC_SCALAR] * 8 + [afx.ATTR_PUBLIC_POINT] * 4 + [afx.ATTR_EITHER_POINT] * 4
     vals5 = np.stack([batch.scalars_from_wide(iss5, rb(n, 64)) if i < 8 else batch.points_from_uniform(iss5, rb(n, 64)) for i in range(16)])
@@ -49,9 +49,9 @@ for n in (1, 16, 256, 1024):
                           ("show", usr3, lambda: batch.show(usr3, sk, vals3, cred["t"], cred["U"], cred["V"], kp, zw, ssd, es, M2, m3)),
                           ("verify", iss3, lambda: batch.verify_presentations(iss3, shape, pres))):
         r = []
-        for thr in (0, 2048):
+        for thr in (0, 4096):
             ctx.set_small_batch_items(thr)
             r.append(timed(fn))
-        ctx.set_small_batch_items(2048)
+        ctx.set_small_batch_items(4096)
         cols.append("%8.3f / %8.3f" % tuple(r))
     print("%-8d %-28s %-28s %-28s" % (n, *cols), flush=True)

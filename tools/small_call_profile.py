@@ -17,7 +17,7 @@ sub = {f: torch.from_numpy(pres[f]).to(dev) for f in batch.PRES_FIELDS}
 sub["enc"] = [{f: torch.from_numpy(d[f]).to(dev) for f in batch.ENC_FIELDS} for d in pres["enc"]]
 soa, keep = batch.presentation_soa(sub, ptr=lambda t: t.data_ptr())
 st = torch.zeros(n, dtype=torch.uint8, device=dev)
-for thr in (0, 2048):
+for thr in (0, 4096):
     issuer.set_small_batch_items(thr)
     call = lambda: afx.check(afx.lib().afx_verify_presentations_dev(issuer.h, C.byref(shape), C.byref(soa), n, st.data_ptr()))
     call(); issuer.synchronize()
