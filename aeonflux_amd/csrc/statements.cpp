@@ -346,7 +346,10 @@ static void add_encproof_verify(Assembler& as, JobSets& js, uint16_t index, cons
   js.pointop.push_back(d1);
   // -E1 (:185): only its encoding is needed (the term a*(-E1) runs as -(a*E1) on E1's table, below), and the encoding of the
   // negation of a DECODED point needs no square root: one inversion per item for all its proofs of encryption (k_negenc)
-  js.negenc.push_back({ row(e.E1, 0), v_E1, e_D2, 1, 0 });
+  // (a small pass has idle lanes and waits for its longest stage: there every -E1 keeps a lane and a square root of its own,
+  // in the launch that computes C_y_1 - E2 anyway, instead of a launch that walks the item's proofs one after the other)
+  if (as.small()) js.pointop.push_back({ v_E1, nullptr, nullptr, -1, 0, nullptr, e_D2, 1 });
+  else js.negenc.push_back({ row(e.E1, 0), v_E1, e_D2, 1, 0 });
   auto resp = [&](int k) { ScalarVar s; s.dev = row(e.responses, k); s.stride = 32; return s; };
   SchnorrBuilder v(as, "2019/1416 anonymous credentials", "2019/1416 proof of encryption");
   const int a = v.allocate_scalar("a", resp(0));
