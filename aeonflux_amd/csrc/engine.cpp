@@ -322,7 +322,7 @@ void Assembler::compress_also(const int32_t* var, uint8_t* out_enc, bool negate,
   stats.encodings++; stats.field_mul += AFX_ENCODE_MUL; stats.field_sq += AFX_ENCODE_SQ;   // compress() rewrites this share
 }
 
-// One chain per term.  A job with more than one part - each variable-base term, and its fixed-base terms together - becomes
+// One chain per term.  A job with more than one part - each variable-base term, and its fixed-base terms six at a time - becomes
 // that many single-part jobs writing partial sums, plus a k_pointsum row adding them (and the addend) up; a job that feeds
 // another (chain_to) is summed before the consumer's chains start, so stages run level by level.  no_naf (small passes): no NAF
 // schedules - a lone key term costs 64 additions instead of ~43, but shares the windowed launch with every other chain of its stage.
@@ -346,7 +346,11 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
       if (level[i] != lv) continue;
       afx_msm_job j = jobs[i];
       j.chain_to = -1;
-      const uint32_t parts = j.n_var + (j.n_terms > j.n_var ? 1u : 0u);
+      // fixed-base terms go six to a part: 120 additions, well under the 252 doublings + 64 additions of a variable-base chain
+      // (the second commitment of an issuance proof has n + 3 of them: one lane with 380 additions was the longest chain of a
+      // small issue call)
+      const uint32_t FIXED_PER_PART = 6;
+      const uint32_t parts = j.n_var + (j.n_terms - j.n_var + FIXED_PER_PART - 1) / FIXED_PER_PART;
       if (parts <= 1) { subs.push_back(j); continue; }   // a single chain already (its addend, if any, is added by its own lane)
       const bool halved = j.out_enc && !j.addend && (!j.out_var || j.leave_half);   // only ever encoded, or leaving its half: halved scalars, k_compress2x (msm_list)
       std::vector<const int32_t*> part_vars;
@@ -361,7 +365,7 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
         subs.push_back(s);
       };
       for (uint32_t t = 0; t < j.n_var; t++) sub_of(t, 1, 1);
-      if (j.n_terms > j.n_var) sub_of(j.n_var, j.n_terms - j.n_var, 0);
+      for (uint32_t first = j.n_var; first < j.n_terms; first += FIXED_PER_PART) sub_of(first, std::min(FIXED_PER_PART, j.n_terms - first), 0);
       afx_pointsum_job sj;
       memset(&sj, 0, sizeof sj);
       sj.parts = put(part_vars.data(), part_vars.size());
