@@ -504,7 +504,12 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
   std::vector<int> producer(n, -1);
   for (size_t i = 0; i < n; i++)
     if (jobs[i].chain_to >= 0) producer[jobs[i].chain_to] = (int)i;
-  auto kind_of = [](const afx_msm_job& j) { return j.n_var == 0 ? 0 : (j.n_uni ? 2 : 1); };
+  // small passes (no_naf): jobs of fixed bases only ride in the windowed launch when there is one - the kernel skips their chain -
+  // instead of a launch of their own ahead of it: one launch less, and the short rows run beside the long ones
+  bool any_window = false;
+  for (size_t i = 0; i < n; i++) any_window |= jobs[i].n_var != 0 && jobs[i].n_uni == 0;
+  const bool merge_fixed = no_naf && any_window;
+  auto kind_of = [&](const afx_msm_job& j) { return j.n_var == 0 ? (merge_fixed ? 1 : 0) : (j.n_uni ? 2 : 1); };
   // Jobs whose result is only ever encoded (no consumer of the point itself, no addend): they run on halved scalars and leave
   // half their sum in a workspace slot; one k_compress2x launch at the end of this list encodes the doubles with a single field
   // inversion per item (kernels.hip).  That is every recomputed or fresh commitment of a Schnorr proof (26 of the 35 encodings

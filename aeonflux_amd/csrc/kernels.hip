@@ -539,8 +539,10 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
         }
       }
     } else {
+      // (nv == 0: a job of fixed bases only that a small pass put into this launch, so that it runs beside the chains instead
+      // of in a launch of its own before them - engine.cpp msm_list)
 #pragma unroll 1
-      for (int w = 63; w >= 0; w--) {
+      for (int w = nv ? 63 : -1; w >= 0; w--) {
         if (w != 63) {
           ge_p2 a2 = ge_p3_to_p2(acc);
 #pragma unroll 1

@@ -64,7 +64,7 @@ hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_ms
   if (kind < 0 || kind > 2) return hipErrorInvalidValue;
   for (uint32_t i = 0; i < n; i++) {
     if (!encodes && j[i].out_enc && !j[i].half_var) return hipErrorInvalidValue;   // a job that encodes in the kernel needs the encoding launch
-    if ((j[i].n_var == 0 ? 0 : j[i].n_uni ? 2 : 1) != kind) return hipErrorInvalidValue;   // every job in its own class's launch
+    if ((j[i].n_var == 0 ? 0 : j[i].n_uni ? 2 : 1) != kind && !(j[i].n_var == 0 && kind == 1)) return hipErrorInvalidValue;   // every job in its own class's launch (fixed-only jobs may ride in the windowed one)
     if (j[i].leave_half && (j[i].out_var || !j[i].half_var)) return hipErrorInvalidValue;    // a job that leaves its half stores only the half
     for (uint32_t t = 0; t < j[i].n_uni; t++) if (j[i].term[t].dbl) return hipErrorInvalidValue;   // NAF schedules never run on a half base
     for (uint32_t t = 0; t < j[i].n_terms; t++) sink += (uintptr_t)j[i].term[t].scalar;
