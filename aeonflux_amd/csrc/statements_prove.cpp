@@ -411,12 +411,25 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
       // Keypair::encrypt (symmetric.rs:252-261): E1 = M2*(a0 + a1*m3), E2 = E1*a + M1
       // E1 and C_y_2' are outputs AND bases of later terms (E2 = a*E1 + M1, the proof's a*(-E1) and m3*C_y_2'): they leave their halves
       msm1.push_back(leaving_half(mk_job({ mk_term(kk, 32, v_M2, -1, false) }, nullptr, v_E1, orow(q.E1, 0), false)));
-      msm1b.push_back(mk_job({ mk_term(a, 32, v_E1, -1, false) }, v_M1[i], v_E2, orow(q.E2, 0), false));
+      // Small passes: a chain that waits for a chain is what a call waits for, and both second-stage results are sums the prover
+      // knows term by term: E2 = a*E1 + M1 = (a*kk)*M2 + M1 and C_y_2' = a1*C_y_2 = (a1*z)*G_y_2 + a1*M2 - chains on decoded
+      // inputs, beside the first stage's.  (Same group elements, hence the same encodings.)
+      const bool flat = as.small();
+      if (flat) {
+        uint8_t *akk = as.new_enc(), *a1z = as.new_enc();
+        sc2.push_back(mk_scalarop(a, 32, kk, 32, nullptr, 0, false, akk));
+        sc1.push_back(mk_scalarop(a1, 32, z, 32, nullptr, 0, false, a1z));
+        msm1.push_back(mk_job({ mk_term(akk, 32, v_M2, -1, false) }, v_M1[i], v_E2, orow(q.E2, 0), false));
+        msm1.push_back(leaving_half(mk_job({ mk_term(a1z, 32, nullptr, (int32_t)c->id_Gy(1), false), mk_term(a1, 32, v_M2, -1, false) }, nullptr, v_C2p,
+                                           orow(q.C_y_2p, 0), false)));
+      } else {
+        msm1b.push_back(mk_job({ mk_term(a, 32, v_E1, -1, false) }, v_M1[i], v_E2, orow(q.E2, 0), false));
+      }
       // C_y_1..3, C_y_2' (encryption.rs:70-75)
       msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gy(0), false) }, v_M1[i], v_C1, orow(q.C_y_1, 0), false));
       msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gy(1), false) }, v_M2, v_C2, orow(q.C_y_2, 0), false));
       msm1.push_back(mk_job({ mk_term(z, 32, nullptr, (int32_t)c->id_Gy(2), false), mk_term(m3, 32, nullptr, (int32_t)c->id_Gm(i), false) }, nullptr, v_C3, orow(q.C_y_3, 0), false));
-      msm1b.push_back(leaving_half(mk_job({ mk_term(a1, 32, v_C2, -1, false) }, nullptr, v_C2p, orow(q.C_y_2p, 0), false)));
+      if (!flat) msm1b.push_back(leaving_half(mk_job({ mk_term(a1, 32, v_C2, -1, false) }, nullptr, v_C2p, orow(q.C_y_2p, 0), false)));
       afx_pointop_job d1 = { v_C1, v_E2, nullptr, +1, -1, v_D1, e_D1, 0 };
       pops.push_back(d1);
       as.compress_also(v_E1, e_D2, true, 0);   // only the encoding of -E1 is needed: from E1's half, with msm1's other commitments
