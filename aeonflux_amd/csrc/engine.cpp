@@ -261,6 +261,8 @@ void Assembler::compress(const std::vector<afx_compress_job>& cjobs, uint32_t gr
 // LONGEST chain, so every variable-base term gets a chain of its own (msm_split).
 void Assembler::msm(std::vector<afx_msm_job> jobs) {
   if (jobs.empty()) return;
+  for (size_t i = 0; i < jobs.size(); i++)
+    if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= jobs.size() || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
   // Secret-independent addressing (afx_ctx_set_secret_independent_addressing): which terms carry a secret scalar.  In a prover-side
   // plan every scalar but the constant 1.  In a verifier-side plan every term of a job that multiplies by the issuer key (Z of
   // Issuer::verify): the key's own terms, and beside them the per-item scalars DERIVED from it by a public factor (y_i * m_i for a

@@ -28,3 +28,12 @@ int verify_my_range(afx_ctx* ctx, unsigned members, unsigned index, const afx_sh
   afx_shard_bounds(count, members, index, &first, &n);
   return afx_verify_presentations_range(ctx, shape, batch, count, first, n, status);
 }
+
+/* a request stream as it arrives: serialized presentations of whatever shapes, one AFXP section each (or one per same-shape
+ * run), back to back in `stream`.  The library groups them by shape, runs one GPU batch per distinct shape and answers in
+ * arrival order: status[i] belongs to the i-th presentation of the stream; *n = how many there were. */
+int verify_request_stream(afx_ctx* ctx, const unsigned char* stream, size_t stream_len, unsigned char* status, size_t status_cap, size_t* n) {
+  const int rc = afx_verify_presentations_mixed_wire(ctx, stream, stream_len, status, status_cap, n);
+  if (rc != AFX_OK) fprintf(stderr, "afx_verify_presentations_mixed_wire: %d %s\n", rc, afx_last_error());
+  return rc;
+}

@@ -37,7 +37,9 @@ def test_header_is_valid_c_and_the_c_example_links(tmp_path):
     import aeonflux_amd as afx
     main = tmp_path / "main.c"
     main.write_text('#include "aeonflux_gpu.h"\nint verify_my_range(afx_ctx*, unsigned, unsigned, const afx_shape*, const afx_presentation_soa*, size_t, unsigned char*);\n'
-                    'int main(void) { return verify_my_range(0, 1, 0, 0, 0, 0, 0) == AFX_E_BAD_ARGS ? 0 : 1; }\n')
+                    'int verify_request_stream(afx_ctx*, const unsigned char*, size_t, unsigned char*, size_t, size_t*);\n'
+                    'int main(void) { size_t n = 7; return (verify_my_range(0, 1, 0, 0, 0, 0, 0) == AFX_E_BAD_ARGS && '
+                    'verify_request_stream(0, 0, 0, 0, 0, &n) == AFX_E_BAD_ARGS) ? 0 : 1; }\n')
     exe = tmp_path / "example"
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", hdr, os.path.join(ROOT, "integration", "example_verify.c"), str(main),
                         "-L", os.path.dirname(afx.LIB_PATH), "-laeonflux_gpu", "-Wl,-rpath," + os.path.dirname(afx.LIB_PATH), "-o", str(exe)],
