@@ -119,7 +119,8 @@ pub struct AfxPresentationGroup {
 /// Bytes that must not outlive the call: randomness the proofs' nonces come from, staged symmetric keys.
 struct Wiped(Vec<u8>);
 impl Wiped { fn new(len: usize) -> Wiped { Wiped(vec![0u8; len]) } }
-impl Drop for Wiped { fn drop(&mut self) { self.0.zeroize(); } }
+// (the slice impl: the crate takes zeroize without its `alloc` feature, Cargo.toml:39, so `Vec<u8>: Zeroize` is not there)
+impl Drop for Wiped { fn drop(&mut self) { self.0.as_mut_slice().zeroize(); } }
 
 // per-item status bytes (AFX_ST_*) and amacs::Attribute kinds (AFX_ATTR_*) of include/aeonflux_gpu.h
 const ST_OK: u8 = 0;
