@@ -128,6 +128,9 @@ def lib():
         _LIB.afx_wire_cells_per_record.argtypes = [C.POINTER(Shape)]
         _LIB.afx_wire_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Shape), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         _LIB.afx_verify_presentations_wire.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        _LIB.afx_verify_presentations_wire_range.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        for name in ("afx_group_verify_presentations_wire", "afx_group_verify_presentations_mixed_wire"):
+            getattr(_LIB, name).argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _LIB.afx_wire_section_bytes.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _LIB.afx_verify_presentations_mixed_wire.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         for name in ("afx_verify_presentations_mixed", "afx_group_verify_presentations_mixed"):

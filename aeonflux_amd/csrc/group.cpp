@@ -78,6 +78,20 @@ extern "C" int afx_group_verify_presentations(afx_group* g, const afx_shape* sha
   if (!g || g->members.empty() || !shape || !batch || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   return run_members(g, count, [&](afx_ctx* c, size_t first, size_t n) { return afx_verify_presentations_range(c, shape, batch, count, first, n, status); });
 } catch (...) { return afx::exception_rc(); }
+// a serialized batch over the group's devices: the records are contiguous, so every member takes a byte range of the caller's blob
+extern "C" int afx_group_verify_presentations_wire(afx_group* g, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out) try {
+  if (!g || g->members.empty() || !status || !count_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  afx_shape sh;
+  size_t count = 0, off = 0;
+  int rc = afx_wire_parse(blob, len, &sh, &count, &off);
+  if (rc) return rc;
+  *count_out = count;
+  if (status_cap < count) { set_error("status buffer too small"); return AFX_E_BAD_ARGS; }
+  return run_members(g, count, [&](afx_ctx* c, size_t first, size_t n) {
+    size_t seen = 0;
+    return afx_verify_presentations_wire_range(c, blob, len, first, n, status, status_cap, &seen);
+  });
+} catch (...) { return afx::exception_rc(); }
 extern "C" int afx_group_issue(afx_group* g, const afx_attributes_soa* requests, const afx_issue_randomness* rnd, size_t count,
                                const afx_issuance_soa* out, uint8_t* status) try {
   if (!g || g->members.empty() || !requests || !rnd || !out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }

@@ -88,9 +88,10 @@ extern "C" int afx_wire_section_bytes(const uint8_t* blob, size_t len, size_t* s
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 
-extern "C" int afx_verify_presentations_mixed_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap,
-                                                   size_t* count_out) try {
-  if (!ctx || (!blob && len) || !count_out || (!status && status_cap)) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+// `verify_section(section bytes, length, status, cap, &n)`: one same-shape AFXP batch on a context or on a group of them
+template <class VerifySection>
+static int mixed_wire(const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out, VerifySection&& verify_section) {
+  if ((!blob && len) || !count_out || (!status && status_cap)) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   struct Section { size_t off, len, hdr, count, first; };
   struct Group { std::vector<Section> sections; size_t count = 0; };
   std::map<std::string, Group> by_shape;
@@ -120,7 +121,7 @@ extern "C" int afx_verify_presentations_mixed_wire(afx_ctx* ctx, const uint8_t* 
     size_t got = 0;
     if (G.sections.size() == 1) {   // the section as it lies in the caller's blob; its statuses are contiguous in the stream
       const Section& S = G.sections[0];
-      const int rc = afx_verify_presentations_wire(ctx, blob + S.off, S.len, status + S.first, S.count, &got);
+      const int rc = verify_section(blob + S.off, S.len, status + S.first, S.count, &got);
       if (rc) return rc;
       continue;
     }
@@ -136,10 +137,24 @@ extern "C" int afx_verify_presentations_mixed_wire(afx_ctx* ctx, const uint8_t* 
     size_t w = S0.hdr;
     for (const Section& S : G.sections) { memcpy(merged.data() + w, blob + S.off + S.hdr, S.len - S.hdr); w += S.len - S.hdr; }
     st.assign(G.count, AFX_ST_VERIFICATION_FAILURE);
-    const int rc = afx_verify_presentations_wire(ctx, merged.data(), merged.size(), st.data(), st.size(), &got);
+    const int rc = verify_section(merged.data(), merged.size(), st.data(), st.size(), &got);
     if (rc) return rc;
     size_t r = 0;
     for (const Section& S : G.sections) { memcpy(status + S.first, st.data() + r, S.count); r += S.count; }
   }
   return AFX_OK;
+}
+extern "C" int afx_verify_presentations_mixed_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap,
+                                                   size_t* count_out) try {
+  if (!ctx) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  return mixed_wire(blob, len, status, status_cap, count_out, [&](const uint8_t* b, size_t l, uint8_t* st, size_t cap, size_t* n) {
+    return afx_verify_presentations_wire(ctx, b, l, st, cap, n);
+  });
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_group_verify_presentations_mixed_wire(afx_group* group, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap,
+                                                         size_t* count_out) try {
+  if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  return mixed_wire(blob, len, status, status_cap, count_out, [&](const uint8_t* b, size_t l, uint8_t* st, size_t cap, size_t* n) {
+    return afx_group_verify_presentations_wire(group, b, l, st, cap, n);
+  });
 } catch (...) { return afx::exception_rc(); }

@@ -816,36 +816,28 @@ extern "C" int afx_wire_parse(const uint8_t* blob, size_t len, afx_shape* shape_
   *records_offset_out = hdr;
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
-extern "C" int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
-  if (!ctx || !status || !count_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  afx_shape sh;
-  size_t count = 0, off = 0;
-  int rc = afx_wire_parse(blob, len, &sh, &count, &off);
-  if (rc) return rc;
-  *count_out = count;
-  if (count == 0) return AFX_OK;
-  if (status_cap < count) { set_error("status buffer too small"); return AFX_E_BAD_ARGS; }
-  if (count > 0xffffffffu / 64) { set_error("batch too large for one call"); return AFX_E_BAD_ARGS; }
+// records [first, first + n) of a parsed AFXP batch; status is the whole batch's array (element first + i answers record first + i)
+static int verify_wire_records(afx_ctx* ctx, const afx_shape& sh, const uint8_t* records, size_t count, size_t first, size_t n, uint8_t* status) {
+  if (n == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
   const uint32_t cells = afx_wire_cells_per_record(&sh);
   // SoA rows: challenge | responses | C_x_0 C_x_1 C_V | C_y[n] | attr_values[n] (secret rows stay unused) | enc proofs
-  const uint32_t n = sh.n_attributes;
-  const uint32_t row_resp = 1, row_cx = row_resp + sh.n_responses, row_cy = row_cx + 3, row_av = row_cy + n, row_enc = row_av + n;
+  const uint32_t na = sh.n_attributes;
+  const uint32_t row_resp = 1, row_cx = row_resp + sh.n_responses, row_cy = row_cx + 3, row_av = row_cy + na, row_enc = row_av + na;
   const uint32_t rows = row_enc + 14 * sh.n_enc_proofs;
   std::vector<uint32_t> row_of_cell;
   for (uint32_t r = 0; r < row_av; r++) row_of_cell.push_back(r);
-  for (uint32_t i = 0; i < n; i++)
+  for (uint32_t i = 0; i < na; i++)
     if (sh.kinds[i] == AFX_ENC_PUBLIC_SCALAR || sh.kinds[i] == AFX_ENC_PUBLIC_POINT) row_of_cell.push_back(row_av + i);
   for (uint32_t r = row_enc; r < rows; r++) row_of_cell.push_back(r);
   if (row_of_cell.size() != cells) { set_error("internal: wire cell map"); return AFX_E_BAD_ARGS; }
   // records are contiguous: a slice of the batch is a byte range of the blob; slices alternate between the two lanes like
   // those of the column-array calls (statements.hpp host_pipe), each transposed on the GPU into its own SoA scratch
-  return host_pipe(ctx, count, [&](Stager& st, size_t first, size_t sn) -> int {
-    const size_t o_rec = st.add(blob + off + first * cells * 32, sn * cells * 32), o_map = st.add((const uint8_t*)row_of_cell.data(), 4 * (size_t)cells),
+  return host_pipe(ctx, n, [&](Stager& st, size_t off, size_t sn) -> int {
+    const size_t f0 = first + off;
+    const size_t o_rec = st.add(records + f0 * cells * 32, sn * cells * 32), o_map = st.add((const uint8_t*)row_of_cell.data(), 4 * (size_t)cells),
                  o_soa = st.reserve(sn * rows * 32), o_st = st.add(nullptr, sn);
-    st.plan_fetch(status, o_st, 1, 1, count, first, sn);
+    st.plan_fetch(status, o_st, 1, 1, count, f0, sn);
     int rc2 = st.upload();
     if (rc2) return rc2;
     AFX_HIP(afxk_aos_to_soa(st.stream(), st.dev(o_rec), st.dev(o_soa), (const uint32_t*)st.dev(o_map), cells, (uint32_t)sn));
@@ -865,6 +857,32 @@ extern "C" int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, 
     if ((rc2 = afx_verify_presentations_dev(ctx, &sh, &d, sn, st.dev(o_st)))) return rc2;
     return st.fetch_all();
   });
+}
+extern "C" int afx_verify_presentations_wire_range(afx_ctx* ctx, const uint8_t* blob, size_t len, size_t first, size_t n, uint8_t* status, size_t status_cap,
+                                                   size_t* count_out) try {
+  std::unique_lock<std::recursive_mutex> lock__;
+  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  if (!ctx || !status || !count_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  afx_shape sh;
+  size_t count = 0, off = 0;
+  int rc = afx_wire_parse(blob, len, &sh, &count, &off);
+  if (rc) return rc;
+  *count_out = count;
+  if (first > count || n > count - first) { set_error("range outside the batch"); return AFX_E_BAD_ARGS; }
+  if (n == 0) return AFX_OK;
+  if (status_cap < count) { set_error("status buffer too small"); return AFX_E_BAD_ARGS; }
+  if (count > 0xffffffffu / 64) { set_error("batch too large for one call"); return AFX_E_BAD_ARGS; }
+  if (!ctx->has_key) { set_error("Issuer::verify needs the issuer key"); return AFX_E_NO_KEY; }
+  return verify_wire_records(ctx, sh, blob + off, count, first, n, status);
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out) try {
+  if (!count_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  size_t count = 0, hdr = 0;
+  afx_shape sh;
+  int rc = afx_wire_parse(blob, len, &sh, &count, &hdr);
+  if (rc) return rc;
+  *count_out = count;
+  return afx_verify_presentations_wire_range(ctx, blob, len, 0, count, status, status_cap, count_out);
 } catch (...) { return afx::exception_rc(); }
 
 // ---- CredentialIssuance batches ("AFXI" v1) -----------------------------------------------------

@@ -75,14 +75,32 @@ def pack_mixed(items):
 
 
 def verify_mixed_wire(ctx, blob):
-    """afx_verify_presentations_mixed_wire: statuses of a stream of AFXP sections, in stream order"""
+    """afx_verify_presentations_mixed_wire: statuses of a stream of AFXP sections, in stream order.  ctx may be a Group."""
     import ctypes as C
     from . import check, lib
     n = C.c_size_t(0)
     cap = max(1, len(blob) // 32)   # a record is at least one cell
     status = np.full(cap, 255, np.uint8)
-    check(lib().afx_verify_presentations_mixed_wire(ctx.h, blob, len(blob), status.ctypes.data, cap, C.byref(n)))
+    fn = lib().afx_group_verify_presentations_mixed_wire if hasattr(ctx, "member") else lib().afx_verify_presentations_mixed_wire
+    check(fn(ctx.h, blob, len(blob), status.ctypes.data, cap, C.byref(n)))
     return status[:n.value]
+
+
+def verify_wire(ctx, blob, first=None, n=None):
+    """Issuer::verify over one AFXP batch (afx_verify_presentations_wire); ctx may be a Group (its devices take byte ranges of the
+    blob); with first/n only those records are verified (afx_verify_presentations_wire_range; the other status bytes stay 255)."""
+    import ctypes as C
+    from . import check, lib
+    cnt = C.c_size_t(0)
+    cap = max(1, len(blob) // 32)
+    status = np.full(cap, 255, np.uint8)
+    if first is not None:
+        check(lib().afx_verify_presentations_wire_range(ctx.h, blob, len(blob), first, n, status.ctypes.data, cap, C.byref(cnt)))
+    elif hasattr(ctx, "member"):
+        check(lib().afx_group_verify_presentations_wire(ctx.h, blob, len(blob), status.ctypes.data, cap, C.byref(cnt)))
+    else:
+        check(lib().afx_verify_presentations_wire(ctx.h, blob, len(blob), status.ctypes.data, cap, C.byref(cnt)))
+    return status[:cnt.value]
 
 
 # ---- CredentialIssuance batches ("AFXI" v1) -------------------------------------------------------

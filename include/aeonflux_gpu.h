@@ -283,6 +283,11 @@ int afx_wire_parse(const uint8_t* blob, size_t len, afx_shape* shape_out, size_t
 /* Issuer::verify over a serialized batch: the records are copied to HBM, transposed to struct-of-arrays by a
  * kernel, and verified.  status must hold `count` bytes (status_cap >= count). */
 int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out);
+/* Records [first, first + n) of the blob's batch (status is the whole batch's array: element first + i answers record first + i), and the
+ * whole blob over a group's devices: the records are contiguous, so every member takes a byte range of the caller's blob. */
+int afx_verify_presentations_wire_range(afx_ctx* ctx, const uint8_t* blob, size_t len, size_t first, size_t n, uint8_t* status, size_t status_cap,
+                                        size_t* count_out);
+int afx_group_verify_presentations_wire(afx_group* group, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out);
 
 /* ---- presentations of DIFFERENT shapes in one call ------------------------------------------------------------------
  * Issuer::verify takes any presentation (src/issuer.rs:141-147): the shape - which attributes are hidden, how many proofs of
@@ -300,6 +305,8 @@ int afx_wire_section_bytes(const uint8_t* blob, size_t len, size_t* section_len_
  * A section whose shape the reference would panic on fails its own items only.  Records are copied once on the host when
  * a group spans several sections (bytes only; no arithmetic leaves the GPU). */
 int afx_verify_presentations_mixed_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out);
+/* ... every shape group split over a group's devices */
+int afx_group_verify_presentations_mixed_wire(afx_group* group, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out);
 
 /* The same over struct-of-arrays groups (host pointers).  `positions`, when not NULL, holds for each of the group's items its
  * index in the caller's order: status[positions[i]] answers item i of the group (every index < status_len, each used once

@@ -225,3 +225,49 @@ def test_fixed_key_schedule_gives_identical_results():
         assert np.array_equal(a[f], b[f]), f
     user.close()
     issuer.close()
+
+
+def test_group_wire_and_mixed_wire_equal_one_context():
+    """a serialized batch, and a stream of sections of mixed shapes, over a group's members (byte ranges of the caller's blob):
+    the statuses of one context, which are the oracle's; ranges of a blob on one context too"""
+    import aeonflux_amd as afx
+    from aeonflux_amd import wire
+    from tests.helpers import corrupt, make_batch
+    from tests.soa import presentation_arrays, shape_of
+    params, key, ip, issuer, pres = make_batch(4, "SSPE", [0, 3], 301, b"gpu-group-wire")
+    corrupt(pres, b"group-wire-corrupt")
+    want = [issuer.verify_presentation(p) for p in pres]
+    sh = afx.Shape.from_buffer_copy(bytes(shape_of(pres[0])))
+    blob = wire.pack_presentations(sh, presentation_arrays(pres))
+    one = afx.Context(params, key, ip)
+    grp = afx.Group(params, key, ip, _devices())
+    for m in range(2):
+        grp.member(m).set_chunk_items(256)   # several slices per member
+    assert wire.verify_wire(one, blob).tolist() == want
+    assert wire.verify_wire(grp, blob).tolist() == want
+    part = wire.verify_wire(one, blob, first=100, n=57)
+    assert part[100:157].tolist() == want[100:157] and (part[:100] == 255).all() and (part[157:] == 255).all()
+    # a second shape (the hidden scalar revealed) in between two runs of the first
+    params2, key2, ip2 = params, key, ip
+    from tests.helpers import make_credentials
+    d = make_credentials(4, "SSPE", 40, b"gpu-group-wire")   # same seed: same parameters and key
+    assert d["params"] == params and d["key"] == key
+    take, user = d["take"], d["user"]
+    others = []
+    for cr in d["creds"]:
+        kinds = list(cr["kinds"])
+        kinds[3] = 4
+        st, p = user.show(kinds, cr["values"], cr["t"], cr["U"], cr["V"], user.keypair_derive(take(64)), take(64), take(32), take(32))
+        assert st == 0
+        others.append(p)
+    others[7].C_V[1] ^= 2
+    want2 = [issuer.verify_presentation(p) for p in others]
+    sh2 = afx.Shape.from_buffer_copy(bytes(shape_of(others[0])))
+    assert bytes(sh2) != bytes(sh)
+    stream = wire.pack_presentations(sh, presentation_arrays(pres[:150])) + wire.pack_presentations(sh2, presentation_arrays(others)) + \
+        wire.pack_presentations(sh, presentation_arrays(pres[150:]))
+    expect = want[:150] + want2 + want[150:]
+    assert wire.verify_mixed_wire(one, stream).tolist() == expect
+    assert wire.verify_mixed_wire(grp, stream).tolist() == expect
+    grp.close()
+    one.close()

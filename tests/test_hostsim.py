@@ -75,13 +75,13 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     sh2 = afx.Shape.from_buffer_copy(bytes(shape))
     sh2.n_enc_proofs = 0
     pres2 = dict(pres, enc=[])
-    stream = wire.pack_presentations(shape, pres) + wire.pack_presentations(sh2, pres2) + wire.pack_presentations(shape, pres)
-    assert wire.verify_mixed_wire(ctx, stream).tolist() == [0x5a] * 9
-    assert afx.lib().afx_verify_presentations_mixed_wire(ctx.h, stream[:-32], len(stream) - 32, stt.ctypes.data, 3, C.byref(cnt)) == afx.E_BAD_ARGS
-    assert afx.lib().afx_verify_presentations_mixed_wire(ctx.h, stream, len(stream), stt.ctypes.data, 3, C.byref(cnt)) == afx.E_BAD_ARGS and cnt.value == 9
+    mixed_stream = wire.pack_presentations(shape, pres) + wire.pack_presentations(sh2, pres2) + wire.pack_presentations(shape, pres)
+    assert wire.verify_mixed_wire(ctx, mixed_stream).tolist() == [0x5a] * 9
+    assert afx.lib().afx_verify_presentations_mixed_wire(ctx.h, mixed_stream[:-32], len(mixed_stream) - 32, stt.ctypes.data, 3, C.byref(cnt)) == afx.E_BAD_ARGS
+    assert afx.lib().afx_verify_presentations_mixed_wire(ctx.h, mixed_stream, len(mixed_stream), stt.ctypes.data, 3, C.byref(cnt)) == afx.E_BAD_ARGS and cnt.value == 9
     sl = C.c_size_t(0)
-    assert afx.lib().afx_wire_section_bytes(stream, len(stream), C.byref(sl)) == 0 and sl.value == len(blob)
-    assert afx.lib().afx_wire_section_bytes(stream, len(blob) - 1, C.byref(sl)) == afx.E_BAD_ARGS
+    assert afx.lib().afx_wire_section_bytes(mixed_stream, len(mixed_stream), C.byref(sl)) == 0 and sl.value == len(blob)
+    assert afx.lib().afx_wire_section_bytes(mixed_stream, len(blob) - 1, C.byref(sl)) == afx.E_BAD_ARGS
     got = batch.verify_mixed(ctx, [(shape, pres), (sh2, pres2), (shape, pres)])
     assert [g.tolist() for g in got] == [[0x5a] * 3] * 3
     # mis-shaped requests take the fail-all path
@@ -153,6 +153,13 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     assert len(grp) == 2 and grp.member(1).n == n
     assert len(batch.verify_presentations(grp, shape, pres)) == 3
     assert [g.tolist() for g in batch.verify_mixed(grp, [(sh2, pres2), (shape, pres)])] == [[0x5a] * 3] * 2
+    assert wire.verify_wire(grp, blob).tolist() == [0x5a] * 3 and wire.verify_mixed_wire(grp, mixed_stream).tolist() == [0x5a] * 9
+    assert wire.verify_wire(ctx, blob, first=1, n=2).tolist() == [255, 0x5a, 0x5a]
+    try:
+        wire.verify_wire(ctx, blob, first=2, n=2)
+        raise SystemExit("a range outside the blob's batch was accepted")
+    except afx.AfxError as ex:
+        assert ex.rc == afx.E_BAD_ARGS
     o2, st2 = batch.issue(grp, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
     assert len(st2) == 3
     assert len(batch.verify_issuances(grp, kinds, values, iss)) == 3
