@@ -131,6 +131,8 @@ def lib():
         _LIB.afx_verify_presentations_wire_range.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         for name in ("afx_group_verify_presentations_wire", "afx_group_verify_presentations_mixed_wire"):
             getattr(_LIB, name).argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        _LIB.afx_wire_pack_presentations.argtypes = [C.POINTER(Shape), C.POINTER(PresentationSoA), C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        _LIB.afx_issuance_wire_pack.argtypes = [C.POINTER(AttributesSoA), C.POINTER(IssuanceSoA), C.c_uint32, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _LIB.afx_wire_section_bytes.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _LIB.afx_verify_presentations_mixed_wire.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         for name in ("afx_verify_presentations_mixed", "afx_group_verify_presentations_mixed"):

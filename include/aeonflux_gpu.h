@@ -280,6 +280,10 @@ size_t afx_wire_header_bytes(const afx_shape* shape);
 uint32_t afx_wire_cells_per_record(const afx_shape* shape);
 /* Parse the header (host).  Returns AFX_OK and fills shape/count/records offset, or AFX_E_BAD_ARGS. */
 int afx_wire_parse(const uint8_t* blob, size_t len, afx_shape* shape_out, size_t* count_out, size_t* records_offset_out);
+/* Write such a batch from the struct-of-arrays (HOST pointers) that afx_show returned: what a user sends to the issuer.  blob == NULL
+ * only reports the length needed in *len_out.  Bytes only. */
+int afx_wire_pack_presentations(const afx_shape* shape, const afx_presentation_soa* batch, size_t count, uint8_t* blob, size_t blob_cap,
+                                size_t* len_out);
 /* Issuer::verify over a serialized batch: the records are copied to HBM, transposed to struct-of-arrays by a
  * kernel, and verified.  status must hold `count` bytes (status_cap >= count). */
 int afx_verify_presentations_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out);
@@ -392,6 +396,10 @@ int afx_verify_issuances_range(afx_ctx* ctx, const afx_attributes_soa* attrs, co
                                uint32_t n_responses, size_t total, size_t first, size_t n, uint8_t* status);
 int afx_group_verify_issuances(afx_group* group, const afx_attributes_soa* attrs, const afx_issuance_soa* issuances,
                                uint32_t n_responses, size_t count, uint8_t* status);
+/* Write an AFXI batch (the wire format above) from what afx_issue returned (HOST pointers): what the issuer sends back to its users.  blob == NULL only
+ * reports the length needed. */
+int afx_issuance_wire_pack(const afx_attributes_soa* attrs, const afx_issuance_soa* issuances, uint32_t n_responses, size_t count, uint8_t* blob,
+                           size_t blob_cap, size_t* len_out);
 
 /* ---- AnonymousCredential::show (src/credential.rs:37-46 -> src/nizk/presentation.rs:139-321) - */
 

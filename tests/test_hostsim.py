@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "aeonflux_amd", "csrc")
 @pytest.fixture(scope="module")
 def hostsim_lib(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("hostsim") / "libafx_hostsim.so")
-    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp", "mixed.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp", "mixed.cpp", "wire.cpp")]
     srcs.append(os.path.join(ROOT, "tests", "hostsim", "fake_hip.cpp"))
     cmd = ["g++", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fPIC", "-std=c++17",
            "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-shared", "-pthread", "-o", out] + srcs
@@ -290,7 +290,7 @@ def test_group_calls_are_race_free_under_tsan(tmp_path):
     if not os.path.isabs(tsan) or not os.path.exists(tsan):
         pytest.skip("no libtsan")
     out = str(tmp_path / "libafx_tsan.so")
-    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp", "mixed.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp", "mixed.cpp", "wire.cpp")]
     srcs.append(os.path.join(ROOT, "tests", "hostsim", "fake_hip.cpp"))
     r = subprocess.run(["g++", "-g", "-O1", "-fsanitize=thread", "-fPIC", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-shared",
                         "-pthread", "-o", out] + srcs, capture_output=True, text=True)

@@ -49,6 +49,45 @@ def test_pack_unpack_roundtrip_and_c_parser():
         assert lib.afx_wire_parse(b, len(b), C.byref(shape), C.byref(count), C.byref(off)) == afx.E_BAD_ARGS
 
 
+def test_c_packers_write_what_the_python_packers_write():
+    """afx_wire_pack_presentations / afx_issuance_wire_pack (host code of the library: bytes only, no GPU) against the Python
+    packers of aeonflux_amd/wire.py, which the GPU tests feed to the verifier; size queries, short buffers and null arrays"""
+    import aeonflux_amd as afx
+    from aeonflux_amd import batch, wire
+    lib = afx.lib()
+    for count in (5, 1, 0):
+        sh, p = synthetic(count=max(count, 1))
+        p = {k: (v[..., :count, :] if k != "enc" else [{f: a[..., :count, :] for f, a in d.items()} for d in v]) for k, v in p.items()}
+        p = {k: (np.ascontiguousarray(v) if k != "enc" else [{f: np.ascontiguousarray(a) for f, a in d.items()} for d in v]) for k, v in p.items()}
+        want = wire.pack_presentations(sh, p)
+        soa, keep = batch.presentation_soa(p)
+        n = C.c_size_t(0)
+        assert lib.afx_wire_pack_presentations(C.byref(sh), C.byref(soa), count, None, 0, C.byref(n)) == 0 and n.value == len(want)
+        buf = np.full(len(want) + 8, 0xEE, np.uint8)
+        assert lib.afx_wire_pack_presentations(C.byref(sh), C.byref(soa), count, buf.ctypes.data, len(want), C.byref(n)) == 0
+        assert bytes(buf[:len(want)]) == want and (buf[len(want):] == 0xEE).all()
+        assert lib.afx_wire_pack_presentations(C.byref(sh), C.byref(soa), count, buf.ctypes.data, len(want) - 1, C.byref(n)) == afx.E_BAD_ARGS
+    null = afx.PresentationSoA()
+    assert lib.afx_wire_pack_presentations(C.byref(sh), C.byref(null), 3, buf.ctypes.data, buf.size, C.byref(n)) == afx.E_BAD_ARGS
+    rng = np.random.default_rng(9)
+    rb = lambda *s: rng.integers(0, 256, size=s, dtype=np.uint8)
+    kinds, cnt = [0, 2, 3, 0, 1], 7
+    values = rb(5, cnt, 32)
+    iss = {"t": rb(cnt, 32), "U": rb(cnt, 32), "V": rb(cnt, 32), "challenge": rb(cnt, 32), "responses": rb(10, cnt, 32)}
+    want = wire.pack_issuances(kinds, values, iss)
+    at = afx.AttributesSoA()
+    at.n_attributes = 5
+    for i, k in enumerate(kinds):
+        at.kinds[i] = k
+    at.values = values.ctypes.data
+    s = afx.IssuanceSoA(*(iss[k].ctypes.data for k in ("t", "U", "V", "challenge", "responses")))
+    assert lib.afx_issuance_wire_pack(C.byref(at), C.byref(s), 10, cnt, None, 0, C.byref(n)) == 0 and n.value == len(want)
+    buf = np.zeros(len(want), np.uint8)
+    assert lib.afx_issuance_wire_pack(C.byref(at), C.byref(s), 10, cnt, buf.ctypes.data, buf.size, C.byref(n)) == 0 and bytes(buf) == want
+    at.kinds[2] = 9
+    assert lib.afx_issuance_wire_pack(C.byref(at), C.byref(s), 10, cnt, buf.ctypes.data, buf.size, C.byref(n)) == afx.E_BAD_ARGS
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,layout,hide,count", [(4, "SSPE", [0, 3], 130), (8, "SSPPEEEE", [4, 5, 6, 7], 20), (2, "SP", [], 3)])
 def test_wire_verify_matches_oracle(n, layout, hide, count):
