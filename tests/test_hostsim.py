@@ -279,6 +279,15 @@ kp = {f: z(cnt, 32) for f in ("a", "a0", "a1", "pk")}
 k2 = [1, 0, 2, 2, 4, 4, 3, 3]
 pg, shg, stg = batch.show(grp, k2, z(8, cnt, 32), o["t"], o["U"], o["V"], kp, z(cnt, 64), z(cnt, 32), z(2, cnt, 32), z(8, cnt, 32), z(8, cnt, 32))
 assert len(stg) == cnt and shg.n_enc_proofs == 2
+# serialized batches and a stream of mixed shapes over the members' threads
+from aeonflux_amd import wire
+blob = wire.pack_presentations(shape, pres)
+assert (wire.verify_wire(grp, blob) == 0x5a).all()
+sh2 = afx.Shape.from_buffer_copy(bytes(shape))
+sh2.n_enc_proofs = 0
+half = {f: np.ascontiguousarray(pres[f][..., :700, :]) for f in batch.PRES_FIELDS}
+assert (wire.verify_mixed_wire(grp, wire.pack_presentations(sh2, dict(half, enc=[])) + blob + wire.pack_presentations(sh2, dict(half, enc=[]))) == 0x5a).all()
+assert all((g == 0x5a).all() for g in batch.verify_mixed(grp, [(shape, pres), (sh2, dict(half, enc=[]))]))
 grp.close()
 print("tsan drive ok")
 """
