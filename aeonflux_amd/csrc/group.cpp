@@ -4,6 +4,7 @@
 // per member, and every member writes its part of the caller's arrays: no data moves between devices and there is no
 // collective.  This is what one `&self` method of the reference (Issuer::verify, /root/reference/src/issuer.rs:141-147;
 // Issuer::issue, :111-124) becomes when the issuer owns a node of GPUs.
+#include <atomic>
 #include <memory>
 #include <string>
 #include <system_error>
@@ -13,6 +14,7 @@
 
 struct afx_group {
   std::vector<afx_ctx*> members;
+  std::atomic<uint32_t> next_small{ 0 };   // small calls go to one member each, in turn (run_members)
   ~afx_group() { for (afx_ctx* m : members) afx_ctx_destroy(m); }   // wipes every member's copy of the key
 };
 
@@ -52,6 +54,15 @@ extern "C" void afx_shard_bounds(size_t count, uint32_t members, uint32_t index,
 template <class F>
 static int run_members(afx_group* g, size_t count, F&& call) {
   const uint32_t m = (uint32_t)g->members.size();
+  // A call small enough for the latency plan gains nothing from being cut into even smaller pieces (its duration is that of one
+  // chain either way) and would pay a host thread per member: it goes to ONE member, the next in turn, so that small calls
+  // arriving from several host threads spread over the group's devices.
+  if (m > 1 && count != 0 && count <= g->members[0]->small_batch_items) {
+    const uint32_t i = g->next_small.fetch_add(1, std::memory_order_relaxed) % m;
+    const int rc = call(g->members[i], (size_t)0, count);
+    if (rc) { const std::string why = afx_last_error(); set_error("member " + std::to_string(i) + ": " + why); }
+    return rc;
+  }
   std::vector<int> rcs(m, AFX_OK);
   std::vector<std::string> errs(m);
   std::vector<std::thread> threads;

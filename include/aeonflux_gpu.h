@@ -253,7 +253,9 @@ int afx_verify_presentations_range(afx_ctx* ctx, const afx_shape* shape, const a
  * copy of parameters, key and tables.  A group call splits [0, count) into contiguous ranges (afx_shard_bounds), one host
  * thread per member runs afx_*_range on its range, and every member writes its part of the caller's arrays.  No data moves
  * between devices; there is no collective.  Host pointers only.  Settings (strict mode, pass size ...) are per member:
- * afx_group_member(). */
+ * afx_group_member().  A call of at most afx_ctx_set_small_batch_items items (member 0's setting) is not cut up - its duration
+ * is one chain's either way - but handed whole to ONE member, the next in turn: small calls from several host threads then
+ * spread over the devices. */
 typedef struct afx_group afx_group;
 int afx_group_create(afx_group** out, const int* devices, uint32_t n_devices, const uint8_t* sysparams, size_t sysparams_len,
                      const uint8_t* amacs_key, size_t amacs_key_len, const uint8_t issuer_params[64]);

@@ -45,6 +45,7 @@ def test_group_ranges_and_slices_equal_one_context_and_the_oracle():
     assert np.array_equal(_oracle_statuses(params, key, ip, shape, pres, count), one)
     # the group: every member its contiguous part, status concatenated in place
     grp = afx.Group(params, key, ip, _devices())
+    grp.member(0).set_small_batch_items(0)   # these batches are small: without this the group hands each call to ONE member (tested below)
     assert len(grp) == 2
     assert np.array_equal(batch.verify_presentations(grp, shape, pres), one)
     # explicit ranges through a second context: three parts, written into one status array
@@ -94,6 +95,7 @@ def test_group_issue_equals_one_context_and_the_oracle():
     o1, s1 = batch.issue(issuer, kinds, values, tw, uw, seed)
     assert s1[7] == afx.ST_MAC_CREATION and s1.sum() == afx.ST_MAC_CREATION
     grp = afx.Group(params, key, ip, _devices())
+    grp.member(0).set_small_batch_items(0)   # these batches are small: without this the group hands each call to ONE member (tested below)
     grp.member(1).set_chunk_items(256)
     o2, s2 = batch.issue(grp, kinds, values, tw, uw, seed)
     assert np.array_equal(s1, s2)
@@ -150,6 +152,7 @@ def test_group_show_and_verify_issuances_equal_one_context():
     bad["V"][17] = bad["V"][18]
     # user-side group (no issuer key)
     grp = afx.Group(params, None, ip, _devices())
+    grp.member(0).set_small_batch_items(0)   # see above
     grp.member(1).set_chunk_items(256)
     s1 = batch.verify_issuances(user, kinds, values, bad)
     assert s1.sum() == 2 * afx.ST_VERIFICATION_FAILURE and s1[17] and s1[1100]
@@ -241,6 +244,7 @@ def test_group_wire_and_mixed_wire_equal_one_context():
     blob = wire.pack_presentations(sh, presentation_arrays(pres))
     one = afx.Context(params, key, ip)
     grp = afx.Group(params, key, ip, _devices())
+    grp.member(0).set_small_batch_items(0)   # these batches are small: without this the group hands each call to ONE member (tested below)
     for m in range(2):
         grp.member(m).set_chunk_items(256)   # several slices per member
     assert wire.verify_wire(one, blob).tolist() == want
@@ -271,3 +275,30 @@ def test_group_wire_and_mixed_wire_equal_one_context():
     assert wire.verify_mixed_wire(grp, stream).tolist() == expect
     grp.close()
     one.close()
+
+
+def test_small_group_calls_go_to_one_member_in_turn():
+    """a call small enough for the latency plan is not cut up: it goes to one member, the next in turn (so that small calls
+    from several threads spread over the devices); same statuses either way"""
+    import aeonflux_amd as afx
+    from aeonflux_amd import batch
+    from tests.helpers import corrupt, make_batch
+    from tests.soa import presentation_arrays, shape_of
+    params, key, ip, issuer, pres = make_batch(4, "SSPE", [0, 3], 50, b"gpu-group-small")
+    corrupt(pres, b"group-small-corrupt")
+    want = [issuer.verify_presentation(p) for p in pres]
+    a = presentation_arrays(pres)
+    sh = afx.Shape.from_buffer_copy(bytes(shape_of(pres[0])))
+    grp = afx.Group(params, key, ip, _devices())
+    m0, m1 = grp.member(0), grp.member(1)
+    for m in (m0, m1):
+        m.set_timing(True)
+    for _ in range(4):
+        assert batch.verify_presentations(grp, sh, a).tolist() == want
+    launches = [m.get_timing("k_finish")[1] for m in (m0, m1)]
+    assert launches == [2, 2], launches        # four calls, two on each member
+    m0.set_small_batch_items(0)                # the shortcut off: both members take a part of every call
+    for _ in range(2):
+        assert batch.verify_presentations(grp, sh, a).tolist() == want
+    assert [m.get_timing("k_finish")[1] for m in (m0, m1)] == [4, 4]
+    grp.close()

@@ -150,6 +150,8 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32), first=2, n=1)
     os.environ["AFX_FAKE_HIP_DEVICES"] = "2"
     grp = afx.Group(d["params"], d["key"], d["ip"], [0, 1])
+    assert len(batch.verify_presentations(grp, shape, pres)) == 3   # a small call: one member takes it whole
+    grp.member(0).set_small_batch_items(0)                            # ... and from here on every call is split over the members
     assert len(grp) == 2 and grp.member(1).n == n
     assert len(batch.verify_presentations(grp, shape, pres)) == 3
     assert [g.tolist() for g in batch.verify_mixed(grp, [(sh2, pres2), (shape, pres)])] == [[0x5a] * 3] * 2
@@ -257,6 +259,7 @@ import bench
 os.environ["AFX_FAKE_HIP_DEVICES"] = "3"
 params, key, ip = bench.load_fixture("c3_8attrs_SSPPeeee")
 grp = afx.Group(params, key, ip, [0, 1, 2])
+grp.member(0).set_small_batch_items(0)   # 1500-item calls: split over the members' threads (what this run is about)
 shape = afx.Shape()
 shape.n_attributes, shape.n_responses, shape.n_hidden_scalars, shape.n_enc_proofs = 8, 3, 0, 4
 for i, k in enumerate((0, 0, 2, 2, 3, 3, 3, 3)):
