@@ -3,6 +3,7 @@
 #include <string.h>
 #include <algorithm>
 #include <map>
+#include <tuple>
 #include <new>
 #include <system_error>
 #include <stdexcept>
@@ -399,9 +400,11 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
   // kilo-cycles of VALU issue per wave (profiles/r01_fe_rates_ubench.txt): 63 windows of 4 doublings + the final
   // encoding; 64 additions + the 9-entry table per variable base; AFX_POS_WINDOWS additions per fixed base
   auto cost = [](const afx_msm_job& j) {
-    uint32_t c = (j.n_var ? 1320u : 160u) + j.n_uni * (330u + 45u /* more conversions to p3 */) + (j.n_var - j.n_uni) * 470u;
+    // a narrow job (a secret scalar on a variable base): AFX_SECVAR_WINDOWS additions per variable term, tables of AFX_SECVAR_STORED
+    const uint32_t per_var = j.narrow ? (AFX_SECVAR_WINDOWS * 13u) / 2u + AFX_SECVAR_STORED * 7u : 470u;
+    uint32_t c = (j.n_var ? 1320u : 160u) + j.n_uni * (330u + 45u /* more conversions to p3 */) + (j.n_var - j.n_uni) * per_var;
     for (uint32_t t = j.n_var; t < j.n_terms; t++) c += ((j.term[t].secret ? AFX_SEC_WINDOWS * 200u : AFX_POS_WINDOWS * 175u)) / 32u;
-    for (uint32_t t = 0; t < j.n_var; t++) c += j.term[t].secret ? 120u : 0u;   // the table scans
+    for (uint32_t t = 0; t < j.n_var; t++) c += j.term[t].secret ? (AFX_SECVAR_WINDOWS * AFX_SECVAR_STORED * 15u) / 64u : 0u;   // the table scans
     return c;
   };
   const size_t n = jobs.size();
@@ -449,8 +452,13 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     j.top_bit = top;
   }
   for (size_t ji = 0; ji < jobs.size(); ji++) {
+    // a secret scalar on a variable base: the job's chain runs AFX_SECVAR_BITS-bit windows (kernels.hip msm_add_var)
+    jobs[ji].narrow = 0;
+    for (uint32_t t = 0; t < jobs[ji].n_var; t++) if (jobs[ji].term[t].secret) jobs[ji].narrow = 1;
+    if (jobs[ji].narrow && jobs[ji].n_uni) throw std::logic_error("a NAF schedule in a job with secret scalars");
     const afx_msm_job& j = jobs[ji];
     const uint64_t nv = j.n_var;
+    const uint64_t wins = j.narrow ? AFX_SECVAR_WINDOWS : 64, wbits = j.narrow ? AFX_SECVAR_BITS : 4, stored = j.narrow ? AFX_SECVAR_STORED : AFX_TABLE_STORED;
     uint64_t nfa = 0;   // additions of the fixed-base terms: AFX_POS_WINDOWS each, AFX_SEC_WINDOWS for a secret scalar
     for (uint32_t t = j.n_var; t < j.n_terms; t++) nfa += j.term[t].secret ? AFX_SEC_WINDOWS : AFX_POS_WINDOWS;
     stats.msm_jobs++;
@@ -477,18 +485,18 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
       stats.field_sq += S;
       continue;
     }
-    stats.doublings += nv ? 252 : 0;
-    stats.var_additions += 64 * nv;
+    stats.doublings += nv ? (wins - 1) * wbits : 0;
+    stats.var_additions += wins * nv;
     stats.fixed_additions += nfa;
-    stats.table_additions += (AFX_TABLE_ENTRIES - 2) * nv;
+    stats.table_additions += (stored - 1) * nv;
     stats.encodings += j.out_enc ? 1 : 0;
     stats.var_additions += j.addend ? 1 : 0;
     // field operations, following k_msm's schedule statement by statement
     uint64_t M = 0, S = 0;
     if (nv) {
-      M += nv * (1 + (AFX_TABLE_ENTRIES - 2) * 9);            // tables: 2dT of P, then (add 4M + to p3 4M + 2dT 1M) per entry
-      for (int w = 63; w >= 0; w--) {
-        if (w != 63) { S += 16; M += 3 * 3 + 4; }             // three doublings to p2, the fourth to p3
+      M += nv * (1 + (stored - 1) * 9);                       // tables: 2dT of P, then (add 4M + to p3 4M + 2dT 1M) per entry
+      for (int w = (int)wins - 1; w >= 0; w--) {
+        if (w != (int)wins - 1) { S += 4 * wbits; M += 3 * (wbits - 1) + 4; }   // the window's doublings to p2, its last to p3
         M += nv * 4;                                          // additions of window-table entries
         M += nv * 4 - (w != 0 ? 1 : 0);                       // back to p3; the window's last one skips T
       }
@@ -528,7 +536,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
   std::vector<char> done(n, 0);
   const uint32_t blocks_per_row = (count + AFX_BLOCK - 1) / AFX_BLOCK, resident = 2 * ctx->n_cu;
   uint32_t dslot = 0, tslot = 0;
-  std::map<std::pair<const int32_t*, bool>, uint32_t> table_of;   // (base, odd multiples?) -> table slot
+  std::map<std::tuple<const int32_t*, bool, bool>, uint32_t> table_of;   // (base, odd multiples?, the short table of a narrow job?) -> table slot
   size_t left = n;
   static const int class_order[3] = { 2, 1, 0 };
   static const LaunchKind class_launch[3] = { L_MSM_FIXED, L_MSM_WINDOW, L_MSM_NAF };
@@ -551,18 +559,18 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
       j.digit_slot = dslot; dslot += j.n_terms;
       // one window table per (base, kind of multiples) of this launch list: constraints that share a base share its table
       // (a proof of encryption uses C_y_2 and C_y_2' in two constraints each, encryption.rs:197,204)
-      j.table_slot = 0;
       for (uint32_t t = 0; t < j.n_var; t++) {
         const bool odd = t < j.n_uni;
-        const std::pair<const int32_t*, bool> tk(j.term[t].var, odd);
+        const uint32_t nstored = j.narrow ? AFX_SECVAR_STORED : AFX_TABLE_STORED;
+        const std::tuple<const int32_t*, bool, bool> tk(j.term[t].var, odd, j.narrow != 0);
         auto hit = table_of.find(tk);
         if (hit == table_of.end()) {
           hit = table_of.emplace(tk, tslot++).first;
-          afx_table_job tj = { j.term[t].var, hit->second, 0 };
+          afx_table_job tj = { j.term[t].var, hit->second, (uint16_t)nstored, (uint16_t)(j.narrow ? 1 : 0) };
           (odd ? odd_rows : plain_rows).push_back(tj);
         } else {
-          stats.table_additions -= odd ? 7 : (AFX_TABLE_ENTRIES - 2);   // counted per term above; this one is shared
-          stats.field_mul -= odd ? (4 + 1 + 1 + 7 * 9) : (1 + (AFX_TABLE_ENTRIES - 2) * 9);
+          stats.table_additions -= odd ? 7 : (nstored - 1);   // counted per term above; this one is shared
+          stats.field_mul -= odd ? (4 + 1 + 1 + 7 * 9) : (1 + (nstored - 1) * 9);
           stats.field_sq -= odd ? 4 : 0;
         }
         j.term[t].table_slot = hit->second;

@@ -113,8 +113,10 @@ AFX_DEV fe fe_carry(const fe& f) {
 // having no outputs, triggers none of the hazard no-ops the compiler puts after inline-asm definitions.
 #if defined(__HIPCC__)
 #define AFX_PIN(x) asm volatile("" ::"v"(x))
+#define AFX_PIN_UNIFORM(x) asm volatile("" ::"s"(x))   // the same for a wave-uniform value (a scalar register)
 #else
 #define AFX_PIN(x) ((void)0)   // host build of this header (tests/hostsim/arith_host.cpp)
+#define AFX_PIN_UNIFORM(x) ((void)0)
 #endif
 // operation counters for the host build (the per-item counts DESIGN.md publishes are measured with them)
 // AFX_CHECK_BOUNDS (host build only): every multiplication / squaring checks what its code relies on - the int32

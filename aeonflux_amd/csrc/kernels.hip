@@ -287,40 +287,79 @@ struct msm_env {
   const int32_t* table_ws;
   const uint32_t* digit_ws;
   uint32_t count, item, dslot, tslot;
+  bool narrow;   // SEC instances: the job's variable terms run AFX_SECVAR_BITS-bit windows (afx_msm_job.narrow; wave-uniform)
 };
 // acc += (4-bit signed digit of window w) * (variable base t), from the lane's own window table
 // `next` (wave-uniform): what consumes the result, GE_FOR_* (ge.cuh)
-// SEC (the launch has secret terms, afx_msm_term.secret): such a term reads ALL eight stored entries of its table, in order, and
-// keeps the digit's with selects (the identity for digit 0), so that no address depends on the digit - what dalek's constant-time
-// LookupTable::select does on the CPU (/root/reference/src/amacs.rs:267-270 multiplies by the key with it).  The branch on
-// `secret` is wave-uniform: it is a property of the term, not of the data.
 template <bool SEC>
 AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w, int next) {
+  const int32_t* table = e.table_ws + ((size_t)e.job->term[t].table_slot * e.count + e.item) * AFX_VAR_TABLE_DWORDS;
   const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + ((uint32_t)w >> 3)) * e.count + e.item];
   const int d = (int)((word >> (((uint32_t)w & 7) * 4)) & 15u) - 8;
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
   const bool neg = (d < 0) != (e.job->term[t].negate != 0);
-  const int32_t* table = e.table_ws + ((size_t)e.job->term[t].table_slot * e.count + e.item) * AFX_VAR_TABLE_DWORDS;
-  if constexpr (SEC) {
-    if (e.job->term[t].secret) {
-      uint32_t sel[32];
-#pragma unroll
-      for (int i = 0; i < 32; i++) sel[i] = (uint32_t)AFX_IDENTITY_ENTRY[i];
-#pragma unroll 1
-      for (uint32_t k = 0; k < AFX_TABLE_STORED; k++) {
-        uint32_t ent[32];
-        cached_load_words(ent, table + k * AFX_TABLE_ENTRY_DWORDS, 4);
-        const bool hit = idx == k + 1;
-#pragma unroll
-        for (int i = 0; i < 32; i++) sel[i] = hit ? ent[i] : sel[i];
-      }
-      return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_from_words(sel), neg), next);
-    }
-  }
   // multiples 1..8 are stored (at 0..7); digit 0 reads the one identity entry every lane shares (an address select, no table bytes)
   const uint32_t stored = idx ? idx - 1 : 0;
   const int32_t* ent = idx ? table + stored * AFX_TABLE_ENTRY_DWORDS : AFX_IDENTITY_ENTRY;
   return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent, 4), neg), next);
+}
+// A job with a secret scalar on a variable base (afx_msm_job.narrow, SEC instances): AFX_SECVAR_BITS-bit signed digits (msm_recode)
+// over tables of AFX_SECVAR_STORED multiples at the head of the slot.  Every addition of such a job reads ALL the stored entries
+// of its table, in order (narrow_fetch: no address depends on a digit), and keeps the digit's with selects, the identity for
+// digit 0 (narrow_add) - what dalek's constant-time LookupTable::select does on the CPU (/root/reference/src/amacs.rs:267-270
+// multiplies by the key with it).  The chain is software-pipelined: the words of the NEXT addition's table are requested before
+// the current addition computes (msm_chain_narrow), so the reads overlap the arithmetic instead of preceding it.
+AFX_DEV void narrow_fetch(uint32_t (&buf)[AFX_SECVAR_STORED * 32], uint64_t& digits, const msm_env& e, uint32_t t, int w) {
+  // the digit's word(s) first: the loads come back in order, and the addition that consumes this fetch starts from the digit
+  const uint32_t o = AFX_SECVAR_BITS * (uint32_t)w, k = o >> 5, sh = o & 31u;
+  const uint32_t* dw = e.digit_ws + ((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + k) * e.count + e.item;
+  digits = dw[0];
+  if (sh + AFX_SECVAR_BITS > 32) digits |= (uint64_t)dw[e.count] << 32;   // uniform condition; k + 1 <= 8
+  // [entry][piece][item]: the 64 lanes of a wave read 1 KB contiguous per load
+  const int32_t* table = e.table_ws + (size_t)e.job->term[t].table_slot * e.count * AFX_VAR_TABLE_DWORDS + (size_t)e.item * 4;
+#pragma unroll
+  for (uint32_t m = 0; m < AFX_SECVAR_STORED; m++) cached_load_words(buf + 32 * m, table + (size_t)m * e.count * AFX_TABLE_ENTRY_DWORDS, (size_t)e.count * 4);
+}
+AFX_DEV ge_p3 narrow_add(const msm_env& e, const ge_p3& acc, uint32_t t, int w, const uint32_t (&buf)[AFX_SECVAR_STORED * 32], uint64_t digits, int next) {
+  const uint32_t sh = (AFX_SECVAR_BITS * (uint32_t)w) & 31u;
+  const int d = (int)((uint32_t)(digits >> sh) & ((1u << AFX_SECVAR_BITS) - 1)) - (1 << (AFX_SECVAR_BITS - 1));
+  const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
+  const bool neg = (d < 0) != (e.job->term[t].negate != 0);
+  uint32_t sel[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) sel[i] = (uint32_t)AFX_IDENTITY_ENTRY[i];
+#pragma unroll
+  for (uint32_t m = 0; m < AFX_SECVAR_STORED; m++) {
+    const bool hit = idx == m + 1;
+#pragma unroll
+    for (int i = 0; i < 32; i++) sel[i] = hit ? buf[32 * m + i] : sel[i];
+  }
+  return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_from_words(sel), neg), next);
+}
+AFX_DEV ge_p3 msm_chain_narrow(const msm_env& e, ge_p3 acc, uint32_t nv) {
+  uint32_t nxt[AFX_SECVAR_STORED * 32];
+  uint64_t nxt_digits;
+  narrow_fetch(nxt, nxt_digits, e, 0, AFX_SECVAR_WINDOWS - 1);
+#pragma unroll 1
+  for (int w = AFX_SECVAR_WINDOWS - 1; w >= 0; w--) {
+    if (w != AFX_SECVAR_WINDOWS - 1) {
+      ge_p2 a2 = ge_p3_to_p2(acc);
+#pragma unroll 1
+      for (int k = 0; k < AFX_SECVAR_BITS - 1; k++) a2 = ge_p1p1_to_p2_before_dbl(ge_p2_dbl(a2));
+      acc = ge_p1p1_to_p3_for<GE_FOR_ADD>(ge_p2_dbl(a2));
+    }
+#pragma unroll 1
+    for (uint32_t t = 0; t < nv; t++) {
+      uint32_t cur[AFX_SECVAR_STORED * 32];
+#pragma unroll
+      for (uint32_t i = 0; i < AFX_SECVAR_STORED * 32; i++) cur[i] = nxt[i];
+      const uint64_t cur_digits = nxt_digits;
+      const bool last = t + 1 == nv;
+      if (!(last && w == 0)) narrow_fetch(nxt, nxt_digits, e, last ? 0 : t + 1, last ? w - 1 : w);
+      acc = narrow_add(e, acc, t, w, cur, cur_digits, !last ? GE_FOR_ADD : (w == 0 ? GE_FOR_ANY : GE_FOR_DBL));
+    }
+  }
+  return acc;
 }
 // acc += (AFX_POS_BITS-bit signed digit j) * 2^(AFX_POS_BITS*j) * (generator of term t), from the positional tables
 AFX_DEV ge_p3 msm_add_positional(const msm_env& e, const int32_t* __restrict__ pos_tables, const ge_p3& acc, uint32_t t, uint32_t j, int next) {
@@ -354,12 +393,23 @@ AFX_DEV ge_p3 msm_add_positional_secret(const msm_env& e, const int32_t* __restr
   int32_t v[27];
 #pragma unroll
   for (int l = 0; l < 27; l++) v[l] = win[l];   // entry 0: the identity in niels form
-#pragma unroll 1
-  for (uint32_t k = 1; k < AFX_SEC_ENTRIES; k++) {
-    const int32_t* ent = win + k * AFX_NIELS_DWORDS;
-    const bool hit = idx == k;
+  // Every entry is READ before its select: pinned in scalar registers, so that the compiler cannot turn "hit ? ent[l] : v[l]" into
+  // a branch around the load (it did - a load skipped when no lane of the wave holds that digit is an access pattern that depends
+  // on the digits, and 27 dependent one-dword round trips per entry besides).  Unrolled: the next entry's loads are in flight
+  // while this one's selects run.
 #pragma unroll
-    for (int l = 0; l < 27; l++) v[l] = hit ? ent[l] : v[l];
+  for (uint32_t k = 1; k < AFX_SEC_ENTRIES; k++) {
+    int32_t ent[27];
+#pragma unroll
+    for (int l = 0; l < 27; l++) ent[l] = win[k * AFX_NIELS_DWORDS + l];
+#pragma unroll
+    for (int l = 0; l < 27; l++) AFX_PIN_UNIFORM(ent[l]);
+    // a lane mask and a bitfield insert: one instruction per dword with the entry read straight from its scalar register
+    // (a select would first copy it into a vector register: the condition already takes the instruction's one scalar operand)
+    uint32_t m = idx == k ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(m));   // opaque: otherwise the mask arithmetic is folded back into selects
+#pragma unroll
+    for (int l = 0; l < 27; l++) v[l] = (int32_t)(((uint32_t)ent[l] & m) | ((uint32_t)v[l] & ~m));
   }
   ge_niels q;
 #pragma unroll
@@ -378,7 +428,7 @@ AFX_DEV ge_p3 msm_add_positional_secret(const msm_env& e, const int32_t* __restr
 enum { MSM_FIXED = 0, MSM_WINDOW = 1, MSM_NAF = 2 };
 
 // recode the per-item scalars of terms [from, nt), stored [slot][AFX_DIGIT_WORDS][count]
-AFX_DEV void msm_recode(const afx_msm_job* job, uint32_t* __restrict__ digit_ws, uint32_t count, uint32_t item, uint32_t from, uint32_t nv, uint32_t nt) {
+AFX_DEV void msm_recode(const afx_msm_job* job, uint32_t* __restrict__ digit_ws, uint32_t count, uint32_t item, uint32_t from, uint32_t nv, uint32_t nt, bool narrow) {
   const uint32_t dslot = job->digit_slot;
 #pragma unroll 1
   for (uint32_t t = from; t < nt; t++) {
@@ -390,7 +440,8 @@ AFX_DEV void msm_recode(const afx_msm_job* job, uint32_t* __restrict__ digit_ws,
     if (twice && !halve) s = sc_dbl(s);
     uint32_t b[9];
     b[8] = 0;
-    if (t < nv || job->term[t].secret) sc_bias(b, s, 0x88888888u);   // signed 4-bit digits: variable bases, and secret scalars on fixed bases
+    if (t < nv && narrow) sc_bias_wide<AFX_SECVAR_BITS, AFX_SECVAR_WINDOWS>(b, s);   // variable bases of a job with a secret on one
+    else if (t < nv || job->term[t].secret) sc_bias(b, s, 0x88888888u);   // signed 4-bit digits: variable bases, and secret scalars on fixed bases
     else sc_bias_wide<AFX_POS_BITS, AFX_POS_WINDOWS>(b, s);
 #pragma unroll
     for (int i = 0; i < AFX_DIGIT_WORDS; i++) digit_ws[((size_t)(dslot + t) * AFX_DIGIT_WORDS + i) * count + item] = b[i];
@@ -402,7 +453,7 @@ AFX_DEV void msm_recode(const afx_msm_job* job, uint32_t* __restrict__ digit_ws,
 // entries are contiguous, its digit picks one), NAF tables entry-major ([entry][item]: every lane of a wave reads the SAME
 // entry; they are stored piece-major inside an entry, see cached_store).  `stride` = dwords between consecutive entries.
 template <bool ODD>
-AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t chunk, const ge_p3& P) {
+AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t chunk, const ge_p3& P, uint32_t stored) {
   ge_p3 Q = P;
   if (ODD) {
     const ge_cached c2 = ge_p3_to_cached(ge_double(P));
@@ -416,7 +467,7 @@ AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t ch
     const ge_cached cP = ge_p3_to_cached(P);   // P centred: Y+X, Y-X, 2Z within 1 unit, what ge_add_cached expects
     cached_store(tab, chunk, cP);   // k*P at entry k - 1; the identity (digit 0) is not stored
 #pragma unroll 1
-    for (int k = 2; k < AFX_TABLE_ENTRIES; k++) {
+    for (uint32_t k = 2; k <= stored; k++) {
       Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
       cached_store(tab + (k - 1) * stride, chunk, ge_p3_to_cached(Q));
     }
@@ -476,9 +527,10 @@ k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table
   const afx_table_job row = rows[blockIdx.y];
   int32_t* slot = table_ws + (size_t)row.table_slot * count * AFX_VAR_TABLE_DWORDS;
   const ge_p3 P = var_load(row.var, count, item);
-  // NAF tables: [entry][piece][item][16 B]; window tables: [item][entry][128 B]
-  if (ODD) msm_build_table<true>(slot + (size_t)item * 4, (size_t)count * AFX_TABLE_ENTRY_DWORDS, (size_t)count * 4, P);
-  else msm_build_table<false>(slot + (size_t)item * AFX_VAR_TABLE_DWORDS, AFX_TABLE_ENTRY_DWORDS, 4, P);
+  // NAF tables and the tables of narrow jobs: [entry][piece][item][16 B]; window tables: [item][entry][128 B]
+  if (ODD) msm_build_table<true>(slot + (size_t)item * 4, (size_t)count * AFX_TABLE_ENTRY_DWORDS, (size_t)count * 4, P, AFX_TABLE_STORED);
+  else if (row.entry_major) msm_build_table<false>(slot + (size_t)item * 4, (size_t)count * AFX_TABLE_ENTRY_DWORDS, (size_t)count * 4, P, row.stored);
+  else msm_build_table<false>(slot + (size_t)item * AFX_VAR_TABLE_DWORDS, AFX_TABLE_ENTRY_DWORDS, 4, P, row.stored);
 }
 
 // ENC: the launch has jobs that encode their result in this kernel (those with an addend or an extended-coordinate output as
@@ -489,7 +541,7 @@ k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table
 // SEC: the launch has terms with secret scalars under afx_ctx_set_secret_independent_addressing (the prover paths, the key's
 // terms of Issuer::verify): an instance of its own, so that the table scans cost the ordinary launches no registers.
 template <int KIND, bool ENC, bool SEC>
-__global__ void __launch_bounds__(AFX_BLOCK, (!ENC && !SEC) ? 3 : 2)
+__global__ void __launch_bounds__(AFX_BLOCK, (!ENC && (!SEC || KIND == MSM_FIXED)) ? 3 : 2)
 k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables, int32_t* __restrict__ table_ws,
       uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count, unsigned long long* __restrict__ clock_probe) {
   // Clock probe (measurement aid): one lane of the launch's first block reads the shader-clock counter (s_memtime) and the
@@ -505,7 +557,8 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
   msm_env env;
   env.job = job; env.table_ws = table_ws; env.digit_ws = digit_ws;
   env.count = count; env.item = item; env.dslot = job->digit_slot; env.tslot = 0;
-  msm_recode(job, digit_ws, count, item, nu, nv, nt);   // batch-constant NAF terms need no digits
+  env.narrow = SEC && KIND == MSM_WINDOW && job->narrow != 0;
+  msm_recode(job, digit_ws, count, item, nu, nv, nt, env.narrow);   // batch-constant NAF terms need no digits
   ge_p3 acc = ge_identity();
   if constexpr (KIND == MSM_FIXED) {
     acc = msm_fixed_terms<SEC>(env, pos_tables, sec_tables, acc, 0, nt);
@@ -541,8 +594,12 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
     } else {
       // (nv == 0: a job of fixed bases only that a small pass put into this launch, so that it runs beside the chains instead
       // of in a launch of its own before them - engine.cpp msm_list)
+      bool chained = false;
+      if constexpr (SEC) {
+        if (env.narrow) { acc = msm_chain_narrow(env, acc, nv); chained = true; }   // wave-uniform: a property of the job
+      }
 #pragma unroll 1
-      for (int w = nv ? 63 : -1; w >= 0; w--) {
+      for (int w = (nv && !chained) ? 63 : -1; w >= 0; w--) {
         if (w != 63) {
           ge_p2 a2 = ge_p3_to_p2(acc);
 #pragma unroll 1

@@ -29,6 +29,18 @@
 #define AFX_SEC_ENTRIES 9
 #define AFX_SEC_WINDOW_DWORDS (AFX_SEC_ENTRIES * AFX_NIELS_DWORDS)
 #define AFX_SEC_TABLE_DWORDS (AFX_SEC_WINDOWS * AFX_SEC_WINDOW_DWORDS)
+/* Variable bases of a job that has a secret scalar on one of them (afx_msm_job.narrow): signed windows of AFX_SECVAR_BITS bits
+ * instead of 4.  Every stored entry of the lane's table is read for every addition of such a term, which makes the chain HBM-bound
+ * (profiles/r03_secret_mode_traffic.txt: 4.5 TB/s of table scans at 4 bits); a 2-bit window reads 2 entries for each of 128
+ * additions instead of 8 for each of 64 - half the bytes for twice the additions, and a table of 2 entries instead of 8 to build.
+ * Measured on one box (profiles/r03_secret_independent_second_pass.txt; 3 bits lay between 2 and 4).  The chain keeps the NEXT
+ * addition's entries in registers while the current one computes (kernels.hip msm_chain_narrow): 32 dwords per stored entry, so
+ * wider windows than 2 bits would not fit the register file. */
+#ifndef AFX_SECVAR_BITS
+#define AFX_SECVAR_BITS 2
+#endif
+#define AFX_SECVAR_WINDOWS ((256 + AFX_SECVAR_BITS - 1) / AFX_SECVAR_BITS)   /* the biased scalar has up to 256 (+ a window) bits */
+#define AFX_SECVAR_STORED (1 << (AFX_SECVAR_BITS - 1))                      /* multiples 1 .. 2^(bits-1) */
 #define AFX_DIGIT_WORDS 9              /* recoded scalar: up to 260 bits (253 + one window of bias) */
 #define AFX_VAR_DWORDS 36              /* extended point: X,Y,Z,T x 9 limbs */
 #define AFX_NIELS_DWORDS 28            /* affine niels: (y+x)/2, (y-x)/2, dxy x 9 limbs + 1 dword of padding = 7 x 16 bytes */
@@ -122,7 +134,9 @@ typedef struct {
                                            does not encode; k_compress2x then encodes TWICE the stored point, which needs one field
                                            inversion per item for all such jobs together instead of a square root each (Assembler::msm) */
   uint32_t digit_slot;                  /* first recoded-scalar slot of this job in digit_ws (one per term)   */
-  uint32_t table_slot;                  /* unused (slots are per term: afx_msm_term.table_slot) */
+  uint32_t narrow;                      /* one of the variable terms has a secret scalar under secret-independent addressing: the job's
+                                           variable terms run AFX_SECVAR_BITS-bit windows over tables of AFX_SECVAR_STORED entries
+                                           (Assembler::msm sets it; only launches of the SEC kernel instances hold such jobs) */
 } afx_msm_job;
 
 /* one window table to build (k_msm_tables<ODD>): the base and where the table goes.  ODD = the odd multiples 1, 3, .., 15
@@ -130,7 +144,9 @@ typedef struct {
 typedef struct {
   const int32_t* var;      /* variable point (SoA)                                                  */
   uint32_t table_slot;     /* slot in table_ws                                                      */
-  uint32_t pad;
+  uint16_t stored;         /* multiples to build: AFX_TABLE_STORED, or AFX_SECVAR_STORED for the table of a narrow job */
+  uint16_t entry_major;    /* the table of a narrow job: [entry][16-byte piece][item] like a NAF table - every lane reads every
+                              entry, so a wave's load is 1 KB contiguous - instead of [item][entry] (a lane's digit picks one) */
 } afx_table_job;
 
 /* k_compress2x: out_enc[item] = encoding of 2 * var[item] (ristretto255) */

@@ -546,7 +546,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or (os.environ.get("AFX_BENCH_PG_ALWAYS") == "1" and "RANK" in os.environ):
+        # (AFX_BENCH_PG_ALWAYS: a one-rank launch under torch.distributed.run still forms the group - how the RCCL leg is
+        # exercised on a one-GPU box)
         import torch.distributed as dist
         # the process group only carries the measurement's barrier and one MAX all-reduce of a double (the data path has no
         # collective): RCCL as the contract asks; if it cannot start on this node, gloo serves the same purpose
@@ -629,7 +631,7 @@ def main():
         elapsed = float(t.item())
     got = status.cpu().numpy()
     assert UNCHECKED or np.array_equal(got, want), "status mismatch after the timed steps"
-    ranks_seen = 1
+    ranks_seen, had_group = 1, dist is not None
     if dist is not None:
         # the measurement is over: every rank leaves the process group here; rank 0 goes on alone with the host-side legs
         ranks_seen = dist.get_world_size()
@@ -723,7 +725,7 @@ def main():
                        "secret_independent_addressing": bool(args.secret_independent),
                        "input_generation_s": round(gen_s, 2), "host_pointer_api_presentations_per_s": pcie,
                        "wire_blob_api_presentations_per_s": wire_rate,
-                       "ranks_seen": ranks_seen, "dist_backend": args.dist_backend if world > 1 else None, "launcher": "bench.py" if os.environ.get("AFX_BENCH_LAUNCHED") else
+                       "ranks_seen": ranks_seen, "dist_backend": args.dist_backend if had_group else None, "launcher": "bench.py" if os.environ.get("AFX_BENCH_LAUNCHED") else
                        ("external" if world > 1 else "none"),
                        "group_api_presentations_per_s": group_rate, "group_api_items": group_items,
                        "group_api_note": "one process, afx_group_verify_presentations over %d device(s) on host arrays (%d copies of "

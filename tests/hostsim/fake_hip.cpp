@@ -52,7 +52,13 @@ hipError_t afxk_sccheck(hipStream_t, const afx_sccheck_job* j, uint32_t n, uint3
 hipError_t afxk_pointop(hipStream_t, const afx_pointop_job* j, uint32_t n, uint32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
 hipError_t afxk_scalarop(hipStream_t, const afx_scalarop_job* j, uint32_t n, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
 hipError_t afxk_setup_postables(hipStream_t, const int32_t*, uint32_t, int32_t*, int32_t*, int) { return hipSuccess; }
-hipError_t afxk_msm_tables(hipStream_t, int, const afx_table_job* r, uint32_t n, int32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)r[i].var + r[i].table_slot; return hipSuccess; }
+hipError_t afxk_msm_tables(hipStream_t, int odd, const afx_table_job* r, uint32_t n, int32_t*, uint32_t) {
+  for (uint32_t i = 0; i < n; i++) {
+    sink += (uintptr_t)r[i].var + r[i].table_slot;
+    if (r[i].entry_major ? (odd || r[i].stored != AFX_SECVAR_STORED) : r[i].stored != AFX_TABLE_STORED) return hipErrorInvalidValue;
+  }
+  return hipSuccess;
+}
 hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_msm_job* j, uint32_t n, const int32_t*, const int32_t* sec_tables, int32_t*, uint32_t*, uint32_t*, uint32_t,
                     unsigned long long* probe) {
   if (probe) { probe[0] += 2250; probe[1] += 100; }
@@ -67,6 +73,9 @@ hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_ms
     if ((j[i].n_var == 0 ? 0 : j[i].n_uni ? 2 : 1) != kind && !(j[i].n_var == 0 && kind == 1)) return hipErrorInvalidValue;   // every job in its own class's launch (fixed-only jobs may ride in the windowed one)
     if (j[i].leave_half && (j[i].out_var || !j[i].half_var)) return hipErrorInvalidValue;    // a job that leaves its half stores only the half
     for (uint32_t t = 0; t < j[i].n_uni; t++) if (j[i].term[t].dbl) return hipErrorInvalidValue;   // NAF schedules never run on a half base
+    int secret_var = 0;
+    for (uint32_t t = 0; t < j[i].n_var; t++) secret_var |= j[i].term[t].secret != 0;
+    if ((j[i].narrow != 0) != (secret_var != 0) || (j[i].narrow && kind != 1)) return hipErrorInvalidValue;   // narrow windows exactly where a variable base carries a secret
     for (uint32_t t = 0; t < j[i].n_terms; t++) sink += (uintptr_t)j[i].term[t].scalar;
     if (j[i].n_uni) {   // the NAF schedule lives in the plan blob: read it to its terminator
       for (const uint32_t* e = j[i].naf_sched; ; e++) { sink += *e; if (*e == 0xffffffffu) break; }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Compare builds of the library on the same GPU box: tools/ab_bench.sh <workload> <rounds> <variant.so>...
-# Alternates the default build and each variant so that box-to-box and thermal differences cancel.
+# BENCH_FLAGS: extra bench.py flags (e.g. --secret-independent).  Alternates the default build and each variant so that box-to-box and thermal differences cancel.
 set -u
 WL=$1; ROUNDS=$2; shift 2
 LIB=aeonflux_amd/lib/libaeonflux_gpu.so
@@ -8,7 +8,7 @@ cp $LIB /tmp/ab_default.so
 for r in $(seq $ROUNDS); do
   for which in /tmp/ab_default.so "$@"; do
     cp $which $LIB
-    python bench.py --workload $WL --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+    python bench.py --workload $WL --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline ${BENCH_FLAGS:-} 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
