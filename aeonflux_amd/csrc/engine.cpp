@@ -551,7 +551,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     for (size_t i : rows) c[i] = cost(jobs[i]);
     rows = balanced_row_order(rows, c, blocks_per_row >= resident ? 1u : (resident + blocks_per_row / 2) / blocks_per_row);
     std::vector<afx_msm_job> out;
-    std::vector<afx_table_job> odd_rows, plain_rows;
+    std::vector<afx_table_job> table_rows[3];   // by kind of table (plan.h afx_table_job): windows, odd multiples, narrow
     for (size_t i : rows) {
       afx_msm_job j = jobs[i];
       j.half_var = half_of[i];
@@ -566,8 +566,8 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
         auto hit = table_of.find(tk);
         if (hit == table_of.end()) {
           hit = table_of.emplace(tk, tslot++).first;
-          afx_table_job tj = { j.term[t].var, hit->second, (uint16_t)nstored, (uint16_t)(j.narrow ? 1 : 0) };
-          (odd ? odd_rows : plain_rows).push_back(tj);
+          afx_table_job tj = { j.term[t].var, hit->second, 0 };
+          table_rows[odd ? 1 : (j.narrow ? 2 : 0)].push_back(tj);
         } else {
           stats.table_additions -= odd ? 7 : (nstored - 1);   // counted per term above; this one is shared
           stats.field_mul -= odd ? (4 + 1 + 1 + 7 * 9) : (1 + (nstored - 1) * 9);
@@ -592,8 +592,8 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
       out.push_back(j);
     }
     for (size_t i : rows) { done[i] = 1; left--; }   // launched: consumers may go into any later launch
-    for (int odd = 1; odd >= 0; odd--) {
-      const std::vector<afx_table_job>& tr = odd ? odd_rows : plain_rows;
+    for (int odd = 2; odd >= 0; odd--) {
+      const std::vector<afx_table_job>& tr = table_rows[odd];
       if (tr.empty()) continue;
       Launch tl;
       tl.kind = L_MSM_TABLES;

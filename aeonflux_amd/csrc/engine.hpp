@@ -143,7 +143,7 @@ struct Launch {
   int32_t* out_var = nullptr;
   uint8_t fail_code = AFX_ST_VERIFICATION_FAILURE;
   size_t bytes = 0;         // L_COPY
-  int odd = 0;              // L_MSM_TABLES: odd multiples (NAF terms) or multiples 0..8
+  int odd = 0;              // L_MSM_TABLES: kind of table (plan.h afx_table_job): 0 multiples 1..8, 1 odd multiples (NAF terms), 2 narrow
   int encodes = 1;          // L_MSM_*: some job of the launch encodes its result inside the kernel (kernels.hip k_msm<KIND, ENC, SEC>)
   int secret = 0;           // L_MSM_*: some term of the launch has a secret scalar under secret-independent addressing
   int32_t* prefix_ws = nullptr;   // L_COMPRESS, L_NEGENC: scratch for the prefix products (njobs * 9 * count dwords)

@@ -7,8 +7,9 @@
 //   k_sccheck           Scalar canonicity
 //   k_pointop           +-P +-Q (+ compress): C_V - W, C_y+M, C_y_1-E2, -E1               (P1, E1)
 //   k_scalarop          a*b+c mod l: y_i*m_i, -t*z, responses s*c+b                       (P1, S1, I2)
-//   k_msm_tables<ODD>   per-lane window tables of the variable bases of a launch list (multiples 0..8, or the odd
-//                       multiples 1..15 for width-5 NAF terms), one (base) per grid row, shared by the jobs that use it
+//   k_msm_tables<kind>  per-lane window tables of the variable bases of a launch list (multiples 1..8, the odd multiples 1..15
+//                       for width-5 NAF terms, or the two multiples of a narrow job), one (base) per grid row, shared by the
+//                       jobs that use it
 //   k_msm<KIND>         R = sum s_k P_k (+-addend) -> compress, one job class per kernel: MSM_FIXED (positional tables only),
 //                       MSM_WINDOW (per-item scalars: signed 4-bit windows over the per-lane tables, shared doublings),
 //                       MSM_NAF (batch-constant scalars - the issuer key - as a wave-uniform width-5 NAF schedule) (P1, P4 iii, I1)
@@ -452,10 +453,11 @@ AFX_DEV void msm_recode(const afx_msm_job* job, uint32_t* __restrict__ digit_ws,
 // Layout inside a slot's AFX_VAR_TABLE_DWORDS * count dwords: 4-bit-window tables are item-major ([item][entry]: a lane's 8 stored
 // entries are contiguous, its digit picks one), NAF tables entry-major ([entry][item]: every lane of a wave reads the SAME
 // entry; they are stored piece-major inside an entry, see cached_store).  `stride` = dwords between consecutive entries.
-template <bool ODD>
-AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t chunk, const ge_p3& P, uint32_t stored) {
+enum { TABLE_WINDOW = 0, TABLE_ODD = 1, TABLE_NARROW = 2 };
+template <int TK>
+AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t chunk, const ge_p3& P) {
   ge_p3 Q = P;
-  if (ODD) {
+  if (TK == TABLE_ODD) {
     const ge_cached c2 = ge_p3_to_cached(ge_double(P));
     cached_store(tab, chunk, ge_p3_to_cached(P));   // the canonical packing carries: no separate reduction
 #pragma unroll 1
@@ -467,7 +469,7 @@ AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t ch
     const ge_cached cP = ge_p3_to_cached(P);   // P centred: Y+X, Y-X, 2Z within 1 unit, what ge_add_cached expects
     cached_store(tab, chunk, cP);   // k*P at entry k - 1; the identity (digit 0) is not stored
 #pragma unroll 1
-    for (uint32_t k = 2; k <= stored; k++) {
+    for (int k = 2; k <= (TK == TABLE_NARROW ? AFX_SECVAR_STORED : AFX_TABLE_STORED); k++) {
       Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
       cached_store(tab + (k - 1) * stride, chunk, ge_p3_to_cached(Q));
     }
@@ -520,7 +522,10 @@ AFX_DEV void msm_finish(const afx_msm_job* job, ge_p3 acc, uint32_t* __restrict_
 }
 
 // window tables of the variable bases of one k_msm launch, one (job, term) pair per grid row: the chain kernels only read them
-template <bool ODD>
+// TK: TABLE_WINDOW the multiples 1..8 (signed 4-bit windows), TABLE_ODD the odd multiples 1..15 (width-5 NAF terms), TABLE_NARROW
+// the multiples 1..AFX_SECVAR_STORED of a job with a secret scalar on a variable base.  A kernel instance each: one body with
+// the layouts and the entry count as run-time values took 256 registers and scratch.
+template <int TK>
 __global__ void __launch_bounds__(AFX_BLOCK, 2)
 k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table_ws, uint32_t count) {
   const uint32_t item = min(blockIdx.x * AFX_BLOCK + threadIdx.x, count - 1);
@@ -528,9 +533,8 @@ k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table
   int32_t* slot = table_ws + (size_t)row.table_slot * count * AFX_VAR_TABLE_DWORDS;
   const ge_p3 P = var_load(row.var, count, item);
   // NAF tables and the tables of narrow jobs: [entry][piece][item][16 B]; window tables: [item][entry][128 B]
-  if (ODD) msm_build_table<true>(slot + (size_t)item * 4, (size_t)count * AFX_TABLE_ENTRY_DWORDS, (size_t)count * 4, P, AFX_TABLE_STORED);
-  else if (row.entry_major) msm_build_table<false>(slot + (size_t)item * 4, (size_t)count * AFX_TABLE_ENTRY_DWORDS, (size_t)count * 4, P, row.stored);
-  else msm_build_table<false>(slot + (size_t)item * AFX_VAR_TABLE_DWORDS, AFX_TABLE_ENTRY_DWORDS, 4, P, row.stored);
+  if (TK == TABLE_WINDOW) msm_build_table<TK>(slot + (size_t)item * AFX_VAR_TABLE_DWORDS, AFX_TABLE_ENTRY_DWORDS, 4, P);
+  else msm_build_table<TK>(slot + (size_t)item * 4, (size_t)count * AFX_TABLE_ENTRY_DWORDS, (size_t)count * 4, P);
 }
 
 // ENC: the launch has jobs that encode their result in this kernel (those with an addend or an extended-coordinate output as
@@ -919,9 +923,13 @@ hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_
   }
   return hipGetLastError();
 }
-hipError_t afxk_msm_tables(hipStream_t s, int odd, const afx_table_job* rows, uint32_t nrows, int32_t* table_ws, uint32_t count) {
-  if (odd) hipLaunchKernelGGL(k_msm_tables<true>, grid_for(count, nrows), dim3(AFX_BLOCK), 0, s, rows, table_ws, count);
-  else hipLaunchKernelGGL(k_msm_tables<false>, grid_for(count, nrows), dim3(AFX_BLOCK), 0, s, rows, table_ws, count);
+hipError_t afxk_msm_tables(hipStream_t s, int kind, const afx_table_job* rows, uint32_t nrows, int32_t* table_ws, uint32_t count) {
+  switch (kind) {
+    case TABLE_WINDOW: hipLaunchKernelGGL(k_msm_tables<TABLE_WINDOW>, grid_for(count, nrows), dim3(AFX_BLOCK), 0, s, rows, table_ws, count); break;
+    case TABLE_ODD: hipLaunchKernelGGL(k_msm_tables<TABLE_ODD>, grid_for(count, nrows), dim3(AFX_BLOCK), 0, s, rows, table_ws, count); break;
+    case TABLE_NARROW: hipLaunchKernelGGL(k_msm_tables<TABLE_NARROW>, grid_for(count, nrows), dim3(AFX_BLOCK), 0, s, rows, table_ws, count); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, uint32_t njobs, uint32_t per_row, int32_t* prefix_ws, uint32_t* bad, uint32_t count) {

@@ -139,14 +139,14 @@ typedef struct {
                                            (Assembler::msm sets it; only launches of the SEC kernel instances hold such jobs) */
 } afx_msm_job;
 
-/* one window table to build (k_msm_tables<ODD>): the base and where the table goes.  ODD = the odd multiples 1, 3, .., 15
- * (terms that run a width-5 NAF), else the multiples 0..8 (signed 4-bit windows) */
+/* one window table to build (k_msm_tables<kind>): the base and where the table goes.  Kinds (one launch each): 0 the multiples
+ * 1..8 (signed 4-bit windows), item-major [item][entry] - a lane's digit picks one entry; 1 the odd multiples 1, 3, .., 15 (terms
+ * that run a width-5 NAF); 2 the multiples 1..AFX_SECVAR_STORED of a narrow job.  Kinds 1 and 2 are entry-major,
+ * [entry][16-byte piece][item]: every lane of a wave reads the same entry, so a wave's load is 1 KB contiguous. */
 typedef struct {
   const int32_t* var;      /* variable point (SoA)                                                  */
   uint32_t table_slot;     /* slot in table_ws                                                      */
-  uint16_t stored;         /* multiples to build: AFX_TABLE_STORED, or AFX_SECVAR_STORED for the table of a narrow job */
-  uint16_t entry_major;    /* the table of a narrow job: [entry][16-byte piece][item] like a NAF table - every lane reads every
-                              entry, so a wave's load is 1 KB contiguous - instead of [item][entry] (a lane's digit picks one) */
+  uint32_t pad;
 } afx_table_job;
 
 /* k_compress2x: out_enc[item] = encoding of 2 * var[item] (ristretto255) */

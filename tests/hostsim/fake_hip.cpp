@@ -52,11 +52,9 @@ hipError_t afxk_sccheck(hipStream_t, const afx_sccheck_job* j, uint32_t n, uint3
 hipError_t afxk_pointop(hipStream_t, const afx_pointop_job* j, uint32_t n, uint32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
 hipError_t afxk_scalarop(hipStream_t, const afx_scalarop_job* j, uint32_t n, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
 hipError_t afxk_setup_postables(hipStream_t, const int32_t*, uint32_t, int32_t*, int32_t*, int) { return hipSuccess; }
-hipError_t afxk_msm_tables(hipStream_t, int odd, const afx_table_job* r, uint32_t n, int32_t*, uint32_t) {
-  for (uint32_t i = 0; i < n; i++) {
-    sink += (uintptr_t)r[i].var + r[i].table_slot;
-    if (r[i].entry_major ? (odd || r[i].stored != AFX_SECVAR_STORED) : r[i].stored != AFX_TABLE_STORED) return hipErrorInvalidValue;
-  }
+hipError_t afxk_msm_tables(hipStream_t, int kind, const afx_table_job* r, uint32_t n, int32_t*, uint32_t) {
+  if (kind < 0 || kind > 2) return hipErrorInvalidValue;
+  for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)r[i].var + r[i].table_slot;
   return hipSuccess;
 }
 hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_msm_job* j, uint32_t n, const int32_t*, const int32_t* sec_tables, int32_t*, uint32_t*, uint32_t*, uint32_t,

@@ -1,0 +1,84 @@
+"""CPU-only: properties of the COMPILED gfx950 kernels that DESIGN.md states and that the compiler can silently take away.
+Reads the device code object embedded in aeonflux_amd/lib/libaeonflux_gpu.so (llvm-objdump --offloading on a copy, llvm-readelf
+--notes, llvm-objdump -d): nothing is compiled here, the test takes a few seconds.
+
+ * register/scratch table of DESIGN.md section 3: the chain, table, decode and encode kernels are scratch-free, and the
+   instances that are launched three blocks per CU fit 168 VGPRs;
+ * secret-independent addressing: the scan of a generator's window reads every entry through wide scalar loads and selects with
+   v_bfi_b32 - round 3 found the compiler had turned the select into a branch around a one-dword load (skipped when no lane of
+   the wave held that digit: an access pattern that depended on the digits).  The SEC instances must not have more exec-mask
+   branches than their ordinary siblings."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "aeonflux_amd", "lib", "libaeonflux_gpu.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+@pytest.fixture(scope="module")
+def code_object(tmp_path_factory):
+    if not os.path.exists(LIB):
+        pytest.fail("aeonflux_amd/lib/libaeonflux_gpu.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    d = tmp_path_factory.mktemp("isa")
+    lib = shutil.copy(LIB, d / "lib.so")
+    subprocess.run([LLVM + "/llvm-objdump", "--offloading", str(lib)], check=True, capture_output=True, cwd=d)
+    cos = [f for f in os.listdir(d) if "gfx950" in f]
+    assert len(cos) == 1, os.listdir(d)
+    co = str(d / cos[0])
+    notes = subprocess.run([LLVM + "/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+    kernels = {}
+    for blk in notes.split(".args:")[1:] if ".args:" in notes else []:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        if name:
+            kernels[name.group(1)] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+                                      for k in ("vgpr_count", "sgpr_count", "private_segment_fixed_size")}
+    dis = subprocess.run([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+    bodies = {}
+    for f in re.split(r"\n(?=[0-9a-f]{16} <)", dis):
+        m = re.match(r"[0-9a-f]{16} <(\S+)>:", f)
+        if m:
+            bodies[m.group(1)] = f
+    return kernels, bodies
+
+
+def msm(kind, enc, sec):
+    return "_Z5k_msmILi%dELb%dELb%dEEvPK11afx_msm_jobPKiS4_PiPjS6_jPy" % (kind, enc, sec)
+
+
+def test_hot_kernels_are_scratch_free_and_fit_their_occupancy(code_object):
+    kernels, _ = code_object
+    assert len(kernels) >= 30, sorted(kernels)
+    hot = [k for k in kernels if re.match(r"_Z\d+k_(msm|decode|compress2x|negenc|pointsum|pointop|hash|from_uniform|scalarop)", k)]
+    assert len(hot) >= 22, hot
+    for k in hot:
+        assert kernels[k]["private_segment_fixed_size"] == 0, (k, kernels[k])
+    # launched with three blocks of 256 per CU (kernels.hip __launch_bounds__): 512 / 3 -> 168 registers
+    three = [msm(0, 0, 0), msm(1, 0, 0), msm(2, 0, 0), msm(0, 0, 1)]
+    for k in three:
+        assert kernels[k]["vgpr_count"] <= 168, (k, kernels[k])
+    for k in hot:
+        assert kernels[k]["vgpr_count"] <= 256, (k, kernels[k])
+    # the table kernels: one instance per table kind (one body with run-time layouts took 256 registers and scratch)
+    tables = sorted(k for k in kernels if "k_msm_tables" in k)
+    assert len(tables) == 3 and all(kernels[k]["vgpr_count"] <= 192 for k in tables), [(k, kernels[k]) for k in tables]
+
+
+def test_secret_independent_scan_reads_every_entry_unconditionally(code_object):
+    _, bodies = code_object
+    count = lambda body, pat: len(re.findall(pat, body))
+    for kind in (0, 1):
+        for enc in (0, 1):
+            sec, plain = bodies[msm(kind, enc, 1)], bodies[msm(kind, enc, 0)]
+            # 8 entries of a window (entry 0 besides): 27 dwords each through s_load_dwordx16 + x8 + ...; none of it in the ordinary instance
+            assert count(sec, r"s_load_dwordx16") >= 8 and count(plain, r"s_load_dwordx16") == 0
+            assert count(sec, r"v_bfi_b32") >= 8 * 20
+            # no branch on the exec mask around the scan's loads: the SEC instance branches where its sibling does (+ the uniform
+            # `secret` / `narrow` tests, which are scalar branches), not once per table word
+            assert count(sec, r"s_cbranch_exec") <= count(plain, r"s_cbranch_exec") + 4, (kind, enc)
+    # the narrow chain of the windowed SEC instance: two entries x eight 16-byte loads in flight per addition
+    assert count(bodies[msm(1, 0, 1)], r"global_load_dwordx4") >= 2 * 16
