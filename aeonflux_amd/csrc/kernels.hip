@@ -337,6 +337,7 @@ AFX_DEV ge_p3 narrow_add(const msm_env& e, const ge_p3& acc, uint32_t t, int w, 
   }
   return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_from_words(sel), neg), next);
 }
+static_assert(AFX_SECVAR_STORED * 32 <= 64, "msm_chain_narrow keeps the next addition's entries in registers: 2-bit windows");
 AFX_DEV ge_p3 msm_chain_narrow(const msm_env& e, ge_p3 acc, uint32_t nv) {
   uint32_t nxt[AFX_SECVAR_STORED * 32];
   uint64_t nxt_digits;
