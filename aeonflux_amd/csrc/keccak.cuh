@@ -2,8 +2,8 @@
 // Underlies the STROBE-128 / merlin transcript hashing the reference reaches through zkp::Transcript
 // [3P] (/root/reference/src/nizk/presentation.rs:355, encryption.rs:160, issuance.rs:142).
 //
-// Written on 32-bit halves: a 64-bit rotation is two v_alignbit_b32 (none when the amount is 32), chi is one
-// v_xor + one v_bfi per half.  Left to the compiler as uint64_t shifts, the same round came out 3.5 times longer
+// Written on 32-bit halves: a 64-bit rotation is two v_alignbit_b32 (none when the amount is 32), chi and the three-input
+// xors of theta are one v_bitop3_b32 per half.  Left to the compiler as uint64_t shifts, the same round came out 3.5 times longer
 // (64-bit shift/add and multiply forms of the rotations plus ~260 register moves per round).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -35,6 +35,15 @@ __device__ __forceinline__ kk_lane kk_rotl(const kk_lane& x) {
   return r;
 }
 __device__ __forceinline__ kk_lane kk_xor(const kk_lane& a, const kk_lane& b) { return { a.lo ^ b.lo, a.hi ^ b.hi }; }
+// a ^ b ^ c: one v_bitop3_b32 per half (gfx950; truth table 0x96)
+__device__ __forceinline__ uint32_t kk_xor3w(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIPCC__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
+__device__ __forceinline__ kk_lane kk_xor3(const kk_lane& a, const kk_lane& b, const kk_lane& c) { return { kk_xor3w(a.lo, b.lo, c.lo), kk_xor3w(a.hi, b.hi, c.hi) }; }
 // a ^ (~b & c)
 __device__ __forceinline__ kk_lane kk_chi(const kk_lane& a, const kk_lane& b, const kk_lane& c) {
   return { a.lo ^ (~b.lo & c.lo), a.hi ^ (~b.hi & c.hi) };
@@ -47,13 +56,14 @@ __device__ __forceinline__ void keccak_f1600(uint64_t st[25]) {
   for (int i = 0; i < 25; i++) { a[i].lo = (uint32_t)st[i]; a[i].hi = (uint32_t)(st[i] >> 32); }
 #pragma unroll 1
   for (int round = 0; round < 24; round++) {
-    kk_lane c[5], d[5];
+    // theta on three-input xors: the column parities (2 per half), then each lane ^= parity(x-1) ^ rotl(parity(x+1), 1) in one
+    kk_lane c[5], c1[5];
 #pragma unroll
-    for (int x = 0; x < 5; x++) c[x] = kk_xor(kk_xor(kk_xor(a[x], a[x + 5]), kk_xor(a[x + 10], a[x + 15])), a[x + 20]);
+    for (int x = 0; x < 5; x++) c[x] = kk_xor3(kk_xor3(a[x], a[x + 5], a[x + 10]), a[x + 15], a[x + 20]);
 #pragma unroll
-    for (int x = 0; x < 5; x++) d[x] = kk_xor(c[(x + 4) % 5], kk_rotl<1>(c[(x + 1) % 5]));
+    for (int x = 0; x < 5; x++) c1[x] = kk_rotl<1>(c[x]);
 #pragma unroll
-    for (int i = 0; i < 25; i++) a[i] = kk_xor(a[i], d[i % 5]);
+    for (int i = 0; i < 25; i++) a[i] = kk_xor3(a[i], c[(i % 5 + 4) % 5], c1[(i % 5 + 1) % 5]);
     // rho + pi: b[y + 5*((2x+3y)%5)] = rotl(a[x+5y], r[x][y])
     kk_lane b[25];
     b[0] = a[0];
