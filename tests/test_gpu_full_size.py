@@ -101,6 +101,41 @@ def test_issue_show_verify_round_trip_at_full_size(name, n, layout, hide, count,
         assert octx.verify_presentation(p) == int(want[i]), (name, i)
 
 
+@pytest.mark.parametrize("count", [1 << 12, 1 << 14, 1 << 17])   # the latency plan, the key-job split, the plan of large passes
+def test_secret_independent_addressing_gives_the_same_bytes_at_size(count):
+    """afx_ctx_set_secret_independent_addressing changes HOW tables are read (2-bit windows over two-entry tables read whole, the
+    generators' 4-bit tables read whole through scalar registers), never a byte of a result: the C3 pipeline - issue, show with
+    four proofs of encryption, verify with 1 % corrupted - with the mode on, on every context, against the same run with it off."""
+    import aeonflux_amd as afx
+    import bench
+    from aeonflux_amd import batch
+    n, layout, hide = 8, "SSPPEEEE", [4, 5, 6, 7]
+    params, key, ip = bench.load_fixture("c3_8attrs_SSPPeeee")
+    runs = []
+    for secret in (False, True):
+        issuer, user = afx.Context(params, key, ip), afx.Context(params, None, ip)
+        issuer.set_secret_independent_addressing(secret)
+        user.set_secret_independent_addressing(secret)
+        pres, shape = bench.generate(afx, batch, issuer, user, params, n, layout, hide, count, 4242)
+        assert (user.plan_stats()["secret_terms"] > 0) == secret   # the last call on `user`: show
+        want = bench.corrupt(pres, count, 17)
+        issuer.set_challenge_trace(1 + shape.n_enc_proofs, count)
+        got = batch.verify_presentations(issuer, shape, pres)
+        assert (issuer.plan_stats()["secret_terms"] > 0) == secret   # the key's terms of Z
+        trace = issuer.get_challenge_trace().copy()
+        issuer.set_challenge_trace(0, 0)
+        assert np.array_equal(got, want)
+        runs.append((pres, got, trace))
+        issuer.close(); user.close()
+    (p0, g0, t0), (p1, g1, t1) = runs
+    for f in batch.PRES_FIELDS:
+        assert np.array_equal(p0[f], p1[f]), f
+    for e0, e1 in zip(p0["enc"], p1["enc"]):
+        for f in batch.ENC_FIELDS:
+            assert np.array_equal(e0[f], e1[f]), f
+    assert np.array_equal(g0, g1) and np.array_equal(t0, t1)
+
+
 def _tile(a, reps):
     return np.ascontiguousarray(np.concatenate([a] * reps, axis=-2))
 
