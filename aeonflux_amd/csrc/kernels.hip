@@ -292,7 +292,6 @@ struct msm_env {
 };
 // acc += (4-bit signed digit of window w) * (variable base t), from the lane's own window table
 // `next` (wave-uniform): what consumes the result, GE_FOR_* (ge.cuh)
-template <bool SEC>
 AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w, int next) {
   const int32_t* table = e.table_ws + ((size_t)e.job->term[t].table_slot * e.count + e.item) * AFX_VAR_TABLE_DWORDS;
   const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + ((uint32_t)w >> 3)) * e.count + e.item];
@@ -593,7 +592,7 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
         }
         if (lane_adds) {
 #pragma unroll 1
-          for (uint32_t t = nu; t < nv; t++) acc = msm_add_var<SEC>(env, acc, t, bit >> 2, t + 1 != nv ? GE_FOR_ADD : after);
+          for (uint32_t t = nu; t < nv; t++) acc = msm_add_var(env, acc, t, bit >> 2, t + 1 != nv ? GE_FOR_ADD : after);
         }
       }
     } else {
@@ -612,8 +611,8 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
           acc = ge_p1p1_to_p3_for<GE_FOR_ADD>(ge_p2_dbl(a2));
         }
 #pragma unroll 1
-        for (uint32_t t = 0; t + 1 < nv; t++) acc = msm_add_var<SEC>(env, acc, t, w, GE_FOR_ADD);
-        acc = msm_add_var<SEC>(env, acc, nv - 1, w, w == 0 ? GE_FOR_ANY : GE_FOR_DBL);   // the window's last addition
+        for (uint32_t t = 0; t + 1 < nv; t++) acc = msm_add_var(env, acc, t, w, GE_FOR_ADD);
+        acc = msm_add_var(env, acc, nv - 1, w, w == 0 ? GE_FOR_ANY : GE_FOR_DBL);   // the window's last addition
       }
     }
     // the fixed bases of a job with variable bases: after the chain (any order gives the same sum)
