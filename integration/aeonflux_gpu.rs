@@ -162,6 +162,22 @@ extern "C" {
     fn afx_group_show(group: *mut c_void, creds: *const AfxCredentialsSoa, keypairs: *const AfxKeypairsSoa,
                       rnd: *const AfxShowRandomness, count: usize, out: *const AfxPresentationOut, shape_out: *mut AfxShape,
                       status: *mut u8) -> i32;
+    fn afx_group_size(group: *const c_void) -> u32;
+    fn afx_group_member(group: *mut c_void, index: u32) -> *mut c_void;
+    fn afx_ctx_set_secret_independent_addressing(ctx: *mut c_void, enable: i32) -> i32;
+}
+
+/// The crate multiplies by secrets in constant time (dalek's `*` and `multiscalar_mul`: src/amacs.rs:267-270,
+/// src/nizk/presentation.rs:162-184, zkp's Prover).  The engine's kernels have no secret-dependent branches in any mode; with this
+/// switched on no memory ADDRESS depends on a secret scalar either (every table entry is read and the wanted one selected), at
+/// the cost INTEGRATION.md section 3 quotes.  Applied to the one context or to every member of the group.
+fn set_secret_independent(ctx: *mut c_void, group: *mut c_void, enable: bool) -> Result<(), CredentialError> {
+    let mut rc = 0;
+    unsafe {
+        if group.is_null() { rc |= afx_ctx_set_secret_independent_addressing(ctx, enable as i32); }
+        else { for i in 0..afx_group_size(group) { rc |= afx_ctx_set_secret_independent_addressing(afx_group_member(group, i), enable as i32); } }
+    }
+    if rc != 0 { Err(CredentialError::NoIssuerKey) } else { Ok(()) }   // the only failure: the device could not hold the 4-bit tables
 }
 
 /// `Issuer` with its parameters, tables and key resident on one MI355X (`ctx`) or on several (`group`: the batch is split
@@ -225,6 +241,10 @@ impl GpuIssuer {
         if rc != 0 { return Err(CredentialError::NoIssuerKey); }
         Ok(GpuIssuer { ctx: core::ptr::null_mut(), group, n: issuer.system_parameters.NUMBER_OF_ATTRIBUTES as usize })
     }
+
+    /// Constant-address table reads for every scalar of `issue_batch` and for the issuer key's terms of `verify_batch` (see
+    /// `set_secret_independent`): what a deployment that relies on the crate's constant-time arithmetic switches on.
+    pub fn set_secret_independent_addressing(&self, enable: bool) -> Result<(), CredentialError> { set_secret_independent(self.ctx, self.group, enable) }
 
     /// Batch `Issuer::issue` (src/issuer.rs:111-124): consumes the requests like the reference does and returns one
     /// `Result` per request, in order.  All requests must share one attribute layout (same kinds per position).
@@ -341,6 +361,9 @@ impl GpuUser {
     /// Batch `AnonymousCredential::show` (src/credential.rs:37-46 -> src/nizk/presentation.rs:139-321).  One keypair per
     /// credential (or `None`: a credential with a SecretPoint attribute then yields `NoSymmetricKey`, presentation.rs:150-157).
     /// All credentials must share one layout after their hide_attribute / reveal_attribute calls.
+    /// Constant-address table reads for every scalar of `show_batch` (blindings, the credential's `t`, the symmetric key).
+    pub fn set_secret_independent_addressing(&self, enable: bool) -> Result<(), CredentialError> { set_secret_independent(self.ctx, self.group, enable) }
+
     pub fn show_batch<C: CryptoRng + RngCore>(&self, creds: &[AnonymousCredential], keypairs: Option<&[SymmetricKeypair]>, csprng: &mut C)
         -> Vec<Result<ProofOfValidCredential, CredentialError>>
     {

@@ -95,7 +95,7 @@ def rust_externs():
     src = re.sub(r"//.*", "", open(os.path.join(ROOT, "integration", "aeonflux_gpu.rs")).read())
     block = re.search(r'extern "C" \{(.*?)\n\}', src, flags=re.S).group(1)
     out = {}
-    for name, args, ret in re.findall(r"fn (afx_\w+)\s*\((.*?)\)\s*(->\s*\w+)?\s*;", block, flags=re.S):
+    for name, args, ret in re.findall(r"fn (afx_\w+)\s*\((.*?)\)\s*(->\s*[\w*]+(?:\s+\w+)?)?\s*;", block, flags=re.S):
         kinds = []
         for a in args.split(","):
             a = " ".join(a.split())
@@ -116,7 +116,7 @@ def test_extern_declarations_match_the_header():
         assert name in cp, name
         cret, ckinds = cp[name]
         assert kinds == ckinds, (name, kinds, ckinds)
-        assert {"int": "i32", "void": "void"}[cret] == ret, (name, cret, ret)
+        assert {"int": "i32", "void": "void", "uint32_t": "u32", "afx_ctx*": "ptr"}[cret] == ("ptr" if ret.startswith("*") else ret), (name, cret, ret)
 
 
 def test_binding_covers_the_three_call_sites_and_documents_the_draw_order():
