@@ -40,10 +40,11 @@ def algorithmic_bytes(shape):
     return 32 * (4 + hs) + 96 + 32 * n + 32 * pub + 448 * hp + (n + 2 * hs + 4 * hp) + 1
 
 
-def traffic_file():
-    """the newest committed traffic measurement, profiles/rNN_traffic.json"""
+def traffic_file(secret=False):
+    """the newest committed traffic measurement, profiles/rNN_traffic.json (rNN_secret_traffic.json: the same passes with
+    secret-independent addressing on, tools/collect_secret_mode_traffic.sh)"""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%straffic.json" % ("secret_" if secret else ""))))
     return found[-1] if found else None
 
 
@@ -52,13 +53,13 @@ def traffic_file():
 UNCHECKED = os.environ.get("AFX_BENCH_UNCHECKED") == "1"
 
 
-def measured_traffic(workload, kernel):
+def measured_traffic(workload, kernel, secret=False):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
     (profiles/rNN_traffic.json, the newest round's; collected with tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes,
     FETCH doubled per MI355X_MICROARCH §HBM).  PMC counters cannot be read from inside the process, so the figure is the
     committed measurement of the same workload, not a live one.  C4 launches are C3 launches (2^19-item passes)."""
     try:
-        with open(traffic_file()) as f:
+        with open(traffic_file(secret)) as f:
             d = json.load(f).get({"c4": "c3"}.get(workload, workload))
         return d.get(kernel) if isinstance(d, dict) else d
     except (OSError, ValueError, TypeError):
@@ -86,14 +87,14 @@ def kernel_times(ctx, steps):
     return out
 
 
-def roofline_of(kt, workload, ab, items_per_step):
+def roofline_of(kt, workload, ab, items_per_step, secret=False):
     """the contract's roofline object for the dominant kernel of the step (the largest ms_per_step)"""
     dom = max((k for k in kt if k in MSM_KERNELS), key=lambda k: kt[k]["ms_per_step"])
     d = kt[dom]
     items_per_launch = items_per_step / d["launches_per_step"]
     achieved = ab * items_per_launch / (d["avg_launch_ms"] / 1e3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "traffic": measured_traffic(workload, dom), "kernel": dom, "launches_per_step": d["launches_per_step"],
+            "traffic": measured_traffic(workload, dom, secret), "kernel": dom, "launches_per_step": d["launches_per_step"],
             "avg_launch_ms": d["avg_launch_ms"], "items_per_launch": items_per_launch, "algorithmic_bytes_per_launch": ab * items_per_launch,
             "kernel_ms_per_step": sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS),
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in kt.items()},
@@ -279,7 +280,7 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
             "config": {"workload": "C5: batch issue 2^20 credentials, 16 attributes (S x8, P x4, E x4)", "credentials_per_gpu": count,
                        "secret_independent_addressing": bool(args.secret_independent),
                        "algorithmic_bytes_per_credential": ab, "parallelism": "host-sharded x%d, no collective" % world},
-            "roofline": roofline_of(kt, "c5", ab, count),
+            "roofline": roofline_of(kt, "c5", ab, count, bool(args.secret_independent)),
             "valu": valu, "cpu_baseline": cpu}))
     issuer.close()
     if dist is not None:
@@ -388,7 +389,7 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
             "config": {"workload": "show 2^16 credentials, 4 attributes (s S P e)", "credentials_per_gpu": count, "algorithmic_bytes_per_presentation": ab,
                        "secret_independent_addressing": bool(args.secret_independent),
                        "parallelism": "host-sharded x%d, no collective" % world},
-            "roofline": roofline_of(kt, "show", ab, count),
+            "roofline": roofline_of(kt, "show", ab, count, bool(args.secret_independent)),
             "valu": valu, "cpu_baseline": None}))
     issuer.close()
     user.close()
@@ -731,7 +732,7 @@ def main():
                        "group_api_note": "one process, afx_group_verify_presentations over %d device(s) on host arrays (%d copies of "
                                          "rank 0's batch), PCIe and staging inclusive" % (world, world),
                        "group_api_error": group_err},
-            "roofline": roofline_of(kt, args.workload, ab, count),
+            "roofline": roofline_of(kt, args.workload, ab, count, bool(args.secret_independent)),
             "valu": valu,
             "cpu_baseline": cpu,
         }

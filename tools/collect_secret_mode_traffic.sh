@@ -1,7 +1,8 @@
 #!/bin/bash
 # HBM traffic of the multiscalar kernels with secret-independent addressing on (C5 issue, C3 verify): separate FETCH_SIZE /
 # WRITE_SIZE passes with --kernel-trace only, as tools/collect_profiles.sh does for the default mode.
-#   gpurun -- 'bash tools/collect_secret_mode_traffic.sh'   ->  gpurun_out/r03_secret_mode_traffic.txt
+#   gpurun -- 'bash tools/collect_secret_mode_traffic.sh'   ->  gpurun_out/r03_secret_mode_traffic.txt, gpurun_out/r03_secret_traffic.json
+# (copy both under profiles/: bench.py --secret-independent reads the json for roofline.traffic)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/secret_traffic
 mkdir -p $O
@@ -12,7 +13,7 @@ for w in c5 c3; do
     rocprofv3 --kernel-trace --pmc $c -d $O/pmc_${w}_$c -o t -- python3 $R/bench.py --workload $w --secret-independent --steps 2 --warmup 1 --no-cpu-baseline --no-group-api > $O/pmc_${w}_$c.log 2>&1
   done
 done
-python3 $R/tools/traffic_json.py $O/secret_traffic.json \
+python3 $R/tools/traffic_json.py $R/gpurun_out/r03_secret_traffic.json \
   c5:$(db $O/pmc_c5_FETCH_SIZE):$(db $O/pmc_c5_WRITE_SIZE):$O/pmc_c5_FETCH_SIZE.log \
   c3:$(db $O/pmc_c3_FETCH_SIZE):$(db $O/pmc_c3_WRITE_SIZE):$O/pmc_c3_FETCH_SIZE.log > $R/gpurun_out/r03_secret_mode_traffic.txt 2>&1
 for w in c5 c3; do grep '^{' $O/pmc_${w}_FETCH_SIZE.log | tail -1 | python3 -c "
