@@ -252,7 +252,7 @@ class Context:
 
     def plan_stats(self):
         """per-item operation counts of the most recent call (afx_plan_stats) as a dict"""
-        names = ("msm_jobs", "doublings", "var_additions", "fixed_additions", "table_additions", "encodings", "decodings", "keccak_permutations", "field_mul", "field_sq", "secret_terms")
+        names = ("msm_jobs", "doublings", "var_additions", "fixed_additions", "table_additions", "encodings", "decodings", "keccak_permutations", "field_mul", "field_sq", "secret_terms", "chain_mul", "chain_sq")
         v = (C.c_uint64 * len(names))()
         check(lib().afx_ctx_get_plan_stats(self.h, v))
         return dict(zip(names, (int(x) for x in v)))

@@ -102,6 +102,8 @@ void Assembler::decode(const std::vector<afx_decode_job>& jobs) {
   stats.decodings += jobs.size();
   stats.field_mul += AFX_DECODE_MUL * jobs.size();
   stats.field_sq += AFX_DECODE_SQ * jobs.size();
+  stats.chain_mul += AFX_CHAIN_SQRT_MUL * jobs.size();
+  stats.chain_sq += AFX_CHAIN_SQRT_SQ * jobs.size();
   add_jobs(L_DECODE, jobs);
 }
 void Assembler::sccheck(const std::vector<afx_sccheck_job>& jobs) { add_jobs(L_SCCHECK, jobs); }
@@ -111,6 +113,8 @@ void Assembler::pointop(const std::vector<afx_pointop_job>& jobs) {
     stats.encodings += j.out_enc != nullptr;
     stats.field_mul += (j.sb != 0 ? 9 : 0) + (j.out_enc ? AFX_ENCODE_MUL : 0);
     stats.field_sq += j.out_enc ? AFX_ENCODE_SQ : 0;
+    stats.chain_mul += j.out_enc ? AFX_CHAIN_SQRT_MUL : 0;
+    stats.chain_sq += j.out_enc ? AFX_CHAIN_SQRT_SQ : 0;
   }
   add_jobs(L_POINTOP, jobs);
 }
@@ -119,6 +123,7 @@ void Assembler::negenc(const std::vector<afx_negenc_job>& jobs) {
   stats.encodings += jobs.size();
   stats.field_mul += 11 + (2 * 3 + 2 + 17) * jobs.size();   // one inversion; per point: the value to invert twice, prefix products, the encoding's tail
   stats.field_sq += 254 + 3 * jobs.size();
+  stats.chain_mul += AFX_CHAIN_INVERT_MUL; stats.chain_sq += AFX_CHAIN_INVERT_SQ;
   add_jobs(L_NEGENC, jobs);
   launches.back().prefix_ws = (int32_t*)ws_alloc(sizeof(int32_t) * 9 * jobs.size() * (size_t)count);
 }
@@ -255,6 +260,8 @@ void Assembler::compress(const std::vector<afx_compress_job>& cjobs, uint32_t gr
   const uint64_t rows = cl.per_group ? (cl.njobs + cl.per_group - 1) / cl.per_group : 1;
   stats.field_mul += 22 * cjobs.size() + 11 * rows; stats.field_mul -= AFX_ENCODE_MUL * cjobs.size();
   stats.field_sq += 8 * cjobs.size() + 254 * rows; stats.field_sq -= AFX_ENCODE_SQ * cjobs.size();
+  stats.chain_mul += AFX_CHAIN_INVERT_MUL * rows; stats.chain_mul -= AFX_CHAIN_SQRT_MUL * cjobs.size();
+  stats.chain_sq += AFX_CHAIN_INVERT_SQ * rows; stats.chain_sq -= AFX_CHAIN_SQRT_SQ * cjobs.size();
 }
 
 // Multiscalar jobs of one statement stage.  Large passes: one lane per (job, item), every job a single chain (msm_list).  Small
@@ -322,7 +329,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
 void Assembler::compress_also(const int32_t* var, uint8_t* out_enc, bool negate, uint32_t reject_identity) {
   afx_compress_job cj = { var, out_enc, reject_identity, negate ? 1u : 0u };
   pending_cjobs_.push_back(cj);
-  stats.encodings++; stats.field_mul += AFX_ENCODE_MUL; stats.field_sq += AFX_ENCODE_SQ;   // compress() rewrites this share
+  stats.encodings++; stats.field_mul += AFX_ENCODE_MUL; stats.field_sq += AFX_ENCODE_SQ; stats.chain_mul += AFX_CHAIN_SQRT_MUL; stats.chain_sq += AFX_CHAIN_SQRT_SQ;   // compress() rewrites this share
 }
 
 // One chain per term.  A job with more than one part - each variable-base term, and its fixed-base terms six at a time - becomes
@@ -381,10 +388,10 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
         if (j.leave_half) sj.out_var = nullptr;
         afx_compress_job cj = { sj.half_var, j.out_enc, j.reject_identity, 0 };
         cjobs.push_back(cj);
-        stats.encodings++; stats.field_mul += AFX_ENCODE_MUL; stats.field_sq += AFX_ENCODE_SQ;   // compress() rewrites this share
+        stats.encodings++; stats.field_mul += AFX_ENCODE_MUL; stats.field_sq += AFX_ENCODE_SQ; stats.chain_mul += AFX_CHAIN_SQRT_MUL; stats.chain_sq += AFX_CHAIN_SQRT_SQ;   // compress() rewrites this share
       } else {
         sj.out_enc = j.out_enc;
-        if (j.out_enc) { stats.encodings++; stats.field_mul += AFX_ENCODE_MUL; stats.field_sq += AFX_ENCODE_SQ; }
+        if (j.out_enc) { stats.encodings++; stats.field_mul += AFX_ENCODE_MUL; stats.field_sq += AFX_ENCODE_SQ; stats.chain_mul += AFX_CHAIN_SQRT_MUL; stats.chain_sq += AFX_CHAIN_SQRT_SQ; }
       }
       stats.var_additions += sj.n_parts - 1 + (sj.addend ? 1 : 0);
       stats.field_mul += 9 * (uint64_t)(sj.n_parts - 1 + (sj.addend ? 1 : 0));
@@ -480,7 +487,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
       stats.encodings += j.out_enc ? 1 : 0;
       stats.var_additions += j.addend ? 1 : 0;
       if (j.addend) M += 9;
-      if (j.out_enc) { M += AFX_ENCODE_MUL; S += AFX_ENCODE_SQ; }
+      if (j.out_enc) { M += AFX_ENCODE_MUL; S += AFX_ENCODE_SQ; stats.chain_mul += AFX_CHAIN_SQRT_MUL; stats.chain_sq += AFX_CHAIN_SQRT_SQ; }
       stats.field_mul += M;
       stats.field_sq += S;
       continue;
@@ -503,7 +510,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     }
     M += nfa * 7;                                             // fixed bases: positional tables, niels addition + to p3
     if (j.addend) M += 9;
-    if (j.out_enc) { M += AFX_ENCODE_MUL; S += AFX_ENCODE_SQ; }
+    if (j.out_enc) { M += AFX_ENCODE_MUL; S += AFX_ENCODE_SQ; stats.chain_mul += AFX_CHAIN_SQRT_MUL; stats.chain_sq += AFX_CHAIN_SQRT_SQ; }
     stats.field_mul += M;
     stats.field_sq += S;
   }

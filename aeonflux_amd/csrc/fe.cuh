@@ -256,13 +256,6 @@ AFX_DEV fe fe_sq_impl(const fe& f) {
 AFX_DEV fe fe_sq(const fe& f) { return fe_sq_impl<true>(f); }
 AFX_DEV fe fe_sq_raw(const fe& f) { return fe_sq_impl<false>(f); }
 
-// f^(2^n), n >= 1, rolled loop (keeps the inversion chains small in code size); every consumer multiplies the result
-AFX_DEV fe fe_sqn(fe f, int n) {
-#pragma unroll 1
-  for (int i = 0; i < n; i++) f = fe_sq_raw(f);
-  return f;
-}
-
 // Load from 8 little-endian dwords, ignoring bit 255 (dalek FieldElement::from_bytes).  Limbs come out raw.
 AFX_DEV fe fe_frombytes(const uint32_t w[8]) {
   fe r;
@@ -323,29 +316,27 @@ AFX_DEV fe fe_cneg(const fe& f, bool b) {
 }
 AFX_DEV fe fe_abs(const fe& f) { return fe_cneg(f, fe_is_negative(f)); }
 
-// z^(2^250-1) and z^11
-AFX_DEV void fe_pow22501(fe& t250, fe& z11, const fe& z) {
-  fe z2 = fe_sq(z);
-  fe z8 = fe_sqn(z2, 2);
-  fe z9 = fe_mul(z, z8);
-  z11 = fe_mul(z2, z9);
-  fe z22 = fe_sq(z11);
-  fe z_5_0 = fe_mul(z9, z22);                       // 2^5 - 1
-  fe z_10_0 = fe_mul(fe_sqn(z_5_0, 5), z_5_0);      // 2^10 - 1
-  fe z_20_0 = fe_mul(fe_sqn(z_10_0, 10), z_10_0);   // 2^20 - 1
-  fe z_40_0 = fe_mul(fe_sqn(z_20_0, 20), z_20_0);   // 2^40 - 1
-  fe z_50_0 = fe_mul(fe_sqn(z_40_0, 10), z_10_0);   // 2^50 - 1
-  fe z_100_0 = fe_mul(fe_sqn(z_50_0, 50), z_50_0);  // 2^100 - 1
-  fe z_200_0 = fe_mul(fe_sqn(z_100_0, 100), z_100_0);
-  t250 = fe_mul(fe_sqn(z_200_0, 50), z_50_0);       // 2^250 - 1
+// The inversion and square-root chains run in the 10 x 25.5-bit form (fe10.cuh: its squaring is 5 % cheaper and a chain is
+// 254 / 251 squarings and 11 products), entered and left through the canonical encoding; the result comes back centred.
+#include "fe10.cuh"
+AFX_DEV fe10 fe10_from_fe(const fe& z) {
+  uint32_t w[8];
+  fe_tobytes(w, z);
+  return fe10_frombytes(w);
+}
+AFX_DEV fe fe_from_fe10(const fe10& z) {
+  uint32_t w[8];
+  fe10_tobytes(w, z);
+  return fe_carry(fe_frombytes(w));
 }
 AFX_DEV fe fe_invert(const fe& z) {
-  fe t250, z11;
-  fe_pow22501(t250, z11, z);
-  return fe_mul(fe_sqn(t250, 5), z11);  // 2^255 - 21
+  fe10 t250, z11;
+  fe10_pow22501(t250, z11, fe10_from_fe(z));
+  return fe_from_fe10(fe10_mul_raw(fe10_sqn(t250, 5), z11));  // 2^255 - 21
 }
 AFX_DEV fe fe_pow22523(const fe& z) {
-  fe t250, z11;
-  fe_pow22501(t250, z11, z);
-  return fe_mul(fe_sqn(t250, 2), z);    // 2^252 - 3
+  const fe10 z10 = fe10_from_fe(z);
+  fe10 t250, z11;
+  fe10_pow22501(t250, z11, z10);
+  return fe_from_fe10(fe10_mul_raw(fe10_sqn(t250, 2), z10));    // 2^252 - 3
 }

@@ -53,6 +53,12 @@
 #define AFX_DECODE_SQ 257
 #define AFX_ENCODE_MUL 32
 #define AFX_ENCODE_SQ 255
+/* of which inside the inversion / square-root chains, which run in the 10 x 25.5-bit form (fe10.cuh): z^((p-5)/8) of a decoding or
+ * an encoding, z^(p-2) of a plain inversion (k_compress2x, k_negenc) */
+#define AFX_CHAIN_SQRT_MUL 11
+#define AFX_CHAIN_SQRT_SQ 251
+#define AFX_CHAIN_INVERT_MUL 11
+#define AFX_CHAIN_INVERT_SQ 254
 
 /* per-item failure bits OR-ed into the `bad` word of an item */
 #define AFX_BAD_DECODE 1u

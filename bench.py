@@ -408,15 +408,17 @@ MAD_SUSTAINED_T = 32.2                                  # what a pure multiply-a
 
 NOMINAL_MHZ = 2400.0
 MADS_PER_MUL, MADS_PER_SQ = 98, 62
+MADS_PER_CHAIN_MUL, MADS_PER_CHAIN_SQ = 100, 55   # inside the inversion / square-root chains: the 10 x 25.5-bit form (fe10.cuh)
 
 
 def valu_side(ctx, items_per_step, field_kernel_ms_per_step):
     """compute-side figure beside the HBM roofline: 32x32->64-bit multiply-adds of the field arithmetic per second.
     Counts come from the engine's own plan of the last call (afx_ctx_get_plan_stats); a field multiplication issues 98
     multiply-adds (81 products, 16 to fold the high columns, 1 for the wrap), a squaring 62 (45 + 16 + 1): 9 x 29-bit limbs,
-    aeonflux_amd/csrc/fe.cuh."""
+    aeonflux_amd/csrc/fe.cuh; inside the inversion / square-root chains (chain_mul, chain_sq of the stats) 100 and 55: fe10.cuh."""
     st = ctx.plan_stats()
-    mads = MADS_PER_MUL * st["field_mul"] + MADS_PER_SQ * st["field_sq"]
+    mads = (MADS_PER_MUL * (st["field_mul"] - st["chain_mul"]) + MADS_PER_SQ * (st["field_sq"] - st["chain_sq"])
+            + MADS_PER_CHAIN_MUL * st["chain_mul"] + MADS_PER_CHAIN_SQ * st["chain_sq"])
     achieved = mads * items_per_step / (field_kernel_ms_per_step / 1e3) / 1e12 if field_kernel_ms_per_step > 0 else 0.0
     mhz = ctx.core_clock_mhz()   # measured inside the timed k_msm_window launches (shader-clock counter / 100 MHz counter)
     at_clock = MAD_PEAK_T * mhz / NOMINAL_MHZ if mhz > 0 else None

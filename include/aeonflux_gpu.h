@@ -216,6 +216,8 @@ typedef struct afx_plan_stats {
                                   schedule (tests/test_device_arith_on_host.py pins the per-block counts)        */
   uint64_t secret_terms;       /* terms of the multiscalar jobs that run with secret-independent addressing (0 unless
                                   afx_ctx_set_secret_independent_addressing is on)                               */
+  uint64_t chain_mul, chain_sq; /* the share of field_mul / field_sq inside the inversion and square-root chains, which run in the
+                                  10 x 25.5-bit form of the field (100 / 55 multiply-adds each instead of 98 / 62)              */
 } afx_plan_stats;
 int afx_ctx_get_plan_stats(afx_ctx* ctx, afx_plan_stats* out);
 

@@ -3,7 +3,7 @@
 // measured rather than estimated.  Test infrastructure only: nothing in the product links this file.
 #include <stdint.h>
 #include <string.h>
-thread_local uint64_t afx_n_mul = 0, afx_n_sq = 0;
+thread_local uint64_t afx_n_mul = 0, afx_n_sq = 0, afx_n_chain_mul = 0, afx_n_chain_sq = 0;
 #define AFX_COUNT_OPS 1
 // every fe_mul / fe_sq of this build checks its operand bounds on the actual values (fe.cuh, AFX_CHECK_BOUNDS)
 #define AFX_CHECK_BOUNDS 1
@@ -102,6 +102,25 @@ int arith_msm_chain(uint8_t out[32], uint32_t nv, const uint8_t* s, const uint8_
 void arith_counters(uint64_t out[2], int reset) {
   out[0] = afx_n_mul; out[1] = afx_n_sq;
   if (reset) afx_n_mul = afx_n_sq = 0;
+}
+// the share of the above executed inside the inversion / square-root chains (fe10.cuh: the 10-limb form); never reset by arith_counters
+void arith_chain_counters(uint64_t out[2], int reset) {
+  out[0] = afx_n_chain_mul; out[1] = afx_n_chain_sq;
+  if (reset) afx_n_chain_mul = afx_n_chain_sq = 0;
+}
+// chain operations of one decode, one encode, one plain inversion (plan.h AFX_CHAIN_*)
+void arith_chain_op_counts(uint64_t out[3][2]) {
+  uint8_t enc[32] = { 0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
+                      0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76 };   // basepoint
+  uint32_t w[8], o[8];
+  load8(w, enc);
+  ge_p3 P;
+  uint64_t c[2];
+  arith_chain_counters(c, 1);
+  ristretto_decode(P, w); arith_chain_counters(out[0], 1);
+  ristretto_encode(o, P); arith_chain_counters(out[1], 1);
+  const fe inv = fe_invert(P.Z); arith_chain_counters(out[2], 1);
+  (void)inv;
 }
 
 // out = canonical encoding of a*b, a^2, 1/a, a^((p-5)/8) over GF(2^255-19); inputs 32-byte little endian (bit 255 ignored)

@@ -279,6 +279,14 @@ OP_COUNTS = {"decode": (27, 257), "encode": (32, 255), "double_to_p2": (3, 4), "
              "add_var_to_p3": (8, 0), "add_fixed_to_p3": (7, 0), "add_var_to_p2": (7, 0)}
 
 
+def test_chain_operations_are_the_published_share(arith):
+    """the inversion / square-root chains run in the 10-limb form (fe10.cuh): 251 squarings + 11 products of a decode or an
+    encode, 254 + 11 of a plain inversion - plan.h AFX_CHAIN_*, what afx_plan_stats.chain_mul / chain_sq count"""
+    out = ((C.c_uint64 * 2) * 3)()
+    arith.arith_chain_op_counts(out)
+    assert [(int(r[0]), int(r[1])) for r in out] == [(11, 251), (11, 251), (11, 254)]
+
+
 def test_operation_counts_are_the_published_ones(arith):
     out = ((C.c_uint64 * 2) * 8)()
     arith.arith_op_counts(out)

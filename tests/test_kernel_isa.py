@@ -56,7 +56,9 @@ def test_hot_kernels_are_scratch_free_and_fit_their_occupancy(code_object):
     hot = [k for k in kernels if re.match(r"_Z\d+k_(msm|decode|compress2x|negenc|pointsum|pointop|hash|from_uniform|scalarop)", k)]
     assert len(hot) >= 22, hot
     for k in hot:
-        assert kernels[k]["private_segment_fixed_size"] == 0, (k, kernels[k])
+        # k_from_uniform (two square-root chains inside Elligator) spills 31 dwords since its chains run in the 10-limb form; it
+        # is faster with them than scratch-free on the 9-limb chains (3.16 -> 2.95 ms on C5, same box)
+        assert kernels[k]["private_segment_fixed_size"] <= (128 if "k_from_uniform" in k else 0), (k, kernels[k])
     # launched with three blocks of 256 per CU (kernels.hip __launch_bounds__): 512 / 3 -> 168 registers
     three = [msm(0, 0, 0), msm(1, 0, 0), msm(2, 0, 0), msm(0, 0, 1)]
     for k in three:
