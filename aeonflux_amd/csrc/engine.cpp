@@ -699,7 +699,11 @@ int Assembler::run() {
         if (ctx->pipelining) { AFX_HIP(hipEventRecord(L.msm_done, s)); L.msm_recorded = true; }
         break;
       }
-      case L_HASH: AFX_HIP(afxk_hash(s, (const afx_hash_program*)jobs, l.njobs, bad_, count)); break;
+      case L_HASH:
+        // small passes: the permutation spread over 32 lanes per item (kernels.hip k_hash_coop), while the device has lanes to spare
+        if (small() && (uint64_t)count * l.njobs <= AFX_HASH_COOP_GROUPS) AFX_HIP(afxk_hash_coop(s, (const afx_hash_program*)jobs, l.njobs, bad_, count));
+        else AFX_HIP(afxk_hash(s, (const afx_hash_program*)jobs, l.njobs, bad_, count));
+        break;
       case L_FROM_UNIFORM: AFX_HIP(afxk_from_uniform(s, l.in, l.out, l.out_var, count)); break;
       case L_REDUCE_WIDE: AFX_HIP(afxk_reduce_wide(s, l.in, l.out, count)); break;
       case L_COPY: AFX_HIP(hipMemcpyAsync(l.out, l.in, l.bytes, hipMemcpyDeviceToDevice, s)); break;

@@ -798,6 +798,84 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_hash(const afx_hash_program* __re
   }
 }
 
+// k_hash_coop: the same transcripts for SMALL passes, 32 lanes per (item, program).  One lane per item runs its 20-80
+// permutations one after the other - 13.6 us each on an otherwise idle SIMD, 1.1 ms of the 2.9 ms a small issue call takes - and
+// a sponge cannot be cut into independent pieces; what can be spread is the permutation itself.  Lane w < 25 of a group holds word
+// w = x + 5y of the state: theta's column parities, the rho/pi move and chi's row neighbours are lane shuffles (9 64-bit shuffles
+// a round), every lane absorbs its own word of a rate block (afx_hash_word is per word already), lane 0 reduces what is squeezed.
+// Only while the device has lanes to spare: the engine launches it for at most AFX_HASH_COOP_GROUPS (item, program) pairs (engine.cpp).
+__device__ __constant__ const uint8_t KECCAK_RHO[25] = { 0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14 };
+// word w of the state after rho+pi comes from word KECCAK_PI_SRC[w] (b[y + 5*((2x+3y)%5)] = rotl(a[x+5y]), keccak.cuh)
+__device__ __constant__ const uint8_t KECCAK_PI_SRC[25] = { 0, 6, 12, 18, 24, 3, 9, 10, 16, 22, 1, 7, 13, 19, 20, 4, 5, 11, 17, 23, 2, 8, 14, 15, 21 };
+AFX_DEV uint64_t shfl64(uint64_t v, uint32_t src) {
+  const uint32_t lo = __shfl((uint32_t)v, (int)src, 32), hi = __shfl((uint32_t)(v >> 32), (int)src, 32);
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__global__ void __launch_bounds__(AFX_BLOCK) k_hash_coop(const afx_hash_program* __restrict__ progs, uint32_t* __restrict__ bad, uint32_t count) {
+  const afx_hash_program* prog = &progs[blockIdx.y];
+  const uint32_t g = threadIdx.x & 31u;
+  const uint32_t group = blockIdx.x * (AFX_BLOCK / 32) + (threadIdx.x >> 5);
+  const bool live = group < count;                      // a whole group is live or not; dead groups shadow the last item and store nothing
+  const uint32_t item = live ? group : count - 1;
+  const bool holds = g < 25;                            // lanes 25..31 take part in the shuffles only (never as a source)
+  const uint32_t w = holds ? g : 24u, x = w % 5u, y = w / 5u;
+  const uint32_t rho = KECCAK_RHO[w], pi_src = KECCAK_PI_SRC[w];
+  const uint32_t col1 = (w + 5u) % 25u, col2 = (w + 10u) % 25u, col3 = (w + 15u) % 25u, col4 = (w + 20u) % 25u;
+  const uint32_t left = 5u * y + (x + 4u) % 5u, right = 5u * y + (x + 1u) % 5u, right2 = 5u * y + (x + 2u) % 5u;
+  uint64_t st = prog->load_state ? prog->load_state[(size_t)w * count + item] : prog->init_state[w];
+  const uint32_t nrec = prog->n_records;
+#pragma unroll 1
+  for (uint32_t r = 0; r < nrec; r++) {
+    const afx_hash_record* rec = &prog->records[r];
+    if (w < 21u) {
+      const afx_hash_word hw = rec->w[w];
+      uint64_t v = hw.c;
+      if (hw.field >= 0) {
+        const uint8_t* f = prog->fields[hw.field] + 32ull * item;
+        const int q = hw.q;
+        const uint64_t lo = (q >= 0) ? load_u64(f + 8 * q) : 0ull;
+        const uint64_t hi = (q < 3) ? load_u64(f + 8 * (q + 1)) : 0ull;
+        const uint32_t sh = 8u * hw.r;
+        const uint64_t val = sh ? ((lo >> sh) | (hi << (64u - sh))) : lo;
+        v ^= val & hw.fmask;
+      }
+      st = (st & hw.keep) ^ v;
+    }
+#pragma unroll 1
+    for (int round = 0; round < 24; round++) {
+      // theta: every lane of column x ends up with the column's parity
+      const uint64_t c = st ^ shfl64(st, col1) ^ shfl64(st, col2) ^ shfl64(st, col3) ^ shfl64(st, col4);
+      const uint64_t cr = shfl64(c, right);
+      st ^= shfl64(c, left) ^ ((cr << 1) | (cr >> 63));
+      // rho on the own word, pi as a shuffle
+      const uint64_t rot = rho ? ((st << rho) | (st >> (64u - rho))) : st;
+      const uint64_t b = shfl64(rot, pi_src);
+      // chi along the row, iota on word 0
+      st = b ^ (~shfl64(b, right) & shfl64(b, right2));
+      if (w == 0u) st ^= KECCAK_RC[round];
+    }
+    if (rec->squeeze != AFX_SQ_NONE) {   // uniform: a property of the record
+      uint32_t xw[16];
+#pragma unroll
+      for (int i = 0; i < 8; i++) { const uint64_t t = shfl64(st, (uint32_t)i); xw[2 * i] = (uint32_t)t; xw[2 * i + 1] = (uint32_t)(t >> 32); }
+      if (g == 0u && live) {
+        const sc c = sc_reduce512(xw);
+        uint32_t w8[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w8[i] = c.v[i];
+        if (rec->squeeze == AFX_SQ_CHALLENGE_COMPARE) {
+          const sc want = sc_load_item(prog->challenge, 32, item);
+          if (!sc_eq(c, want)) atomicOr(&bad[item], AFX_BAD_CHALLENGE);
+          if (prog->trace) enc_store(prog->trace, item, w8);
+        } else {
+          enc_store(prog->outs[rec->squeeze_out], item, w8);
+        }
+      }
+    }
+  }
+  if (prog->save_state && holds && live) prog->save_state[(size_t)w * count + item] = st;
+}
+
 // ---------------------------------------------------------------------------------------------
 // status / utilities
 // ---------------------------------------------------------------------------------------------
@@ -943,6 +1021,11 @@ hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, uint32_t njobs
 }
 hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count) {
   hipLaunchKernelGGL(k_pointsum, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, bad, count);
+  return hipGetLastError();
+}
+hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count) {
+  const uint32_t per_block = AFX_BLOCK / 32;
+  hipLaunchKernelGGL(k_hash_coop, dim3((count + per_block - 1) / per_block, nprogs), dim3(AFX_BLOCK), 0, s, progs, bad, count);
   return hipGetLastError();
 }
 hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count) {

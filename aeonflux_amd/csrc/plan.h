@@ -47,6 +47,10 @@
 #define AFX_TABLE_ENTRY_DWORDS 32       /* a window-table entry: 4 field elements as canonical 256-bit words = 128 B = 2 HBM sectors */
 #define AFX_VAR_TABLE_DWORDS (AFX_TABLE_STORED * AFX_TABLE_ENTRY_DWORDS)
 #define AFX_BLOCK 256
+#define AFX_HASH_COOP_GROUPS 4096       /* a small pass hashes with 32 lanes per (item, program) - k_hash_coop - while items x programs of
+                                          the launch stay within this: beyond it the lane groups queue up and one lane per item is as
+                                          fast (measured: issue, 1-2 programs per launch, gains up to 4096 items; show and verify,
+                                          5 programs, up to ~800: tools/small_call_latency.py) */
 /* field multiplications / squarings of one ristretto255 decoding / encoding as ge.cuh implements them
  * (measured on the host build of that header: tests/test_device_arith_on_host.py) */
 #define AFX_DECODE_MUL 27

@@ -104,6 +104,10 @@ hipError_t afxk_hash(hipStream_t, const afx_hash_program* p, uint32_t n, uint32_
         if (p[i].records[r].w[w].field >= 0) sink += (uintptr_t)p[i].fields[p[i].records[r].w[w].field];
   return hipSuccess;
 }
+hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* p, uint32_t n, uint32_t* bad, uint32_t count) {
+  if ((uint64_t)count * n > AFX_HASH_COOP_GROUPS) return hipErrorInvalidValue;   // only small passes hash with a lane group per item
+  return afxk_hash(s, p, n, bad, count);
+}
 hipError_t afxk_finish(hipStream_t, const uint32_t*, uint8_t* status, uint32_t count, uint32_t, uint8_t) { memset(status, 0x5a, count); return hipSuccess; }
 hipError_t afxk_fill_u32(hipStream_t, uint32_t* p, uint32_t v, uint32_t n) { for (uint32_t i = 0; i < n; i++) p[i] = v; return hipSuccess; }
 hipError_t afxk_from_uniform(hipStream_t, const uint8_t*, uint8_t*, int32_t*, uint32_t) { return hipSuccess; }

@@ -1,6 +1,7 @@
 """Latency of ONE synchronous host-pointer call of each operation at small batch sizes, for the two plans
 (afx_ctx_set_small_batch_items 0 / 4096 (the default)): python tools/small_call_latency.py
 Shapes: issue n = 16 (C5's layout), show and verify the C3 shape (8 attributes, 4 hidden encrypted points)."""
+import os
 import sys
 import time
 sys.path.insert(0, ".")
@@ -25,7 +26,7 @@ iss5 = afx.Context(p5, k5, i5)
 p3, k3, i3 = bench.load_fixture("c3_8attrs_SSPPeeee")
 iss3, usr3 = afx.Context(p3, k3, i3), afx.Context(p3, None, i3)
 print("%-8s %-28s %-28s %-28s" % ("items", "issue n=16  (0 / 4096) ms", "show C3  (0 / 4096) ms", "verify C3  (0 / 4096) ms"))
-for n in (1, 16, 256, 1024):
+for n in [int(x) for x in os.environ.get("AFX_LATENCY_ITEMS", "1,16,256,1024").split(",")]:
     kinds5 = [afx.ATTR_PUBLIC_SCALAR] * 8 + [afx.ATTR_PUBLIC_POINT] * 4 + [afx.ATTR_EITHER_POINT] * 4
     vals5 = np.stack([batch.scalars_from_wide(iss5, rb(n, 64)) if i < 8 else batch.points_from_uniform(iss5, rb(n, 64)) for i in range(16)])
     tw, uw, sd = rb(n, 64), rb(n, 64), rb(n, 32)
