@@ -432,6 +432,16 @@ def test_the_three_plans_agree():
         ctx.set_challenge_trace(0, 0)
         assert np.array_equal(st, np.tile(want, reps)), name
         seen[name] = (tr, ctx.plan_stats()["msm_jobs"])
+        if name == "one chain per job":
+            # the per-presentation operation counts DESIGN.md section 3 publishes for C3 (afx_ctx_get_plan_stats of the plan of
+            # large passes); chain_*: the share of the field operations inside the inversion / square-root chains (fe10.cuh)
+            ps = ctx.plan_stats()
+            published = {"msm_jobs": 27, "doublings": 6804, "fixed_additions": 740, "table_additions": 287, "encodings": 35, "decodings": 41,
+                         "keccak_permutations": 46, "field_sq": 39796, "chain_mul": 528, "chain_sq": 12054, "secret_terms": 0}
+            assert {k: ps[k] for k in published} == published, ps
+            # the key's ten scalars run as width-5 NAF schedules: ~42 additions each, the exact number is the key's NAF weight
+            # (3182 and 55 691 products with the bench fixture's key)
+            assert 3140 <= ps["var_additions"] <= 3230 and ps["field_mul"] == 55691 + 8 * (ps["var_additions"] - 3182), ps
     ctx.close()
     assert np.array_equal(seen["one chain per job"][0], seen["one chain per term"][0]) and np.array_equal(seen["one chain per job"][0], seen["key job split"][0])
     assert seen["one chain per job"][1] < seen["key job split"][1] < seen["one chain per term"][1]   # 27 < 27 - 1 + 11 < 86
