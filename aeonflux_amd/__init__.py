@@ -79,6 +79,22 @@ class PresentationOut(C.Structure):
                [("enc", C.POINTER(EncProofOut))]
 
 
+class IssueGroup(C.Structure):
+    """afx_issue_group: the requests of one attribute layout in a mixed call (afx_issue_mixed)"""
+    _fields_ = [("requests", AttributesSoA), ("rnd", IssueRandomness), ("out", IssuanceSoA), ("count", C.c_size_t), ("positions", C.POINTER(C.c_uint64))]
+
+
+class IssuanceGroup(C.Structure):
+    """afx_issuance_group: the issuances of one layout in a mixed call (afx_verify_issuances_mixed)"""
+    _fields_ = [("attrs", AttributesSoA), ("issuances", IssuanceSoA), ("n_responses", C.c_uint32), ("count", C.c_size_t), ("positions", C.POINTER(C.c_uint64))]
+
+
+class ShowGroup(C.Structure):
+    """afx_show_group: the credentials of one layout in a mixed call (afx_show_mixed)"""
+    _fields_ = [("creds", CredentialsSoA), ("keypairs", C.POINTER(KeypairsSoA)), ("rnd", ShowRandomness), ("out", PresentationOut), ("shape_out", Shape),
+                ("count", C.c_size_t), ("positions", C.POINTER(C.c_uint64))]
+
+
 _LIB = None
 
 
@@ -137,6 +153,9 @@ def lib():
         _LIB.afx_verify_presentations_mixed_wire.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         for name in ("afx_verify_presentations_mixed", "afx_group_verify_presentations_mixed"):
             getattr(_LIB, name).argtypes = [C.c_void_p, C.POINTER(PresentationGroup), C.c_size_t, C.c_void_p, C.c_size_t]
+        for name, grp in (("afx_issue_mixed", IssueGroup), ("afx_group_issue_mixed", IssueGroup), ("afx_verify_issuances_mixed", IssuanceGroup),
+                          ("afx_group_verify_issuances_mixed", IssuanceGroup), ("afx_show_mixed", ShowGroup), ("afx_group_show_mixed", ShowGroup)):
+            getattr(_LIB, name).argtypes = [C.c_void_p, C.POINTER(grp), C.c_size_t, C.c_void_p, C.c_size_t]
         _LIB.afx_ctx_set_pipelining.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_get_plan_stats.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.afx_ctx_set_strict.argtypes = [C.c_void_p, C.c_int]

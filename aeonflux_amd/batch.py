@@ -8,8 +8,8 @@ import ctypes as C
 
 import numpy as np
 
-from . import (AttributesSoA, CredentialsSoA, EncProofOut, EncProofSoA, IssuanceSoA, IssueRandomness, KeypairsSoA,
-               PresentationOut, PresentationSoA, Shape, ShowRandomness, check, lib)
+from . import (AttributesSoA, CredentialsSoA, EncProofOut, EncProofSoA, IssuanceGroup, IssuanceSoA, IssueGroup, IssueRandomness, KeypairsSoA,
+               PresentationOut, PresentationSoA, Shape, ShowGroup, ShowRandomness, check, lib)
 
 ENC_FIELDS = ("challenge", "responses", "pk", "E1", "E2", "C_y_1", "C_y_2", "C_y_3", "C_y_2p")
 PRES_FIELDS = ("challenge", "responses", "C_x_0", "C_x_1", "C_V", "C_y", "attr_values")
@@ -29,17 +29,23 @@ def _attrs(kinds, values):
     return s
 
 
-def issue(ctx, kinds, values, t_wide, U_wide, rng_seed, first=None, n=None):
-    """Issuer::issue over a batch.  values [n,count,32], t_wide/U_wide [count,64], rng_seed [count,32].
-    Returns (dict(t,U,V,challenge,responses[n+5,count,32]), status[count]).  ctx may be a Group (all its GPUs); with
-    first/n only that range of the batch is issued (afx_issue_range; the other output rows stay zero / status 255)."""
+def _issue_args(n_ctx, kinds, values, t_wide, U_wide, rng_seed):
+    """(AttributesSoA, IssueRandomness, IssuanceSoA, output dict, count, keepalive) of one layout's requests"""
     values, t_wide, U_wide, rng_seed = map(_u8, (values, t_wide, U_wide, rng_seed))
     cnt = t_wide.shape[0]
     req = _attrs(kinds, values)
     rnd = IssueRandomness(t_wide.ctypes.data, U_wide.ctypes.data, rng_seed.ctypes.data)
     o = {k: np.zeros((cnt, 32), np.uint8) for k in ("t", "U", "V", "challenge")}
-    o["responses"] = np.zeros((ctx.n + 5, cnt, 32), np.uint8)
+    o["responses"] = np.zeros((n_ctx + 5, cnt, 32), np.uint8)
     out = IssuanceSoA(*(o[k].ctypes.data for k in ("t", "U", "V", "challenge", "responses")))
+    return req, rnd, out, o, cnt, (values, t_wide, U_wide, rng_seed)
+
+
+def issue(ctx, kinds, values, t_wide, U_wide, rng_seed, first=None, n=None):
+    """Issuer::issue over a batch.  values [n,count,32], t_wide/U_wide [count,64], rng_seed [count,32].
+    Returns (dict(t,U,V,challenge,responses[n+5,count,32]), status[count]).  ctx may be a Group (all its GPUs); with
+    first/n only that range of the batch is issued (afx_issue_range; the other output rows stay zero / status 255)."""
+    req, rnd, out, o, cnt, keep = _issue_args(ctx.n, kinds, values, t_wide, U_wide, rng_seed)
     status = np.full(cnt, 255, np.uint8)
     if first is not None:
         check(lib().afx_issue_range(ctx.h, C.byref(req), C.byref(rnd), cnt, first, n, C.byref(out), status.ctypes.data))
@@ -50,16 +56,54 @@ def issue(ctx, kinds, values, t_wide, U_wide, rng_seed, first=None, n=None):
     return o, status
 
 
-def verify_issuances(ctx, kinds, values, issuance, n_responses=None, first=None, n=None):
-    """CredentialIssuance::verify over a batch; issuance = dict as returned by issue().  ctx may be a Group; with first/n only
-    that range is verified (afx_verify_issuances_range; the other status bytes stay 255)."""
+def _positions(items, total=None):
+    """per group: its items' places in the caller's order.  An item may carry "positions"; otherwise the groups are contiguous."""
+    out, nxt = [], 0
+    for it, cnt in items:
+        pos = np.ascontiguousarray(it["positions"], dtype=np.uint64) if it.get("positions") is not None else np.arange(nxt, nxt + cnt, dtype=np.uint64)
+        assert pos.size == cnt
+        out.append(pos)
+        nxt += cnt
+    return out, nxt
+
+
+def issue_mixed(ctx, items):
+    """Issuer::issue over requests of DIFFERENT attribute layouts in one call (afx_issue_mixed / afx_group_issue_mixed).
+    items = [dict(kinds, values [n,count,32], t_wide, U_wide, rng_seed, positions=None)], one per layout group (layouts may
+    repeat).  Returns ([output dict per group], status in the caller's order)."""
+    arr = (IssueGroup * max(1, len(items)))()
+    keep, outs, counts = [], [], []
+    for g, it in enumerate(items):
+        req, rnd, out, o, cnt, k = _issue_args(ctx.n, it["kinds"], it["values"], it["t_wide"], it["U_wide"], it["rng_seed"])
+        arr[g].requests, arr[g].rnd, arr[g].out, arr[g].count = req, rnd, out, cnt
+        keep.append(k)
+        outs.append(o)
+        counts.append(cnt)
+    pos, total = _positions(list(zip(items, counts)))
+    total = max([total] + [int(p.max()) + 1 for p in pos if p.size])
+    for g, p in enumerate(pos):
+        arr[g].positions = p.ctypes.data_as(C.POINTER(C.c_uint64))
+    status = np.full(total, 255, np.uint8)
+    fn = lib().afx_group_issue_mixed if hasattr(ctx, "member") else lib().afx_issue_mixed
+    check(fn(ctx.h, arr, len(items), status.ctypes.data, total))
+    return outs, status
+
+
+def _issuance_args(kinds, values, issuance, n_responses=None):
     values = _u8(values)
     iss = {k: _u8(issuance[k]) for k in ("t", "U", "V", "challenge", "responses")}
     cnt = iss["t"].shape[0]
     req = _attrs(kinds, values)
     s = IssuanceSoA(*(iss[k].ctypes.data for k in ("t", "U", "V", "challenge", "responses")))
-    status = np.full(cnt, 255, np.uint8)
     nr = iss["responses"].shape[0] if n_responses is None else n_responses
+    return req, s, nr, cnt, (values, iss)
+
+
+def verify_issuances(ctx, kinds, values, issuance, n_responses=None, first=None, n=None):
+    """CredentialIssuance::verify over a batch; issuance = dict as returned by issue().  ctx may be a Group; with first/n only
+    that range is verified (afx_verify_issuances_range; the other status bytes stay 255)."""
+    req, s, nr, cnt, keep = _issuance_args(kinds, values, issuance, n_responses)
+    status = np.full(cnt, 255, np.uint8)
     if first is not None:
         check(lib().afx_verify_issuances_range(ctx.h, C.byref(req), C.byref(s), nr, cnt, first, n, status.ctypes.data))
     elif hasattr(ctx, "member"):
@@ -69,11 +113,28 @@ def verify_issuances(ctx, kinds, values, issuance, n_responses=None, first=None,
     return status
 
 
-def show(ctx, kinds, values, t, U, V, keypairs, z_wide, rng_seed, enc_seeds=None, M2=None, m3=None, first=None, n_items=None):
-    """AnonymousCredential::show over a batch.  kinds: AFX_ATTR_* after hide/reveal.  values/M2/m3 [n,count,32];
-    keypairs: dict(a,a0,a1,pk -> [count,32]) or None; enc_seeds [#secret points, count, 32].
-    Returns (presentation dict incl. 'enc' list, Shape, status).  ctx may be a Group; with first/n_items only that range
-    of the batch is shown (afx_show_range; the other output rows stay zero / status 255)."""
+def verify_issuances_mixed(ctx, items):
+    """CredentialIssuance::verify over issuances of DIFFERENT layouts in one call.  items = [dict(kinds, values, issuance,
+    n_responses=None, positions=None)].  Returns the statuses in the caller's order."""
+    arr = (IssuanceGroup * max(1, len(items)))()
+    keep, counts = [], []
+    for g, it in enumerate(items):
+        req, s, nr, cnt, k = _issuance_args(it["kinds"], it["values"], it["issuance"], it.get("n_responses"))
+        arr[g].attrs, arr[g].issuances, arr[g].n_responses, arr[g].count = req, s, nr, cnt
+        keep.append(k)
+        counts.append(cnt)
+    pos, total = _positions(list(zip(items, counts)))
+    total = max([total] + [int(p.max()) + 1 for p in pos if p.size])
+    for g, p in enumerate(pos):
+        arr[g].positions = p.ctypes.data_as(C.POINTER(C.c_uint64))
+    status = np.full(total, 255, np.uint8)
+    fn = lib().afx_group_verify_issuances_mixed if hasattr(ctx, "member") else lib().afx_verify_issuances_mixed
+    check(fn(ctx.h, arr, len(items), status.ctypes.data, total))
+    return status
+
+
+def _show_args(kinds, values, t, U, V, keypairs, z_wide, rng_seed, enc_seeds=None, M2=None, m3=None):
+    """(CredentialsSoA, KeypairsSoA or None, ShowRandomness, PresentationOut, output dict, count, keepalive) of one layout's credentials"""
     n = len(kinds)
     values, t, U, V, z_wide, rng_seed = map(_u8, (values, t, U, V, z_wide, rng_seed))
     cnt = t.shape[0]
@@ -110,6 +171,16 @@ def show(ctx, kinds, values, t, U, V, keypairs, z_wide, rng_seed, enc_seeds=None
     for f in PRES_FIELDS:
         setattr(out, f, o[f].ctypes.data)
     out.enc = C.cast(eouts, C.POINTER(EncProofOut))
+    keep.append(eouts)
+    return cs, kp, rnd, out, o, cnt, keep
+
+
+def show(ctx, kinds, values, t, U, V, keypairs, z_wide, rng_seed, enc_seeds=None, M2=None, m3=None, first=None, n_items=None):
+    """AnonymousCredential::show over a batch.  kinds: AFX_ATTR_* after hide/reveal.  values/M2/m3 [n,count,32];
+    keypairs: dict(a,a0,a1,pk -> [count,32]) or None; enc_seeds [#secret points, count, 32].
+    Returns (presentation dict incl. 'enc' list, Shape, status).  ctx may be a Group; with first/n_items only that range
+    of the batch is shown (afx_show_range; the other output rows stay zero / status 255)."""
+    cs, kp, rnd, out, o, cnt, keep = _show_args(kinds, values, t, U, V, keypairs, z_wide, rng_seed, enc_seeds, M2, m3)
     shape = Shape()
     status = np.full(cnt, 255, np.uint8)
     kpp = C.byref(kp) if kp is not None else None
@@ -120,6 +191,31 @@ def show(ctx, kinds, values, t, U, V, keypairs, z_wide, rng_seed, enc_seeds=None
     else:
         check(lib().afx_show(ctx.h, C.byref(cs), kpp, C.byref(rnd), cnt, C.byref(out), C.byref(shape), status.ctypes.data))
     return o, shape, status
+
+
+def show_mixed(ctx, items):
+    """AnonymousCredential::show over credentials of DIFFERENT layouts in one call (afx_show_mixed / afx_group_show_mixed).
+    items = [dict(kinds, values, t, U, V, keypairs, z_wide, rng_seed, enc_seeds=None, M2=None, m3=None, positions=None)].
+    Returns ([(presentation dict, Shape) per group], status in the caller's order)."""
+    arr = (ShowGroup * max(1, len(items)))()
+    keep, outs, counts = [], [], []
+    for g, it in enumerate(items):
+        cs, kp, rnd, out, o, cnt, k = _show_args(it["kinds"], it["values"], it["t"], it["U"], it["V"], it.get("keypairs"), it["z_wide"], it["rng_seed"],
+                                                 it.get("enc_seeds"), it.get("M2"), it.get("m3"))
+        arr[g].creds, arr[g].rnd, arr[g].out, arr[g].count = cs, rnd, out, cnt
+        if kp is not None:
+            arr[g].keypairs = C.pointer(kp)
+        keep.append((k, kp))
+        outs.append(o)
+        counts.append(cnt)
+    pos, total = _positions(list(zip(items, counts)))
+    total = max([total] + [int(p.max()) + 1 for p in pos if p.size])
+    for g, p in enumerate(pos):
+        arr[g].positions = p.ctypes.data_as(C.POINTER(C.c_uint64))
+    status = np.full(total, 255, np.uint8)
+    fn = lib().afx_group_show_mixed if hasattr(ctx, "member") else lib().afx_show_mixed
+    check(fn(ctx.h, arr, len(items), status.ctypes.data, total))
+    return [(o, Shape.from_buffer_copy(bytes(arr[g].shape_out))) for g, o in enumerate(outs)], status
 
 
 def presentation_soa(p, ptr=lambda a: a.ctypes.data):

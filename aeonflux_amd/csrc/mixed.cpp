@@ -17,41 +17,43 @@ std::string shape_key(const afx_shape& sh) {
 uint32_t rd32(const uint8_t* b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); }
 
 // positions given: each < status_len and used once over all groups; not given: contiguous after the groups before
-int check_positions(const afx_presentation_group* groups, size_t n_groups, size_t status_len) {
+template <class G>
+int check_positions(const G* groups, size_t n_groups, size_t status_len) {
   std::vector<uint8_t> used(status_len, 0);
   size_t next = 0;
   for (size_t g = 0; g < n_groups; g++) {
-    const afx_presentation_group& G = groups[g];
-    for (size_t i = 0; i < G.count; i++) {
-      const uint64_t p = G.positions ? G.positions[i] : (uint64_t)(next + i);
+    const G& grp = groups[g];
+    for (size_t i = 0; i < grp.count; i++) {
+      const uint64_t p = grp.positions ? grp.positions[i] : (uint64_t)(next + i);
       if (p >= status_len) { set_error("group " + std::to_string(g) + ": position outside the status array"); return AFX_E_BAD_ARGS; }
       if (used[p]) { set_error("group " + std::to_string(g) + ": a status position is used twice"); return AFX_E_BAD_ARGS; }
       used[p] = 1;
     }
-    next += G.count;
+    next += grp.count;
   }
   return AFX_OK;
 }
 
-template <class VerifyOne>
-int verify_groups(const afx_presentation_group* groups, size_t n_groups, uint8_t* status, size_t status_len, VerifyOne&& verify_one) {
+// one ordinary batch call per group (`run_one(group, its status bytes)`), status bytes back to the caller's order
+template <class G, class RunOne>
+int run_groups(G* groups, size_t n_groups, uint8_t* status, size_t status_len, RunOne&& run_one) {
   if ((!groups && n_groups) || (!status && status_len)) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   int rc = check_positions(groups, n_groups, status_len);
   if (rc) return rc;
   std::vector<uint8_t> tmp;
   size_t next = 0;
   for (size_t g = 0; g < n_groups; g++) {
-    const afx_presentation_group& G = groups[g];
-    if (G.count) {
-      if (!G.positions) {
-        if ((rc = verify_one(G, status + next))) return rc;
+    G& grp = groups[g];
+    if (grp.count) {
+      if (!grp.positions) {
+        if ((rc = run_one(grp, status + next))) { set_error("group " + std::to_string(g) + ": " + afx_last_error()); return rc; }
       } else {
-        tmp.assign(G.count, AFX_ST_VERIFICATION_FAILURE);
-        if ((rc = verify_one(G, tmp.data()))) return rc;
-        for (size_t i = 0; i < G.count; i++) status[G.positions[i]] = tmp[i];
+        tmp.assign(grp.count, AFX_ST_VERIFICATION_FAILURE);
+        if ((rc = run_one(grp, tmp.data()))) { set_error("group " + std::to_string(g) + ": " + afx_last_error()); return rc; }
+        for (size_t i = 0; i < grp.count; i++) status[grp.positions[i]] = tmp[i];
       }
     }
-    next += G.count;
+    next += grp.count;
   }
   return AFX_OK;
 }
@@ -61,7 +63,7 @@ int verify_groups(const afx_presentation_group* groups, size_t n_groups, uint8_t
 extern "C" int afx_verify_presentations_mixed(afx_ctx* ctx, const afx_presentation_group* groups, size_t n_groups, uint8_t* status,
                                               size_t status_len) try {
   if (!ctx) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return verify_groups(groups, n_groups, status, status_len, [&](const afx_presentation_group& G, uint8_t* st) {
+  return run_groups(groups, n_groups, status, status_len, [&](const afx_presentation_group& G, uint8_t* st) {
     return afx_verify_presentations(ctx, &G.shape, &G.batch, G.count, st);
   });
 } catch (...) { return afx::exception_rc(); }
@@ -69,8 +71,50 @@ extern "C" int afx_verify_presentations_mixed(afx_ctx* ctx, const afx_presentati
 extern "C" int afx_group_verify_presentations_mixed(afx_group* group, const afx_presentation_group* groups, size_t n_groups, uint8_t* status,
                                                     size_t status_len) try {
   if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return verify_groups(groups, n_groups, status, status_len, [&](const afx_presentation_group& G, uint8_t* st) {
+  return run_groups(groups, n_groups, status, status_len, [&](const afx_presentation_group& G, uint8_t* st) {
     return afx_group_verify_presentations(group, &G.shape, &G.batch, G.count, st);
+  });
+} catch (...) { return afx::exception_rc(); }
+
+// Issuer::issue over requests of several attribute layouts (/root/reference/src/issuer.rs:111-124; kinds per attribute: src/amacs.rs:168-179)
+extern "C" int afx_issue_mixed(afx_ctx* ctx, const afx_issue_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
+  if (!ctx) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  return run_groups(groups, n_groups, status, status_len, [&](const afx_issue_group& G, uint8_t* st) {
+    return afx_issue(ctx, &G.requests, &G.rnd, G.count, &G.out, st);
+  });
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_group_issue_mixed(afx_group* group, const afx_issue_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
+  if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  return run_groups(groups, n_groups, status, status_len, [&](const afx_issue_group& G, uint8_t* st) {
+    return afx_group_issue(group, &G.requests, &G.rnd, G.count, &G.out, st);
+  });
+} catch (...) { return afx::exception_rc(); }
+
+// CredentialIssuance::verify over issuances of several layouts (src/issuer.rs:48-57)
+extern "C" int afx_verify_issuances_mixed(afx_ctx* ctx, const afx_issuance_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
+  if (!ctx) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  return run_groups(groups, n_groups, status, status_len, [&](const afx_issuance_group& G, uint8_t* st) {
+    return afx_verify_issuances(ctx, &G.attrs, &G.issuances, G.n_responses, G.count, st);
+  });
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_group_verify_issuances_mixed(afx_group* group, const afx_issuance_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
+  if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  return run_groups(groups, n_groups, status, status_len, [&](const afx_issuance_group& G, uint8_t* st) {
+    return afx_group_verify_issuances(group, &G.attrs, &G.issuances, G.n_responses, G.count, st);
+  });
+} catch (...) { return afx::exception_rc(); }
+
+// AnonymousCredential::show over credentials of several layouts (src/credential.rs:37-46); every group reports its own shape
+extern "C" int afx_show_mixed(afx_ctx* ctx, afx_show_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
+  if (!ctx) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  return run_groups(groups, n_groups, status, status_len, [&](afx_show_group& G, uint8_t* st) {
+    return afx_show(ctx, &G.creds, G.keypairs, &G.rnd, G.count, &G.out, &G.shape_out, st);
+  });
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_group_show_mixed(afx_group* group, afx_show_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
+  if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  return run_groups(groups, n_groups, status, status_len, [&](afx_show_group& G, uint8_t* st) {
+    return afx_group_show(group, &G.creds, G.keypairs, &G.rnd, G.count, &G.out, &G.shape_out, st);
   });
 } catch (...) { return afx::exception_rc(); }
 

@@ -465,6 +465,47 @@ int afx_group_show(afx_group* group, const afx_credentials_soa* creds, const afx
                    const afx_show_randomness* rnd, size_t count, const afx_presentation_out* out, afx_shape* shape_out,
                    uint8_t* status);
 
+/* ---- requests, credentials and issuances of DIFFERENT layouts in one call -------------------------------------------
+ * Issuer::issue takes any request (src/issuer.rs:111-124: the attribute kinds are per attribute, src/amacs.rs:168-179),
+ * AnonymousCredential::show any credential in whatever state its hide_attribute / reveal_attribute calls left it
+ * (src/credential.rs:37-46, :53-97) and CredentialIssuance::verify any issuance (src/issuer.rs:48-57).  As for
+ * afx_verify_presentations_mixed above, the caller hands over one struct-of-arrays group per distinct layout; each group has its
+ * own input AND output arrays ([k][count][32], item i of the group in element i), and only the status bytes go back to the
+ * caller's order: status[positions[i]] answers item i of the group (positions == NULL: contiguous, after the groups before it;
+ * every index < status_len and used once over all groups - checked before anything runs).  Groups may repeat a layout.  Small
+ * groups are assembled into ONE set of kernel launches (mixed.cpp), so a stream of many layouts costs about one small call. */
+typedef struct {
+  afx_attributes_soa requests;   /* n_attributes != ctx n => the group's statuses are all MAC_CREATION (amacs.rs:285-287)      */
+  afx_issue_randomness rnd;
+  afx_issuance_soa out;          /* the group's own output arrays; responses [ctx n + 5][count][32]                           */
+  size_t count;
+  const uint64_t* positions;     /* [count] or NULL                                                                           */
+} afx_issue_group;
+int afx_issue_mixed(afx_ctx* ctx, const afx_issue_group* groups, size_t n_groups, uint8_t* status, size_t status_len);
+int afx_group_issue_mixed(afx_group* group, const afx_issue_group* groups, size_t n_groups, uint8_t* status, size_t status_len);
+
+typedef struct {
+  afx_attributes_soa attrs;
+  afx_issuance_soa issuances;    /* read only here                                                                            */
+  uint32_t n_responses;          /* proof.responses.len() of the group's issuances                                            */
+  size_t count;
+  const uint64_t* positions;
+} afx_issuance_group;
+int afx_verify_issuances_mixed(afx_ctx* ctx, const afx_issuance_group* groups, size_t n_groups, uint8_t* status, size_t status_len);
+int afx_group_verify_issuances_mixed(afx_group* group, const afx_issuance_group* groups, size_t n_groups, uint8_t* status, size_t status_len);
+
+typedef struct {
+  afx_credentials_soa creds;
+  const afx_keypairs_soa* keypairs;  /* or NULL (see afx_show)                                                                */
+  afx_show_randomness rnd;
+  afx_presentation_out out;          /* the group's own output arrays                                                         */
+  afx_shape shape_out;               /* written: the presentation shape of this group                                         */
+  size_t count;
+  const uint64_t* positions;
+} afx_show_group;
+int afx_show_mixed(afx_ctx* ctx, afx_show_group* groups, size_t n_groups, uint8_t* status, size_t status_len);
+int afx_group_show_mixed(afx_group* group, afx_show_group* groups, size_t n_groups, uint8_t* status, size_t status_len);
+
 /* ---- setup helpers (cold path; still GPU arithmetic) ---------------------------------------- */
 
 /* IssuerParameters::generate (src/parameters.rs:349-362) and W = w*G_w (src/amacs.rs:104): given

@@ -84,6 +84,27 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     assert afx.lib().afx_wire_section_bytes(mixed_stream, len(blob) - 1, C.byref(sl)) == afx.E_BAD_ARGS
     got = batch.verify_mixed(ctx, [(shape, pres), (sh2, pres2), (shape, pres)])
     assert [g.tolist() for g in got] == [[0x5a] * 3] * 3
+    # requests / issuances / credentials of several layouts in one call, statuses scattered to the caller's order; a position used
+    # twice or outside the status array is refused before anything runs
+    kflip = [2 if k == 0 else k for k in kinds]
+    ia = dict(kinds=kinds, values=values, t_wide=rb(3, 64), U_wide=rb(3, 64), rng_seed=rb(3, 32), positions=[4, 0, 2])
+    ib = dict(kinds=kflip, values=values, t_wide=rb(3, 64), U_wide=rb(3, 64), rng_seed=rb(3, 32), positions=[1, 3, 5])
+    outs_m, st_m = batch.issue_mixed(ctx, [ia, ib])
+    assert st_m.tolist() == [0x5a] * 6 and len(outs_m) == 2 and outs_m[1]["responses"].shape == (n + 5, 3, 32)
+    for bad_pos in ([1, 3, 4], [1, 1, 5]):
+        try:
+            batch.issue_mixed(ctx, [ia, dict(ib, positions=bad_pos)])
+            raise SystemExit("bad positions accepted")
+        except (afx.AfxError, AssertionError) as ex:
+            assert getattr(ex, "rc", afx.E_BAD_ARGS) == afx.E_BAD_ARGS
+    st_m = batch.verify_issuances_mixed(ctx, [dict(kinds=kinds, values=values, issuance=iss, positions=[5, 4, 3]),
+                                              dict(kinds=kflip, values=values, issuance=iss, n_responses=2, positions=[0, 1, 2])])
+    assert st_m.tolist() == [1, 1, 1, 0x5a, 0x5a, 0x5a]   # the group with the wrong response count fails whole, on the host
+    sa = dict(kinds=k2, values=values, t=iss["t"], U=iss["U"], V=iss["V"], keypairs=kp, z_wide=rb(3, 64), rng_seed=rb(3, 32), enc_seeds=rb(max(nsp, 1), 3, 32),
+              M2=values, m3=values, positions=[0, 2, 4])
+    sb = dict(sa, kinds=list(kinds), enc_seeds=None, positions=[1, 3, 5])
+    outs_s, st_s = batch.show_mixed(ctx, [sa, sb])
+    assert st_s.tolist() == [0x5a] * 6 and bytes(outs_s[0][1]) == bytes(shape) and outs_s[1][1].n_enc_proofs == 0
     # mis-shaped requests take the fail-all path
     bad = afx.Shape.from_buffer_copy(bytes(shape))
     bad.n_responses += 1   # claims a row the arrays do not have: must be rejected without reading them
@@ -155,6 +176,9 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     assert len(grp) == 2 and grp.member(1).n == n
     assert len(batch.verify_presentations(grp, shape, pres)) == 3
     assert [g.tolist() for g in batch.verify_mixed(grp, [(sh2, pres2), (shape, pres)])] == [[0x5a] * 3] * 2
+    assert batch.issue_mixed(grp, [ia, ib])[1].tolist() == [0x5a] * 6
+    assert batch.show_mixed(grp, [sa, sb])[1].tolist() == [0x5a] * 6
+    assert batch.verify_issuances_mixed(grp, [dict(kinds=kinds, values=values, issuance=iss)]).tolist() == [0x5a] * 3
     assert wire.verify_wire(grp, blob).tolist() == [0x5a] * 3 and wire.verify_mixed_wire(grp, mixed_stream).tolist() == [0x5a] * 9
     assert wire.verify_wire(ctx, blob, first=1, n=2).tolist() == [255, 0x5a, 0x5a]
     try:
