@@ -60,9 +60,12 @@ void DevBuf::release(bool wipe) {
 // ------------------------------------------------------------------------------------------------
 // Assembler
 // ------------------------------------------------------------------------------------------------
+// memset that the optimiser may not drop (the byte-by-byte volatile loop this replaces was 43 % of a small call's host time:
+// an Assembler wipes its ~150 KB plan blob on destruction)
 static void secure_zero(void* p, size_t n) {
-  volatile uint8_t* q = (volatile uint8_t*)p;
-  for (size_t i = 0; i < n; i++) q[i] = 0;
+  if (!n) return;
+  memset(p, 0, n);
+  __asm__ __volatile__("" : : "r"(p) : "memory");
 }
 Assembler::~Assembler() { secure_zero(blob_.data(), blob_.size()); }
 Assembler::Assembler(afx_ctx* c, uint32_t cnt, bool sizing, int ln) : ctx(c), lane(ln), count(cnt), sizing_(sizing) {
@@ -788,11 +791,32 @@ static void order_terms(afx_msm_job& j, const std::vector<afx_msm_term>& terms) 
   for (const afx_msm_term& t : terms) if (t.fixed_idx >= 0) j.term[k++] = t;
 }
 afx_hash_program SchnorrBuilder::make_program(const StrobeSim& sim) {
+  // The transcript's leading all-constant blocks are applied on the host, once per distinct prefix and context (SURVEY.md section 7
+  // step 4): the device starts from the folded state.  A prover's prefix can hold key material (witnesses rekey the rng clone,
+  // zkp's TranscriptRngBuilder): the cache is wiped with the context, the state travels in the plan blob like the constants did.
+  const size_t k = sim.constant_prefix();
+  uint64_t folded[25];
+  if (k == 0) memcpy(folded, sim.init_state, sizeof folded);
+  else {
+    std::string key;
+    sim.prefix_key(k, key);
+    afx_ctx* c = as_.ctx;
+    auto hit = c->folded_states.find(key);
+    if (hit == c->folded_states.end()) {
+      sim.fold_prefix(k, folded);
+      std::array<uint64_t, 25> a;
+      memcpy(a.data(), folded, sizeof folded);
+      if (c->folded_states.size() < 1024) c->folded_states.emplace(key, a);
+      secure_zero(a.data(), sizeof folded);
+    } else memcpy(folded, hit->second.data(), sizeof folded);
+    secure_zero(&key[0], key.size());
+  }
   std::vector<afx_hash_record> recs;
-  sim.emit(recs);
+  sim.emit(recs, k);
   afx_hash_program p;
   memset(&p, 0, sizeof p);
-  p.init_state = as_.put(sim.init_state, 25);
+  p.init_state = as_.put(folded, 25);
+  secure_zero(folded, sizeof folded);
   p.n_records = (uint32_t)recs.size();
   p.records = as_.put(recs.data(), recs.size());
   p.fields = as_.put(fields_.data(), fields_.size());

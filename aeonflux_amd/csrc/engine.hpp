@@ -110,6 +110,8 @@ struct afx_ctx {
   uint32_t chunk_items = 0;   // afx_ctx_set_chunk_items; 0 = default
   uint32_t small_batch_items = 4096;   // afx_ctx_set_small_batch_items: passes of at most this many items take the latency plan
   afx_plan_stats last_stats = {};   // per-item operation counts of the most recent plan
+  std::map<std::string, std::array<uint64_t, 25>> folded_states;   // STROBE state after a transcript's all-constant leading blocks, by those blocks' bytes
+                                                                   // (SchnorrBuilder::make_program); may derive from the key: wiped on destroy
   std::map<std::pair<std::string, uint32_t>, size_t> plan_sizes;   // (plan key bytes, pass size) -> workspace bytes (statements.hpp run_chunked)
   uint32_t n_cu = 256;   // compute units of the device (k_msm keeps 2 blocks resident on each)
   // parity aid (afx_ctx_set_challenge_trace): device array [trace_rows][trace_count][32] receiving every recomputed challenge

@@ -217,6 +217,13 @@ extern "C" void afx_ctx_destroy(afx_ctx* c) {
   for (auto& t : c->timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   for (auto& k : c->host_key) { volatile uint8_t* p = k.data(); for (int i = 0; i < 32; i++) p[i] = 0; }
+  // folded transcript states of prover plans derive from the key (and their cache keys hold the witnesses' bytes)
+  for (auto& kv : c->folded_states) {
+    volatile uint8_t* p = (volatile uint8_t*)kv.second.data();
+    for (size_t i = 0; i < sizeof(uint64_t) * 25; i++) p[i] = 0;
+    volatile char* q = const_cast<volatile char*>(kv.first.data());
+    for (size_t i = 0; i < kv.first.size(); i++) q[i] = 0;
+  }
   for (auto& L : c->lane)
     if (L.stream) (void)hipStreamDestroy(L.stream);
   delete c;

@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdexcept>
+#include <string>
 #include <vector>
 #include "plan.h"
 
@@ -69,16 +70,24 @@ class StrobeSim {
 
   // Strobe128::new(label) then merlin Transcript::new(label): init_state is concrete, the rest is recorded.
   explicit StrobeSim(const char* merlin_label) {
-    uint8_t st[200];
-    memset(st, 0, sizeof st);
-    const uint8_t hdr[6] = { 1, R + 2, 1, 0, 1, 96 };
-    memcpy(st, hdr, 6);
-    memcpy(st + 6, "STROBEv1.0.2", 12);
-    for (int i = 0; i < 25; i++) {
-      init_state[i] = 0;
-      for (int j = 0; j < 8; j++) init_state[i] |= (uint64_t)st[8 * i + j] << (8 * j);
-    }
-    keccak_f1600_host(init_state);
+    // the state after Strobe128::new's permutation is one constant: computed once per process
+    struct Init {
+      uint64_t w[25];
+      Init() {
+        uint8_t st[200];
+        memset(st, 0, sizeof st);
+        const uint8_t hdr[6] = { 1, R + 2, 1, 0, 1, 96 };
+        memcpy(st, hdr, 6);
+        memcpy(st + 6, "STROBEv1.0.2", 12);
+        for (int i = 0; i < 25; i++) {
+          w[i] = 0;
+          for (int j = 0; j < 8; j++) w[i] |= (uint64_t)st[8 * i + j] << (8 * j);
+        }
+        keccak_f1600_host(w);
+      }
+    };
+    static const Init init;
+    memcpy(init_state, init.w, sizeof init_state);
     meta_ad_const((const uint8_t*)"Merlin v1.0", 11, false);
     append_message_const("dom-sep", (const uint8_t*)merlin_label, strlen(merlin_label));
   }
@@ -122,9 +131,42 @@ class StrobeSim {
   void absorb_const(const uint8_t* d, size_t n) { for (size_t i = 0; i < n; i++) absorb_sym(d[i], -1, 0); }
   void absorb_hole32(int field) { for (int i = 0; i < 32; i++) absorb_sym(0, field, (uint8_t)i); }
 
-  // translate completed records (and nothing else) to device form
-  void emit(std::vector<afx_hash_record>& out) const {
-    for (const SimRecord& r : records) out.push_back(to_device(r));
+  // translate completed records [from, end) (and nothing else) to device form
+  void emit(std::vector<afx_hash_record>& out, size_t from = 0) const {
+    for (size_t i = from; i < records.size(); i++) out.push_back(to_device(records[i]));
+  }
+  // How many leading records act on the state with constants only (no per-item hole, nothing squeezed): labels, lengths, domain
+  // separators and batch-constant points - the same for every item, so the host applies them once (fold_prefix) instead of every
+  // lane permuting through them (an issuance transcript opens with ~1.8 KB of such bytes: 10 of its 79 permutations).
+  size_t constant_prefix() const {
+    size_t k = 0;
+    for (; k < records.size(); k++) {
+      const SimRecord& r = records[k];
+      if (r.squeeze != AFX_SQ_NONE) break;
+      bool hole = false;
+      for (int t = 0; t < 168 && !hole; t++) hole = r.b[t].field >= 0;
+      if (hole) break;
+    }
+    return k;
+  }
+  // the bytes that determine fold_prefix's result: the key of the context's cache of folded states
+  void prefix_key(size_t k, std::string& key) const {
+    key.assign((const char*)init_state, sizeof init_state);
+    for (size_t i = 0; i < k; i++)
+      for (int t = 0; t < 168; t++) { key.push_back((char)records[i].b[t].c); key.push_back(records[i].b[t].overwrite ? 1 : 0); }
+  }
+  // state after the first k records, exactly as k_hash would compute it: st = (st & keep) ^ c per byte, then Keccak-f
+  void fold_prefix(size_t k, uint64_t st[25]) const {
+    memcpy(st, init_state, sizeof init_state);
+    for (size_t i = 0; i < k; i++) {
+      for (int t = 0; t < 168; t++) {
+        const SymByte& s = records[i].b[t];
+        const int sh = 8 * (t & 7);
+        if (s.overwrite) st[t >> 3] &= ~(0xffULL << sh);
+        st[t >> 3] ^= (uint64_t)s.c << sh;
+      }
+      keccak_f1600_host(st);
+    }
   }
 
  private:
