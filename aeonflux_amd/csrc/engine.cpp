@@ -271,7 +271,18 @@ void Assembler::compress(const std::vector<afx_compress_job>& cjobs, uint32_t gr
 // passes (at most afx_ctx_set_small_batch_items items, default 4096): the device is mostly idle and a call's duration is the
 // LONGEST chain, so every variable-base term gets a chain of its own (msm_split).
 void Assembler::msm(std::vector<afx_msm_job> jobs) {
-  if (jobs.empty()) return;
+  if (jobs.empty()) {
+    // encodings queued by compress_also() ride in this call's k_compress2x launch even when it has no chains of its own
+    if (!pending_cjobs_.empty()) {
+      for (const int32_t* v : pending_half_vars_)
+        if (!half_bases_.count(v)) throw std::logic_error("compress_also: the variable does not hold a half");
+      pending_half_vars_.clear();
+      std::vector<afx_compress_job> cjobs;
+      cjobs.swap(pending_cjobs_);
+      compress(cjobs, small() ? 8u : 1u);
+    }
+    return;
+  }
   for (size_t i = 0; i < jobs.size(); i++)
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= jobs.size() || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
   // Secret-independent addressing (afx_ctx_set_secret_independent_addressing): which terms carry a secret scalar.  In a prover-side
@@ -287,6 +298,10 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     if (j.leave_half && !(j.out_var && j.out_enc && !j.addend && !j.half_var)) j.leave_half = 0;   // nothing to gain or not possible
     if (j.leave_half) half_bases_.insert(j.out_var);
   }
+  // compress_also() encodes +-2 * var: var must be (or become, in this call) a half some job left - never a whole point
+  for (const int32_t* v : pending_half_vars_)
+    if (!half_bases_.count(v)) throw std::logic_error("compress_also: the variable does not hold a half (its producer's leave_half was dropped)");
+  pending_half_vars_.clear();
   for (afx_msm_job& j : jobs) {
     for (uint32_t t = 0; t < j.n_var; t++) j.term[t].dbl = half_bases_.count(j.term[t].var) ? 1u : 0u;
     for (uint32_t t = j.n_var; t < j.n_terms; t++) j.term[t].dbl = 0;
@@ -315,8 +330,12 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
       for (uint32_t t = 0; t < jobs[i].n_var; t++) k += naf_term(jobs[i].term[t]);
       if (k >= 2) first.push_back(jobs[i]); else { new_index[i] = (int)rest.size(); rest.push_back(jobs[i]); }
     }
-    for (size_t i = 0; i < jobs.size() && ok; i++)
-      if (jobs[i].chain_to >= 0 && new_index[i] >= 0 && new_index[jobs[i].chain_to] < 0) ok = false;   // a split job would wait for one that is not
+    for (size_t i = 0; i < jobs.size() && ok; i++) {
+      if (jobs[i].chain_to < 0) continue;
+      if (new_index[i] >= 0 && new_index[jobs[i].chain_to] < 0) ok = false;   // a split job would wait for one that is not
+      if (new_index[i] < 0 && new_index[jobs[i].chain_to] < 0) ok = false;    // producer and consumer both split: msm_split levels them, but
+                                                                               // `first` drops its chain links below - keep the list whole
+    }
     if (first.empty() || !ok) msm_list(std::move(jobs), false, cjobs);
     else {
       for (afx_msm_job& j : first) j.chain_to = -1;   // their consumers are all in `rest`, which starts after their sums
@@ -332,6 +351,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
 void Assembler::compress_also(const int32_t* var, uint8_t* out_enc, bool negate, uint32_t reject_identity) {
   afx_compress_job cj = { var, out_enc, reject_identity, negate ? 1u : 0u };
   pending_cjobs_.push_back(cj);
+  pending_half_vars_.push_back(var);
   stats.encodings++; stats.field_mul += AFX_ENCODE_MUL; stats.field_sq += AFX_ENCODE_SQ; stats.chain_mul += AFX_CHAIN_SQRT_MUL; stats.chain_sq += AFX_CHAIN_SQRT_SQ;   // compress() rewrites this share
 }
 
@@ -657,6 +677,7 @@ size_t Assembler::total_ws_bytes() const {
 int Assembler::run() {
   if (sizing_) { set_error("run() on a sizing assembler"); return AFX_E_BAD_ARGS; }
   if (!plan_error.empty()) { set_error(plan_error); return AFX_E_BAD_ARGS; }
+  if (!pending_cjobs_.empty()) { set_error("an encoding queued by compress_also() was never launched"); return AFX_E_BAD_ARGS; }
   afx_ctx::Lane& L = ctx->lane[lane];
   ctx->last_stats = stats;
   if (total_ws_bytes() > L.ws.cap) { set_error("workspace smaller than the sized plan"); return AFX_E_BAD_ARGS; }

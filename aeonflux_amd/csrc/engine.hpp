@@ -219,6 +219,7 @@ class Assembler {
   void add_jobs(LaunchKind k, const std::vector<T>& jobs);
   std::set<const int32_t*> half_bases_;            // variables that hold HALF their point (producers with leave_half)
   std::vector<afx_compress_job> pending_cjobs_;    // compress_also()
+  std::vector<const int32_t*> pending_half_vars_;  // ... and the variables they read: checked to hold halves when the queue is consumed
   bool sizing_ = false;
   std::vector<uint8_t> blob_;
   uint8_t* blob_base_ = nullptr;   // device address the blob will live at

@@ -183,6 +183,7 @@ struct Stager {
     bytes = off + rows * n * elem;
     if (src)
       for (size_t r = 0; r < rows; r++) copies.push_back({ off + r * n * elem, src + (r * total + first) * elem, n * elem });
+    else if (rows != 0 && n != 0 && elem != 0) blanks.push_back({ off, nullptr, rows * n * elem });   // rows nobody fills start from zero, like add(nullptr, ..)
     return off;
   }
   // Calls of few items are many short rows (75 arrays for a C3 presentation batch): each row as its own copy from pageable
@@ -194,18 +195,23 @@ struct Stager {
     int rc = L.staging.ensure(bytes + 256);
     if (rc) return rc;
     if (bytes <= PACK_LIMIT && copies.size() > 2) {
+      // the event first: a buffer is only published together with the event that guards its reuse
+      if (!L.pin_in_done) AFX_HIP(hipEventCreateWithFlags(&L.pin_in_done, hipEventDisableTiming));
       if (bytes > L.pin_in_cap) {
         if (L.pin_in) { AFX_HIP(hipEventSynchronize(L.pin_in_done)); memset(L.pin_in, 0, L.pin_in_cap); (void)hipHostFree(L.pin_in); L.pin_in = nullptr; L.pin_in_cap = 0; }
         const size_t want = std::min(PACK_LIMIT, std::max<size_t>(size_t(1) << 18, (bytes + 65535) & ~size_t(65535)));
-        AFX_HIP(hipHostMalloc(&L.pin_in, want, hipHostMallocDefault));
+        void* fresh = nullptr;
+        AFX_HIP(hipHostMalloc(&fresh, want, hipHostMallocDefault));
+        L.pin_in = fresh;
         L.pin_in_cap = want;
-        if (!L.pin_in_done) AFX_HIP(hipEventCreateWithFlags(&L.pin_in_done, hipEventDisableTiming));
       } else {
         AFX_HIP(hipEventSynchronize(L.pin_in_done));   // the previous call's transfer out of this buffer
       }
       uint8_t* img = (uint8_t*)L.pin_in;
+      // The image starts from zero: what no copy covers - result areas, reserve() scratch, the 256-byte padding between rows -
+      // would otherwise carry an EARLIER call's bytes (staged keys, seeds) into this call's staging area (at most 4 MB: ~50 us)
+      memset(img, 0, bytes);
       for (const Copy& k : copies) memcpy(img + k.off, k.src, k.len);
-      for (const Copy& k : blanks) memset(img + k.off, 0, k.len);
       AFX_HIP(hipMemcpyAsync(L.staging.p, img, bytes, hipMemcpyHostToDevice, L.stream));
       AFX_HIP(hipEventRecord(L.pin_in_done, L.stream));
       return AFX_OK;

@@ -53,6 +53,29 @@ def traffic_file(secret=False):
 UNCHECKED = os.environ.get("AFX_BENCH_UNCHECKED") == "1"
 
 
+# the device code a traffic measurement belongs to: every file the kernels are compiled from
+KERNEL_SOURCES = ("kernels.hip", "fe.cuh", "fe10.cuh", "sc.cuh", "ge.cuh", "keccak.cuh", "constants.cuh", "plan.h")
+
+
+def kernel_sources_sha256():
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "aeonflux_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def traffic_is_stale(secret=False):
+    """True when the committed traffic measurement was taken on other device code than this tree's (or says nothing about it):
+    tools/traffic_json.py stores the sha256 of the kernel sources it measured"""
+    try:
+        with open(traffic_file(secret)) as f:
+            return json.load(f).get("kernel_sources_sha256") != kernel_sources_sha256()
+    except (OSError, ValueError, TypeError):
+        return True
+
+
 def measured_traffic(workload, kernel, secret=False):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
     (profiles/rNN_traffic.json, the newest round's; collected with tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes,
@@ -93,8 +116,13 @@ def roofline_of(kt, workload, ab, items_per_step, secret=False):
     d = kt[dom]
     items_per_launch = items_per_step / d["launches_per_step"]
     achieved = ab * items_per_launch / (d["avg_launch_ms"] / 1e3) / 1e9
+    # PMC counters cannot be read from inside the process: the traffic figure is the committed measurement of this same command
+    # (profiles/rNN_traffic.json) - but only while it was taken on THIS tree's device code (its kernel_sources_sha256)
+    stale = traffic_is_stale(secret)
     return {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "traffic": measured_traffic(workload, dom, secret), "kernel": dom, "launches_per_step": d["launches_per_step"],
+            "traffic": None if stale else measured_traffic(workload, dom, secret), "traffic_stale": stale,
+            "traffic_source": os.path.relpath(traffic_file(secret), ROOT) if traffic_file(secret) else None,
+            "kernel": dom, "launches_per_step": d["launches_per_step"],
             "avg_launch_ms": d["avg_launch_ms"], "items_per_launch": items_per_launch, "algorithmic_bytes_per_launch": ab * items_per_launch,
             "kernel_ms_per_step": sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS),
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in kt.items()},
@@ -281,7 +309,7 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
                        "secret_independent_addressing": bool(args.secret_independent),
                        "algorithmic_bytes_per_credential": ab, "parallelism": "host-sharded x%d, no collective" % world},
             "roofline": roofline_of(kt, "c5", ab, count, bool(args.secret_independent)),
-            "valu": valu, "cpu_baseline": cpu}))
+            "valu": with_value_per_mhz(valu, count * world * args.steps / elapsed), "cpu_baseline": cpu}))
     issuer.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -390,7 +418,7 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
                        "secret_independent_addressing": bool(args.secret_independent),
                        "parallelism": "host-sharded x%d, no collective" % world},
             "roofline": roofline_of(kt, "show", ab, count, bool(args.secret_independent)),
-            "valu": valu, "cpu_baseline": None}))
+            "valu": with_value_per_mhz(valu, count * world * args.steps / elapsed), "cpu_baseline": None}))
     issuer.close()
     user.close()
     if dist is not None:
@@ -424,10 +452,19 @@ def valu_side(ctx, items_per_step, field_kernel_ms_per_step):
     at_clock = MAD_PEAK_T * mhz / NOMINAL_MHZ if mhz > 0 else None
     return {"unit": "T multiply-adds/s (v_mad_i64_i32 / v_mad_u64_u32)", "achieved": achieved, "peak": MAD_PEAK_T, "frac": achieved / MAD_PEAK_T,
             "core_clock_mhz_measured": mhz, "peak_at_measured_clock": at_clock, "frac_at_measured_clock": (achieved / at_clock) if at_clock else None,
+            # the boxes of the pool run this path at 1.85-1.98 GHz (socket power cap): items per second and measured MHz of THIS
+            # process's field kernels is the figure that compares across boxes and rounds
+            "items_per_s_per_mhz_field_kernels": (items_per_step / (field_kernel_ms_per_step / 1e3) / mhz) if (mhz > 0 and field_kernel_ms_per_step > 0) else None,
             "clock_note": "peak is at the nominal 2400 MHz; the kernels run at the socket power cap, below it",
             "peak_source": "tools/ubench/mad_sustained.hip on this GPU (no published figure): %.2f cycles per wave-instruction" % MAD_CYCLES,
             "peak_sustained_pure_mad_loop": MAD_SUSTAINED_T, "frac_of_sustained": achieved / MAD_SUSTAINED_T, "per_item": dict(st, mads=mads),
             "time_base": "summed durations of the kernels doing field arithmetic (k_msm_*, k_compress2x, k_negenc, k_pointsum, k_decode, k_pointop, k_from_uniform)"}
+
+
+def with_value_per_mhz(valu, value):
+    """the line's `value` (whole-job items per second) per measured MHz of the core clock: what compares across the pool's boxes"""
+    mhz = valu.get("core_clock_mhz_measured") or 0
+    return dict(valu, value_per_mhz=(value / mhz) if mhz > 0 else None)
 
 
 def free_port():
@@ -536,7 +573,9 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher around this process: be the launcher (before anything here touches the GPU)
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        # a rank that hangs (a process group that half-formed) must not hang the launcher: an hour covers generation + parity
+        # checks + the timed steps of the largest workload many times over
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], timeout_s=float(os.environ.get("AFX_BENCH_LAUNCH_TIMEOUT_S", "3600"))))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
@@ -555,15 +594,21 @@ def main():
         import torch.distributed as dist
         # the process group only carries the measurement's barrier and one MAX all-reduce of a double (the data path has no
         # collective): RCCL as the contract asks; if it cannot start on this node, gloo serves the same purpose
-        if args.dist_backend == "nccl":
-            try:
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-            except Exception as e:   # noqa: BLE001 - reported in the output line
-                sys.stderr.write("bench.py: rank %d: RCCL process group failed (%s); using gloo\n" % (rank, e))
-                args.dist_backend = "gloo (nccl failed to initialise)"
-                dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend=args.dist_backend)
+        # The backend is decided ONCE, the same way on every rank, before any group forms: --dist-backend, and gloo instead of
+        # nccl only when this build of torch has no RCCL at all (a property of the image, equal on all ranks of a node).  A rank
+        # whose group does not form exits non-zero - the launcher (torch.distributed.run, or launch_ranks above) then stops the
+        # others; ranks falling back one by one would end up on different backends and hang in the first barrier.
+        import datetime
+        if args.dist_backend == "nccl" and not dist.is_nccl_available():
+            args.dist_backend = "gloo (this torch build has no RCCL)"
+        backend = args.dist_backend.split()[0]
+        try:
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=10))
+            else:
+                dist.init_process_group(backend=backend, timeout=datetime.timedelta(minutes=10))
+        except Exception as e:   # noqa: BLE001
+            raise SystemExit("bench.py: rank %d: the %s process group did not form (%s)" % (rank, backend, e))
     import aeonflux_amd as afx
     from aeonflux_amd import batch
 
@@ -728,6 +773,9 @@ def main():
                        "secret_independent_addressing": bool(args.secret_independent),
                        "input_generation_s": round(gen_s, 2), "host_pointer_api_presentations_per_s": pcie,
                        "wire_blob_api_presentations_per_s": wire_rate,
+                       "n1_vs_n_note": "the N=1 default workload is C3 (2^20 presentations on the one GPU, \"weak\"); N>1 defaults to C4 (2^22 in all, "
+                                       "2^22/N per GPU, \"strong\"): the curve's first point is a different batch size from the rest - immaterial above "
+                                       "2^17 items per GPU, where a pass fills the device",
                        "ranks_seen": ranks_seen, "dist_backend": args.dist_backend if had_group else None, "launcher": "bench.py" if os.environ.get("AFX_BENCH_LAUNCHED") else
                        ("external" if world > 1 else "none"),
                        "group_api_presentations_per_s": group_rate, "group_api_items": group_items,
@@ -735,7 +783,7 @@ def main():
                                          "rank 0's batch), PCIe and staging inclusive" % (world, world),
                        "group_api_error": group_err},
             "roofline": roofline_of(kt, args.workload, ab, count, bool(args.secret_independent)),
-            "valu": valu,
+            "valu": with_value_per_mhz(valu, total / elapsed),
             "cpu_baseline": cpu,
         }
         if UNCHECKED:

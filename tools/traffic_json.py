@@ -6,6 +6,7 @@ the last steps x launches_per_step dispatches, among those with the kernel's lar
 kernel (launches_per_step from the bench's own JSON line).
 Usage: traffic_json.py out.json workload:fetch_db:write_db:bench_log ..."""
 import json
+import os
 import sqlite3
 import sys
 
@@ -49,6 +50,11 @@ def main(out, *specs):
             res[w][k] = (2 * sum(fe) / len(fe) + sum(wb) / len(wb)) * 1024.0
             print("%s %-14s launches averaged %3d  FETCH_SIZE avg KB %14.1f  WRITE_SIZE avg KB %14.1f  -> bytes/launch %.4g" %
                   (w, k, n, sum(fe) / len(fe), sum(wb) / len(wb), res[w][k]))
+    # which kernels these bytes were measured on: bench.py compares this with the tree it runs from and reports
+    # "traffic_stale" instead of a ratio when the device code has moved on since the collection
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res["kernel_sources_sha256"] = bench.kernel_sources_sha256()
     json.dump(res, open(out, "w"), indent=1)
 
 
