@@ -1,5 +1,6 @@
 // Engine core: device buffers, launch assembler, Schnorr constraint-system builder.
 #include "engine.hpp"
+#include <stdio.h>
 #include <string.h>
 #include <algorithm>
 #include <map>
@@ -68,14 +69,20 @@ static void secure_zero(void* p, size_t n) {
   __asm__ __volatile__("" : : "r"(p) : "memory");
 }
 Assembler::~Assembler() { secure_zero(blob_.data(), blob_.size()); }
-Assembler::Assembler(afx_ctx* c, uint32_t cnt, bool sizing, int ln) : ctx(c), lane(ln), count(cnt), sizing_(sizing) {
+// Provisional bases: non-canonical addresses (bit 62 set: never a valid user-space pointer on x86-64, never a device allocation),
+// one window per range and per variant, so that a pointer's range is unambiguous and a pointer that escaped relocation faults
+// instead of reading somewhere plausible.
+static uint8_t* provisional_base(int range, int variant) { return (uint8_t*)(uintptr_t)(0x4000000000000000ull + ((uint64_t)(1 + range + 4 * variant) << 44)); }
+Assembler::Assembler(afx_ctx* c, uint32_t cnt, int variant) : ctx(c), count(cnt) {
   blob_.reserve(1 << 16);
-  afx_ctx::Lane& L = ctx->lane[lane];
-  blob_base_ = (uint8_t*)L.blob_dev[L.blob_next].p;
-  ws_base_ = sizing ? nullptr : (uint8_t*)L.ws.p;
+  blob_base_ = provisional_base(0, variant);
+  ws_base_ = provisional_base(1, variant);
+  blob_alloc(sizeof(afx_pass), 16);   // the pass first (finish_plan fills it in): offset 0 of every plan's blob
   bad_ = (uint32_t*)ws_alloc(sizeof(uint32_t) * (size_t)count);
   Launch l;
-  l.kind = L_FILL_BAD;
+  l.kind = L_FILL_BAD;   // its one job is written by finish_plan, when fail_all is known
+  l.njobs = 1;
+  l.jobs_off = blob_alloc(sizeof(afx_fill_job), 16);
   launches.push_back(l);
 }
 uint8_t* Assembler::ws_alloc(size_t bytes) {
@@ -91,6 +98,24 @@ size_t Assembler::blob_alloc(size_t bytes, size_t align) {
   blob_.resize(off + bytes);
   return off;
 }
+// A job as it goes into the blob: field by field into zeroed storage for the structs that have padding, so that equal plans are
+// equal BYTES (plan self-check, and no stack garbage travels to the device)
+template <class T> static void put_job(uint8_t* dst, const T& j) { memcpy(dst, &j, sizeof j); }
+template <> void put_job(uint8_t* dst, const afx_decode_job& j) {
+  afx_decode_job z; memset(&z, 0, sizeof z);
+  z.enc = j.enc; z.out = j.out; z.reject_identity = j.reject_identity;
+  memcpy(dst, &z, sizeof z);
+}
+template <> void put_job(uint8_t* dst, const afx_pointop_job& j) {
+  afx_pointop_job z; memset(&z, 0, sizeof z);
+  z.a = j.a; z.b = j.b; z.b_const = j.b_const; z.sa = j.sa; z.sb = j.sb; z.out = j.out; z.out_enc = j.out_enc; z.reject_identity = j.reject_identity;
+  memcpy(dst, &z, sizeof z);
+}
+template <> void put_job(uint8_t* dst, const afx_scalarop_job& j) {
+  afx_scalarop_job z; memset(&z, 0, sizeof z);
+  z.a = j.a; z.a_stride = j.a_stride; z.b = j.b; z.b_stride = j.b_stride; z.c = j.c; z.c_stride = j.c_stride; z.negate = j.negate; z.out = j.out;
+  memcpy(dst, &z, sizeof z);
+}
 template <class T>
 void Assembler::add_jobs(LaunchKind k, const std::vector<T>& jobs) {
   if (jobs.empty()) return;
@@ -98,7 +123,7 @@ void Assembler::add_jobs(LaunchKind k, const std::vector<T>& jobs) {
   l.kind = k;
   l.njobs = (uint32_t)jobs.size();
   l.jobs_off = blob_alloc(sizeof(T) * jobs.size(), 16);
-  memcpy(blob_.data() + l.jobs_off, jobs.data(), sizeof(T) * jobs.size());
+  for (size_t i = 0; i < jobs.size(); i++) put_job(blob_.data() + l.jobs_off + sizeof(T) * i, jobs[i]);
   launches.push_back(l);
 }
 void Assembler::decode(const std::vector<afx_decode_job>& jobs) {
@@ -128,7 +153,24 @@ void Assembler::negenc(const std::vector<afx_negenc_job>& jobs) {
   stats.field_sq += 254 + 3 * jobs.size();
   stats.chain_mul += AFX_CHAIN_INVERT_MUL; stats.chain_sq += AFX_CHAIN_INVERT_SQ;
   add_jobs(L_NEGENC, jobs);
-  launches.back().prefix_ws = (int32_t*)ws_alloc(sizeof(int32_t) * 9 * jobs.size() * (size_t)count);
+  add_walk_rows(launches.back(), 0);
+}
+// grid rows of a k_compress2x / k_negenc launch: per_row jobs each (0 = all in one row), each row with scratch for its prefix products
+void Assembler::add_walk_rows(Launch& l, uint32_t per_row) {
+  if (per_row == 0 || per_row > l.njobs) per_row = l.njobs;
+  std::vector<afx_walk_row> rows;
+  for (uint32_t first = 0; first < l.njobs; first += per_row) {
+    afx_walk_row r;
+    memset(&r, 0, sizeof r);
+    r.job_off = first * (uint32_t)(l.kind == L_COMPRESS ? sizeof(afx_compress_job) : sizeof(afx_negenc_job));
+    r.n_jobs = std::min(per_row, l.njobs - first);
+    r.pass = 0;
+    r.prefix_ws = (int32_t*)ws_alloc(sizeof(int32_t) * 9 * (size_t)r.n_jobs * (size_t)count);
+    rows.push_back(r);
+  }
+  l.nrows = (uint32_t)rows.size();
+  l.rows_off = blob_alloc(sizeof(afx_walk_row) * rows.size(), 16);
+  memcpy(blob_.data() + l.rows_off, rows.data(), sizeof(afx_walk_row) * rows.size());
 }
 void Assembler::scalarop(const std::vector<afx_scalarop_job>& jobs) { add_jobs(L_SCALAROP, jobs); }
 void Assembler::hash(const std::vector<afx_hash_program>& progs) {
@@ -253,14 +295,13 @@ void Assembler::compress(const std::vector<afx_compress_job>& cjobs, uint32_t gr
   Launch cl;
   cl.kind = L_COMPRESS;
   cl.njobs = (uint32_t)cjobs.size();
-  cl.per_group = groups > 1 ? (cl.njobs + groups - 1) / groups : 0;
   cl.jobs_off = blob_alloc(sizeof(afx_compress_job) * cjobs.size(), 16);
   memcpy(blob_.data() + cl.jobs_off, cjobs.data(), sizeof(afx_compress_job) * cjobs.size());
-  cl.prefix_ws = (int32_t*)ws_alloc(sizeof(int32_t) * 9 * cjobs.size() * (size_t)count);
+  add_walk_rows(cl, groups > 1 ? (cl.njobs + groups - 1) / groups : 0);
   launches.push_back(cl);
   // the plain encodings were counted job by job: replace them by k_compress2x's share (two passes over e, f, g, h per job, one
   // inversion per row)
-  const uint64_t rows = cl.per_group ? (cl.njobs + cl.per_group - 1) / cl.per_group : 1;
+  const uint64_t rows = cl.nrows;
   stats.field_mul += 22 * cjobs.size() + 11 * rows; stats.field_mul -= AFX_ENCODE_MUL * cjobs.size();
   stats.field_sq += 8 * cjobs.size() + 254 * rows; stats.field_sq -= AFX_ENCODE_SQ * cjobs.size();
   stats.chain_mul += AFX_CHAIN_INVERT_MUL * rows; stats.chain_mul -= AFX_CHAIN_SQRT_MUL * cjobs.size();
@@ -401,7 +442,7 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
       for (uint32_t first = j.n_var; first < j.n_terms; first += FIXED_PER_PART) sub_of(first, std::min(FIXED_PER_PART, j.n_terms - first), 0);
       afx_pointsum_job sj;
       memset(&sj, 0, sizeof sj);
-      sj.parts = put(part_vars.data(), part_vars.size());
+      sj.parts = put_ptrs(part_vars.data(), part_vars.size());
       sj.n_parts = (uint32_t)part_vars.size();
       sj.addend = j.addend; sj.addend_negate = j.addend_negate;
       sj.out_var = j.out_var;
@@ -643,58 +684,360 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     for (const afx_msm_job& j : out)
       for (uint32_t t = 0; t < j.n_terms; t++) if (j.term[t].secret) l.secret = 1;
     l.njobs = (uint32_t)out.size();
-    l.jobs_off = blob_alloc(sizeof(afx_msm_job) * out.size(), 16);
-    memcpy(blob_.data() + l.jobs_off, out.data(), sizeof(afx_msm_job) * out.size());
+    // the kernels' form of a job: its terms in a side array (plan.h afx_msm_djob)
+    std::vector<afx_msm_djob> dj(out.size());
+    for (size_t i = 0; i < out.size(); i++) {
+      const afx_msm_job& j = out[i];
+      afx_msm_djob& d = dj[i];
+      memset(&d, 0, sizeof d);
+      d.n_terms = j.n_terms; d.n_var = j.n_var; d.n_uni = j.n_uni; d.top_bit = j.top_bit;
+      d.naf_sched = j.naf_sched;
+      d.term = put(j.term, j.n_terms);
+      if (j.n_terms) term_tables_.push_back({ (size_t)((const uint8_t*)d.term - blob_base_), j.n_terms });
+      d.addend = j.addend; d.addend_negate = j.addend_negate; d.reject_identity = j.reject_identity;
+      d.out_enc = j.out_enc; d.out_var = j.out_var; d.half_var = j.half_var;
+      d.digit_slot = j.digit_slot; d.narrow = j.narrow; d.leave_half = j.leave_half;
+    }
+    l.jobs_off = blob_alloc(sizeof(afx_msm_djob) * dj.size(), 16);
+    memcpy(blob_.data() + l.jobs_off, dj.data(), sizeof(afx_msm_djob) * dj.size());
     launches.push_back(l);
   }
   max_digit_slots = std::max<size_t>(max_digit_slots, dslot);
   max_table_slots = std::max<size_t>(max_table_slots, tslot);
 }
 void Assembler::from_uniform(const uint8_t* wide, uint8_t* out_enc, int32_t* out_var) {
-  Launch l; l.kind = L_FROM_UNIFORM; l.in = wide; l.out = out_enc; l.out_var = out_var;
-  launches.push_back(l);
+  const afx_uniform_job j = { wide, out_enc, out_var };
+  add_jobs(L_FROM_UNIFORM, std::vector<afx_uniform_job>(1, j));
 }
 void Assembler::reduce_wide(const uint8_t* wide, uint8_t* out) {
-  Launch l; l.kind = L_REDUCE_WIDE; l.in = wide; l.out = out;
-  launches.push_back(l);
+  const afx_reduce_job j = { wide, out };
+  add_jobs(L_REDUCE_WIDE, std::vector<afx_reduce_job>(1, j));
 }
 void Assembler::copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
   Launch l; l.kind = L_COPY; l.in = src; l.out = dst; l.bytes = bytes;
   launches.push_back(l);
 }
 void Assembler::finish(uint8_t* status_dev, uint8_t fail_code) {
-  Launch l; l.kind = L_FINISH; l.out = status_dev; l.fail_code = fail_code;
-  launches.push_back(l);
+  const afx_finish_job j = { bad_, status_dev, count, fail_code };
+  add_jobs(L_FINISH, std::vector<afx_finish_job>(1, j));
 }
-size_t Assembler::total_ws_bytes() const {
-  size_t off = (ws_off_ + 255) & ~size_t(255);
-  off += max_table_slots * (size_t)count * AFX_VAR_TABLE_DWORDS * sizeof(int32_t);
-  off = (off + 255) & ~size_t(255);
-  off += max_digit_slots * AFX_DIGIT_WORDS * (size_t)count * sizeof(uint32_t);
-  return off + 256;
-}
-
-int Assembler::run() {
-  if (sizing_) { set_error("run() on a sizing assembler"); return AFX_E_BAD_ARGS; }
+int Assembler::finish_plan(Plan& out, uint8_t* in_base, size_t in_bytes, uint8_t* out_base, size_t out_bytes) {
   if (!plan_error.empty()) { set_error(plan_error); return AFX_E_BAD_ARGS; }
   if (!pending_cjobs_.empty()) { set_error("an encoding queued by compress_also() was never launched"); return AFX_E_BAD_ARGS; }
+  if (launches.empty() || launches[0].kind != L_FILL_BAD) { set_error("internal: plan without its opening launch"); return AFX_E_BAD_ARGS; }
+  const afx_fill_job fj = { bad_, fail_all ? AFX_BAD_SHAPE : 0u, count };
+  memcpy(blob_.data() + launches[0].jobs_off, &fj, sizeof fj);
+  afx_pass P;
+  memset(&P, 0, sizeof P);
+  P.count = count;
+  P.bad = bad_;
+  P.table_ws = (int32_t*)ws_alloc(max_table_slots * (size_t)count * AFX_VAR_TABLE_DWORDS * sizeof(int32_t));
+  P.digit_ws = (uint32_t*)ws_alloc(max_digit_slots * AFX_DIGIT_WORDS * (size_t)count * sizeof(uint32_t));
+  memcpy(blob_.data(), &P, sizeof P);
+  out.blob.swap(blob_);
+  secure_zero(blob_.data(), blob_.size());
+  blob_.clear();
+  out.launches.swap(launches);
+  out.ptr_tables.swap(ptr_tables_);
+  out.term_tables.swap(term_tables_);
+  out.blob_base = blob_base_;
+  out.ws_base = ws_base_;
+  out.ws_bytes = ((ws_off_ + 255) & ~size_t(255)) + 256;
+  out.in_base = in_base; out.in_bytes = in_bytes;
+  out.out_base = out_base; out.out_bytes = out_bytes;
+  out.pass_off = 0;
+  out.count = count;
+  out.small = small();
+  out.stats = stats;
+  return AFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Plan: relocation and execution
+// ------------------------------------------------------------------------------------------------
+Plan::~Plan() { secure_zero(blob.data(), blob.size()); }
+
+namespace {
+// a pointer moves with the range it points into (end inclusive: one-past-the-end pointers of empty rows move along)
+struct Mover {
+  struct R { uintptr_t lo, hi; intptr_t delta; } r[4];
+  template <class T>
+  void fix(T*& p) const {
+    const uintptr_t v = (uintptr_t)p;
+    if (!v) return;
+    for (const R& x : r)
+      if (x.hi > x.lo && v >= x.lo && v <= x.hi) { p = (T*)(v + x.delta); return; }
+  }
+  template <class T>
+  void fix(const T*& p) const { T* q = const_cast<T*>(p); fix(q); p = q; }
+};
+size_t job_size(LaunchKind k) {
+  switch (k) {
+    case L_FILL_BAD: return sizeof(afx_fill_job);
+    case L_DECODE: return sizeof(afx_decode_job);
+    case L_SCCHECK: return sizeof(afx_sccheck_job);
+    case L_POINTOP: return sizeof(afx_pointop_job);
+    case L_SCALAROP: return sizeof(afx_scalarop_job);
+    case L_MSM_WINDOW: case L_MSM_FIXED: case L_MSM_NAF: return sizeof(afx_msm_djob);
+    case L_HASH: return sizeof(afx_hash_program);
+    case L_FROM_UNIFORM: return sizeof(afx_uniform_job);
+    case L_REDUCE_WIDE: return sizeof(afx_reduce_job);
+    case L_FINISH: return sizeof(afx_finish_job);
+    case L_MSM_TABLES: return sizeof(afx_table_job);
+    case L_COMPRESS: return sizeof(afx_compress_job);
+    case L_POINTSUM: return sizeof(afx_pointsum_job);
+    case L_NEGENC: return sizeof(afx_negenc_job);
+    default: return 0;
+  }
+}
+}  // namespace
+
+// Every pointer field of every plan structure, by type.  Side tables that hold pointers themselves (a job's terms, a sum's parts,
+// a transcript's field and output tables) are listed by the Assembler as it writes them (put_ptrs, term_tables_).
+void Plan::relocate(uint8_t* nblob, uint8_t* nws, uint8_t* nin, uint8_t* nout) {
+  if (nblob == blob_base && nws == ws_base && (nin == in_base || !in_bytes) && (nout == out_base || !out_bytes)) return;
+  Mover m;
+  m.r[0] = { (uintptr_t)blob_base, (uintptr_t)blob_base + blob.size(), (intptr_t)((uintptr_t)nblob - (uintptr_t)blob_base) };
+  m.r[1] = { (uintptr_t)ws_base, (uintptr_t)ws_base + ws_bytes, (intptr_t)((uintptr_t)nws - (uintptr_t)ws_base) };
+  m.r[2] = { (uintptr_t)in_base, (uintptr_t)in_base + in_bytes, (intptr_t)((uintptr_t)nin - (uintptr_t)in_base) };
+  m.r[3] = { (uintptr_t)out_base, (uintptr_t)out_base + out_bytes, (intptr_t)((uintptr_t)nout - (uintptr_t)out_base) };
+  // side tables first, from the plan's own lists (a table no job refers to - the statement ended in fail_all before its jobs were
+  // emitted - moves like any other: equal plans stay equal bytes)
+  for (const auto& t : ptr_tables) {
+    uint8_t** tab = (uint8_t**)(blob.data() + t.first);
+    for (uint32_t k = 0; k < t.second; k++) m.fix(tab[k]);
+  }
+  for (const auto& t : term_tables) {
+    afx_msm_term* tab = (afx_msm_term*)(blob.data() + t.first);
+    for (uint32_t k = 0; k < t.second; k++) { m.fix(tab[k].scalar); m.fix(tab[k].var); }
+  }
+  afx_pass* P = (afx_pass*)(blob.data() + pass_off);
+  m.fix(P->bad); m.fix(P->table_ws); m.fix(P->digit_ws);
+  for (Launch& l : launches) {
+    uint8_t* J = blob.data() + l.jobs_off;
+    switch (l.kind) {
+      case L_FILL_BAD: for (uint32_t i = 0; i < l.njobs; i++) m.fix(((afx_fill_job*)J)[i].p); break;
+      case L_DECODE: for (uint32_t i = 0; i < l.njobs; i++) { afx_decode_job& j = ((afx_decode_job*)J)[i]; m.fix(j.enc); m.fix(j.out); } break;
+      case L_SCCHECK: for (uint32_t i = 0; i < l.njobs; i++) m.fix(((afx_sccheck_job*)J)[i].sc); break;
+      case L_POINTOP:
+        for (uint32_t i = 0; i < l.njobs; i++) { afx_pointop_job& j = ((afx_pointop_job*)J)[i]; m.fix(j.a); m.fix(j.b); m.fix(j.b_const); m.fix(j.out); m.fix(j.out_enc); }
+        break;
+      case L_SCALAROP: for (uint32_t i = 0; i < l.njobs; i++) { afx_scalarop_job& j = ((afx_scalarop_job*)J)[i]; m.fix(j.a); m.fix(j.b); m.fix(j.c); m.fix(j.out); } break;
+      case L_MSM_WINDOW: case L_MSM_FIXED: case L_MSM_NAF:
+        for (uint32_t i = 0; i < l.njobs; i++) {
+          afx_msm_djob& j = ((afx_msm_djob*)J)[i];
+          m.fix(j.term); m.fix(j.naf_sched); m.fix(j.addend); m.fix(j.out_enc); m.fix(j.out_var); m.fix(j.half_var);
+        }
+        break;
+      case L_MSM_TABLES: for (uint32_t i = 0; i < l.njobs; i++) m.fix(((afx_table_job*)J)[i].var); break;
+      case L_COMPRESS: for (uint32_t i = 0; i < l.njobs; i++) { afx_compress_job& j = ((afx_compress_job*)J)[i]; m.fix(j.var); m.fix(j.out_enc); } break;
+      case L_NEGENC: for (uint32_t i = 0; i < l.njobs; i++) { afx_negenc_job& j = ((afx_negenc_job*)J)[i]; m.fix(j.enc); m.fix(j.var); m.fix(j.out_enc); } break;
+      case L_POINTSUM:
+        for (uint32_t i = 0; i < l.njobs; i++) {
+          afx_pointsum_job& j = ((afx_pointsum_job*)J)[i];
+          m.fix(j.parts); m.fix(j.addend); m.fix(j.out_var); m.fix(j.half_var); m.fix(j.out_enc);
+        }
+        break;
+      case L_HASH:
+        for (uint32_t i = 0; i < l.njobs; i++) {
+          afx_hash_program& j = ((afx_hash_program*)J)[i];
+          m.fix(j.init_state); m.fix(j.load_state); m.fix(j.save_state); m.fix(j.records); m.fix(j.fields); m.fix(j.outs); m.fix(j.challenge); m.fix(j.trace);
+        }
+        break;
+      case L_FROM_UNIFORM: for (uint32_t i = 0; i < l.njobs; i++) { afx_uniform_job& j = ((afx_uniform_job*)J)[i]; m.fix(j.wide); m.fix(j.out_enc); m.fix(j.out_var); } break;
+      case L_REDUCE_WIDE: for (uint32_t i = 0; i < l.njobs; i++) { afx_reduce_job& j = ((afx_reduce_job*)J)[i]; m.fix(j.wide); m.fix(j.out); } break;
+      case L_FINISH: for (uint32_t i = 0; i < l.njobs; i++) { afx_finish_job& j = ((afx_finish_job*)J)[i]; m.fix(j.bad); m.fix(j.status); } break;
+      case L_COPY: m.fix(l.in); m.fix(l.out); break;
+      case L_KINDS: break;
+    }
+    if (l.nrows) {
+      afx_walk_row* rows = (afx_walk_row*)(blob.data() + l.rows_off);
+      for (uint32_t i = 0; i < l.nrows; i++) m.fix(rows[i].prefix_ws);
+    }
+  }
+  blob_base = nblob; ws_base = nws;
+  if (in_bytes) in_base = nin;
+  if (out_bytes) out_base = nout;
+}
+
+bool Plan::same_as(const Plan& o, std::string* why) const {
+  auto no = [&](const char* w) { if (why) *why = w; return false; };
+  if (blob.size() != o.blob.size()) return no("blob sizes differ");
+  if (ws_bytes != o.ws_bytes || count != o.count || small != o.small) return no("workspace size / count differ");
+  if (launches.size() != o.launches.size()) return no("launch lists differ in length");
+  for (size_t i = 0; i < launches.size(); i++) {
+    const Launch &a = launches[i], &b = o.launches[i];
+    if (a.kind != b.kind || a.jobs_off != b.jobs_off || a.njobs != b.njobs || a.rows_off != b.rows_off || a.nrows != b.nrows || a.in != b.in || a.out != b.out ||
+        a.bytes != b.bytes || a.odd != b.odd || a.encodes != b.encodes || a.secret != b.secret) return no("a launch differs");
+  }
+  std::vector<std::pair<size_t, std::string>> regions;
+  for (size_t i = 0; i < blob.size(); i++)
+    if (blob[i] != o.blob[i]) {
+      if (why) {
+        *why = "blob byte " + std::to_string(i) + " differs (a pointer field the relocation does not know?)";
+        if ((i & ~size_t(7)) + 8 <= blob.size()) {
+          uint64_t a, b;
+          memcpy(&a, blob.data() + (i & ~size_t(7)), 8); memcpy(&b, o.blob.data() + (i & ~size_t(7)), 8);
+          char buf[80];
+          snprintf(buf, sizeof buf, " [word %016llx vs %016llx]", (unsigned long long)a, (unsigned long long)b);
+          *why += buf;
+        }
+        auto in = [&](const void* dev, size_t bytes) {
+          const uintptr_t v = (uintptr_t)dev, b = (uintptr_t)blob_base;
+          if (dev && v >= b) regions.push_back({ (size_t)(v - b), "side table of " + std::to_string(bytes) + " bytes" });
+          return dev && v >= b && i >= v - b && i < v - b + bytes;
+        };
+        for (const Launch& l : launches) {
+          const size_t js = job_size(l.kind);
+          if (js && i >= l.jobs_off && i < l.jobs_off + js * l.njobs)
+            *why += ": launch kind " + std::to_string((int)l.kind) + ", job " + std::to_string((i - l.jobs_off) / js) + ", byte " + std::to_string((i - l.jobs_off) % js) + " of its struct";
+          if (l.nrows && i >= l.rows_off && i < l.rows_off + sizeof(afx_walk_row) * l.nrows) *why += ": walk rows of launch kind " + std::to_string((int)l.kind);
+          regions.push_back({ l.jobs_off, "jobs of launch kind " + std::to_string((int)l.kind) + " x" + std::to_string(l.njobs) });
+          const uint8_t* J = blob.data() + l.jobs_off;
+          for (uint32_t k = 0; k < l.njobs; k++) {
+            if (l.kind == L_MSM_WINDOW || l.kind == L_MSM_FIXED || l.kind == L_MSM_NAF) {
+              const afx_msm_djob& j = ((const afx_msm_djob*)J)[k];
+              if (in(j.term, sizeof(afx_msm_term) * j.n_terms)) *why += ": terms of msm job " + std::to_string(k) + " (launch kind " + std::to_string((int)l.kind) + ")";
+            } else if (l.kind == L_POINTSUM) {
+              const afx_pointsum_job& j = ((const afx_pointsum_job*)J)[k];
+              if (in(j.parts, 8 * j.n_parts)) *why += ": parts of pointsum job " + std::to_string(k);
+            } else if (l.kind == L_HASH) {
+              const afx_hash_program& j = ((const afx_hash_program*)J)[k];
+              if (in(j.fields, 8 * j.n_fields)) *why += ": fields of hash program " + std::to_string(k);
+              if (in(j.outs, 8 * j.n_outs)) *why += ": outs of hash program " + std::to_string(k);
+              if (in(j.records, sizeof(afx_hash_record) * j.n_records)) *why += ": records of hash program " + std::to_string(k);
+            }
+          }
+        }
+      }
+      if (why) {
+        std::sort(regions.begin(), regions.end());
+        for (size_t r = 0; r < regions.size(); r++)
+          if (regions[r].first <= i && (r + 1 == regions.size() || regions[r + 1].first > i)) *why += " {last known region before it: @" + std::to_string(regions[r].first) + " " + regions[r].second + "}";
+      }
+      return false;
+    }
+  return true;
+}
+
+static int grow_blob(afx_ctx::Lane& L, int slot, size_t bytes) {
+  if (bytes <= L.blob_dev[slot].cap && bytes <= L.blob_host_cap[slot]) return AFX_OK;
+  const size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+  int rc = L.blob_dev[slot].ensure(want);   // waits for the device before it frees the old buffer
+  if (rc) return rc;
+  if (want > L.blob_host_cap[slot]) {
+    if (L.blob_host[slot]) { memset(L.blob_host[slot], 0, L.blob_host_cap[slot]); (void)hipHostFree(L.blob_host[slot]); L.blob_host[slot] = nullptr; L.blob_host_cap[slot] = 0; }
+    void* p = nullptr;
+    AFX_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+    L.blob_host[slot] = p;
+    L.blob_host_cap[slot] = want;
+  }
+  return AFX_OK;
+}
+
+int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
+  if (n == 0) return AFX_OK;
   afx_ctx::Lane& L = ctx->lane[lane];
-  ctx->last_stats = stats;
-  if (total_ws_bytes() > L.ws.cap) { set_error("workspace smaller than the sized plan"); return AFX_E_BAD_ARGS; }
-  int32_t* table_ws = (int32_t*)ws_alloc(max_table_slots * (size_t)count * AFX_VAR_TABLE_DWORDS * sizeof(int32_t));
-  uint32_t* digit_ws = (uint32_t*)ws_alloc(max_digit_slots * AFX_DIGIT_WORDS * (size_t)count * sizeof(uint32_t));
-  hipStream_t s = L.stream;
+  ctx->last_stats = plans[0]->stats;
+  // where every plan's blob and workspace go
+  std::vector<size_t> boff(n), woff(n);
+  size_t blob_total = 0, ws_total = 0;
+  for (size_t i = 0; i < n; i++) {
+    boff[i] = (blob_total + 255) & ~size_t(255);
+    blob_total = boff[i] + plans[i]->blob.size();
+    woff[i] = (ws_total + 255) & ~size_t(255);
+    ws_total = woff[i] + plans[i]->ws_bytes;
+  }
+  // Merged launch list.  Every plan's launches run in the plan's own order; launches of the same kernel at the heads of several
+  // plans' lists become one launch over all their rows.  Greedy: take the kernel at the head of the first unfinished plan and
+  // every other plan whose head is that kernel.
+  struct Part { uint32_t plan, launch; };
+  struct Merged { LaunchKind kind; int odd; std::vector<Part> parts; size_t rows_off = 0; uint32_t nrows = 0; };
+  std::vector<Merged> sched;
+  if (n > 1) {
+    std::vector<size_t> head(n, 0);
+    for (;;) {
+      size_t lead = n;
+      for (size_t i = 0; i < n; i++) if (head[i] < plans[i]->launches.size()) { lead = i; break; }
+      if (lead == n) break;
+      const Launch& h = plans[lead]->launches[head[lead]];
+      Merged mg;
+      mg.kind = h.kind; mg.odd = h.odd;
+      for (size_t i = lead; i < n; i++) {
+        if (head[i] >= plans[i]->launches.size()) continue;
+        const Launch& c = plans[i]->launches[head[i]];
+        const bool same = c.kind == h.kind && (h.kind != L_MSM_TABLES || c.odd == h.odd) && (h.kind != L_COPY || i == lead);
+        if (!same) continue;
+        mg.parts.push_back({ (uint32_t)i, (uint32_t)head[i] });
+        head[i]++;
+      }
+      sched.push_back(std::move(mg));
+    }
+    // the merged launches' row tables and the pass table, behind the plans' blobs
+    blob_total = (blob_total + 255) & ~size_t(255);
+    for (Merged& mg : sched) {
+      if (mg.kind == L_COPY) continue;
+      const bool walk = mg.kind == L_COMPRESS || mg.kind == L_NEGENC;
+      uint32_t rows = 0;
+      for (const Part& p : mg.parts) { const Launch& l = plans[p.plan]->launches[p.launch]; rows += walk ? l.nrows : l.njobs; }
+      mg.nrows = rows;
+      mg.rows_off = blob_total;
+      blob_total += ((walk ? sizeof(afx_walk_row) : sizeof(afx_row)) * (size_t)rows + 15) & ~size_t(15);
+    }
+  }
+  const size_t passes_off = (blob_total + 15) & ~size_t(15);
+  if (n > 1) blob_total = passes_off + sizeof(afx_pass) * n;
+  if (blob_total > 0xffffffffull) { set_error("plan blob too large"); return AFX_E_BAD_ARGS; }
+  // place and relocate
   const int slot = L.blob_next;
-  if (blob_.size() > L.blob_dev[slot].cap || blob_.size() > L.blob_host_cap[slot]) { set_error("plan blob too large"); return AFX_E_BAD_ARGS; }
-  // the pinned mirror of this slot may still be the source of an in-flight copy from two calls ago
-  AFX_HIP(hipEventSynchronize(L.blob_event[slot]));
-  memcpy(L.blob_host[slot], blob_.data(), blob_.size());
-  if (!blob_.empty()) AFX_HIP(hipMemcpyAsync(L.blob_dev[slot].p, L.blob_host[slot], blob_.size(), hipMemcpyHostToDevice, s));
+  AFX_HIP(hipEventSynchronize(L.blob_event[slot]));   // the pinned mirror of this slot may still be the source of a copy from two calls ago
+  int rc = grow_blob(L, slot, blob_total);
+  if (rc) return rc;
+  if ((rc = L.ws.ensure(ws_total))) return rc;
+  uint8_t* const bdev = (uint8_t*)L.blob_dev[slot].p;
+  uint8_t* const bhost = (uint8_t*)L.blob_host[slot];
+  for (size_t i = 0; i < n; i++) {
+    plans[i]->relocate(bdev + boff[i], (uint8_t*)L.ws.p + woff[i], plans[i]->in_base, plans[i]->out_base);
+    memcpy(bhost + boff[i], plans[i]->blob.data(), plans[i]->blob.size());
+  }
+  if (n > 1) {
+    for (const Merged& mg : sched) {
+      if (mg.kind == L_COPY) continue;
+      const bool walk = mg.kind == L_COMPRESS || mg.kind == L_NEGENC;
+      size_t w = mg.rows_off;
+      for (const Part& p : mg.parts) {
+        const Plan& pl = *plans[p.plan];
+        const Launch& l = pl.launches[p.launch];
+        if (walk) {
+          const afx_walk_row* src = (const afx_walk_row*)(pl.blob.data() + l.rows_off);
+          for (uint32_t r = 0; r < l.nrows; r++) {
+            afx_walk_row row = src[r];
+            row.job_off = (uint32_t)(boff[p.plan] + l.jobs_off + row.job_off);
+            row.pass = p.plan;
+            memcpy(bhost + w, &row, sizeof row);
+            w += sizeof row;
+          }
+        } else {
+          const size_t js = job_size(mg.kind);
+          for (uint32_t r = 0; r < l.njobs; r++) {
+            const afx_row row = { p.plan, (uint32_t)(boff[p.plan] + l.jobs_off + r * js) };
+            memcpy(bhost + w, &row, sizeof row);
+            w += sizeof row;
+          }
+        }
+      }
+    }
+    for (size_t i = 0; i < n; i++) memcpy(bhost + passes_off + sizeof(afx_pass) * i, plans[i]->blob.data() + plans[i]->pass_off, sizeof(afx_pass));
+  }
+  hipStream_t s = L.stream;
+  AFX_HIP(hipMemcpyAsync(bdev, bhost, blob_total, hipMemcpyHostToDevice, s));
   AFX_HIP(hipEventRecord(L.blob_event[slot], s));
   L.blob_next ^= 1;
-  for (const Launch& l : launches) {
-    const uint8_t* jobs = blob_base_ + l.jobs_off;
-    afx_ctx::TimedLaunch tl = { (int)l.kind, nullptr, nullptr };
+
+  // one launch: `jobs` / `rows` / `passes` as the kernels take them (kernels.h)
+  auto launch = [&](LaunchKind kind, int odd, int encodes, int secret, const uint8_t* jobs, uint32_t nrows, const void* rows, const afx_pass* passes,
+                    uint32_t max_count, bool coop, const Launch* copy) -> int {
+    afx_ctx::TimedLaunch tl = { (int)kind, nullptr, nullptr };
     if (ctx->timing) {
       for (hipEvent_t* e : { &tl.start, &tl.stop }) {
         if (ctx->event_pool.empty()) AFX_HIP(hipEventCreate(e));
@@ -702,42 +1045,76 @@ int Assembler::run() {
       }
       AFX_HIP(hipEventRecord(tl.start, s));
     }
-    switch (l.kind) {
-      case L_FILL_BAD: AFX_HIP(afxk_fill_u32(s, bad_, fail_all ? AFX_BAD_SHAPE : 0u, count)); break;
-      case L_DECODE: AFX_HIP(afxk_decode(s, (const afx_decode_job*)jobs, l.njobs, bad_, count)); break;
-      case L_SCCHECK: AFX_HIP(afxk_sccheck(s, (const afx_sccheck_job*)jobs, l.njobs, bad_, count)); break;
-      case L_POINTOP: AFX_HIP(afxk_pointop(s, (const afx_pointop_job*)jobs, l.njobs, bad_, count)); break;
-      case L_SCALAROP: AFX_HIP(afxk_scalarop(s, (const afx_scalarop_job*)jobs, l.njobs, count)); break;
-      case L_COMPRESS: AFX_HIP(afxk_compress2x(s, (const afx_compress_job*)jobs, l.njobs, l.per_group, l.prefix_ws, bad_, count)); break;
-      case L_NEGENC: AFX_HIP(afxk_negenc(s, (const afx_negenc_job*)jobs, l.njobs, l.prefix_ws, bad_, count)); break;
-      case L_POINTSUM: AFX_HIP(afxk_pointsum(s, (const afx_pointsum_job*)jobs, l.njobs, bad_, count)); break;
-      case L_MSM_TABLES: AFX_HIP(afxk_msm_tables(s, l.odd, (const afx_table_job*)jobs, l.njobs, table_ws, count)); break;
+    const afx_row* rw = (const afx_row*)rows;
+    switch (kind) {
+      case L_FILL_BAD: AFX_HIP(afxk_fill_u32(s, (const afx_fill_job*)jobs, nrows, rw, max_count)); break;
+      case L_DECODE: AFX_HIP(afxk_decode(s, (const afx_decode_job*)jobs, nrows, rw, passes, max_count)); break;
+      case L_SCCHECK: AFX_HIP(afxk_sccheck(s, (const afx_sccheck_job*)jobs, nrows, rw, passes, max_count)); break;
+      case L_POINTOP: AFX_HIP(afxk_pointop(s, (const afx_pointop_job*)jobs, nrows, rw, passes, max_count)); break;
+      case L_SCALAROP: AFX_HIP(afxk_scalarop(s, (const afx_scalarop_job*)jobs, nrows, rw, passes, max_count)); break;
+      case L_COMPRESS: AFX_HIP(afxk_compress2x(s, (const afx_compress_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
+      case L_NEGENC: AFX_HIP(afxk_negenc(s, (const afx_negenc_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
+      case L_POINTSUM: AFX_HIP(afxk_pointsum(s, (const afx_pointsum_job*)jobs, nrows, rw, passes, max_count)); break;
+      case L_MSM_TABLES: AFX_HIP(afxk_msm_tables(s, odd, (const afx_table_job*)jobs, nrows, rw, passes, max_count)); break;
       case L_MSM_FIXED: case L_MSM_WINDOW: case L_MSM_NAF: {
         // pipelined lanes: the heavy kernel of one lane never runs beside the other lane's (only the light kernels
         // overlap it), which keeps per-launch timings meaningful and the VALU free of two competing table working sets
         afx_ctx::Lane& other = ctx->lane[lane ^ 1];
         if (ctx->pipelining && other.msm_recorded) AFX_HIP(hipStreamWaitEvent(s, other.msm_done, 0));
-        AFX_HIP(afxk_msm(s, l.kind == L_MSM_FIXED ? 0 : l.kind == L_MSM_WINDOW ? 1 : 2, l.encodes, l.secret, (const afx_msm_job*)jobs, l.njobs,
-                         (const int32_t*)ctx->d_pos_tables.p, (const int32_t*)ctx->d_sec_tables.p, table_ws, digit_ws, bad_, count,
-                         (ctx->timing && l.kind == L_MSM_WINDOW) ? ctx->clock_probe() : nullptr));
+        AFX_HIP(afxk_msm(s, kind == L_MSM_FIXED ? 0 : kind == L_MSM_WINDOW ? 1 : 2, encodes, secret, (const afx_msm_djob*)jobs, nrows,
+                         (const int32_t*)ctx->d_pos_tables.p, (const int32_t*)ctx->d_sec_tables.p, rw, passes, max_count,
+                         (ctx->timing && kind == L_MSM_WINDOW) ? ctx->clock_probe() : nullptr));
         if (ctx->pipelining) { AFX_HIP(hipEventRecord(L.msm_done, s)); L.msm_recorded = true; }
         break;
       }
       case L_HASH:
         // small passes: the permutation spread over 32 lanes per item (kernels.hip k_hash_coop), while the device has lanes to spare
-        if (small() && (uint64_t)count * l.njobs <= AFX_HASH_COOP_GROUPS) AFX_HIP(afxk_hash_coop(s, (const afx_hash_program*)jobs, l.njobs, bad_, count));
-        else AFX_HIP(afxk_hash(s, (const afx_hash_program*)jobs, l.njobs, bad_, count));
+        if (coop) AFX_HIP(afxk_hash_coop(s, (const afx_hash_program*)jobs, nrows, rw, passes, max_count));
+        else AFX_HIP(afxk_hash(s, (const afx_hash_program*)jobs, nrows, rw, passes, max_count));
         break;
-      case L_FROM_UNIFORM: AFX_HIP(afxk_from_uniform(s, l.in, l.out, l.out_var, count)); break;
-      case L_REDUCE_WIDE: AFX_HIP(afxk_reduce_wide(s, l.in, l.out, count)); break;
-      case L_COPY: AFX_HIP(hipMemcpyAsync(l.out, l.in, l.bytes, hipMemcpyDeviceToDevice, s)); break;
-      case L_FINISH: AFX_HIP(afxk_finish(s, bad_, l.out, count, 0, l.fail_code)); break;
+      case L_FROM_UNIFORM: AFX_HIP(afxk_from_uniform_jobs(s, (const afx_uniform_job*)jobs, nrows, rw, passes, max_count)); break;
+      case L_REDUCE_WIDE: AFX_HIP(afxk_reduce_wide_jobs(s, (const afx_reduce_job*)jobs, nrows, rw, passes, max_count)); break;
+      case L_COPY: AFX_HIP(hipMemcpyAsync(copy->out, copy->in, copy->bytes, hipMemcpyDeviceToDevice, s)); break;
+      case L_FINISH: AFX_HIP(afxk_finish(s, (const afx_finish_job*)jobs, nrows, rw, max_count)); break;
       case L_KINDS: break;
     }
     if (ctx->timing) {
       AFX_HIP(hipEventRecord(tl.stop, s));
       ctx->timed.push_back(tl);
     }
+    return AFX_OK;
+  };
+  if (n == 1) {
+    const Plan& pl = *plans[0];
+    const afx_pass* passes = (const afx_pass*)(bdev + boff[0] + pl.pass_off);
+    for (const Launch& l : pl.launches) {
+      const bool walk = l.kind == L_COMPRESS || l.kind == L_NEGENC;
+      const bool coop = l.kind == L_HASH && pl.small && (uint64_t)pl.count * l.njobs <= AFX_HASH_COOP_GROUPS;
+      if ((rc = launch(l.kind, l.odd, l.encodes, l.secret, bdev + boff[0] + l.jobs_off, walk ? l.nrows : l.njobs, walk ? (const void*)(bdev + boff[0] + l.rows_off) : nullptr,
+                       passes, pl.count, coop, &l)))
+        return rc;
+    }
+    return AFX_OK;
+  }
+  const afx_pass* passes = (const afx_pass*)(bdev + passes_off);
+  for (const Merged& mg : sched) {
+    int encodes = 0, secret = 0;
+    uint32_t max_count = 0;
+    uint64_t hash_groups = 0;
+    bool all_small = true;
+    for (const Part& p : mg.parts) {
+      const Plan& pl = *plans[p.plan];
+      const Launch& l = pl.launches[p.launch];
+      encodes |= l.encodes; secret |= l.secret;
+      max_count = std::max(max_count, pl.count);
+      hash_groups += (uint64_t)pl.count * l.njobs;
+      all_small = all_small && pl.small;
+    }
+    const Launch* first = &plans[mg.parts[0].plan]->launches[mg.parts[0].launch];
+    // jobs = the blob itself: every row names its job by byte offset (plan.h afx_row)
+    if ((rc = launch(mg.kind, mg.odd, encodes, secret, bdev, mg.nrows, bdev + mg.rows_off, passes, max_count,
+                     mg.kind == L_HASH && all_small && hash_groups <= AFX_HASH_COOP_GROUPS, first)))
+      return rc;
   }
   return AFX_OK;
 }
@@ -840,7 +1217,8 @@ afx_hash_program SchnorrBuilder::make_program(const StrobeSim& sim) {
   secure_zero(folded, sizeof folded);
   p.n_records = (uint32_t)recs.size();
   p.records = as_.put(recs.data(), recs.size());
-  p.fields = as_.put(fields_.data(), fields_.size());
+  p.fields = as_.put_ptrs(fields_.data(), fields_.size());
+  p.n_fields = (uint32_t)fields_.size();
   return p;
 }
 
@@ -929,11 +1307,13 @@ void SchnorrBuilder::prove_compact(const uint8_t* rng_seed_dev, uint8_t* challen
   sim_.challenge64("chal", AFX_SQ_SCALAR_OUT, 0);
   // programs are made after all field_of() calls so both share the final field table
   afx_hash_program pr = make_program(rng);
-  pr.outs = as_.put(blind.data(), blind.size());
+  pr.outs = as_.put_ptrs(blind.data(), blind.size());
+  pr.n_outs = (uint32_t)blind.size();
   rng_hash.push_back(pr);
   afx_hash_program pc = make_program(sim_);
   uint8_t* couts[1] = { challenge_out };
-  pc.outs = as_.put(couts, 1);
+  pc.outs = as_.put_ptrs(couts, 1);
+  pc.n_outs = 1;
   chal_hash.push_back(pc);
   // responses s*c + b
   for (size_t i = 0; i < ns; i++) {

@@ -45,6 +45,9 @@ using Enc = std::array<uint8_t, 32>;
 
 }  // namespace afx
 
+namespace afx { struct Plan; struct Session; }
+struct Stager;
+
 struct afx_ctx {
   std::recursive_mutex mu;   // one call at a time per context (workspace, staging and the plan ring are shared)
   int device = 0;
@@ -96,7 +99,8 @@ struct afx_ctx {
     int blob_next = 0;
     hipEvent_t msm_done = nullptr;   // end of this lane's latest k_msm launch
     bool msm_recorded = false;
-    afx::DevBuf staging;             // host-pointer front ends: the call's inputs and outputs in HBM (grow-only; zeroed on destroy)
+    afx::DevBuf staging;             // host-pointer front ends: the call's inputs (and kernel scratch) in HBM (grow-only; zeroed on destroy)
+    afx::DevBuf staging_out;         // ... and its outputs, a region of their own: one copy brings a small call's results back
     void* pin = nullptr;             // pinned bounce buffer for results (a device-to-host copy into pageable memory would
     size_t pin_cap = 0;              // block the host until the kernels end and serialise the two lanes)
     void* pin_in = nullptr;          // pinned image of a SMALL call's whole staging area: its many short input rows are gathered
@@ -112,7 +116,14 @@ struct afx_ctx {
   afx_plan_stats last_stats = {};   // per-item operation counts of the most recent plan
   std::map<std::string, std::array<uint64_t, 25>> folded_states;   // STROBE state after a transcript's all-constant leading blocks, by those blocks' bytes
                                                                    // (SchnorrBuilder::make_program); may derive from the key: wiped on destroy
-  std::map<std::pair<std::string, uint32_t>, size_t> plan_sizes;   // (plan key bytes, pass size) -> workspace bytes (statements.hpp run_chunked)
+  // assembled plans of small host-pointer calls, by (plan key bytes, padded pass size): position-independent (afx::Plan), placed by
+  // relocation at every reuse (statements.hpp run_chunked).  May hold key material (prover plans): wiped on destroy.
+  std::map<std::pair<std::string, uint32_t>, std::shared_ptr<afx::Plan>> plan_cache;
+  size_t plan_cache_bytes = 0;
+  bool plan_selfcheck = false;   // AFX_PLAN_SELFCHECK=1 at context creation (tests): every plan is assembled twice against different
+                                 // provisional bases and both relocated copies must be byte-identical - a pointer field the relocation
+                                 // does not know shows up as a difference
+  afx::Session* session = nullptr;   // set while several small calls are being collected into one set of launches (statements.hpp)
   uint32_t n_cu = 256;   // compute units of the device (k_msm keeps 2 blocks resident on each)
   // parity aid (afx_ctx_set_challenge_trace): device array [trace_rows][trace_count][32] receiving every recomputed challenge
   uint8_t* trace = nullptr;
@@ -120,6 +131,7 @@ struct afx_ctx {
   afx::DevBuf trace_buf;
   unsigned lane_next = 0;
   int force_lane = -1;   // >= 0: every *_dev call runs on this lane (host-pointer front ends pick the lane they staged on)
+  Stager* cur_stager = nullptr;   // the host-pointer front end whose *_dev call is running (its staged ranges: plan reuse), or null
   // optional per-launch HIP-event timing on `stream` (bench.py's roofline figure)
   bool timing = false;
   struct TimedLaunch { int kind; hipEvent_t start, stop; };
@@ -137,31 +149,59 @@ enum LaunchKind { L_FILL_BAD, L_DECODE, L_SCCHECK, L_POINTOP, L_SCALAROP, L_MSM_
 
 struct Launch {
   LaunchKind kind;
-  size_t jobs_off = 0;      // offset of the job array in the blob
+  size_t jobs_off = 0;      // offset of the job array in the plan's blob
   uint32_t njobs = 0;
-  // L_FROM_UNIFORM / L_REDUCE_WIDE / L_FINISH direct arguments
+  size_t rows_off = 0;      // L_COMPRESS, L_NEGENC: the afx_walk_row array (grid rows; each walks a range of the jobs)
+  uint32_t nrows = 0;
+  // L_COPY: direct arguments (device-to-device)
   const uint8_t* in = nullptr;
   uint8_t* out = nullptr;
-  int32_t* out_var = nullptr;
-  uint8_t fail_code = AFX_ST_VERIFICATION_FAILURE;
-  size_t bytes = 0;         // L_COPY
+  size_t bytes = 0;
   int odd = 0;              // L_MSM_TABLES: kind of table (plan.h afx_table_job): 0 multiples 1..8, 1 odd multiples (NAF terms), 2 narrow
   int encodes = 1;          // L_MSM_*: some job of the launch encodes its result inside the kernel (kernels.hip k_msm<KIND, ENC, SEC>)
   int secret = 0;           // L_MSM_*: some term of the launch has a secret scalar under secret-independent addressing
-  int32_t* prefix_ws = nullptr;   // L_COMPRESS, L_NEGENC: scratch for the prefix products (njobs * 9 * count dwords)
-  uint32_t per_group = 0;         // L_COMPRESS: jobs per grid row (each row shares one inversion per item); 0 = all in one row
 };
 
-// Builds one call's kernel launch list over a chunk of `count` items.
+// What an Assembler leaves behind: one statement over one pass of `count` items as a POSITION-INDEPENDENT unit.  Every device
+// pointer inside - in the job arrays, in their side tables, in the pass - points into one of four ranges: the plan's own blob,
+// its workspace, and the staged inputs / outputs of the host-pointer call it serves (anything else is context-resident: generator
+// tables, the key, or the caller's own device arrays).  The plan is assembled against PROVISIONAL bases (non-canonical addresses
+// that are never dereferenced) and moved to real ones by relocate(), which knows every pointer field by type (engine.cpp).  That
+// is what lets a plan be (1) assembled once and reused by later calls of the same statement, shape and size - the host side of a
+// small call was 0.3 ms of its 1.2 ms - and (2) placed next to the plans of OTHER small calls in one blob, workspace and set of
+// kernel launches (run_plans): presentations of 64 shapes in one Issuer::verify stream cost a dozen launches, not 64 dozens.
+struct Plan {
+  std::vector<uint8_t> blob;
+  std::vector<Launch> launches;
+  std::vector<std::pair<size_t, uint32_t>> ptr_tables, term_tables;   // side tables that hold device pointers: (blob offset, entries)
+  uint8_t* blob_base = nullptr;                       // what blob[0]'s device address is assumed to be
+  uint8_t* ws_base = nullptr;  size_t ws_bytes = 0;   // workspace: failure words, variables, encodings, window tables, recoded scalars
+  uint8_t* in_base = nullptr;  size_t in_bytes = 0;   // staged inputs of the call (Stager), or none
+  uint8_t* out_base = nullptr; size_t out_bytes = 0;  // staged outputs
+  size_t pass_off = 0;                                // the plan's afx_pass inside blob
+  uint32_t count = 0;
+  bool small = false;                                 // a latency plan: its hash launches may run k_hash_coop
+  afx_plan_stats stats = {};
+  Plan() = default;
+  Plan(const Plan&) = default;
+  ~Plan();                                            // plans can hold key material (NAF digits, witnesses in transcript constants): wiped
+  void relocate(uint8_t* new_blob, uint8_t* new_ws, uint8_t* new_in, uint8_t* new_out);
+  bool same_as(const Plan& o, std::string* why) const;   // byte comparison after relocation (plan_selfcheck)
+};
+// Launches the plans' kernels on the lane's stream (asynchronous): ONE plan runs its launches as they are; several are merged
+// launch by launch (same kernel = one launch over all their rows, plan.h afx_pass).  Places the plans in the lane's blob and
+// workspace (growing them if need be) and relocates them there.
+int run_plans(afx_ctx* c, int lane, Plan* const* plans, size_t n);
+
+// Builds one call's kernel launch list over a pass of `count` items.
 class Assembler {
  public:
-  // sizing == true: dry run that only measures workspace / blob needs (device addresses are meaningless)
-  Assembler(afx_ctx* ctx, uint32_t count, bool sizing, int lane = 0);
+  // variant: which set of provisional bases the plan is assembled against (plan_selfcheck assembles every plan under two)
+  Assembler(afx_ctx* ctx, uint32_t count, int variant = 0);
   ~Assembler();   // the plan can hold key material (prover witnesses in transcript constants, NAF digits of the key): wiped
   Assembler(const Assembler&) = delete;
   Assembler& operator=(const Assembler&) = delete;
   afx_ctx* ctx;
-  int lane;
   uint32_t count;
   bool fail_all = false;      // statement-level failure for every item (reference would panic / reject all)
   bool secret_scalars = false;   // a prover-side plan (issue, show, the symmetric-key helpers): every scalar of its multiscalar jobs
@@ -170,11 +210,10 @@ class Assembler {
   std::string plan_error;     // a request the plan cannot serve (reported as AFX_E_BAD_ARGS, nothing is launched)
   afx_plan_stats stats = {};  // per-item operation counts of this plan
 
-  // workspace (device addresses are final; the bump pointer starts at the chunk workspace base)
-  int32_t* new_var();         // extended point, SoA [40][count]
+  // workspace (addresses relative to the plan's provisional workspace base)
+  int32_t* new_var();         // extended point, SoA [36][count]
   uint8_t* new_enc();         // [count][32]
   uint64_t* new_state();      // [25][count]
-  size_t total_ws_bytes() const;   // workspace incl. window tables and recoded scalars
   size_t blob_bytes() const { return blob_.size(); }
 
   // launches, executed in the order added
@@ -193,7 +232,7 @@ class Assembler {
   void copy(uint8_t* dst, const uint8_t* src, size_t bytes);   // device-to-device
   void finish(uint8_t* status_dev, uint8_t fail_code);
 
-  // blob: plan data copied to the device in one transfer; returns DEVICE address of the copy
+  // blob: plan data copied to the device in one transfer; returns the (provisional) DEVICE address of the copy
   template <class T>
   const T* put(const T* src, size_t n) {
     const size_t off = blob_alloc(sizeof(T) * n, alignof(T) < 8 ? 8 : alignof(T));
@@ -201,11 +240,20 @@ class Assembler {
     return reinterpret_cast<const T*>(blob_base_ + off);
   }
   size_t blob_alloc(size_t bytes, size_t align);
+  // a table of device pointers: listed, so that Plan::relocate moves its entries
+  template <class T>
+  T* const* put_ptrs(T* const* src, size_t n) {
+    T* const* dev = put(src, n);
+    if (n) ptr_tables_.push_back({ (size_t)((const uint8_t*)dev - blob_base_), (uint32_t)n });
+    return dev;
+  }
 
   uint32_t* bad() const { return bad_; }
   // this pass takes the latency plan (afx_ctx_set_small_batch_items): one chain per term, statements avoid chains that wait for chains
   bool small() const { return ctx->small_batch_items != 0 && count <= ctx->small_batch_items; }
-  int run();   // upload blob, launch everything on ctx->stream (asynchronous)
+  // The plan, relocatable (window-table and digit workspace added, the pass written).  in/out: the staged ranges of the host-pointer
+  // call this plan serves (its pointers into them are moved when the plan is reused under another staging layout), or null.
+  int finish_plan(Plan& out, uint8_t* in_base, size_t in_bytes, uint8_t* out_base, size_t out_bytes);
 
   size_t max_digit_slots = 0, max_table_slots = 0;
   std::vector<Launch> launches;
@@ -217,13 +265,14 @@ class Assembler {
   void compress(const std::vector<afx_compress_job>& cjobs, uint32_t groups);
   template <class T>
   void add_jobs(LaunchKind k, const std::vector<T>& jobs);
+  void add_walk_rows(Launch& l, uint32_t per_row);   // the afx_walk_row array of a k_compress2x / k_negenc launch (+ its prefix scratch)
   std::set<const int32_t*> half_bases_;            // variables that hold HALF their point (producers with leave_half)
   std::vector<afx_compress_job> pending_cjobs_;    // compress_also()
   std::vector<const int32_t*> pending_half_vars_;  // ... and the variables they read: checked to hold halves when the queue is consumed
-  bool sizing_ = false;
+  std::vector<std::pair<size_t, uint32_t>> ptr_tables_, term_tables_;   // (blob offset, entries) of the pointer tables / afx_msm_term tables written so far
   std::vector<uint8_t> blob_;
-  uint8_t* blob_base_ = nullptr;   // device address the blob will live at
-  uint8_t* ws_base_ = nullptr;
+  uint8_t* blob_base_ = nullptr;   // provisional device address of blob_[0]
+  uint8_t* ws_base_ = nullptr;     // provisional device address of the workspace
   size_t ws_off_ = 0;
   uint32_t* bad_ = nullptr;
   friend class SchnorrBuilder;

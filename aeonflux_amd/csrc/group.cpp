@@ -59,15 +59,15 @@ static int run_members(afx_group* g, size_t count, F&& call) {
   // arriving from several host threads spread over the group's devices.
   if (m > 1 && count != 0 && count <= g->members[0]->small_batch_items) {
     // ... in turn only while the members are interchangeable: settings are per member (afx_group_member), and a call must not
-    // see strict mode, secret-independent addressing, a challenge trace or kernel timing on every m-th call only.  Members that
+    // see strict mode, secret-independent addressing, kernel timing or a challenge trace on every m-th call only.  Members that
     // differ (a test set one of them up on purpose): member 0, whose threshold routed the call here, takes every small call.
     bool alike = true;
     for (uint32_t k = 1; k < m && alike; k++) {
       const afx_ctx *a = g->members[0], *b = g->members[k];
       alike = a->small_batch_items == b->small_batch_items && a->strict == b->strict && a->fixed_key_schedule == b->fixed_key_schedule &&
-              a->secret_independent == b->secret_independent && a->chunk_items == b->chunk_items && !b->trace && !b->timing;
+              a->secret_independent == b->secret_independent && a->chunk_items == b->chunk_items && a->timing == b->timing && !b->trace;
     }
-    alike = alike && !g->members[0]->trace && !g->members[0]->timing;
+    alike = alike && !g->members[0]->trace;   // (a challenge trace is read back from ONE member's buffer)
     const uint32_t i = alike ? g->next_small.fetch_add(1, std::memory_order_relaxed) % m : 0;
     const int rc = call(g->members[i], (size_t)0, count);
     if (rc) { const std::string why = afx_last_error(); set_error("member " + std::to_string(i) + ": " + why); }

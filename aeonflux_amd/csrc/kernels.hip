@@ -198,10 +198,25 @@ __global__ void k_setup_postables(const int32_t* __restrict__ base, uint32_t nge
 }
 
 // ---------------------------------------------------------------------------------------------
+// grid row -> (job, pass).  A plan's own launch: rows == null, row r runs jobs[r] of pass 0.  A launch merged from several plans
+// (engine.cpp run_plans): rows[r] gives the pass and where the row's job lies, as a byte offset from `jobs` (then the base of the
+// blob that holds every plan's job arrays where the plans left them - nothing is copied to merge).
+// ---------------------------------------------------------------------------------------------
+template <class T>
+AFX_DEV const T* row_job(const T* __restrict__ jobs, const afx_row* __restrict__ rows) {
+  if (rows) return reinterpret_cast<const T*>(reinterpret_cast<const uint8_t*>(jobs) + rows[blockIdx.y].job_off);
+  return jobs + blockIdx.y;
+}
+AFX_DEV uint32_t row_pass_index(const afx_row* __restrict__ rows) { return rows ? rows[blockIdx.y].pass : 0u; }
+
+// ---------------------------------------------------------------------------------------------
 // decode / scalar checks / small point and scalar ops
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(AFX_BLOCK, 2) k_decode(const afx_decode_job* __restrict__ jobs, uint32_t* __restrict__ bad, uint32_t count) {
-  const afx_decode_job job = jobs[blockIdx.y];
+__global__ void __launch_bounds__(AFX_BLOCK, 2) k_decode(const afx_decode_job* __restrict__ jobs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_decode_job job = *row_job(jobs, rows);
+  const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
+  const uint32_t count = pass.count;
+  uint32_t* __restrict__ bad = pass.bad;
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
   if (item >= count) return;
   uint32_t w[8];
@@ -214,16 +229,22 @@ __global__ void __launch_bounds__(AFX_BLOCK, 2) k_decode(const afx_decode_job* _
   if (job.out) var_store(job.out, count, item, ok ? P : ge_identity());
 }
 
-__global__ void __launch_bounds__(AFX_BLOCK) k_sccheck(const afx_sccheck_job* __restrict__ jobs, uint32_t* __restrict__ bad, uint32_t count) {
-  const afx_sccheck_job job = jobs[blockIdx.y];
+__global__ void __launch_bounds__(AFX_BLOCK) k_sccheck(const afx_sccheck_job* __restrict__ jobs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_sccheck_job job = *row_job(jobs, rows);
+  const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
+  const uint32_t count = pass.count;
+  uint32_t* __restrict__ bad = pass.bad;
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
   if (item >= count) return;
   const sc s = sc_load_item(job.sc, 32, item);
   if (!sc_is_canonical(s)) atomicOr(&bad[item], AFX_BAD_SCALAR);
 }
 
-__global__ void __launch_bounds__(AFX_BLOCK, 2) k_pointop(const afx_pointop_job* __restrict__ jobs, uint32_t* __restrict__ bad, uint32_t count) {
-  const afx_pointop_job job = jobs[blockIdx.y];
+__global__ void __launch_bounds__(AFX_BLOCK, 2) k_pointop(const afx_pointop_job* __restrict__ jobs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_pointop_job job = *row_job(jobs, rows);
+  const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
+  const uint32_t count = pass.count;
+  uint32_t* __restrict__ bad = pass.bad;
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
   if (item >= count) return;
   ge_p3 A = var_load(job.a, count, item);
@@ -245,8 +266,10 @@ __global__ void __launch_bounds__(AFX_BLOCK, 2) k_pointop(const afx_pointop_job*
   }
 }
 
-__global__ void __launch_bounds__(AFX_BLOCK) k_scalarop(const afx_scalarop_job* __restrict__ jobs, uint32_t count) {
-  const afx_scalarop_job job = jobs[blockIdx.y];
+__global__ void __launch_bounds__(AFX_BLOCK) k_scalarop(const afx_scalarop_job* __restrict__ jobs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_scalarop_job job = *row_job(jobs, rows);
+  const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
+  const uint32_t count = pass.count;
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
   if (item >= count) return;
   const sc a = sc_load_item(job.a, job.a_stride, item);
@@ -284,7 +307,7 @@ __device__ __attribute__((aligned(16))) const int32_t AFX_IDENTITY_ENTRY[AFX_TAB
   1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 // per-lane context of one job inside k_msm
 struct msm_env {
-  const afx_msm_job* job;
+  const afx_msm_djob* job;
   const int32_t* table_ws;
   const uint32_t* digit_ws;
   uint32_t count, item, dslot, tslot;
@@ -429,7 +452,7 @@ AFX_DEV ge_p3 msm_add_positional_secret(const msm_env& e, const int32_t* __restr
 enum { MSM_FIXED = 0, MSM_WINDOW = 1, MSM_NAF = 2 };
 
 // recode the per-item scalars of terms [from, nt), stored [slot][AFX_DIGIT_WORDS][count]
-AFX_DEV void msm_recode(const afx_msm_job* job, uint32_t* __restrict__ digit_ws, uint32_t count, uint32_t item, uint32_t from, uint32_t nv, uint32_t nt, bool narrow) {
+AFX_DEV void msm_recode(const afx_msm_djob* job, uint32_t* __restrict__ digit_ws, uint32_t count, uint32_t item, uint32_t from, uint32_t nv, uint32_t nt, bool narrow) {
   const uint32_t dslot = job->digit_slot;
 #pragma unroll 1
   for (uint32_t t = from; t < nt; t++) {
@@ -506,7 +529,7 @@ AFX_DEV ge_p3 msm_fixed_terms(const msm_env& e, const int32_t* __restrict__ pos_
 }
 // addend, extended-coordinate output, compressed output (ENC = false: a launch none of whose jobs encodes here)
 template <bool ENC>
-AFX_DEV void msm_finish(const afx_msm_job* job, ge_p3 acc, uint32_t* __restrict__ bad, uint32_t count, uint32_t item) {
+AFX_DEV void msm_finish(const afx_msm_djob* job, ge_p3 acc, uint32_t* __restrict__ bad, uint32_t count, uint32_t item) {
   if (job->addend) {
     const ge_p3 A = var_load(job->addend, count, item);
     acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_p3_to_cached(A), job->addend_negate != 0));
@@ -527,9 +550,13 @@ AFX_DEV void msm_finish(const afx_msm_job* job, ge_p3 acc, uint32_t* __restrict_
 // the layouts and the entry count as run-time values took 256 registers and scratch.
 template <int TK>
 __global__ void __launch_bounds__(AFX_BLOCK, 2)
-k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table_ws, uint32_t count) {
+k_msm_tables(const afx_table_job* __restrict__ jobs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
+  const uint32_t count = pass.count;
+  int32_t* __restrict__ table_ws = pass.table_ws;
+  if (blockIdx.x * AFX_BLOCK >= count) return;   // a block past the end of this row's pass (the grid is sized for the launch's largest)
   const uint32_t item = min(blockIdx.x * AFX_BLOCK + threadIdx.x, count - 1);
-  const afx_table_job row = rows[blockIdx.y];
+  const afx_table_job row = *row_job(jobs, rows);
   int32_t* slot = table_ws + (size_t)row.table_slot * count * AFX_VAR_TABLE_DWORDS;
   const ge_p3 P = var_load(row.var, count, item);
   // NAF tables and the tables of narrow jobs: [entry][piece][item][16 B]; window tables: [item][entry][128 B]
@@ -546,17 +573,23 @@ k_msm_tables(const afx_table_job* __restrict__ rows, int32_t* __restrict__ table
 // terms of Issuer::verify): an instance of its own, so that the table scans cost the ordinary launches no registers.
 template <int KIND, bool ENC, bool SEC>
 __global__ void __launch_bounds__(AFX_BLOCK, (!ENC && (!SEC || KIND == MSM_FIXED)) ? 3 : 2)
-k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables, int32_t* __restrict__ table_ws,
-      uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count, unsigned long long* __restrict__ clock_probe) {
+k_msm(const afx_msm_djob* __restrict__ jobs, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes,
+      unsigned long long* __restrict__ clock_probe) {
+  const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
+  const uint32_t count = pass.count;
+  uint32_t* __restrict__ bad = pass.bad;
+  int32_t* __restrict__ table_ws = pass.table_ws;
+  uint32_t* __restrict__ digit_ws = pass.digit_ws;
   // Clock probe (measurement aid): one lane of the launch's first block reads the shader-clock counter (s_memtime) and the
   // constant 100 MHz counter (s_memrealtime) around its chain; their ratio is the core clock this kernel actually ran at
   // (the kernels run at the socket power cap, below the nominal clock: DESIGN.md section 4).
   const bool probe = clock_probe && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
   unsigned long long c0 = 0, r0 = 0;
   if (probe) { c0 = clock64(); r0 = wall_clock64(); }
+  if (blockIdx.x * AFX_BLOCK >= count) return;   // a block past the end of this row's pass (the grid is sized for the launch's largest)
   // lanes past the end of the batch shadow the last item (identical values, identical stores)
   const uint32_t item = min(blockIdx.x * AFX_BLOCK + threadIdx.x, count - 1);
-  const afx_msm_job* job = &jobs[blockIdx.y];
+  const afx_msm_djob* job = row_job(jobs, rows);
   const uint32_t nt = job->n_terms, nv = job->n_var, nu = job->n_uni;
   msm_env env;
   env.job = job; env.table_ws = table_ws; env.digit_ws = digit_ws;
@@ -640,12 +673,16 @@ k_msm(const afx_msm_job* __restrict__ jobs, const int32_t* __restrict__ pos_tabl
 // Grid row y walks the jobs [y * per_row, (y + 1) * per_row) of the item: one row (and one inversion per item) for large passes;
 // small passes, where the serial walk is what a call waits for, spread an item's commitments over up to 8 rows.
 __global__ void __launch_bounds__(AFX_BLOCK, 2)
-k_compress2x(const afx_compress_job* __restrict__ jobs, uint32_t njobs_all, uint32_t per_row, int32_t* __restrict__ prefix_ws, uint32_t* __restrict__ bad, uint32_t count) {
+k_compress2x(const afx_compress_job* __restrict__ jobs, const afx_walk_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_walk_row row = rows[blockIdx.y];   // wave-uniform
+  const afx_pass pass = passes[row.pass];
+  const uint32_t count = pass.count;
+  uint32_t* __restrict__ bad = pass.bad;
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
   if (item >= count) return;
-  const uint32_t first = blockIdx.y * per_row, njobs = min(per_row, njobs_all - first);
-  jobs += first;
-  prefix_ws += (size_t)first * AFX_FE_LIMBS * count;
+  const uint32_t njobs = row.n_jobs;
+  jobs = reinterpret_cast<decltype(jobs)>(reinterpret_cast<const uint8_t*>(jobs) + row.job_off);
+  int32_t* __restrict__ prefix_ws = row.prefix_ws;
   fe prod = fe_one();
 #pragma unroll 1
   for (uint32_t j = 0; j < njobs; j++) {
@@ -676,9 +713,16 @@ k_compress2x(const afx_compress_job* __restrict__ jobs, uint32_t njobs_all, uint
 // two-pass walk as k_compress2x; a point whose factor is zero (the identity, or the placeholder of a failed decode - the item
 // is rejected either way) is left out of the product and encodes to zeros.
 __global__ void __launch_bounds__(AFX_BLOCK, 2)
-k_negenc(const afx_negenc_job* __restrict__ jobs, uint32_t njobs, int32_t* __restrict__ prefix_ws, uint32_t* __restrict__ bad, uint32_t count) {
+k_negenc(const afx_negenc_job* __restrict__ jobs, const afx_walk_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_walk_row row = rows[blockIdx.y];   // wave-uniform
+  const afx_pass pass = passes[row.pass];
+  const uint32_t count = pass.count;
+  uint32_t* __restrict__ bad = pass.bad;
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
   if (item >= count) return;
+  const uint32_t njobs = row.n_jobs;
+  jobs = reinterpret_cast<decltype(jobs)>(reinterpret_cast<const uint8_t*>(jobs) + row.job_off);
+  int32_t* __restrict__ prefix_ws = row.prefix_ws;
   fe prod = fe_one();
 #pragma unroll 1
   for (uint32_t j = 0; j < njobs; j++) {
@@ -712,8 +756,11 @@ k_negenc(const afx_negenc_job* __restrict__ jobs, uint32_t njobs, int32_t* __res
 }
 
 // k_pointsum: out = sum of the partial results of a job that Assembler::msm_split cut into one chain per term (+- addend)
-__global__ void __launch_bounds__(AFX_BLOCK, 2) k_pointsum(const afx_pointsum_job* __restrict__ jobs, uint32_t* __restrict__ bad, uint32_t count) {
-  const afx_pointsum_job job = jobs[blockIdx.y];
+__global__ void __launch_bounds__(AFX_BLOCK, 2) k_pointsum(const afx_pointsum_job* __restrict__ jobs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_pointsum_job job = *row_job(jobs, rows);
+  const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
+  const uint32_t count = pass.count;
+  uint32_t* __restrict__ bad = pass.bad;
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
   if (item >= count) return;
   ge_p3 acc = var_load(job.parts[0], count, item);
@@ -738,8 +785,11 @@ AFX_DEV uint64_t load_u64(const uint8_t* p) {
   return (uint64_t)v.x | ((uint64_t)v.y << 32);
 }
 
-__global__ void __launch_bounds__(AFX_BLOCK) k_hash(const afx_hash_program* __restrict__ progs, uint32_t* __restrict__ bad, uint32_t count) {
-  const afx_hash_program* prog = &progs[blockIdx.y];
+__global__ void __launch_bounds__(AFX_BLOCK) k_hash(const afx_hash_program* __restrict__ progs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_hash_program* prog = row_job(progs, rows);
+  const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
+  const uint32_t count = pass.count;
+  uint32_t* __restrict__ bad = pass.bad;
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
   if (item >= count) return;
   uint64_t st[25];
@@ -811,8 +861,12 @@ AFX_DEV uint64_t shfl64(uint64_t v, uint32_t src) {
   const uint32_t lo = __shfl((uint32_t)v, (int)src, 32), hi = __shfl((uint32_t)(v >> 32), (int)src, 32);
   return (uint64_t)lo | ((uint64_t)hi << 32);
 }
-__global__ void __launch_bounds__(AFX_BLOCK) k_hash_coop(const afx_hash_program* __restrict__ progs, uint32_t* __restrict__ bad, uint32_t count) {
-  const afx_hash_program* prog = &progs[blockIdx.y];
+__global__ void __launch_bounds__(AFX_BLOCK) k_hash_coop(const afx_hash_program* __restrict__ progs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_hash_program* prog = row_job(progs, rows);
+  const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
+  const uint32_t count = pass.count;
+  uint32_t* __restrict__ bad = pass.bad;
+  if (blockIdx.x * (AFX_BLOCK / 32) >= count) return;   // a block past the end of this row's pass
   const uint32_t g = threadIdx.x & 31u;
   const uint32_t group = blockIdx.x * (AFX_BLOCK / 32) + (threadIdx.x >> 5);
   const bool live = group < count;                      // a whole group is live or not; dead groups shadow the last item and store nothing
@@ -879,14 +933,17 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_hash_coop(const afx_hash_program*
 // ---------------------------------------------------------------------------------------------
 // status / utilities
 // ---------------------------------------------------------------------------------------------
-__global__ void k_finish(const uint32_t* __restrict__ bad, uint8_t* __restrict__ status, uint32_t count, uint32_t fail_all, uint8_t fail_code) {
+// one grid row per job: the status bytes of one pass / one array to fill (several passes share a launch, engine.cpp)
+__global__ void k_finish(const afx_finish_job* __restrict__ jobs, const afx_row* __restrict__ rows) {
+  const afx_finish_job job = *row_job(jobs, rows);
   const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= count) return;
-  status[item] = (fail_all || bad[item]) ? fail_code : 0;
+  if (item >= job.count) return;
+  job.status[item] = job.bad[item] ? (uint8_t)job.fail_code : (uint8_t)0;
 }
-__global__ void k_fill_u32(uint32_t* p, uint32_t v, uint32_t n) {
+__global__ void k_fill_u32(const afx_fill_job* __restrict__ jobs, const afx_row* __restrict__ rows) {
+  const afx_fill_job job = *row_job(jobs, rows);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
+  if (i < job.n) job.p[i] = job.v;
 }
 __global__ void __launch_bounds__(AFX_BLOCK, 2) k_from_uniform(const uint8_t* __restrict__ wide, uint8_t* __restrict__ out_enc, int32_t* out_var, uint32_t count) {
   const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
@@ -913,6 +970,38 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_reduce_wide(const uint8_t* __rest
 #pragma unroll
   for (int i = 0; i < 8; i++) o[i] = r.v[i];
   enc_store(out, item, o);
+}
+// the same two for the launches of a plan: one job per grid row, the row's pass gives the item count
+__global__ void __launch_bounds__(AFX_BLOCK, 2) k_from_uniform_jobs(const afx_uniform_job* __restrict__ jobs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_uniform_job job = *row_job(jobs, rows);
+  const afx_pass pass = passes[row_pass_index(rows)];
+  const uint32_t count = pass.count;
+  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  if (item >= count) return;
+  uint32_t w[16];
+  enc_load(w, job.wide, 2 * item);
+  enc_load(w + 8, job.wide, 2 * item + 1);
+  const ge_p3 P = ristretto_from_uniform(w);
+  if (job.out_var) var_store(job.out_var, count, item, P);
+  if (job.out_enc) {
+    uint32_t e[8];
+    ristretto_encode(e, P);
+    enc_store(job.out_enc, item, e);
+  }
+}
+__global__ void __launch_bounds__(AFX_BLOCK) k_reduce_wide_jobs(const afx_reduce_job* __restrict__ jobs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_reduce_job job = *row_job(jobs, rows);
+  const afx_pass pass = passes[row_pass_index(rows)];
+  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  if (item >= pass.count) return;
+  uint32_t w[16];
+  enc_load(w, job.wide, 2 * item);
+  enc_load(w + 8, job.wide, 2 * item + 1);
+  const sc r = sc_reduce512(w);
+  uint32_t o[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) o[i] = r.v[i];
+  enc_store(job.out, item, o);
 }
 // decode -> ok flag -> re-encode (round-trip parity test of decode+encode)
 __global__ void __launch_bounds__(AFX_BLOCK, 2) k_validate(const uint8_t* __restrict__ enc, uint8_t* __restrict__ ok, uint8_t* __restrict__ reenc, uint32_t count) {
@@ -954,20 +1043,21 @@ hipError_t afxk_setup_generators(hipStream_t s, const uint8_t* enc, uint32_t nge
   hipLaunchKernelGGL(k_setup_generators, dim3((ngen + 63) / 64), dim3(64), 0, s, enc, ngen, ext, neg_enc, ok);
   return hipGetLastError();
 }
-hipError_t afxk_decode(hipStream_t s, const afx_decode_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count) {
-  hipLaunchKernelGGL(k_decode, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, bad, count);
+// `max_count`: the largest item count among the passes of the launch (sizes the grid; a row's lanes past its own pass's count retire)
+hipError_t afxk_decode(hipStream_t s, const afx_decode_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  hipLaunchKernelGGL(k_decode, grid_for(max_count, njobs), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
-hipError_t afxk_sccheck(hipStream_t s, const afx_sccheck_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count) {
-  hipLaunchKernelGGL(k_sccheck, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, bad, count);
+hipError_t afxk_sccheck(hipStream_t s, const afx_sccheck_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  hipLaunchKernelGGL(k_sccheck, grid_for(max_count, njobs), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
-hipError_t afxk_pointop(hipStream_t s, const afx_pointop_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count) {
-  hipLaunchKernelGGL(k_pointop, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, bad, count);
+hipError_t afxk_pointop(hipStream_t s, const afx_pointop_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  hipLaunchKernelGGL(k_pointop, grid_for(max_count, njobs), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
-hipError_t afxk_scalarop(hipStream_t s, const afx_scalarop_job* jobs, uint32_t njobs, uint32_t count) {
-  hipLaunchKernelGGL(k_scalarop, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, count);
+hipError_t afxk_scalarop(hipStream_t s, const afx_scalarop_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  hipLaunchKernelGGL(k_scalarop, grid_for(max_count, njobs), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 // base: scratch for ngen * windows extended points (AFX_VAR_DWORDS each); secret != 0: the 4-bit tables (AFX_SEC_*)
@@ -980,64 +1070,71 @@ hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen
   return hipGetLastError();
 }
 template <int KIND>
-static void launch_msm(hipStream_t s, int encodes, int secret, dim3 grid, const afx_msm_job* jobs, const int32_t* pos_tables, const int32_t* sec_tables,
-                       int32_t* table_ws, uint32_t* digit_ws, uint32_t* bad, uint32_t count, unsigned long long* clock_probe) {
+static void launch_msm(hipStream_t s, int encodes, int secret, dim3 grid, const afx_msm_djob* jobs, const int32_t* pos_tables, const int32_t* sec_tables,
+                       const afx_row* rows, const afx_pass* passes, unsigned long long* clock_probe) {
   if (secret) {
-    if (encodes) hipLaunchKernelGGL((k_msm<KIND, true, true>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe);
-    else hipLaunchKernelGGL((k_msm<KIND, false, true>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe);
+    if (encodes) hipLaunchKernelGGL((k_msm<KIND, true, true>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, rows, passes, clock_probe);
+    else hipLaunchKernelGGL((k_msm<KIND, false, true>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, rows, passes, clock_probe);
   } else {
-    if (encodes) hipLaunchKernelGGL((k_msm<KIND, true, false>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe);
-    else hipLaunchKernelGGL((k_msm<KIND, false, false>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe);
+    if (encodes) hipLaunchKernelGGL((k_msm<KIND, true, false>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, rows, passes, clock_probe);
+    else hipLaunchKernelGGL((k_msm<KIND, false, false>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, rows, passes, clock_probe);
   }
 }
-hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_msm_job* jobs, uint32_t njobs, const int32_t* pos_tables,
-                    const int32_t* sec_tables, int32_t* table_ws, uint32_t* digit_ws, uint32_t* bad, uint32_t count, unsigned long long* clock_probe) {
+hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t njobs, const int32_t* pos_tables,
+                    const int32_t* sec_tables, const afx_row* rows, const afx_pass* passes, uint32_t max_count, unsigned long long* clock_probe) {
   if (secret && !sec_tables) return hipErrorInvalidValue;
   switch (kind) {
-    case MSM_FIXED: launch_msm<MSM_FIXED>(s, encodes, secret, grid_for(count, njobs), jobs, pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe); break;
-    case MSM_WINDOW: launch_msm<MSM_WINDOW>(s, encodes, secret, grid_for(count, njobs), jobs, pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe); break;
-    case MSM_NAF: launch_msm<MSM_NAF>(s, encodes, secret, grid_for(count, njobs), jobs, pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe); break;
+    case MSM_FIXED: launch_msm<MSM_FIXED>(s, encodes, secret, grid_for(max_count, njobs), jobs, pos_tables, sec_tables, rows, passes, clock_probe); break;
+    case MSM_WINDOW: launch_msm<MSM_WINDOW>(s, encodes, secret, grid_for(max_count, njobs), jobs, pos_tables, sec_tables, rows, passes, clock_probe); break;
+    case MSM_NAF: launch_msm<MSM_NAF>(s, encodes, secret, grid_for(max_count, njobs), jobs, pos_tables, sec_tables, rows, passes, clock_probe); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
-hipError_t afxk_msm_tables(hipStream_t s, int kind, const afx_table_job* rows, uint32_t nrows, int32_t* table_ws, uint32_t count) {
+hipError_t afxk_msm_tables(hipStream_t s, int kind, const afx_table_job* jobs, uint32_t nrows, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
   switch (kind) {
-    case TABLE_WINDOW: hipLaunchKernelGGL(k_msm_tables<TABLE_WINDOW>, grid_for(count, nrows), dim3(AFX_BLOCK), 0, s, rows, table_ws, count); break;
-    case TABLE_ODD: hipLaunchKernelGGL(k_msm_tables<TABLE_ODD>, grid_for(count, nrows), dim3(AFX_BLOCK), 0, s, rows, table_ws, count); break;
-    case TABLE_NARROW: hipLaunchKernelGGL(k_msm_tables<TABLE_NARROW>, grid_for(count, nrows), dim3(AFX_BLOCK), 0, s, rows, table_ws, count); break;
+    case TABLE_WINDOW: hipLaunchKernelGGL(k_msm_tables<TABLE_WINDOW>, grid_for(max_count, nrows), dim3(AFX_BLOCK), 0, s, jobs, rows, passes); break;
+    case TABLE_ODD: hipLaunchKernelGGL(k_msm_tables<TABLE_ODD>, grid_for(max_count, nrows), dim3(AFX_BLOCK), 0, s, jobs, rows, passes); break;
+    case TABLE_NARROW: hipLaunchKernelGGL(k_msm_tables<TABLE_NARROW>, grid_for(max_count, nrows), dim3(AFX_BLOCK), 0, s, jobs, rows, passes); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
-hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, uint32_t njobs, uint32_t per_row, int32_t* prefix_ws, uint32_t* bad, uint32_t count) {
-  if (per_row == 0 || per_row > njobs) per_row = njobs;
-  hipLaunchKernelGGL(k_compress2x, dim3((count + AFX_BLOCK - 1) / AFX_BLOCK, (njobs + per_row - 1) / per_row), dim3(AFX_BLOCK), 0, s, jobs, njobs, per_row, prefix_ws, bad, count);
+hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
+  hipLaunchKernelGGL(k_compress2x, grid_for(max_count, nrows), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
-hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, uint32_t njobs, int32_t* prefix_ws, uint32_t* bad, uint32_t count) {
-  hipLaunchKernelGGL(k_negenc, dim3((count + AFX_BLOCK - 1) / AFX_BLOCK), dim3(AFX_BLOCK), 0, s, jobs, njobs, prefix_ws, bad, count);
+hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
+  hipLaunchKernelGGL(k_negenc, grid_for(max_count, nrows), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
-hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, uint32_t* bad, uint32_t count) {
-  hipLaunchKernelGGL(k_pointsum, grid_for(count, njobs), dim3(AFX_BLOCK), 0, s, jobs, bad, count);
+hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  hipLaunchKernelGGL(k_pointsum, grid_for(max_count, njobs), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
-hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count) {
+hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
   const uint32_t per_block = AFX_BLOCK / 32;
-  hipLaunchKernelGGL(k_hash_coop, dim3((count + per_block - 1) / per_block, nprogs), dim3(AFX_BLOCK), 0, s, progs, bad, count);
+  hipLaunchKernelGGL(k_hash_coop, dim3((max_count + per_block - 1) / per_block, nprogs), dim3(AFX_BLOCK), 0, s, progs, rows, passes);
   return hipGetLastError();
 }
-hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, uint32_t* bad, uint32_t count) {
-  hipLaunchKernelGGL(k_hash, grid_for(count, nprogs), dim3(AFX_BLOCK), 0, s, progs, bad, count);
+hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  hipLaunchKernelGGL(k_hash, grid_for(max_count, nprogs), dim3(AFX_BLOCK), 0, s, progs, rows, passes);
   return hipGetLastError();
 }
-hipError_t afxk_finish(hipStream_t s, const uint32_t* bad, uint8_t* status, uint32_t count, uint32_t fail_all, uint8_t fail_code) {
-  hipLaunchKernelGGL(k_finish, dim3((count + 255) / 256), dim3(256), 0, s, bad, status, count, fail_all, fail_code);
+hipError_t afxk_finish(hipStream_t s, const afx_finish_job* jobs, uint32_t njobs, const afx_row* rows, uint32_t max_count) {
+  hipLaunchKernelGGL(k_finish, dim3((max_count + 255) / 256, njobs), dim3(256), 0, s, jobs, rows);
   return hipGetLastError();
 }
-hipError_t afxk_fill_u32(hipStream_t s, uint32_t* p, uint32_t v, uint32_t n) {
-  hipLaunchKernelGGL(k_fill_u32, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
+hipError_t afxk_fill_u32(hipStream_t s, const afx_fill_job* jobs, uint32_t njobs, const afx_row* rows, uint32_t max_n) {
+  hipLaunchKernelGGL(k_fill_u32, dim3((max_n + 255) / 256, njobs), dim3(256), 0, s, jobs, rows);
+  return hipGetLastError();
+}
+hipError_t afxk_from_uniform_jobs(hipStream_t s, const afx_uniform_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  hipLaunchKernelGGL(k_from_uniform_jobs, grid_for(max_count, njobs), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
+  return hipGetLastError();
+}
+hipError_t afxk_reduce_wide_jobs(hipStream_t s, const afx_reduce_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  hipLaunchKernelGGL(k_reduce_wide_jobs, grid_for(max_count, njobs), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_from_uniform(hipStream_t s, const uint8_t* wide, uint8_t* out_enc, int32_t* out_var, uint32_t count) {

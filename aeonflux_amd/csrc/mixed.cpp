@@ -4,6 +4,8 @@
 // host, by the used part of the shape; each group is one ordinary batch call of this library and the status bytes go back to
 // the caller's order.  Only bytes move on the host (record copies when a shape's sections are not adjacent).
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "statements.hpp"
@@ -34,27 +36,51 @@ int check_positions(const G* groups, size_t n_groups, size_t status_len) {
   return AFX_OK;
 }
 
-// one ordinary batch call per group (`run_one(group, its status bytes)`), status bytes back to the caller's order
+// One ordinary batch call per group (`run_one(group, its status bytes)`), status bytes back to the caller's order.  With a
+// context (`ctx` non-null) the groups small enough for the latency plan are COLLECTED (afx::Session): their arrays go to the
+// device in one copy, their plans run merged - one launch per kernel over all the groups' rows - and their results come back in
+// one copy, so a request of many layouts costs about one small call instead of one per layout.  A large group runs by itself, in
+// between (the session is flushed first: results of one item never wait on another request's batch longer than they must).
 template <class G, class RunOne>
-int run_groups(G* groups, size_t n_groups, uint8_t* status, size_t status_len, RunOne&& run_one) {
+int run_groups(afx_ctx* ctx, G* groups, size_t n_groups, uint8_t* status, size_t status_len, RunOne&& run_one) {
   if ((!groups && n_groups) || (!status && status_len)) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   int rc = check_positions(groups, n_groups, status_len);
   if (rc) return rc;
-  std::vector<uint8_t> tmp;
+  std::unique_lock<std::recursive_mutex> lock;
+  std::unique_ptr<afx::Session> ses;
+  if (ctx && n_groups > 1 && ctx->small_batch_items && !ctx->trace && !ctx->session) {
+    lock = std::unique_lock<std::recursive_mutex>(ctx->mu);   // the session owns the context until its last flush
+    ses.reset(new afx::Session(ctx));
+    if ((rc = ses->ensure_images(0, 0))) return rc;
+  }
+  // statuses of groups with positions land in a buffer of the group's own first (the session fills it at its flush)
+  std::vector<std::vector<uint8_t>> tmp(n_groups);
   size_t next = 0;
-  for (size_t g = 0; g < n_groups; g++) {
+  for (size_t g = 0; g < n_groups && !rc; g++) {
     G& grp = groups[g];
     if (grp.count) {
-      if (!grp.positions) {
-        if ((rc = run_one(grp, status + next))) { set_error("group " + std::to_string(g) + ": " + afx_last_error()); return rc; }
-      } else {
-        tmp.assign(grp.count, AFX_ST_VERIFICATION_FAILURE);
-        if ((rc = run_one(grp, tmp.data()))) { set_error("group " + std::to_string(g) + ": " + afx_last_error()); return rc; }
-        for (size_t i = 0; i < grp.count; i++) status[grp.positions[i]] = tmp[i];
+      uint8_t* st = status + next;
+      if (grp.positions) { tmp[g].assign(grp.count, AFX_ST_VERIFICATION_FAILURE); st = tmp[g].data(); }
+      const bool collect = ses && grp.count <= ctx->small_batch_items;
+      if (ses && !collect) {
+        if ((rc = ses->flush())) break;
+        ses->paused = true;
       }
+      rc = run_one(grp, st);
+      if (ses) ses->paused = false;
+      if (rc) set_error("group " + std::to_string(g) + ": " + afx_last_error());
     }
     next += grp.count;
   }
+  if (ses) {
+    if (rc) ses->drop();
+    else rc = ses->flush();
+    ses.reset();
+  }
+  if (rc) return rc;
+  for (size_t g = 0; g < n_groups; g++)
+    if (groups[g].positions)
+      for (size_t i = 0; i < groups[g].count; i++) status[groups[g].positions[i]] = tmp[g][i];
   return AFX_OK;
 }
 
@@ -63,7 +89,7 @@ int run_groups(G* groups, size_t n_groups, uint8_t* status, size_t status_len, R
 extern "C" int afx_verify_presentations_mixed(afx_ctx* ctx, const afx_presentation_group* groups, size_t n_groups, uint8_t* status,
                                               size_t status_len) try {
   if (!ctx) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return run_groups(groups, n_groups, status, status_len, [&](const afx_presentation_group& G, uint8_t* st) {
+  return run_groups(ctx, groups, n_groups, status, status_len, [&](const afx_presentation_group& G, uint8_t* st) {
     return afx_verify_presentations(ctx, &G.shape, &G.batch, G.count, st);
   });
 } catch (...) { return afx::exception_rc(); }
@@ -71,7 +97,7 @@ extern "C" int afx_verify_presentations_mixed(afx_ctx* ctx, const afx_presentati
 extern "C" int afx_group_verify_presentations_mixed(afx_group* group, const afx_presentation_group* groups, size_t n_groups, uint8_t* status,
                                                     size_t status_len) try {
   if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return run_groups(groups, n_groups, status, status_len, [&](const afx_presentation_group& G, uint8_t* st) {
+  return run_groups((afx_ctx*)nullptr, groups, n_groups, status, status_len, [&](const afx_presentation_group& G, uint8_t* st) {
     return afx_group_verify_presentations(group, &G.shape, &G.batch, G.count, st);
   });
 } catch (...) { return afx::exception_rc(); }
@@ -79,13 +105,13 @@ extern "C" int afx_group_verify_presentations_mixed(afx_group* group, const afx_
 // Issuer::issue over requests of several attribute layouts (/root/reference/src/issuer.rs:111-124; kinds per attribute: src/amacs.rs:168-179)
 extern "C" int afx_issue_mixed(afx_ctx* ctx, const afx_issue_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
   if (!ctx) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return run_groups(groups, n_groups, status, status_len, [&](const afx_issue_group& G, uint8_t* st) {
+  return run_groups(ctx, groups, n_groups, status, status_len, [&](const afx_issue_group& G, uint8_t* st) {
     return afx_issue(ctx, &G.requests, &G.rnd, G.count, &G.out, st);
   });
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_group_issue_mixed(afx_group* group, const afx_issue_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
   if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return run_groups(groups, n_groups, status, status_len, [&](const afx_issue_group& G, uint8_t* st) {
+  return run_groups((afx_ctx*)nullptr, groups, n_groups, status, status_len, [&](const afx_issue_group& G, uint8_t* st) {
     return afx_group_issue(group, &G.requests, &G.rnd, G.count, &G.out, st);
   });
 } catch (...) { return afx::exception_rc(); }
@@ -93,13 +119,13 @@ extern "C" int afx_group_issue_mixed(afx_group* group, const afx_issue_group* gr
 // CredentialIssuance::verify over issuances of several layouts (src/issuer.rs:48-57)
 extern "C" int afx_verify_issuances_mixed(afx_ctx* ctx, const afx_issuance_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
   if (!ctx) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return run_groups(groups, n_groups, status, status_len, [&](const afx_issuance_group& G, uint8_t* st) {
+  return run_groups(ctx, groups, n_groups, status, status_len, [&](const afx_issuance_group& G, uint8_t* st) {
     return afx_verify_issuances(ctx, &G.attrs, &G.issuances, G.n_responses, G.count, st);
   });
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_group_verify_issuances_mixed(afx_group* group, const afx_issuance_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
   if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return run_groups(groups, n_groups, status, status_len, [&](const afx_issuance_group& G, uint8_t* st) {
+  return run_groups((afx_ctx*)nullptr, groups, n_groups, status, status_len, [&](const afx_issuance_group& G, uint8_t* st) {
     return afx_group_verify_issuances(group, &G.attrs, &G.issuances, G.n_responses, G.count, st);
   });
 } catch (...) { return afx::exception_rc(); }
@@ -107,13 +133,13 @@ extern "C" int afx_group_verify_issuances_mixed(afx_group* group, const afx_issu
 // AnonymousCredential::show over credentials of several layouts (src/credential.rs:37-46); every group reports its own shape
 extern "C" int afx_show_mixed(afx_ctx* ctx, afx_show_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
   if (!ctx) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return run_groups(groups, n_groups, status, status_len, [&](afx_show_group& G, uint8_t* st) {
+  return run_groups(ctx, groups, n_groups, status, status_len, [&](afx_show_group& G, uint8_t* st) {
     return afx_show(ctx, &G.creds, G.keypairs, &G.rnd, G.count, &G.out, &G.shape_out, st);
   });
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_group_show_mixed(afx_group* group, afx_show_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
   if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return run_groups(groups, n_groups, status, status_len, [&](afx_show_group& G, uint8_t* st) {
+  return run_groups((afx_ctx*)nullptr, groups, n_groups, status, status_len, [&](afx_show_group& G, uint8_t* st) {
     return afx_group_show(group, &G.creds, G.keypairs, &G.rnd, G.count, &G.out, &G.shape_out, st);
   });
 } catch (...) { return afx::exception_rc(); }
@@ -134,7 +160,7 @@ extern "C" int afx_wire_section_bytes(const uint8_t* blob, size_t len, size_t* s
 
 // `verify_section(section bytes, length, status, cap, &n)`: one same-shape AFXP batch on a context or on a group of them
 template <class VerifySection>
-static int mixed_wire(const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out, VerifySection&& verify_section) {
+static int mixed_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out, VerifySection&& verify_section) {
   if ((!blob && len) || !count_out || (!status && status_cap)) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   struct Section { size_t off, len, hdr, count, first; };
   struct Group { std::vector<Section> sections; size_t count = 0; };
@@ -158,47 +184,72 @@ static int mixed_wire(const uint8_t* blob, size_t len, uint8_t* status, size_t s
   }
   *count_out = total;
   if (total > status_cap) { set_error("status buffer too small"); return AFX_E_BAD_ARGS; }
-  std::vector<uint8_t> merged, st;
-  for (const std::string& key : order) {
-    const Group& G = by_shape[key];
+  // with a context: the small groups are collected and run as one set of launches (see run_groups)
+  std::unique_lock<std::recursive_mutex> lock;
+  std::unique_ptr<afx::Session> ses;
+  int rc = AFX_OK;
+  if (ctx && order.size() > 1 && ctx->small_batch_items && !ctx->trace && !ctx->session) {
+    lock = std::unique_lock<std::recursive_mutex>(ctx->mu);
+    ses.reset(new afx::Session(ctx));
+    if ((rc = ses->ensure_images(0, 0))) return rc;
+  }
+  std::vector<uint8_t> merged;
+  std::vector<std::vector<uint8_t>> sts(order.size());   // statuses of the groups whose sections are not adjacent: scattered after the flush
+  for (size_t gi = 0; gi < order.size() && !rc; gi++) {
+    const Group& G = by_shape[order[gi]];
     if (G.count == 0) continue;
     size_t got = 0;
+    const bool collect = ses && G.count <= ctx->small_batch_items;
+    if (ses && !collect) {
+      if ((rc = ses->flush())) break;
+      ses->paused = true;
+    }
     if (G.sections.size() == 1) {   // the section as it lies in the caller's blob; its statuses are contiguous in the stream
       const Section& S = G.sections[0];
-      const int rc = verify_section(blob + S.off, S.len, status + S.first, S.count, &got);
-      if (rc) return rc;
-      continue;
+      rc = verify_section(blob + S.off, S.len, status + S.first, S.count, &got);
+    } else if (G.count > 0xffffffffu) {
+      set_error("too many presentations of one shape");
+      rc = AFX_E_BAD_ARGS;
+    } else {
+      // one header (the first section's, with the group's count) and every section's records behind it
+      const Section& S0 = G.sections[0];
+      size_t bytes = S0.hdr;
+      for (const Section& S : G.sections) bytes += S.len - S.hdr;
+      merged.resize(bytes);
+      memcpy(merged.data(), blob + S0.off, S0.hdr);
+      const uint32_t c32 = (uint32_t)G.count;
+      for (int b = 0; b < 4; b++) merged[8 + b] = (uint8_t)(c32 >> (8 * b));
+      size_t w = S0.hdr;
+      for (const Section& S : G.sections) { memcpy(merged.data() + w, blob + S.off + S.hdr, S.len - S.hdr); w += S.len - S.hdr; }
+      sts[gi].assign(G.count, AFX_ST_VERIFICATION_FAILURE);
+      rc = verify_section(merged.data(), merged.size(), sts[gi].data(), sts[gi].size(), &got);   // (a collected call copies its records at once)
     }
-    if (G.count > 0xffffffffu) { set_error("too many presentations of one shape"); return AFX_E_BAD_ARGS; }
-    // one header (the first section's, with the group's count) and every section's records behind it
-    const Section& S0 = G.sections[0];
-    size_t bytes = S0.hdr;
-    for (const Section& S : G.sections) bytes += S.len - S.hdr;
-    merged.resize(bytes);
-    memcpy(merged.data(), blob + S0.off, S0.hdr);
-    const uint32_t c32 = (uint32_t)G.count;
-    for (int b = 0; b < 4; b++) merged[8 + b] = (uint8_t)(c32 >> (8 * b));
-    size_t w = S0.hdr;
-    for (const Section& S : G.sections) { memcpy(merged.data() + w, blob + S.off + S.hdr, S.len - S.hdr); w += S.len - S.hdr; }
-    st.assign(G.count, AFX_ST_VERIFICATION_FAILURE);
-    const int rc = verify_section(merged.data(), merged.size(), st.data(), st.size(), &got);
-    if (rc) return rc;
+    if (ses) ses->paused = false;
+  }
+  if (ses) {
+    if (rc) ses->drop();
+    else rc = ses->flush();
+    ses.reset();
+  }
+  if (rc) return rc;
+  for (size_t gi = 0; gi < order.size(); gi++) {
+    if (sts[gi].empty()) continue;
     size_t r = 0;
-    for (const Section& S : G.sections) { memcpy(status + S.first, st.data() + r, S.count); r += S.count; }
+    for (const Section& S : by_shape[order[gi]].sections) { memcpy(status + S.first, sts[gi].data() + r, S.count); r += S.count; }
   }
   return AFX_OK;
 }
 extern "C" int afx_verify_presentations_mixed_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap,
                                                    size_t* count_out) try {
   if (!ctx) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return mixed_wire(blob, len, status, status_cap, count_out, [&](const uint8_t* b, size_t l, uint8_t* st, size_t cap, size_t* n) {
+  return mixed_wire(ctx, blob, len, status, status_cap, count_out, [&](const uint8_t* b, size_t l, uint8_t* st, size_t cap, size_t* n) {
     return afx_verify_presentations_wire(ctx, b, l, st, cap, n);
   });
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_group_verify_presentations_mixed_wire(afx_group* group, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap,
                                                          size_t* count_out) try {
   if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return mixed_wire(blob, len, status, status_cap, count_out, [&](const uint8_t* b, size_t l, uint8_t* st, size_t cap, size_t* n) {
+  return mixed_wire((afx_ctx*)nullptr, blob, len, status, status_cap, count_out, [&](const uint8_t* b, size_t l, uint8_t* st, size_t cap, size_t* n) {
     return afx_group_verify_presentations_wire(group, b, l, st, cap, n);
   });
 } catch (...) { return afx::exception_rc(); }

@@ -71,6 +71,41 @@
 #define AFX_BAD_CHALLENGE 8u
 #define AFX_BAD_SHAPE 16u
 
+/* One PASS = one statement over one batch of `count` items: the item count (which is also the stride of every struct-of-arrays
+ * variable of the pass), its per-item failure words and its window-table / recoded-scalar workspace.  A kernel launch carries an
+ * array of passes and, per grid row, the index of the row's pass (row_pass; null = every row belongs to pass 0): the launches of
+ * SEVERAL small calls - presentations of many shapes behind one Issuer::verify stream - are merged row by row into one launch
+ * per kernel (engine.cpp PlanSet), so that a stream of n shapes costs one small call's dozen launches, not n dozens. */
+typedef struct {
+  uint32_t count;
+  uint32_t pad;
+  uint32_t* bad;         /* [count] failure bits (AFX_BAD_*)                                              */
+  int32_t* table_ws;     /* window tables of the pass's k_msm launches                                    */
+  uint32_t* digit_ws;    /* recoded scalars of the pass's k_msm launches                                  */
+} afx_pass;
+
+/* A grid row of a MERGED launch: which pass the row belongs to and where its job lies, as a byte offset from the launch's `jobs`
+ * pointer (then the base of the blob holding every plan's job arrays where the plans left them: merging copies no job).  A plan's
+ * own launch passes rows == null: row r runs jobs[r] of pass 0. */
+typedef struct {
+  uint32_t pass;
+  uint32_t job_off;
+} afx_row;
+
+/* a grid row of k_compress2x / k_negenc: the jobs one lane walks for its item with a single field inversion */
+typedef struct {
+  uint32_t job_off;             /* first job of the walk: byte offset from the launch's `jobs` pointer                 */
+  uint32_t n_jobs;
+  uint32_t pass, pad;
+  int32_t* prefix_ws;           /* scratch for the walk's prefix products: n_jobs * 9 * count dwords                   */
+} afx_walk_row;
+
+/* rows of the small utility launches that open and close a plan */
+typedef struct { uint32_t* p; uint32_t v, n; } afx_fill_job;                                            /* p[0..n) = v                */
+typedef struct { const uint32_t* bad; uint8_t* status; uint32_t count, fail_code; } afx_finish_job;     /* status[i] = bad[i] ? code : 0 */
+typedef struct { const uint8_t* wide; uint8_t* out_enc; int32_t* out_var; } afx_uniform_job;            /* RistrettoPoint::from_uniform_bytes */
+typedef struct { const uint8_t* wide; uint8_t* out; } afx_reduce_job;                                   /* Scalar::from_bytes_mod_order_wide  */
+
 /* variable point storage: struct-of-arrays, limb (c*9+l) of item i at base[(c*9+l)*count + i] */
 typedef int32_t* afx_var_t;
 
@@ -149,6 +184,25 @@ typedef struct {
                                            (Assembler::msm sets it; only launches of the SEC kernel instances hold such jobs) */
 } afx_msm_job;
 
+/* The same job as the kernels read it (Assembler::msm_list writes this form into the plan's blob): the terms it HAS, in a side
+ * array, instead of room for AFX_MSM_MAX_TERMS of them - 0.1 KB + 40 B a term instead of 2.9 KB a job (a small C3 verification
+ * has 86 jobs of 1-3 terms: 14 KB of plan instead of 250 KB to assemble, relocate, copy and send). */
+typedef struct {
+  uint32_t n_terms, n_var, n_uni;
+  int32_t top_bit;
+  const uint32_t* naf_sched;
+  const afx_msm_term* term;             /* n_terms entries                                        */
+  const int32_t* addend;
+  uint32_t addend_negate;
+  uint32_t reject_identity;
+  uint8_t* out_enc;
+  afx_var_t out_var;
+  afx_var_t half_var;
+  uint32_t digit_slot;
+  uint32_t narrow;
+  uint32_t leave_half, pad;             /* host-side checks only (tests/hostsim)                  */
+} afx_msm_djob;
+
 /* one window table to build (k_msm_tables<kind>): the base and where the table goes.  Kinds (one launch each): 0 the multiples
  * 1..8 (signed 4-bit windows), item-major [item][entry] - a lane's digit picks one entry; 1 the odd multiples 1, 3, .., 15 (terms
  * that run a width-5 NAF); 2 the multiples 1..AFX_SECVAR_STORED of a narrow job.  Kinds 1 and 2 are entry-major,
@@ -222,4 +276,5 @@ typedef struct {
   uint8_t* const* outs;            /* device table of [count][32] output arrays                 */
   const uint8_t* challenge;        /* [count][32] for AFX_SQ_CHALLENGE_COMPARE                  */
   uint8_t* trace;                  /* optional [count][32]: the recomputed challenge is also stored here (parity aid) */
+  uint32_t n_fields, n_outs;       /* host only: entries of the `fields` / `outs` pointer tables (Plan::relocate walks them)  */
 } afx_hash_program;

@@ -13,6 +13,7 @@
 #include <stdexcept>
 #include <vector>
 #include "engine.hpp"
+#include <stdlib.h>
 #include "statements.hpp"
 
 using namespace afx;
@@ -196,6 +197,7 @@ extern "C" void afx_ctx_destroy(afx_ctx* c) {
   for (auto& L : c->lane) L.ws.release(true);
   for (auto& L : c->lane) {
     L.staging.release(true);
+    L.staging_out.release(true);
     if (L.pin) { memset(L.pin, 0, L.pin_cap); (void)hipHostFree(L.pin); L.pin = nullptr; L.pin_cap = 0; }
     if (L.pin_in) { memset(L.pin_in, 0, L.pin_in_cap); (void)hipHostFree(L.pin_in); L.pin_in = nullptr; L.pin_in_cap = 0; }
     if (L.pin_in_done) { (void)hipEventDestroy(L.pin_in_done); L.pin_in_done = nullptr; }
@@ -224,6 +226,7 @@ extern "C" void afx_ctx_destroy(afx_ctx* c) {
     volatile char* q = const_cast<volatile char*>(kv.first.data());
     for (size_t i = 0; i < kv.first.size(); i++) q[i] = 0;
   }
+  c->plan_cache.clear();   // ~Plan wipes the blobs (prover plans hold witnesses and blinding schedules)
   for (auto& L : c->lane)
     if (L.stream) (void)hipStreamDestroy(L.stream);
   delete c;
@@ -242,6 +245,7 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   const uint32_t n = rd32(sp);
   if (n == 0 || n > AFX_MAX_ATTRIBUTES || splen != sizeof_system_parameters(n)) { set_error("SystemParameters length / attribute count"); return AFX_E_BAD_PARAMS; }
   std::unique_ptr<afx_ctx, void (*)(afx_ctx*)> c(new afx_ctx(), afx_ctx_destroy);
+  { const char* sc = getenv("AFX_PLAN_SELFCHECK"); c->plan_selfcheck = sc && sc[0] == '1'; }   // tests: every plan assembled twice and compared
   c->device = device;
   c->n = n;
   c->g = n < 3 ? 3 : n;
@@ -613,9 +617,9 @@ extern "C" int afx_verify_encryption_proofs_dev(afx_ctx* ctx, uint16_t index, co
 // host-pointer front ends: stage the SoA batch into HBM, run the *_dev form, fetch the status bytes
 // ------------------------------------------------------------------------------------------------
 
-static void stage_encproof(Stager& st, const afx_encproof_soa& e, size_t total, size_t first, size_t n, size_t offs[9]) {
+static void stage_encproof(Stager& st, const afx_encproof_soa& e, size_t total, size_t first, size_t n, size_t dn, size_t offs[9]) {
   const uint8_t* f[9] = { e.challenge, e.responses, e.pk, e.E1, e.E2, e.C_y_1, e.C_y_2, e.C_y_3, e.C_y_2p };
-  for (int i = 0; i < 9; i++) offs[i] = st.add_rows(f[i], i == 1 ? 6 : 1, 32, total, first, n);
+  for (int i = 0; i < 9; i++) offs[i] = st.add_rows(f[i], i == 1 ? 6 : 1, 32, total, first, n, dn);
 }
 static afx_encproof_soa dev_encproof(const Stager& st, const size_t offs[9]) {
   afx_encproof_soa d = { st.dev(offs[0]), st.dev(offs[1]), st.dev(offs[2]), st.dev(offs[3]), st.dev(offs[4]),
@@ -642,20 +646,21 @@ static int verify_presentations_host(afx_ctx* ctx, const afx_shape* shape, const
   if (!b->challenge || !b->C_x_0 || !b->C_x_1 || !b->C_V || (na && !b->C_y) || (nr && !b->responses) || (ne && !b->enc)) { set_error("null batch array"); return AFX_E_BAD_ARGS; }
   return host_pipe(ctx, n, [&](Stager& st, size_t off, size_t sn) -> int {
     const size_t f0 = first + off;
-    const size_t o_ch = st.add_rows(b->challenge, 1, 32, total, f0, sn), o_rs = st.add_rows(b->responses, nr, 32, total, f0, sn),
-                 o_x0 = st.add_rows(b->C_x_0, 1, 32, total, f0, sn), o_x1 = st.add_rows(b->C_x_1, 1, 32, total, f0, sn),
-                 o_cv = st.add_rows(b->C_V, 1, 32, total, f0, sn), o_cy = st.add_rows(b->C_y, na, 32, total, f0, sn),
-                 o_av = st.add_rows(b->attr_values, b->attr_values ? na : 0, 32, total, f0, sn);
+    const size_t dn = st.dev_items(sn);   // the pass's size on the device: small calls are padded to the size their plan is kept for
+    const size_t o_ch = st.add_rows(b->challenge, 1, 32, total, f0, sn, dn), o_rs = st.add_rows(b->responses, nr, 32, total, f0, sn, dn),
+                 o_x0 = st.add_rows(b->C_x_0, 1, 32, total, f0, sn, dn), o_x1 = st.add_rows(b->C_x_1, 1, 32, total, f0, sn, dn),
+                 o_cv = st.add_rows(b->C_V, 1, 32, total, f0, sn, dn), o_cy = st.add_rows(b->C_y, na, 32, total, f0, sn, dn),
+                 o_av = b->attr_values ? st.add_rows(b->attr_values, na, 32, total, f0, sn, dn) : st.reserve(0);
     std::vector<std::array<size_t, 9>> eo(ne);
-    for (uint32_t e = 0; e < ne; e++) stage_encproof(st, b->enc[e], total, f0, sn, eo[e].data());
-    const size_t o_st = st.add(nullptr, sn);
-    st.plan_fetch(status, o_st, 1, 1, total, f0, sn);
+    for (uint32_t e = 0; e < ne; e++) stage_encproof(st, b->enc[e], total, f0, sn, dn, eo[e].data());
+    const size_t o_st = st.add(nullptr, dn);
+    st.plan_fetch(status, o_st, 1, 1, total, f0, sn, dn);
     int rc = st.upload();
     if (rc) return rc;
     std::vector<afx_encproof_soa> de(ne);
     for (uint32_t e = 0; e < ne; e++) de[e] = dev_encproof(st, eo[e].data());
-    afx_presentation_soa d = { st.dev(o_ch), st.dev(o_rs), st.dev(o_x0), st.dev(o_x1), st.dev(o_cv), st.dev(o_cy), st.dev(o_av), de.data() };
-    if ((rc = afx_verify_presentations_dev(ctx, shape, &d, sn, st.dev(o_st)))) return rc;
+    afx_presentation_soa d = { st.dev(o_ch), st.dev(o_rs), st.dev(o_x0), st.dev(o_x1), st.dev(o_cv), st.dev(o_cy), b->attr_values ? st.dev(o_av) : nullptr, de.data() };
+    if ((rc = afx_verify_presentations_dev(ctx, shape, &d, dn, st.dev(o_st)))) return rc;
     return st.fetch_all();
   });
 }
@@ -680,7 +685,7 @@ extern "C" int afx_verify_encryption_proofs(afx_ctx* ctx, uint16_t index, const 
   AFX_HIP(hipSetDevice(ctx->device));
   Stager st(ctx);
   size_t eo[9];
-  stage_encproof(st, *b, count, 0, count, eo);
+  stage_encproof(st, *b, count, 0, count, count, eo);
   const size_t o_st = st.add(nullptr, count);
   int rc = st.upload();
   if (rc) return rc;
@@ -847,7 +852,17 @@ static int verify_wire_records(afx_ctx* ctx, const afx_shape& sh, const uint8_t*
     st.plan_fetch(status, o_st, 1, 1, count, f0, sn);
     int rc2 = st.upload();
     if (rc2) return rc2;
-    AFX_HIP(afxk_aos_to_soa(st.stream(), st.dev(o_rec), st.dev(o_soa), (const uint32_t*)st.dev(o_map), cells, (uint32_t)sn));
+    {
+      // the transposition reads what the upload brings: under a Session it waits for the session's one upload
+      hipStream_t strm = st.stream();
+      const uint8_t* rec_d = st.dev(o_rec);
+      uint8_t* soa_d = st.dev(o_soa);
+      const uint32_t* map_d = (const uint32_t*)st.dev(o_map);
+      const uint32_t cells_ = cells, sn_ = (uint32_t)sn;
+      auto transpose = [=]() -> int { AFX_HIP(afxk_aos_to_soa(strm, rec_d, soa_d, map_d, cells_, sn_)); return AFX_OK; };
+      if (st.ses) st.ses->pre.push_back(transpose);
+      else if ((rc2 = transpose())) return rc2;
+    }
     auto rowp = [&](uint32_t r) { return (const uint8_t*)st.dev(o_soa) + (size_t)r * sn * 32; };
     afx_presentation_soa d;
     d.challenge = rowp(0);
@@ -938,7 +953,17 @@ extern "C" int afx_verify_issuances_wire(afx_ctx* ctx, const uint8_t* blob, size
     st.plan_fetch(status, o_st, 1, 1, count, first, sn);
     int rc2 = st.upload();
     if (rc2) return rc2;
-    AFX_HIP(afxk_aos_to_soa(st.stream(), st.dev(o_rec), st.dev(o_soa), (const uint32_t*)st.dev(o_map), cells, (uint32_t)sn));
+    {
+      // the transposition reads what the upload brings: under a Session it waits for the session's one upload
+      hipStream_t strm = st.stream();
+      const uint8_t* rec_d = st.dev(o_rec);
+      uint8_t* soa_d = st.dev(o_soa);
+      const uint32_t* map_d = (const uint32_t*)st.dev(o_map);
+      const uint32_t cells_ = cells, sn_ = (uint32_t)sn;
+      auto transpose = [=]() -> int { AFX_HIP(afxk_aos_to_soa(strm, rec_d, soa_d, map_d, cells_, sn_)); return AFX_OK; };
+      if (st.ses) st.ses->pre.push_back(transpose);
+      else if ((rc2 = transpose())) return rc2;
+    }
     auto rowp = [&](uint32_t r) { return (uint8_t*)st.dev(o_soa) + (size_t)r * sn * 32; };
     afx_attributes_soa as = at;
     as.values = rowp(4 + nr);

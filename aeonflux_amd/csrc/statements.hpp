@@ -11,26 +11,29 @@
 #include "engine.hpp"
 
 namespace afx {
-static constexpr size_t BLOB_CAP = size_t(4) << 20;
+static constexpr size_t BLOB_CAP = size_t(4) << 20;   // initial size of a lane's plan-blob buffers (they grow: engine.cpp run_plans)
 // Items per pass (afx_ctx_set_chunk_items).  Bounds the workspace: window tables + points in flight are ~25 KB (issue,
 // n = 16) to ~70 KB (C3 verification) per item, so the default 2^19 needs 13-37 GB of the 288 GB.  Measured on 2^20-item
 // batches: issue 6.21 M/s at 2^17, 6.45 at 2^18, 6.76 at 2^19, 6.84 at 2^20; C3 verification 2.42 / 2.45 / 2.45 / 2.44.
 static constexpr uint32_t CHUNK_DEFAULT = 1u << 19;
+// assembled plans kept for reuse (afx_ctx.plan_cache): entries / bytes
+static constexpr size_t PLAN_CACHE_ENTRIES = 512, PLAN_CACHE_BYTES = size_t(64) << 20;
 }
 using namespace afx;
+struct Stager;
 
 // context construction shared with afx_issuer_keygen (issuer_params may be null there)
 int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t splen, const uint8_t* key, size_t klen,
                         const uint8_t* key_scalars_only, const uint8_t* issuer_params);
 
 // ------------------------------------------------------------------------------------------------
-// running a statement: size it, grow the workspace, assemble for real, launch
+// running a statement: assemble its plan (or take it from the cache), place it, launch
 // ------------------------------------------------------------------------------------------------
 using BuildFn = std::function<void(Assembler&, size_t /*chunk offset*/, uint32_t /*chunk count*/)>;
 
-// The bytes that determine a plan's SIZE (statement, shape, mode flags - never the data pointers), as the cache key itself:
-// no hash, so two requests share an entry only when these bytes are equal.  Callers pass a CANONICAL shape (unused array
-// tails zeroed: canonical_shape), because the shape of afx_verify_presentations_wire comes from the caller's blob.
+// The bytes that determine a plan apart from its addresses (statement, shape, mode flags - never the data pointers), as the cache
+// key itself: no hash, so two requests share an entry only when these bytes are equal.  Callers pass a CANONICAL shape (unused
+// array tails zeroed: canonical_shape), because the shape of afx_verify_presentations_wire comes from the caller's blob.
 using PlanKey = std::string;   // empty: not cached
 inline PlanKey plan_key(const char* statement, const void* shape, size_t shape_len, uint64_t flags) {
   PlanKey k(statement);
@@ -48,60 +51,41 @@ inline afx_shape canonical_shape(const afx_shape& sh) {
   for (uint32_t i = 0; i < sh.n_enc_proofs && i < AFX_MAX_ATTRIBUTES; i++) c.enc_indices[i] = sh.enc_indices[i];
   return c;
 }
-// mode flags that change a plan's size, for plan_key (every statement passes them all: a flag that does not matter to a
-// statement only costs it a second cache entry)
+// mode flags that change a plan, for plan_key (every statement passes them all: a flag that does not matter to a statement only
+// costs it a second cache entry)
 inline uint64_t mode_flags(const afx_ctx* c) {
   return (c->strict ? 1u : 0u) | (c->fixed_key_schedule ? 2u : 0u) | (c->secret_independent ? 8u : 0u) | ((uint64_t)c->small_batch_items << 8);
 }
 
-// key non-empty: the plan's workspace size is remembered per (key, pass size), so that repeated calls of one statement
-// on one shape assemble their plan once per pass instead of twice (the dry sizing run is skipped).  A remembered size that
-// turns out too small for the assembled plan is dropped and the pass is sized again.
-inline int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, const PlanKey& key = PlanKey()) {
-  AFX_HIP(hipSetDevice(c->device));
-  // all chunks of one call run on one lane; calls alternate lanes only when the caller switched pipelining on
-  const int lane = c->force_lane >= 0 ? c->force_lane : (c->pipelining ? (int)(c->lane_next++ & 1u) : 0);
-  uint32_t chunk = c->chunk_items ? c->chunk_items : CHUNK_DEFAULT;
-  for (size_t off = 0; off < count;) {
-    const uint32_t cc = (uint32_t)std::min<size_t>(chunk, count - off);
-    try {
-      size_t ws_bytes = 0;
-      const std::pair<PlanKey, uint32_t> ck(key, cc);
-      auto hit = !key.empty() ? c->plan_sizes.find(ck) : c->plan_sizes.end();
-      const bool cached = hit != c->plan_sizes.end();
-      if (cached) {
-        ws_bytes = hit->second;
-      } else {
-        Assembler sizing(c, cc, true, lane);
-        build(sizing, off, cc);
-        if (!sizing.plan_error.empty()) { set_error(sizing.plan_error); return AFX_E_BAD_ARGS; }
-        if (sizing.blob_bytes() > BLOB_CAP) { set_error("plan blob exceeds its fixed capacity"); return AFX_E_BAD_ARGS; }
-        ws_bytes = sizing.total_ws_bytes();
-        if (!key.empty() && c->plan_sizes.size() < 4096) c->plan_sizes[ck] = ws_bytes;
-      }
-      int rc = c->lane[lane].ws.ensure(ws_bytes);
-      if (rc) {
-        // the device cannot hold this pass's workspace: take smaller passes (an engine on a shared or smaller GPU still works)
-        if (chunk <= 4096 || cc <= 4096) return rc;
-        (void)hipGetLastError();
-        chunk >>= 1;
-        continue;
-      }
-      Assembler as(c, cc, false, lane);
-      build(as, off, cc);
-      if (cached && (as.total_ws_bytes() > c->lane[lane].ws.cap || as.blob_bytes() > BLOB_CAP)) {
-        c->plan_sizes.erase(ck);   // the remembered size does not fit this plan: size the pass again
-        continue;
-      }
-      if ((rc = as.run())) return rc;
-    } catch (const std::exception& e) {
-      set_error(std::string("plan assembly: ") + e.what());
-      return AFX_E_BAD_ARGS;
-    }
-    off += cc;
-  }
-  return AFX_OK;
-}
+namespace afx {
+// Several small host-pointer calls collected into ONE set of kernel launches (mixed.cpp: the shape groups of a mixed request).
+// While a session is open on a context, every host-pointer front end stages its arrays into the session's image instead of
+// sending them, every *_dev call leaves its plan with the session instead of launching it, and results are declared instead of
+// fetched; flush() sends the image in one copy, runs all the plans merged launch by launch (engine.cpp run_plans), brings every
+// result back in one copy and scatters them to the callers' arrays.  The calls must be independent of each other.
+struct Session {
+  afx_ctx* c;
+  int lane = 0;
+  bool paused = false;
+  std::vector<std::unique_ptr<Plan>> plans;
+  size_t in_used = 0, out_used = 0;                 // bump pointers into the lane's staging / staging_out buffers (and their pinned images)
+  struct Out { uint8_t* dst; size_t pin_off, len; };
+  std::vector<Out> outs;
+  std::vector<std::function<int()>> pre;            // launches that run after the upload and before the plans (k_aos_to_soa of a serialized batch)
+  explicit Session(afx_ctx* ctx) : c(ctx) { c->session = this; }
+  ~Session() { if (c->session == this) c->session = nullptr; }
+  Session(const Session&) = delete;
+  Session& operator=(const Session&) = delete;
+  bool empty() const { return plans.empty() && outs.empty() && pre.empty() && in_used == 0 && out_used == 0; }
+  void drop() { plans.clear(); outs.clear(); pre.clear(); in_used = out_used = 0; }
+  int ensure_images(size_t in_bytes, size_t out_bytes);   // device staging + pinned images of at least these sizes (only while empty)
+  int flush();
+};
+}  // namespace afx
+
+// key non-empty and the call is a small host-pointer one (a Stager is staging it): the assembled plan is kept, position-independent,
+// and reused by later calls of the same statement, shape, mode and (padded) size - those only copy it and move its pointers.
+int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, const PlanKey& key = PlanKey());
 
 struct JobSets {
   std::vector<afx_sccheck_job> sccheck;
@@ -145,116 +129,98 @@ inline void emit(Assembler& as, JobSets& js, uint8_t* status_dev, uint8_t fail_c
   as.finish(status_dev, fail_code);
 }
 
-// Host-pointer front ends: the call's arrays staged into HBM on one of the context's two lanes.  Inputs are copied on the
-// lane's stream; results come back through the lane's pinned buffer (fetch*/drain), so that a front end can keep one slice
-// of a batch computing on one lane while it stages the next slice on the other (statements.cpp, HostPipe).
+// Host-pointer front ends: the call's arrays staged into HBM on one of the context's two lanes.  Inputs (and kernel scratch) and
+// outputs live in two regions (Lane::staging, Lane::staging_out), offsets of the second carry the OUT bit.  Inputs are copied on
+// the lane's stream; results come back through the lane's pinned buffer (fetch_all / drain), so that a front end can keep one
+// slice of a batch computing on one lane while it stages the next slice on the other (host_pipe).  Under a Session (several small
+// calls in one set of launches) the same calls only fill the session's images and declare their results.
 struct Stager {
   afx_ctx* c;
   int ln;
   int prev_force;
-  size_t bytes = 0, pin_bytes = 0;
+  Stager* prev_stager;
+  afx::Session* ses;                 // non-null: this call is being collected
+  size_t in_bytes = 0, out_bytes = 0, pin_bytes = 0;
+  size_t in_at = 0, out_at = 0;      // session mode: where this call's regions start inside the lane's buffers
+  bool uploaded = false;
+  static constexpr size_t OUT = size_t(1) << 62;
   struct Copy { size_t off; const uint8_t* src; size_t len; };
   struct Out { uint8_t* dst; size_t pin_off, len; };
-  std::vector<Copy> copies, blanks;
+  std::vector<Copy> copies, zeros;   // zeros: row tails of padded passes (only the unpacked upload needs them spelled out)
   std::vector<Out> outs;
-  // the *_dev calls made while this object lives run on its lane
-  explicit Stager(afx_ctx* ctx, int lane = 0) : c(ctx), ln(lane), prev_force(ctx->force_lane) { c->force_lane = lane; }
-  ~Stager() { c->force_lane = prev_force; }
+  // the *_dev calls made while this object lives run on its lane and know its staged ranges (run_chunked: plan reuse)
+  // session: the Session collecting this call (host_pipe passes the context's), or null: the call stages and launches by itself
+  explicit Stager(afx_ctx* ctx, int lane = 0, afx::Session* session = nullptr)
+      : c(ctx), ln(session ? session->lane : lane), prev_force(ctx->force_lane), prev_stager(ctx->cur_stager), ses(session) {
+    c->force_lane = ln;
+    c->cur_stager = this;
+  }
+  ~Stager() { c->force_lane = prev_force; c->cur_stager = prev_stager; }
   Stager(const Stager&) = delete;
   Stager& operator=(const Stager&) = delete;
   hipStream_t stream() const { return c->lane[ln].stream; }
-  // reserve `len` bytes, to be filled from host `src` (or left for output when src == nullptr); returns offset
+  // Items a pass of `n` host items runs with on the device.  Small calls are padded up to a power of two (at least 16): the
+  // plan of a padded size serves every call of that statement and shape up to it (afx_ctx.plan_cache), the extra lanes work on
+  // zeros and their results are never fetched - in the latency regime the device has lanes to spare.  Larger calls: n.
+  uint32_t dev_items(size_t n) const {
+    if (!c->small_batch_items || n > c->small_batch_items || c->trace || n == 0) return (uint32_t)n;
+    uint32_t b = 16;
+    while (b < n) b <<= 1;
+    return std::min<uint32_t>(b, c->small_batch_items) < n ? (uint32_t)n : std::min<uint32_t>(b, c->small_batch_items);
+  }
+  // reserve `len` bytes: filled from host `src` (input region), or an output area when src == nullptr (output region, zeroed)
   size_t add(const uint8_t* src, size_t len) {
-    const size_t off = (bytes + 255) & ~size_t(255);
-    bytes = off + len;
-    if (src) copies.push_back({ off, src, len });
-    else if (len) blanks.push_back({ off, nullptr, len });
+    if (!src) { const size_t off = (out_bytes + 255) & ~size_t(255); out_bytes = off + len; return OUT | off; }
+    const size_t off = (in_bytes + 255) & ~size_t(255);
+    in_bytes = off + len;
+    copies.push_back({ off, src, len });
     return off;
   }
-  // scratch that the call's own kernels fill before anything reads it (not zeroed)
+  // scratch that the call's own kernels fill before anything reads it
   size_t reserve(size_t len) {
-    const size_t off = (bytes + 255) & ~size_t(255);
-    bytes = off + len;
+    const size_t off = (in_bytes + 255) & ~size_t(255);
+    in_bytes = off + len;
     return off;
   }
-  // items [first, first + n) of a [rows][total][elem] host array -> a contiguous [rows][n][elem] device array
-  size_t add_rows(const uint8_t* src, size_t rows, size_t elem, size_t total, size_t first, size_t n) {
-    const size_t off = (bytes + 255) & ~size_t(255);
-    bytes = off + rows * n * elem;
-    if (src)
-      for (size_t r = 0; r < rows; r++) copies.push_back({ off + r * n * elem, src + (r * total + first) * elem, n * elem });
-    else if (rows != 0 && n != 0 && elem != 0) blanks.push_back({ off, nullptr, rows * n * elem });   // rows nobody fills start from zero, like add(nullptr, ..)
+  // items [first, first + n) of a [rows][total][elem] host array -> a [rows][dn][elem] device array (dn >= n: dev_items; the
+  // rows' tails stay zero); src == nullptr: an output array of that extent
+  size_t add_rows(const uint8_t* src, size_t rows, size_t elem, size_t total, size_t first, size_t n, size_t dn = 0) {
+    if (dn < n) dn = n;
+    if (!src) return add(nullptr, rows * dn * elem);
+    const size_t off = (in_bytes + 255) & ~size_t(255);
+    in_bytes = off + rows * dn * elem;
+    for (size_t r = 0; r < rows; r++) {
+      copies.push_back({ off + r * dn * elem, src + (r * total + first) * elem, n * elem });
+      if (dn > n) zeros.push_back({ off + (r * dn + n) * elem, nullptr, (dn - n) * elem });   // the padding lanes read zeros
+    }
     return off;
   }
+  uint8_t* in_base() const { return (uint8_t*)c->lane[ln].staging.p + in_at; }
+  uint8_t* out_base() const { return (uint8_t*)c->lane[ln].staging_out.p + out_at; }
+  uint8_t* dev(size_t off) const { return (off & OUT) ? out_base() + (off & ~OUT) : in_base() + off; }
   // Calls of few items are many short rows (75 arrays for a C3 presentation batch): each row as its own copy from pageable
-  // memory costs more than the kernels gain from the latency plan.  Up to PACK_LIMIT bytes the staging area's image is put
-  // together in a pinned buffer (inputs copied, result areas zeroed) and sent in ONE transfer.
+  // memory costs more than the kernels gain from the latency plan.  Up to PACK_LIMIT bytes the input region's image is put
+  // together in a pinned buffer and sent in ONE transfer.
   static constexpr size_t PACK_LIMIT = size_t(4) << 20;
-  int upload() {
-    afx_ctx::Lane& L = c->lane[ln];
-    int rc = L.staging.ensure(bytes + 256);
-    if (rc) return rc;
-    if (bytes <= PACK_LIMIT && copies.size() > 2) {
-      // the event first: a buffer is only published together with the event that guards its reuse
-      if (!L.pin_in_done) AFX_HIP(hipEventCreateWithFlags(&L.pin_in_done, hipEventDisableTiming));
-      if (bytes > L.pin_in_cap) {
-        if (L.pin_in) { AFX_HIP(hipEventSynchronize(L.pin_in_done)); memset(L.pin_in, 0, L.pin_in_cap); (void)hipHostFree(L.pin_in); L.pin_in = nullptr; L.pin_in_cap = 0; }
-        const size_t want = std::min(PACK_LIMIT, std::max<size_t>(size_t(1) << 18, (bytes + 65535) & ~size_t(65535)));
-        void* fresh = nullptr;
-        AFX_HIP(hipHostMalloc(&fresh, want, hipHostMallocDefault));
-        L.pin_in = fresh;
-        L.pin_in_cap = want;
-      } else {
-        AFX_HIP(hipEventSynchronize(L.pin_in_done));   // the previous call's transfer out of this buffer
-      }
-      uint8_t* img = (uint8_t*)L.pin_in;
-      // The image starts from zero: what no copy covers - result areas, reserve() scratch, the 256-byte padding between rows -
-      // would otherwise carry an EARLIER call's bytes (staged keys, seeds) into this call's staging area (at most 4 MB: ~50 us)
-      memset(img, 0, bytes);
-      for (const Copy& k : copies) memcpy(img + k.off, k.src, k.len);
-      AFX_HIP(hipMemcpyAsync(L.staging.p, img, bytes, hipMemcpyHostToDevice, L.stream));
-      AFX_HIP(hipEventRecord(L.pin_in_done, L.stream));
-      return AFX_OK;
-    }
-    for (const Copy& k : copies) AFX_HIP(hipMemcpyAsync((uint8_t*)L.staging.p + k.off, k.src, k.len, hipMemcpyHostToDevice, L.stream));
-    // result areas start from zero: the staging buffer is reused from call to call, and what a call does not write (the
-    // outputs of a failed item, the hidden rows of attr_values) must not hand an earlier call's bytes to this caller
-    for (const Copy& k : blanks) AFX_HIP(hipMemsetAsync((uint8_t*)L.staging.p + k.off, 0, k.len, L.stream));
-    return AFX_OK;
-  }
-  uint8_t* dev(size_t off) const { return (uint8_t*)c->lane[ln].staging.p + off; }
-  // results: the device array [rows][n][elem] at `off` goes to items [first, first + n) of the host array [rows][total][elem].
-  // plan_fetch() declares them (before reserve_pin); fetch_all() enqueues the copies into the pinned buffer after the
-  // kernels; drain() waits for the lane and scatters them to the caller's arrays.
-  void plan_fetch(uint8_t* dst, size_t off, size_t rows, size_t elem, size_t total, size_t first, size_t n) {
+  int upload();
+  // results: the device array [rows][dn][elem] at `off` goes to items [first, first + n) of the host array [rows][total][elem].
+  // plan_fetch() declares them; fetch_all() enqueues the copies into the pinned buffer after the kernels; drain() waits for the
+  // lane and scatters them to the caller's arrays.
+  void plan_fetch(uint8_t* dst, size_t off, size_t rows, size_t elem, size_t total, size_t first, size_t n, size_t dn = 0) {
     if (!dst || !rows || !n) return;
-    pend_.push_back({ off, pin_bytes, rows * n * elem });
-    for (size_t r = 0; r < rows; r++) outs.push_back({ dst + (r * total + first) * elem, pin_bytes + r * n * elem, n * elem });
-    pin_bytes += (rows * n * elem + 63) & ~size_t(63);
+    if (dn < n) dn = n;
+    const size_t o = off & ~OUT;   // outputs only
+    for (size_t r = 0; r < rows; r++) outs.push_back({ dst + (r * total + first) * elem, o + r * dn * elem, n * elem });
+    pend_.push_back({ o, rows * dn * elem });
   }
-  int fetch_all() {
-    afx_ctx::Lane& L = c->lane[ln];
-    if (pin_bytes > L.pin_cap) {
-      if (L.pin) { (void)hipHostFree(L.pin); L.pin = nullptr; L.pin_cap = 0; }
-      const size_t want = (pin_bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
-      AFX_HIP(hipHostMalloc(&L.pin, want, hipHostMallocDefault));
-      L.pin_cap = want;
-    }
-    for (const Pend& p : pend_) AFX_HIP(hipMemcpyAsync((uint8_t*)L.pin + p.pin_off, dev(p.off), p.len, hipMemcpyDeviceToHost, L.stream));
-    return AFX_OK;
-  }
-  int drain() {
-    afx_ctx::Lane& L = c->lane[ln];
-    AFX_HIP(hipStreamSynchronize(L.stream));
-    for (const Out& o : outs) memcpy(o.dst, (const uint8_t*)L.pin + o.pin_off, o.len);
-    outs.clear();
-    pend_.clear();
-    return AFX_OK;
-  }
+  int fetch_all();
+  int drain();
 
  private:
-  struct Pend { size_t off, pin_off, len; };
+  struct Pend { size_t off, len; };
   std::vector<Pend> pend_;
+  bool whole_ = false;   // fetch_all copied the whole output region: pin offsets are output offsets
+  bool fetched_ = false; // fetch_all ran: the pinned buffer holds (or will hold, once the lane is drained) this call's results
 };
 
 // Items per slice of a host-pointer call: slices alternate between the two lanes, so the host-to-device copy of one
@@ -265,40 +231,7 @@ inline size_t host_slice_items(const afx_ctx* c) {
   const size_t chunk = c->chunk_items ? c->chunk_items : CHUNK_DEFAULT;
   return std::min(chunk, HOST_SLICE_DEFAULT);
 }
-// Runs `slice(lane, first, n)` over [0, count) in slices on alternating lanes; `slice` stages, launches and calls
+// Runs `slice(stager, first, n)` over [0, count) in slices on alternating lanes; `slice` stages, launches and calls
 // fetch_all() on the Stager it is given; the pipe drains a lane before that lane is used again, and both at the end.
-inline int host_pipe(afx_ctx* c, size_t count, const std::function<int(Stager&, size_t, size_t)>& slice) {
-  const int entry_force = c->force_lane;
-  const size_t per = host_slice_items(c);
-  std::unique_ptr<Stager> st[2];
-  int rc = AFX_OK;
-  size_t i = 0;
-  try {
-    for (size_t off = 0; off < count && !rc; i++) {
-      const size_t n = std::min(per, count - off);
-      const int lane = (int)(i & 1);
-      if (st[lane]) { rc = st[lane]->drain(); st[lane].reset(); }
-      if (rc) break;
-      st[lane].reset(new Stager(c, lane));
-      c->force_lane = lane;
-      rc = slice(*st[lane], off, n);
-      off += n;
-    }
-  } catch (...) {
-    // copies from and to the caller's arrays may be in flight: wait for them before the exception goes on to the entry
-    // point's handler (which turns it into a return code)
-    for (auto& L : c->lane) if (L.stream) (void)hipStreamSynchronize(L.stream);
-    st[0].reset(); st[1].reset();
-    c->force_lane = entry_force;
-    throw;
-  }
-  for (int k = 0; k < 2; k++) {
-    const int lane = (int)((i + k) & 1);   // oldest first
-    if (st[lane]) { const int r2 = st[lane]->drain(); if (!rc) rc = r2; }
-  }
-  // a failed slice may leave work in flight on the other lane: wait before the Stagers (and the caller's arrays) go away
-  if (rc) for (auto& L : c->lane) if (L.stream) (void)hipStreamSynchronize(L.stream);
-  st[0].reset(); st[1].reset();
-  c->force_lane = entry_force;
-  return rc;
-}
+// Under a Session the call is one slice whose work is left with the session.
+int host_pipe(afx_ctx* c, size_t count, const std::function<int(Stager&, size_t, size_t)>& slice);

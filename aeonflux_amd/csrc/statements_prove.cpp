@@ -505,23 +505,24 @@ extern "C" int afx_issue_range(afx_ctx* ctx, const afx_attributes_soa* req, cons
   const uint32_t na = req->n_attributes, nr = ctx->n + 5;
   return host_pipe(ctx, n, [&](Stager& st, size_t off, size_t sn) -> int {
     const size_t f0 = first + off;
-    const size_t o_val = st.add_rows(req->values, na, 32, total, f0, sn), o_tw = st.add_rows(rnd->t_wide, 1, 64, total, f0, sn),
-                 o_uw = st.add_rows(rnd->U_wide, 1, 64, total, f0, sn), o_seed = st.add_rows(rnd->rng_seed, 1, 32, total, f0, sn),
-                 o_t = st.add(nullptr, 32 * sn), o_U = st.add(nullptr, 32 * sn), o_V = st.add(nullptr, 32 * sn), o_ch = st.add(nullptr, 32 * sn),
-                 o_rs = st.add(nullptr, 32 * sn * nr), o_st = st.add(nullptr, sn);
-    st.plan_fetch(out->t, o_t, 1, 32, total, f0, sn);
-    st.plan_fetch(out->U, o_U, 1, 32, total, f0, sn);
-    st.plan_fetch(out->V, o_V, 1, 32, total, f0, sn);
-    st.plan_fetch(out->challenge, o_ch, 1, 32, total, f0, sn);
-    st.plan_fetch(out->responses, o_rs, nr, 32, total, f0, sn);
-    st.plan_fetch(status, o_st, 1, 1, total, f0, sn);
+    const size_t dn = st.dev_items(sn);   // the pass's size on the device (small calls: padded to the size their plan is kept for)
+    const size_t o_val = st.add_rows(req->values, na, 32, total, f0, sn, dn), o_tw = st.add_rows(rnd->t_wide, 1, 64, total, f0, sn, dn),
+                 o_uw = st.add_rows(rnd->U_wide, 1, 64, total, f0, sn, dn), o_seed = st.add_rows(rnd->rng_seed, 1, 32, total, f0, sn, dn),
+                 o_t = st.add(nullptr, 32 * dn), o_U = st.add(nullptr, 32 * dn), o_V = st.add(nullptr, 32 * dn), o_ch = st.add(nullptr, 32 * dn),
+                 o_rs = st.add(nullptr, 32 * dn * nr), o_st = st.add(nullptr, dn);
+    st.plan_fetch(out->t, o_t, 1, 32, total, f0, sn, dn);
+    st.plan_fetch(out->U, o_U, 1, 32, total, f0, sn, dn);
+    st.plan_fetch(out->V, o_V, 1, 32, total, f0, sn, dn);
+    st.plan_fetch(out->challenge, o_ch, 1, 32, total, f0, sn, dn);
+    st.plan_fetch(out->responses, o_rs, nr, 32, total, f0, sn, dn);
+    st.plan_fetch(status, o_st, 1, 1, total, f0, sn, dn);
     int rc = st.upload();
     if (rc) return rc;
     afx_attributes_soa da = *req;
     da.values = st.dev(o_val);
     afx_issue_randomness dr = { st.dev(o_tw), st.dev(o_uw), st.dev(o_seed) };
     afx_issuance_soa dout = { st.dev(o_t), st.dev(o_U), st.dev(o_V), st.dev(o_ch), st.dev(o_rs) };
-    if ((rc = afx_issue_dev(ctx, &da, &dr, sn, &dout, st.dev(o_st)))) return rc;
+    if ((rc = afx_issue_dev(ctx, &da, &dr, dn, &dout, st.dev(o_st)))) return rc;
     return st.fetch_all();
   });
 } catch (...) { return afx::exception_rc(); }
@@ -548,17 +549,18 @@ extern "C" int afx_verify_issuances_range(afx_ctx* ctx, const afx_attributes_soa
   const uint32_t na = attrs->n_attributes, nr = n_responses;
   return host_pipe(ctx, n, [&](Stager& st, size_t off, size_t sn) -> int {
     const size_t f0 = first + off;
-    const size_t o_val = st.add_rows(attrs->values, na, 32, total, f0, sn), o_t = st.add_rows(iss->t, 1, 32, total, f0, sn),
-                 o_U = st.add_rows(iss->U, 1, 32, total, f0, sn), o_V = st.add_rows(iss->V, 1, 32, total, f0, sn),
-                 o_ch = st.add_rows(iss->challenge, 1, 32, total, f0, sn), o_rs = st.add_rows(iss->responses, nr, 32, total, f0, sn),
-                 o_st = st.add(nullptr, sn);
-    st.plan_fetch(status, o_st, 1, 1, total, f0, sn);
+    const size_t dn = st.dev_items(sn);
+    const size_t o_val = st.add_rows(attrs->values, na, 32, total, f0, sn, dn), o_t = st.add_rows(iss->t, 1, 32, total, f0, sn, dn),
+                 o_U = st.add_rows(iss->U, 1, 32, total, f0, sn, dn), o_V = st.add_rows(iss->V, 1, 32, total, f0, sn, dn),
+                 o_ch = st.add_rows(iss->challenge, 1, 32, total, f0, sn, dn), o_rs = st.add_rows(iss->responses, nr, 32, total, f0, sn, dn),
+                 o_st = st.add(nullptr, dn);
+    st.plan_fetch(status, o_st, 1, 1, total, f0, sn, dn);
     int rc = st.upload();
     if (rc) return rc;
     afx_attributes_soa da = *attrs;
     da.values = st.dev(o_val);
     afx_issuance_soa di = { st.dev(o_t), st.dev(o_U), st.dev(o_V), st.dev(o_ch), st.dev(o_rs) };
-    if ((rc = afx_verify_issuances_dev(ctx, &da, &di, n_responses, sn, st.dev(o_st)))) return rc;
+    if ((rc = afx_verify_issuances_dev(ctx, &da, &di, n_responses, dn, st.dev(o_st)))) return rc;
     return st.fetch_all();
   });
 } catch (...) { return afx::exception_rc(); }
@@ -594,10 +596,11 @@ extern "C" int afx_show_range(afx_ctx* ctx, const afx_credentials_soa* creds, co
   }
   return host_pipe(ctx, n, [&](Stager& st, size_t off, size_t sn) -> int {
     const size_t f0 = first + off;
-    auto in = [&](const uint8_t* p, size_t rows, size_t elem) { return st.add_rows(p, rows, elem, total, f0, sn); };
+    const size_t dn = st.dev_items(sn);
+    auto in = [&](const uint8_t* p, size_t rows, size_t elem) { return (p && rows) ? st.add_rows(p, rows, elem, total, f0, sn, dn) : st.reserve(0); };
     auto res = [&](uint8_t* dst, size_t rows, size_t elem) {
-      const size_t o = st.add(nullptr, rows * sn * elem);
-      st.plan_fetch(dst, o, rows, elem, total, f0, sn);
+      const size_t o = st.add(nullptr, rows * dn * elem);
+      st.plan_fetch(dst, o, rows, elem, total, f0, sn, dn);
       return o;
     };
     const size_t o_val = in(creds->values, na, 32), o_M2 = in(nsp ? creds->M2 : nullptr, nsp ? na : 0, 32), o_m3 = in(nsp ? creds->m3 : nullptr, nsp ? na : 0, 32),
@@ -624,7 +627,7 @@ extern "C" int afx_show_range(afx_ctx* ctx, const afx_credentials_soa* creds, co
     for (uint32_t e = 0; e < nsp; e++)
       de[e] = { st.dev(oe[e][0]), st.dev(oe[e][1]), st.dev(oe[e][2]), st.dev(oe[e][3]), st.dev(oe[e][4]), st.dev(oe[e][5]), st.dev(oe[e][6]), st.dev(oe[e][7]), st.dev(oe[e][8]) };
     afx_presentation_out dout = { st.dev(o_ch), st.dev(o_rs), st.dev(o_x0), st.dev(o_x1), st.dev(o_cv), st.dev(o_cy), st.dev(o_av), de.data() };
-    if ((rc = afx_show_dev(ctx, &dc, kp ? &dk : nullptr, &dr, sn, &dout, shape_out, st.dev(o_st)))) return rc;
+    if ((rc = afx_show_dev(ctx, &dc, kp ? &dk : nullptr, &dr, dn, &dout, shape_out, st.dev(o_st)))) return rc;
     return st.fetch_all();
   });
 } catch (...) { return afx::exception_rc(); }

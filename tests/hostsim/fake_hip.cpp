@@ -47,69 +47,153 @@ hipError_t afxk_setup_generators(hipStream_t, const uint8_t*, uint32_t ngen, int
   for (uint32_t i = 0; i < ngen; i++) ok[i] = 1;
   return hipSuccess;
 }
-hipError_t afxk_decode(hipStream_t, const afx_decode_job* j, uint32_t n, uint32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].enc; return hipSuccess; }
-hipError_t afxk_sccheck(hipStream_t, const afx_sccheck_job* j, uint32_t n, uint32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].sc; return hipSuccess; }
-hipError_t afxk_pointop(hipStream_t, const afx_pointop_job* j, uint32_t n, uint32_t*, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
-hipError_t afxk_scalarop(hipStream_t, const afx_scalarop_job* j, uint32_t n, uint32_t) { for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)j[i].a; return hipSuccess; }
-hipError_t afxk_setup_postables(hipStream_t, const int32_t*, uint32_t, int32_t*, int32_t*, int) { return hipSuccess; }
-hipError_t afxk_msm_tables(hipStream_t, int kind, const afx_table_job* r, uint32_t n, int32_t*, uint32_t) {
-  if (kind < 0 || kind > 2) return hipErrorInvalidValue;
-  for (uint32_t i = 0; i < n; i++) sink += (uintptr_t)r[i].var + r[i].table_slot;
+// Every plan launch comes with its passes and (merged launches) its row table: the fake kernels resolve each grid row to its job the
+// way the real ones do (plan.h afx_row) and touch every pointer-sized field - a row table or a pass that points outside the blob,
+// or a job pointer that escaped relocation (plans are assembled against non-canonical provisional addresses), faults here under ASan.
+template <class T>
+static const T& job_of(const T* jobs, const afx_row* rows, uint32_t r) { return rows ? *(const T*)((const uint8_t*)jobs + rows[r].job_off) : jobs[r]; }
+static const afx_pass& pass_of(const afx_pass* passes, const afx_row* rows, uint32_t r) { return passes[rows ? rows[r].pass : 0]; }
+static bool canonical(const void* p) { return ((uintptr_t)p >> 47) == 0; }   // provisional plan addresses have bit 62 set
+#define CHECK_PTR(p) do { if (!canonical(p)) return hipErrorInvalidDevicePointer; sink += (uintptr_t)(p); } while (0)
+static hipError_t check_pass(const afx_pass& P, uint32_t max_count) {
+  if (P.count == 0 || P.count > max_count) return hipErrorInvalidValue;
+  if (!canonical(P.bad) || !canonical(P.table_ws) || !canonical(P.digit_ws)) return hipErrorInvalidDevicePointer;
+  P.bad[0] |= 0; P.bad[P.count - 1] |= 0;   // the failure words are real memory of the pass's workspace
   return hipSuccess;
 }
-hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_msm_job* j, uint32_t n, const int32_t*, const int32_t* sec_tables, int32_t*, uint32_t*, uint32_t*, uint32_t,
-                    unsigned long long* probe) {
+hipError_t afxk_decode(hipStream_t, const afx_decode_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  for (uint32_t i = 0; i < n; i++) { hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e; CHECK_PTR(job_of(j, rows, i).enc); CHECK_PTR(job_of(j, rows, i).out); }
+  return hipSuccess;
+}
+hipError_t afxk_sccheck(hipStream_t, const afx_sccheck_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  for (uint32_t i = 0; i < n; i++) { hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e; CHECK_PTR(job_of(j, rows, i).sc); }
+  return hipSuccess;
+}
+hipError_t afxk_pointop(hipStream_t, const afx_pointop_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  for (uint32_t i = 0; i < n; i++) {
+    hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e;
+    const afx_pointop_job& q = job_of(j, rows, i);
+    CHECK_PTR(q.a); CHECK_PTR(q.b); CHECK_PTR(q.b_const); CHECK_PTR(q.out); CHECK_PTR(q.out_enc);
+  }
+  return hipSuccess;
+}
+hipError_t afxk_scalarop(hipStream_t, const afx_scalarop_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  for (uint32_t i = 0; i < n; i++) {
+    hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e;
+    const afx_scalarop_job& q = job_of(j, rows, i);
+    CHECK_PTR(q.a); CHECK_PTR(q.b); CHECK_PTR(q.c); CHECK_PTR(q.out);
+  }
+  return hipSuccess;
+}
+hipError_t afxk_setup_postables(hipStream_t, const int32_t*, uint32_t, int32_t*, int32_t*, int) { return hipSuccess; }
+hipError_t afxk_msm_tables(hipStream_t, int kind, const afx_table_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  if (kind < 0 || kind > 2) return hipErrorInvalidValue;
+  for (uint32_t i = 0; i < n; i++) { hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e; CHECK_PTR(job_of(j, rows, i).var); sink += job_of(j, rows, i).table_slot; }
+  return hipSuccess;
+}
+hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t n, const int32_t*, const int32_t* sec_tables, const afx_row* rows,
+                    const afx_pass* passes, uint32_t max_count, unsigned long long* probe) {
   if (probe) { probe[0] += 2250; probe[1] += 100; }
   if (secret && !sec_tables) return hipErrorInvalidValue;
   int any_secret = 0;
   for (uint32_t i = 0; i < n; i++)
-    for (uint32_t t = 0; t < j[i].n_terms; t++) any_secret |= j[i].term[t].secret != 0;
+    for (uint32_t t = 0; t < job_of(jobs, rows, i).n_terms; t++) any_secret |= job_of(jobs, rows, i).term[t].secret != 0;
   if (any_secret != (secret != 0)) return hipErrorInvalidValue;   // the launch's flag is the OR of its terms' flags
   if (kind < 0 || kind > 2) return hipErrorInvalidValue;
   for (uint32_t i = 0; i < n; i++) {
-    if (!encodes && j[i].out_enc && !j[i].half_var) return hipErrorInvalidValue;   // a job that encodes in the kernel needs the encoding launch
-    if ((j[i].n_var == 0 ? 0 : j[i].n_uni ? 2 : 1) != kind && !(j[i].n_var == 0 && kind == 1)) return hipErrorInvalidValue;   // every job in its own class's launch (fixed-only jobs may ride in the windowed one)
-    if (j[i].leave_half && (j[i].out_var || !j[i].half_var)) return hipErrorInvalidValue;    // a job that leaves its half stores only the half
-    for (uint32_t t = 0; t < j[i].n_uni; t++) if (j[i].term[t].dbl) return hipErrorInvalidValue;   // NAF schedules never run on a half base
+    hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e;
+    const afx_msm_djob& j = job_of(jobs, rows, i);
+    if (!encodes && j.out_enc && !j.half_var) return hipErrorInvalidValue;   // a job that encodes in the kernel needs the encoding launch
+    if ((j.n_var == 0 ? 0 : j.n_uni ? 2 : 1) != kind && !(j.n_var == 0 && kind == 1)) return hipErrorInvalidValue;   // every job in its own class's launch (fixed-only jobs may ride in the windowed one)
+    if (j.leave_half && (j.out_var || !j.half_var)) return hipErrorInvalidValue;    // a job that leaves its half stores only the half
+    for (uint32_t t = 0; t < j.n_uni; t++) if (j.term[t].dbl) return hipErrorInvalidValue;   // NAF schedules never run on a half base
     int secret_var = 0;
-    for (uint32_t t = 0; t < j[i].n_var; t++) secret_var |= j[i].term[t].secret != 0;
-    if ((j[i].narrow != 0) != (secret_var != 0) || (j[i].narrow && kind != 1)) return hipErrorInvalidValue;   // narrow windows exactly where a variable base carries a secret
-    for (uint32_t t = 0; t < j[i].n_terms; t++) sink += (uintptr_t)j[i].term[t].scalar;
-    if (j[i].n_uni) {   // the NAF schedule lives in the plan blob: read it to its terminator
-      for (const uint32_t* e = j[i].naf_sched; ; e++) { sink += *e; if (*e == 0xffffffffu) break; }
+    for (uint32_t t = 0; t < j.n_var; t++) secret_var |= j.term[t].secret != 0;
+    if ((j.narrow != 0) != (secret_var != 0) || (j.narrow && kind != 1)) return hipErrorInvalidValue;   // narrow windows exactly where a variable base carries a secret
+    for (uint32_t t = 0; t < j.n_terms; t++) { CHECK_PTR(j.term[t].scalar); CHECK_PTR(j.term[t].var); }
+    CHECK_PTR(j.addend); CHECK_PTR(j.out_enc); CHECK_PTR(j.out_var); CHECK_PTR(j.half_var);
+    if (j.n_uni) {   // the NAF schedule lives in the plan blob: read it to its terminator
+      for (const uint32_t* e2 = j.naf_sched; ; e2++) { sink += *e2; if (*e2 == 0xffffffffu) break; }
     }
   }
   return hipSuccess;
 }
-hipError_t afxk_negenc(hipStream_t, const afx_negenc_job* j, uint32_t n, int32_t* ws, uint32_t*, uint32_t count) {
-  for (uint32_t i = 0; i < n; i++) { sink += (uintptr_t)j[i].enc + (uintptr_t)j[i].var + (uintptr_t)j[i].out_enc; ws[(size_t)i * 9 * count] = 1; ws[((size_t)i * 9 + 8) * count + count - 1] = 1; }
-  return hipSuccess;
-}
-hipError_t afxk_pointsum(hipStream_t, const afx_pointsum_job* j, uint32_t n, uint32_t*, uint32_t) {
-  for (uint32_t i = 0; i < n; i++) {
-    if (j[i].n_parts < 2 || (!j[i].out_var && !j[i].half_var && !j[i].out_enc)) return hipErrorInvalidValue;
-    for (uint32_t k = 0; k < j[i].n_parts; k++) sink += (uintptr_t)j[i].parts[k];
+static hipError_t walk_rows(const uint8_t* jobs, size_t job_size, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count, int kind) {
+  for (uint32_t r = 0; r < nrows; r++) {
+    const afx_pass& P = passes[rows[r].pass];
+    hipError_t e = check_pass(P, max_count); if (e) return e;
+    if (rows[r].n_jobs == 0 || !canonical(rows[r].prefix_ws)) return hipErrorInvalidValue;
+    for (uint32_t i = 0; i < rows[r].n_jobs; i++) {
+      const uint8_t* q = jobs + rows[r].job_off + (size_t)i * job_size;
+      if (kind == 0) { const afx_compress_job* c = (const afx_compress_job*)q; CHECK_PTR(c->var); CHECK_PTR(c->out_enc); }
+      else { const afx_negenc_job* c = (const afx_negenc_job*)q; CHECK_PTR(c->enc); CHECK_PTR(c->var); CHECK_PTR(c->out_enc); }
+    }
+    // the walk's scratch: n_jobs field elements per item
+    rows[r].prefix_ws[0] = 1;
+    rows[r].prefix_ws[(size_t)rows[r].n_jobs * 9 * P.count - 1] = 1;
   }
   return hipSuccess;
 }
-hipError_t afxk_compress2x(hipStream_t, const afx_compress_job* j, uint32_t n, uint32_t per_row, int32_t* ws, uint32_t*, uint32_t count) {
-  if (per_row > n) return hipErrorInvalidValue;
-  for (uint32_t i = 0; i < n; i++) { sink += (uintptr_t)j[i].var + (uintptr_t)j[i].out_enc; ws[(size_t)i * 9 * count] = 1; ws[((size_t)i * 9 + 8) * count + count - 1] = 1; }
+hipError_t afxk_negenc(hipStream_t, const afx_negenc_job* j, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
+  return walk_rows((const uint8_t*)j, sizeof(afx_negenc_job), rows, nrows, passes, max_count, 1);
+}
+hipError_t afxk_compress2x(hipStream_t, const afx_compress_job* j, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
+  return walk_rows((const uint8_t*)j, sizeof(afx_compress_job), rows, nrows, passes, max_count, 0);
+}
+hipError_t afxk_pointsum(hipStream_t, const afx_pointsum_job* jobs, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  for (uint32_t i = 0; i < n; i++) {
+    hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e;
+    const afx_pointsum_job& j = job_of(jobs, rows, i);
+    if (j.n_parts < 2 || (!j.out_var && !j.half_var && !j.out_enc)) return hipErrorInvalidValue;
+    for (uint32_t k = 0; k < j.n_parts; k++) CHECK_PTR(j.parts[k]);
+    CHECK_PTR(j.addend); CHECK_PTR(j.out_var); CHECK_PTR(j.half_var); CHECK_PTR(j.out_enc);
+  }
   return hipSuccess;
 }
-hipError_t afxk_hash(hipStream_t, const afx_hash_program* p, uint32_t n, uint32_t*, uint32_t) {
-  for (uint32_t i = 0; i < n; i++)
-    for (uint32_t r = 0; r < p[i].n_records; r++)
+hipError_t afxk_hash(hipStream_t, const afx_hash_program* p, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  for (uint32_t i = 0; i < n; i++) {
+    hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e;
+    const afx_hash_program& q = job_of(p, rows, i);
+    sink += q.init_state[0] + q.init_state[24];
+    for (uint32_t r = 0; r < q.n_records; r++)
       for (int w = 0; w < 21; w++)
-        if (p[i].records[r].w[w].field >= 0) sink += (uintptr_t)p[i].fields[p[i].records[r].w[w].field];
+        if (q.records[r].w[w].field >= 0) { if ((uint32_t)q.records[r].w[w].field >= q.n_fields) return hipErrorInvalidValue; CHECK_PTR(q.fields[q.records[r].w[w].field]); }
+    for (uint32_t k = 0; k < q.n_outs; k++) CHECK_PTR(q.outs[k]);
+    CHECK_PTR(q.challenge);
+  }
   return hipSuccess;
 }
-hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* p, uint32_t n, uint32_t* bad, uint32_t count) {
-  if ((uint64_t)count * n > AFX_HASH_COOP_GROUPS) return hipErrorInvalidValue;   // only small passes hash with a lane group per item
-  return afxk_hash(s, p, n, bad, count);
+hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* p, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  uint64_t groups = 0;
+  for (uint32_t i = 0; i < n; i++) groups += pass_of(passes, rows, i).count;
+  if (groups > AFX_HASH_COOP_GROUPS) return hipErrorInvalidValue;   // only small passes hash with a lane group per item
+  return afxk_hash(s, p, n, rows, passes, max_count);
 }
-hipError_t afxk_finish(hipStream_t, const uint32_t*, uint8_t* status, uint32_t count, uint32_t, uint8_t) { memset(status, 0x5a, count); return hipSuccess; }
-hipError_t afxk_fill_u32(hipStream_t, uint32_t* p, uint32_t v, uint32_t n) { for (uint32_t i = 0; i < n; i++) p[i] = v; return hipSuccess; }
+hipError_t afxk_finish(hipStream_t, const afx_finish_job* j, uint32_t n, const afx_row* rows, uint32_t max_count) {
+  for (uint32_t i = 0; i < n; i++) {
+    const afx_finish_job& q = job_of(j, rows, i);
+    if (q.count == 0 || q.count > max_count || !canonical(q.bad) || !canonical(q.status)) return hipErrorInvalidValue;
+    sink += q.bad[0] + q.bad[q.count - 1];
+    memset(q.status, 0x5a, q.count);
+  }
+  return hipSuccess;
+}
+hipError_t afxk_fill_u32(hipStream_t, const afx_fill_job* j, uint32_t n, const afx_row* rows, uint32_t max_n) {
+  for (uint32_t i = 0; i < n; i++) {
+    const afx_fill_job& q = job_of(j, rows, i);
+    if (q.n > max_n || !canonical(q.p)) return hipErrorInvalidValue;
+    for (uint32_t k = 0; k < q.n; k++) q.p[k] = q.v;
+  }
+  return hipSuccess;
+}
+hipError_t afxk_from_uniform_jobs(hipStream_t, const afx_uniform_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  for (uint32_t i = 0; i < n; i++) { hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e; CHECK_PTR(job_of(j, rows, i).wide); CHECK_PTR(job_of(j, rows, i).out_enc); CHECK_PTR(job_of(j, rows, i).out_var); }
+  return hipSuccess;
+}
+hipError_t afxk_reduce_wide_jobs(hipStream_t, const afx_reduce_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  for (uint32_t i = 0; i < n; i++) { hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e; CHECK_PTR(job_of(j, rows, i).wide); CHECK_PTR(job_of(j, rows, i).out); }
+  return hipSuccess;
+}
 hipError_t afxk_from_uniform(hipStream_t, const uint8_t*, uint8_t*, int32_t*, uint32_t) { return hipSuccess; }
 hipError_t afxk_reduce_wide(hipStream_t, const uint8_t*, uint8_t*, uint32_t) { return hipSuccess; }
 hipError_t afxk_validate(hipStream_t, const uint8_t*, uint8_t*, uint8_t*, uint32_t) { return hipSuccess; }

@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "aeonflux_amd", "csrc")
 @pytest.fixture(scope="module")
 def hostsim_lib(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("hostsim") / "libafx_hostsim.so")
-    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp", "mixed.cpp", "wire.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "plans.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp", "mixed.cpp", "wire.cpp")]
     srcs.append(os.path.join(ROOT, "tests", "hostsim", "fake_hip.cpp"))
     cmd = ["g++", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fPIC", "-std=c++17",
            "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-shared", "-pthread", "-o", out] + srcs
@@ -267,8 +267,10 @@ def test_every_entry_point_assembles_cleanly_under_asan(hostsim_lib, tmp_path):
     script = tmp_path / "drive.py"
     script.write_text(DRIVER % {"root": ROOT, "lib": hostsim_lib})
     asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
-    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
-    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    # AFX_PLAN_SELFCHECK: every plan is assembled twice against different provisional addresses and the two copies, relocated to
+    # the same place, must be byte-identical; a reused plan must equal a freshly assembled one (engine.hpp afx::Plan)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", AFX_PLAN_SELFCHECK="1")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "hostsim ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
@@ -326,7 +328,7 @@ def test_group_calls_are_race_free_under_tsan(tmp_path):
     if not os.path.isabs(tsan) or not os.path.exists(tsan):
         pytest.skip("no libtsan")
     out = str(tmp_path / "libafx_tsan.so")
-    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp", "mixed.cpp", "wire.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "plans.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp", "mixed.cpp", "wire.cpp")]
     srcs.append(os.path.join(ROOT, "tests", "hostsim", "fake_hip.cpp"))
     r = subprocess.run(["g++", "-g", "-O1", "-fsanitize=thread", "-fPIC", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-shared",
                         "-pthread", "-o", out] + srcs, capture_output=True, text=True)
