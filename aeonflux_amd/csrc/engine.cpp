@@ -686,19 +686,21 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     l.njobs = (uint32_t)out.size();
     // the kernels' form of a job: its terms in a side array (plan.h afx_msm_djob)
     std::vector<afx_msm_djob> dj(out.size());
+    std::vector<size_t> terms_at(out.size());
     for (size_t i = 0; i < out.size(); i++) {
       const afx_msm_job& j = out[i];
       afx_msm_djob& d = dj[i];
       memset(&d, 0, sizeof d);
       d.n_terms = j.n_terms; d.n_var = j.n_var; d.n_uni = j.n_uni; d.top_bit = j.top_bit;
       d.naf_sched = j.naf_sched;
-      d.term = put(j.term, j.n_terms);
-      if (j.n_terms) term_tables_.push_back({ (size_t)((const uint8_t*)d.term - blob_base_), j.n_terms });
+      terms_at[i] = (size_t)((const uint8_t*)put(j.term, j.n_terms) - blob_base_);
+      if (j.n_terms) term_tables_.push_back({ terms_at[i], j.n_terms });
       d.addend = j.addend; d.addend_negate = j.addend_negate; d.reject_identity = j.reject_identity;
       d.out_enc = j.out_enc; d.out_var = j.out_var; d.half_var = j.half_var;
       d.digit_slot = j.digit_slot; d.narrow = j.narrow; d.leave_half = j.leave_half;
     }
     l.jobs_off = blob_alloc(sizeof(afx_msm_djob) * dj.size(), 16);
+    for (size_t i = 0; i < dj.size(); i++) dj[i].term_off = (int32_t)((int64_t)terms_at[i] - (int64_t)(l.jobs_off + sizeof(afx_msm_djob) * i));   // from the job itself
     memcpy(blob_.data() + l.jobs_off, dj.data(), sizeof(afx_msm_djob) * dj.size());
     launches.push_back(l);
   }
@@ -826,7 +828,7 @@ void Plan::relocate(uint8_t* nblob, uint8_t* nws, uint8_t* nin, uint8_t* nout) {
       case L_MSM_WINDOW: case L_MSM_FIXED: case L_MSM_NAF:
         for (uint32_t i = 0; i < l.njobs; i++) {
           afx_msm_djob& j = ((afx_msm_djob*)J)[i];
-          m.fix(j.term); m.fix(j.naf_sched); m.fix(j.addend); m.fix(j.out_enc); m.fix(j.out_var); m.fix(j.half_var);
+          m.fix(j.naf_sched); m.fix(j.addend); m.fix(j.out_enc); m.fix(j.out_var); m.fix(j.half_var);
         }
         break;
       case L_MSM_TABLES: for (uint32_t i = 0; i < l.njobs; i++) m.fix(((afx_table_job*)J)[i].var); break;
@@ -897,7 +899,7 @@ bool Plan::same_as(const Plan& o, std::string* why) const {
           for (uint32_t k = 0; k < l.njobs; k++) {
             if (l.kind == L_MSM_WINDOW || l.kind == L_MSM_FIXED || l.kind == L_MSM_NAF) {
               const afx_msm_djob& j = ((const afx_msm_djob*)J)[k];
-              if (in(j.term, sizeof(afx_msm_term) * j.n_terms)) *why += ": terms of msm job " + std::to_string(k) + " (launch kind " + std::to_string((int)l.kind) + ")";
+              if (in(blob_base + (((const uint8_t*)&j - blob.data()) + j.term_off), sizeof(afx_msm_term) * j.n_terms)) *why += ": terms of msm job " + std::to_string(k) + " (launch kind " + std::to_string((int)l.kind) + ")";
             } else if (l.kind == L_POINTSUM) {
               const afx_pointsum_job& j = ((const afx_pointsum_job*)J)[k];
               if (in(j.parts, 8 * j.n_parts)) *why += ": parts of pointsum job " + std::to_string(k);
@@ -1036,7 +1038,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
 
   // one launch: `jobs` / `rows` / `passes` as the kernels take them (kernels.h)
   auto launch = [&](LaunchKind kind, int odd, int encodes, int secret, const uint8_t* jobs, uint32_t nrows, const void* rows, const afx_pass* passes,
-                    uint32_t max_count, bool coop, const Launch* copy) -> int {
+                    const afx_pass* pass_host, uint32_t max_count, bool coop, const Launch* copy) -> int {
     afx_ctx::TimedLaunch tl = { (int)kind, nullptr, nullptr };
     if (ctx->timing) {
       for (hipEvent_t* e : { &tl.start, &tl.stop }) {
@@ -1062,7 +1064,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
         afx_ctx::Lane& other = ctx->lane[lane ^ 1];
         if (ctx->pipelining && other.msm_recorded) AFX_HIP(hipStreamWaitEvent(s, other.msm_done, 0));
         AFX_HIP(afxk_msm(s, kind == L_MSM_FIXED ? 0 : kind == L_MSM_WINDOW ? 1 : 2, encodes, secret, (const afx_msm_djob*)jobs, nrows,
-                         (const int32_t*)ctx->d_pos_tables.p, (const int32_t*)ctx->d_sec_tables.p, rw, passes, max_count,
+                         (const int32_t*)ctx->d_pos_tables.p, (const int32_t*)ctx->d_sec_tables.p, rw, passes, pass_host, max_count,
                          (ctx->timing && kind == L_MSM_WINDOW) ? ctx->clock_probe() : nullptr));
         if (ctx->pipelining) { AFX_HIP(hipEventRecord(L.msm_done, s)); L.msm_recorded = true; }
         break;
@@ -1091,7 +1093,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
       const bool walk = l.kind == L_COMPRESS || l.kind == L_NEGENC;
       const bool coop = l.kind == L_HASH && pl.small && (uint64_t)pl.count * l.njobs <= AFX_HASH_COOP_GROUPS;
       if ((rc = launch(l.kind, l.odd, l.encodes, l.secret, bdev + boff[0] + l.jobs_off, walk ? l.nrows : l.njobs, walk ? (const void*)(bdev + boff[0] + l.rows_off) : nullptr,
-                       passes, pl.count, coop, &l)))
+                       passes, (const afx_pass*)(pl.blob.data() + pl.pass_off), pl.count, coop, &l)))
         return rc;
     }
     return AFX_OK;
@@ -1112,7 +1114,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
     }
     const Launch* first = &plans[mg.parts[0].plan]->launches[mg.parts[0].launch];
     // jobs = the blob itself: every row names its job by byte offset (plan.h afx_row)
-    if ((rc = launch(mg.kind, mg.odd, encodes, secret, bdev, mg.nrows, bdev + mg.rows_off, passes, max_count,
+    if ((rc = launch(mg.kind, mg.odd, encodes, secret, bdev, mg.nrows, bdev + mg.rows_off, passes, nullptr, max_count,
                      mg.kind == L_HASH && all_small && hash_groups <= AFX_HASH_COOP_GROUPS, first)))
       return rc;
   }

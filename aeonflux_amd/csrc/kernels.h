@@ -18,8 +18,9 @@ hipError_t afxk_msm_tables(hipStream_t s, int kind, const afx_table_job* jobs, u
 // kind: 0 fixed bases only, 1 per-item windows, 2 uniform NAF terms (kernels.hip MSM_*)
 // clock_probe: two 64-bit counters (shader-clock cycles, 100 MHz ticks) one lane of the launch adds its chain's span to; may be null
 // secret: some term of the launch has afx_msm_term.secret set (sec_tables must then be the context's 4-bit tables)
+// rows == null (a plan's own launch): pass_host = the HOST copy of the plan's pass, whose fields go as kernel arguments; merged launches: kinds 0 and 1 only
 hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t njobs, const int32_t* pos_tables, const int32_t* sec_tables,
-                    const afx_row* rows, const afx_pass* passes, uint32_t max_count, unsigned long long* clock_probe);
+                    const afx_row* rows, const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* clock_probe);
 // out_enc = encoding of twice each job's point; every row (plan.h afx_walk_row) shares one field inversion per item
 hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count);
 // out_enc = encoding of the negation of each job's decoded point

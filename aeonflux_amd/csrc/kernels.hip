@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(AFX_BLOCK, 2) k_decode(const afx_decode_job* _
   const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
   const uint32_t count = pass.count;
   uint32_t* __restrict__ bad = pass.bad;
-  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= count) return;
   uint32_t w[8];
   enc_load(w, job.enc, item);
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_sccheck(const afx_sccheck_job* __
   const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
   const uint32_t count = pass.count;
   uint32_t* __restrict__ bad = pass.bad;
-  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= count) return;
   const sc s = sc_load_item(job.sc, 32, item);
   if (!sc_is_canonical(s)) atomicOr(&bad[item], AFX_BAD_SCALAR);
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(AFX_BLOCK, 2) k_pointop(const afx_pointop_job*
   const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
   const uint32_t count = pass.count;
   uint32_t* __restrict__ bad = pass.bad;
-  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= count) return;
   ge_p3 A = var_load(job.a, count, item);
   if (job.sa < 0) A = ge_neg(A);
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_scalarop(const afx_scalarop_job* 
   const afx_scalarop_job job = *row_job(jobs, rows);
   const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
   const uint32_t count = pass.count;
-  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= count) return;
   const sc a = sc_load_item(job.a, job.a_stride, item);
   const sc b = sc_load_item(job.b, job.b_stride, item);
@@ -308,6 +308,7 @@ __device__ __attribute__((aligned(16))) const int32_t AFX_IDENTITY_ENTRY[AFX_TAB
 // per-lane context of one job inside k_msm
 struct msm_env {
   const afx_msm_djob* job;
+  const afx_msm_term* __restrict__ term;   // the job's terms (plan.h afx_job_terms: an offset from the job, itself reached from a kernel argument)
   const int32_t* table_ws;
   const uint32_t* digit_ws;
   uint32_t count, item, dslot, tslot;
@@ -316,11 +317,11 @@ struct msm_env {
 // acc += (4-bit signed digit of window w) * (variable base t), from the lane's own window table
 // `next` (wave-uniform): what consumes the result, GE_FOR_* (ge.cuh)
 AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w, int next) {
-  const int32_t* table = e.table_ws + ((size_t)e.job->term[t].table_slot * e.count + e.item) * AFX_VAR_TABLE_DWORDS;
+  const int32_t* table = e.table_ws + ((size_t)e.term[t].table_slot * e.count + e.item) * AFX_VAR_TABLE_DWORDS;
   const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + ((uint32_t)w >> 3)) * e.count + e.item];
   const int d = (int)((word >> (((uint32_t)w & 7) * 4)) & 15u) - 8;
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
-  const bool neg = (d < 0) != (e.job->term[t].negate != 0);
+  const bool neg = (d < 0) != (e.term[t].negate != 0);
   // multiples 1..8 are stored (at 0..7); digit 0 reads the one identity entry every lane shares (an address select, no table bytes)
   const uint32_t stored = idx ? idx - 1 : 0;
   const int32_t* ent = idx ? table + stored * AFX_TABLE_ENTRY_DWORDS : AFX_IDENTITY_ENTRY;
@@ -339,7 +340,7 @@ AFX_DEV void narrow_fetch(uint32_t (&buf)[AFX_SECVAR_STORED * 32], uint64_t& dig
   digits = dw[0];
   if (sh + AFX_SECVAR_BITS > 32) digits |= (uint64_t)dw[e.count] << 32;   // uniform condition; k + 1 <= 8
   // [entry][piece][item]: the 64 lanes of a wave read 1 KB contiguous per load
-  const int32_t* table = e.table_ws + (size_t)e.job->term[t].table_slot * e.count * AFX_VAR_TABLE_DWORDS + (size_t)e.item * 4;
+  const int32_t* table = e.table_ws + (size_t)e.term[t].table_slot * e.count * AFX_VAR_TABLE_DWORDS + (size_t)e.item * 4;
 #pragma unroll
   for (uint32_t m = 0; m < AFX_SECVAR_STORED; m++) cached_load_words(buf + 32 * m, table + (size_t)m * e.count * AFX_TABLE_ENTRY_DWORDS, (size_t)e.count * 4);
 }
@@ -347,7 +348,7 @@ AFX_DEV ge_p3 narrow_add(const msm_env& e, const ge_p3& acc, uint32_t t, int w, 
   const uint32_t sh = (AFX_SECVAR_BITS * (uint32_t)w) & 31u;
   const int d = (int)((uint32_t)(digits >> sh) & ((1u << AFX_SECVAR_BITS) - 1)) - (1 << (AFX_SECVAR_BITS - 1));
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
-  const bool neg = (d < 0) != (e.job->term[t].negate != 0);
+  const bool neg = (d < 0) != (e.term[t].negate != 0);
   uint32_t sel[32];
 #pragma unroll
   for (int i = 0; i < 32; i++) sel[i] = (uint32_t)AFX_IDENTITY_ENTRY[i];
@@ -393,8 +394,8 @@ AFX_DEV ge_p3 msm_add_positional(const msm_env& e, const int32_t* __restrict__ p
   if (sh + AFX_POS_BITS > 32) w |= (uint64_t)dw[e.count] << 32;   // uniform condition (j is uniform); k + 1 <= 8
   const int d = (int)((uint32_t)(w >> sh) & ((1u << AFX_POS_BITS) - 1)) - (1 << (AFX_POS_BITS - 1));
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
-  const bool neg = (d < 0) != (e.job->term[t].negate != 0);
-  const int4* p = reinterpret_cast<const int4*>(pos_tables + (size_t)e.job->term[t].fixed_idx * AFX_POS_TABLE_DWORDS +
+  const bool neg = (d < 0) != (e.term[t].negate != 0);
+  const int4* p = reinterpret_cast<const int4*>(pos_tables + (size_t)e.term[t].fixed_idx * AFX_POS_TABLE_DWORDS +
                                                 (size_t)j * AFX_POS_WINDOW_DWORDS + idx * AFX_NIELS_DWORDS);
   int32_t v[AFX_NIELS_DWORDS];   // 7 x 16 bytes: 27 limbs + padding
 #pragma unroll
@@ -412,8 +413,8 @@ AFX_DEV ge_p3 msm_add_positional_secret(const msm_env& e, const int32_t* __restr
   const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + (j >> 3)) * e.count + e.item];
   const int d = (int)((word >> ((j & 7) * 4)) & 15u) - 8;
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
-  const bool neg = (d < 0) != (e.job->term[t].negate != 0);
-  const int32_t* win = sec_tables + (size_t)e.job->term[t].fixed_idx * AFX_SEC_TABLE_DWORDS + (size_t)j * AFX_SEC_WINDOW_DWORDS;
+  const bool neg = (d < 0) != (e.term[t].negate != 0);
+  const int32_t* win = sec_tables + (size_t)e.term[t].fixed_idx * AFX_SEC_TABLE_DWORDS + (size_t)j * AFX_SEC_WINDOW_DWORDS;
   int32_t v[27];
 #pragma unroll
   for (int l = 0; l < 27; l++) v[l] = win[l];   // entry 0: the identity in niels form
@@ -454,18 +455,19 @@ enum { MSM_FIXED = 0, MSM_WINDOW = 1, MSM_NAF = 2 };
 // recode the per-item scalars of terms [from, nt), stored [slot][AFX_DIGIT_WORDS][count]
 AFX_DEV void msm_recode(const afx_msm_djob* job, uint32_t* __restrict__ digit_ws, uint32_t count, uint32_t item, uint32_t from, uint32_t nv, uint32_t nt, bool narrow) {
   const uint32_t dslot = job->digit_slot;
+  const afx_msm_term* __restrict__ terms = afx_job_terms(job);
 #pragma unroll 1
   for (uint32_t t = from; t < nt; t++) {
-    sc s = sc_load_item(job->term[t].scalar, job->term[t].scalar_stride, item);
+    sc s = sc_load_item(terms[t].scalar, terms[t].scalar_stride, item);
     // the job computes half of its sum (k_compress2x encodes the double); the term's base holds half its point (leave_half):
     // each alone changes the scalar, both together cancel
-    const bool halve = job->half_var != nullptr, twice = job->term[t].dbl != 0;
+    const bool halve = job->half_var != nullptr, twice = terms[t].dbl != 0;
     if (halve && !twice) s = sc_half(s);
     if (twice && !halve) s = sc_dbl(s);
     uint32_t b[9];
     b[8] = 0;
     if (t < nv && narrow) sc_bias_wide<AFX_SECVAR_BITS, AFX_SECVAR_WINDOWS>(b, s);   // variable bases of a job with a secret on one
-    else if (t < nv || job->term[t].secret) sc_bias(b, s, 0x88888888u);   // signed 4-bit digits: variable bases, and secret scalars on fixed bases
+    else if (t < nv || terms[t].secret) sc_bias(b, s, 0x88888888u);   // signed 4-bit digits: variable bases, and secret scalars on fixed bases
     else sc_bias_wide<AFX_POS_BITS, AFX_POS_WINDOWS>(b, s);
 #pragma unroll
     for (int i = 0; i < AFX_DIGIT_WORDS; i++) digit_ws[((size_t)(dslot + t) * AFX_DIGIT_WORDS + i) * count + item] = b[i];
@@ -505,12 +507,12 @@ AFX_DEV ge_p3 msm_fixed_terms(const msm_env& e, const int32_t* __restrict__ pos_
   int last_pub = -1, last_sec = -1;   // wave-uniform
   if constexpr (SEC) {
 #pragma unroll 1
-    for (uint32_t t = from; t < nt; t++) { if (e.job->term[t].secret) last_sec = (int)t; else last_pub = (int)t; }
+    for (uint32_t t = from; t < nt; t++) { if (e.term[t].secret) last_sec = (int)t; else last_pub = (int)t; }
 #pragma unroll 1
     for (uint32_t j = 0; j < AFX_SEC_WINDOWS && last_sec >= 0; j++) {
 #pragma unroll 1
       for (uint32_t t = from; t < nt; t++)
-        if (e.job->term[t].secret)
+        if (e.term[t].secret)
           acc = msm_add_positional_secret(e, sec_tables, acc, t, j, (last_pub < 0 && j + 1 == AFX_SEC_WINDOWS && (int)t == last_sec) ? GE_FOR_ANY : GE_FOR_ADD);
     }
     if (last_pub < 0) return acc;
@@ -521,7 +523,7 @@ AFX_DEV ge_p3 msm_fixed_terms(const msm_env& e, const int32_t* __restrict__ pos_
   for (uint32_t j = 0; j < AFX_POS_WINDOWS; j++) {
 #pragma unroll 1
     for (uint32_t t = from; t < nt; t++) {
-      if (SEC && e.job->term[t].secret) continue;
+      if (SEC && e.term[t].secret) continue;
       acc = msm_add_positional(e, pos_tables, acc, t, j, (j + 1 == AFX_POS_WINDOWS && (int)t == last_pub) ? GE_FOR_ANY : GE_FOR_ADD);
     }
   }
@@ -554,8 +556,10 @@ k_msm_tables(const afx_table_job* __restrict__ jobs, const afx_row* __restrict__
   const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
   const uint32_t count = pass.count;
   int32_t* __restrict__ table_ws = pass.table_ws;
-  if (blockIdx.x * AFX_BLOCK >= count) return;   // a block past the end of this row's pass (the grid is sized for the launch's largest)
-  const uint32_t item = min(blockIdx.x * AFX_BLOCK + threadIdx.x, count - 1);
+  // a WAVE past the end of this row's pass retires (the grid is sized for the launch's largest pass, and a pass of 16 items is one wave
+  // of its block's four; no kernel here has a barrier).  Inside the last live wave, lanes past the end shadow the last item.
+  if (blockIdx.x * blockDim.x + ((uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x) & ~63u) >= count) return;   // (first lane's id: the branch is scalar)
+  const uint32_t item = min(blockIdx.x * blockDim.x + threadIdx.x, count - 1);
   const afx_table_job row = *row_job(jobs, rows);
   int32_t* slot = table_ws + (size_t)row.table_slot * count * AFX_VAR_TABLE_DWORDS;
   const ge_p3 P = var_load(row.var, count, item);
@@ -571,28 +575,28 @@ k_msm_tables(const afx_table_job* __restrict__ jobs, const afx_row* __restrict__
 // blocks, the fixed-base sums 4.5 %, same box).
 // SEC: the launch has terms with secret scalars under afx_ctx_set_secret_independent_addressing (the prover paths, the key's
 // terms of Issuer::verify): an instance of its own, so that the table scans cost the ordinary launches no registers.
+// The body is shared by two kernels: k_msm, a plan's own launch - the pass's item count and workspace pointers are kernel
+// ARGUMENTS, as they always were (restrict-qualified parameters: the 2^19-item passes of the throughput path measured 0.3-2 %
+// slower with them read from a pass table: profiles/r04_ab_pass_descriptors.txt) - and k_msm_rows, a launch merged from several
+// small plans, where every grid row finds its job and its pass through the row table (plan.h afx_row).
 template <int KIND, bool ENC, bool SEC>
-__global__ void __launch_bounds__(AFX_BLOCK, (!ENC && (!SEC || KIND == MSM_FIXED)) ? 3 : 2)
-k_msm(const afx_msm_djob* __restrict__ jobs, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes,
-      unsigned long long* __restrict__ clock_probe) {
-  const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
-  const uint32_t count = pass.count;
-  uint32_t* __restrict__ bad = pass.bad;
-  int32_t* __restrict__ table_ws = pass.table_ws;
-  uint32_t* __restrict__ digit_ws = pass.digit_ws;
+__device__ __forceinline__ void msm_body(const afx_msm_djob* __restrict__ job, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables,
+                                         int32_t* __restrict__ table_ws, uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count,
+                                         unsigned long long* __restrict__ clock_probe) {
   // Clock probe (measurement aid): one lane of the launch's first block reads the shader-clock counter (s_memtime) and the
   // constant 100 MHz counter (s_memrealtime) around its chain; their ratio is the core clock this kernel actually ran at
   // (the kernels run at the socket power cap, below the nominal clock: DESIGN.md section 4).
   const bool probe = clock_probe && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
   unsigned long long c0 = 0, r0 = 0;
   if (probe) { c0 = clock64(); r0 = wall_clock64(); }
-  if (blockIdx.x * AFX_BLOCK >= count) return;   // a block past the end of this row's pass (the grid is sized for the launch's largest)
+  // a WAVE past the end of this row's pass retires (the grid is sized for the launch's largest pass, and a pass of 16 items is one wave
+  // of its block's four; no kernel here has a barrier).  Inside the last live wave, lanes past the end shadow the last item.
+  if (blockIdx.x * blockDim.x + ((uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x) & ~63u) >= count) return;   // (first lane's id: the branch is scalar)
   // lanes past the end of the batch shadow the last item (identical values, identical stores)
-  const uint32_t item = min(blockIdx.x * AFX_BLOCK + threadIdx.x, count - 1);
-  const afx_msm_djob* job = row_job(jobs, rows);
+  const uint32_t item = min(blockIdx.x * blockDim.x + threadIdx.x, count - 1);
   const uint32_t nt = job->n_terms, nv = job->n_var, nu = job->n_uni;
   msm_env env;
-  env.job = job; env.table_ws = table_ws; env.digit_ws = digit_ws;
+  env.job = job; env.term = afx_job_terms(job); env.table_ws = table_ws; env.digit_ws = digit_ws;
   env.count = count; env.item = item; env.dslot = job->digit_slot; env.tslot = 0;
   env.narrow = SEC && KIND == MSM_WINDOW && job->narrow != 0;
   msm_recode(job, digit_ws, count, item, nu, nv, nt, env.narrow);   // batch-constant NAF terms need no digits
@@ -620,7 +624,7 @@ k_msm(const afx_msm_djob* __restrict__ jobs, const int32_t* __restrict__ pos_tab
           const bool neg = (ev & 0x80u) != 0;
           ev = sched[++ei];
           const bool last = !lane_adds && (ev >> 16) != (uint32_t)bit;
-          const int32_t* ent = table_ws + (size_t)job->term[t].table_slot * count * AFX_VAR_TABLE_DWORDS + (size_t)idx * count * AFX_TABLE_ENTRY_DWORDS + (size_t)item * 4;
+          const int32_t* ent = table_ws + (size_t)env.term[t].table_slot * count * AFX_VAR_TABLE_DWORDS + (size_t)idx * count * AFX_TABLE_ENTRY_DWORDS + (size_t)item * 4;
           acc = ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent, (size_t)count * 4), neg), last ? after : GE_FOR_ADD);
         }
         if (lane_adds) {
@@ -657,6 +661,22 @@ k_msm(const afx_msm_djob* __restrict__ jobs, const int32_t* __restrict__ pos_tab
     atomicAdd(&clock_probe[1], (unsigned long long)wall_clock64() - r0);
   }
 }
+#define AFX_MSM_OCCUPANCY(KIND, ENC, SEC) ((!(ENC) && (!(SEC) || (KIND) == MSM_FIXED)) ? 3 : 2)
+template <int KIND, bool ENC, bool SEC>
+__global__ void __launch_bounds__(AFX_BLOCK, AFX_MSM_OCCUPANCY(KIND, ENC, SEC))
+k_msm(const afx_msm_djob* __restrict__ jobs, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables, int32_t* __restrict__ table_ws,
+      uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count, unsigned long long* __restrict__ clock_probe) {
+  msm_body<KIND, ENC, SEC>(&jobs[blockIdx.y], pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe);
+}
+// (small plans only: they have no NAF schedules - engine.cpp msm_split(no_naf) - so there is no merged NAF instance)
+template <int KIND, bool ENC, bool SEC>
+__global__ void __launch_bounds__(AFX_BLOCK, AFX_MSM_OCCUPANCY(KIND, ENC, SEC))
+k_msm_rows(const uint8_t* __restrict__ blob, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables, const afx_row* __restrict__ rows,
+           const afx_pass* __restrict__ passes, unsigned long long* __restrict__ clock_probe) {
+  const afx_row row = rows[blockIdx.y];      // wave-uniform: scalar loads
+  const afx_pass pass = passes[row.pass];
+  msm_body<KIND, ENC, SEC>(reinterpret_cast<const afx_msm_djob*>(blob + row.job_off), pos_tables, sec_tables, pass.table_ws, pass.digit_ws, pass.bad, pass.count, clock_probe);
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_compress2x: the encodings of 2*P_j for all the points P_j an item's jobs left in half_var, with ONE field inversion per item
@@ -678,7 +698,7 @@ k_compress2x(const afx_compress_job* __restrict__ jobs, const afx_walk_row* __re
   const afx_pass pass = passes[row.pass];
   const uint32_t count = pass.count;
   uint32_t* __restrict__ bad = pass.bad;
-  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= count) return;
   const uint32_t njobs = row.n_jobs;
   jobs = reinterpret_cast<decltype(jobs)>(reinterpret_cast<const uint8_t*>(jobs) + row.job_off);
@@ -718,7 +738,7 @@ k_negenc(const afx_negenc_job* __restrict__ jobs, const afx_walk_row* __restrict
   const afx_pass pass = passes[row.pass];
   const uint32_t count = pass.count;
   uint32_t* __restrict__ bad = pass.bad;
-  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= count) return;
   const uint32_t njobs = row.n_jobs;
   jobs = reinterpret_cast<decltype(jobs)>(reinterpret_cast<const uint8_t*>(jobs) + row.job_off);
@@ -761,7 +781,7 @@ __global__ void __launch_bounds__(AFX_BLOCK, 2) k_pointsum(const afx_pointsum_jo
   const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
   const uint32_t count = pass.count;
   uint32_t* __restrict__ bad = pass.bad;
-  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= count) return;
   ge_p3 acc = var_load(job.parts[0], count, item);
 #pragma unroll 1
@@ -790,7 +810,7 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_hash(const afx_hash_program* __re
   const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
   const uint32_t count = pass.count;
   uint32_t* __restrict__ bad = pass.bad;
-  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= count) return;
   uint64_t st[25];
   if (prog->load_state) {
@@ -866,9 +886,9 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_hash_coop(const afx_hash_program*
   const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
   const uint32_t count = pass.count;
   uint32_t* __restrict__ bad = pass.bad;
-  if (blockIdx.x * (AFX_BLOCK / 32) >= count) return;   // a block past the end of this row's pass
+  if (blockIdx.x * (blockDim.x >> 5) + (((uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6) << 1) >= count) return;   // a wave (two lane groups) past the end of this row's pass retires
   const uint32_t g = threadIdx.x & 31u;
-  const uint32_t group = blockIdx.x * (AFX_BLOCK / 32) + (threadIdx.x >> 5);
+  const uint32_t group = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
   const bool live = group < count;                      // a whole group is live or not; dead groups shadow the last item and store nothing
   const uint32_t item = live ? group : count - 1;
   const bool holds = g < 25;                            // lanes 25..31 take part in the shuffles only (never as a source)
@@ -946,7 +966,7 @@ __global__ void k_fill_u32(const afx_fill_job* __restrict__ jobs, const afx_row*
   if (i < job.n) job.p[i] = job.v;
 }
 __global__ void __launch_bounds__(AFX_BLOCK, 2) k_from_uniform(const uint8_t* __restrict__ wide, uint8_t* __restrict__ out_enc, int32_t* out_var, uint32_t count) {
-  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= count) return;
   uint32_t w[16];
   enc_load(w, wide, 2 * item);
@@ -960,7 +980,7 @@ __global__ void __launch_bounds__(AFX_BLOCK, 2) k_from_uniform(const uint8_t* __
   }
 }
 __global__ void __launch_bounds__(AFX_BLOCK) k_reduce_wide(const uint8_t* __restrict__ wide, uint8_t* __restrict__ out, uint32_t count) {
-  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= count) return;
   uint32_t w[16];
   enc_load(w, wide, 2 * item);
@@ -976,7 +996,7 @@ __global__ void __launch_bounds__(AFX_BLOCK, 2) k_from_uniform_jobs(const afx_un
   const afx_uniform_job job = *row_job(jobs, rows);
   const afx_pass pass = passes[row_pass_index(rows)];
   const uint32_t count = pass.count;
-  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= count) return;
   uint32_t w[16];
   enc_load(w, job.wide, 2 * item);
@@ -992,7 +1012,7 @@ __global__ void __launch_bounds__(AFX_BLOCK, 2) k_from_uniform_jobs(const afx_un
 __global__ void __launch_bounds__(AFX_BLOCK) k_reduce_wide_jobs(const afx_reduce_job* __restrict__ jobs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
   const afx_reduce_job job = *row_job(jobs, rows);
   const afx_pass pass = passes[row_pass_index(rows)];
-  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= pass.count) return;
   uint32_t w[16];
   enc_load(w, job.wide, 2 * item);
@@ -1005,7 +1025,7 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_reduce_wide_jobs(const afx_reduce
 }
 // decode -> ok flag -> re-encode (round-trip parity test of decode+encode)
 __global__ void __launch_bounds__(AFX_BLOCK, 2) k_validate(const uint8_t* __restrict__ enc, uint8_t* __restrict__ ok, uint8_t* __restrict__ reenc, uint32_t count) {
-  const uint32_t item = blockIdx.x * AFX_BLOCK + threadIdx.x;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= count) return;
   uint32_t w[8];
   enc_load(w, enc, item);
@@ -1023,7 +1043,7 @@ __global__ void __launch_bounds__(AFX_BLOCK, 2) k_validate(const uint8_t* __rest
 // row_of_cell maps a record cell to its SoA row (revealed attribute values land on their attribute position)
 __global__ void __launch_bounds__(AFX_BLOCK) k_aos_to_soa(const uint8_t* __restrict__ rec, uint8_t* __restrict__ soa,
                                                           const uint32_t* __restrict__ row_of_cell, uint32_t cells, uint32_t count) {
-  const uint64_t t = (uint64_t)blockIdx.x * AFX_BLOCK + threadIdx.x;   // t = cell * count + item: writes are coalesced
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // t = cell * count + item: writes are coalesced
   if (t >= (uint64_t)cells * count) return;
   const uint32_t cell = (uint32_t)(t / count), item = (uint32_t)(t % count);
   const uint4* src = reinterpret_cast<const uint4*>(rec + ((uint64_t)item * cells + cell) * 32);
@@ -1037,7 +1057,11 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_aos_to_soa(const uint8_t* __restr
 // host-callable launch wrappers (engine.cpp is plain C++ and never sees a kernel symbol)
 // ---------------------------------------------------------------------------------------------
 #include "kernels.h"
-static inline dim3 grid_for(uint32_t count, uint32_t njobs) { return dim3((count + AFX_BLOCK - 1) / AFX_BLOCK, njobs, 1); }
+// Block size of a plan launch: AFX_BLOCK, but one or two waves when no pass of the launch has more items than that - a launch merged
+// from many small passes (16 items each) then holds one live wave per row instead of a block of four of which three retire at once,
+// and a compute unit keeps twelve such rows in flight instead of three.
+static inline uint32_t block_for(uint32_t max_count) { return max_count <= 64 ? 64u : max_count <= 128 ? 128u : (uint32_t)AFX_BLOCK; }
+static inline dim3 grid_for(uint32_t count, uint32_t njobs) { const uint32_t b = block_for(count); return dim3((count + b - 1) / b, njobs, 1); }
 
 hipError_t afxk_setup_generators(hipStream_t s, const uint8_t* enc, uint32_t ngen, int32_t* ext, uint8_t* neg_enc, uint32_t* ok) {
   hipLaunchKernelGGL(k_setup_generators, dim3((ngen + 63) / 64), dim3(64), 0, s, enc, ngen, ext, neg_enc, ok);
@@ -1045,19 +1069,19 @@ hipError_t afxk_setup_generators(hipStream_t s, const uint8_t* enc, uint32_t nge
 }
 // `max_count`: the largest item count among the passes of the launch (sizes the grid; a row's lanes past its own pass's count retire)
 hipError_t afxk_decode(hipStream_t s, const afx_decode_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
-  hipLaunchKernelGGL(k_decode, grid_for(max_count, njobs), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
+  hipLaunchKernelGGL(k_decode, grid_for(max_count, njobs), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_sccheck(hipStream_t s, const afx_sccheck_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
-  hipLaunchKernelGGL(k_sccheck, grid_for(max_count, njobs), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
+  hipLaunchKernelGGL(k_sccheck, grid_for(max_count, njobs), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_pointop(hipStream_t s, const afx_pointop_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
-  hipLaunchKernelGGL(k_pointop, grid_for(max_count, njobs), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
+  hipLaunchKernelGGL(k_pointop, grid_for(max_count, njobs), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_scalarop(hipStream_t s, const afx_scalarop_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
-  hipLaunchKernelGGL(k_scalarop, grid_for(max_count, njobs), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
+  hipLaunchKernelGGL(k_scalarop, grid_for(max_count, njobs), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 // base: scratch for ngen * windows extended points (AFX_VAR_DWORDS each); secret != 0: the 4-bit tables (AFX_SEC_*)
@@ -1070,55 +1094,78 @@ hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen
   return hipGetLastError();
 }
 template <int KIND>
-static void launch_msm(hipStream_t s, int encodes, int secret, dim3 grid, const afx_msm_djob* jobs, const int32_t* pos_tables, const int32_t* sec_tables,
-                       const afx_row* rows, const afx_pass* passes, unsigned long long* clock_probe) {
+static void launch_msm(hipStream_t s, int encodes, int secret, dim3 grid, dim3 block, const afx_msm_djob* jobs, const int32_t* pos_tables, const int32_t* sec_tables,
+                       const afx_pass& P, unsigned long long* clock_probe) {
   if (secret) {
-    if (encodes) hipLaunchKernelGGL((k_msm<KIND, true, true>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, rows, passes, clock_probe);
-    else hipLaunchKernelGGL((k_msm<KIND, false, true>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, rows, passes, clock_probe);
+    if (encodes) hipLaunchKernelGGL((k_msm<KIND, true, true>), grid, block, 0, s, jobs, pos_tables, sec_tables, P.table_ws, P.digit_ws, P.bad, P.count, clock_probe);
+    else hipLaunchKernelGGL((k_msm<KIND, false, true>), grid, block, 0, s, jobs, pos_tables, sec_tables, P.table_ws, P.digit_ws, P.bad, P.count, clock_probe);
   } else {
-    if (encodes) hipLaunchKernelGGL((k_msm<KIND, true, false>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, rows, passes, clock_probe);
-    else hipLaunchKernelGGL((k_msm<KIND, false, false>), grid, dim3(AFX_BLOCK), 0, s, jobs, pos_tables, sec_tables, rows, passes, clock_probe);
+    if (encodes) hipLaunchKernelGGL((k_msm<KIND, true, false>), grid, block, 0, s, jobs, pos_tables, sec_tables, P.table_ws, P.digit_ws, P.bad, P.count, clock_probe);
+    else hipLaunchKernelGGL((k_msm<KIND, false, false>), grid, block, 0, s, jobs, pos_tables, sec_tables, P.table_ws, P.digit_ws, P.bad, P.count, clock_probe);
   }
 }
+template <int KIND>
+static void launch_msm_rows(hipStream_t s, int encodes, int secret, dim3 grid, dim3 block, const uint8_t* blob, const int32_t* pos_tables, const int32_t* sec_tables,
+                            const afx_row* rows, const afx_pass* passes, unsigned long long* clock_probe) {
+  if (secret) {
+    if (encodes) hipLaunchKernelGGL((k_msm_rows<KIND, true, true>), grid, block, 0, s, blob, pos_tables, sec_tables, rows, passes, clock_probe);
+    else hipLaunchKernelGGL((k_msm_rows<KIND, false, true>), grid, block, 0, s, blob, pos_tables, sec_tables, rows, passes, clock_probe);
+  } else {
+    if (encodes) hipLaunchKernelGGL((k_msm_rows<KIND, true, false>), grid, block, 0, s, blob, pos_tables, sec_tables, rows, passes, clock_probe);
+    else hipLaunchKernelGGL((k_msm_rows<KIND, false, false>), grid, block, 0, s, blob, pos_tables, sec_tables, rows, passes, clock_probe);
+  }
+}
+// rows == null: a plan's own launch; `pass_host` is the HOST copy of its pass (the fields travel as kernel arguments).  Otherwise a
+// merged launch: `jobs` is the blob's base, rows / passes are device tables.
 hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t njobs, const int32_t* pos_tables,
-                    const int32_t* sec_tables, const afx_row* rows, const afx_pass* passes, uint32_t max_count, unsigned long long* clock_probe) {
+                    const int32_t* sec_tables, const afx_row* rows, const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* clock_probe) {
   if (secret && !sec_tables) return hipErrorInvalidValue;
+  const dim3 grid = grid_for(max_count, njobs), block(block_for(max_count));
+  if (!rows) {
+    if (!pass_host) return hipErrorInvalidValue;
+    switch (kind) {
+      case MSM_FIXED: launch_msm<MSM_FIXED>(s, encodes, secret, grid, block, jobs, pos_tables, sec_tables, *pass_host, clock_probe); break;
+      case MSM_WINDOW: launch_msm<MSM_WINDOW>(s, encodes, secret, grid, block, jobs, pos_tables, sec_tables, *pass_host, clock_probe); break;
+      case MSM_NAF: launch_msm<MSM_NAF>(s, encodes, secret, grid, block, jobs, pos_tables, sec_tables, *pass_host, clock_probe); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (kind) {
-    case MSM_FIXED: launch_msm<MSM_FIXED>(s, encodes, secret, grid_for(max_count, njobs), jobs, pos_tables, sec_tables, rows, passes, clock_probe); break;
-    case MSM_WINDOW: launch_msm<MSM_WINDOW>(s, encodes, secret, grid_for(max_count, njobs), jobs, pos_tables, sec_tables, rows, passes, clock_probe); break;
-    case MSM_NAF: launch_msm<MSM_NAF>(s, encodes, secret, grid_for(max_count, njobs), jobs, pos_tables, sec_tables, rows, passes, clock_probe); break;
-    default: return hipErrorInvalidValue;
+    case MSM_FIXED: launch_msm_rows<MSM_FIXED>(s, encodes, secret, grid, block, (const uint8_t*)jobs, pos_tables, sec_tables, rows, passes, clock_probe); break;
+    case MSM_WINDOW: launch_msm_rows<MSM_WINDOW>(s, encodes, secret, grid, block, (const uint8_t*)jobs, pos_tables, sec_tables, rows, passes, clock_probe); break;
+    default: return hipErrorInvalidValue;   // NAF schedules belong to the plans of large passes, which are never merged
   }
   return hipGetLastError();
 }
 hipError_t afxk_msm_tables(hipStream_t s, int kind, const afx_table_job* jobs, uint32_t nrows, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
   switch (kind) {
-    case TABLE_WINDOW: hipLaunchKernelGGL(k_msm_tables<TABLE_WINDOW>, grid_for(max_count, nrows), dim3(AFX_BLOCK), 0, s, jobs, rows, passes); break;
-    case TABLE_ODD: hipLaunchKernelGGL(k_msm_tables<TABLE_ODD>, grid_for(max_count, nrows), dim3(AFX_BLOCK), 0, s, jobs, rows, passes); break;
-    case TABLE_NARROW: hipLaunchKernelGGL(k_msm_tables<TABLE_NARROW>, grid_for(max_count, nrows), dim3(AFX_BLOCK), 0, s, jobs, rows, passes); break;
+    case TABLE_WINDOW: hipLaunchKernelGGL(k_msm_tables<TABLE_WINDOW>, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes); break;
+    case TABLE_ODD: hipLaunchKernelGGL(k_msm_tables<TABLE_ODD>, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes); break;
+    case TABLE_NARROW: hipLaunchKernelGGL(k_msm_tables<TABLE_NARROW>, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
-  hipLaunchKernelGGL(k_compress2x, grid_for(max_count, nrows), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
+  hipLaunchKernelGGL(k_compress2x, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
-  hipLaunchKernelGGL(k_negenc, grid_for(max_count, nrows), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
+  hipLaunchKernelGGL(k_negenc, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
-  hipLaunchKernelGGL(k_pointsum, grid_for(max_count, njobs), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
+  hipLaunchKernelGGL(k_pointsum, grid_for(max_count, njobs), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
-  const uint32_t per_block = AFX_BLOCK / 32;
-  hipLaunchKernelGGL(k_hash_coop, dim3((max_count + per_block - 1) / per_block, nprogs), dim3(AFX_BLOCK), 0, s, progs, rows, passes);
+  const uint32_t block = max_count <= 2 ? 64u : max_count <= 4 ? 128u : (uint32_t)AFX_BLOCK, per_block = block / 32;   // 32 lanes per item
+  hipLaunchKernelGGL(k_hash_coop, dim3((max_count + per_block - 1) / per_block, nprogs), dim3(block), 0, s, progs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
-  hipLaunchKernelGGL(k_hash, grid_for(max_count, nprogs), dim3(AFX_BLOCK), 0, s, progs, rows, passes);
+  hipLaunchKernelGGL(k_hash, grid_for(max_count, nprogs), dim3(block_for(max_count)), 0, s, progs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_finish(hipStream_t s, const afx_finish_job* jobs, uint32_t njobs, const afx_row* rows, uint32_t max_count) {
@@ -1130,11 +1177,11 @@ hipError_t afxk_fill_u32(hipStream_t s, const afx_fill_job* jobs, uint32_t njobs
   return hipGetLastError();
 }
 hipError_t afxk_from_uniform_jobs(hipStream_t s, const afx_uniform_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
-  hipLaunchKernelGGL(k_from_uniform_jobs, grid_for(max_count, njobs), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
+  hipLaunchKernelGGL(k_from_uniform_jobs, grid_for(max_count, njobs), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_reduce_wide_jobs(hipStream_t s, const afx_reduce_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
-  hipLaunchKernelGGL(k_reduce_wide_jobs, grid_for(max_count, njobs), dim3(AFX_BLOCK), 0, s, jobs, rows, passes);
+  hipLaunchKernelGGL(k_reduce_wide_jobs, grid_for(max_count, njobs), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_from_uniform(hipStream_t s, const uint8_t* wide, uint8_t* out_enc, int32_t* out_var, uint32_t count) {

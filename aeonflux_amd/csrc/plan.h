@@ -191,7 +191,10 @@ typedef struct {
   uint32_t n_terms, n_var, n_uni;
   int32_t top_bit;
   const uint32_t* naf_sched;
-  const afx_msm_term* term;             /* n_terms entries                                        */
+  int32_t term_off;                     /* the job's n_terms afx_msm_term entries lie at (const uint8_t*)job + term_off: an OFFSET, so that the
+                                           kernels reach them from their own kernel argument (scalar loads the compiler can prove unclobbered;
+                                           a loaded pointer made every term field a vector load and every branch on one an exec-mask branch) */
+  uint32_t pad0;
   const int32_t* addend;
   uint32_t addend_negate;
   uint32_t reject_identity;
@@ -202,6 +205,14 @@ typedef struct {
   uint32_t narrow;
   uint32_t leave_half, pad;             /* host-side checks only (tests/hostsim)                  */
 } afx_msm_djob;
+
+#ifdef __cplusplus
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+const afx_msm_term* afx_job_terms(const afx_msm_djob* j) { return (const afx_msm_term*)((const uint8_t*)j + j->term_off); }
+#endif
 
 /* one window table to build (k_msm_tables<kind>): the base and where the table goes.  Kinds (one launch each): 0 the multiples
  * 1..8 (signed 4-bit windows), item-major [item][entry] - a lane's digit picks one entry; 1 the odd multiples 1, 3, .., 15 (terms

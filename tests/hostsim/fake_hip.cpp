@@ -92,25 +92,29 @@ hipError_t afxk_msm_tables(hipStream_t, int kind, const afx_table_job* j, uint32
   return hipSuccess;
 }
 hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t n, const int32_t*, const int32_t* sec_tables, const afx_row* rows,
-                    const afx_pass* passes, uint32_t max_count, unsigned long long* probe) {
+                    const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* probe) {
+  if (!rows) {   // a plan's own launch: the pass travels as kernel arguments, from its host copy - which must equal the device's
+    if (!pass_host || memcmp(pass_host, passes, sizeof(afx_pass)) != 0) return hipErrorInvalidValue;
+  } else if (kind == 2) return hipErrorInvalidValue;   // no merged NAF launches
   if (probe) { probe[0] += 2250; probe[1] += 100; }
   if (secret && !sec_tables) return hipErrorInvalidValue;
   int any_secret = 0;
   for (uint32_t i = 0; i < n; i++)
-    for (uint32_t t = 0; t < job_of(jobs, rows, i).n_terms; t++) any_secret |= job_of(jobs, rows, i).term[t].secret != 0;
+    for (uint32_t t = 0; t < job_of(jobs, rows, i).n_terms; t++) any_secret |= afx_job_terms(&job_of(jobs, rows, i))[t].secret != 0;
   if (any_secret != (secret != 0)) return hipErrorInvalidValue;   // the launch's flag is the OR of its terms' flags
   if (kind < 0 || kind > 2) return hipErrorInvalidValue;
   for (uint32_t i = 0; i < n; i++) {
     hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e;
     const afx_msm_djob& j = job_of(jobs, rows, i);
+    const afx_msm_term* term = afx_job_terms(&j);
     if (!encodes && j.out_enc && !j.half_var) return hipErrorInvalidValue;   // a job that encodes in the kernel needs the encoding launch
     if ((j.n_var == 0 ? 0 : j.n_uni ? 2 : 1) != kind && !(j.n_var == 0 && kind == 1)) return hipErrorInvalidValue;   // every job in its own class's launch (fixed-only jobs may ride in the windowed one)
     if (j.leave_half && (j.out_var || !j.half_var)) return hipErrorInvalidValue;    // a job that leaves its half stores only the half
-    for (uint32_t t = 0; t < j.n_uni; t++) if (j.term[t].dbl) return hipErrorInvalidValue;   // NAF schedules never run on a half base
+    for (uint32_t t = 0; t < j.n_uni; t++) if (term[t].dbl) return hipErrorInvalidValue;   // NAF schedules never run on a half base
     int secret_var = 0;
-    for (uint32_t t = 0; t < j.n_var; t++) secret_var |= j.term[t].secret != 0;
+    for (uint32_t t = 0; t < j.n_var; t++) secret_var |= term[t].secret != 0;
     if ((j.narrow != 0) != (secret_var != 0) || (j.narrow && kind != 1)) return hipErrorInvalidValue;   // narrow windows exactly where a variable base carries a secret
-    for (uint32_t t = 0; t < j.n_terms; t++) { CHECK_PTR(j.term[t].scalar); CHECK_PTR(j.term[t].var); }
+    for (uint32_t t = 0; t < j.n_terms; t++) { CHECK_PTR(term[t].scalar); CHECK_PTR(term[t].var); }
     CHECK_PTR(j.addend); CHECK_PTR(j.out_enc); CHECK_PTR(j.out_var); CHECK_PTR(j.half_var);
     if (j.n_uni) {   // the NAF schedule lives in the plan blob: read it to its terminator
       for (const uint32_t* e2 = j.naf_sched; ; e2++) { sink += *e2; if (*e2 == 0xffffffffu) break; }

@@ -47,7 +47,7 @@ def code_object(tmp_path_factory):
 
 
 def msm(kind, enc, sec):
-    return "_Z5k_msmILi%dELb%dELb%dEEvPK11afx_msm_jobPKiS4_PiPjS6_jPy" % (kind, enc, sec)
+    return "_Z5k_msmILi%dELb%dELb%dEEvPK12afx_msm_djobPKiS4_PiPjS6_jPy" % (kind, enc, sec)
 
 
 def test_hot_kernels_are_scratch_free_and_fit_their_occupancy(code_object):
@@ -77,7 +77,8 @@ def test_secret_independent_scan_reads_every_entry_unconditionally(code_object):
         for enc in (0, 1):
             sec, plain = bodies[msm(kind, enc, 1)], bodies[msm(kind, enc, 0)]
             # 8 entries of a window (entry 0 besides): 27 dwords each through s_load_dwordx16 + x8 + ...; none of it in the ordinary instance
-            assert count(sec, r"s_load_dwordx16") >= 8 and count(plain, r"s_load_dwordx16") == 0
+            # (whose only wide scalar loads are its kernel arguments and the job's header)
+            assert count(plain, r"s_load_dwordx16") <= 2 and count(sec, r"s_load_dwordx16") >= 8 + count(plain, r"s_load_dwordx16")
             assert count(sec, r"v_bfi_b32") >= 8 * 20
             # no branch on the exec mask around the scan's loads: the SEC instance branches where its sibling does (+ the uniform
             # `secret` / `narrow` tests, which are scalar branches), not once per table word
