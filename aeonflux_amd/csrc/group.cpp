@@ -4,6 +4,10 @@
 // per member, and every member writes its part of the caller's arrays: no data moves between devices and there is no
 // collective.  This is what one `&self` method of the reference (Issuer::verify, /root/reference/src/issuer.rs:141-147;
 // Issuer::issue, :111-124) becomes when the issuer owns a node of GPUs.
+#include <ctype.h>
+#include <sched.h>
+#include <stdio.h>
+#include <string.h>
 #include <atomic>
 #include <memory>
 #include <string>
@@ -12,8 +16,65 @@
 #include <vector>
 #include "statements.hpp"
 
+// Host threads follow their devices: a member's thread runs on the CPUs of the NUMA node its GPU hangs off
+// (/sys/bus/pci/devices/<bdf>/numa_node -> /sys/devices/system/node/node<N>/cpulist, intersected with what the process may use), so
+// that the pageable-to-pinned staging copies and the pinned buffers themselves (first touched by that thread) stay on the node the
+// PCIe root of the device belongs to.  Eight members pulling ~6 GB/s each out of the caller's arrays through ONE node's memory
+// controllers was the review's concern; nothing is pinned where the topology is not exposed (containers, the host simulation).
+struct NodeCpus {
+  bool valid = false;
+  cpu_set_t set;
+};
+static NodeCpus cpus_of_device(int device) {
+  NodeCpus out;
+  char bdf[64] = { 0 };
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess || !bdf[0]) return out;
+  for (char* p = bdf; *p; p++) *p = (char)tolower((unsigned char)*p);
+  int node = -1;
+  {
+    FILE* f = fopen((std::string("/sys/bus/pci/devices/") + bdf + "/numa_node").c_str(), "r");
+    if (!f) return out;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+  }
+  if (node < 0) return out;
+  FILE* f = fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
+  if (!f) return out;
+  char list[4096] = { 0 };
+  const size_t got = fread(list, 1, sizeof list - 1, f);
+  fclose(f);
+  list[got] = 0;
+  cpu_set_t allowed, want;
+  CPU_ZERO(&want);
+  if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
+  for (char* tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+    int a = 0, b = 0;
+    const int k = sscanf(tok, "%d-%d", &a, &b);
+    if (k < 1) continue;
+    if (k == 1) b = a;
+    for (int c = a; c <= b && c < CPU_SETSIZE; c++)
+      if (c >= 0 && CPU_ISSET(c, &allowed)) CPU_SET(c, &want);
+  }
+  if (CPU_COUNT(&want) == 0) return out;
+  out.set = want;
+  out.valid = true;
+  return out;
+}
+// pins the calling thread for the scope's life (a thread the group started simply ends; the caller's own thread gets its mask back)
+struct PinScope {
+  bool restore = false;
+  cpu_set_t saved;
+  PinScope(const NodeCpus& n, bool caller_thread) {
+    if (!n.valid) return;
+    if (caller_thread) restore = sched_getaffinity(0, sizeof saved, &saved) == 0;
+    (void)sched_setaffinity(0, sizeof n.set, &n.set);
+  }
+  ~PinScope() { if (restore) (void)sched_setaffinity(0, sizeof saved, &saved); }
+};
+
 struct afx_group {
   std::vector<afx_ctx*> members;
+  std::vector<NodeCpus> node_cpus;   // per member: where its host thread runs
   std::atomic<uint32_t> next_small{ 0 };   // small calls go to one member each, in turn (run_members)
   ~afx_group() { for (afx_ctx* m : members) afx_ctx_destroy(m); }   // wipes every member's copy of the key
 };
@@ -26,6 +87,9 @@ extern "C" int afx_group_create(afx_group** out, const int* devices, uint32_t n_
   g->members.reserve(n_devices);
   for (uint32_t i = 0; i < n_devices; i++) {
     afx_ctx* c = nullptr;
+    g->node_cpus.push_back(cpus_of_device(devices[i]));
+    // (the context's pinned plan buffers are first touched here: on the device's node too)
+    PinScope pin(g->node_cpus.back(), true);
     const int rc = afx_ctx_create(&c, devices[i], sysparams, sysparams_len, amacs_key, amacs_key_len, issuer_params);
     if (rc) {
       const std::string why = afx_last_error();
@@ -37,6 +101,8 @@ extern "C" int afx_group_create(afx_group** out, const int* devices, uint32_t n_
   *out = g.release();
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
+GroupPin::GroupPin(afx_group* g, uint32_t index, bool caller_thread) { if (g && index < g->node_cpus.size()) impl = new PinScope(g->node_cpus[index], caller_thread); }
+GroupPin::~GroupPin() { delete (PinScope*)impl; }
 extern "C" void afx_group_destroy(afx_group* g) { delete g; }
 extern "C" uint32_t afx_group_size(const afx_group* g) { return g ? (uint32_t)g->members.size() : 0; }
 extern "C" afx_ctx* afx_group_member(afx_group* g, uint32_t i) { return (g && i < g->members.size()) ? g->members[i] : nullptr; }
@@ -69,6 +135,7 @@ static int run_members(afx_group* g, size_t count, F&& call) {
     }
     alike = alike && !g->members[0]->trace;   // (a challenge trace is read back from ONE member's buffer)
     const uint32_t i = alike ? g->next_small.fetch_add(1, std::memory_order_relaxed) % m : 0;
+    PinScope pin(g->node_cpus[i], true);
     const int rc = call(g->members[i], (size_t)0, count);
     if (rc) { const std::string why = afx_last_error(); set_error("member " + std::to_string(i) + ": " + why); }
     return rc;
@@ -80,6 +147,7 @@ static int run_members(afx_group* g, size_t count, F&& call) {
     size_t first = 0, n = 0;
     afx_shard_bounds(count, m, i, &first, &n);
     if (n == 0) return;
+    PinScope pin(g->node_cpus[i], i == 0);   // member 0 runs on the caller's thread, which gets its mask back
     rcs[i] = call(g->members[i], first, n);
     if (rcs[i]) errs[i] = afx_last_error();   // the error string is per thread
   };

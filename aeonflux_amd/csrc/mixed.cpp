@@ -7,6 +7,8 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 #include "statements.hpp"
 
@@ -84,6 +86,76 @@ int run_groups(afx_ctx* ctx, G* groups, size_t n_groups, uint8_t* status, size_t
   return AFX_OK;
 }
 
+// The same request on a group of devices: the groups small enough to be collected are dealt out to the members in turn and every
+// member runs its share as ONE collected request on a host thread of its own (`mixed_on_ctx`: the single-context entry point);
+// a large group is split over all the members by the group's ordinary batch call (`run_one`), before the small ones start.
+// Statuses land where they belong because every share carries explicit positions.
+template <class G, class MixedOnCtx, class RunOne>
+int run_groups_on_devices(afx_group* group, G* groups, size_t n_groups, uint8_t* status, size_t status_len, MixedOnCtx&& mixed_on_ctx, RunOne&& run_one) {
+  if ((!groups && n_groups) || (!status && status_len)) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  int rc = check_positions(groups, n_groups, status_len);
+  if (rc) return rc;
+  const uint32_t m = afx_group_size(group);
+  if (m == 0) { set_error("empty group"); return AFX_E_BAD_ARGS; }
+  const uint32_t small = afx_group_member(group, 0)->small_batch_items;
+  std::vector<std::vector<G>> share(m);
+  std::vector<std::vector<uint64_t>> made;   // positions of groups that came without: contiguous after the groups before them
+  made.reserve(n_groups);
+  std::vector<uint8_t> tmp;
+  size_t next = 0;
+  uint32_t turn = 0;
+  for (size_t g = 0; g < n_groups; g++) {
+    G grp = groups[g];
+    if (grp.count) {
+      if (small && grp.count <= small) {
+        if (!grp.positions) {
+          made.emplace_back(grp.count);
+          for (size_t i = 0; i < grp.count; i++) made.back()[i] = next + i;
+          grp.positions = made.back().data();
+        }
+        share[turn++ % m].push_back(grp);
+      } else if (!grp.positions) {
+        if ((rc = run_one(groups[g], status + next))) { set_error("group " + std::to_string(g) + ": " + afx_last_error()); return rc; }
+      } else {
+        tmp.assign(grp.count, AFX_ST_VERIFICATION_FAILURE);
+        if ((rc = run_one(groups[g], tmp.data()))) { set_error("group " + std::to_string(g) + ": " + afx_last_error()); return rc; }
+        for (size_t i = 0; i < grp.count; i++) status[grp.positions[i]] = tmp[i];
+      }
+    }
+    next += grp.count;
+  }
+  std::vector<int> rcs(m, AFX_OK);
+  std::vector<std::string> errs(m);
+  auto body = [&](uint32_t k) {
+    if (share[k].empty()) return;
+    GroupPin pin(group, k, k == 0);   // the member's thread on its device's NUMA node (member 0: the caller's thread, restored)
+    rcs[k] = mixed_on_ctx(afx_group_member(group, k), share[k].data(), share[k].size());
+    if (rcs[k]) errs[k] = afx_last_error();   // the error string is per thread
+  };
+  std::vector<std::thread> threads;
+  for (uint32_t k = 1; k < m; k++) {
+    if (share[k].empty()) continue;
+    try { threads.emplace_back(body, k); } catch (const std::system_error&) { body(k); }
+  }
+  body(0);
+  for (std::thread& t : threads) t.join();
+  // shape_out and the like were written into the shares' copies of the group structs: hand them back
+  {
+    std::vector<size_t> at(m, 0);
+    uint32_t t2 = 0;
+    for (size_t g = 0; g < n_groups; g++) {
+      if (!groups[g].count || !(small && groups[g].count <= small)) continue;
+      const uint32_t k = t2++ % m;
+      const uint64_t* keep = groups[g].positions;
+      groups[g] = share[k][at[k]++];
+      groups[g].positions = keep;
+    }
+  }
+  for (uint32_t k = 0; k < m; k++)
+    if (rcs[k]) { set_error("member " + std::to_string(k) + ": " + errs[k]); return rcs[k]; }
+  return AFX_OK;
+}
+
 }  // namespace
 
 extern "C" int afx_verify_presentations_mixed(afx_ctx* ctx, const afx_presentation_group* groups, size_t n_groups, uint8_t* status,
@@ -94,12 +166,14 @@ extern "C" int afx_verify_presentations_mixed(afx_ctx* ctx, const afx_presentati
   });
 } catch (...) { return afx::exception_rc(); }
 
-extern "C" int afx_group_verify_presentations_mixed(afx_group* group, const afx_presentation_group* groups, size_t n_groups, uint8_t* status,
-                                                    size_t status_len) try {
+extern "C" int afx_group_verify_presentations_mixed(afx_group* group, const afx_presentation_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
   if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return run_groups((afx_ctx*)nullptr, groups, n_groups, status, status_len, [&](const afx_presentation_group& G, uint8_t* st) {
-    return afx_group_verify_presentations(group, &G.shape, &G.batch, G.count, st);
-  });
+  std::vector<afx_presentation_group> mine(groups, groups + (groups ? n_groups : 0));   // the shares take copies; what the calls write into them (shape_out) comes back
+  const int rc = run_groups_on_devices(group, mine.data(), n_groups, status, status_len,
+    [&](afx_ctx* c, afx_presentation_group* sub, size_t n) { return afx_verify_presentations_mixed(c, sub, n, status, status_len); },
+    [&](afx_presentation_group& G, uint8_t* st) { return afx_group_verify_presentations(group, &G.shape, &G.batch, G.count, st); });
+
+  return rc;
 } catch (...) { return afx::exception_rc(); }
 
 // Issuer::issue over requests of several attribute layouts (/root/reference/src/issuer.rs:111-124; kinds per attribute: src/amacs.rs:168-179)
@@ -111,9 +185,12 @@ extern "C" int afx_issue_mixed(afx_ctx* ctx, const afx_issue_group* groups, size
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_group_issue_mixed(afx_group* group, const afx_issue_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
   if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return run_groups((afx_ctx*)nullptr, groups, n_groups, status, status_len, [&](const afx_issue_group& G, uint8_t* st) {
-    return afx_group_issue(group, &G.requests, &G.rnd, G.count, &G.out, st);
-  });
+  std::vector<afx_issue_group> mine(groups, groups + (groups ? n_groups : 0));   // the shares take copies; what the calls write into them (shape_out) comes back
+  const int rc = run_groups_on_devices(group, mine.data(), n_groups, status, status_len,
+    [&](afx_ctx* c, afx_issue_group* sub, size_t n) { return afx_issue_mixed(c, sub, n, status, status_len); },
+    [&](afx_issue_group& G, uint8_t* st) { return afx_group_issue(group, &G.requests, &G.rnd, G.count, &G.out, st); });
+
+  return rc;
 } catch (...) { return afx::exception_rc(); }
 
 // CredentialIssuance::verify over issuances of several layouts (src/issuer.rs:48-57)
@@ -125,9 +202,12 @@ extern "C" int afx_verify_issuances_mixed(afx_ctx* ctx, const afx_issuance_group
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_group_verify_issuances_mixed(afx_group* group, const afx_issuance_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
   if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return run_groups((afx_ctx*)nullptr, groups, n_groups, status, status_len, [&](const afx_issuance_group& G, uint8_t* st) {
-    return afx_group_verify_issuances(group, &G.attrs, &G.issuances, G.n_responses, G.count, st);
-  });
+  std::vector<afx_issuance_group> mine(groups, groups + (groups ? n_groups : 0));   // the shares take copies; what the calls write into them (shape_out) comes back
+  const int rc = run_groups_on_devices(group, mine.data(), n_groups, status, status_len,
+    [&](afx_ctx* c, afx_issuance_group* sub, size_t n) { return afx_verify_issuances_mixed(c, sub, n, status, status_len); },
+    [&](afx_issuance_group& G, uint8_t* st) { return afx_group_verify_issuances(group, &G.attrs, &G.issuances, G.n_responses, G.count, st); });
+
+  return rc;
 } catch (...) { return afx::exception_rc(); }
 
 // AnonymousCredential::show over credentials of several layouts (src/credential.rs:37-46); every group reports its own shape
@@ -139,9 +219,12 @@ extern "C" int afx_show_mixed(afx_ctx* ctx, afx_show_group* groups, size_t n_gro
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_group_show_mixed(afx_group* group, afx_show_group* groups, size_t n_groups, uint8_t* status, size_t status_len) try {
   if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return run_groups((afx_ctx*)nullptr, groups, n_groups, status, status_len, [&](afx_show_group& G, uint8_t* st) {
-    return afx_group_show(group, &G.creds, G.keypairs, &G.rnd, G.count, &G.out, &G.shape_out, st);
-  });
+  std::vector<afx_show_group> mine(groups, groups + (groups ? n_groups : 0));   // the shares take copies; what the calls write into them (shape_out) comes back
+  const int rc = run_groups_on_devices(group, mine.data(), n_groups, status, status_len,
+    [&](afx_ctx* c, afx_show_group* sub, size_t n) { return afx_show_mixed(c, sub, n, status, status_len); },
+    [&](afx_show_group& G, uint8_t* st) { return afx_group_show(group, &G.creds, G.keypairs, &G.rnd, G.count, &G.out, &G.shape_out, st); });
+  if (!rc) for (size_t g = 0; g < n_groups; g++) groups[g].shape_out = mine[g].shape_out;
+  return rc;
 } catch (...) { return afx::exception_rc(); }
 
 extern "C" int afx_wire_section_bytes(const uint8_t* blob, size_t len, size_t* section_len_out) try {

@@ -22,6 +22,9 @@ static constexpr size_t PLAN_CACHE_ENTRIES = 512, PLAN_CACHE_BYTES = size_t(64) 
 using namespace afx;
 struct Stager;
 
+// pins the calling thread to the CPUs of member `index`'s NUMA node for the life of the returned object (group.cpp; no-op where the
+// topology is not exposed); `caller_thread`: restore the thread's mask afterwards
+struct GroupPin { void* impl = nullptr; GroupPin(afx_group* g, uint32_t index, bool caller_thread); ~GroupPin(); GroupPin(const GroupPin&) = delete; };
 // context construction shared with afx_issuer_keygen (issuer_params may be null there)
 int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t splen, const uint8_t* key, size_t klen,
                         const uint8_t* key_scalars_only, const uint8_t* issuer_params);

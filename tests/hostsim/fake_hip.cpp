@@ -3,6 +3,7 @@
 // on a machine without a GPU under ASan/UBSan.  Nothing here computes results: every "kernel" is a no-op
 // and status bytes come back as whatever malloc'ed memory held.  Never shipped, never loaded by the product.
 #include <hip/hip_runtime_api.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "../../aeonflux_amd/csrc/kernels.h"
@@ -11,7 +12,11 @@ extern "C" {
 // AFX_FAKE_HIP_DEVICES: how many devices the fake runtime reports (default 1)
 hipError_t hipGetDeviceCount(int* n) { const char* d = getenv("AFX_FAKE_HIP_DEVICES"); *n = d ? atoi(d) : 1; return hipSuccess; }
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
-hipError_t hipSetDevice(int) { return hipSuccess; }
+static thread_local int cur_device = 0;
+hipError_t hipSetDevice(int d) { cur_device = d; return hipSuccess; }
+hipError_t hipDeviceGetPCIBusId(char* out, int len, int d) { snprintf(out, (size_t)len, "0000:%02x:00.0", d & 0xff); return hipSuccess; }
+// AFX_FAKE_HIP_FAIL_DEVICE: the finishing launch of every plan on that device fails (a member of a group that breaks mid-call)
+static bool device_fails() { const char* f = getenv("AFX_FAKE_HIP_FAIL_DEVICE"); return f && atoi(f) == cur_device; }
 // AFX_FAKE_HIP_MAX_ALLOC (bytes) makes larger single allocations fail, to exercise the engine's out-of-memory handling
 hipError_t hipMalloc(void** p, size_t n) {
   const char* lim = getenv("AFX_FAKE_HIP_MAX_ALLOC");
@@ -174,6 +179,7 @@ hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* p, uint32_t n, 
   return afxk_hash(s, p, n, rows, passes, max_count);
 }
 hipError_t afxk_finish(hipStream_t, const afx_finish_job* j, uint32_t n, const afx_row* rows, uint32_t max_count) {
+  if (device_fails()) return hipErrorLaunchFailure;
   for (uint32_t i = 0; i < n; i++) {
     const afx_finish_job& q = job_of(j, rows, i);
     if (q.count == 0 || q.count > max_count || !canonical(q.bad) || !canonical(q.status)) return hipErrorInvalidValue;

@@ -318,6 +318,41 @@ half = {f: np.ascontiguousarray(pres[f][..., :700, :]) for f in batch.PRES_FIELD
 assert (wire.verify_mixed_wire(grp, wire.pack_presentations(sh2, dict(half, enc=[])) + blob + wire.pack_presentations(sh2, dict(half, enc=[]))) == 0x5a).all()
 assert all((g == 0x5a).all() for g in batch.verify_mixed(grp, [(shape, pres), (sh2, dict(half, enc=[]))]))
 grp.close()
+# eight members (what a node has): ragged splits (1501 items over 8), a request of mixed layouts dealt out to the members' threads,
+# and a member that fails in the middle of a call: the call reports that member and the others finish
+os.environ["AFX_FAKE_HIP_DEVICES"] = "8"
+grp8 = afx.Group(params, key, ip, list(range(8)))
+for m in range(8):
+    grp8.member(m).set_chunk_items(256)
+rag = 1501
+pr = {f: np.ascontiguousarray(np.concatenate([pres[f], pres[f][..., :1, :]], axis=-2)) for f in batch.PRES_FIELDS}
+pr["enc"] = [{f: np.ascontiguousarray(np.concatenate([d[f], d[f][..., :1, :]], axis=-2)) for f in batch.ENC_FIELDS} for d in pres["enc"]]
+grp8.member(0).set_small_batch_items(0)
+for m in range(1, 8):
+    grp8.member(m).set_small_batch_items(0)
+assert (batch.verify_presentations(grp8, shape, pr) == 0x5a).all() and len(batch.verify_presentations(grp8, shape, pr)) == rag
+assert len(batch.verify_presentations(grp8, shape, {f: (pr[f][..., :5, :] if f != "enc" else None) for f in batch.PRES_FIELDS} | {"enc": [{f: d[f][..., :5, :] for f in batch.ENC_FIELDS} for d in pr["enc"]]})) == 5   # fewer items than members
+for m in range(8):
+    grp8.member(m).set_small_batch_items(4096)
+small = lambda p, n: dict({f: np.ascontiguousarray(p[f][..., :n, :]) for f in batch.PRES_FIELDS}, enc=[{f: np.ascontiguousarray(d[f][..., :n, :]) for f in batch.ENC_FIELDS} for d in p["enc"]])
+items = []
+for g in range(20):
+    items.append((shape, small(pres, 3 + g)) if g %% 2 == 0 else (sh2, dict(small(pres, 2 + g), enc=[])))
+assert all((g == 0x5a).all() for g in batch.verify_mixed(grp8, items))
+ia = [dict(kinds=kinds, values=z(8, 4 + g, 32), t_wide=z(4 + g, 64), U_wide=z(4 + g, 64), rng_seed=z(4 + g, 32)) for g in range(11)]
+outs8, st8 = batch.issue_mixed(grp8, ia)
+assert (st8 == 0x5a).all() and len(st8) == sum(4 + g for g in range(11))
+os.environ["AFX_FAKE_HIP_FAIL_DEVICE"] = "5"
+for m in range(8):
+    grp8.member(m).set_small_batch_items(0)
+try:
+    batch.verify_presentations(grp8, shape, pr)
+    raise SystemExit("a failing member went unnoticed")
+except afx.AfxError as e:
+    assert e.rc == afx.E_HIP and "member 5" in str(e), str(e)
+del os.environ["AFX_FAKE_HIP_FAIL_DEVICE"]
+assert (batch.verify_presentations(grp8, shape, pr) == 0x5a).all()   # and the group is usable afterwards
+grp8.close()
 print("tsan drive ok")
 """
 
