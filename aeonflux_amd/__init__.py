@@ -250,9 +250,12 @@ class Context:
         """key scalars without NAF: running time independent of the issuer key (afx_ctx_set_fixed_key_schedule)"""
         check(lib().afx_ctx_set_fixed_key_schedule(self.h, 1 if enable else 0))
 
-    def set_secret_independent_addressing(self, enable):
-        """no memory address depends on a secret scalar's digits (afx_ctx_set_secret_independent_addressing); same bytes, slower"""
-        check(lib().afx_ctx_set_secret_independent_addressing(self.h, 1 if enable else 0))
+    def set_secret_independent_addressing(self, mode):
+        """where no memory address may depend on a secret scalar's digits (afx_ctx_set_secret_independent_addressing; same bytes in every
+        mode).  True / 1: everywhere (the issuer key's terms of Issuer::verify included); False / 0: nowhere (fastest); 2 or "prover": the
+        prover-side calls only - issue, show, the symmetric-key helpers - which is what a new context does."""
+        m = {True: 1, False: 0, "prover": 2, "all": 1, "off": 0}.get(mode, mode)
+        check(lib().afx_ctx_set_secret_independent_addressing(self.h, int(m)))
 
     def issuer_parameters(self):
         """IssuerParameters as C_W || I (64 bytes)"""

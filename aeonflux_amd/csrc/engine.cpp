@@ -349,7 +349,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     bool key_job = false;
     for (uint32_t t = 0; t < j.n_terms; t++) key_job |= is_key_scalar(j.term[t]);
     for (uint32_t t = 0; t < j.n_terms; t++) {
-      j.term[t].secret = (ctx->secret_independent && (secret_scalars || key_job) && j.term[t].scalar != ctx->const_one()) ? 1u : 0u;
+      j.term[t].secret = (ctx->secure_plan(secret_scalars) && (secret_scalars || key_job) && j.term[t].scalar != ctx->const_one()) ? 1u : 0u;
       stats.secret_terms += j.term[t].secret;
     }
   }
@@ -362,7 +362,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   const bool mid = !small && ctx->small_batch_items != 0 && count <= 4 * (uint64_t)ctx->small_batch_items;
   if (small) msm_split(std::move(jobs), cjobs, true);
   else if (mid) {
-    auto naf_term = [&](const afx_msm_term& t) { return t.scalar_stride == 0 && !ctx->fixed_key_schedule && !ctx->secret_independent && !t.dbl && host_scalar_of(ctx, t.scalar) != nullptr; };
+    auto naf_term = [&](const afx_msm_term& t) { return t.scalar_stride == 0 && !ctx->fixed_key_schedule && !ctx->secure_plan(secret_scalars) && !t.dbl && host_scalar_of(ctx, t.scalar) != nullptr; };
     std::vector<afx_msm_job> first, rest;
     std::vector<int> new_index(jobs.size(), -1);
     bool ok = true;
@@ -479,7 +479,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     return c;
   };
   const size_t n = jobs.size();
-  const bool sec_mode = ctx->secret_independent;   // terms were marked by Assembler::msm, before any splitting
+  const bool sec_mode = ctx->secure_plan(secret_scalars);   // terms were marked by Assembler::msm, before any splitting
   for (size_t i = 0; i < n; i++)
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
   // Jobs whose result is only ever encoded (no consumer of the point itself, no addend) run on halved scalars; k_compress2x

@@ -110,7 +110,12 @@ struct afx_ctx {
   bool pipelining = false;
   bool strict = false;   // afx_ctx_set_strict
   bool fixed_key_schedule = false;   // afx_ctx_set_fixed_key_schedule: no NAF for the issuer key's scalars
-  bool secret_independent = false;   // afx_ctx_set_secret_independent_addressing: no memory address depends on a secret digit
+  // afx_ctx_set_secret_independent_addressing: where no memory address may depend on a secret scalar's digits.
+  //   2 (default) the prover-side plans - issue, show, the symmetric-key helpers: what the crate's users get from dalek's constant-time
+  //     arithmetic (src/amacs.rs:267-270, src/nizk/presentation.rs:162-184, zkp's Prover);  1: those and the issuer key's terms of
+  //     Issuer::verify;  0: nowhere (the fastest tables; a device of the engine's own)
+  int secret_mode = 2;
+  bool secure_plan(bool prover_plan) const { return prover_plan ? secret_mode != 0 : secret_mode == 1; }
   uint32_t chunk_items = 0;   // afx_ctx_set_chunk_items; 0 = default
   uint32_t small_batch_items = 4096;   // afx_ctx_set_small_batch_items: passes of at most this many items take the latency plan
   afx_plan_stats last_stats = {};   // per-item operation counts of the most recent plan

@@ -131,7 +131,7 @@ static int run_members(afx_group* g, size_t count, F&& call) {
     for (uint32_t k = 1; k < m && alike; k++) {
       const afx_ctx *a = g->members[0], *b = g->members[k];
       alike = a->small_batch_items == b->small_batch_items && a->strict == b->strict && a->fixed_key_schedule == b->fixed_key_schedule &&
-              a->secret_independent == b->secret_independent && a->chunk_items == b->chunk_items && a->timing == b->timing && !b->trace;
+              a->secret_mode == b->secret_mode && a->chunk_items == b->chunk_items && a->timing == b->timing && !b->trace;
     }
     alike = alike && !g->members[0]->trace;   // (a challenge trace is read back from ONE member's buffer)
     const uint32_t i = alike ? g->next_small.fetch_add(1, std::memory_order_relaxed) % m : 0;

@@ -1,6 +1,7 @@
 // How a statement's plan gets to the device: assembled (or taken from the context's cache of position-independent plans),
 // placed and launched - alone, or together with the plans of other small calls collected by a Session - and how host-pointer
 // front ends stage their arrays (Stager, host_pipe).  Declarations and the design notes: statements.hpp, engine.hpp (afx::Plan).
+#include <stdlib.h>
 #include "statements.hpp"
 
 // ------------------------------------------------------------------------------------------------
@@ -99,6 +100,11 @@ int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, const PlanKey& k
 // ------------------------------------------------------------------------------------------------
 // Stager
 // ------------------------------------------------------------------------------------------------
+// AFX_PACK_LIMIT_MB (measurement aid): up to how many bytes a call's rows are gathered into one pinned image
+size_t Stager::pack_limit() {
+  static const size_t lim = [] { const char* e = getenv("AFX_PACK_LIMIT_MB"); return e ? (size_t)strtoull(e, nullptr, 10) << 20 : PACK_LIMIT; }();
+  return lim;
+}
 static int ensure_pinned(void*& buf, size_t& cap, size_t bytes, size_t granule) {
   if (bytes <= cap) return AFX_OK;
   if (buf) { memset(buf, 0, cap); (void)hipHostFree(buf); buf = nullptr; cap = 0; }
@@ -137,7 +143,7 @@ int Stager::upload() {
   // result areas start from zero: the buffers are reused from call to call, and what a call does not write (the outputs of a
   // failed item, the hidden rows of attr_values) must not hand an earlier call's bytes to this caller
   if (out_bytes) AFX_HIP(hipMemsetAsync(L.staging_out.p, 0, out_bytes, L.stream));
-  if (in_bytes <= PACK_LIMIT && copies.size() > 2) {
+  if (in_bytes <= pack_limit() && copies.size() > 2) {
     // the event first: a buffer is only published together with the event that guards its reuse
     if (!L.pin_in_done) AFX_HIP(hipEventCreateWithFlags(&L.pin_in_done, hipEventDisableTiming));
     AFX_HIP(hipEventSynchronize(L.pin_in_done));   // the previous call's transfer out of this buffer
@@ -167,7 +173,7 @@ int Stager::fetch_all() {
   }
   fetched_ = true;
   // a small call's output region in ONE copy (its rows are scattered over it); large calls row block by row block
-  whole_ = out_bytes <= PACK_LIMIT;
+  whole_ = out_bytes <= pack_limit();
   if (whole_) {
     int rc = ensure_pinned(L.pin, L.pin_cap, std::max<size_t>(out_bytes, 1), size_t(1) << 20);
     if (rc) return rc;

@@ -116,22 +116,26 @@ extern "C" int afx_ctx_set_fixed_key_schedule(afx_ctx* c, int enable) try {
   c->fixed_key_schedule = enable != 0;
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
-extern "C" int afx_ctx_set_secret_independent_addressing(afx_ctx* c, int enable) try {
+// the generators' 4-bit positional tables (AFX_SEC_*), once per context: window bases through lane 0's workspace, like the 13-bit ones
+static int build_secret_tables(afx_ctx* c) {
+  if (c->d_sec_tables.p || c->ngen == 0) return AFX_OK;
+  AFX_HIP(hipSetDevice(c->device));
+  for (auto& L : c->lane)
+    if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
+  int rc;
+  if ((rc = c->d_sec_tables.ensure(sizeof(int32_t) * AFX_SEC_TABLE_DWORDS * (size_t)c->ngen)) ||
+      (rc = c->lane[0].ws.ensure(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)c->ngen * AFX_SEC_WINDOWS)))
+    return rc;
+  AFX_HIP(afxk_setup_postables(c->stream, (const int32_t*)c->d_gen_ext.p, c->ngen, (int32_t*)c->lane[0].ws.p, (int32_t*)c->d_sec_tables.p, 1));
+  AFX_HIP(hipStreamSynchronize(c->stream));
+  return AFX_OK;
+}
+extern "C" int afx_ctx_set_secret_independent_addressing(afx_ctx* c, int mode) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (mode < 0 || mode > 2) { set_error("mode must be 0 (nowhere), 1 (everywhere) or 2 (the prover-side calls: the default)"); return AFX_E_BAD_ARGS; }
   std::unique_lock<std::recursive_mutex> lock(c->mu);
-  if (enable && !c->d_sec_tables.p) {
-    // the generators' 4-bit positional tables, once per context: window bases through lane 0's workspace, like the 13-bit ones
-    AFX_HIP(hipSetDevice(c->device));
-    for (auto& L : c->lane)
-      if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
-    int rc;
-    if ((rc = c->d_sec_tables.ensure(sizeof(int32_t) * AFX_SEC_TABLE_DWORDS * (size_t)c->ngen)) ||
-        (rc = c->lane[0].ws.ensure(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)c->ngen * AFX_SEC_WINDOWS)))
-      return rc;
-    AFX_HIP(afxk_setup_postables(c->stream, (const int32_t*)c->d_gen_ext.p, c->ngen, (int32_t*)c->lane[0].ws.p, (int32_t*)c->d_sec_tables.p, 1));
-    AFX_HIP(hipStreamSynchronize(c->stream));
-  }
-  c->secret_independent = enable != 0;
+  if (mode) { const int rc = build_secret_tables(c); if (rc) return rc; }
+  c->secret_mode = mode;
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_get_plan_stats(afx_ctx* c, afx_plan_stats* out) try {
@@ -326,6 +330,8 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
     if (!ok[i]) { set_error("generator / key point " + std::to_string(i) + " does not decompress"); return AFX_E_BAD_PARAMS; }   // parameters.rs:77-89
   c->gen_neg_enc.assign(c->ngen, Enc{});
   for (uint32_t i = 0; i < c->ngen; i++) memcpy(c->gen_neg_enc[i].data(), neg.data() + 32 * (size_t)i, 32);
+  // the default mode keeps secrets out of table addresses on the prover-side calls: their generator tables (63 KB each) are part of every context
+  if ((rc = build_secret_tables(c.get()))) return rc;
   *out = c.release();
   return AFX_OK;
 }
@@ -534,7 +540,7 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
   PointVar pZ = PointVar::Var(v_Z, e_Z);
   // (not with secret-independent addressing: the products c*x0 ... are the key times a public factor, and the expanded terms would
   // have to scan their tables like Z's own do - the second chain is the cheaper price there)
-  const bool expand_Z = as.small() && !c->secret_independent;
+  const bool expand_Z = as.small() && !c->secure_plan(false);
   if (expand_Z) {
     pZ.parts.push_back({ nullptr, 0, false, v_A, -1 });
     for (const afx_msm_term& t : zterms) pZ.parts.push_back({ t.scalar, t.scalar_stride, true, t.var, t.fixed_idx });

@@ -57,7 +57,7 @@ inline afx_shape canonical_shape(const afx_shape& sh) {
 // mode flags that change a plan, for plan_key (every statement passes them all: a flag that does not matter to a statement only
 // costs it a second cache entry)
 inline uint64_t mode_flags(const afx_ctx* c) {
-  return (c->strict ? 1u : 0u) | (c->fixed_key_schedule ? 2u : 0u) | (c->secret_independent ? 8u : 0u) | ((uint64_t)c->small_batch_items << 8);
+  return (c->strict ? 1u : 0u) | (c->fixed_key_schedule ? 2u : 0u) | ((uint64_t)(c->secret_mode & 3) << 3) | ((uint64_t)c->small_batch_items << 8);
 }
 
 namespace afx {
@@ -203,8 +203,10 @@ struct Stager {
   uint8_t* dev(size_t off) const { return (off & OUT) ? out_base() + (off & ~OUT) : in_base() + off; }
   // Calls of few items are many short rows (75 arrays for a C3 presentation batch): each row as its own copy from pageable
   // memory costs more than the kernels gain from the latency plan.  Up to PACK_LIMIT bytes the input region's image is put
-  // together in a pinned buffer and sent in ONE transfer.
-  static constexpr size_t PACK_LIMIT = size_t(4) << 20;
+  // together in a pinned buffer and sent in ONE transfer.  16 MB by measurement (tools/midsize_host_calls.py, C3 shape, ms per
+  // call at a limit of 4 / 16 / 64 MB: 2^11 items 2.73 / 2.04 / 2.03, 2^12 4.19 / 3.51 / 3.54, 2^13 and beyond no gain).
+  static constexpr size_t PACK_LIMIT = size_t(16) << 20;
+  static size_t pack_limit();
   int upload();
   // results: the device array [rows][dn][elem] at `off` goes to items [first, first + n) of the host array [rows][total][elem].
   // plan_fetch() declares them; fetch_all() enqueues the copies into the pinned buffer after the kernels; drain() waits for the

@@ -165,8 +165,13 @@ def load_fixture(name):
     return bytes.fromhex(r["params"]), bytes.fromhex(r["key"]), bytes.fromhex(r["issuer_params"])
 
 
-def generate(afx, batch, issuer, user, params, n, layout, hide, count, seed):
-    """synthetic credentials -> presentations, all arithmetic on the GPU (issue, show)"""
+def generate(afx, batch, issuer, user, params, n, layout, hide, count, seed, fast_tables=False):
+    """synthetic credentials -> presentations, all arithmetic on the GPU (issue, show).  fast_tables: the two contexts run their
+    prover-side calls with afx_ctx_set_secret_independent_addressing 0 from here on (the bench's input generation: synthetic keys
+    and nonces are no secrets, and generation is not what is measured; the caller sets the mode it measures afterwards)."""
+    if fast_tables:
+        issuer.set_secret_independent_addressing(0)
+        user.set_secret_independent_addressing(0)
     rng = np.random.default_rng(seed)
     rb = lambda *shape: rng.integers(0, 256, size=shape, dtype=np.uint8)
     values = np.zeros((n, count, 32), np.uint8)
@@ -229,7 +234,7 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
     n, layout, count = 16, "SSSSSSSSPPPPEEEE", (args.batch or (1 << 20))
     params, key, ip = load_fixture("c5_16attrs")
     issuer = afx.Context(params, key, ip, device=local_rank)
-    issuer.set_secret_independent_addressing(args.secret_independent)
+    issuer.set_secret_independent_addressing(secret_mode_of(args))
     rng = np.random.default_rng(4242 + rank)
     rb = lambda *shape: rng.integers(0, 256, size=shape, dtype=np.uint8)
     dev = torch.device("cuda", local_rank)
@@ -306,9 +311,9 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
             "unit": "credentials/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic (random attribute values)",
             "config": {"workload": "C5: batch issue 2^20 credentials, 16 attributes (S x8, P x4, E x4)", "credentials_per_gpu": count,
-                       "secret_independent_addressing": bool(args.secret_independent),
+                       "secret_independent_addressing": {0: "nowhere (mode 0)", 1: "everywhere (mode 1)", 2: "prover-side calls (mode 2, the default)"}[secret_mode_of(args)],
                        "algorithmic_bytes_per_credential": ab, "parallelism": "host-sharded x%d, no collective" % world},
-            "roofline": roofline_of(kt, "c5", ab, count, bool(args.secret_independent)),
+            "roofline": roofline_of(kt, "c5", ab, count, secret_mode_of(args) != 0),
             "valu": with_value_per_mhz(valu, count * world * args.steps / elapsed), "cpu_baseline": cpu}))
     issuer.close()
     if dist is not None:
@@ -321,7 +326,8 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
     params, key, ip = load_fixture("readme_4attrs_sSPe")
     issuer = afx.Context(params, key, ip, device=local_rank)
     user = afx.Context(params, None, ip, device=local_rank)
-    user.set_secret_independent_addressing(args.secret_independent)
+    issuer.set_secret_independent_addressing(0)   # the issuer only makes the synthetic credentials here
+    user.set_secret_independent_addressing(secret_mode_of(args))
     rng = np.random.default_rng(99 + rank)
     rb = lambda *shape: rng.integers(0, 256, size=shape, dtype=np.uint8)
     dev = torch.device("cuda", local_rank)
@@ -415,9 +421,9 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
             "unit": "presentations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic (GPU-issued credentials)",
             "config": {"workload": "show 2^16 credentials, 4 attributes (s S P e)", "credentials_per_gpu": count, "algorithmic_bytes_per_presentation": ab,
-                       "secret_independent_addressing": bool(args.secret_independent),
+                       "secret_independent_addressing": {0: "nowhere (mode 0)", 1: "everywhere (mode 1)", 2: "prover-side calls (mode 2, the default)"}[secret_mode_of(args)],
                        "parallelism": "host-sharded x%d, no collective" % world},
-            "roofline": roofline_of(kt, "show", ab, count, bool(args.secret_independent)),
+            "roofline": roofline_of(kt, "show", ab, count, secret_mode_of(args) != 0),
             "valu": with_value_per_mhz(valu, count * world * args.steps / elapsed), "cpu_baseline": None}))
     issuer.close()
     user.close()
@@ -459,6 +465,13 @@ def valu_side(ctx, items_per_step, field_kernel_ms_per_step):
             "peak_source": "tools/ubench/mad_sustained.hip on this GPU (no published figure): %.2f cycles per wave-instruction" % MAD_CYCLES,
             "peak_sustained_pure_mad_loop": MAD_SUSTAINED_T, "frac_of_sustained": achieved / MAD_SUSTAINED_T, "per_item": dict(st, mads=mads),
             "time_base": "summed durations of the kernels doing field arithmetic (k_msm_*, k_compress2x, k_negenc, k_pointsum, k_decode, k_pointop, k_from_uniform)"}
+
+
+def secret_mode_of(args):
+    """the afx_ctx_set_secret_independent_addressing mode of the measured context"""
+    if args.secret_mode is not None:
+        return args.secret_mode
+    return 1 if args.secret_independent else 2
 
 
 def with_value_per_mhz(valu, value):
@@ -566,7 +579,11 @@ def main():
     ap.add_argument("--no-group-api", action="store_true", help="skip the afx_group_verify_presentations leg (rank 0, after the timed steps)")
     ap.add_argument("--pipelining", action="store_true", help="alternate steps between the engine's two streams (measured slower: the "
                     "path is VALU-bound, overlap only adds contention; default off)")
-    ap.add_argument("--secret-independent", action="store_true", help="afx_ctx_set_secret_independent_addressing on every context (cost "
+    ap.add_argument("--secret-mode", type=int, choices=(0, 1, 2), default=None,
+                    help="afx_ctx_set_secret_independent_addressing of the measured context: 2 = the library's default (secrets never pick a table "
+                         "address on the prover-side calls: issue, show), 1 = also the issuer key's terms of Issuer::verify, 0 = nowhere (the figures of "
+                         "rounds 1-3).  Default: the library's default; the C3 / C4 verification lines are the same in modes 0 and 2")
+    ap.add_argument("--secret-independent", action="store_true", help="= --secret-mode 1: afx_ctx_set_secret_independent_addressing everywhere (cost "
                     "measurement; results are the same bytes)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL; the driver's launch) or gloo (testing two ranks on one GPU)")
     args = ap.parse_args()
@@ -626,7 +643,7 @@ def main():
     user = afx.Context(params, None, ip, device=local_rank)
     t0 = time.time()
     gen_chunk = 1 << 16
-    parts = [generate(afx, batch, issuer, user, params, n, layout, hide, min(gen_chunk, count - o), 1000 + 97 * rank + o)
+    parts = [generate(afx, batch, issuer, user, params, n, layout, hide, min(gen_chunk, count - o), 1000 + 97 * rank + o, fast_tables=True)
              for o in range(0, count, gen_chunk)]
     shape = parts[0][1]
     pres = {f: np.concatenate([p[0][f] for p in parts], axis=-2) for f in batch.PRES_FIELDS}
@@ -636,7 +653,7 @@ def main():
     want = corrupt(pres, count, 7 + rank)
     user.close()
     gen_s = time.time() - t0
-    issuer.set_secret_independent_addressing(args.secret_independent)   # after generation: only the timed verification pays
+    issuer.set_secret_independent_addressing(secret_mode_of(args))   # after generation: only the timed verification pays
 
     # inputs resident in HBM before the timed region
     dev = torch.device("cuda", local_rank)
@@ -770,7 +787,7 @@ def main():
             "config": {"workload": desc, "presentations_per_gpu": count, "attributes": n, "shape": layout, "hidden": hide,
                        "algorithmic_bytes_per_presentation": ab, "parallelism": "host-sharded x%d, no collective" % world,
                        "step_pipelining": "2 streams" if args.pipelining else "off",
-                       "secret_independent_addressing": bool(args.secret_independent),
+                       "secret_independent_addressing": {0: "nowhere (mode 0)", 1: "everywhere (mode 1)", 2: "prover-side calls (mode 2, the default)"}[secret_mode_of(args)],
                        "input_generation_s": round(gen_s, 2), "host_pointer_api_presentations_per_s": pcie,
                        "wire_blob_api_presentations_per_s": wire_rate,
                        "n1_vs_n_note": "the N=1 default workload is C3 (2^20 presentations on the one GPU, \"weak\"); N>1 defaults to C4 (2^22 in all, "
@@ -782,7 +799,7 @@ def main():
                        "group_api_note": "one process, afx_group_verify_presentations over %d device(s) on host arrays (%d copies of "
                                          "rank 0's batch), PCIe and staging inclusive" % (world, world),
                        "group_api_error": group_err},
-            "roofline": roofline_of(kt, args.workload, ab, count, bool(args.secret_independent)),
+            "roofline": roofline_of(kt, args.workload, ab, count, secret_mode_of(args) == 1),
             "valu": with_value_per_mhz(valu, total / elapsed),
             "cpu_baseline": cpu,
         }

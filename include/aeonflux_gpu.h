@@ -155,23 +155,28 @@ int afx_ctx_set_strict(afx_ctx* ctx, int enable);
  * Results are identical in both modes. */
 int afx_ctx_set_fixed_key_schedule(afx_ctx* ctx, int enable);
 
-/* Secret-independent addressing (off by default).  The reference multiplies by secrets - the issuer key, the prover's nonces,
- * blindings and witnesses - with dalek's constant-time `*` / `multiscalar_mul` (src/amacs.rs:267-270, src/nizk/presentation.rs:162-184,
- * zkp's Prover), whose table lookups read every entry and select.  By default this engine's instruction stream is already
- * independent of per-item secrets, but the window digit of a secret picks WHICH table entry a lane gathers from HBM.  With this
- * mode on, no memory address depends on a secret digit either:
- *   - afx_issue*, afx_show* and the symmetric-key helpers (afx_keypairs_derive, afx_encrypt, afx_decrypt, afx_issuer_keygen's
- *     context): every scalar of every multiscalar job but the constant 1 is treated as a secret;
- *   - afx_verify_presentations*: every scalar of the job that computes Z - the issuer key's (which then also run the fixed
- *     schedule of afx_ctx_set_fixed_key_schedule, whatever that setting says) and the per-item products y_i * m_i of the key with
- *     revealed scalar attributes, whose digits would give the key away just the same;
- *   - a job with a secret term on a per-item base runs 2-bit signed windows: every addition reads both stored entries of its
- *     lane's table and keeps the digit's with selects (128 additions per term instead of 64); a secret term on a generator
- *     uses 4-bit positional tables (63 KB per generator, built when the mode is first switched on) whose 9 entries per window
- *     are all read: 64 additions per term instead of 20.
- * Results are byte-identical in both modes.  Cost, measured on one MI355X: issue -51 %, show -39 %,
- * verification -11 %.  Everything else about timing is unchanged: kernels have no data-dependent branches in either mode. */
-int afx_ctx_set_secret_independent_addressing(afx_ctx* ctx, int enable);
+/* Secret-independent addressing.  The reference multiplies by secrets - the issuer key, the prover's nonces, blindings and
+ * witnesses - with dalek's constant-time `*` / `multiscalar_mul` (src/amacs.rs:267-270, src/nizk/presentation.rs:162-184, zkp's
+ * Prover), whose table lookups read every entry and select.  This engine's INSTRUCTION stream never depends on a per-item secret
+ * in any mode; what the mode decides is whether the window digit of a secret may pick WHICH table entry a lane gathers from HBM:
+ *   AFX_SECRETS_PROVER_SIDE (2, the default of a new context): not on the prover-side calls - afx_issue*, afx_show* and the
+ *     symmetric-key helpers (afx_keypairs_derive, afx_encrypt, afx_decrypt): every scalar of every multiscalar job there but the
+ *     constant 1 is treated as a secret.  What a user of the crate gets from its constant-time arithmetic.  Issuer::verify runs
+ *     the fast tables (its only secret is the issuer key, see afx_ctx_set_fixed_key_schedule).
+ *   AFX_SECRETS_EVERYWHERE (1): additionally on afx_verify_presentations*: every scalar of the job that computes Z - the issuer
+ *     key's (which then also run the fixed schedule, whatever afx_ctx_set_fixed_key_schedule says) and the per-item products
+ *     y_i * m_i of the key with revealed scalar attributes, whose digits would give the key away just the same.
+ *   AFX_SECRETS_NOWHERE (0): the fastest tables everywhere (rounds 1-3 of this engine; a device of the engine's own, or inputs
+ *     that are no secrets: synthetic benchmark data).
+ * Where the mode applies, a job with a secret term on a per-item base runs 2-bit signed windows: every addition reads both stored
+ * entries of its lane's table and keeps the digit's with selects (128 additions per term instead of 64); a secret term on a
+ * generator uses 4-bit positional tables (63 KB per generator, part of every context) whose 9 entries per window are all read: 64
+ * additions per term instead of 20.  Results are byte-identical in every mode.  Cost against mode 0, measured on one MI355X
+ * (DESIGN.md section 4): issue -51 %, show -39 %; verification unchanged in mode 2, -11 % in mode 1. */
+#define AFX_SECRETS_NOWHERE 0
+#define AFX_SECRETS_EVERYWHERE 1
+#define AFX_SECRETS_PROVER_SIDE 2
+int afx_ctx_set_secret_independent_addressing(afx_ctx* ctx, int mode);
 
 /* Items per internal pass (tuning; 0 restores the default of 2^19).  A batch larger than this is processed in passes
  * of this many items, which bounds the device workspace (about 25-70 KB per item and pass, depending on the

@@ -215,7 +215,7 @@ extern "C" {
     fn afx_group_destroy(group: *mut c_void);
     fn afx_group_size(group: *const c_void) -> u32;
     fn afx_group_member(group: *mut c_void, index: u32) -> *mut c_void;
-    fn afx_ctx_set_secret_independent_addressing(ctx: *mut c_void, enable: i32) -> i32;
+    fn afx_ctx_set_secret_independent_addressing(ctx: *mut c_void, mode: i32) -> i32;
 }
 
 /// Which of the crate's operations an engine failure interrupted: decides the nearest `CredentialError`.
@@ -239,16 +239,21 @@ fn engine_error(rc: i32, op: Op) -> CredentialError {
 }
 
 /// The crate multiplies by secrets in constant time (dalek's `*` and `multiscalar_mul`: src/amacs.rs:267-270,
-/// src/nizk/presentation.rs:162-184, zkp's Prover).  The engine's kernels have no secret-dependent branches in any mode; with this
-/// switched on no memory ADDRESS depends on a secret scalar either (every table entry is read and the wanted one selected), at
-/// the cost INTEGRATION.md section 3 quotes.  Applied to the one context or to every member of the group.
-fn set_secret_independent(ctx: *mut c_void, group: *mut c_void, enable: bool) -> Result<(), CredentialError> {
+/// src/nizk/presentation.rs:162-184, zkp's Prover).  The engine's kernels have no secret-dependent branches in any mode; the mode
+/// says where no memory ADDRESS may depend on a secret scalar either (every table entry is read and the wanted one selected), at
+/// the cost INTEGRATION.md section 2b quotes.  A new engine runs `ProverSide`: issue and show are covered, verification runs the
+/// fast tables; `Everywhere` adds the issuer key's terms of `verify`; `Nowhere` is for a device of the engine's own.
+#[derive(Clone, Copy)]
+pub enum SecretAddressing { Nowhere = 0, Everywhere = 1, ProverSide = 2 }
+
+/// Applied to the one context or to every member of the group.
+fn set_secret_addressing(ctx: *mut c_void, group: *mut c_void, mode: SecretAddressing) -> Result<(), CredentialError> {
     let mut rc = 0;
     unsafe {
-        if group.is_null() { rc |= afx_ctx_set_secret_independent_addressing(ctx, enable as i32); }
-        else { for i in 0..afx_group_size(group) { rc |= afx_ctx_set_secret_independent_addressing(afx_group_member(group, i), enable as i32); } }
+        if group.is_null() { rc |= afx_ctx_set_secret_independent_addressing(ctx, mode as i32); }
+        else { for i in 0..afx_group_size(group) { rc |= afx_ctx_set_secret_independent_addressing(afx_group_member(group, i), mode as i32); } }
     }
-    if rc != 0 { Err(CredentialError::NoIssuerKey) } else { Ok(()) }   // the only failure: the device could not hold the 4-bit tables
+    if rc != 0 { Err(engine_error(rc, Op::Create)) } else { Ok(()) }
 }
 
 /// `Issuer` with its parameters, tables and key resident on one MI355X (`ctx`) or on several (`group`: the batch is split
@@ -344,9 +349,9 @@ impl GpuIssuer {
                        last_rc: AtomicI32::new(0) })
     }
 
-    /// Constant-address table reads for every scalar of `issue` and for the issuer key's terms of `verify` (see
-    /// `set_secret_independent`): what a deployment that relies on the crate's constant-time arithmetic switches on.
-    pub fn set_secret_independent_addressing(&self, enable: bool) -> Result<(), CredentialError> { set_secret_independent(self.ctx, self.group, enable) }
+    /// Where secrets are kept out of table addresses (`SecretAddressing`; the default covers `issue`, `Everywhere` adds the issuer
+    /// key's terms of `verify`).
+    pub fn set_secret_addressing(&self, mode: SecretAddressing) -> Result<(), CredentialError> { set_secret_addressing(self.ctx, self.group, mode) }
 
     /// The engine's return code (AFX_E_*, 0 = none) of the most recent call that failed as a whole.
     pub fn last_engine_code(&self) -> i32 { self.last_rc.load(Ordering::Relaxed) }
@@ -560,8 +565,9 @@ impl GpuUser {
                      last_rc: AtomicI32::new(0) })
     }
 
-    /// Constant-address table reads for every scalar of `show` (blindings, the credential's `t`, the symmetric key).
-    pub fn set_secret_independent_addressing(&self, enable: bool) -> Result<(), CredentialError> { set_secret_independent(self.ctx, self.group, enable) }
+    /// Where secrets are kept out of table addresses (`SecretAddressing`; the default covers every scalar of `show`: blindings, the
+    /// credential's `t`, the symmetric key).
+    pub fn set_secret_addressing(&self, mode: SecretAddressing) -> Result<(), CredentialError> { set_secret_addressing(self.ctx, self.group, mode) }
 
     /// The engine's return code (AFX_E_*, 0 = none) of the most recent call that failed as a whole.
     pub fn last_engine_code(&self) -> i32 { self.last_rc.load(Ordering::Relaxed) }
