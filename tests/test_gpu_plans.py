@@ -1,0 +1,81 @@
+"""GPU parity for REUSED plans.  A small call's launch list is assembled once per (statement, shape, padded size) and kept on the
+context (afx::Plan, plans.cpp run_chunked: position-independent, relocated to wherever the call's staging and workspace stand); every
+later call of that statement and shape up to the padded size runs the kept plan on its own data.  The reference has no such state
+(Issuer::verify is a pure function of the presentation, /root/reference/src/issuer.rs:141-145), so nothing of an earlier call may show
+in a later one: calls of different counts, different items, other shapes in between and a changed workspace must each give the
+ORACLE's statuses / bytes, with the plan self-check on (every plan assembled twice against different provisional bases and compared
+after relocation) as well as off."""
+import numpy as np
+import pytest
+
+from tests.helpers import corrupt, gpu_verify, make_batch, make_credentials
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_statuses(issuer, pres):
+    return [issuer.verify_presentation(p) for p in pres]
+
+
+@pytest.fixture(scope="module")
+def batches():
+    params, key, ip, issuer, a = make_batch(4, "SSPE", [0, 3], 70, b"gpu-plans-a")
+    _, _, _, _, b = make_batch(4, "SSPE", [1], 20, b"gpu-plans-a")        # same parameters and key, another shape
+    corrupt(a, b"plans-a")
+    corrupt(b, b"plans-b")
+    return params, key, ip, issuer, a, b, oracle_statuses(issuer, a), oracle_statuses(issuer, b)
+
+
+@pytest.mark.parametrize("selfcheck", [False, True])
+def test_a_kept_plan_serves_other_counts_and_other_items(batches, selfcheck, monkeypatch):
+    import aeonflux_amd as afx
+    params, key, ip, issuer, a, b, want_a, want_b = batches
+    if selfcheck:
+        monkeypatch.setenv("AFX_PLAN_SELFCHECK", "1")
+    else:
+        monkeypatch.delenv("AFX_PLAN_SELFCHECK", raising=False)
+    ctx = afx.Context(params, key, ip)
+    assert any(want_a) and not all(want_a), "the batch must hold rejected items"
+    # (offset, count): padded sizes 16, 16, 32, 64, 16 (kept plan, other items), 128 (70 items), 32 again, 1
+    for off, cnt in [(0, 5), (5, 16), (3, 17), (10, 40), (50, 9), (0, 70), (40, 30), (69, 1)]:
+        assert gpu_verify(afx, ctx, a[off:off + cnt]) == want_a[off:off + cnt], (off, cnt)
+        if cnt % 2:   # another shape's plan in between, and back
+            assert gpu_verify(afx, ctx, b[:cnt % 20 + 1]) == want_b[:cnt % 20 + 1]
+    # the large-pass plan moves the workspace (ensure_ws grows it); the kept small plans must follow
+    ctx.set_small_batch_items(0)
+    assert gpu_verify(afx, ctx, a) == want_a
+    ctx.set_small_batch_items(4096)
+    assert gpu_verify(afx, ctx, a[7:30]) == want_a[7:30]
+    assert gpu_verify(afx, ctx, b) == want_b
+    ctx.close()
+
+
+def test_kept_prover_plans_issue_the_oracles_bytes_call_after_call():
+    """afx_issue on a kept plan: the second and third calls (other requests, another count under the same padded size) give the
+    oracle's bytes; the secret mode is part of the plan's identity, so switching it between calls must not reuse the other mode's
+    launch list"""
+    import aeonflux_amd as afx
+    from aeonflux_amd import batch
+    n = 4
+    d = make_credentials(n, "SSPE", 24, b"gpu-plans-issue")
+    cr = d["creds"]
+    col = lambda items, f: np.stack([np.frombuffer(f(c), np.uint8) for c in items])
+    ctx = afx.Context(d["params"], d["key"], d["ip"])
+
+    def issue(items):
+        g = dict(kinds=items[0]["kinds"], values=np.stack([col(items, lambda c, i=i: c["values"][i][:32]) for i in range(n)]),
+                 t_wide=col(items, lambda c: c["rnd"][0]), U_wide=col(items, lambda c: c["rnd"][1]), rng_seed=col(items, lambda c: c["rnd"][2]),
+                 positions=np.arange(len(items), dtype=np.uint64))
+        outs, status = batch.issue_mixed(ctx, [g])
+        assert not status.any()
+        o = outs[0]
+        for i, c in enumerate(items):
+            assert (o["t"][i].tobytes(), o["U"][i].tobytes(), o["V"][i].tobytes(), o["challenge"][i].tobytes()) == (c["t"], c["U"], c["V"], c["challenge"])
+            assert [o["responses"][k, i].tobytes() for k in range(n + 5)] == c["responses"]
+    for mode in (2, 0, 2, 1):
+        ctx.set_secret_independent_addressing({0: False, 1: True, 2: "prover"}[mode])
+        issue(cr[:7])
+        issue(cr[7:20])
+        issue(cr[20:])
+        issue(cr[3:19])
+    ctx.close()

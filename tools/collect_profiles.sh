@@ -1,37 +1,70 @@
 #!/bin/bash
-# Everything profiles/ holds for one round, collected on the GPU box:  gpurun -- 'bash tools/collect_profiles.sh r02'
+# Everything profiles/ holds for one round, collected on the GPU box:  gpurun -- 'bash tools/collect_profiles.sh r04'
 # Output: gpurun_out/profiles_<tag>/ (copy what should be judged into profiles/).
-#  - bench JSON lines of the workloads (default = C3, C2, C5 issue, show)
-#  - rocprofv3 --kernel-trace --stats summaries of the default bench command (C3) and of the C5 issue bench
+#  - bench JSON lines: default = C3; C2; C5 issue and show in the library's default mode (secrets off the table addresses on the
+#    prover-side calls, afx_ctx_set_secret_independent_addressing 2) and with the fast tables (mode 0, rounds 1-3); C3 in mode 1
+#  - rocprofv3 --kernel-trace --stats summaries of the default bench command (C3) and of the C5 issue bench (both modes)
 #  - PMC passes, each in its own run with --kernel-trace only (MI355X_MICROARCH: separate passes):
-#      FETCH_SIZE, WRITE_SIZE (HBM traffic per kernel, C3 and C5), the SQ issue/wait counters and the instruction mix (C3)
-TAG=${1:-r02}
+#      FETCH_SIZE, WRITE_SIZE -> <tag>_traffic.json (C3 default; C5 mode 0) and <tag>_secret_traffic.json (C5 default mode; C3
+#      mode 1) with the sha256 of the kernel sources they were measured on; the SQ issue/wait counters and the instruction mix (C3),
+#      the SQ counters of C5 in both modes
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
 cd $R
-python3 bench.py > $O/bench_c3.log 2>&1
-grep '^{' $O/bench_c3.log | tail -1 > $O/${TAG}_bench_c3.json
-for w in c2 c5 show; do
-  python3 bench.py --workload $w > $O/bench_$w.log 2>&1
-  grep '^{' $O/bench_$w.log | tail -1 > $O/${TAG}_bench_$w.json
+line() { grep '^{' $1 | tail -1; }
+python3 bench.py > $O/bench_c3.log 2>&1; line $O/bench_c3.log > $O/${TAG}_bench_c3.json
+python3 bench.py --workload c2 > $O/bench_c2.log 2>&1; line $O/bench_c2.log > $O/${TAG}_bench_c2.json
+for w in c5 show; do
+  python3 bench.py --workload $w > $O/bench_$w.log 2>&1; line $O/bench_$w.log > $O/${TAG}_bench_$w.json
+  python3 bench.py --workload $w --secret-mode 0 --no-cpu-baseline > $O/bench_${w}_mode0.log 2>&1; line $O/bench_${w}_mode0.log > $O/${TAG}_bench_${w}_fast_tables.json
 done
+python3 bench.py --secret-mode 1 --no-cpu-baseline > $O/bench_c3_mode1.log 2>&1; line $O/bench_c3_mode1.log > $O/${TAG}_bench_c3_secret_everywhere.json
 cd /tmp && export TMPDIR=/tmp
-db() { ls $1/*/$2_results.db $1/$2_results.db 2>/dev/null | head -1; }
-for w in c3 c5; do
-  rocprofv3 --kernel-trace --stats -d $O/trace_$w -o t -- python3 $R/bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > $O/trace_$w.log 2>&1
-  python3 $R/tools/rocpd_summary.py $(db $O/trace_$w t) > $O/${TAG}_${w}_kernel_trace.txt 2>&1
-  grep '^{' $O/trace_$w.log | tail -1 > $O/${TAG}_${w}_kernel_trace_bench_line.json
+db() { ls $1/*/t_results.db $1/t_results.db 2>/dev/null | head -1; }
+trace() {   # name, bench flags...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats -d $O/trace_$name -o t -- python3 $R/bench.py "$@" --steps 10 --warmup 2 --no-cpu-baseline > $O/trace_$name.log 2>&1
+  python3 $R/tools/rocpd_summary.py $(db $O/trace_$name) > $O/${TAG}_${name}_kernel_trace.txt 2>&1
+  line $O/trace_$name.log > $O/${TAG}_${name}_kernel_trace_bench_line.json
+  rm -rf $O/trace_$name
+}
+pmc2() {    # name, bench flags...: FETCH_SIZE and WRITE_SIZE passes
+  local name=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c -d $O/pmc_${w}_$c -o t -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_${w}_$c.log 2>&1
+    rocprofv3 --kernel-trace --pmc $c -d $O/pmc_${name}_$c -o t -- python3 $R/bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_${name}_$c.log 2>&1
   done
-done
+}
+trace c3 --workload c3
+trace c5 --workload c5
+trace c5_fast_tables --workload c5 --secret-mode 0
+pmc2 c3 --workload c3
+pmc2 c5fast --workload c5 --secret-mode 0
+pmc2 c5 --workload c5
+pmc2 c3all --workload c3 --secret-mode 1
 python3 $R/tools/traffic_json.py $O/${TAG}_traffic.json \
-  c3:$(db $O/pmc_c3_FETCH_SIZE t):$(db $O/pmc_c3_WRITE_SIZE t):$O/pmc_c3_FETCH_SIZE.log \
-  c5:$(db $O/pmc_c5_FETCH_SIZE t):$(db $O/pmc_c5_WRITE_SIZE t):$O/pmc_c5_FETCH_SIZE.log > $O/${TAG}_traffic.txt 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d $O/pmc_sq -o t -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_sq.log 2>&1
-python3 $R/tools/rocpd_pmc.py $(db $O/pmc_sq t) k_ > $O/${TAG}_c3_pmc.txt 2>&1
+  c3:$(db $O/pmc_c3_FETCH_SIZE):$(db $O/pmc_c3_WRITE_SIZE):$O/pmc_c3_FETCH_SIZE.log \
+  c5:$(db $O/pmc_c5fast_FETCH_SIZE):$(db $O/pmc_c5fast_WRITE_SIZE):$O/pmc_c5fast_FETCH_SIZE.log > $O/${TAG}_traffic.txt 2>&1
+python3 $R/tools/traffic_json.py $O/${TAG}_secret_traffic.json \
+  c5:$(db $O/pmc_c5_FETCH_SIZE):$(db $O/pmc_c5_WRITE_SIZE):$O/pmc_c5_FETCH_SIZE.log \
+  c3:$(db $O/pmc_c3all_FETCH_SIZE):$(db $O/pmc_c3all_WRITE_SIZE):$O/pmc_c3all_FETCH_SIZE.log > $O/${TAG}_secret_traffic.txt 2>&1
+sq() {      # name, bench flags...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES -d $O/pmc_sq_$name -o t -- python3 $R/bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_sq_$name.log 2>&1
+  python3 $R/tools/rocpd_pmc.py $(db $O/pmc_sq_$name) k_ > $O/${TAG}_${name}_pmc.txt 2>&1
+  rm -rf $O/pmc_sq_$name
+}
+sq c3 --workload c3
+sq c5 --workload c5
+sq c5_fast_tables --workload c5 --secret-mode 0
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/pmc_mix -o t -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mix.log 2>&1
-python3 $R/tools/rocpd_pmc.py $(db $O/pmc_mix t) k_msm > $O/${TAG}_c3_instruction_mix.txt 2>&1
-rm -rf $O/trace_c3 $O/trace_c5 $O/pmc_c3_FETCH_SIZE $O/pmc_c3_WRITE_SIZE $O/pmc_c5_FETCH_SIZE $O/pmc_c5_WRITE_SIZE $O/pmc_sq $O/pmc_mix   # databases are large; the summaries are kept
+python3 $R/tools/rocpd_pmc.py $(db $O/pmc_mix) k_msm > $O/${TAG}_c3_instruction_mix.txt 2>&1
+rm -rf $O/pmc_*_FETCH_SIZE $O/pmc_*_WRITE_SIZE $O/pmc_mix   # databases are large; the summaries are kept
+# the small-call and mixed-request measurements of the round
+cd $R
+python3 tools/mixed_concurrency.py 64 16 > $O/${TAG}_mixed_concurrency.txt 2>&1
+for a in "8 16" "64 1" "32 64" "64 256"; do python3 tools/mixed_concurrency.py $a >> $O/${TAG}_mixed_concurrency.txt 2>&1; done
+python3 tools/small_call_latency.py > $O/${TAG}_small_call_latency.txt 2>&1
+for m in 4 16 64; do AFX_PACK_LIMIT_MB=$m python3 tools/midsize_host_calls.py; done > $O/${TAG}_midsize_host_calls.txt 2>&1
 ls -la $O
