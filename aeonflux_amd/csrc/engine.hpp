@@ -73,7 +73,7 @@ struct afx_ctx {
   std::vector<afx::Enc> gen_enc, gen_neg_enc;   // host copies of compress(G), compress(-G)
   // device residents
   afx::DevBuf d_gen_enc, d_pos_tables, d_gen_ext, d_key, d_consts;
-  afx::DevBuf d_sec_tables;   // 4-bit positional tables of the generators (AFX_SEC_*), built when secret-independent addressing is first switched on
+  afx::DevBuf d_sec_tables;   // 6-bit positional tables of the generators (AFX_SEC_*) for secret scalars, built at context creation
   // key scalar slots in d_key ([k][32]): w, w', x0, x1, y[0..n), then constants one, zero
   const uint8_t* key_w() const { return (const uint8_t*)d_key.p; }
   const uint8_t* key_wp() const { return (const uint8_t*)d_key.p + 32; }

@@ -139,7 +139,7 @@ __global__ void k_setup_generators(const uint8_t* __restrict__ enc, uint32_t nge
 // d = 0 .. 2^(BITS-1) as halved affine niels ((y+x)/2, (y-x)/2, dxy; ge.cuh).  Two kernels: the window bases B_{g,j} = 2^(BITS*j) G_g
 // (thread per (g, j)), then thread (g, j, c) writes the 16 entries 16c .. 16c+15 with ONE field inversion
 // (Montgomery's trick over the 16 Z coordinates).
-// The same two kernels build the 13-bit tables of the public path and the 4-bit tables of the secret-independent one
+// The same two kernels build the 13-bit tables of the public path and the 6-bit tables of the secret-independent one
 // (AFX_SEC_*): `bits`, `windows`, `entries` (= 2^(bits-1) + 1) and the dword strides are launch arguments.
 __global__ void k_setup_posbase(const int32_t* __restrict__ ext, uint32_t ngen, int32_t* __restrict__ base, uint32_t bits, uint32_t windows) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,35 +406,39 @@ AFX_DEV ge_p3 msm_add_positional(const msm_env& e, const int32_t* __restrict__ p
   return ge_p1p1_to_p3_next(ge_madd(acc, q, neg), next);
 }
 
-// acc += (signed 4-bit digit j) * 16^j * (generator of term t) for a SECRET scalar: the nine entries d = 0..8 of window j of the
-// generator's 4-bit positional table are all read (the addresses are wave-uniform and the same for every item) and the digit's
-// entry is kept with selects.  Digits as for a variable base (s + 0x88..88).
+// acc += (signed AFX_SEC_BITS-bit digit j) * 2^(AFX_SEC_BITS*j) * (generator of term t) for a SECRET scalar.  No memory address
+// depends on the digit: the 32 stored multiples of window j are read ONE PER LANE (lane l and lane l + 32 read multiple (l & 31) + 1:
+// the address is a function of the lane's id), and each lane then takes the dwords of the multiple its digit names from the lane
+// that holds it with ds_bpermute_b32 - a register-to-register exchange through the LDS crossbar that touches no memory.  Its source
+// slots are lanes 0..31 only, one per LDS bank, so any pattern of digits is served without a bank conflict (equal digits read one
+// slot: a broadcast) - tools/ubench/bperm_lookup.hip times the patterns, SQ_LDS_BANK_CONFLICT stays 0.  Digit 0 takes the
+// identity (entry 0 of the window, read through scalar registers) with a select.  Every lane of a live wave is active here
+// (msm_body: lanes past the end shadow the last item), which the exchange needs of its source lanes.
+// (Rounds 3-4 read all nine entries of a 4-bit window through scalar registers and selected: 64 additions per term, 216 selects each.)
+static_assert(AFX_SEC_ENTRIES == 33, "one stored multiple per lane of a 32-lane half: 6-bit signed digits");
 AFX_DEV ge_p3 msm_add_positional_secret(const msm_env& e, const int32_t* __restrict__ sec_tables, const ge_p3& acc, uint32_t t, uint32_t j, int next) {
-  const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + (j >> 3)) * e.count + e.item];
-  const int d = (int)((word >> ((j & 7) * 4)) & 15u) - 8;
+  const uint32_t o = AFX_SEC_BITS * j, k = o >> 5, sh = o & 31u;
+  const uint32_t* dw = e.digit_ws + ((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + k) * e.count + e.item;
+  uint64_t w = dw[0];
+  if (sh + AFX_SEC_BITS > 32) w |= (uint64_t)dw[e.count] << 32;   // uniform condition (j is uniform); k + 1 <= 8
+  const int d = (int)((uint32_t)(w >> sh) & ((1u << AFX_SEC_BITS) - 1)) - (1 << (AFX_SEC_BITS - 1));
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
   const bool neg = (d < 0) != (e.term[t].negate != 0);
   const int32_t* win = sec_tables + (size_t)e.term[t].fixed_idx * AFX_SEC_TABLE_DWORDS + (size_t)j * AFX_SEC_WINDOW_DWORDS;
+  // this lane's share of the window: multiple (lane & 31) + 1, seven 16-byte loads
+  const int4* mine = reinterpret_cast<const int4*>(win + ((threadIdx.x & 31u) + 1u) * AFX_NIELS_DWORDS);
+  int32_t held[AFX_NIELS_DWORDS];
+#pragma unroll
+  for (int l = 0; l < AFX_NIELS_DWORDS / 4; l++) { const int4 x = mine[l]; held[4 * l] = x.x; held[4 * l + 1] = x.y; held[4 * l + 2] = x.z; held[4 * l + 3] = x.w; }
+  const int src = (int)(((idx - 1u) & 31u) << 2);   // byte offset of the source lane's slot; digit 0 reads some lane and drops it below
+  uint32_t keep = idx != 0 ? 0xffffffffu : 0u;
+  asm volatile("" : "+v"(keep));   // opaque: the compiler would turn the mask arithmetic back into a select on a lane mask and a copy
   int32_t v[27];
 #pragma unroll
-  for (int l = 0; l < 27; l++) v[l] = win[l];   // entry 0: the identity in niels form
-  // Every entry is READ before its select: pinned in scalar registers, so that the compiler cannot turn "hit ? ent[l] : v[l]" into
-  // a branch around the load (it did - a load skipped when no lane of the wave holds that digit is an access pattern that depends
-  // on the digits, and 27 dependent one-dword round trips per entry besides).  Unrolled: the next entry's loads are in flight
-  // while this one's selects run.
-#pragma unroll
-  for (uint32_t k = 1; k < AFX_SEC_ENTRIES; k++) {
-    int32_t ent[27];
-#pragma unroll
-    for (int l = 0; l < 27; l++) ent[l] = win[k * AFX_NIELS_DWORDS + l];
-#pragma unroll
-    for (int l = 0; l < 27; l++) AFX_PIN_UNIFORM(ent[l]);
-    // a lane mask and a bitfield insert: one instruction per dword with the entry read straight from its scalar register
-    // (a select would first copy it into a vector register: the condition already takes the instruction's one scalar operand)
-    uint32_t m = idx == k ? 0xffffffffu : 0u;
-    asm volatile("" : "+v"(m));   // opaque: otherwise the mask arithmetic is folded back into selects
-#pragma unroll
-    for (int l = 0; l < 27; l++) v[l] = (int32_t)(((uint32_t)ent[l] & m) | ((uint32_t)v[l] & ~m));
+  for (int l = 0; l < 27; l++) {
+    const int32_t id = win[l];   // entry 0, the identity in niels form: wave-uniform, scalar loads
+    const int32_t got = __builtin_amdgcn_ds_bpermute(src, held[l]);
+    v[l] = (int32_t)(((uint32_t)got & keep) | ((uint32_t)id & ~keep));
   }
   ge_niels q;
 #pragma unroll
@@ -467,7 +471,8 @@ AFX_DEV void msm_recode(const afx_msm_djob* job, uint32_t* __restrict__ digit_ws
     uint32_t b[9];
     b[8] = 0;
     if (t < nv && narrow) sc_bias_wide<AFX_SECVAR_BITS, AFX_SECVAR_WINDOWS>(b, s);   // variable bases of a job with a secret on one
-    else if (t < nv || terms[t].secret) sc_bias(b, s, 0x88888888u);   // signed 4-bit digits: variable bases, and secret scalars on fixed bases
+    else if (t < nv) sc_bias(b, s, 0x88888888u);   // signed 4-bit digits: variable bases
+    else if (terms[t].secret) sc_bias_wide<AFX_SEC_BITS, AFX_SEC_WINDOWS>(b, s);   // secret scalars on fixed bases
     else sc_bias_wide<AFX_POS_BITS, AFX_POS_WINDOWS>(b, s);
 #pragma unroll
     for (int i = 0; i < AFX_DIGIT_WORDS; i++) digit_ws[((size_t)(dslot + t) * AFX_DIGIT_WORDS + i) * count + item] = b[i];
@@ -501,7 +506,7 @@ AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t ch
   }
 }
 // the fixed bases of a job (terms [from, nt)): positional tables, no doubling; the sum's last step leaves acc centred.
-// SEC: terms with a secret scalar take the 4-bit tables with all entries read (64 additions each), the others the 13-bit ones.
+// SEC: terms with a secret scalar take the AFX_SEC_BITS-bit tables through the lane exchange (AFX_SEC_WINDOWS additions each), the others the 13-bit ones.
 template <bool SEC>
 AFX_DEV ge_p3 msm_fixed_terms(const msm_env& e, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables, ge_p3 acc, uint32_t from, uint32_t nt) {
   int last_pub = -1, last_sec = -1;   // wave-uniform

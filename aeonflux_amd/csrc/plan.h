@@ -21,12 +21,14 @@
 #define AFX_POS_ENTRIES ((1 << (AFX_POS_BITS - 1)) + 1)
 #define AFX_POS_WINDOW_DWORDS ((AFX_POS_ENTRIES * AFX_NIELS_DWORDS + 3) & ~3)   /* 16-byte multiple */
 #define AFX_POS_TABLE_DWORDS (AFX_POS_WINDOWS * AFX_POS_WINDOW_DWORDS)
-/* Positional tables for SECRET scalars on fixed bases (afx_ctx_set_secret_independent_addressing): 4-bit windows, so that all
- * 9 entries d = 0..8 of a window are read for every addition and the one wanted is picked with selects - no address depends on a
- * digit.  64 additions per term instead of AFX_POS_WINDOWS; 63 KB per generator, built when the mode is first switched on. */
-#define AFX_SEC_BITS 4
-#define AFX_SEC_WINDOWS 64
-#define AFX_SEC_ENTRIES 9
+/* Positional tables for SECRET scalars on fixed bases (afx_ctx_set_secret_independent_addressing): signed 6-bit windows.  The 32
+ * stored multiples d = 1..32 of a window are read one per lane (an address that depends on the lane's id only) and every lane takes
+ * the multiple its digit names from the lane that holds it (ds_bpermute_b32: no memory access; kernels.hip
+ * msm_add_positional_secret) - no address depends on a digit.  43 additions per term instead of AFX_POS_WINDOWS; 155 KB per
+ * generator, built at context creation. */
+#define AFX_SEC_BITS 6
+#define AFX_SEC_WINDOWS ((253 + AFX_SEC_BITS - 1) / AFX_SEC_BITS)
+#define AFX_SEC_ENTRIES ((1 << (AFX_SEC_BITS - 1)) + 1)
 #define AFX_SEC_WINDOW_DWORDS (AFX_SEC_ENTRIES * AFX_NIELS_DWORDS)
 #define AFX_SEC_TABLE_DWORDS (AFX_SEC_WINDOWS * AFX_SEC_WINDOW_DWORDS)
 /* Variable bases of a job that has a secret scalar on one of them (afx_msm_job.narrow): signed windows of AFX_SECVAR_BITS bits
@@ -149,7 +151,7 @@ typedef struct {
                               launch list that share a base and a table kind share the table)              */
   uint32_t secret;         /* the scalar is a secret and the context runs with secret-independent addressing (Assembler::msm
                               sets it): every entry of the window's table is read and the digit's entry selected; a fixed base
-                              uses the 4-bit positional tables (AFX_SEC_*), recoded like a variable term              */
+                              uses the 6-bit positional tables (AFX_SEC_*) through the lane exchange            */
   uint32_t dbl;            /* the base holds HALF the point the statement means (its producer left its half for k_compress2x,
                               afx_msm_job.leave_half): the term's scalar counts twice (Assembler::msm sets it)           */
 } afx_msm_term;

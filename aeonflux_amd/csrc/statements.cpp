@@ -116,7 +116,7 @@ extern "C" int afx_ctx_set_fixed_key_schedule(afx_ctx* c, int enable) try {
   c->fixed_key_schedule = enable != 0;
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
-// the generators' 4-bit positional tables (AFX_SEC_*), once per context: window bases through lane 0's workspace, like the 13-bit ones
+// the generators' 6-bit positional tables (AFX_SEC_*), once per context: window bases through lane 0's workspace, like the 13-bit ones
 static int build_secret_tables(afx_ctx* c) {
   if (c->d_sec_tables.p || c->ngen == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(c->device));

@@ -4,10 +4,10 @@ Reads the device code object embedded in aeonflux_amd/lib/libaeonflux_gpu.so (ll
 
  * register/scratch table of DESIGN.md section 3: the chain, table, decode and encode kernels are scratch-free, and the
    instances that are launched three blocks per CU fit 168 VGPRs;
- * secret-independent addressing: the scan of a generator's window reads every entry through wide scalar loads and selects with
-   v_bfi_b32 - round 3 found the compiler had turned the select into a branch around a one-dword load (skipped when no lane of
-   the wave held that digit: an access pattern that depended on the digits).  The SEC instances must not have more exec-mask
-   branches than their ordinary siblings."""
+ * secret-independent addressing: a secret scalar on a generator takes its table entry through a lane exchange (ds_bpermute_b32
+   from lanes that each loaded one entry at an address made of the lane's id) - no load whose address comes from a digit, no LDS
+   memory, no branch on the exec mask around it.  (Round 3 had found the compiler turning a select into a branch around a one-dword
+   load, skipped when no lane of the wave held that digit - an access pattern that depended on the digits; hence this file.)"""
 import os
 import re
 import shutil
@@ -70,18 +70,24 @@ def test_hot_kernels_are_scratch_free_and_fit_their_occupancy(code_object):
     assert len(tables) == 3 and all(kernels[k]["vgpr_count"] <= 192 for k in tables), [(k, kernels[k]) for k in tables]
 
 
-def test_secret_independent_scan_reads_every_entry_unconditionally(code_object):
+def test_secret_independent_lookups_address_nothing_by_a_digit(code_object):
     _, bodies = code_object
     count = lambda body, pat: len(re.findall(pat, body))
     for kind in (0, 1):
         for enc in (0, 1):
             sec, plain = bodies[msm(kind, enc, 1)], bodies[msm(kind, enc, 0)]
-            # 8 entries of a window (entry 0 besides): 27 dwords each through s_load_dwordx16 + x8 + ...; none of it in the ordinary instance
-            # (whose only wide scalar loads are its kernel arguments and the job's header)
-            assert count(plain, r"s_load_dwordx16") <= 2 and count(sec, r"s_load_dwordx16") >= 8 + count(plain, r"s_load_dwordx16")
-            assert count(sec, r"v_bfi_b32") >= 8 * 20
-            # no branch on the exec mask around the scan's loads: the SEC instance branches where its sibling does (+ the uniform
+            # a secret scalar on a generator: the window's 32 multiples are loaded one per lane (seven 16-byte loads at an address made
+            # of the lane's id) and the digit's multiple comes from the lane that holds it through ds_bpermute_b32, 27 dwords - a
+            # lane exchange, no memory access; none of it in the ordinary instance
+            assert count(plain, r"ds_bpermute_b32") == 0 and count(sec, r"ds_bpermute_b32") == 27, (kind, enc, count(sec, r"ds_bpermute_b32"))
+            assert count(sec, r"global_load_dwordx[34]") >= count(plain, r"global_load_dwordx[34]") + 7
+            # digit 0 takes the identity (entry 0 through scalar registers) with a mask insert per dword, not a branch
+            assert count(sec, r"v_bfi_b32") >= 27
+            # no LDS memory is read or written by these kernels: the exchange is the only DS instruction
+            assert count(sec, r"\bds_(read|write|load|store)") == 0
+            # no branch on the exec mask around the lookups: the SEC instance branches where its sibling does (+ the uniform
             # `secret` / `narrow` tests, which are scalar branches), not once per table word
             assert count(sec, r"s_cbranch_exec") <= count(plain, r"s_cbranch_exec") + 4, (kind, enc)
-    # the narrow chain of the windowed SEC instance: two entries x eight 16-byte loads in flight per addition
+    # the narrow chain of the windowed SEC instance (a secret scalar on a per-item base): every stored entry of the lane's table is
+    # read for every addition, two entries x eight 16-byte loads in flight
     assert count(bodies[msm(1, 0, 1)], r"global_load_dwordx4") >= 2 * 16

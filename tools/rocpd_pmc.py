@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel sums/averages of PMC counters from a rocprofv3 rocpd database (--pmc ... --kernel-trace).
-Usage: tools/rocpd_pmc.py db [kernel_name_filter]"""
+Usage: tools/rocpd_pmc.py db [kernel_name_filter]
+       tools/rocpd_pmc.py db --last N kernel     sums over the last N dispatches of a kernel
+       tools/rocpd_pmc.py db --each kernel       one line per dispatch of a kernel, in launch order"""
 import sqlite3
 import sys
 
@@ -22,6 +24,28 @@ def last_dispatches(path, kernel, n):
     print("# %s: sums over the last %d dispatches of %s" % (path, len(ids), kernel))
     for name, v in db.execute(q):
         print("%-24s %18.0f   per dispatch %16.0f" % (name, v, v / max(1, len(ids))))
+
+
+def each_dispatch(path, kernel):
+    db = sqlite3.connect(path)
+    tables = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
+    kd = next(t for t in tables if "kernel_dispatch" in t)
+    ks = next(t for t in tables if "kernel_symbol" in t)
+    pe = next(t for t in tables if "rocpd_pmc_event" in t)
+    pi = next(t for t in tables if "rocpd_info_pmc" in t)
+    icols = [r[1] for r in db.execute(f"pragma table_info('{pi}')")]
+    namecol = "symbol" if "symbol" in icols else "name"
+    q = f"""select d.dispatch_id, i.{namecol}, sum(p.value), max(d.end - d.start), max(d.grid_size_x) from {pe} p join {pi} i on p.pmc_id = i.id
+            join {kd} d on p.event_id = d.event_id join {ks} s on d.kernel_id = s.id where s.display_name like '{kernel}%'
+            group by d.dispatch_id, i.{namecol} order by d.dispatch_id, i.{namecol}"""
+    rows = {}
+    for did, name, v, ns, gx in db.execute(q):
+        rows.setdefault(did, {"ms": ns / 1e6, "grid": gx})[name] = v
+    names = sorted({k for r in rows.values() for k in r if k not in ("ms", "grid")})
+    print("# %s: every dispatch of %s in launch order" % (path, kernel))
+    print("%4s %10s %9s  " % ("#", "grid_x", "ms") + "  ".join("%22s" % n for n in names))
+    for n, (did, r) in enumerate(sorted(rows.items())):
+        print("%4d %10d %9.3f  " % (n, r["grid"], r["ms"]) + "  ".join("%22.0f" % r.get(k, 0) for k in names))
 
 
 def main(path, flt=None):
@@ -48,5 +72,7 @@ def main(path, flt=None):
 
 if __name__ == "__main__" and len(sys.argv) == 5 and sys.argv[2] == "--last":
     last_dispatches(sys.argv[1], sys.argv[4], int(sys.argv[3]))
+elif __name__ == "__main__" and len(sys.argv) == 4 and sys.argv[2] == "--each":
+    each_dispatch(sys.argv[1], sys.argv[3])
 elif __name__ == "__main__":
     main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
