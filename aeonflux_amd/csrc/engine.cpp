@@ -10,6 +10,7 @@
 #include <stdexcept>
 
 namespace afx {
+namespace { size_t job_size(LaunchKind k); }   // bytes of one job of a launch kind (below, with the relocation)
 
 static thread_local std::string g_error;
 void set_error(const std::string& s) { g_error = s; }
@@ -155,17 +156,18 @@ void Assembler::negenc(const std::vector<afx_negenc_job>& jobs) {
   add_jobs(L_NEGENC, jobs);
   add_walk_rows(launches.back(), 0);
 }
-// grid rows of a k_compress2x / k_negenc launch: per_row jobs each (0 = all in one row), each row with scratch for its prefix products
+// grid rows of a k_compress2x / k_negenc / k_table_affine launch: per_row jobs each (0 = all in one row), each row with scratch for
+// its prefix products (k_table_affine keeps them inside the table entries)
 void Assembler::add_walk_rows(Launch& l, uint32_t per_row) {
   if (per_row == 0 || per_row > l.njobs) per_row = l.njobs;
   std::vector<afx_walk_row> rows;
   for (uint32_t first = 0; first < l.njobs; first += per_row) {
     afx_walk_row r;
     memset(&r, 0, sizeof r);
-    r.job_off = first * (uint32_t)(l.kind == L_COMPRESS ? sizeof(afx_compress_job) : sizeof(afx_negenc_job));
+    r.job_off = first * (uint32_t)job_size(l.kind);
     r.n_jobs = std::min(per_row, l.njobs - first);
     r.pass = 0;
-    r.prefix_ws = (int32_t*)ws_alloc(sizeof(int32_t) * 9 * (size_t)r.n_jobs * (size_t)count);
+    r.prefix_ws = l.kind == L_TABLE_AFFINE ? nullptr : (int32_t*)ws_alloc(sizeof(int32_t) * 9 * (size_t)r.n_jobs * (size_t)count);
     rows.push_back(r);
   }
   l.nrows = (uint32_t)rows.size();
@@ -565,10 +567,12 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     // field operations, following k_msm's schedule statement by statement
     uint64_t M = 0, S = 0;
     if (nv) {
-      M += nv * (1 + (stored - 1) * 9);                       // tables: 2dT of P, then (add 4M + to p3 4M + 2dT 1M) per entry
+      // tables: 2dT of P, then (add 4M + to p3 4M + 2dT 1M) per entry; a narrow job's entries leave as X, Y, Z (k_table_affine's
+      // share is counted where that launch is emitted)
+      M += nv * (1 + (stored - 1) * (j.narrow ? 8 : 9));
       for (int w = (int)wins - 1; w >= 0; w--) {
         if (w != (int)wins - 1) { S += 4 * wbits; M += 3 * (wbits - 1) + 4; }   // the window's doublings to p2, its last to p3
-        M += nv * 4;                                          // additions of window-table entries
+        M += nv * (j.narrow ? 3 : 4);                         // additions of window-table entries (affine ones in a narrow job)
         M += nv * 4 - (w != 0 ? 1 : 0);                       // back to p3; the window's last one skips T
       }
     }
@@ -641,7 +645,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
           table_rows[odd ? 1 : (j.narrow ? 2 : 0)].push_back(tj);
         } else {
           stats.table_additions -= odd ? 7 : (nstored - 1);   // counted per term above; this one is shared
-          stats.field_mul -= odd ? (4 + 1 + 1 + 7 * 9) : (1 + (nstored - 1) * 9);
+          stats.field_mul -= odd ? (4 + 1 + 1 + 7 * 9) : (1 + (nstored - 1) * (j.narrow ? 8 : 9));
           stats.field_sq -= odd ? 4 : 0;
         }
         j.term[t].table_slot = hit->second;
@@ -673,6 +677,22 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
       tl.jobs_off = blob_alloc(sizeof(afx_table_job) * tr.size(), 16);
       memcpy(blob_.data() + tl.jobs_off, tr.data(), sizeof(afx_table_job) * tr.size());
       launches.push_back(tl);
+      if (odd == 2) {
+        // the tables of narrow jobs become affine entries: one inversion per item and grid row over all of the launch's tables
+        // (kernels.hip k_table_affine); a small pass, which waits for the serial walk, spreads them over up to 8 rows
+        Launch al;
+        al.kind = L_TABLE_AFFINE;
+        al.njobs = tl.njobs;
+        al.jobs_off = blob_alloc(sizeof(afx_table_job) * tr.size(), 16);
+        memcpy(blob_.data() + al.jobs_off, tr.data(), sizeof(afx_table_job) * tr.size());
+        const uint32_t groups = small() ? 8u : 1u;
+        add_walk_rows(al, groups > 1 ? (al.njobs + groups - 1) / groups : 0);
+        launches.push_back(al);
+        // per entry: the prefix product, 1/Z and the running inverse, x and y, the niels form (4); per row the inversion
+        stats.field_mul += (uint64_t)tr.size() * AFX_SECVAR_STORED * 9 + (uint64_t)al.nrows * 11;
+        stats.field_sq += (uint64_t)al.nrows * 254;
+        stats.chain_mul += (uint64_t)al.nrows * AFX_CHAIN_INVERT_MUL; stats.chain_sq += (uint64_t)al.nrows * AFX_CHAIN_INVERT_SQ;
+      }
     }
     // a launch none of whose jobs encodes inside the kernel (every windowed launch of Issuer::verify: results that are only
     // encoded go through k_compress2x) runs the kernel compiled without the encoder (kernels.hip, k_msm<KIND, ENC>).  Splitting
@@ -789,6 +809,7 @@ size_t job_size(LaunchKind k) {
     case L_COMPRESS: return sizeof(afx_compress_job);
     case L_POINTSUM: return sizeof(afx_pointsum_job);
     case L_NEGENC: return sizeof(afx_negenc_job);
+    case L_TABLE_AFFINE: return sizeof(afx_table_job);
     default: return 0;
   }
 }
@@ -831,7 +852,7 @@ void Plan::relocate(uint8_t* nblob, uint8_t* nws, uint8_t* nin, uint8_t* nout) {
           m.fix(j.naf_sched); m.fix(j.addend); m.fix(j.out_enc); m.fix(j.out_var); m.fix(j.half_var);
         }
         break;
-      case L_MSM_TABLES: for (uint32_t i = 0; i < l.njobs; i++) m.fix(((afx_table_job*)J)[i].var); break;
+      case L_MSM_TABLES: case L_TABLE_AFFINE: for (uint32_t i = 0; i < l.njobs; i++) m.fix(((afx_table_job*)J)[i].var); break;
       case L_COMPRESS: for (uint32_t i = 0; i < l.njobs; i++) { afx_compress_job& j = ((afx_compress_job*)J)[i]; m.fix(j.var); m.fix(j.out_enc); } break;
       case L_NEGENC: for (uint32_t i = 0; i < l.njobs; i++) { afx_negenc_job& j = ((afx_negenc_job*)J)[i]; m.fix(j.enc); m.fix(j.var); m.fix(j.out_enc); } break;
       case L_POINTSUM:
@@ -979,7 +1000,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
     blob_total = (blob_total + 255) & ~size_t(255);
     for (Merged& mg : sched) {
       if (mg.kind == L_COPY) continue;
-      const bool walk = mg.kind == L_COMPRESS || mg.kind == L_NEGENC;
+      const bool walk = walks(mg.kind);
       uint32_t rows = 0;
       for (const Part& p : mg.parts) { const Launch& l = plans[p.plan]->launches[p.launch]; rows += walk ? l.nrows : l.njobs; }
       mg.nrows = rows;
@@ -1005,7 +1026,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
   if (n > 1) {
     for (const Merged& mg : sched) {
       if (mg.kind == L_COPY) continue;
-      const bool walk = mg.kind == L_COMPRESS || mg.kind == L_NEGENC;
+      const bool walk = walks(mg.kind);
       size_t w = mg.rows_off;
       for (const Part& p : mg.parts) {
         const Plan& pl = *plans[p.plan];
@@ -1056,6 +1077,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
       case L_SCALAROP: AFX_HIP(afxk_scalarop(s, (const afx_scalarop_job*)jobs, nrows, rw, passes, max_count)); break;
       case L_COMPRESS: AFX_HIP(afxk_compress2x(s, (const afx_compress_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
       case L_NEGENC: AFX_HIP(afxk_negenc(s, (const afx_negenc_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
+      case L_TABLE_AFFINE: AFX_HIP(afxk_table_affine(s, (const afx_table_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
       case L_POINTSUM: AFX_HIP(afxk_pointsum(s, (const afx_pointsum_job*)jobs, nrows, rw, passes, max_count)); break;
       case L_MSM_TABLES: AFX_HIP(afxk_msm_tables(s, odd, (const afx_table_job*)jobs, nrows, rw, passes, max_count)); break;
       case L_MSM_FIXED: case L_MSM_WINDOW: case L_MSM_NAF: {
@@ -1090,7 +1112,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
     const Plan& pl = *plans[0];
     const afx_pass* passes = (const afx_pass*)(bdev + boff[0] + pl.pass_off);
     for (const Launch& l : pl.launches) {
-      const bool walk = l.kind == L_COMPRESS || l.kind == L_NEGENC;
+      const bool walk = walks(l.kind);
       const bool coop = l.kind == L_HASH && pl.small && (uint64_t)pl.count * l.njobs <= AFX_HASH_COOP_GROUPS;
       if ((rc = launch(l.kind, l.odd, l.encodes, l.secret, bdev + boff[0] + l.jobs_off, walk ? l.nrows : l.njobs, walk ? (const void*)(bdev + boff[0] + l.rows_off) : nullptr,
                        passes, (const afx_pass*)(pl.blob.data() + pl.pass_off), pl.count, coop, &l)))

@@ -150,13 +150,15 @@ namespace afx {
 
 // L_MSM_WINDOW keeps the slot the single k_msm kernel had (timing names: statements.cpp KIND_NAMES)
 enum LaunchKind { L_FILL_BAD, L_DECODE, L_SCCHECK, L_POINTOP, L_SCALAROP, L_MSM_WINDOW, L_HASH, L_FROM_UNIFORM, L_REDUCE_WIDE, L_COPY, L_FINISH,
-                  L_MSM_FIXED, L_MSM_NAF, L_MSM_TABLES, L_COMPRESS, L_POINTSUM, L_NEGENC, L_KINDS };
+                  L_MSM_FIXED, L_MSM_NAF, L_MSM_TABLES, L_COMPRESS, L_POINTSUM, L_NEGENC, L_TABLE_AFFINE, L_KINDS };
+// the kernels whose grid rows WALK a range of the launch's jobs (afx_walk_row) instead of taking one job each (afx_row)
+inline bool walks(LaunchKind k) { return k == L_COMPRESS || k == L_NEGENC || k == L_TABLE_AFFINE; }
 
 struct Launch {
   LaunchKind kind;
   size_t jobs_off = 0;      // offset of the job array in the plan's blob
   uint32_t njobs = 0;
-  size_t rows_off = 0;      // L_COMPRESS, L_NEGENC: the afx_walk_row array (grid rows; each walks a range of the jobs)
+  size_t rows_off = 0;      // L_COMPRESS, L_NEGENC, L_TABLE_AFFINE (walks()): the afx_walk_row array (grid rows; each walks a range of the jobs)
   uint32_t nrows = 0;
   // L_COPY: direct arguments (device-to-device)
   const uint8_t* in = nullptr;
@@ -270,7 +272,7 @@ class Assembler {
   void compress(const std::vector<afx_compress_job>& cjobs, uint32_t groups);
   template <class T>
   void add_jobs(LaunchKind k, const std::vector<T>& jobs);
-  void add_walk_rows(Launch& l, uint32_t per_row);   // the afx_walk_row array of a k_compress2x / k_negenc launch (+ its prefix scratch)
+  void add_walk_rows(Launch& l, uint32_t per_row);   // the afx_walk_row array of a k_compress2x / k_negenc / k_table_affine launch (+ its prefix scratch)
   std::set<const int32_t*> half_bases_;            // variables that hold HALF their point (producers with leave_half)
   std::vector<afx_compress_job> pending_cjobs_;    // compress_also()
   std::vector<const int32_t*> pending_half_vars_;  // ... and the variables they read: checked to hold halves when the queue is consumed

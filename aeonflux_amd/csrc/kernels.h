@@ -22,6 +22,8 @@ hipError_t afxk_msm_tables(hipStream_t s, int kind, const afx_table_job* jobs, u
 hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t njobs, const int32_t* pos_tables, const int32_t* sec_tables,
                     const afx_row* rows, const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* clock_probe);
 // out_enc = encoding of twice each job's point; every row (plan.h afx_walk_row) shares one field inversion per item
+// the tables of narrow jobs (secret scalars on per-item bases), second step: X, Y, Z -> affine entries, one inversion per item and row
+hipError_t afxk_table_affine(hipStream_t s, const afx_table_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count);
 hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count);
 // out_enc = encoding of the negation of each job's decoded point
 hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count);

@@ -88,6 +88,24 @@ AFX_DEV void cached_store(int32_t* p, size_t chunk, const ge_cached& q) {
 #pragma unroll
   for (int i = 0; i < 8; i++) *reinterpret_cast<uint4*>(p + i * chunk) = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
+// one field element as a canonical 32-byte word in pieces `first`, `first` + 1 of an entry
+AFX_DEV void fe_store_pieces(int32_t* p, size_t chunk, int first, const fe& f) {
+  uint32_t w[8];
+  fe_tobytes(w, f);
+  *reinterpret_cast<uint4*>(p + first * chunk) = make_uint4(w[0], w[1], w[2], w[3]);
+  *reinterpret_cast<uint4*>(p + (first + 1) * chunk) = make_uint4(w[4], w[5], w[6], w[7]);
+}
+AFX_DEV fe fe_load_pieces(const int32_t* p, size_t chunk, int first) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p + first * chunk), b = *reinterpret_cast<const uint4*>(p + (first + 1) * chunk);
+  const uint32_t w[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+  return fe_frombytes(w);
+}
+// an entry of a narrow job's table before k_table_affine: X, Y, Z in pieces 0..5 (6, 7: that kernel's prefix product)
+AFX_DEV void xyz_store(int32_t* p, size_t chunk, const ge_p3& q) {
+  fe_store_pieces(p, chunk, 0, q.X);
+  fe_store_pieces(p, chunk, 2, q.Y);
+  fe_store_pieces(p, chunk, 4, q.Z);
+}
 AFX_DEV void cached_load_words(uint32_t w[32], const int32_t* p, size_t chunk) {
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -328,12 +346,22 @@ AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w,
   return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent, 4), neg), next);
 }
 // A job with a secret scalar on a variable base (afx_msm_job.narrow, SEC instances): AFX_SECVAR_BITS-bit signed digits (msm_recode)
-// over tables of AFX_SECVAR_STORED multiples at the head of the slot.  Every addition of such a job reads ALL the stored entries
-// of its table, in order (narrow_fetch: no address depends on a digit), and keeps the digit's with selects, the identity for
-// digit 0 (narrow_add) - what dalek's constant-time LookupTable::select does on the CPU (/root/reference/src/amacs.rs:267-270
-// multiplies by the key with it).  The chain is software-pipelined: the words of the NEXT addition's table are requested before
-// the current addition computes (msm_chain_narrow), so the reads overlap the arithmetic instead of preceding it.
-AFX_DEV void narrow_fetch(uint32_t (&buf)[AFX_SECVAR_STORED * 32], uint64_t& digits, const msm_env& e, uint32_t t, int w) {
+// over tables of AFX_SECVAR_STORED multiples at the head of the slot, each an AFFINE entry in the halved niels form of the
+// positional tables - (y+x)/2, (y-x)/2, dxy as three canonical 32-byte words, 96 bytes (k_msm_tables<TABLE_NARROW> leaves X, Y, Z
+// there and k_table_affine divides, one inversion per item for all of its tables) - so that an addition is ge_madd's 7 products
+// instead of 8 and reads three quarters of the bytes.  Every addition of such a job reads ALL the stored entries of its table, in
+// order (narrow_fetch: no address depends on a digit), and keeps the digit's with selects, the identity for digit 0
+// (narrow_select) - what dalek's constant-time LookupTable::select does on the CPU (/root/reference/src/amacs.rs:267-270
+// multiplies by the key with it).  The chain is software-pipelined: once an addition's entries have been reduced to the selected
+// one, the words of the NEXT addition's table are requested, before this addition computes (msm_chain_narrow), so the reads
+// overlap the arithmetic instead of preceding it.
+#define AFX_NARROW_ENTRY_WORDS 24   // of the entry's 32 dwords (AFX_TABLE_ENTRY_DWORDS: the slot layout is the cached tables')
+// the identity in that form: (1/2, 1/2, 0), 1/2 = (p + 1)/2 = 2^254 - 9
+__device__ __attribute__((aligned(16))) const uint32_t AFX_IDENTITY_NIELS[AFX_NARROW_ENTRY_WORDS] = {
+  0xfffffff7u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu,
+  0xfffffff7u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu,
+  0, 0, 0, 0, 0, 0, 0, 0 };
+AFX_DEV void narrow_fetch(uint32_t (&buf)[AFX_SECVAR_STORED * AFX_NARROW_ENTRY_WORDS], uint64_t& digits, const msm_env& e, uint32_t t, int w) {
   // the digit's word(s) first: the loads come back in order, and the addition that consumes this fetch starts from the digit
   const uint32_t o = AFX_SECVAR_BITS * (uint32_t)w, k = o >> 5, sh = o & 31u;
   const uint32_t* dw = e.digit_ws + ((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + k) * e.count + e.item;
@@ -342,29 +370,37 @@ AFX_DEV void narrow_fetch(uint32_t (&buf)[AFX_SECVAR_STORED * 32], uint64_t& dig
   // [entry][piece][item]: the 64 lanes of a wave read 1 KB contiguous per load
   const int32_t* table = e.table_ws + (size_t)e.term[t].table_slot * e.count * AFX_VAR_TABLE_DWORDS + (size_t)e.item * 4;
 #pragma unroll
-  for (uint32_t m = 0; m < AFX_SECVAR_STORED; m++) cached_load_words(buf + 32 * m, table + (size_t)m * e.count * AFX_TABLE_ENTRY_DWORDS, (size_t)e.count * 4);
+  for (uint32_t m = 0; m < AFX_SECVAR_STORED; m++) {
+    const int32_t* p = table + (size_t)m * e.count * AFX_TABLE_ENTRY_DWORDS;
+#pragma unroll
+    for (int i = 0; i < AFX_NARROW_ENTRY_WORDS / 4; i++) {
+      const uint4 q = *reinterpret_cast<const uint4*>(p + i * (size_t)e.count * 4);
+      buf[AFX_NARROW_ENTRY_WORDS * m + 4 * i] = q.x; buf[AFX_NARROW_ENTRY_WORDS * m + 4 * i + 1] = q.y;
+      buf[AFX_NARROW_ENTRY_WORDS * m + 4 * i + 2] = q.z; buf[AFX_NARROW_ENTRY_WORDS * m + 4 * i + 3] = q.w;
+    }
+  }
 }
-AFX_DEV ge_p3 narrow_add(const msm_env& e, const ge_p3& acc, uint32_t t, int w, const uint32_t (&buf)[AFX_SECVAR_STORED * 32], uint64_t digits, int next) {
+// the entry the digit of window w names among the fetched ones (the identity for digit 0), and whether it is subtracted
+AFX_DEV void narrow_select(ge_niels& q, bool& neg, const msm_env& e, uint32_t t, int w, const uint32_t (&buf)[AFX_SECVAR_STORED * AFX_NARROW_ENTRY_WORDS], uint64_t digits) {
   const uint32_t sh = (AFX_SECVAR_BITS * (uint32_t)w) & 31u;
   const int d = (int)((uint32_t)(digits >> sh) & ((1u << AFX_SECVAR_BITS) - 1)) - (1 << (AFX_SECVAR_BITS - 1));
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
-  const bool neg = (d < 0) != (e.term[t].negate != 0);
-  uint32_t sel[32];
+  neg = (d < 0) != (e.term[t].negate != 0);
+  uint32_t sel[AFX_NARROW_ENTRY_WORDS];
 #pragma unroll
-  for (int i = 0; i < 32; i++) sel[i] = (uint32_t)AFX_IDENTITY_ENTRY[i];
+  for (int i = 0; i < AFX_NARROW_ENTRY_WORDS; i++) sel[i] = AFX_IDENTITY_NIELS[i];
 #pragma unroll
   for (uint32_t m = 0; m < AFX_SECVAR_STORED; m++) {
     const bool hit = idx == m + 1;
 #pragma unroll
-    for (int i = 0; i < 32; i++) sel[i] = hit ? buf[32 * m + i] : sel[i];
+    for (int i = 0; i < AFX_NARROW_ENTRY_WORDS; i++) sel[i] = hit ? buf[AFX_NARROW_ENTRY_WORDS * m + i] : sel[i];
   }
-  return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_from_words(sel), neg), next);
+  q.ypx = fe_frombytes(sel); q.ymx = fe_frombytes(sel + 8); q.xyd = fe_frombytes(sel + 16);
 }
-static_assert(AFX_SECVAR_STORED * 32 <= 64, "msm_chain_narrow keeps the next addition's entries in registers: 2-bit windows");
 AFX_DEV ge_p3 msm_chain_narrow(const msm_env& e, ge_p3 acc, uint32_t nv) {
-  uint32_t nxt[AFX_SECVAR_STORED * 32];
-  uint64_t nxt_digits;
-  narrow_fetch(nxt, nxt_digits, e, 0, AFX_SECVAR_WINDOWS - 1);
+  uint32_t buf[AFX_SECVAR_STORED * AFX_NARROW_ENTRY_WORDS];
+  uint64_t digits;
+  narrow_fetch(buf, digits, e, 0, AFX_SECVAR_WINDOWS - 1);
 #pragma unroll 1
   for (int w = AFX_SECVAR_WINDOWS - 1; w >= 0; w--) {
     if (w != AFX_SECVAR_WINDOWS - 1) {
@@ -375,13 +411,12 @@ AFX_DEV ge_p3 msm_chain_narrow(const msm_env& e, ge_p3 acc, uint32_t nv) {
     }
 #pragma unroll 1
     for (uint32_t t = 0; t < nv; t++) {
-      uint32_t cur[AFX_SECVAR_STORED * 32];
-#pragma unroll
-      for (uint32_t i = 0; i < AFX_SECVAR_STORED * 32; i++) cur[i] = nxt[i];
-      const uint64_t cur_digits = nxt_digits;
+      ge_niels q;
+      bool neg;
+      narrow_select(q, neg, e, t, w, buf, digits);
       const bool last = t + 1 == nv;
-      if (!(last && w == 0)) narrow_fetch(nxt, nxt_digits, e, last ? 0 : t + 1, last ? w - 1 : w);
-      acc = narrow_add(e, acc, t, w, cur, cur_digits, !last ? GE_FOR_ADD : (w == 0 ? GE_FOR_ANY : GE_FOR_DBL));
+      if (!(last && w == 0)) narrow_fetch(buf, digits, e, last ? 0 : t + 1, last ? w - 1 : w);
+      acc = ge_p1p1_to_p3_next(ge_madd(acc, q, neg), !last ? GE_FOR_ADD : (w == 0 ? GE_FOR_ANY : GE_FOR_DBL));
     }
   }
   return acc;
@@ -497,11 +532,12 @@ AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t ch
     }
   } else {
     const ge_cached cP = ge_p3_to_cached(P);   // P centred: Y+X, Y-X, 2Z within 1 unit, what ge_add_cached expects
-    cached_store(tab, chunk, cP);   // k*P at entry k - 1; the identity (digit 0) is not stored
+    // k*P at entry k - 1; the identity (digit 0) is not stored.  A narrow job's entries: X, Y, Z for k_table_affine to divide
+    if (TK == TABLE_NARROW) xyz_store(tab, chunk, P); else cached_store(tab, chunk, cP);
 #pragma unroll 1
     for (int k = 2; k <= (TK == TABLE_NARROW ? AFX_SECVAR_STORED : AFX_TABLE_STORED); k++) {
       Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
-      cached_store(tab + (k - 1) * stride, chunk, ge_p3_to_cached(Q));
+      if (TK == TABLE_NARROW) xyz_store(tab + (k - 1) * stride, chunk, Q); else cached_store(tab + (k - 1) * stride, chunk, ge_p3_to_cached(Q));
     }
   }
 }
@@ -571,6 +607,43 @@ k_msm_tables(const afx_table_job* __restrict__ jobs, const afx_row* __restrict__
   // NAF tables and the tables of narrow jobs: [entry][piece][item][16 B]; window tables: [item][entry][128 B]
   if (TK == TABLE_WINDOW) msm_build_table<TK>(slot + (size_t)item * AFX_VAR_TABLE_DWORDS, AFX_TABLE_ENTRY_DWORDS, 4, P);
   else msm_build_table<TK>(slot + (size_t)item * 4, (size_t)count * AFX_TABLE_ENTRY_DWORDS, (size_t)count * 4, P);
+}
+
+// The tables of narrow jobs, second step: every entry (X : Y : Z) that k_msm_tables<TABLE_NARROW> left becomes the affine entry
+// ((y+x)/2, (y-x)/2, dxy) the narrow chain adds with 7 products.  Lane = item walks the entries of its row's tables twice, like
+// k_compress2x: prefix products of the Z forwards (kept in the entry's last two pieces), ONE inversion, the quotients backwards.
+// Z is never 0 on the curve.  Rows: one per launch for large passes (one inversion per item); small passes, where the serial walk
+// is what a call waits for, spread the tables over up to 8 rows (engine.cpp msm_list).
+__global__ void __launch_bounds__(AFX_BLOCK, 2)
+k_table_affine(const afx_table_job* __restrict__ jobs, const afx_walk_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_walk_row row = rows[blockIdx.y];   // wave-uniform
+  const afx_pass pass = passes[row.pass];
+  const uint32_t count = pass.count;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= count) return;
+  jobs = reinterpret_cast<decltype(jobs)>(reinterpret_cast<const uint8_t*>(jobs) + row.job_off);
+  const uint32_t n = row.n_jobs * AFX_SECVAR_STORED;
+  const size_t chunk = (size_t)count * 4;
+  int32_t* const mine = pass.table_ws + (size_t)item * 4;
+  fe prod = fe_one();
+#pragma unroll 1
+  for (uint32_t k = 0; k < n; k++) {
+    int32_t* e = mine + (size_t)jobs[k / AFX_SECVAR_STORED].table_slot * count * AFX_VAR_TABLE_DWORDS + (size_t)(k % AFX_SECVAR_STORED) * count * AFX_TABLE_ENTRY_DWORDS;
+    fe_store_pieces(e, chunk, 6, prod);   // product of the Z before this entry
+    prod = fe_mul(prod, fe_load_pieces(e, chunk, 4));
+  }
+  fe inv = fe_invert(prod);
+#pragma unroll 1
+  for (uint32_t kk = n; kk > 0; kk--) {
+    const uint32_t k = kk - 1;
+    int32_t* e = mine + (size_t)jobs[k / AFX_SECVAR_STORED].table_slot * count * AFX_VAR_TABLE_DWORDS + (size_t)(k % AFX_SECVAR_STORED) * count * AFX_TABLE_ENTRY_DWORDS;
+    const fe zinv = fe_mul(inv, fe_load_pieces(e, chunk, 6));
+    inv = fe_mul(inv, fe_load_pieces(e, chunk, 4));
+    const ge_niels q = ge_niels_from_affine(fe_mul(fe_load_pieces(e, chunk, 0), zinv), fe_mul(fe_load_pieces(e, chunk, 2), zinv));
+    fe_store_pieces(e, chunk, 0, q.ypx);
+    fe_store_pieces(e, chunk, 2, q.ymx);
+    fe_store_pieces(e, chunk, 4, q.xyd);
+  }
 }
 
 // ENC: the launch has jobs that encode their result in this kernel (those with an addend or an extended-coordinate output as
@@ -666,7 +739,12 @@ __device__ __forceinline__ void msm_body(const afx_msm_djob* __restrict__ job, c
     atomicAdd(&clock_probe[1], (unsigned long long)wall_clock64() - r0);
   }
 }
-#define AFX_MSM_OCCUPANCY(KIND, ENC, SEC) ((!(ENC) && (!(SEC) || (KIND) == MSM_FIXED)) ? 3 : 2)
+// blocks of 256 per CU the instances are compiled for: three (168 registers) without the encoder, two with it; the windowed SEC
+// instance (the narrow chain's entries in flight) AFX_SEC_WINDOW_OCCUPANCY
+#ifndef AFX_SEC_WINDOW_OCCUPANCY
+#define AFX_SEC_WINDOW_OCCUPANCY 2
+#endif
+#define AFX_MSM_OCCUPANCY(KIND, ENC, SEC) ((ENC) ? 2 : !(SEC) || (KIND) == MSM_FIXED ? 3 : (KIND) == MSM_WINDOW ? AFX_SEC_WINDOW_OCCUPANCY : 2)
 template <int KIND, bool ENC, bool SEC>
 __global__ void __launch_bounds__(AFX_BLOCK, AFX_MSM_OCCUPANCY(KIND, ENC, SEC))
 k_msm(const afx_msm_djob* __restrict__ jobs, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables, int32_t* __restrict__ table_ws,
@@ -1154,6 +1232,10 @@ hipError_t afxk_msm_tables(hipStream_t s, int kind, const afx_table_job* jobs, u
 }
 hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
   hipLaunchKernelGGL(k_compress2x, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
+  return hipGetLastError();
+}
+hipError_t afxk_table_affine(hipStream_t s, const afx_table_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
+  hipLaunchKernelGGL(k_table_affine, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {

@@ -90,11 +90,11 @@ def measured_traffic(workload, kernel, secret=False):
 
 
 MSM_KERNELS = ("k_msm_window", "k_msm_naf", "k_msm_fixed", "k_msm_tables")
-OTHER_KERNELS = ("k_compress2x", "k_negenc", "k_pointsum", "k_decode", "k_pointop", "k_hash", "k_scalarop", "k_sccheck", "k_from_uniform", "k_reduce_wide", "k_finish", "k_fill_u32")
+OTHER_KERNELS = ("k_table_affine", "k_compress2x", "k_negenc", "k_pointsum", "k_decode", "k_pointop", "k_hash", "k_scalarop", "k_sccheck", "k_from_uniform", "k_reduce_wide", "k_finish", "k_fill_u32")
 
 
 # the kernels doing field arithmetic beside the multiscalar ones (the time base of the "valu" figure)
-FIELD_KERNELS = ("k_compress2x", "k_negenc", "k_pointsum", "k_decode", "k_pointop", "k_from_uniform")
+FIELD_KERNELS = ("k_table_affine", "k_compress2x", "k_negenc", "k_pointsum", "k_decode", "k_pointop", "k_from_uniform")
 
 
 def kernel_times(ctx, steps):

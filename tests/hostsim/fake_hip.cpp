@@ -143,6 +143,23 @@ static hipError_t walk_rows(const uint8_t* jobs, size_t job_size, const afx_walk
   }
   return hipSuccess;
 }
+// the tables of narrow jobs made affine: every table of the row lies inside the pass's table workspace (its first and last dword are
+// touched: the sanitizers see a slot past the allocation); the prefix products live inside the entries, so no scratch of its own
+hipError_t afxk_table_affine(hipStream_t, const afx_table_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
+  for (uint32_t r = 0; r < nrows; r++) {
+    const afx_pass& P = passes[rows[r].pass];
+    hipError_t e = check_pass(P, max_count); if (e) return e;
+    if (rows[r].n_jobs == 0 || rows[r].prefix_ws != nullptr) return hipErrorInvalidValue;
+    for (uint32_t i = 0; i < rows[r].n_jobs; i++) {
+      const afx_table_job& t = *(const afx_table_job*)((const uint8_t*)jobs + rows[r].job_off + (size_t)i * sizeof(afx_table_job));
+      CHECK_PTR(t.var);
+      int32_t* slot = P.table_ws + (size_t)t.table_slot * P.count * AFX_VAR_TABLE_DWORDS;
+      slot[0] += 1;
+      slot[(size_t)AFX_SECVAR_STORED * P.count * AFX_TABLE_ENTRY_DWORDS - 1] += 1;
+    }
+  }
+  return hipSuccess;
+}
 hipError_t afxk_negenc(hipStream_t, const afx_negenc_job* j, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
   return walk_rows((const uint8_t*)j, sizeof(afx_negenc_job), rows, nrows, passes, max_count, 1);
 }

@@ -79,7 +79,7 @@ def main():
     issuer.set_timing(True)
     for _ in range(10):
         mixed()
-    names = ("k_msm_window", "k_msm_tables", "k_msm_fixed", "k_msm_naf", "k_pointsum", "k_compress2x", "k_negenc", "k_decode", "k_pointop", "k_hash", "k_scalarop", "k_sccheck",
+    names = ("k_msm_window", "k_msm_tables", "k_table_affine", "k_msm_fixed", "k_msm_naf", "k_pointsum", "k_compress2x", "k_negenc", "k_decode", "k_pointop", "k_hash", "k_scalarop", "k_sccheck",
              "k_finish", "k_fill_u32")
     parts = {}
     for k in names:
