@@ -168,11 +168,14 @@ int afx_ctx_set_fixed_key_schedule(afx_ctx* ctx, int enable);
  *     y_i * m_i of the key with revealed scalar attributes, whose digits would give the key away just the same.
  *   AFX_SECRETS_NOWHERE (0): the fastest tables everywhere (rounds 1-3 of this engine; a device of the engine's own, or inputs
  *     that are no secrets: synthetic benchmark data).
- * Where the mode applies, a job with a secret term on a per-item base runs 2-bit signed windows: every addition reads both stored
- * entries of its lane's table and keeps the digit's with selects (128 additions per term instead of 64); a secret term on a
- * generator uses 4-bit positional tables (63 KB per generator, part of every context) whose 9 entries per window are all read: 64
- * additions per term instead of 20.  Results are byte-identical in every mode.  Cost against mode 0, measured on one MI355X
- * (DESIGN.md section 4): issue -51 %, show -39 %; verification unchanged in mode 2, -11 % in mode 1. */
+ * Where the mode applies no load's address is made from a digit of a secret.  A secret term on a per-item base runs 2-bit signed
+ * windows: every addition reads both stored (affine) entries of its lane's table and keeps the digit's with selects - 128 additions
+ * per term instead of 64.  A secret term on a generator runs 6-bit signed windows over positional tables (155 KB per generator,
+ * part of every context): each lane of the wave loads one of the window's 32 multiples, the one its lane id names, and every lane
+ * takes the multiple its digit names from the lane that holds it (ds_bpermute_b32: a register exchange, no memory access, source
+ * lanes chosen so that no pattern of digits conflicts in the crossbar) - 43 additions per term instead of 20.  Results are
+ * byte-identical in every mode.  Cost against mode 0, measured on one MI355X: issue -35 %, show -24 %;
+ * verification unchanged in mode 2, -7 % in mode 1. */
 #define AFX_SECRETS_NOWHERE 0
 #define AFX_SECRETS_EVERYWHERE 1
 #define AFX_SECRETS_PROVER_SIDE 2

@@ -58,6 +58,16 @@ sq() {      # name, bench flags...
 sq c3 --workload c3
 sq c5 --workload c5
 sq c5_fast_tables --workload c5 --secret-mode 0
+# the lane exchange of the secret generator lookups: LDS bank conflicts of the C5 issue bench (default mode), and the microbenchmark
+# of ds_bpermute_b32 against the pattern of lanes read, plain and under the counters (one launch per pattern, in pattern order)
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS -d $O/pmc_lds_c5 -o t -- python3 $R/bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_lds_c5.log 2>&1
+python3 $R/tools/rocpd_pmc.py $(db $O/pmc_lds_c5) k_msm > $O/${TAG}_c5_lds_pmc.txt 2>&1
+rm -rf $O/pmc_lds_c5
+if [ ! -x $R/variants/bperm_lookup ]; then mkdir -p $R/variants; hipcc -O3 -Wno-unused-value --offload-arch=gfx950 $R/tools/ubench/bperm_lookup.hip -o $R/variants/bperm_lookup > /dev/null 2>&1; fi
+$R/variants/bperm_lookup > $O/${TAG}_bperm_lookup.txt 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/pmc_bperm -o t -- $R/variants/bperm_lookup once > /dev/null 2>&1
+python3 $R/tools/rocpd_pmc.py $(db $O/pmc_bperm) --each k_lookup >> $O/${TAG}_bperm_lookup.txt 2>&1
+rm -rf $O/pmc_bperm
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/pmc_mix -o t -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mix.log 2>&1
 python3 $R/tools/rocpd_pmc.py $(db $O/pmc_mix) k_msm > $O/${TAG}_c3_instruction_mix.txt 2>&1
 rm -rf $O/pmc_*_FETCH_SIZE $O/pmc_*_WRITE_SIZE $O/pmc_mix   # databases are large; the summaries are kept
