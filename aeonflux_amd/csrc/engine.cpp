@@ -362,7 +362,21 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   // which holds the ONE job that multiplies by the issuer key (Z: a single grid row of ten NAF terms, 16-128 blocks on 256
   // compute units for 1.7 ms).  There that job alone is split into one NAF chain per term and summed, ahead of the others.
   const bool mid = !small && ctx->small_batch_items != 0 && count <= 4 * (uint64_t)ctx->small_batch_items;
-  if (small) msm_split(std::move(jobs), cjobs, true);
+  if (small) {
+    // One chain per term while the stage's chains find room on the device (4 waves for each of its SIMDs: measured, 2048 ... 6144
+    // tried - tools/experiments/r04_chain_room.sh); a wider stage - a few thousand items, or the stages of many merged passes - takes
+    // up to four variable-base terms per chain: fewer doublings in all, and the chains would have queued anyway (one call of 4096
+    // presentations 3.56 -> 3.15 ms, 8 shapes x 1024 in one request 3.9 -> 3.3 ms, 64 x 16 3.4 -> 3.25 ms).  (A stage of few jobs - Z of Issuer::verify - keeps one term per chain
+    // however many passes are merged: its duration is its longest chain's.)
+    const uint64_t row_waves = ctx->row_waves(count), room = 4ull * 4 * ctx->n_cu;
+    uint32_t per_chain = 1;
+    for (; per_chain < 4; per_chain++) {
+      uint64_t chains = 0;
+      for (const afx_msm_job& j : jobs) chains += (j.n_var + per_chain - 1) / per_chain + (j.n_terms - j.n_var + 5) / 6;
+      if (chains * row_waves <= room) break;
+    }
+    msm_split(std::move(jobs), cjobs, true, per_chain);
+  }
   else if (mid) {
     auto naf_term = [&](const afx_msm_term& t) { return t.scalar_stride == 0 && !ctx->fixed_key_schedule && !ctx->secure_plan(secret_scalars) && !t.dbl && host_scalar_of(ctx, t.scalar) != nullptr; };
     std::vector<afx_msm_job> first, rest;
@@ -398,11 +412,13 @@ void Assembler::compress_also(const int32_t* var, uint8_t* out_enc, bool negate,
   stats.encodings++; stats.field_mul += AFX_ENCODE_MUL; stats.field_sq += AFX_ENCODE_SQ; stats.chain_mul += AFX_CHAIN_SQRT_MUL; stats.chain_sq += AFX_CHAIN_SQRT_SQ;   // compress() rewrites this share
 }
 
-// One chain per term.  A job with more than one part - each variable-base term, and its fixed-base terms six at a time - becomes
-// that many single-part jobs writing partial sums, plus a k_pointsum row adding them (and the addend) up; a job that feeds
+// One chain per term (var_per_part = 1; up to four terms per chain when the pass's chains would queue on the device:
+// afx_ctx::terms_per_chain).  A job with more than one part - its variable-base terms var_per_part at a time, and its fixed-base
+// terms six at a time - becomes that many single-part jobs writing partial sums, plus a k_pointsum row adding them (and the addend) up; a job that feeds
 // another (chain_to) is summed before the consumer's chains start, so stages run level by level.  no_naf (small passes): no NAF
 // schedules - a lone key term costs 64 additions instead of ~43, but shares the windowed launch with every other chain of its stage.
-void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compress_job>& cjobs, bool no_naf) {
+void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compress_job>& cjobs, bool no_naf, uint32_t var_per_part) {
+  if (var_per_part == 0) var_per_part = 1;
   const size_t n = jobs.size();
   for (size_t i = 0; i < n; i++)
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
@@ -426,7 +442,7 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
       // (the second commitment of an issuance proof has n + 3 of them: one lane with 380 additions was the longest chain of a
       // small issue call)
       const uint32_t FIXED_PER_PART = 6;
-      const uint32_t parts = j.n_var + (j.n_terms - j.n_var + FIXED_PER_PART - 1) / FIXED_PER_PART;
+      const uint32_t parts = (j.n_var + var_per_part - 1) / var_per_part + (j.n_terms - j.n_var + FIXED_PER_PART - 1) / FIXED_PER_PART;
       if (parts <= 1) { subs.push_back(j); continue; }   // a single chain already (its addend, if any, is added by its own lane)
       const bool halved = j.out_enc && !j.addend && (!j.out_var || j.leave_half);   // only ever encoded, or leaving its half: halved scalars, k_compress2x (msm_list)
       std::vector<const int32_t*> part_vars;
@@ -440,7 +456,7 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
         part_vars.push_back(v);
         subs.push_back(s);
       };
-      for (uint32_t t = 0; t < j.n_var; t++) sub_of(t, 1, 1);
+      for (uint32_t t = 0; t < j.n_var; t += var_per_part) { const uint32_t k = std::min(var_per_part, j.n_var - t); sub_of(t, k, k); }
       for (uint32_t first = j.n_var; first < j.n_terms; first += FIXED_PER_PART) sub_of(first, std::min(FIXED_PER_PART, j.n_terms - first), 0);
       afx_pointsum_job sj;
       memset(&sj, 0, sizeof sj);

@@ -118,6 +118,13 @@ struct afx_ctx {
   bool secure_plan(bool prover_plan) const { return prover_plan ? secret_mode != 0 : secret_mode == 1; }
   uint32_t chunk_items = 0;   // afx_ctx_set_chunk_items; 0 = default
   uint32_t small_batch_items = 4096;   // afx_ctx_set_small_batch_items: passes of at most this many items take the latency plan
+  // While a session collects the groups of a mixed request (mixed.cpp run_groups): how many 64-lane waves ONE grid row of the merged
+  // launches will be (every collected group's items / 64, summed), as a class: 0 no session, k > 0 up to 12 << k waves.  The
+  // latency plan cuts a stage's jobs into fewer, longer chains when one chain per term would queue on the device (Assembler::msm)
+  uint32_t merge_class = 0;
+  static uint32_t merge_class_of(uint64_t waves) { uint32_t k = 1; while (k < 7 && waves > (12ull << k)) k++; return k; }
+  // waves per grid row of a pass of `count` items, alone or among the passes merged with it
+  uint32_t row_waves(uint32_t count) const { return merge_class ? (9u << merge_class) : (count + 63) / 64; }   // (the class's middle)
   afx_plan_stats last_stats = {};   // per-item operation counts of the most recent plan
   std::map<std::string, std::array<uint64_t, 25>> folded_states;   // STROBE state after a transcript's all-constant leading blocks, by those blocks' bytes
                                                                    // (SchnorrBuilder::make_program); may derive from the key: wiped on destroy
@@ -268,7 +275,7 @@ class Assembler {
  private:
   uint8_t* ws_alloc(size_t bytes);
   void msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector<afx_compress_job>& cjobs);
-  void msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compress_job>& cjobs, bool no_naf);
+  void msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compress_job>& cjobs, bool no_naf, uint32_t var_per_part = 1);
   void compress(const std::vector<afx_compress_job>& cjobs, uint32_t groups);
   template <class T>
   void add_jobs(LaunchKind k, const std::vector<T>& jobs);

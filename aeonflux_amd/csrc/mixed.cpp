@@ -54,7 +54,14 @@ int run_groups(afx_ctx* ctx, G* groups, size_t n_groups, uint8_t* status, size_t
     lock = std::unique_lock<std::recursive_mutex>(ctx->mu);   // the session owns the context until its last flush
     ses.reset(new afx::Session(ctx));
     if ((rc = ses->ensure_images(0, 0))) return rc;
+    // how wide the merged launches will be, in 64-lane waves per grid row: the latency plans of the collected groups cut a stage's
+    // jobs into fewer, longer chains when one chain per term would queue on the device (Assembler::msm, afx_ctx::merge_class)
+    uint64_t width = 0;
+    for (size_t g = 0; g < n_groups; g++)
+      if (groups[g].count && groups[g].count <= ctx->small_batch_items) width += (groups[g].count + 63) / 64;
+    ctx->merge_class = afx_ctx::merge_class_of(width);
   }
+  struct WidthReset { afx_ctx* c; ~WidthReset() { if (c) c->merge_class = 0; } } width_reset = { ses ? ctx : nullptr };
   // statuses of groups with positions land in a buffer of the group's own first (the session fills it at its flush)
   std::vector<std::vector<uint8_t>> tmp(n_groups);
   size_t next = 0;
@@ -275,7 +282,14 @@ static int mixed_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* st
     lock = std::unique_lock<std::recursive_mutex>(ctx->mu);
     ses.reset(new afx::Session(ctx));
     if ((rc = ses->ensure_images(0, 0))) return rc;
+    uint64_t width = 0;   // as in run_groups
+    for (size_t gi = 0; gi < order.size(); gi++) {
+      const size_t cnt = by_shape[order[gi]].count;
+      if (cnt && cnt <= ctx->small_batch_items) width += (cnt + 63) / 64;
+    }
+    ctx->merge_class = afx_ctx::merge_class_of(width);
   }
+  struct WidthReset { afx_ctx* c; ~WidthReset() { if (c) c->merge_class = 0; } } width_reset = { ses ? ctx : nullptr };
   std::vector<uint8_t> merged;
   std::vector<std::vector<uint8_t>> sts(order.size());   // statuses of the groups whose sections are not adjacent: scattered after the flush
   for (size_t gi = 0; gi < order.size() && !rc; gi++) {

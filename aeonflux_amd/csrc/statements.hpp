@@ -57,7 +57,9 @@ inline afx_shape canonical_shape(const afx_shape& sh) {
 // mode flags that change a plan, for plan_key (every statement passes them all: a flag that does not matter to a statement only
 // costs it a second cache entry)
 inline uint64_t mode_flags(const afx_ctx* c) {
-  return (c->strict ? 1u : 0u) | (c->fixed_key_schedule ? 2u : 0u) | ((uint64_t)(c->secret_mode & 3) << 3) | ((uint64_t)c->small_batch_items << 8);
+  // (bits 5-7: the chain width a collecting session asks of the latency plan; outside a session it follows from the count, which is in the key)
+  return (c->strict ? 1u : 0u) | (c->fixed_key_schedule ? 2u : 0u) | ((uint64_t)(c->secret_mode & 3) << 3) | ((uint64_t)(c->merge_class & 7) << 5) |
+         ((uint64_t)c->small_batch_items << 8);
 }
 
 namespace afx {

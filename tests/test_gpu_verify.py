@@ -409,7 +409,7 @@ def test_mixed_shapes_through_the_c_entry_points():
 
 def test_the_three_plans_agree():
     """One batch of 9000 presentations (60 distinct ones tiled, a third corrupted) under the plan of large passes (one chain per
-    job), the latency plan (one chain per term, -c*Z over Z's terms) and the plan in between (only the job that multiplies by
+    job), the latency plan (one chain per term - at this size up to four terms per chain in the wide stage -, -c*Z over Z's terms) and the plan in between (only the job that multiplies by
     the issuer key split into NAF chains): the same statuses - the oracle's - and the same recomputed challenges."""
     import aeonflux_amd as afx
     from aeonflux_amd import batch
