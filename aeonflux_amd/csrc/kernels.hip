@@ -113,14 +113,6 @@ AFX_DEV void cached_load_words(uint32_t w[32], const int32_t* p, size_t chunk) {
     w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
   }
 }
-AFX_DEV ge_cached cached_from_words(const uint32_t w[32]) {
-  ge_cached q;
-  q.YpX = fe_frombytes(w);
-  q.YmX = fe_frombytes(w + 8);
-  q.Z2 = fe_frombytes(w + 16);
-  q.T2d = fe_frombytes(w + 24);
-  return q;
-}
 AFX_DEV ge_cached cached_load(const int32_t* p, size_t chunk) {
   uint32_t w[32];
   cached_load_words(w, p, chunk);

@@ -175,7 +175,7 @@ int afx_ctx_set_fixed_key_schedule(afx_ctx* ctx, int enable);
  * takes the multiple its digit names from the lane that holds it (ds_bpermute_b32: a register exchange, no memory access, source
  * lanes chosen so that no pattern of digits conflicts in the crossbar) - 43 additions per term instead of 20.  Results are
  * byte-identical in every mode.  Cost against mode 0, measured on one MI355X: issue -35 %, show -24 %;
- * verification unchanged in mode 2, -7 % in mode 1. */
+ * verification unchanged in mode 2, -8 % in mode 1. */
 #define AFX_SECRETS_NOWHERE 0
 #define AFX_SECRETS_EVERYWHERE 1
 #define AFX_SECRETS_PROVER_SIDE 2

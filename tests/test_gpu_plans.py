@@ -82,10 +82,10 @@ def test_kept_prover_plans_issue_the_oracles_bytes_call_after_call():
 
 
 def test_a_wide_request_takes_longer_chains_and_the_same_statuses(batches):
-    """70 groups of one presentation each (one shape repeated: the library keeps the caller's groups apart) in one
-    afx_verify_presentations_mixed request: the merged launches are 70 waves wide per grid row, so the constraint stage of every
-    group's latency plan takes more than one term per chain (engine.cpp Assembler::msm) while the Z stage keeps one; the statuses
-    are the oracle's, at the positions given (reversed), and equal to what one call per presentation says."""
+    """210 groups of one presentation each (one shape repeated: the library keeps the caller's groups apart) in one
+    afx_verify_presentations_mixed request: the merged launches are 210 waves wide per grid row, so the constraint stage of every
+    group's latency plan takes more than one term per chain (engine.cpp Assembler::msm); the statuses are the oracle's, at the
+    positions given (reversed), and one call alone goes back to one chain per term."""
     import ctypes as C
 
     import aeonflux_amd as afx
@@ -94,11 +94,12 @@ def test_a_wide_request_takes_longer_chains_and_the_same_statuses(batches):
     params, key, ip, issuer, a, b, want_a, want_b = batches
     ctx = afx.Context(params, key, ip)
     sh = afx.Shape.from_buffer_copy(bytes(shape_of(a[0])))
-    total = len(a)
+    reps = 3
+    total = reps * len(a)
     arr = (afx.PresentationGroup * total)()
     keep = []
-    for g, p in enumerate(a):
-        cols = presentation_arrays([p])
+    for g in range(total):
+        cols = presentation_arrays([a[g % len(a)]])
         soa, encs = batch.presentation_soa(cols)
         pos = np.array([total - 1 - g], np.uint64)
         arr[g].shape, arr[g].batch, arr[g].count = sh, soa, 1
@@ -106,7 +107,7 @@ def test_a_wide_request_takes_longer_chains_and_the_same_statuses(batches):
         keep.append((cols, soa, encs, pos))
     status = np.full(total, 255, np.uint8)
     afx.check(afx.lib().afx_verify_presentations_mixed(ctx.h, arr, total, status.ctypes.data, total))
-    assert status.tolist() == want_a[::-1]
+    assert status.tolist() == (want_a * reps)[::-1]
     wide_jobs = ctx.plan_stats()["msm_jobs"]
     assert gpu_verify(afx, ctx, a[:1]) == want_a[:1]
     assert ctx.plan_stats()["msm_jobs"] > wide_jobs, "one call alone: one chain per term"
