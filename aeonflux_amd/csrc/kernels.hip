@@ -754,6 +754,182 @@ k_msm_rows(const uint8_t* __restrict__ blob, const int32_t* __restrict__ pos_tab
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_msm_quad: the same jobs with FOUR waves per item chain, for passes that leave the device idle
+// ---------------------------------------------------------------------------------------------
+// What one small call waits for is its longest chain - 252 doublings and 64 additions in a row on a lane whose wave is alone on
+// its SIMD, where a wave issues at less than half the SIMD's rate.  Here a block is four waves = four ROLES over the same 64
+// items: every point operation is two rounds of four independent field products (a doubling: X^2, Y^2, Z^2, (Y-X)^2, then the
+// four products of the completed point; an addition: its four products with the table entry, then the same four), each role
+// computes one product per round on its own SIMD and the four results change hands through LDS (two buffers, one barrier per
+// round).  A round costs one product and the exchange instead of four products: the chain is ~3x shorter in time at 4x the
+// waves, which a small pass has to spare.  The arithmetic is the centred flavour throughout (fe_mul, fe_sq: every operand
+// within the bounds ge.cuh states for the completed point), the digits, table layouts and job fields are k_msm's, and so is the
+// result, bit for bit (a field element has one centred representation).  Role 0 recodes the scalars and finishes the job.
+// Taken by afxk_msm for windowed and fixed-base launches without secret terms or in-kernel encodings whose grid is small.
+struct quad_lds { int4 v[2][4][3][64]; };   // [buffer][slot][16-byte piece][lane]: 9 limbs + padding per element, 24 KB
+AFX_DEV void quad_put(quad_lds& L, int buf, uint32_t slot, uint32_t lane, const fe& f) {
+  L.v[buf][slot][0][lane] = make_int4(f.v[0], f.v[1], f.v[2], f.v[3]);
+  L.v[buf][slot][1][lane] = make_int4(f.v[4], f.v[5], f.v[6], f.v[7]);
+  L.v[buf][slot][2][lane] = make_int4(f.v[8], 0, 0, 0);
+}
+AFX_DEV fe quad_get(const quad_lds& L, int buf, uint32_t slot, uint32_t lane) {
+  const int4 a = L.v[buf][slot][0][lane], b = L.v[buf][slot][1][lane], c = L.v[buf][slot][2][lane];
+  fe f;
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w; f.v[8] = c.x;
+  return f;
+}
+// every role hands in one element; afterwards each reads the ones it needs.  The barrier waits for this wave's LDS traffic only
+// (s_waitcnt lgkmcnt(0); LDS is coherent inside the CU) - not for its outstanding global loads: the next table entry is already
+// on its way (msm_quad_body) and must stay in flight across the exchange.
+AFX_DEV void quad_post(quad_lds& L, int buf, uint32_t role, uint32_t lane, const fe& mine) {
+  quad_put(L, buf, role, lane, mine);
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
+}
+// completed point -> extended, a product per role: T*X, Y*Z, T*Z, Y*X (ge_p1p1_to_p3); the next round writes the other buffer -
+// whoever writes this one again has passed the next barrier, behind every reader.  (Every role reads all four back: reading only
+// the coordinates its part of the next operation takes - 1 or 2 of them - measured SLOWER, 0.42 against 0.38 ms per chain stage:
+// the branches cost more than the loads.)
+AFX_DEV ge_p3 quad_complete(quad_lds& L, int& buf, uint32_t role, uint32_t lane, const ge_p1p1& r) {
+  const fe m = fe_mul((role == 0 || role == 2) ? r.T : r.Y, (role == 0 || role == 3) ? r.X : r.Z);
+  quad_post(L, buf, role, lane, m);
+  ge_p3 o;
+  o.X = quad_get(L, buf, 0, lane); o.Y = quad_get(L, buf, 1, lane); o.Z = quad_get(L, buf, 2, lane); o.T = quad_get(L, buf, 3, lane);
+  buf ^= 1;
+  return o;
+}
+// 2 * p (ge_p2_dbl with centred squares: 2XY from (Y - X)^2)
+AFX_DEV ge_p3 quad_dbl(quad_lds& L, int& buf, uint32_t role, uint32_t lane, const ge_p3& p) {
+  const fe sq = fe_sq(role == 0 ? p.X : role == 1 ? p.Y : role == 2 ? p.Z : fe_sub(p.Y, p.X));
+  quad_post(L, buf, role, lane, sq);
+  const fe XX = quad_get(L, buf, 0, lane), YY = quad_get(L, buf, 1, lane), ZZ = quad_get(L, buf, 2, lane), AA = quad_get(L, buf, 3, lane);
+  buf ^= 1;
+  ge_p1p1 r;
+  r.Y = fe_add(YY, XX);
+  r.Z = fe_sub(YY, XX);
+  r.X = fe_sub(r.Y, AA);
+  r.T = fe_sub(fe_add(ZZ, ZZ), r.Z);
+  return quad_complete(L, buf, role, lane, r);
+}
+// p +- (an entry): `e0` is what this role multiplies by - role 0 the entry's Y+X (Y-X when subtracting), role 1 its Y-X (Y+X),
+// role 2 its 2dT, role 3 its 2Z (a cached entry) or nothing (NIELS: a halved affine entry, D = Z)
+template <bool NIELS>
+AFX_DEV ge_p3 quad_add(quad_lds& L, int& buf, uint32_t role, uint32_t lane, const ge_p3& p, const fe& e0, bool neg) {
+  fe m;
+  if (role == 0) m = fe_mul(fe_add(p.Y, p.X), e0);
+  else if (role == 1) m = fe_mul(fe_sub(p.Y, p.X), e0);
+  else if (role == 2) m = fe_mul(fe_cneg(e0, !neg), p.T);   // -C (the sign flipped again when subtracting): ge_add_cached
+  else m = NIELS ? p.Z : fe_mul(p.Z, e0);
+  quad_post(L, buf, role, lane, m);
+  const fe A = quad_get(L, buf, 0, lane), B = quad_get(L, buf, 1, lane), Cn = quad_get(L, buf, 2, lane), D = quad_get(L, buf, 3, lane);
+  buf ^= 1;
+  ge_p1p1 r;
+  r.X = fe_sub(A, B);
+  r.Y = fe_add(A, B);
+  r.Z = fe_sub(D, Cn);
+  r.T = fe_add(D, Cn);
+  return quad_complete(L, buf, role, lane, r);
+}
+// this role's 32 bytes of a window-table entry (cached form: Y+X | Y-X | 2Z | 2dT, canonical), as loaded words
+struct quad_words { uint4 a, b; };
+AFX_DEV quad_words quad_entry_load(const int32_t* ent, uint32_t role, bool neg) {
+  const uint32_t part = role == 0 ? (neg ? 1u : 0u) : role == 1 ? (neg ? 0u : 1u) : role == 2 ? 3u : 2u;
+  quad_words q;
+  q.a = *reinterpret_cast<const uint4*>(ent + 8 * part);
+  q.b = *reinterpret_cast<const uint4*>(ent + 8 * part + 4);
+  return q;
+}
+AFX_DEV fe quad_entry_fe(const quad_words& q) {
+  const uint32_t w[8] = { q.a.x, q.a.y, q.a.z, q.a.w, q.b.x, q.b.y, q.b.z, q.b.w };
+  return fe_frombytes(w);
+}
+template <bool ROWS>
+__device__ __forceinline__ void msm_quad_body(const afx_msm_djob* __restrict__ job, const int32_t* __restrict__ pos_tables, int32_t* __restrict__ table_ws,
+                                              uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count) {
+  __shared__ quad_lds L;
+  if (blockIdx.x * 64u >= count) return;   // block-uniform: the grid is sized for the launch's largest pass
+  const uint32_t lane = threadIdx.x & 63u, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t item = min(blockIdx.x * 64u + lane, count - 1);   // lanes past the end shadow the last item
+  const uint32_t nt = job->n_terms, nv = job->n_var;
+  msm_env e;
+  e.job = job; e.term = afx_job_terms(job); e.table_ws = table_ws; e.digit_ws = digit_ws;
+  e.count = count; e.item = item; e.dslot = job->digit_slot; e.tslot = 0; e.narrow = false;
+  if (role == 0) msm_recode(job, digit_ws, count, item, 0, nv, nt, false);
+  __syncthreads();   // the digits are in memory for the other roles (same CU: one vector cache)
+  int buf = 0;
+  ge_p3 acc = ge_identity();
+  // the entry of addition (w, t), requested ahead of its use: before the window's doublings for t = 0, an addition ahead otherwise
+  auto var_entry = [&](int w, uint32_t t, bool& neg) {
+    const int32_t* table = table_ws + ((size_t)e.term[t].table_slot * count + item) * AFX_VAR_TABLE_DWORDS;
+    const uint32_t word = digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + ((uint32_t)w >> 3)) * count + item];
+    const int d = (int)((word >> (((uint32_t)w & 7) * 4)) & 15u) - 8;
+    const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
+    neg = (d < 0) != (e.term[t].negate != 0);
+    return quad_entry_load(idx ? table + (idx - 1) * AFX_TABLE_ENTRY_DWORDS : AFX_IDENTITY_ENTRY, role, neg);
+  };
+  bool nneg = false;
+  quad_words nxt = {};
+  if (nv) nxt = var_entry(63, 0, nneg);
+#pragma unroll 1
+  for (int w = nv ? 63 : -1; w >= 0; w--) {
+    if (w != 63) {
+#pragma unroll 1
+      for (int k = 0; k < 4; k++) acc = quad_dbl(L, buf, role, lane, acc);
+    }
+#pragma unroll 1
+    for (uint32_t t = 0; t < nv; t++) {
+      const quad_words cur = nxt;
+      const bool neg = nneg;
+      const bool last = t + 1 == nv;
+      if (!(last && w == 0)) nxt = var_entry(last ? w - 1 : w, last ? 0 : t + 1, nneg);
+      acc = quad_add<false>(L, buf, role, lane, acc, quad_entry_fe(cur), neg);
+    }
+  }
+  // fixed bases: the same one-ahead request of the 9 limbs this role multiplies by ((y+x)/2 | (y-x)/2 | dxy; role 3 reads what
+  // role 2 does and drops it)
+  auto pos_entry = [&](uint32_t j, uint32_t t, bool& neg, fe& q) {
+    const uint32_t o = AFX_POS_BITS * j, k = o >> 5, sh = o & 31u;
+    const uint32_t* dw = digit_ws + ((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + k) * count + item;
+    uint64_t ww = dw[0];
+    if (sh + AFX_POS_BITS > 32) ww |= (uint64_t)dw[count] << 32;
+    const int d = (int)((uint32_t)(ww >> sh) & ((1u << AFX_POS_BITS) - 1)) - (1 << (AFX_POS_BITS - 1));
+    const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
+    neg = (d < 0) != (e.term[t].negate != 0);
+    const int32_t* ent = pos_tables + (size_t)e.term[t].fixed_idx * AFX_POS_TABLE_DWORDS + (size_t)j * AFX_POS_WINDOW_DWORDS + idx * AFX_NIELS_DWORDS;
+    const uint32_t part = role == 0 ? (neg ? 1u : 0u) : role == 1 ? (neg ? 0u : 1u) : 2u;
+#pragma unroll
+    for (int l = 0; l < AFX_FE_LIMBS; l++) q.v[l] = ent[9 * part + l];
+  };
+  if (nt != nv) {
+    fe qn;
+    pos_entry(0, nv, nneg, qn);
+#pragma unroll 1
+    for (uint32_t j = 0; j < AFX_POS_WINDOWS; j++) {
+#pragma unroll 1
+      for (uint32_t t = nv; t < nt; t++) {
+        const fe q = qn;
+        const bool neg = nneg;
+        const bool last = t + 1 == nt;
+        if (!(last && j + 1 == AFX_POS_WINDOWS)) pos_entry(last ? j + 1 : j, last ? nv : t + 1, nneg, qn);
+        acc = quad_add<true>(L, buf, role, lane, acc, q, neg);
+      }
+    }
+  }
+  if (role == 0) msm_finish<false>(job, acc, bad, count, item);
+}
+__global__ void __launch_bounds__(256, 2)
+k_msm_quad(const afx_msm_djob* __restrict__ jobs, const int32_t* __restrict__ pos_tables, int32_t* __restrict__ table_ws, uint32_t* __restrict__ digit_ws,
+           uint32_t* __restrict__ bad, uint32_t count) {
+  msm_quad_body<false>(&jobs[blockIdx.y], pos_tables, table_ws, digit_ws, bad, count);
+}
+__global__ void __launch_bounds__(256, 2)
+k_msm_quad_rows(const uint8_t* __restrict__ blob, const int32_t* __restrict__ pos_tables, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_row row = rows[blockIdx.y];      // block-uniform: scalar loads
+  const afx_pass pass = passes[row.pass];
+  msm_quad_body<true>(reinterpret_cast<const afx_msm_djob*>(blob + row.job_off), pos_tables, pass.table_ws, pass.digit_ws, pass.bad, pass.count);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_compress2x: the encodings of 2*P_j for all the points P_j an item's jobs left in half_var, with ONE field inversion per item
 // ---------------------------------------------------------------------------------------------
 // RistrettoPoint::compress needs an inverse square root per point (254 squarings).  The encoding of TWICE a point does not: with
@@ -1195,6 +1371,20 @@ static void launch_msm_rows(hipStream_t s, int encodes, int secret, dim3 grid, d
 hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t njobs, const int32_t* pos_tables,
                     const int32_t* sec_tables, const afx_row* rows, const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* clock_probe) {
   if (secret && !sec_tables) return hipErrorInvalidValue;
+  // a launch that leaves the device idle - windowed or fixed-base jobs without secret terms or in-kernel encodings, at most two
+  // blocks of four waves per compute unit in all - runs four waves per item chain (k_msm_quad).  AFX_QUAD_CHAINS=0 switches it off
+  // (measurement aid: the two kernels give the same bytes).
+  static const bool quad_on = !(getenv("AFX_QUAD_CHAINS") && getenv("AFX_QUAD_CHAINS")[0] == '0');
+  const uint32_t quad_blocks = (max_count + 63) / 64;
+  if (quad_on && !secret && !encodes && kind != MSM_NAF && max_count && (uint64_t)quad_blocks * njobs <= 512) {   // (1024: 512-item calls gain 7 %, 16-shape requests lose 14 %)
+    if (!rows) {
+      if (!pass_host) return hipErrorInvalidValue;
+      hipLaunchKernelGGL(k_msm_quad, dim3(quad_blocks, njobs), dim3(256), 0, s, jobs, pos_tables, pass_host->table_ws, pass_host->digit_ws, pass_host->bad, pass_host->count);
+    } else {
+      hipLaunchKernelGGL(k_msm_quad_rows, dim3(quad_blocks, njobs), dim3(256), 0, s, (const uint8_t*)jobs, pos_tables, rows, passes);
+    }
+    return hipGetLastError();
+  }
   const dim3 grid = grid_for(max_count, njobs), block(block_for(max_count));
   if (!rows) {
     if (!pass_host) return hipErrorInvalidValue;

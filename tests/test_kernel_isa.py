@@ -36,7 +36,7 @@ def code_object(tmp_path_factory):
         name = re.search(r"\.name:\s+(\S+)", blk)
         if name:
             kernels[name.group(1)] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
-                                      for k in ("vgpr_count", "sgpr_count", "private_segment_fixed_size")}
+                                      for k in ("vgpr_count", "sgpr_count", "private_segment_fixed_size", "group_segment_fixed_size")}
     dis = subprocess.run([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
     bodies = {}
     for f in re.split(r"\n(?=[0-9a-f]{16} <)", dis):
@@ -91,3 +91,22 @@ def test_secret_independent_lookups_address_nothing_by_a_digit(code_object):
     # the narrow chain of the windowed SEC instance (a secret scalar on a per-item base): every stored entry of the lane's table is
     # read for every addition - two affine entries x six 16-byte loads, at the chain's two fetch sites
     assert count(bodies[msm(1, 0, 1)], r"global_load_dwordx4") >= 2 * 2 * 6
+
+
+def test_the_four_wave_chain_kernel_exchanges_through_lds_only(code_object):
+    """k_msm_quad (four waves per item chain, small passes): two LDS buffers of four field elements for 64 items, no scratch, a
+    barrier per exchange that waits for the wave's LDS traffic only - the next table entry's global loads stay in flight across it
+    (a `s_waitcnt vmcnt(0)` next to every barrier would put their latency back on the chain)."""
+    kernels, bodies = code_object
+    quad = [k for k in kernels if "k_msm_quad" in k]
+    assert len(quad) == 2, quad
+    for k in quad:
+        assert kernels[k]["private_segment_fixed_size"] == 0 and kernels[k]["group_segment_fixed_size"] == 2 * 4 * 3 * 64 * 16, (k, kernels[k])
+        assert kernels[k]["vgpr_count"] <= 128, (k, kernels[k])
+        body = bodies[k]
+        barriers = len(re.findall(r"s_barrier", body))
+        assert barriers >= 6, (k, barriers)
+        # at most the entry barrier (after the recoding) is a full __syncthreads; the exchanges wait on lgkmcnt alone
+        full = len(re.findall(r"s_waitcnt vmcnt\(0\)[^\n]*\n\s*s_barrier|s_waitcnt vmcnt\(0\) lgkmcnt\(0\)[^\n]*\n\s*s_barrier", body))
+        assert full <= 2, (k, full, barriers)
+        assert len(re.findall(r"ds_read_b128|ds_load_b128", body)) >= 12 and len(re.findall(r"ds_write_b128|ds_store_b128", body)) >= 3
