@@ -765,7 +765,7 @@ k_msm_rows(const uint8_t* __restrict__ blob, const int32_t* __restrict__ pos_tab
 // waves, which a small pass has to spare.  The arithmetic is the centred flavour throughout (fe_mul, fe_sq: every operand
 // within the bounds ge.cuh states for the completed point), the digits, table layouts and job fields are k_msm's, and so is the
 // result, bit for bit (a field element has one centred representation).  Role 0 recodes the scalars and finishes the job.
-// Taken by afxk_msm for windowed and fixed-base launches without secret terms or in-kernel encodings whose grid is small.
+// Taken by afxk_msm for windowed and fixed-base launches without in-kernel encodings whose grid is small.
 struct quad_lds { int4 v[2][4][3][64]; };   // [buffer][slot][16-byte piece][lane]: 9 limbs + padding per element, 24 KB
 AFX_DEV void quad_put(quad_lds& L, int buf, uint32_t slot, uint32_t lane, const fe& f) {
   L.v[buf][slot][0][lane] = make_int4(f.v[0], f.v[1], f.v[2], f.v[3]);
@@ -843,21 +843,98 @@ AFX_DEV fe quad_entry_fe(const quad_words& q) {
   const uint32_t w[8] = { q.a.x, q.a.y, q.a.z, q.a.w, q.b.x, q.b.y, q.b.z, q.b.w };
   return fe_frombytes(w);
 }
-template <bool ROWS>
-__device__ __forceinline__ void msm_quad_body(const afx_msm_djob* __restrict__ job, const int32_t* __restrict__ pos_tables, int32_t* __restrict__ table_ws,
-                                              uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count) {
+// SEC: the launch has terms with secret scalars (afx_ctx_set_secret_independent_addressing): the same two mechanisms as k_msm's SEC
+// instances, a role's share of each.  A job with a secret on a per-item base (afx_msm_job.narrow) runs the 2-bit windows: roles 0
+// and 1 read (y+x)/2 AND (y-x)/2 of BOTH stored entries of the lane's table, role 2 dxy of both - every byte either could need,
+// at addresses made of the item only - and keep the digit's with selects (the identity for digit 0; the sign picks between the
+// two halves by a select as well, where the public path picks an address).  A secret on a generator takes its limbs from the
+// lane that holds the digit's multiple (ds_bpermute_b32, source lanes 0..31: msm_add_positional_secret), 18 limbs for roles 0
+// and 1, 9 for role 2.  tests/test_kernel_isa.py reads the instances for it.
+// [entry][16-byte half]: roles 0, 1: a = (y+x)/2, b = (y-x)/2; role 2: a = dxy, b unused
+struct quad_narrow { uint4 a[2][2], b[2][2]; };
+// a lane mask the compiler cannot see through (it would turn mask arithmetic back into selects, and selects on a lane mask into
+// branches around the work: a branch on a secret)
+AFX_DEV uint32_t quad_mask(bool b) { uint32_t m = b ? 0xffffffffu : 0u; asm volatile("" : "+v"(m)); return m; }
+AFX_DEV uint32_t quad_pick(uint32_t m, uint32_t yes, uint32_t no) { return (yes & m) | (no & ~m); }
+template <bool SEC>
+__device__ __forceinline__ void msm_quad_body(const afx_msm_djob* __restrict__ job, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables,
+                                              int32_t* __restrict__ table_ws, uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count) {
   __shared__ quad_lds L;
   if (blockIdx.x * 64u >= count) return;   // block-uniform: the grid is sized for the launch's largest pass
   const uint32_t lane = threadIdx.x & 63u, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t item = min(blockIdx.x * 64u + lane, count - 1);   // lanes past the end shadow the last item
   const uint32_t nt = job->n_terms, nv = job->n_var;
+  const bool narrow = SEC && job->narrow != 0;
   msm_env e;
   e.job = job; e.term = afx_job_terms(job); e.table_ws = table_ws; e.digit_ws = digit_ws;
-  e.count = count; e.item = item; e.dslot = job->digit_slot; e.tslot = 0; e.narrow = false;
-  if (role == 0) msm_recode(job, digit_ws, count, item, 0, nv, nt, false);
+  e.count = count; e.item = item; e.dslot = job->digit_slot; e.tslot = 0; e.narrow = narrow;
+  if (role == 0) msm_recode(job, digit_ws, count, item, 0, nv, nt, narrow);
   __syncthreads();   // the digits are in memory for the other roles (same CU: one vector cache)
   int buf = 0;
   ge_p3 acc = ge_identity();
+  bool chained = false;
+  if constexpr (SEC) {
+    if (narrow) {
+      chained = true;
+      // everything addition (w, t) could need of the lane's two-entry table, and its digit word; requested an addition ahead
+      auto fetch = [&](int w, uint32_t t, uint32_t& dword) {
+        const uint32_t o = AFX_SECVAR_BITS * (uint32_t)w;
+        dword = digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + (o >> 5)) * count + item];
+        const int32_t* table = table_ws + (size_t)e.term[t].table_slot * count * AFX_VAR_TABLE_DWORDS + (size_t)item * 4;
+        const size_t piece = (size_t)count * 4, entry = (size_t)count * AFX_TABLE_ENTRY_DWORDS;
+        // roles 0, 1: pieces 0, 1 and 2, 3; role 2 (and 3, which drops them): pieces 4, 5 twice - uniform offsets, every field set
+        const size_t first = role < 2 ? 0 : 4, other = role < 2 ? 2 : 4;
+        quad_narrow q;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            q.a[m][h] = *reinterpret_cast<const uint4*>(table + m * entry + (first + h) * piece);
+            q.b[m][h] = *reinterpret_cast<const uint4*>(table + m * entry + (other + h) * piece);
+          }
+        return q;
+      };
+      static_assert(AFX_SECVAR_BITS == 2 && AFX_SECVAR_STORED == 2, "k_msm_quad's narrow chain reads the two stored entries of a 2-bit window");
+      uint32_t nword = 0;
+      quad_narrow nxt = fetch(AFX_SECVAR_WINDOWS - 1, 0, nword);
+#pragma unroll 1
+      for (int w = AFX_SECVAR_WINDOWS - 1; w >= 0; w--) {
+        if (w != AFX_SECVAR_WINDOWS - 1) {
+#pragma unroll 1
+          for (int k = 0; k < AFX_SECVAR_BITS; k++) acc = quad_dbl(L, buf, role, lane, acc);
+        }
+#pragma unroll 1
+        for (uint32_t t = 0; t < nv; t++) {
+          const quad_narrow cur = nxt;
+          const uint32_t word = nword;
+          const bool last = t + 1 == nv;
+          if (!(last && w == 0)) nxt = fetch(last ? w - 1 : w, last ? 0 : t + 1, nword);
+          const int d = (int)((word >> ((AFX_SECVAR_BITS * (uint32_t)w) & 31u)) & 3u) - 2;
+          const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
+          const bool neg = (d < 0) != (e.term[t].negate != 0);
+          // the 8 words this role multiplies by: of entry idx (the identity for 0); roles 0, 1: the half the sign names (role 0
+          // takes (y-x)/2 when subtracting, role 1 when adding).  Mask arithmetic, no branch and no address from the digit.
+          const uint32_t second = quad_mask(role < 2 && (role == 0 ? neg : !neg));
+          uint32_t sel[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) sel[i] = role < 2 ? AFX_IDENTITY_NIELS[i] : 0u;   // (1/2, 1/2, 0)
+#pragma unroll
+          for (uint32_t m = 0; m < 2; m++) {
+            const uint32_t hit = quad_mask(idx == m + 1);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const uint4 a = cur.a[m][h], b = cur.b[m][h];
+              sel[4 * h] = quad_pick(hit, quad_pick(second, b.x, a.x), sel[4 * h]);
+              sel[4 * h + 1] = quad_pick(hit, quad_pick(second, b.y, a.y), sel[4 * h + 1]);
+              sel[4 * h + 2] = quad_pick(hit, quad_pick(second, b.z, a.z), sel[4 * h + 2]);
+              sel[4 * h + 3] = quad_pick(hit, quad_pick(second, b.w, a.w), sel[4 * h + 3]);
+            }
+          }
+          acc = quad_add<true>(L, buf, role, lane, acc, fe_frombytes(sel), neg);
+        }
+      }
+    }
+  }
   // the entry of addition (w, t), requested ahead of its use: before the window's doublings for t = 0, an addition ahead otherwise
   auto var_entry = [&](int w, uint32_t t, bool& neg) {
     const int32_t* table = table_ws + ((size_t)e.term[t].table_slot * count + item) * AFX_VAR_TABLE_DWORDS;
@@ -869,9 +946,9 @@ __device__ __forceinline__ void msm_quad_body(const afx_msm_djob* __restrict__ j
   };
   bool nneg = false;
   quad_words nxt = {};
-  if (nv) nxt = var_entry(63, 0, nneg);
+  if (nv && !chained) nxt = var_entry(63, 0, nneg);
 #pragma unroll 1
-  for (int w = nv ? 63 : -1; w >= 0; w--) {
+  for (int w = (nv && !chained) ? 63 : -1; w >= 0; w--) {
     if (w != 63) {
 #pragma unroll 1
       for (int k = 0; k < 4; k++) acc = quad_dbl(L, buf, role, lane, acc);
@@ -883,6 +960,44 @@ __device__ __forceinline__ void msm_quad_body(const afx_msm_djob* __restrict__ j
       const bool last = t + 1 == nv;
       if (!(last && w == 0)) nxt = var_entry(last ? w - 1 : w, last ? 0 : t + 1, nneg);
       acc = quad_add<false>(L, buf, role, lane, acc, quad_entry_fe(cur), neg);
+    }
+  }
+  // fixed bases with secret scalars: the lane exchange, a role's limbs of the multiple
+  if constexpr (SEC) {
+    bool any_secret = false;
+#pragma unroll 1
+    for (uint32_t t = nv; t < nt; t++) any_secret |= e.term[t].secret != 0;
+#pragma unroll 1
+    for (uint32_t j = 0; j < AFX_SEC_WINDOWS && any_secret; j++) {
+#pragma unroll 1
+      for (uint32_t t = nv; t < nt; t++) {
+        if (!e.term[t].secret) continue;   // uniform
+        const uint32_t o = AFX_SEC_BITS * j, k = o >> 5, sh = o & 31u;
+        const uint32_t* dw = digit_ws + ((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + k) * count + item;
+        uint64_t ww = dw[0];
+        if (sh + AFX_SEC_BITS > 32) ww |= (uint64_t)dw[count] << 32;
+        const int d = (int)((uint32_t)(ww >> sh) & ((1u << AFX_SEC_BITS) - 1)) - (1 << (AFX_SEC_BITS - 1));
+        const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
+        const bool neg = (d < 0) != (e.term[t].negate != 0);
+        const int32_t* win = sec_tables + (size_t)e.term[t].fixed_idx * AFX_SEC_TABLE_DWORDS + (size_t)j * AFX_SEC_WINDOW_DWORDS;
+        const int32_t* mine = win + ((lane & 31u) + 1u) * AFX_NIELS_DWORDS;   // this lane's multiple: an address made of the lane's id
+        const int src = (int)(((idx - 1u) & 31u) << 2);
+        const uint32_t keep = quad_mask(idx != 0);
+        fe q = fe_zero();
+        if (role < 2) {
+          const uint32_t second = quad_mask(role == 0 ? neg : !neg);
+#pragma unroll
+          for (int l = 0; l < AFX_FE_LIMBS; l++) {
+            const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(src, mine[l]), b = (uint32_t)__builtin_amdgcn_ds_bpermute(src, mine[9 + l]);
+            // entry 0, the identity, has (y+x)/2 = (y-x)/2: one wave-uniform limb serves both halves
+            q.v[l] = (int32_t)quad_pick(keep, quad_pick(second, b, a), (uint32_t)win[l]);
+          }
+        } else if (role == 2) {
+#pragma unroll
+          for (int l = 0; l < AFX_FE_LIMBS; l++) q.v[l] = (int32_t)quad_pick(keep, (uint32_t)__builtin_amdgcn_ds_bpermute(src, mine[18 + l]), (uint32_t)win[18 + l]);
+        }
+        acc = quad_add<true>(L, buf, role, lane, acc, q, neg);
+      }
     }
   }
   // fixed bases: the same one-ahead request of the 9 limbs this role multiplies by ((y+x)/2 | (y-x)/2 | dxy; role 3 reads what
@@ -900,33 +1015,42 @@ __device__ __forceinline__ void msm_quad_body(const afx_msm_djob* __restrict__ j
 #pragma unroll
     for (int l = 0; l < AFX_FE_LIMBS; l++) q.v[l] = ent[9 * part + l];
   };
-  if (nt != nv) {
+  // (the public fixed-base terms of the job: all of them unless SEC)
+  uint32_t first_pub = nt, last_pub = nt;
+#pragma unroll 1
+  for (uint32_t t = nv; t < nt; t++)
+    if (!SEC || !e.term[t].secret) { if (first_pub == nt) first_pub = t; last_pub = t; }
+  auto next_pub = [&](uint32_t t) { t++; while (SEC && t < nt && e.term[t].secret) t++; return t; };
+  if (first_pub != nt) {
     fe qn;
-    pos_entry(0, nv, nneg, qn);
+    pos_entry(0, first_pub, nneg, qn);
 #pragma unroll 1
     for (uint32_t j = 0; j < AFX_POS_WINDOWS; j++) {
 #pragma unroll 1
-      for (uint32_t t = nv; t < nt; t++) {
+      for (uint32_t t = first_pub; t <= last_pub; t = next_pub(t)) {
         const fe q = qn;
         const bool neg = nneg;
-        const bool last = t + 1 == nt;
-        if (!(last && j + 1 == AFX_POS_WINDOWS)) pos_entry(last ? j + 1 : j, last ? nv : t + 1, nneg, qn);
+        const bool last = t == last_pub;
+        if (!(last && j + 1 == AFX_POS_WINDOWS)) pos_entry(last ? j + 1 : j, last ? first_pub : next_pub(t), nneg, qn);
         acc = quad_add<true>(L, buf, role, lane, acc, q, neg);
       }
     }
   }
   if (role == 0) msm_finish<false>(job, acc, bad, count, item);
 }
+template <bool SEC>
 __global__ void __launch_bounds__(256, 2)
-k_msm_quad(const afx_msm_djob* __restrict__ jobs, const int32_t* __restrict__ pos_tables, int32_t* __restrict__ table_ws, uint32_t* __restrict__ digit_ws,
-           uint32_t* __restrict__ bad, uint32_t count) {
-  msm_quad_body<false>(&jobs[blockIdx.y], pos_tables, table_ws, digit_ws, bad, count);
+k_msm_quad(const afx_msm_djob* __restrict__ jobs, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables, int32_t* __restrict__ table_ws,
+           uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count) {
+  msm_quad_body<SEC>(&jobs[blockIdx.y], pos_tables, sec_tables, table_ws, digit_ws, bad, count);
 }
+template <bool SEC>
 __global__ void __launch_bounds__(256, 2)
-k_msm_quad_rows(const uint8_t* __restrict__ blob, const int32_t* __restrict__ pos_tables, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+k_msm_quad_rows(const uint8_t* __restrict__ blob, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables, const afx_row* __restrict__ rows,
+                const afx_pass* __restrict__ passes) {
   const afx_row row = rows[blockIdx.y];      // block-uniform: scalar loads
   const afx_pass pass = passes[row.pass];
-  msm_quad_body<true>(reinterpret_cast<const afx_msm_djob*>(blob + row.job_off), pos_tables, pass.table_ws, pass.digit_ws, pass.bad, pass.count);
+  msm_quad_body<SEC>(reinterpret_cast<const afx_msm_djob*>(blob + row.job_off), pos_tables, sec_tables, pass.table_ws, pass.digit_ws, pass.bad, pass.count);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1376,12 +1500,15 @@ hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_
   // (measurement aid: the two kernels give the same bytes).
   static const bool quad_on = !(getenv("AFX_QUAD_CHAINS") && getenv("AFX_QUAD_CHAINS")[0] == '0');
   const uint32_t quad_blocks = (max_count + 63) / 64;
-  if (quad_on && !secret && !encodes && kind != MSM_NAF && max_count && (uint64_t)quad_blocks * njobs <= 512) {   // (1024: 512-item calls gain 7 %, 16-shape requests lose 14 %)
+  if (quad_on && !encodes && kind != MSM_NAF && max_count && (uint64_t)quad_blocks * njobs <= 512) {   // (1024: 512-item calls gain 7 %, 16-shape requests lose 14 %)
+    const dim3 qgrid(quad_blocks, njobs);
     if (!rows) {
       if (!pass_host) return hipErrorInvalidValue;
-      hipLaunchKernelGGL(k_msm_quad, dim3(quad_blocks, njobs), dim3(256), 0, s, jobs, pos_tables, pass_host->table_ws, pass_host->digit_ws, pass_host->bad, pass_host->count);
+      if (secret) hipLaunchKernelGGL(k_msm_quad<true>, qgrid, dim3(256), 0, s, jobs, pos_tables, sec_tables, pass_host->table_ws, pass_host->digit_ws, pass_host->bad, pass_host->count);
+      else hipLaunchKernelGGL(k_msm_quad<false>, qgrid, dim3(256), 0, s, jobs, pos_tables, sec_tables, pass_host->table_ws, pass_host->digit_ws, pass_host->bad, pass_host->count);
     } else {
-      hipLaunchKernelGGL(k_msm_quad_rows, dim3(quad_blocks, njobs), dim3(256), 0, s, (const uint8_t*)jobs, pos_tables, rows, passes);
+      if (secret) hipLaunchKernelGGL(k_msm_quad_rows<true>, qgrid, dim3(256), 0, s, (const uint8_t*)jobs, pos_tables, sec_tables, rows, passes);
+      else hipLaunchKernelGGL(k_msm_quad_rows<false>, qgrid, dim3(256), 0, s, (const uint8_t*)jobs, pos_tables, sec_tables, rows, passes);
     }
     return hipGetLastError();
   }

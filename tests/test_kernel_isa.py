@@ -96,17 +96,26 @@ def test_secret_independent_lookups_address_nothing_by_a_digit(code_object):
 def test_the_four_wave_chain_kernel_exchanges_through_lds_only(code_object):
     """k_msm_quad (four waves per item chain, small passes): two LDS buffers of four field elements for 64 items, no scratch, a
     barrier per exchange that waits for the wave's LDS traffic only - the next table entry's global loads stay in flight across it
-    (a `s_waitcnt vmcnt(0)` next to every barrier would put their latency back on the chain)."""
+    (a `s_waitcnt vmcnt(0)` next to every barrier would put their latency back on the chain).  Its SEC instances (secret scalars):
+    the lane exchange for generators - 18 limbs for the roles that multiply by (y+x)/2 or (y-x)/2, 9 for the one that takes dxy -
+    and mask arithmetic where the digit and the sign choose among the loaded entries: no scratch, and no more branches on the
+    exec mask than the uniform plan flags explain."""
     kernels, bodies = code_object
-    quad = [k for k in kernels if "k_msm_quad" in k]
-    assert len(quad) == 2, quad
+    quad = sorted(k for k in kernels if "k_msm_quad" in k)
+    assert len(quad) == 4, quad
+    count = lambda body, pat: len(re.findall(pat, body))
     for k in quad:
         assert kernels[k]["private_segment_fixed_size"] == 0 and kernels[k]["group_segment_fixed_size"] == 2 * 4 * 3 * 64 * 16, (k, kernels[k])
         assert kernels[k]["vgpr_count"] <= 128, (k, kernels[k])
         body = bodies[k]
-        barriers = len(re.findall(r"s_barrier", body))
+        barriers = count(body, r"s_barrier")
         assert barriers >= 6, (k, barriers)
         # at most the entry barrier (after the recoding) is a full __syncthreads; the exchanges wait on lgkmcnt alone
-        full = len(re.findall(r"s_waitcnt vmcnt\(0\)[^\n]*\n\s*s_barrier|s_waitcnt vmcnt\(0\) lgkmcnt\(0\)[^\n]*\n\s*s_barrier", body))
+        full = count(body, r"s_waitcnt vmcnt\(0\)[^\n]*\n\s*s_barrier|s_waitcnt vmcnt\(0\) lgkmcnt\(0\)[^\n]*\n\s*s_barrier")
         assert full <= 2, (k, full, barriers)
-        assert len(re.findall(r"ds_read_b128|ds_load_b128", body)) >= 12 and len(re.findall(r"ds_write_b128|ds_store_b128", body)) >= 3
+        assert count(body, r"ds_read_b128|ds_load_b128") >= 12 and count(body, r"ds_write_b128|ds_store_b128") >= 3
+    for rows in ("k_msm_quad_rows", "k_msm_quadI"):
+        sec = next(bodies[k] for k in quad if rows in k and "ILb1E" in k)
+        plain = next(bodies[k] for k in quad if rows in k and "ILb0E" in k)
+        assert count(plain, r"ds_bpermute_b32") == 0 and count(sec, r"ds_bpermute_b32") == 27
+        assert count(sec, r"s_cbranch_exec") <= count(plain, r"s_cbranch_exec") + 3, rows

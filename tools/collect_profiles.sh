@@ -14,13 +14,6 @@ O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
 cd $R
 line() { grep '^{' $1 | tail -1; }
-python3 bench.py > $O/bench_c3.log 2>&1; line $O/bench_c3.log > $O/${TAG}_bench_c3.json
-python3 bench.py --workload c2 > $O/bench_c2.log 2>&1; line $O/bench_c2.log > $O/${TAG}_bench_c2.json
-for w in c5 show; do
-  python3 bench.py --workload $w > $O/bench_$w.log 2>&1; line $O/bench_$w.log > $O/${TAG}_bench_$w.json
-  python3 bench.py --workload $w --secret-mode 0 --no-cpu-baseline > $O/bench_${w}_mode0.log 2>&1; line $O/bench_${w}_mode0.log > $O/${TAG}_bench_${w}_fast_tables.json
-done
-python3 bench.py --secret-mode 1 --no-cpu-baseline > $O/bench_c3_mode1.log 2>&1; line $O/bench_c3_mode1.log > $O/${TAG}_bench_c3_secret_everywhere.json
 cd /tmp && export TMPDIR=/tmp
 db() { ls $1/*/t_results.db $1/t_results.db 2>/dev/null | head -1; }
 trace() {   # name, bench flags...
@@ -71,6 +64,17 @@ rm -rf $O/pmc_bperm
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/pmc_mix -o t -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mix.log 2>&1
 python3 $R/tools/rocpd_pmc.py $(db $O/pmc_mix) k_msm > $O/${TAG}_c3_instruction_mix.txt 2>&1
 rm -rf $O/pmc_*_FETCH_SIZE $O/pmc_*_WRITE_SIZE $O/pmc_mix   # databases are large; the summaries are kept
+# the bench lines last: their roofline.traffic comes from the traffic files just measured on these kernels (bench.py takes the newest
+# profiles/rNN_traffic.json whose kernel_sources_sha256 is this tree's)
+mkdir -p $R/profiles && cp $O/${TAG}_traffic.json $O/${TAG}_secret_traffic.json $R/profiles/
+cd $R
+python3 bench.py > $O/bench_c3.log 2>&1; line $O/bench_c3.log > $O/${TAG}_bench_c3.json
+python3 bench.py --workload c2 > $O/bench_c2.log 2>&1; line $O/bench_c2.log > $O/${TAG}_bench_c2.json
+for w in c5 show; do
+  python3 bench.py --workload $w > $O/bench_$w.log 2>&1; line $O/bench_$w.log > $O/${TAG}_bench_$w.json
+  python3 bench.py --workload $w --secret-mode 0 --no-cpu-baseline > $O/bench_${w}_mode0.log 2>&1; line $O/bench_${w}_mode0.log > $O/${TAG}_bench_${w}_fast_tables.json
+done
+python3 bench.py --secret-mode 1 --no-cpu-baseline > $O/bench_c3_mode1.log 2>&1; line $O/bench_c3_mode1.log > $O/${TAG}_bench_c3_secret_everywhere.json
 # the small-call and mixed-request measurements of the round
 cd $R
 python3 tools/mixed_concurrency.py 64 16 > $O/${TAG}_mixed_concurrency.txt 2>&1
