@@ -1053,6 +1053,59 @@ k_msm_quad_rows(const uint8_t* __restrict__ blob, const int32_t* __restrict__ po
   msm_quad_body<SEC>(reinterpret_cast<const afx_msm_djob*>(blob + row.job_off), pos_tables, sec_tables, pass.table_ws, pass.digit_ws, pass.bad, pass.count);
 }
 
+// k_pointsum for the same idle device: a job's partial sums added up by four waves - role r takes parts r, r + 4, ..., each
+// requesting its next part while it adds the current one, then two levels through LDS (1 -> 0 and 3 -> 2, then 2 -> 0) - instead
+// of one lane adding up to fifteen parts in a row, each behind its own load.  Role 0 adds the addend and finishes as k_pointsum does.
+AFX_DEV void quad_put_point(quad_lds& L, int buf, uint32_t lane, const ge_p3& p) {
+  quad_put(L, buf, 0, lane, p.X); quad_put(L, buf, 1, lane, p.Y); quad_put(L, buf, 2, lane, p.Z); quad_put(L, buf, 3, lane, p.T);
+}
+AFX_DEV ge_p3 quad_get_point(const quad_lds& L, int buf, uint32_t lane) {
+  ge_p3 p;
+  p.X = quad_get(L, buf, 0, lane); p.Y = quad_get(L, buf, 1, lane); p.Z = quad_get(L, buf, 2, lane); p.T = quad_get(L, buf, 3, lane);
+  return p;
+}
+__global__ void __launch_bounds__(256, 2)
+k_pointsum_quad(const afx_pointsum_job* __restrict__ jobs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  __shared__ quad_lds L;
+  const afx_pointsum_job job = *row_job(jobs, rows);
+  const afx_pass pass = passes[row_pass_index(rows)];   // block-uniform: scalar loads
+  const uint32_t count = pass.count;
+  uint32_t* __restrict__ bad = pass.bad;
+  if (blockIdx.x * 64u >= count) return;   // block-uniform
+  const uint32_t lane = threadIdx.x & 63u, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t item = min(blockIdx.x * 64u + lane, count - 1);   // lanes past the end shadow the last item
+  ge_p3 acc = ge_identity();
+  if (role < job.n_parts) {
+    acc = var_load(job.parts[role], count, item);
+    ge_p3 nxt = acc;
+    if (role + 4 < job.n_parts) nxt = var_load(job.parts[role + 4], count, item);
+#pragma unroll 1
+    for (uint32_t k = role + 4; k < job.n_parts; k += 4) {
+      const ge_p3 cur = nxt;
+      if (k + 4 < job.n_parts) nxt = var_load(job.parts[k + 4], count, item);
+      acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_p3_to_cached(cur), false));
+    }
+  }
+  // (fewer than 3 parts: the upper roles hold the identity, whose addition changes nothing)
+  if (role & 1u) quad_put_point(L, (int)(role >> 1), lane, acc);
+  __syncthreads();
+  if (!(role & 1u)) acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_p3_to_cached(quad_get_point(L, (int)(role >> 1), lane)), false));
+  __syncthreads();
+  if (role == 2) quad_put_point(L, 0, lane, acc);
+  __syncthreads();
+  if (role != 0) return;
+  acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_p3_to_cached(quad_get_point(L, 0, lane)), false));
+  if (job.addend) acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_p3_to_cached(var_load(job.addend, count, item)), job.addend_negate != 0));
+  if (job.out_var) var_store(job.out_var, count, item, acc);
+  if (job.half_var) { var_store(job.half_var, count, item, acc); return; }   // encoded by k_compress2x
+  if (job.out_enc) {
+    uint32_t w[8];
+    ristretto_encode(w, acc);
+    enc_store(job.out_enc, item, w);
+    if (job.reject_identity && is_identity_encoding(w)) atomicOr(&bad[item], AFX_BAD_IDENTITY);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_compress2x: the encodings of 2*P_j for all the points P_j an item's jobs left in half_var, with ONE field inversion per item
 // ---------------------------------------------------------------------------------------------
@@ -1552,6 +1605,12 @@ hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, const afx_walk
   return hipGetLastError();
 }
 hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  // the idle-device form, under the same rule as k_msm_quad (and the same switch)
+  static const bool quad_on = !(getenv("AFX_QUAD_CHAINS") && getenv("AFX_QUAD_CHAINS")[0] == '0');
+  if (quad_on && max_count && (uint64_t)((max_count + 63) / 64) * njobs <= 512) {
+    hipLaunchKernelGGL(k_pointsum_quad, dim3((max_count + 63) / 64, njobs), dim3(256), 0, s, jobs, rows, passes);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_pointsum, grid_for(max_count, njobs), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }

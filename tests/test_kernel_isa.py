@@ -103,6 +103,8 @@ def test_the_four_wave_chain_kernel_exchanges_through_lds_only(code_object):
     kernels, bodies = code_object
     quad = sorted(k for k in kernels if "k_msm_quad" in k)
     assert len(quad) == 4, quad
+    psum = [k for k in kernels if "k_pointsum_quad" in k]
+    assert len(psum) == 1 and kernels[psum[0]]["private_segment_fixed_size"] == 0 and kernels[psum[0]]["group_segment_fixed_size"] == 2 * 4 * 3 * 64 * 16, (psum, kernels.get(psum[0]) if psum else None)
     count = lambda body, pat: len(re.findall(pat, body))
     for k in quad:
         assert kernels[k]["private_segment_fixed_size"] == 0 and kernels[k]["group_segment_fixed_size"] == 2 * 4 * 3 * 64 * 16, (k, kernels[k])
