@@ -1,5 +1,6 @@
 """Latency of ONE synchronous host-pointer call of each operation at small batch sizes, for the two plans
 (afx_ctx_set_small_batch_items 0 / 4096 (the default)): python tools/small_call_latency.py
+(AFX_LATENCY_ITEMS=1,16,... picks the sizes; AFX_LATENCY_KERNELS=1 adds the per-kernel times of the default plan's call)
 Shapes: issue n = 16 (C5's layout), show and verify the C3 shape (8 attributes, 4 hidden encrypted points)."""
 import os
 import sys
@@ -55,4 +56,12 @@ for n in [int(x) for x in os.environ.get("AFX_LATENCY_ITEMS", "1,16,256,1024").s
             r.append(timed(fn))
         ctx.set_small_batch_items(4096)
         cols.append("%8.3f / %8.3f" % tuple(r))
+        if os.environ.get("AFX_LATENCY_KERNELS"):   # where the default plan's call goes, kernel by kernel (HIP events on the engine's stream)
+            ctx.set_timing(True)
+            for _ in range(10):
+                fn()
+            kt = bench.kernel_times(ctx, 10)
+            ctx.set_timing(False)
+            print("   %s, %d items: kernels %.3f ms in %d launches: %s" % (name, n, sum(v["ms_per_step"] for v in kt.values()), sum(v["launches_per_step"] for v in kt.values()),
+                                                                            ", ".join("%s %.3f" % (k, v["ms_per_step"]) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms_per_step"]))))
     print("%-8d %-28s %-28s %-28s" % (n, *cols), flush=True)
