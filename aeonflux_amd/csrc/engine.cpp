@@ -322,7 +322,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
       pending_half_vars_.clear();
       std::vector<afx_compress_job> cjobs;
       cjobs.swap(pending_cjobs_);
-      compress(cjobs, small() ? 8u : 1u);
+      compress(cjobs, ctx->walk_rows(count, cjobs.size(), small()));
     }
     return;
   }
@@ -401,8 +401,8 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
       msm_list(std::move(rest), false, cjobs);
     }
   } else msm_list(std::move(jobs), false, cjobs);
-  // small passes: the item's commitments are encoded in up to 8 rows, an inversion each, instead of one serial walk
-  compress(cjobs, small ? 8u : 1u);
+  // small passes: the item's commitments are encoded in a row each (8 rows when the device is busy), an inversion each, instead of one serial walk
+  compress(cjobs, ctx->walk_rows(count, cjobs.size(), small));
 }
 
 void Assembler::compress_also(const int32_t* var, uint8_t* out_enc, bool negate, uint32_t reject_identity) {
@@ -701,7 +701,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
         al.njobs = tl.njobs;
         al.jobs_off = blob_alloc(sizeof(afx_table_job) * tr.size(), 16);
         memcpy(blob_.data() + al.jobs_off, tr.data(), sizeof(afx_table_job) * tr.size());
-        const uint32_t groups = small() ? 8u : 1u;
+        const uint32_t groups = ctx->walk_rows(count, tr.size(), small());
         add_walk_rows(al, groups > 1 ? (al.njobs + groups - 1) / groups : 0);
         launches.push_back(al);
         // per entry: the prefix product, 1/Z and the running inverse, x and y, the niels form (4); per row the inversion

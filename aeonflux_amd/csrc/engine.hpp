@@ -125,6 +125,13 @@ struct afx_ctx {
   static uint32_t merge_class_of(uint64_t waves) { uint32_t k = 1; while (k < 7 && waves > (12ull << k)) k++; return k; }
   // waves per grid row of a pass of `count` items, alone or among the passes merged with it
   uint32_t row_waves(uint32_t count) const { return merge_class ? (9u << merge_class) : (count + 63) / 64; }   // (the class's middle)
+  // grid rows of a walk kernel (k_compress2x, k_table_affine: one inversion per row) for `njobs` jobs of a small pass: a row per job
+  // while those rows leave the device idle (a call waits for the longest walk: one inversion and one job instead of one and four),
+  // 8 rows otherwise, 1 for large passes
+  uint32_t walk_rows(uint32_t count, size_t njobs, bool small) const {
+    if (!small) return 1u;
+    return (uint64_t)row_waves(count) * njobs <= 2ull * 4 * n_cu ? (uint32_t)std::max<size_t>(njobs, 1) : 8u;
+  }
   afx_plan_stats last_stats = {};   // per-item operation counts of the most recent plan
   std::map<std::string, std::array<uint64_t, 25>> folded_states;   // STROBE state after a transcript's all-constant leading blocks, by those blocks' bytes
                                                                    // (SchnorrBuilder::make_program); may derive from the key: wiped on destroy
