@@ -145,6 +145,21 @@ void Assembler::pointop(const std::vector<afx_pointop_job>& jobs) {
     stats.chain_mul += j.out_enc ? AFX_CHAIN_SQRT_MUL : 0;
     stats.chain_sq += j.out_enc ? AFX_CHAIN_SQRT_SQ : 0;
   }
+  // A small pass on an idle device: the encodings of these points (a square-root chain each) leave this launch, which stands
+  // BEFORE the chains, for the k_compress2x launch after them, where they run beside the other encodings (plain jobs, a row
+  // each): the transcript is their only reader.  (reject_identity 2, the strict mode's "must be the identity", stays here.)
+  if (small() && (uint64_t)ctx->row_waves(count) * jobs.size() <= 2ull * 4 * ctx->n_cu) {
+    std::vector<afx_pointop_job> moved(jobs);
+    for (afx_pointop_job& j : moved) {
+      if (!j.out_enc || j.reject_identity == 2) continue;
+      if (!j.out) j.out = new_var();
+      afx_compress_job cj = { j.out, j.out_enc, j.reject_identity, AFX_COMPRESS_PLAIN };
+      pending_cjobs_.push_back(cj);
+      j.out_enc = nullptr; j.reject_identity = 0;
+    }
+    add_jobs(L_POINTOP, moved);
+    return;
+  }
   add_jobs(L_POINTOP, jobs);
 }
 void Assembler::negenc(const std::vector<afx_negenc_job>& jobs) {
@@ -176,6 +191,7 @@ void Assembler::add_walk_rows(Launch& l, uint32_t per_row) {
 }
 void Assembler::scalarop(const std::vector<afx_scalarop_job>& jobs) { add_jobs(L_SCALAROP, jobs); }
 void Assembler::hash(const std::vector<afx_hash_program>& progs) {
+  if (!pending_cjobs_.empty()) msm(std::vector<afx_msm_job>());   // encodings still queued (Assembler::pointop, compress_also) are launched before their reader
   for (const afx_hash_program& p : progs) stats.keccak_permutations += p.n_records;
   add_jobs(L_HASH, progs);
 }
@@ -303,11 +319,14 @@ void Assembler::compress(const std::vector<afx_compress_job>& cjobs, uint32_t gr
   launches.push_back(cl);
   // the plain encodings were counted job by job: replace them by k_compress2x's share (two passes over e, f, g, h per job, one
   // inversion per row)
+  // (plain jobs - points encoded as they are, moved here by Assembler::pointop - keep the share they were counted with)
+  uint64_t halves = 0;
+  for (const afx_compress_job& j : cjobs) halves += j.negate != AFX_COMPRESS_PLAIN;
   const uint64_t rows = cl.nrows;
-  stats.field_mul += 22 * cjobs.size() + 11 * rows; stats.field_mul -= AFX_ENCODE_MUL * cjobs.size();
-  stats.field_sq += 8 * cjobs.size() + 254 * rows; stats.field_sq -= AFX_ENCODE_SQ * cjobs.size();
-  stats.chain_mul += AFX_CHAIN_INVERT_MUL * rows; stats.chain_mul -= AFX_CHAIN_SQRT_MUL * cjobs.size();
-  stats.chain_sq += AFX_CHAIN_INVERT_SQ * rows; stats.chain_sq -= AFX_CHAIN_SQRT_SQ * cjobs.size();
+  stats.field_mul += 22 * halves + 11 * rows; stats.field_mul -= AFX_ENCODE_MUL * halves;
+  stats.field_sq += 8 * halves + 254 * rows; stats.field_sq -= AFX_ENCODE_SQ * halves;
+  stats.chain_mul += AFX_CHAIN_INVERT_MUL * rows; stats.chain_mul -= AFX_CHAIN_SQRT_MUL * halves;
+  stats.chain_sq += AFX_CHAIN_INVERT_SQ * rows; stats.chain_sq -= AFX_CHAIN_SQRT_SQ * halves;
 }
 
 // Multiscalar jobs of one statement stage.  Large passes: one lane per (job, item), every job a single chain (msm_list).  Small

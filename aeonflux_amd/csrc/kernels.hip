@@ -1132,18 +1132,29 @@ k_compress2x(const afx_compress_job* __restrict__ jobs, const afx_walk_row* __re
   jobs = reinterpret_cast<decltype(jobs)>(reinterpret_cast<const uint8_t*>(jobs) + row.job_off);
   int32_t* __restrict__ prefix_ws = row.prefix_ws;
   fe prod = fe_one();
+  bool halves = false;   // (uniform) the row has jobs that share the inversion
 #pragma unroll 1
   for (uint32_t j = 0; j < njobs; j++) {
     ge_p3 P = var_load(jobs[j].var, count, item);
+    if (jobs[j].negate == AFX_COMPRESS_PLAIN) {   // (uniform) the point itself, with its own inverse square root: no part of the shared inversion
+      uint32_t w[8];
+      ristretto_encode(w, P);
+      enc_store(jobs[j].out_enc, item, w);
+      if (jobs[j].reject_identity && is_identity_encoding(w)) atomicOr(&bad[item], AFX_BAD_IDENTITY);
+      continue;
+    }
     if (jobs[j].negate) P = ge_neg(P);
+    halves = true;
     const c2x_state s = c2x_from(P);
     fe_store_soa(prefix_ws + (size_t)j * AFX_FE_LIMBS * count, 0, count, item, prod);   // product of the factors before j
     prod = fe_mul(prod, s.efgh);
   }
+  if (!halves) return;
   fe inv = fe_invert(prod);
 #pragma unroll 1
   for (uint32_t jj = njobs; jj > 0; jj--) {
     const uint32_t j = jj - 1;
+    if (jobs[j].negate == AFX_COMPRESS_PLAIN) continue;
     ge_p3 P = var_load(jobs[j].var, count, item);
     if (jobs[j].negate) P = ge_neg(P);
     const c2x_state s = c2x_from(P);

@@ -231,8 +231,12 @@ typedef struct {
   const int32_t* var;      /* SoA extended point, the half of what is to be encoded                 */
   uint8_t* out_enc;        /* [count][32]                                                            */
   uint32_t reject_identity;
-  uint32_t negate;         /* encode -2 * var instead (the "-E1" beside an E1 that left its half)                            */
+  uint32_t negate;         /* 1: encode -2 * var instead (the "-E1" beside an E1 that left its half); 2 (AFX_COMPRESS_PLAIN): encode var
+                              ITSELF, with an inverse square root of its own - a point that is no half (a sum of decoded points), whose
+                              encoding a small pass moves here from k_pointop so that it runs beside the other encodings instead of
+                              before the chains (Assembler::pointop)                                                          */
 } afx_compress_job;
+#define AFX_COMPRESS_PLAIN 2u
 
 /* k_negenc: out_enc[item] = encoding of -P, P = the point that `enc` decodes to (coordinates in `var`, Z = 1, as k_decode left
  * them): no square root, one field inversion per item for all its jobs (ge.cuh negenc_*) */
