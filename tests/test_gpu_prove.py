@@ -342,3 +342,35 @@ def test_issuance_verification_recomputes_the_oracles_challenge():
             assert bytes(got[0, i]) == want[i], i
             reached += 1
     assert reached >= cnt - 6
+
+
+@pytest.mark.parametrize("secret", ["prover", False])
+def test_a_wide_issue_pass_takes_several_terms_per_chain_and_issues_the_same_bytes(secret):
+    """20 000 requests of 16 attributes through the latency plan (afx_ctx_set_small_batch_items raised above them): its stages would
+    put more than four waves of one-term chains on every SIMD, so the jobs take two or more terms per chain (engine.cpp
+    Assembler::msm; with secrets: narrow chains of several terms, and the lane exchange beside them).  Every output byte is the
+    oracle's (20 distinct requests tiled: equal inputs, equal outputs), and the plan has fewer chains than a small call's."""
+    import aeonflux_amd as afx
+    n, layout, distinct, reps = 16, "SSSSSSSSPPPPEEEE", 20, 1000
+    d = make_credentials(n, layout, distinct, b"gpu-issue-%d" % n)
+    creds = d["creds"] * reps
+    count = len(creds)
+    ctx = afx.Context(d["params"], d["key"], d["ip"])
+    ctx.set_secret_independent_addressing(secret)
+    kinds = creds[0]["kinds"]
+    values_rows = [[c["values"][i][:32] for c in creds] for i in range(n)]
+    args = (kinds, values_rows, [c["rnd"][0] for c in creds], [c["rnd"][1] for c in creds], [c["rnd"][2] for c in creds])
+    gpu_issue(afx, ctx, kinds, [r[:distinct] for r in values_rows], *[a[:distinct] for a in args[2:]])
+    small_jobs = ctx.plan_stats()["msm_jobs"]
+    ctx.set_small_batch_items(32768)
+    o, status = gpu_issue(afx, ctx, *args)
+    assert not status.any()
+    assert ctx.plan_stats()["msm_jobs"] < small_jobs, (ctx.plan_stats()["msm_jobs"], small_jobs)
+    for f in ("t", "U", "V", "challenge"):
+        got = np.frombuffer(bytes(o[f]), np.uint8).reshape(count, 32)
+        want = np.stack([np.frombuffer(c[f], np.uint8) for c in creds])
+        assert np.array_equal(got, want), f
+    got = np.frombuffer(bytes(o["responses"]), np.uint8).reshape(n + 5, count, 32)
+    want = np.stack([np.stack([np.frombuffer(c["responses"][k], np.uint8) for c in creds]) for k in range(n + 5)])
+    assert np.array_equal(got, want)
+    ctx.close()
