@@ -732,6 +732,20 @@ def main():
         wire_rate = wn / (time.perf_counter() - t0)
         assert UNCHECKED or np.array_equal(wst, want[:wn])
         del blob, wsub
+        # ... and what ONE small synchronous host-pointer call costs (the latency plan: DESIGN.md section 3): the first 64
+        # presentations of the batch, mean over 20 calls after two warm-up calls (the first assembles and keeps the plan)
+        sn = min(count, 64)
+        ssub = {f: np.ascontiguousarray(pres[f][..., :sn, :]) for f in batch.PRES_FIELDS}
+        ssub["enc"] = [{f: np.ascontiguousarray(d[f][..., :sn, :]) for f in batch.ENC_FIELDS} for d in pres["enc"]]
+        ssoa, keep_s = batch.presentation_soa(ssub)
+        sst = np.full(sn, 255, np.uint8)
+        for _ in range(2):
+            afx.check(afx.lib().afx_verify_presentations(issuer.h, C.byref(shape), C.byref(ssoa), sn, sst.ctypes.data))
+        t0 = time.perf_counter()
+        for _ in range(20):
+            afx.check(afx.lib().afx_verify_presentations(issuer.h, C.byref(shape), C.byref(ssoa), sn, sst.ctypes.data))
+        small_call_ms = (time.perf_counter() - t0) / 20 * 1e3
+        assert UNCHECKED or np.array_equal(sst, want[:sn])
         # ... and through ONE afx_group over the node's GPUs (one process, host arrays): the in-library split
         if not args.no_group_api:
             del dpres, soa, status
@@ -790,6 +804,7 @@ def main():
                        "secret_independent_addressing": {0: "nowhere (mode 0)", 1: "everywhere (mode 1)", 2: "prover-side calls (mode 2, the default)"}[secret_mode_of(args)],
                        "input_generation_s": round(gen_s, 2), "host_pointer_api_presentations_per_s": pcie,
                        "wire_blob_api_presentations_per_s": wire_rate,
+                       "small_call_ms": None if pcie is None else round(small_call_ms, 4), "small_call_items": 64,
                        "n1_vs_n_note": "the N=1 default workload is C3 (2^20 presentations on the one GPU, \"weak\"); N>1 defaults to C4 (2^22 in all, "
                                        "2^22/N per GPU, \"strong\"): the curve's first point is a different batch size from the rest - immaterial above "
                                        "2^17 items per GPU, where a pass fills the device",
