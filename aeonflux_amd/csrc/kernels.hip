@@ -1564,7 +1564,8 @@ hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_
   // (measurement aid: the two kernels give the same bytes).
   static const bool quad_on = !(getenv("AFX_QUAD_CHAINS") && getenv("AFX_QUAD_CHAINS")[0] == '0');
   const uint32_t quad_blocks = (max_count + 63) / 64;
-  if (quad_on && !encodes && kind != MSM_NAF && max_count && (uint64_t)quad_blocks * njobs <= 512) {   // (1024: 512-item calls gain 7 %, 16-shape requests lose 14 %)
+  // (a plan on its own up to 1024 blocks: 512-item calls gain 7 %; merged launches up to 512: at 1024 a 16-shape request loses 14 %)
+  if (quad_on && !encodes && kind != MSM_NAF && max_count && (uint64_t)quad_blocks * njobs <= (rows ? 512u : 1024u)) {
     const dim3 qgrid(quad_blocks, njobs);
     if (!rows) {
       if (!pass_host) return hipErrorInvalidValue;
