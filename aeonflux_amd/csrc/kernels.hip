@@ -1310,8 +1310,8 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_hash(const afx_hash_program* __re
 // k_hash_coop: the same transcripts for SMALL passes, 32 lanes per (item, program).  One lane per item runs its 20-80
 // permutations one after the other - 13.6 us each on an otherwise idle SIMD, 1.1 ms of the 2.9 ms a small issue call takes - and
 // a sponge cannot be cut into independent pieces; what can be spread is the permutation itself.  Lane w < 25 of a group holds word
-// w = x + 5y of the state: theta's column parities, the rho/pi move and chi's row neighbours are lane shuffles (9 64-bit shuffles
-// a round), every lane absorbs its own word of a rate block (afx_hash_word is per word already), lane 0 reduces what is squeezed.
+// w = x + 5y of the state: theta's column parities, the rho/pi move and chi's row neighbours are lane moves (round 4: 3 64-bit
+// shuffles and 12 DPP moves a round, below; 9 shuffles before), every lane absorbs its own word of a rate block (afx_hash_word is per word already), lane 0 reduces what is squeezed.
 // Only while the device has lanes to spare: the engine launches it for at most AFX_HASH_COOP_GROUPS (item, program) pairs (engine.cpp).
 __device__ __constant__ const uint8_t KECCAK_RHO[25] = { 0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14 };
 // word w of the state after rho+pi comes from word KECCAK_PI_SRC[w] (b[y + 5*((2x+3y)%5)] = rotl(a[x+5y]), keccak.cuh)
@@ -1320,6 +1320,25 @@ AFX_DEV uint64_t shfl64(uint64_t v, uint32_t src) {
   const uint32_t lo = __shfl((uint32_t)v, (int)src, 32), hi = __shfl((uint32_t)(v >> 32), (int)src, 32);
   return (uint64_t)lo | ((uint64_t)hi << 32);
 }
+// The words of a row of five sit in five neighbouring lanes INSIDE one 16-lane DPP row (lane 15 of a group is skipped: words 0..14
+// in lanes 0..14, words 15..24 in lanes 16..25), so that theta's and chi's row neighbours are data-parallel-primitive moves at
+// VALU rate - a shift by the distance, or by the distance minus five where the row wraps - instead of trips through the LDS
+// crossbar, of which a lone wave gets one per ~38 cycles; the column parities need two shuffles (their halves inside the two DPP rows are
+// shifts as well) and pi one: 3 of the 9 a round.
+AFX_DEV uint32_t kc_lane(uint32_t w) { return w + (w >= 15u ? 1u : 0u); }
+template <int CTRL>
+AFX_DEV uint64_t kc_row_shift(uint64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, true), hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, true);
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+template <int NEAR, int WRAP>
+AFX_DEV uint64_t kc_row_fetch(uint64_t v, bool wraps) {
+  const int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+  const uint32_t nl = (uint32_t)__builtin_amdgcn_update_dpp(0, lo, NEAR, 0xf, 0xf, true), nh = (uint32_t)__builtin_amdgcn_update_dpp(0, hi, NEAR, 0xf, 0xf, true);
+  const uint32_t wl = (uint32_t)__builtin_amdgcn_update_dpp(0, lo, WRAP, 0xf, 0xf, true), wh = (uint32_t)__builtin_amdgcn_update_dpp(0, hi, WRAP, 0xf, 0xf, true);
+  return (uint64_t)(wraps ? wl : nl) | ((uint64_t)(wraps ? wh : nh) << 32);
+}
+enum { KC_SHL1 = 0x101, KC_SHL2 = 0x102, KC_SHL4 = 0x104, KC_SHL5 = 0x105, KC_SHL10 = 0x10a, KC_SHR1 = 0x111, KC_SHR3 = 0x113, KC_SHR4 = 0x114 };   // row_shl:n = 0x100 + n (lane i reads lane i + n), row_shr:n = 0x110 + n
 __global__ void __launch_bounds__(AFX_BLOCK) k_hash_coop(const afx_hash_program* __restrict__ progs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
   const afx_hash_program* prog = row_job(progs, rows);
   const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
@@ -1330,11 +1349,9 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_hash_coop(const afx_hash_program*
   const uint32_t group = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
   const bool live = group < count;                      // a whole group is live or not; dead groups shadow the last item and store nothing
   const uint32_t item = live ? group : count - 1;
-  const bool holds = g < 25;                            // lanes 25..31 take part in the shuffles only (never as a source)
-  const uint32_t w = holds ? g : 24u, x = w % 5u, y = w / 5u;
-  const uint32_t rho = KECCAK_RHO[w], pi_src = KECCAK_PI_SRC[w];
-  const uint32_t col1 = (w + 5u) % 25u, col2 = (w + 10u) % 25u, col3 = (w + 15u) % 25u, col4 = (w + 20u) % 25u;
-  const uint32_t left = 5u * y + (x + 4u) % 5u, right = 5u * y + (x + 1u) % 5u, right2 = 5u * y + (x + 2u) % 5u;
+  const bool holds = g < 15u || (g >= 16u && g <= 25u);   // lanes 15 and 26..31 take part in the shuffles only (never as a source)
+  const uint32_t w = !holds ? 24u : g < 15u ? g : g - 1u, x = w % 5u;
+  const uint32_t rho = KECCAK_RHO[w], pi_src = kc_lane(KECCAK_PI_SRC[w]);
   uint64_t st = prog->load_state ? prog->load_state[(size_t)w * count + item] : prog->init_state[w];
   const uint32_t nrec = prog->n_records;
 #pragma unroll 1
@@ -1354,17 +1371,19 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_hash_coop(const afx_hash_program*
       }
       st = (st & hw.keep) ^ v;
     }
-#pragma unroll 1
-    for (int round = 0; round < 24; round++) {
-      // theta: every lane of column x ends up with the column's parity
-      const uint64_t c = st ^ shfl64(st, col1) ^ shfl64(st, col2) ^ shfl64(st, col3) ^ shfl64(st, col4);
-      const uint64_t cr = shfl64(c, right);
-      st ^= shfl64(c, left) ^ ((cr << 1) | (cr >> 63));
+#pragma unroll
+    for (int round = 0; round < 24; round++) {   // unrolled: the round constants become literals (a scalar load and its wait a round otherwise)
+      // theta: the parity of the column's words inside each DPP row lands on the row's first five lanes (words y = 0, 1, 2 on lanes
+      // 0..4; y = 3, 4 on lanes 16..20) by two shifts, and every lane of column x fetches the two halves: 2 shuffles, not 4
+      const uint64_t p = st ^ kc_row_shift<KC_SHL5>(st) ^ (g < 16u ? kc_row_shift<KC_SHL10>(st) : 0ull);
+      const uint64_t c = shfl64(p, x) ^ shfl64(p, 16u + x);
+      const uint64_t cr = kc_row_fetch<KC_SHL1, KC_SHR4>(c, x == 4u);   // column x + 1
+      st ^= kc_row_fetch<KC_SHR1, KC_SHL4>(c, x == 0u) ^ ((cr << 1) | (cr >> 63));   // column x - 1
       // rho on the own word, pi as a shuffle
       const uint64_t rot = rho ? ((st << rho) | (st >> (64u - rho))) : st;
       const uint64_t b = shfl64(rot, pi_src);
       // chi along the row, iota on word 0
-      st = b ^ (~shfl64(b, right) & shfl64(b, right2));
+      st = b ^ (~kc_row_fetch<KC_SHL1, KC_SHR4>(b, x == 4u) & kc_row_fetch<KC_SHL2, KC_SHR3>(b, x >= 3u));
       if (w == 0u) st ^= KECCAK_RC[round];
     }
     if (rec->squeeze != AFX_SQ_NONE) {   // uniform: a property of the record
