@@ -5,11 +5,14 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <array>
+#include <chrono>
+#include <condition_variable>
 #include <map>
 #include <memory>
 #include <set>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/aeonflux_gpu.h"
 #include "kernels.h"
@@ -49,7 +52,31 @@ namespace afx { struct Plan; struct Session; }
 struct Stager;
 
 struct afx_ctx {
-  std::recursive_mutex mu;   // one call at a time per context (workspace, staging and the plan ring are shared)
+  std::recursive_mutex mu;   // the context's host state (workspace, staging, plan ring and cache) has one user at a time; see `co` below
+  int lock_depth = 0;        // how many CtxLocks (statements.hpp) the thread that owns `mu` holds; 0 while it waits on co.cv
+  // Concurrent small calls.  Issuer::verify takes `&self`, has no interior state and is called one presentation at a time from as
+  // many threads as the server has (/root/reference/src/issuer.rs:141-147; Issuer::issue :111-124, AnonymousCredential::show
+  // src/credential.rs:37-46 likewise).  A mutex around the whole call would give such a server the rate of ONE call however many
+  // threads it has.  Instead a small host-pointer call that finds the context busy JOINS the session that is collecting (statements.hpp
+  // afx::Session; plans.cpp coalesced_call): it holds `mu` only while it stages its rows - into free item slots of a same-shape
+  // call's arrays when there are any, so that 64 callers of one shape become ONE pass of 64 items - and then sleeps on `cv` until
+  // the flush that carries its rows has completed.  One leader per session (the caller that opened it) launches it: at once while
+  // the device is idle, otherwise when the session ahead of it completes, it fills up, or `max_wait_us` have passed; the device
+  // wait itself runs without `mu`, so the next session collects (on the other lane) while this one computes.
+  struct Coalesce {
+    bool enabled = true;
+    uint32_t max_wait_us = 2000;      // a collecting session waits at most this long for the launches ahead of it
+    uint32_t max_items = 4096;        // items per session: a session that reaches them is launched whatever is in flight
+    uint32_t max_call_items = 512;    // larger calls fill the device by themselves: they run alone
+    std::condition_variable_any cv;   // waits on `mu`: session completed / lane free / exclusive caller done
+    std::shared_ptr<afx::Session> open;   // the session that collects, or null
+    int inflight = 0;                 // sessions launched and not yet completed
+    bool lane_busy[2] = { false, false };   // a session (collecting or in flight) owns the lane's staging images
+    int exclusive_waiters = 0;        // callers that need the whole context (large batches, setters): no new session opens meanwhile
+    std::map<std::string, uint32_t> demand;   // by join key: the items the last session carried (the item slots the next one starts with)
+    uint32_t last_waves = 0, last_plans = 0;  // width of the last session launched: the merge class the next one assembles for
+    uint64_t n_sessions = 0, n_calls = 0, n_items = 0, n_appended = 0, n_max_calls = 0, n_waited_flushes = 0;   // afx_ctx_get_coalescing_stats
+  } co;
   int device = 0;
   hipStream_t stream = nullptr;
   uint32_t n = 0, g = 0;

@@ -5,7 +5,6 @@
 // the caller's order.  Only bytes move on the host (record copies when a shape's sections are not adjacent).
 #include <map>
 #include <memory>
-#include <mutex>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -48,10 +47,10 @@ int run_groups(afx_ctx* ctx, G* groups, size_t n_groups, uint8_t* status, size_t
   if ((!groups && n_groups) || (!status && status_len)) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   int rc = check_positions(groups, n_groups, status_len);
   if (rc) return rc;
-  std::unique_lock<std::recursive_mutex> lock;
+  std::unique_ptr<CtxLock> lock;
   std::unique_ptr<afx::Session> ses;
-  if (ctx && n_groups > 1 && ctx->small_batch_items && !ctx->trace && !ctx->session) {
-    lock = std::unique_lock<std::recursive_mutex>(ctx->mu);   // the session owns the context until its last flush
+  if (ctx && n_groups > 1) lock.reset(new CtxLock(ctx));   // the session owns the context until its last flush
+  if (lock && ctx->small_batch_items && !ctx->trace && !ctx->session) {
     ses.reset(new afx::Session(ctx));
     if ((rc = ses->ensure_images(0, 0))) return rc;
     // how wide the merged launches will be, in 64-lane waves per grid row: the latency plans of the collected groups cut a stage's
@@ -275,11 +274,11 @@ static int mixed_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* st
   *count_out = total;
   if (total > status_cap) { set_error("status buffer too small"); return AFX_E_BAD_ARGS; }
   // with a context: the small groups are collected and run as one set of launches (see run_groups)
-  std::unique_lock<std::recursive_mutex> lock;
+  std::unique_ptr<CtxLock> lock;
   std::unique_ptr<afx::Session> ses;
   int rc = AFX_OK;
-  if (ctx && order.size() > 1 && ctx->small_batch_items && !ctx->trace && !ctx->session) {
-    lock = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  if (ctx && order.size() > 1) lock.reset(new CtxLock(ctx));
+  if (lock && ctx->small_batch_items && !ctx->trace && !ctx->session) {
     ses.reset(new afx::Session(ctx));
     if ((rc = ses->ensure_images(0, 0))) return rc;
     uint64_t width = 0;   // as in run_groups

@@ -43,6 +43,9 @@ int assemble(afx_ctx* c, const BuildFn& build, size_t off, uint32_t cc, const St
 int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, const PlanKey& key) {
   AFX_HIP(hipSetDevice(c->device));
   Stager* st = c->cur_stager;
+  // the call took free item slots of a pass another call of this statement, shape and mode has already left with the session
+  // (afx::Session::Slots): that pass's plan covers its items too
+  if (st && st->app) return AFX_OK;
   afx::Session* ses = (c->session && !c->session->paused) ? c->session : nullptr;
   // all chunks of one call run on one lane; calls alternate lanes only when the caller switched pipelining on
   const int lane = ses ? ses->lane : (c->force_lane >= 0 ? c->force_lane : (c->pipelining ? (int)(c->lane_next++ & 1u) : 0));
@@ -53,7 +56,8 @@ int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, const PlanKey& k
       // a small host-pointer call (one pass, arrays staged by a Stager): its plan is kept and reused
       const bool reusable = !key.empty() && st && st->uploaded && cc == count && c->small_batch_items && cc <= c->small_batch_items && !c->trace;
       std::unique_ptr<Plan> plan(new Plan());
-      const std::pair<PlanKey, uint32_t> ck(key, cc);
+      // (the staging layout is part of the key: the column-array and the serialized front ends of one statement stage differently)
+      const std::pair<PlanKey, uint32_t> ck(reusable ? key + (char)('0' + st->layout_tag) : key, cc);
       auto hit = reusable ? c->plan_cache.find(ck) : c->plan_cache.end();
       if (hit != c->plan_cache.end() && hit->second->in_bytes == st->in_bytes && hit->second->out_bytes == st->out_bytes) {
         *plan = *hit->second;
@@ -118,10 +122,25 @@ static int ensure_pinned(void*& buf, size_t& cap, size_t bytes, size_t granule) 
 
 int Stager::upload() {
   afx_ctx::Lane& L = c->lane[ln];
+  if (ses && app) {
+    // item slots of an existing group: nothing is written before the call is known to fit them
+    if (mismatch || op_i != app->ops.size()) return afx::AFX_RETRY_NOAPPEND;
+    in_at = app->in_at; out_at = app->out_at;
+    in_bytes = app->in_bytes; out_bytes = app->out_bytes;
+    uint8_t* img = (uint8_t*)L.pin_in + in_at;
+    for (const Copy& k : copies)
+      if (k.constant && memcmp(img + k.off, k.src, k.len) != 0) return afx::AFX_RETRY_NOAPPEND;
+    for (const Copy& k : copies)
+      if (!k.constant) memcpy(img + k.off, k.src, k.len);
+    uploaded = true;
+    return AFX_OK;
+  }
   if (ses) {
     // this call's regions inside the session's images; a session that cannot take them is flushed first (and, empty, grown)
     size_t ia = (ses->in_used + 255) & ~size_t(255), oa = (ses->out_used + 255) & ~size_t(255);
     if (ia + in_bytes + 256 > L.staging.cap || oa + out_bytes + 256 > L.staging_out.cap || ia + in_bytes > L.pin_in_cap || oa + out_bytes > L.pin_cap) {
+      // (a shared session has other callers' rows in it: they are launched by its leader, this call goes to the next session)
+      if (ses->shared && !ses->empty()) return afx::AFX_RETRY_FULL;
       int rc = ses->flush();
       if (rc) return rc;
       if ((rc = ses->ensure_images(in_bytes + 256, out_bytes + 256))) return rc;
@@ -208,11 +227,141 @@ int Stager::drain() {
 // ------------------------------------------------------------------------------------------------
 // host_pipe
 // ------------------------------------------------------------------------------------------------
-int host_pipe(afx_ctx* c, size_t count, const std::function<int(Stager&, size_t, size_t)>& slice) {
+namespace {
+using SliceFn = std::function<int(Stager&, size_t, size_t)>;
+
+// One small host-pointer call on a context other threads are calling too (afx_ctx::co has the protocol).  Entered with c->mu
+// held once; returns with it held once.
+int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey& jkey) {
+  afx_ctx::Coalesce& co = c->co;
+  using clock = std::chrono::steady_clock;
+  const std::thread::id me = std::this_thread::get_id();
+  std::shared_ptr<afx::Session> S;
+  bool no_append = false;
+  for (;;) {
+    // ---- a session to stage into: the one that collects, or a new one on a free lane
+    while (!co.open) {
+      const int lane = co.exclusive_waiters ? -1 : !co.lane_busy[0] ? 0 : !co.lane_busy[1] ? 1 : -1;
+      if (lane < 0) { CtxLock::wait(c); continue; }
+      AFX_HIP(hipSetDevice(c->device));
+      std::shared_ptr<afx::Session> n(new afx::Session(c, true));
+      n->lane = lane;
+      const int rc = n->ensure_images(0, 0);
+      if (rc) return rc;
+      n->leader = me;
+      n->deadline = clock::now() + std::chrono::microseconds(co.max_wait_us);
+      // the launches this session's plans will share, guessed from the last one's (afx_ctx::merge_class: how long the chains of a
+      // latency plan are; results do not depend on it)
+      n->mclass = co.last_plans > 1 ? afx_ctx::merge_class_of(co.last_waves) : 0;
+      co.open = n;
+      co.lane_busy[lane] = true;
+      co.n_sessions++;
+    }
+    S = co.open;
+    if (S->full) { CtxLock::wait(c); continue; }   // its leader is about to launch it
+    // ---- stage this call's rows (and, unless they went into another call's free item slots, its plan)
+    int rc;
+    bool appended = false;
+    {
+      struct Staging {   // the context collects into S for exactly this scope
+        afx_ctx* c;
+        Staging(afx_ctx* ctx, afx::Session* s) : c(ctx) { c->session = s; c->merge_class = s->mclass; }
+        ~Staging() { c->session = nullptr; c->merge_class = 0; }
+      } staging(c, S.get());
+      Stager st(c, S->lane, S.get());
+      if (!jkey.empty() && !no_append)
+        for (afx::Session::Slots& g : S->slots)
+          if (g.key == jkey && g.dn - g.used >= count) { st.app = &g; st.slot = g.used; break; }
+      if (!st.app && !jkey.empty()) {
+        auto d = co.demand.find(jkey);
+        if (d != co.demand.end()) st.slots_hint = d->second;
+      }
+      // (nothing may leave this function by exception: a session whose leader is gone would never be launched)
+      try { rc = slice(st, 0, count); } catch (...) { rc = afx::exception_rc(); }
+      if (!rc) {
+        if (st.app) { st.app->used += (uint32_t)count; appended = true; }
+        else if (!jkey.empty() && st.last_dn && st.uploaded)
+          S->slots.push_back({ jkey, st.ops, st.in_at, st.out_at, st.in_bytes, st.out_bytes, st.last_dn, (uint32_t)count });
+      }
+    }
+    if (rc == afx::AFX_RETRY_NOAPPEND && !no_append) { no_append = true; continue; }
+    if (rc == afx::AFX_RETRY_FULL) {
+      S->full = true;
+      co.cv.notify_all();
+      while (co.open == S) CtxLock::wait(c);
+      continue;
+    }
+    if (rc) {
+      if (rc == afx::AFX_RETRY_NOAPPEND) { set_error("internal: a call does not reproduce its own staging layout"); rc = AFX_E_BAD_ARGS; }
+      // nothing of this call is in the session (a plan is left with it last); a session its opener could not use is given up
+      if (S->leader == me && S->calls == 0) {
+        S->drop();
+        S->state = afx::Session::DONE;
+        co.open.reset();
+        co.lane_busy[S->lane] = false;
+        co.cv.notify_all();
+      }
+      return rc;
+    }
+    S->calls++;
+    S->items += count;
+    if (!jkey.empty()) S->key_items[jkey] += (uint32_t)count;
+    co.n_calls++; co.n_items += count; co.n_appended += appended;
+    if (S->items >= co.max_items) { S->full = true; co.cv.notify_all(); }
+    break;
+  }
+  // ---- the leader launches; everybody waits for the flush that carries their rows
+  while (S->state != afx::Session::DONE) {
+    if (S->leader != me || S->state != afx::Session::COLLECTING) { CtxLock::wait(c); continue; }
+    const bool go = S->full || S->hurry || co.inflight == 0 || clock::now() >= S->deadline;
+    if (!go) { co.n_waited_flushes++; CtxLock::wait_until(c, S->deadline); continue; }
+    S->state = afx::Session::LAUNCHING;
+    co.open.reset();
+    co.inflight++;
+    uint64_t waves = 0;
+    for (const auto& p : S->plans) waves += (p->count + 63) / 64;
+    co.last_waves = (uint32_t)waves;
+    co.last_plans = (uint32_t)S->plans.size();
+    for (const auto& kv : S->key_items) co.demand[kv.first] = kv.second;
+    if (co.demand.size() > 4096) co.demand.clear();   // (keys come from callers' shapes)
+    co.n_max_calls = std::max<uint64_t>(co.n_max_calls, S->calls);
+    int rc = S->launch();
+    S->state = afx::Session::INFLIGHT;
+    {
+      // the device wait and the scatter of the results run without the context: the next session collects meanwhile
+      const int d = c->lock_depth;
+      c->lock_depth = 0;
+      c->mu.unlock();
+      rc = S->complete(rc);
+      std::string err = rc ? afx_last_error() : "";
+      c->mu.lock();
+      c->lock_depth = d;
+      S->rc = rc;
+      S->err.swap(err);
+    }
+    S->state = afx::Session::DONE;
+    co.inflight--;
+    co.lane_busy[S->lane] = false;
+    co.cv.notify_all();
+  }
+  if (S->rc) set_error(S->err);
+  return S->rc;
+}
+}  // namespace
+
+int host_pipe(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey& join_key) {
   if (c->session && !c->session->paused) {
     // collected: one slice, staged into the session's images; nothing is waited for here
     Stager st(c, c->session->lane, c->session);
     return slice(st, 0, count);
+  }
+  if (c->lock_depth == 1) {
+    // the outermost call on this context: a small one joins the other threads' small calls, anything else needs the context to itself
+    const afx_ctx::Coalesce& co = c->co;
+    if (co.enabled && co.max_items && count && count <= co.max_call_items && c->small_batch_items && count <= c->small_batch_items && !c->trace &&
+        !c->pipelining && !c->cur_stager)
+      return coalesced_call(c, count, slice, join_key);
+    CtxLock::quiesce(c);
   }
   const int entry_force = c->force_lane;
   Stager* const entry_stager = c->cur_stager;
@@ -269,7 +418,7 @@ int afx::Session::ensure_images(size_t in_bytes, size_t out_bytes) {
   return ensure_pinned(L.pin, L.pin_cap, out_bytes, size_t(1) << 20);
 }
 
-int afx::Session::flush() {
+int afx::Session::launch() {
   if (empty()) return AFX_OK;
   afx_ctx::Lane& L = c->lane[lane];
   hipStream_t s = L.stream;
@@ -285,7 +434,15 @@ int afx::Session::flush() {
     rc = run_plans(c, lane, ps.data(), ps.size());
   }
   if (!rc && out_used && !outs.empty()) AFX_HIP(hipMemcpyAsync(L.pin, L.staging_out.p, out_used, hipMemcpyDeviceToHost, s));
-  const hipError_t e = hipStreamSynchronize(s);
+  return rc;
+}
+
+int afx::Session::complete(int rc) {
+  if (empty()) return rc;
+  afx_ctx::Lane& L = c->lane[lane];
+  (void)hipSetDevice(c->device);
+  // whatever was enqueued before a failure is waited for too: the callers' arrays and the images are reused after this
+  const hipError_t e = hipStreamSynchronize(L.stream);
   if (!rc && e != hipSuccess) { set_error(std::string("hipStreamSynchronize: ") + hipGetErrorString(e)); rc = AFX_E_HIP; }
   if (!rc)
     for (const Out& o : outs) memcpy(o.dst, (const uint8_t*)L.pin + o.pin_off, o.len);

@@ -56,7 +56,7 @@ static int drain_timing(afx_ctx* c) {
 }
 extern "C" int afx_ctx_set_pipelining(afx_ctx* c, int enable) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  CtxLock lock(c);
   AFX_HIP(hipSetDevice(c->device));
   for (auto& L : c->lane)
     if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
@@ -67,7 +67,7 @@ extern "C" int afx_ctx_set_pipelining(afx_ctx* c, int enable) try {
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_set_challenge_trace(afx_ctx* c, size_t rows, size_t count) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  CtxLock lock(c);
   AFX_HIP(hipSetDevice(c->device));
   for (auto& L : c->lane)
     if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
@@ -84,7 +84,7 @@ extern "C" int afx_ctx_set_challenge_trace(afx_ctx* c, size_t rows, size_t count
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_get_challenge_trace(afx_ctx* c, uint8_t* host_out) try {
   if (!c || !host_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  CtxLock lock(c);
   if (!c->trace) { set_error("challenge trace is off"); return AFX_E_BAD_ARGS; }
   AFX_HIP(hipSetDevice(c->device));
   for (auto& L : c->lane)
@@ -94,25 +94,40 @@ extern "C" int afx_ctx_get_challenge_trace(afx_ctx* c, uint8_t* host_out) try {
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_set_chunk_items(afx_ctx* c, uint32_t items) try {
   if (!c || (items != 0 && (items < 256 || items > (1u << 22)))) { set_error("chunk size out of range"); return AFX_E_BAD_ARGS; }
-  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  CtxLock lock(c);
   c->chunk_items = items;
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_set_small_batch_items(afx_ctx* c, uint32_t items) try {
   if (!c || items > (1u << 16)) { set_error("small-batch threshold out of range"); return AFX_E_BAD_ARGS; }
-  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  CtxLock lock(c);
   c->small_batch_items = items;
+  return AFX_OK;
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_set_coalescing(afx_ctx* c, uint32_t max_wait_us, uint32_t max_items) try {
+  if (!c || max_items > (1u << 16) || max_wait_us > 1000000u) { set_error("coalescing bounds out of range"); return AFX_E_BAD_ARGS; }
+  CtxLock lock(c);   // (waits for the sessions in flight)
+  c->co.enabled = max_items != 0;
+  c->co.max_wait_us = max_wait_us;
+  if (max_items) c->co.max_items = max_items;
+  return AFX_OK;
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_get_coalescing_stats(afx_ctx* c, afx_coalescing_stats* out) try {
+  if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  CtxLock lock(c, true);   // (a reader: no need to wait for the sessions in flight)
+  const afx_ctx::Coalesce& co = c->co;
+  *out = afx_coalescing_stats{ co.n_sessions, co.n_calls, co.n_items, co.n_appended, co.n_max_calls, co.n_waited_flushes };
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_set_strict(afx_ctx* c, int enable) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  CtxLock lock(c);
   c->strict = enable != 0;
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_set_fixed_key_schedule(afx_ctx* c, int enable) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  CtxLock lock(c);
   c->fixed_key_schedule = enable != 0;
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
@@ -133,20 +148,20 @@ static int build_secret_tables(afx_ctx* c) {
 extern "C" int afx_ctx_set_secret_independent_addressing(afx_ctx* c, int mode) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (mode < 0 || mode > 2) { set_error("mode must be 0 (nowhere), 1 (everywhere) or 2 (the prover-side calls: the default)"); return AFX_E_BAD_ARGS; }
-  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  CtxLock lock(c);
   if (mode) { const int rc = build_secret_tables(c); if (rc) return rc; }
   c->secret_mode = mode;
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_get_plan_stats(afx_ctx* c, afx_plan_stats* out) try {
   if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  CtxLock lock(c);
   *out = c->last_stats;
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_synchronize(afx_ctx* c) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  CtxLock lock(c);
   AFX_HIP(hipSetDevice(c->device));
   for (auto& L : c->lane)
     if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
@@ -154,7 +169,7 @@ extern "C" int afx_ctx_synchronize(afx_ctx* c) try {
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_set_timing(afx_ctx* c, int enable) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  CtxLock lock(c);
   AFX_HIP(hipSetDevice(c->device));
   int rc = drain_timing(c);
   if (rc) return rc;
@@ -165,7 +180,7 @@ extern "C" int afx_ctx_set_timing(afx_ctx* c, int enable) try {
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_get_core_clock_mhz(afx_ctx* c, double* mhz) try {
   if (!c || !mhz) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  CtxLock lock(c);
   AFX_HIP(hipSetDevice(c->device));
   for (auto& L : c->lane)
     if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
@@ -176,7 +191,7 @@ extern "C" int afx_ctx_get_core_clock_mhz(afx_ctx* c, double* mhz) try {
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_get_timing(afx_ctx* c, const char* kernel, double* total_ms, uint64_t* launches) try {
   if (!c || !kernel || !total_ms || !launches) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  CtxLock lock(c);
   AFX_HIP(hipSetDevice(c->device));
   int rc = drain_timing(c);
   if (rc) return rc;
@@ -566,8 +581,7 @@ static void build_presentation_verify(Assembler& as, const afx_shape& sh, const 
 
 extern "C" int afx_verify_presentations_dev(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* batch, size_t count,
                                             uint8_t* status_dev) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx);
   if (!ctx || !shape || !batch || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (!ctx->has_key) { set_error("Issuer::verify needs the issuer key"); return AFX_E_NO_KEY; }
   if (count == 0) return AFX_OK;
@@ -603,8 +617,7 @@ extern "C" int afx_verify_presentations_dev(afx_ctx* ctx, const afx_shape* shape
 } catch (...) { return afx::exception_rc(); }
 
 extern "C" int afx_verify_encryption_proofs_dev(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* batch, size_t count, uint8_t* status_dev) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx);
   if (!ctx || !batch || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   const afx_encproof_soa e = *batch;
@@ -650,6 +663,9 @@ static int verify_presentations_host(afx_ctx* ctx, const afx_shape* shape, const
   }
   const uint32_t na = shape->n_attributes, nr = shape->n_responses, ne = shape->n_enc_proofs;
   if (!b->challenge || !b->C_x_0 || !b->C_x_1 || !b->C_V || (na && !b->C_y) || (nr && !b->responses) || (ne && !b->enc)) { set_error("null batch array"); return AFX_E_BAD_ARGS; }
+  // what makes two calls one pass (statements.hpp host_pipe): the statement, the shape's used fields, the mode, the optional array
+  const afx_shape jsh = canonical_shape(*shape);
+  const PlanKey jkey = plan_key("V", &jsh, sizeof jsh, mode_flags(ctx) | (b->attr_values ? (uint64_t)1 << 63 : 0));
   return host_pipe(ctx, n, [&](Stager& st, size_t off, size_t sn) -> int {
     const size_t f0 = first + off;
     const size_t dn = st.dev_items(sn);   // the pass's size on the device: small calls are padded to the size their plan is kept for
@@ -668,13 +684,12 @@ static int verify_presentations_host(afx_ctx* ctx, const afx_shape* shape, const
     afx_presentation_soa d = { st.dev(o_ch), st.dev(o_rs), st.dev(o_x0), st.dev(o_x1), st.dev(o_cv), st.dev(o_cy), b->attr_values ? st.dev(o_av) : nullptr, de.data() };
     if ((rc = afx_verify_presentations_dev(ctx, shape, &d, dn, st.dev(o_st)))) return rc;
     return st.fetch_all();
-  });
+  }, jkey);
 }
 
 extern "C" int afx_verify_presentations_range(afx_ctx* ctx, const afx_shape* shape, const afx_presentation_soa* b, size_t total, size_t first,
                                               size_t n, uint8_t* status) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx, true);
   if (!ctx || !shape || !b || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (first > total || n > total - first) { set_error("range outside the batch"); return AFX_E_BAD_ARGS; }
   return verify_presentations_host(ctx, shape, b, total, first, n, status);
@@ -684,8 +699,7 @@ extern "C" int afx_verify_presentations(afx_ctx* ctx, const afx_shape* shape, co
 } catch (...) { return afx::exception_rc(); }
 
 extern "C" int afx_verify_encryption_proofs(afx_ctx* ctx, uint16_t index, const afx_encproof_soa* b, size_t count, uint8_t* status) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx);
   if (!ctx || !b || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -706,8 +720,7 @@ extern "C" int afx_verify_encryption_proofs(afx_ctx* ctx, uint16_t index, const 
 // batch primitives (K* rows): from_uniform_bytes, from_bytes_mod_order_wide, decompress/compress, MSM
 // ------------------------------------------------------------------------------------------------
 extern "C" int afx_points_from_uniform_bytes(afx_ctx* ctx, const uint8_t* wide, size_t count, uint8_t* out) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx);
   if (!ctx || !wide || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -721,8 +734,7 @@ extern "C" int afx_points_from_uniform_bytes(afx_ctx* ctx, const uint8_t* wide, 
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_scalars_from_wide_bytes(afx_ctx* ctx, const uint8_t* wide, size_t count, uint8_t* out) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx);
   if (!ctx || !wide || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -736,8 +748,7 @@ extern "C" int afx_scalars_from_wide_bytes(afx_ctx* ctx, const uint8_t* wide, si
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_points_validate(afx_ctx* ctx, const uint8_t* pts, size_t count, uint8_t* ok, uint8_t* reencoded) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx);
   if (!ctx || !pts || !ok) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -752,8 +763,7 @@ extern "C" int afx_points_validate(afx_ctx* ctx, const uint8_t* pts, size_t coun
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_multiscalar_mul(afx_ctx* ctx, uint32_t n_terms, const uint8_t* scalars, const uint8_t* points, size_t count, uint8_t* out, uint8_t* ok) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx);
   if (!ctx || !scalars || !points || !out || !ok) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (n_terms == 0 || n_terms > AFX_MSM_MAX_TERMS) { set_error("n_terms out of range"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
@@ -851,25 +861,29 @@ static int verify_wire_records(afx_ctx* ctx, const afx_shape& sh, const uint8_t*
   if (row_of_cell.size() != cells) { set_error("internal: wire cell map"); return AFX_E_BAD_ARGS; }
   // records are contiguous: a slice of the batch is a byte range of the blob; slices alternate between the two lanes like
   // those of the column-array calls (statements.hpp host_pipe), each transposed on the GPU into its own SoA scratch
+  const afx_shape jsh = canonical_shape(sh);
+  const PlanKey jkey = plan_key("VW", &jsh, sizeof jsh, mode_flags(ctx));
   return host_pipe(ctx, n, [&](Stager& st, size_t off, size_t sn) -> int {
     const size_t f0 = first + off;
-    const size_t o_rec = st.add(records + f0 * cells * 32, sn * cells * 32), o_map = st.add((const uint8_t*)row_of_cell.data(), 4 * (size_t)cells),
-                 o_soa = st.reserve(sn * rows * 32), o_st = st.add(nullptr, sn);
-    st.plan_fetch(status, o_st, 1, 1, count, f0, sn);
+    st.layout_tag = 1;
+    const size_t dn = st.dev_items(sn);
+    const size_t o_rec = st.add_rows(records, 1, (size_t)cells * 32, count, f0, sn, dn), o_map = st.add((const uint8_t*)row_of_cell.data(), 4 * (size_t)cells),
+                 o_soa = st.reserve(dn * rows * 32), o_st = st.add(nullptr, dn);
+    st.plan_fetch(status, o_st, 1, 1, count, f0, sn, dn);
     int rc2 = st.upload();
     if (rc2) return rc2;
-    {
+    if (!st.app) {   // (a call that took item slots of an earlier call's pass: that call's transposition covers them)
       // the transposition reads what the upload brings: under a Session it waits for the session's one upload
       hipStream_t strm = st.stream();
       const uint8_t* rec_d = st.dev(o_rec);
       uint8_t* soa_d = st.dev(o_soa);
       const uint32_t* map_d = (const uint32_t*)st.dev(o_map);
-      const uint32_t cells_ = cells, sn_ = (uint32_t)sn;
-      auto transpose = [=]() -> int { AFX_HIP(afxk_aos_to_soa(strm, rec_d, soa_d, map_d, cells_, sn_)); return AFX_OK; };
+      const uint32_t cells_ = cells, dn_ = (uint32_t)dn;
+      auto transpose = [=]() -> int { AFX_HIP(afxk_aos_to_soa(strm, rec_d, soa_d, map_d, cells_, dn_)); return AFX_OK; };
       if (st.ses) st.ses->pre.push_back(transpose);
       else if ((rc2 = transpose())) return rc2;
     }
-    auto rowp = [&](uint32_t r) { return (const uint8_t*)st.dev(o_soa) + (size_t)r * sn * 32; };
+    auto rowp = [&](uint32_t r) { return (const uint8_t*)st.dev(o_soa) + (size_t)r * dn * 32; };
     afx_presentation_soa d;
     d.challenge = rowp(0);
     d.responses = rowp(row_resp);
@@ -882,14 +896,13 @@ static int verify_wire_records(afx_ctx* ctx, const afx_shape& sh, const uint8_t*
       encs[e] = { rowp(r), rowp(r + 1), rowp(r + 7), rowp(r + 8), rowp(r + 9), rowp(r + 10), rowp(r + 11), rowp(r + 12), rowp(r + 13) };
     }
     d.enc = encs.data();
-    if ((rc2 = afx_verify_presentations_dev(ctx, &sh, &d, sn, st.dev(o_st)))) return rc2;
+    if ((rc2 = afx_verify_presentations_dev(ctx, &sh, &d, dn, st.dev(o_st)))) return rc2;
     return st.fetch_all();
-  });
+  }, jkey);
 }
 extern "C" int afx_verify_presentations_wire_range(afx_ctx* ctx, const uint8_t* blob, size_t len, size_t first, size_t n, uint8_t* status, size_t status_cap,
                                                    size_t* count_out) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx, true);
   if (!ctx || !status || !count_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   afx_shape sh;
   size_t count = 0, off = 0;
@@ -936,8 +949,7 @@ extern "C" int afx_issuance_wire_parse(const uint8_t* blob, size_t len, uint32_t
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_verify_issuances_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx, true);
   if (!ctx || !status || !count_out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   afx_attributes_soa at;
   memset(&at, 0, sizeof at);
@@ -953,34 +965,40 @@ extern "C" int afx_verify_issuances_wire(afx_ctx* ctx, const uint8_t* blob, size
   const uint32_t n = at.n_attributes, cells = 4 + nr + n;
   std::vector<uint32_t> row_of_cell(cells);
   for (uint32_t r = 0; r < cells; r++) row_of_cell[r] = r;   // SoA rows in record order: t U V challenge responses[] values[]
+  struct { uint32_t n, nr; uint8_t kinds[AFX_MAX_ATTRIBUTES]; } jd;
+  memset(&jd, 0, sizeof jd);
+  jd.n = n; jd.nr = nr; memcpy(jd.kinds, at.kinds, AFX_MAX_ATTRIBUTES);
+  const PlanKey jkey = plan_key("VIW", &jd, sizeof jd, mode_flags(ctx));
   return host_pipe(ctx, count, [&](Stager& st, size_t first, size_t sn) -> int {
-    const size_t o_rec = st.add(blob + off + first * cells * 32, sn * cells * 32), o_map = st.add((const uint8_t*)row_of_cell.data(), 4 * (size_t)cells),
-                 o_soa = st.reserve(sn * cells * 32), o_st = st.add(nullptr, sn);
-    st.plan_fetch(status, o_st, 1, 1, count, first, sn);
+    st.layout_tag = 1;
+    const size_t dn = st.dev_items(sn);
+    const size_t o_rec = st.add_rows(blob + off, 1, (size_t)cells * 32, count, first, sn, dn), o_map = st.add((const uint8_t*)row_of_cell.data(), 4 * (size_t)cells),
+                 o_soa = st.reserve(dn * cells * 32), o_st = st.add(nullptr, dn);
+    st.plan_fetch(status, o_st, 1, 1, count, first, sn, dn);
     int rc2 = st.upload();
     if (rc2) return rc2;
-    {
+    if (!st.app) {
       // the transposition reads what the upload brings: under a Session it waits for the session's one upload
       hipStream_t strm = st.stream();
       const uint8_t* rec_d = st.dev(o_rec);
       uint8_t* soa_d = st.dev(o_soa);
       const uint32_t* map_d = (const uint32_t*)st.dev(o_map);
-      const uint32_t cells_ = cells, sn_ = (uint32_t)sn;
-      auto transpose = [=]() -> int { AFX_HIP(afxk_aos_to_soa(strm, rec_d, soa_d, map_d, cells_, sn_)); return AFX_OK; };
+      const uint32_t cells_ = cells, dn_ = (uint32_t)dn;
+      auto transpose = [=]() -> int { AFX_HIP(afxk_aos_to_soa(strm, rec_d, soa_d, map_d, cells_, dn_)); return AFX_OK; };
       if (st.ses) st.ses->pre.push_back(transpose);
       else if ((rc2 = transpose())) return rc2;
     }
-    auto rowp = [&](uint32_t r) { return (uint8_t*)st.dev(o_soa) + (size_t)r * sn * 32; };
+    auto rowp = [&](uint32_t r) { return (uint8_t*)st.dev(o_soa) + (size_t)r * dn * 32; };
     afx_attributes_soa as = at;
     as.values = rowp(4 + nr);
     const afx_issuance_soa iss = { rowp(0), rowp(1), rowp(2), rowp(3), rowp(4) };
-    if ((rc2 = afx_verify_issuances_dev(ctx, &as, &iss, nr, sn, st.dev(o_st)))) return rc2;
+    if ((rc2 = afx_verify_issuances_dev(ctx, &as, &iss, nr, dn, st.dev(o_st)))) return rc2;
     return st.fetch_all();
-  });
+  }, jkey);
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_issuer_parameters(afx_ctx* c, uint8_t out[64]) try {
   if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  std::unique_lock<std::recursive_mutex> lock(c->mu);
+  CtxLock lock(c);
   memcpy(out, c->gen_enc[c->id_CW()].data(), 32);
   memcpy(out + 32, c->gen_enc[c->id_I()].data(), 32);
   return AFX_OK;

@@ -63,7 +63,12 @@ inline uint64_t mode_flags(const afx_ctx* c) {
 }
 
 namespace afx {
-// Several small host-pointer calls collected into ONE set of kernel launches (mixed.cpp: the shape groups of a mixed request).
+// internal return codes of the staging path (never leave the library)
+static constexpr int AFX_RETRY_FULL = -1000;       // the collecting session cannot take this call: wait for the next one
+static constexpr int AFX_RETRY_NOAPPEND = -1001;   // the call does not fit the item slots it was offered: stage it as a group of its own
+
+// Several small host-pointer calls collected into ONE set of kernel launches (mixed.cpp: the shape groups of a mixed request;
+// plans.cpp coalesced_call: calls of several host threads on one context).
 // While a session is open on a context, every host-pointer front end stages its arrays into the session's image instead of
 // sending them, every *_dev call leaves its plan with the session instead of launching it, and results are declared instead of
 // fetched; flush() sends the image in one copy, runs all the plans merged launch by launch (engine.cpp run_plans), brings every
@@ -77,16 +82,81 @@ struct Session {
   struct Out { uint8_t* dst; size_t pin_off, len; };
   std::vector<Out> outs;
   std::vector<std::function<int()>> pre;            // launches that run after the upload and before the plans (k_aos_to_soa of a serialized batch)
-  explicit Session(afx_ctx* ctx) : c(ctx) { c->session = this; }
+  // `shared`: a session of the context's coalescer (afx_ctx::co) - it is the context's `session` only while one call stages into it
+  explicit Session(afx_ctx* ctx, bool shared_ = false) : c(ctx), shared(shared_) { if (!shared) c->session = this; }
   ~Session() { if (c->session == this) c->session = nullptr; }
   Session(const Session&) = delete;
   Session& operator=(const Session&) = delete;
   bool empty() const { return plans.empty() && outs.empty() && pre.empty() && in_used == 0 && out_used == 0; }
-  void drop() { plans.clear(); outs.clear(); pre.clear(); in_used = out_used = 0; }
+  void drop() { plans.clear(); outs.clear(); pre.clear(); slots.clear(); in_used = out_used = 0; }
   int ensure_images(size_t in_bytes, size_t out_bytes);   // device staging + pinned images of at least these sizes (only while empty)
-  int flush();
+  // flush() = launch() + complete(): everything is enqueued on the lane's stream by launch() (the context's host state is used:
+  // under afx_ctx::mu), complete() waits for the stream and scatters the results (no context state: the coalescer runs it unlocked)
+  int launch();
+  int complete(int launch_rc);
+  int flush() { return complete(launch()); }
+
+  // ---- item slots: same-shape calls of a shared session in ONE pass -------------------------------------------------------
+  // A group created by the first call of a (statement, shape, mode) - the join key - is laid out for `dn` items (at least a
+  // wave's 64) of which the call uses the first few; a later call of the same key copies its rows into the next free slots of
+  // the SAME arrays and declares its results there: no second plan, no second set of rows in the launches.  `ops` is the
+  // layout the creating call's Stager recorded; a joining call must reproduce it operation by operation (else it is staged as a
+  // group of its own).
+  struct Op { uint8_t kind; size_t rows, elem, dn, len, off; };   // kind: 0 constant bytes, 1 output bytes, 2 scratch, 3 input rows, 4 output rows
+  struct Slots { PlanKey key; std::vector<Op> ops; size_t in_at, out_at, in_bytes, out_bytes; uint32_t dn, used; };
+  std::vector<Slots> slots;
+  // ---- coalescer state (under afx_ctx::mu) ---------------------------------------------------------------------------------
+  bool shared = false;
+  enum State { COLLECTING, LAUNCHING, INFLIGHT, DONE } state = COLLECTING;
+  int rc = 0;                       // of the flush: every joined call returns it
+  std::string err;
+  std::thread::id leader;           // the caller that opened the session launches it
+  bool hurry = false, full = false; // launch now: an exclusive caller waits / the session has all it can take
+  std::chrono::steady_clock::time_point deadline;
+  uint32_t mclass = 0;              // afx_ctx::merge_class while calls stage into this session
+  uint32_t calls = 0;
+  uint64_t items = 0;
+  std::map<std::string, uint32_t> key_items;   // items per join key (next session's slot counts)
 };
 }  // namespace afx
+
+// Every entry point that touches a context's host state holds this.  `joiner`: a small host-pointer front end, which may join the
+// coalescer's collecting session (host_pipe decides); everything else needs the context to itself and first waits until no session
+// collects or is in flight (quiesce).  Re-entrant on the owning thread (the host-pointer front ends call the *_dev forms).
+struct CtxLock {
+  afx_ctx* c;
+  explicit CtxLock(afx_ctx* ctx, bool joiner = false) : c(ctx) {
+    if (!c) return;
+    c->mu.lock();
+    if (++c->lock_depth == 1 && !joiner) quiesce(c);
+  }
+  ~CtxLock() { if (c) { --c->lock_depth; c->mu.unlock(); } }
+  CtxLock(const CtxLock&) = delete;
+  CtxLock& operator=(const CtxLock&) = delete;
+  // waits on the coalescer's condition with `mu` released (only ever at depth 1: the recursive mutex is released by ONE unlock)
+  static void wait(afx_ctx* c) { const int d = c->lock_depth; c->lock_depth = 0; c->co.cv.wait(c->mu); c->lock_depth = d; }
+  // (the bound is converted to the system clock: waits on it are pthread_cond_timedwait, which the thread sanitizer of this
+  // toolchain understands; it only bounds how long a collection lingers)
+  static void wait_until(afx_ctx* c, std::chrono::steady_clock::time_point t) {
+    const auto left = t - std::chrono::steady_clock::now();
+    const int d = c->lock_depth;
+    c->lock_depth = 0;
+    if (left > std::chrono::steady_clock::duration::zero()) c->co.cv.wait_until(c->mu, std::chrono::system_clock::now() + std::chrono::duration_cast<std::chrono::system_clock::duration>(left));
+    c->lock_depth = d;
+  }
+  static void quiesce(afx_ctx* c) {
+    afx_ctx::Coalesce& co = c->co;
+    if (!co.open && !co.inflight) return;
+    co.exclusive_waiters++;
+    while (co.open || co.inflight) {
+      if (co.open) co.open->hurry = true;
+      co.cv.notify_all();
+      wait(c);
+    }
+    co.exclusive_waiters--;
+    co.cv.notify_all();
+  }
+};
 
 // key non-empty and the call is a small host-pointer one (a Stager is staging it): the assembled plan is kept, position-independent,
 // and reused by later calls of the same statement, shape, mode and (padded) size - those only copy it and move its pointers.
@@ -149,10 +219,19 @@ struct Stager {
   size_t in_at = 0, out_at = 0;      // session mode: where this call's regions start inside the lane's buffers
   bool uploaded = false;
   static constexpr size_t OUT = size_t(1) << 62;
-  struct Copy { size_t off; const uint8_t* src; size_t len; };
+  struct Copy { size_t off; const uint8_t* src; size_t len; bool constant; };
   struct Out { uint8_t* dst; size_t pin_off, len; };
   std::vector<Copy> copies, zeros;   // zeros: row tails of padded passes (only the unpacked upload needs them spelled out)
   std::vector<Out> outs;
+  // ---- item slots of a shared session (afx::Session::Slots) ----
+  using Op = afx::Session::Op;
+  std::vector<Op> ops;               // this call's layout, operation by operation (what a later call of the same key must reproduce)
+  afx::Session::Slots* app = nullptr;   // non-null: this call takes items [slot, slot + n) of that group's arrays
+  size_t slot = 0, op_i = 0;
+  bool mismatch = false;             // the call's operations are not the group's
+  uint32_t slots_hint = 0;           // a new group in a shared session: lay it out for at least this many items
+  uint32_t last_dn = 0;              // what dev_items() answered (0: the front end does not pad - its group cannot be joined)
+  uint32_t layout_tag = 0;           // which front end staged the arrays (part of the plan cache key: 0 column arrays, 1 serialized records)
   // the *_dev calls made while this object lives run on its lane and know its staged ranges (run_chunked: plan reuse)
   // session: the Session collecting this call (host_pipe passes the context's), or null: the call stages and launches by itself
   explicit Stager(afx_ctx* ctx, int lane = 0, afx::Session* session = nullptr)
@@ -167,37 +246,69 @@ struct Stager {
   // Items a pass of `n` host items runs with on the device.  Small calls are padded up to a power of two (at least 16): the
   // plan of a padded size serves every call of that statement and shape up to it (afx_ctx.plan_cache), the extra lanes work on
   // zeros and their results are never fetched - in the latency regime the device has lanes to spare.  Larger calls: n.
-  uint32_t dev_items(size_t n) const {
-    if (!c->small_batch_items || n > c->small_batch_items || c->trace || n == 0) return (uint32_t)n;
+  // In a shared session: the item slots of the group the call joins, or (a new group) at least a wave's 64 and what the last
+  // session carried of this key - the slots later callers fill.
+  uint32_t dev_items(size_t n) {
+    if (app) return last_dn = app->dn;
+    if (!c->small_batch_items || n > c->small_batch_items || c->trace || n == 0) return last_dn = (uint32_t)n;
     uint32_t b = 16;
+    if (ses && ses->shared) b = std::max<uint32_t>(64, slots_hint);
     while (b < n) b <<= 1;
-    return std::min<uint32_t>(b, c->small_batch_items) < n ? (uint32_t)n : std::min<uint32_t>(b, c->small_batch_items);
+    return last_dn = (std::min<uint32_t>(b, c->small_batch_items) < n ? (uint32_t)n : std::min<uint32_t>(b, c->small_batch_items));
   }
-  // reserve `len` bytes: filled from host `src` (input region), or an output area when src == nullptr (output region, zeroed)
+  // the recorded operation a joining call is at: must equal what the call is doing now
+  size_t joined(uint8_t kind, size_t rows, size_t elem, size_t dn, size_t len) {
+    if (op_i >= app->ops.size()) { mismatch = true; return 0; }
+    const Op& o = app->ops[op_i++];
+    if (o.kind != kind || o.rows != rows || o.elem != elem || o.dn != dn || o.len != len) { mismatch = true; return 0; }
+    return o.off;
+  }
+  // reserve `len` bytes: filled from host `src` (input region; the same bytes for every call of the join key: a cell map), or an
+  // output area when src == nullptr (output region, zeroed)
   size_t add(const uint8_t* src, size_t len) {
-    if (!src) { const size_t off = (out_bytes + 255) & ~size_t(255); out_bytes = off + len; return OUT | off; }
+    if (app) {
+      const size_t off = joined(src ? 0 : 1, 0, 0, 0, len);
+      if (src && !mismatch) copies.push_back({ off, src, len, true });
+      return off;
+    }
+    if (!src) { const size_t off = (out_bytes + 255) & ~size_t(255); out_bytes = off + len; ops.push_back({ 1, 0, 0, 0, len, OUT | off }); return OUT | off; }
     const size_t off = (in_bytes + 255) & ~size_t(255);
     in_bytes = off + len;
-    copies.push_back({ off, src, len });
+    copies.push_back({ off, src, len, true });
+    ops.push_back({ 0, 0, 0, 0, len, off });
     return off;
   }
   // scratch that the call's own kernels fill before anything reads it
   size_t reserve(size_t len) {
+    if (app) return joined(2, 0, 0, 0, len);
     const size_t off = (in_bytes + 255) & ~size_t(255);
     in_bytes = off + len;
+    ops.push_back({ 2, 0, 0, 0, len, off });
     return off;
   }
   // items [first, first + n) of a [rows][total][elem] host array -> a [rows][dn][elem] device array (dn >= n: dev_items; the
   // rows' tails stay zero); src == nullptr: an output array of that extent
   size_t add_rows(const uint8_t* src, size_t rows, size_t elem, size_t total, size_t first, size_t n, size_t dn = 0) {
     if (dn < n) dn = n;
-    if (!src) return add(nullptr, rows * dn * elem);
+    if (app) {
+      const size_t off = joined(src ? 3 : 4, rows, elem, dn, 0);
+      if (src && !mismatch)
+        for (size_t r = 0; r < rows; r++) copies.push_back({ off + (r * dn + slot) * elem, src + (r * total + first) * elem, n * elem, false });
+      return off;
+    }
+    if (!src) {
+      const size_t off = (out_bytes + 255) & ~size_t(255);
+      out_bytes = off + rows * dn * elem;
+      ops.push_back({ 4, rows, elem, dn, 0, OUT | off });
+      return OUT | off;
+    }
     const size_t off = (in_bytes + 255) & ~size_t(255);
     in_bytes = off + rows * dn * elem;
     for (size_t r = 0; r < rows; r++) {
-      copies.push_back({ off + r * dn * elem, src + (r * total + first) * elem, n * elem });
-      if (dn > n) zeros.push_back({ off + (r * dn + n) * elem, nullptr, (dn - n) * elem });   // the padding lanes read zeros
+      copies.push_back({ off + r * dn * elem, src + (r * total + first) * elem, n * elem, false });
+      if (dn > n) zeros.push_back({ off + (r * dn + n) * elem, nullptr, (dn - n) * elem, false });   // the padding lanes read zeros
     }
+    ops.push_back({ 3, rows, elem, dn, 0, off });
     return off;
   }
   uint8_t* in_base() const { return (uint8_t*)c->lane[ln].staging.p + in_at; }
@@ -217,8 +328,8 @@ struct Stager {
     if (!dst || !rows || !n) return;
     if (dn < n) dn = n;
     const size_t o = off & ~OUT;   // outputs only
-    for (size_t r = 0; r < rows; r++) outs.push_back({ dst + (r * total + first) * elem, o + r * dn * elem, n * elem });
-    pend_.push_back({ o, rows * dn * elem });
+    for (size_t r = 0; r < rows; r++) outs.push_back({ dst + (r * total + first) * elem, o + (r * dn + (app ? slot : 0)) * elem, n * elem });
+    if (!app) pend_.push_back({ o, rows * dn * elem });
   }
   int fetch_all();
   int drain();
@@ -241,4 +352,7 @@ inline size_t host_slice_items(const afx_ctx* c) {
 // Runs `slice(stager, first, n)` over [0, count) in slices on alternating lanes; `slice` stages, launches and calls
 // fetch_all() on the Stager it is given; the pipe drains a lane before that lane is used again, and both at the end.
 // Under a Session the call is one slice whose work is left with the session.
-int host_pipe(afx_ctx* c, size_t count, const std::function<int(Stager&, size_t, size_t)>& slice);
+// `join_key` (optional): what makes two calls of this front end the same pass apart from their items - statement, shape, mode, which
+// optional arrays are present.  With it, a small call may run in the coalescer's shared session (afx_ctx::co) and share a pass
+// with other threads' calls of the same key; the front end must then stage per-item data with add_rows() / dev_items() only.
+int host_pipe(afx_ctx* c, size_t count, const std::function<int(Stager&, size_t, size_t)>& slice, const PlanKey& join_key = PlanKey());

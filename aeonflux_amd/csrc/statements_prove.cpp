@@ -100,8 +100,7 @@ static void messages_from_attributes(Assembler& as, const afx_attributes_soa& a,
 // ------------------------------------------------------------------------------------------------
 extern "C" int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* iss, uint32_t n_responses,
                                         size_t count, uint8_t* status_dev) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx);
   if (!ctx || !attrs || !iss || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   const afx_attributes_soa a = *attrs;
@@ -151,8 +150,7 @@ extern "C" int afx_verify_issuances_dev(afx_ctx* ctx, const afx_attributes_soa* 
 // ------------------------------------------------------------------------------------------------
 extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, const afx_issue_randomness* rnd, size_t count,
                              const afx_issuance_soa* out, uint8_t* status_dev) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx);
   if (!ctx || !requests || !rnd || !out || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (!ctx->has_key) { set_error("Issuer::issue needs the issuer key"); return AFX_E_NO_KEY; }
   if (count == 0) return AFX_OK;
@@ -242,8 +240,7 @@ extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, c
 // ------------------------------------------------------------------------------------------------
 extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
                             size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status_dev) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx);
   if (!ctx || !creds || !rnd || !out || !shape_out || !status_dev) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   const afx_credentials_soa cr = *creds;
   const uint32_t na = cr.n_attributes;
@@ -489,8 +486,7 @@ static int fetch(afx_ctx* ctx, void* dst, const uint8_t* src_dev, size_t n) {
 // item i of the batch lands in element i of every output array).  Slices alternate between the two lanes (statements.hpp).
 extern "C" int afx_issue_range(afx_ctx* ctx, const afx_attributes_soa* req, const afx_issue_randomness* rnd, size_t total, size_t first, size_t n,
                                const afx_issuance_soa* out, uint8_t* status) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx, true);
   if (!ctx || !req || !rnd || !out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (!rnd->t_wide || !rnd->U_wide || !rnd->rng_seed || !out->t || !out->U || !out->V || !out->challenge || !out->responses || (req->n_attributes && !req->values)) {
     set_error("null batch array");
@@ -503,6 +499,10 @@ extern "C" int afx_issue_range(afx_ctx* ctx, const afx_attributes_soa* req, cons
   // wrong attribute count: every request is MacCreation (amacs.rs:285-287); the arrays' extents are not trusted then
   if (req->n_attributes != ctx->n) { memset(status + first, AFX_ST_MAC_CREATION, n); return AFX_OK; }
   const uint32_t na = req->n_attributes, nr = ctx->n + 5;
+  struct { uint32_t n; uint8_t kinds[AFX_MAX_ATTRIBUTES]; } jd;   // what makes two calls one pass (statements.hpp host_pipe)
+  memset(&jd, 0, sizeof jd);
+  jd.n = na; memcpy(jd.kinds, req->kinds, std::min<size_t>(na, AFX_MAX_ATTRIBUTES));
+  const PlanKey jkey = plan_key("I", &jd, sizeof jd, mode_flags(ctx));
   return host_pipe(ctx, n, [&](Stager& st, size_t off, size_t sn) -> int {
     const size_t f0 = first + off;
     const size_t dn = st.dev_items(sn);   // the pass's size on the device (small calls: padded to the size their plan is kept for)
@@ -524,7 +524,7 @@ extern "C" int afx_issue_range(afx_ctx* ctx, const afx_attributes_soa* req, cons
     afx_issuance_soa dout = { st.dev(o_t), st.dev(o_U), st.dev(o_V), st.dev(o_ch), st.dev(o_rs) };
     if ((rc = afx_issue_dev(ctx, &da, &dr, dn, &dout, st.dev(o_st)))) return rc;
     return st.fetch_all();
-  });
+  }, jkey);
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_issue(afx_ctx* ctx, const afx_attributes_soa* req, const afx_issue_randomness* rnd, size_t count,
                          const afx_issuance_soa* out, uint8_t* status) try {
@@ -534,8 +534,7 @@ extern "C" int afx_issue(afx_ctx* ctx, const afx_attributes_soa* req, const afx_
 // Issuances [first, first + n) of a host batch of `total` (user side, CredentialIssuance::verify, /root/reference/src/issuer.rs:48-57)
 extern "C" int afx_verify_issuances_range(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* iss, uint32_t n_responses,
                                           size_t total, size_t first, size_t n, uint8_t* status) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx, true);
   if (!ctx || !attrs || !iss || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (!iss->t || !iss->U || !iss->V || !iss->challenge || (n_responses && !iss->responses) || (attrs->n_attributes && !attrs->values)) {
     set_error("null batch array");
@@ -547,6 +546,10 @@ extern "C" int afx_verify_issuances_range(afx_ctx* ctx, const afx_attributes_soa
   // shapes every item fails on (zkp: responses.len() != num_scalars; G_m[i] out of range): answer without reading the arrays
   if (attrs->n_attributes > ctx->n || n_responses != ctx->n + 5) { memset(status + first, AFX_ST_VERIFICATION_FAILURE, n); return AFX_OK; }
   const uint32_t na = attrs->n_attributes, nr = n_responses;
+  struct { uint32_t n, nr; uint8_t kinds[AFX_MAX_ATTRIBUTES]; } jd;
+  memset(&jd, 0, sizeof jd);
+  jd.n = na; jd.nr = nr; memcpy(jd.kinds, attrs->kinds, std::min<size_t>(na, AFX_MAX_ATTRIBUTES));
+  const PlanKey jkey = plan_key("VI", &jd, sizeof jd, mode_flags(ctx));
   return host_pipe(ctx, n, [&](Stager& st, size_t off, size_t sn) -> int {
     const size_t f0 = first + off;
     const size_t dn = st.dev_items(sn);
@@ -562,7 +565,7 @@ extern "C" int afx_verify_issuances_range(afx_ctx* ctx, const afx_attributes_soa
     afx_issuance_soa di = { st.dev(o_t), st.dev(o_U), st.dev(o_V), st.dev(o_ch), st.dev(o_rs) };
     if ((rc = afx_verify_issuances_dev(ctx, &da, &di, n_responses, dn, st.dev(o_st)))) return rc;
     return st.fetch_all();
-  });
+  }, jkey);
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_verify_issuances(afx_ctx* ctx, const afx_attributes_soa* attrs, const afx_issuance_soa* iss, uint32_t n_responses,
                                     size_t count, uint8_t* status) try {
@@ -573,8 +576,7 @@ extern "C" int afx_verify_issuances(afx_ctx* ctx, const afx_attributes_soa* attr
 // every output array is indexed like the inputs.  shape_out is the same for every range of one batch.
 extern "C" int afx_show_range(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
                               size_t total, size_t first, size_t n, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx, true);
   if (!ctx || !creds || !rnd || !out || !shape_out || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   const uint32_t na = creds->n_attributes;
   if (na == 0 || na > ctx->n) { set_error("credential attribute count does not fit the system parameters"); return AFX_E_BAD_ARGS; }
@@ -594,6 +596,10 @@ extern "C" int afx_show_range(afx_ctx* ctx, const afx_credentials_soa* creds, co
     afx_show_randomness dr = *rnd;
     return afx_show_dev(ctx, &dc, kp ? keypairs : nullptr, &dr, 0, out, shape_out, status);
   }
+  struct { uint32_t n; uint8_t kinds[AFX_MAX_ATTRIBUTES]; } jd;
+  memset(&jd, 0, sizeof jd);
+  jd.n = na; memcpy(jd.kinds, creds->kinds, std::min<size_t>(na, AFX_MAX_ATTRIBUTES));
+  const PlanKey jkey = plan_key("S", &jd, sizeof jd, mode_flags(ctx) | (kp ? (uint64_t)1 << 63 : 0) | (out->attr_values ? (uint64_t)1 << 62 : 0));
   return host_pipe(ctx, n, [&](Stager& st, size_t off, size_t sn) -> int {
     const size_t f0 = first + off;
     const size_t dn = st.dev_items(sn);
@@ -629,7 +635,7 @@ extern "C" int afx_show_range(afx_ctx* ctx, const afx_credentials_soa* creds, co
     afx_presentation_out dout = { st.dev(o_ch), st.dev(o_rs), st.dev(o_x0), st.dev(o_x1), st.dev(o_cv), st.dev(o_cy), st.dev(o_av), de.data() };
     if ((rc = afx_show_dev(ctx, &dc, kp ? &dk : nullptr, &dr, dn, &dout, shape_out, st.dev(o_st)))) return rc;
     return st.fetch_all();
-  });
+  }, jkey);
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_show(afx_ctx* ctx, const afx_credentials_soa* creds, const afx_keypairs_soa* keypairs, const afx_show_randomness* rnd,
                         size_t count, const afx_presentation_out* out, afx_shape* shape_out, uint8_t* status) try {

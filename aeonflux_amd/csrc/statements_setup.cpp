@@ -115,8 +115,7 @@ extern "C" int afx_system_parameters_generate(int device, uint32_t n, const uint
 } catch (...) { return afx::exception_rc(); }
 
 extern "C" int afx_plaintexts_from_bytes(afx_ctx* ctx, const uint8_t* msgs, size_t count, uint8_t* M1, uint8_t* M2, uint8_t* m3, uint32_t* counters) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx);
   if (!ctx || !msgs || !M1 || !M2 || !m3) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -168,8 +167,7 @@ extern "C" int afx_plaintexts_from_bytes(afx_ctx* ctx, const uint8_t* msgs, size
 } catch (...) { return afx::exception_rc(); }
 
 extern "C" int afx_keypairs_derive(afx_ctx* ctx, const uint8_t* master_secrets, size_t count, uint8_t* a, uint8_t* a0, uint8_t* a1, uint8_t* pk) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx);
   if (!ctx || !master_secrets || !a || !a0 || !a1 || !pk) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -206,8 +204,7 @@ extern "C" int afx_keypairs_derive(afx_ctx* ctx, const uint8_t* master_secrets, 
 
 extern "C" int afx_encrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8_t* M1, const uint8_t* M2, const uint8_t* m3, size_t count,
                            uint8_t* E1, uint8_t* E2, uint8_t* status) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx);
   if (!ctx || !kp || !kp->a || !kp->a0 || !kp->a1 || !M1 || !M2 || !m3 || !E1 || !E2 || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));
@@ -239,8 +236,7 @@ extern "C" int afx_encrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8
 
 extern "C" int afx_decrypt(afx_ctx* ctx, const afx_keypairs_soa* kp, const uint8_t* E1, const uint8_t* E2, size_t count, uint8_t* M1, uint8_t* M2,
                            uint8_t* m3, uint8_t* messages, uint8_t* status) try {
-  std::unique_lock<std::recursive_mutex> lock__;
-  if (ctx) lock__ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+  CtxLock lock__(ctx);
   if (!ctx || !kp || !kp->a || !kp->a0 || !kp->a1 || !E1 || !E2 || !M1 || !M2 || !m3 || !status) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   if (count == 0) return AFX_OK;
   AFX_HIP(hipSetDevice(ctx->device));

@@ -113,8 +113,9 @@ typedef struct {
  *                    user-side context (show / issuance-verify only).  Every y_i is read (the
  *                    reference's from_bytes re-reads one chunk, src/amacs.rs:148-150 — a bug).
  *   issuer_params  : C_W || I (64 B; intended IssuerParameters layout, src/issuer.rs:155,163)
- * Decompresses the generators, builds the fixed-base window tables in HBM.  ctx is immutable
- * after creation; concurrent calls on one ctx are serialised on its stream. */
+ * Decompresses the generators, builds the fixed-base window tables in HBM.  A ctx may be called from any number of threads
+ * at once, like the `&self` methods it stands behind: small host-pointer calls that arrive while the device is busy share
+ * ONE set of kernel launches (afx_ctx_set_coalescing below); everything else takes the context in turn. */
 int afx_ctx_create(afx_ctx** out, int device, const uint8_t* sysparams, size_t sysparams_len,
                    const uint8_t* amacs_key, size_t amacs_key_len, const uint8_t issuer_params[64]);
 /* Overwrites device and host copies of the key and tables before freeing (Zeroize+Drop on
@@ -195,6 +196,31 @@ int afx_ctx_set_chunk_items(afx_ctx* ctx, uint32_t items);
  * only the job that multiplies by the issuer key (Z: one grid row that cannot fill the device at such sizes) into one NAF
  * chain per term (5.0 ms against 5.8 ms at 2^13 items, 8.7 against 9.0 at 2^14).  Results are identical under every plan. */
 int afx_ctx_set_small_batch_items(afx_ctx* ctx, uint32_t items);
+
+/* Concurrent small calls (on by default).  Issuer::verify takes `&self`, keeps no state and is called one presentation at a time
+ * from as many threads as a server has (src/issuer.rs:141-147); Issuer::issue (:111-124), CredentialIssuance::verify (:48-57) and
+ * AnonymousCredential::show (src/credential.rs:37-46) likewise.  One such call costs one chain of field operations on a device
+ * that is otherwise idle (0.8 ms), so calls that queue behind each other would cap a server at ~1.2 k calls/s whatever its thread
+ * count.  Instead, host-pointer calls (afx_verify_presentations[_range,_wire,_wire_range], afx_issue[_range],
+ * afx_verify_issuances[_range,_wire], afx_show[_range]) of at most 512 items that arrive while another call's kernels run are
+ * COLLECTED: each stages its rows - calls of one statement, shape and mode into the free item slots of ONE pass, so 64 callers of
+ * one shape are one pass of 64 items - and sleeps until the flush that carries its rows completes.  The caller that opened a
+ * collection launches it as soon as the device is free, at the latest `max_wait_us` after it opened it (default 2000) or when it
+ * holds `max_items` items (default 4096; at most 2^16).  A call that finds the device idle is launched at once: a single thread
+ * sees the latency it saw before.  Results are byte-identical to separate calls; a flush that fails (AFX_E_HIP ...) fails every call
+ * it carried with the same code and message, and the context stays usable.  max_items == 0 switches collection off (every call
+ * then takes the context in turn).  Large calls, device-pointer calls and the afx_ctx_set_* functions wait for the collections
+ * in flight and then have the context to themselves. */
+int afx_ctx_set_coalescing(afx_ctx* ctx, uint32_t max_wait_us, uint32_t max_items);
+typedef struct afx_coalescing_stats {
+  uint64_t sessions;        /* sets of launches that carried collected calls                                    */
+  uint64_t calls;           /* calls that went through them                                                     */
+  uint64_t items;           /* ... and their items                                                              */
+  uint64_t appended_calls;  /* calls that took free item slots of another call's pass (no plan of their own)    */
+  uint64_t max_calls;       /* most calls one set of launches carried                                           */
+  uint64_t leader_waits;    /* times a collection's opener slept because an earlier one was still computing     */
+} afx_coalescing_stats;
+int afx_ctx_get_coalescing_stats(afx_ctx* ctx, afx_coalescing_stats* out);
 
 /* Challenge trace (parity aid; off by default).  set(rows, count) allocates a device array [rows][count][32]; while it
  * exists, every verification call (presentations, proofs of encryption, issuances) of at most `count` items also

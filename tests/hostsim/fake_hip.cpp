@@ -6,7 +6,26 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <atomic>
+#include <map>
+#include <mutex>
 #include "../../aeonflux_amd/csrc/kernels.h"
+
+// Knobs a test sets WHILE other threads are inside the library (environment variables cannot be changed then):
+//   sync_us    every hipStreamSynchronize sleeps this long - a launch set "computes" for a while, so that calls of other threads
+//              arrive meanwhile and are collected (afx_ctx::co)
+//   fail_next  the next `fail_next` finishing launches fail (a flush that fails with calls of several threads in it)
+//   echo       a pass's status bytes are the first byte of each item of the first scalar array the pass checks (the challenge
+//              row of a verification): a test sees that every caller gets the result of ITS OWN rows
+static std::atomic<int> g_sync_us{ 0 }, g_fail_next{ 0 }, g_echo{ 0 };
+extern "C" void afx_fake_set(const char* what, int v) {
+  if (!strcmp(what, "sync_us")) g_sync_us = v;
+  else if (!strcmp(what, "fail_next")) g_fail_next = v;
+  else if (!strcmp(what, "echo")) g_echo = v;
+}
+static std::mutex echo_mu;   // (a global under a mutex: launches of two lanes run on two threads)
+static std::map<const void*, const uint8_t*> echo_src;   // pass (its failure words) -> first scalar array checked
 
 extern "C" {
 // AFX_FAKE_HIP_DEVICES: how many devices the fake runtime reports (default 1)
@@ -34,7 +53,11 @@ hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)0x1; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) {
+  const int us = g_sync_us.load();
+  if (us > 0) { struct timespec ts = { us / 1000000, (long)(us % 1000000) * 1000 }; nanosleep(&ts, nullptr); }
+  return hipSuccess;
+}
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)0x1; return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
@@ -71,7 +94,11 @@ hipError_t afxk_decode(hipStream_t, const afx_decode_job* j, uint32_t n, const a
   return hipSuccess;
 }
 hipError_t afxk_sccheck(hipStream_t, const afx_sccheck_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
-  for (uint32_t i = 0; i < n; i++) { hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e; CHECK_PTR(job_of(j, rows, i).sc); }
+  for (uint32_t i = 0; i < n; i++) {
+    hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e;
+    CHECK_PTR(job_of(j, rows, i).sc);
+    if (g_echo.load()) { std::lock_guard<std::mutex> lk(echo_mu); echo_src.emplace(pass_of(passes, rows, i).bad, job_of(j, rows, i).sc); }   // the first one of the pass stays
+  }
   return hipSuccess;
 }
 hipError_t afxk_pointop(hipStream_t, const afx_pointop_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
@@ -197,11 +224,24 @@ hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* p, uint32_t n, 
 }
 hipError_t afxk_finish(hipStream_t, const afx_finish_job* j, uint32_t n, const afx_row* rows, uint32_t max_count) {
   if (device_fails()) return hipErrorLaunchFailure;
+  for (int f = g_fail_next.load(); f > 0; f = g_fail_next.load())
+    if (g_fail_next.compare_exchange_strong(f, f - 1)) {
+      std::lock_guard<std::mutex> lk(echo_mu);
+      for (uint32_t i = 0; i < n; i++) echo_src.erase(job_of(j, rows, i).bad);
+      return hipErrorLaunchFailure;
+    }
   for (uint32_t i = 0; i < n; i++) {
     const afx_finish_job& q = job_of(j, rows, i);
     if (q.count == 0 || q.count > max_count || !canonical(q.bad) || !canonical(q.status)) return hipErrorInvalidValue;
     sink += q.bad[0] + q.bad[q.count - 1];
     memset(q.status, 0x5a, q.count);
+    std::lock_guard<std::mutex> lk(echo_mu);
+    auto src = echo_src.find(q.bad);
+    if (src != echo_src.end()) {
+      if (g_echo.load())
+        for (uint32_t k = 0; k < q.count; k++) q.status[k] = src->second[32 * (size_t)k];
+      echo_src.erase(src);
+    }
   }
   return hipSuccess;
 }
