@@ -95,6 +95,16 @@ class ShowGroup(C.Structure):
                 ("count", C.c_size_t), ("positions", C.POINTER(C.c_uint64))]
 
 
+class CoalescingStats(C.Structure):
+    """afx_coalescing_stats: how concurrent small calls on one context were collected (afx_ctx_set_coalescing)"""
+    _fields_ = [(k, C.c_uint64) for k in ("sessions", "calls", "items", "appended_calls", "max_calls", "leader_waits")]
+
+
+class PlanCacheStats(C.Structure):
+    """afx_plan_cache_stats"""
+    _fields_ = [(k, C.c_uint64) for k in ("hits", "misses", "evictions", "entries", "bytes")]
+
+
 _LIB = None
 
 
@@ -174,6 +184,10 @@ def lib():
         _LIB.afx_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
         _LIB.afx_ctx_get_timing.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         _LIB.afx_ctx_get_core_clock_mhz.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        _LIB.afx_ctx_get_core_clock_samples.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_uint32)]
+        _LIB.afx_ctx_set_coalescing.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        _LIB.afx_ctx_get_coalescing_stats.argtypes = [C.c_void_p, C.POINTER(CoalescingStats)]
+        _LIB.afx_ctx_get_plan_cache_stats.argtypes = [C.c_void_p, C.POINTER(PlanCacheStats)]
         _LIB.afx_verify_presentations_range.argtypes = [C.c_void_p, C.POINTER(Shape), C.POINTER(PresentationSoA), C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
         _LIB.afx_issue_range.argtypes = [C.c_void_p, C.POINTER(AttributesSoA), C.POINTER(IssueRandomness), C.c_size_t, C.c_size_t, C.c_size_t,
                                          C.POINTER(IssuanceSoA), C.c_void_p]
@@ -305,6 +319,26 @@ class Context:
         ms, n = C.c_double(0), C.c_uint64(0)
         check(lib().afx_ctx_get_timing(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def set_coalescing(self, max_wait_us=2000, max_items=4096):
+        """concurrent small host-pointer calls share launch sets (on by default); max_items=0 switches it off (afx_ctx_set_coalescing)"""
+        check(lib().afx_ctx_set_coalescing(self.h, max_wait_us, max_items))
+
+    def coalescing_stats(self):
+        s = CoalescingStats()
+        check(lib().afx_ctx_get_coalescing_stats(self.h, C.byref(s)))
+        return {k: int(getattr(s, k)) for k, _ in CoalescingStats._fields_}
+
+    def plan_cache_stats(self):
+        s = PlanCacheStats()
+        check(lib().afx_ctx_get_plan_cache_stats(self.h, C.byref(s)))
+        return {k: int(getattr(s, k)) for k, _ in PlanCacheStats._fields_}
+
+    def core_clock_samples(self):
+        """the clocks (MHz, increasing) of the 64 probing blocks of the timed k_msm_window launches (afx_ctx_get_core_clock_samples)"""
+        v, n = (C.c_double * 64)(), C.c_uint32(0)
+        check(lib().afx_ctx_get_core_clock_samples(self.h, v, 64, C.byref(n)))
+        return [float(x) for x in v[:n.value]]
 
     def core_clock_mhz(self):
         """core clock the timed k_msm_window launches ran at (afx_ctx_get_core_clock_mhz)"""

@@ -351,8 +351,10 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   // plan every scalar but the constant 1.  In a verifier-side plan every term of a job that multiplies by the issuer key (Z of
   // Issuer::verify): the key's own terms, and beside them the per-item scalars DERIVED from it by a public factor (y_i * m_i for a
   // revealed scalar attribute), whose digits would give the key away just the same.  Marked here, before a small pass splits the
-  // job into one chain per term.  Such terms never run as a NAF schedule (whose table indices are the key's digits), read every
-  // entry of their window's table, and on a fixed base use the 4-bit positional tables.
+  // job into one chain per term.  Such terms never run as a NAF schedule (whose table indices are the key's digits).  On a per-item
+  // base they run 2-bit signed windows over a two-entry affine table of which every addition reads both entries and selects; on a
+  // generator 6-bit signed windows over the positional tables AFX_SEC_*, the window's 32 multiples loaded one per lane and the digit's
+  // taken from the lane that holds it (ds_bpermute_b32, kernels.hip msm_fixed_terms): no load address is made from a digit.
   auto is_key_scalar = [&](const afx_msm_term& t) { return t.scalar_stride == 0 && host_scalar_of(ctx, t.scalar) != nullptr; };
   // producers that leave their half (plan.h afx_msm_job.leave_half): known before the terms are marked, so that a consumer in this
   // same call doubles its scalar too
@@ -1118,7 +1120,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
       case L_MSM_FIXED: case L_MSM_WINDOW: case L_MSM_NAF: {
         // pipelined lanes: the heavy kernel of one lane never runs beside the other lane's (only the light kernels
         // overlap it), which keeps per-launch timings meaningful and the VALU free of two competing table working sets
-        afx_ctx::Lane& other = ctx->lane[lane ^ 1];
+        afx_ctx::Lane& other = ctx->lane[lane < 2 ? lane ^ 1 : 0];   // (pipelined calls run on lanes 0 and 1)
         if (ctx->pipelining && other.msm_recorded) AFX_HIP(hipStreamWaitEvent(s, other.msm_done, 0));
         AFX_HIP(afxk_msm(s, kind == L_MSM_FIXED ? 0 : kind == L_MSM_WINDOW ? 1 : 2, encodes, secret, (const afx_msm_djob*)jobs, nrows,
                          (const int32_t*)ctx->d_pos_tables.p, (const int32_t*)ctx->d_sec_tables.p, rw, passes, pass_host, max_count,

@@ -53,6 +53,7 @@ struct Stager;
 
 struct afx_ctx {
   std::recursive_mutex mu;   // the context's host state (workspace, staging, plan ring and cache) has one user at a time; see `co` below
+  std::mutex settings_mu;    // the afx_ctx_set_* values are written under `mu` AND this; a group reads its members' settings under this alone (group.cpp)
   int lock_depth = 0;        // how many CtxLocks (statements.hpp) the thread that owns `mu` holds; 0 while it waits on co.cv
   // Concurrent small calls.  Issuer::verify takes `&self`, has no interior state and is called one presentation at a time from as
   // many threads as the server has (/root/reference/src/issuer.rs:141-147; Issuer::issue :111-124, AnonymousCredential::show
@@ -61,8 +62,8 @@ struct afx_ctx {
   // afx::Session; plans.cpp coalesced_call): it holds `mu` only while it stages its rows - into free item slots of a same-shape
   // call's arrays when there are any, so that 64 callers of one shape become ONE pass of 64 items - and then sleeps on `cv` until
   // the flush that carries its rows has completed.  One leader per session (the caller that opened it) launches it: at once while
-  // the device is idle, otherwise when the session ahead of it completes, it fills up, or `max_wait_us` have passed; the device
-  // wait itself runs without `mu`, so the next session collects (on the other lane) while this one computes.
+  // fewer than `max_inflight` sessions compute, otherwise when one of those completes, it fills up, or `max_wait_us` have passed;
+  // the device wait itself runs without `mu`, so the next session collects (on another lane) while these compute.
   struct Coalesce {
     bool enabled = true;
     uint32_t max_wait_us = 2000;      // a collecting session waits at most this long for the launches ahead of it
@@ -71,7 +72,8 @@ struct afx_ctx {
     std::condition_variable_any cv;   // waits on `mu`: session completed / lane free / exclusive caller done
     std::shared_ptr<afx::Session> open;   // the session that collects, or null
     int inflight = 0;                 // sessions launched and not yet completed
-    bool lane_busy[2] = { false, false };   // a session (collecting or in flight) owns the lane's staging images
+    bool lane_busy[3] = { false, false, false };   // a session (collecting or in flight) owns the lane's staging images
+    int max_inflight = 2;             // sessions computing at once (small passes leave most of the device idle); AFX_COALESCE_INFLIGHT=1|2 at context creation
     int exclusive_waiters = 0;        // callers that need the whole context (large batches, setters): no new session opens meanwhile
     std::map<std::string, uint32_t> demand;   // by join key: the items the last session carried (the item slots the next one starts with)
     uint32_t last_waves = 0, last_plans = 0;  // width of the last session launched: the merge class the next one assembles for
@@ -133,7 +135,7 @@ struct afx_ctx {
     void* pin_in = nullptr;          // pinned image of a SMALL call's whole staging area: its many short input rows are gathered
     size_t pin_in_cap = 0;           // here on the host and go to HBM in one copy (statements.hpp Stager::upload); wiped on destroy
     hipEvent_t pin_in_done = nullptr;   // end of the copy that last read pin_in
-  } lane[2];
+  } lane[3];   // large calls alternate between lanes 0 and 1 (host_pipe, pipelining); the coalescer's sessions take whichever of the three is free
   bool pipelining = false;
   bool strict = false;   // afx_ctx_set_strict
   bool fixed_key_schedule = false;   // afx_ctx_set_fixed_key_schedule: no NAF for the issuer key's scalars
@@ -164,8 +166,12 @@ struct afx_ctx {
                                                                    // (SchnorrBuilder::make_program); may derive from the key: wiped on destroy
   // assembled plans of small host-pointer calls, by (plan key bytes, padded pass size): position-independent (afx::Plan), placed by
   // relocation at every reuse (statements.hpp run_chunked).  May hold key material (prover plans): wiped on destroy.
-  std::map<std::pair<std::string, uint32_t>, std::shared_ptr<afx::Plan>> plan_cache;
+  // Least recently used entries make room for new ones (shapes come from callers - a serialized batch names its own - so a stream of
+  // unusual shapes must not pin the cache: the shapes a server really sees come back after a call or two).
+  struct CachedPlan { std::shared_ptr<afx::Plan> plan; uint64_t last_use = 0; };
+  std::map<std::pair<std::string, uint32_t>, CachedPlan> plan_cache;
   size_t plan_cache_bytes = 0;
+  uint64_t plan_cache_tick = 0, plan_cache_hits = 0, plan_cache_misses = 0, plan_cache_evictions = 0;   // afx_ctx_get_plan_cache_stats
   bool plan_selfcheck = false;   // AFX_PLAN_SELFCHECK=1 at context creation (tests): every plan is assembled twice against different
                                  // provisional bases and both relocated copies must be byte-identical - a pointer field the relocation
                                  // does not know shows up as a difference

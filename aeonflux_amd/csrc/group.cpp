@@ -7,9 +7,11 @@
 #include <ctype.h>
 #include <sched.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <atomic>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -25,20 +27,24 @@ struct NodeCpus {
   bool valid = false;
   cpu_set_t set;
 };
+// AFX_SYSFS_ROOT (tests): a directory that stands in for "/" when the topology is read - tests/test_hostsim.py gives the host
+// simulation a two-socket tree there
 static NodeCpus cpus_of_device(int device) {
   NodeCpus out;
   char bdf[64] = { 0 };
   if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess || !bdf[0]) return out;
   for (char* p = bdf; *p; p++) *p = (char)tolower((unsigned char)*p);
+  const char* root_env = getenv("AFX_SYSFS_ROOT");
+  const std::string root = root_env ? root_env : "";
   int node = -1;
   {
-    FILE* f = fopen((std::string("/sys/bus/pci/devices/") + bdf + "/numa_node").c_str(), "r");
+    FILE* f = fopen((root + "/sys/bus/pci/devices/" + bdf + "/numa_node").c_str(), "r");
     if (!f) return out;
     if (fscanf(f, "%d", &node) != 1) node = -1;
     fclose(f);
   }
   if (node < 0) return out;
-  FILE* f = fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
+  FILE* f = fopen((root + "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
   if (!f) return out;
   char list[4096] = { 0 };
   const size_t got = fread(list, 1, sizeof list - 1, f);
@@ -116,24 +122,40 @@ extern "C" void afx_shard_bounds(size_t count, uint32_t members, uint32_t index,
   *n = base + (index < extra ? 1 : 0);
 }
 
+// a member's settings, read under its settings lock (afx_ctx_set_* on a member - afx_group_member hands the contexts out - writes them under it)
+struct MemberSettings {
+  uint32_t small_batch_items, chunk_items;
+  bool strict, fixed_key_schedule, timing, trace;
+  int secret_mode;
+  bool same_as(const MemberSettings& o) const {
+    return small_batch_items == o.small_batch_items && chunk_items == o.chunk_items && strict == o.strict && fixed_key_schedule == o.fixed_key_schedule &&
+           timing == o.timing && secret_mode == o.secret_mode;
+  }
+};
+static MemberSettings settings_of(afx_ctx* c) {
+  std::lock_guard<std::mutex> lock(c->settings_mu);   // (not the context's own lock: a member may be busy with a long call)
+  return { c->small_batch_items, c->chunk_items, c->strict, c->fixed_key_schedule, c->timing, c->trace != nullptr, c->secret_mode };
+}
+uint32_t afx_group_small_batch_items(afx_group* g) { return g && !g->members.empty() ? settings_of(g->members[0]).small_batch_items : 0; }
+
 // one host thread per member; the first failure (lowest member index) is reported, with its message
 template <class F>
 static int run_members(afx_group* g, size_t count, F&& call) {
   const uint32_t m = (uint32_t)g->members.size();
   // A call small enough for the latency plan gains nothing from being cut into even smaller pieces (its duration is that of one
   // chain either way) and would pay a host thread per member: it goes to ONE member, the next in turn, so that small calls
-  // arriving from several host threads spread over the group's devices.
-  if (m > 1 && count != 0 && count <= g->members[0]->small_batch_items) {
+  // arriving from several host threads spread over the group's devices (where each member collects the calls it is dealt:
+  // afx_ctx_set_coalescing).
+  const MemberSettings s0 = settings_of(g->members[0]);
+  if (m > 1 && count != 0 && count <= s0.small_batch_items) {
     // ... in turn only while the members are interchangeable: settings are per member (afx_group_member), and a call must not
     // see strict mode, secret-independent addressing, kernel timing or a challenge trace on every m-th call only.  Members that
     // differ (a test set one of them up on purpose): member 0, whose threshold routed the call here, takes every small call.
-    bool alike = true;
+    bool alike = !s0.trace;   // (a challenge trace is read back from ONE member's buffer)
     for (uint32_t k = 1; k < m && alike; k++) {
-      const afx_ctx *a = g->members[0], *b = g->members[k];
-      alike = a->small_batch_items == b->small_batch_items && a->strict == b->strict && a->fixed_key_schedule == b->fixed_key_schedule &&
-              a->secret_mode == b->secret_mode && a->chunk_items == b->chunk_items && a->timing == b->timing && !b->trace;
+      const MemberSettings sk = settings_of(g->members[k]);
+      alike = s0.same_as(sk) && !sk.trace;
     }
-    alike = alike && !g->members[0]->trace;   // (a challenge trace is read back from ONE member's buffer)
     const uint32_t i = alike ? g->next_small.fetch_add(1, std::memory_order_relaxed) % m : 0;
     PinScope pin(g->node_cpus[i], true);
     const int rc = call(g->members[i], (size_t)0, count);

@@ -653,10 +653,25 @@ template <int KIND, bool ENC, bool SEC>
 __device__ __forceinline__ void msm_body(const afx_msm_djob* __restrict__ job, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables,
                                          int32_t* __restrict__ table_ws, uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count,
                                          unsigned long long* __restrict__ clock_probe) {
-  // Clock probe (measurement aid): one lane of the launch's first block reads the shader-clock counter (s_memtime) and the
-  // constant 100 MHz counter (s_memrealtime) around its chain; their ratio is the core clock this kernel actually ran at
-  // (the kernels run at the socket power cap, below the nominal clock: DESIGN.md section 4).
-  const bool probe = clock_probe && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+  // Clock probe (measurement aid): lane 0 of AFX_CLOCK_SLOTS blocks of the launch reads the shader-clock counter (s_memtime) and
+  // the constant 100 MHz counter (s_memrealtime) around its chain; their ratio is the core clock that block actually ran at (the
+  // kernels run at the socket power cap, below the nominal clock: DESIGN.md section 4).  The probing blocks are spread evenly
+  // over the launch's linear block order - that is, over its DURATION (blocks start in order: the first ones run at the boost
+  // clock the launch starts with, the later ones at what the power cap leaves) and over the eight XCDs (a block's XCD is its
+  // linear id mod 8: slot k probes a block whose id is k mod 8).  One slot per probing block; the host takes the median.
+  // (the choice is the block's, not a lane's: the counters stay in scalar registers - as lane 0's alone they cost the three-block
+  // instances four vector registers they do not have)
+  bool probe = false;
+  uint32_t pslot = 0;
+  if (clock_probe) {
+    const uint32_t total = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+    if (total < 8 * AFX_CLOCK_SLOTS) { probe = b < AFX_CLOCK_SLOTS; pslot = b; }
+    else {
+      const uint32_t stride = (total / AFX_CLOCK_SLOTS) & ~7u;
+      pslot = b / stride;
+      probe = pslot < AFX_CLOCK_SLOTS && b - pslot * stride == (pslot & 7u);
+    }
+  }
   unsigned long long c0 = 0, r0 = 0;
   if (probe) { c0 = clock64(); r0 = wall_clock64(); }
   // a WAVE past the end of this row's pass retires (the grid is sized for the launch's largest pass, and a pass of 16 items is one wave
@@ -727,8 +742,11 @@ __device__ __forceinline__ void msm_body(const afx_msm_djob* __restrict__ job, c
   }
   msm_finish<ENC>(job, acc, bad, count, item);
   if (probe) {
-    atomicAdd(&clock_probe[0], (unsigned long long)clock64() - c0);
-    atomicAdd(&clock_probe[1], (unsigned long long)wall_clock64() - r0);
+    const unsigned long long dc = (unsigned long long)clock64() - c0, dr = (unsigned long long)wall_clock64() - r0;
+    if (threadIdx.x == 0) {
+      atomicAdd(&clock_probe[2 * pslot], dc);
+      atomicAdd(&clock_probe[2 * pslot + 1], dr);
+    }
   }
 }
 // blocks of 256 per CU the instances are compiled for: three (168 registers) without the encoder, two with it; the windowed SEC
@@ -778,13 +796,17 @@ AFX_DEV fe quad_get(const quad_lds& L, int buf, uint32_t slot, uint32_t lane) {
   f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w; f.v[8] = c.x;
   return f;
 }
-// every role hands in one element; afterwards each reads the ones it needs.  The barrier waits for this wave's LDS traffic only
-// (s_waitcnt lgkmcnt(0); LDS is coherent inside the CU) - not for its outstanding global loads: the next table entry is already
-// on its way (msm_quad_body) and must stay in flight across the exchange.
+// every role hands in one element; afterwards each reads the ones it needs.  The exchange is ordered by workgroup-scope fences on
+// the LDS address space alone, on both sides of the barrier: a release after the store (s_waitcnt lgkmcnt(0): LDS is coherent
+// inside the CU), an acquire before the loads - what __syncthreads() does, minus its wait for this wave's outstanding GLOBAL
+// loads: the next table entry is already on its way (msm_quad_body) and must stay in flight across the exchange.  (The bare
+// s_barrier intrinsic touches no memory as far as the compiler knows: without the fences nothing but may-alias analysis kept
+// the loads behind it.  tests/test_kernel_isa.py reads the order ds_write .. s_waitcnt lgkmcnt(0) .. s_barrier .. ds_read back.)
 AFX_DEV void quad_post(quad_lds& L, int buf, uint32_t role, uint32_t lane, const fe& mine) {
   quad_put(L, buf, role, lane, mine);
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 // completed point -> extended, a product per role: T*X, Y*Z, T*Z, Y*X (ge_p1p1_to_p3); the next round writes the other buffer -
 // whoever writes this one again has passed the next barrier, behind every reader.  (Every role reads all four back: reading only
@@ -1542,7 +1564,7 @@ hipError_t afxk_scalarop(hipStream_t s, const afx_scalarop_job* jobs, uint32_t n
   hipLaunchKernelGGL(k_scalarop, grid_for(max_count, njobs), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
-// base: scratch for ngen * windows extended points (AFX_VAR_DWORDS each); secret != 0: the 4-bit tables (AFX_SEC_*)
+// base: scratch for ngen * windows extended points (AFX_VAR_DWORDS each); secret != 0: the 6-bit tables for secret scalars (AFX_SEC_*: a window's 32 multiples, fetched one per lane and exchanged)
 hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen, int32_t* base, int32_t* postab, int secret) {
   const uint32_t bits = secret ? AFX_SEC_BITS : AFX_POS_BITS, windows = secret ? AFX_SEC_WINDOWS : AFX_POS_WINDOWS;
   const uint32_t entries = secret ? AFX_SEC_ENTRIES : AFX_POS_ENTRIES, wd = secret ? AFX_SEC_WINDOW_DWORDS : AFX_POS_WINDOW_DWORDS;

@@ -103,7 +103,7 @@ int run_groups_on_devices(afx_group* group, G* groups, size_t n_groups, uint8_t*
   if (rc) return rc;
   const uint32_t m = afx_group_size(group);
   if (m == 0) { set_error("empty group"); return AFX_E_BAD_ARGS; }
-  const uint32_t small = afx_group_member(group, 0)->small_batch_items;
+  const uint32_t small = afx_group_small_batch_items(group);   // (the rule afx_group_* calls route by: group.cpp run_members)
   std::vector<std::vector<G>> share(m);
   std::vector<std::vector<uint64_t>> made;   // positions of groups that came without: contiguous after the groups before them
   made.reserve(n_groups);
@@ -248,6 +248,7 @@ extern "C" int afx_wire_section_bytes(const uint8_t* blob, size_t len, size_t* s
 } catch (...) { return afx::exception_rc(); }
 
 // `verify_section(section bytes, length, status, cap, &n)`: one same-shape AFXP batch on a context or on a group of them
+// (one context; the group form below deals the shape groups out to its members)
 template <class VerifySection>
 static int mixed_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap, size_t* count_out, VerifySection&& verify_section) {
   if ((!blob && len) || !count_out || (!status && status_cap)) { set_error("null argument"); return AFX_E_BAD_ARGS; }
@@ -342,10 +343,101 @@ extern "C" int afx_verify_presentations_mixed_wire(afx_ctx* ctx, const uint8_t* 
     return afx_verify_presentations_wire(ctx, b, l, st, cap, n);
   });
 } catch (...) { return afx::exception_rc(); }
+// The same stream on a group of devices.  Shape groups small enough for the latency plan are dealt out to the members in turn and
+// every member verifies its share - sections of several shapes - as ONE collected request on a host thread of its own (the
+// single-context entry point above: one upload, one set of launches, one download per member); a large shape group is split over all
+// the members by the group's batch call.  Only bytes move on the host: a member's share is its sections copied back to back.
 extern "C" int afx_group_verify_presentations_mixed_wire(afx_group* group, const uint8_t* blob, size_t len, uint8_t* status, size_t status_cap,
                                                          size_t* count_out) try {
   if (!group) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  return mixed_wire((afx_ctx*)nullptr, blob, len, status, status_cap, count_out, [&](const uint8_t* b, size_t l, uint8_t* st, size_t cap, size_t* n) {
-    return afx_group_verify_presentations_wire(group, b, l, st, cap, n);
-  });
+  if ((!blob && len) || !count_out || (!status && status_cap)) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  const uint32_t m = afx_group_size(group);
+  if (m == 0) { set_error("empty group"); return AFX_E_BAD_ARGS; }
+  struct Section { size_t off, len, hdr, count, first; };
+  struct Group { std::vector<Section> sections; size_t count = 0; };
+  std::map<std::string, Group> by_shape;
+  std::vector<std::string> order;   // groups in order of first appearance
+  size_t total = 0;
+  for (size_t off = 0; off < len;) {
+    size_t sl = 0;
+    int rc = afx_wire_section_bytes(blob + off, len - off, &sl);
+    if (rc) { set_error("section at byte " + std::to_string(off) + ": " + afx_last_error()); return rc; }
+    afx_shape sh;
+    size_t cnt = 0, rec = 0;
+    if ((rc = afx_wire_parse(blob + off, sl, &sh, &cnt, &rec))) { set_error("section at byte " + std::to_string(off) + ": " + afx_last_error()); return rc; }
+    const std::string key = shape_key(sh);
+    auto it = by_shape.find(key);
+    if (it == by_shape.end()) { it = by_shape.emplace(key, Group()).first; order.push_back(key); }
+    it->second.sections.push_back({ off, sl, rec, cnt, total });
+    it->second.count += cnt;
+    total += cnt;
+    off += sl;
+  }
+  *count_out = total;
+  if (total > status_cap) { set_error("status buffer too small"); return AFX_E_BAD_ARGS; }
+  const uint32_t small = afx_group_small_batch_items(group);
+  // a member's share: its sections back to back, and where each section's statuses belong in the caller's array
+  struct Share { std::vector<uint8_t> bytes; std::vector<std::pair<size_t, size_t>> ranges; size_t items = 0; };
+  std::vector<Share> share(m);
+  uint32_t turn = 0;
+  std::vector<uint8_t> merged, st;
+  for (const std::string& key : order) {
+    const Group& G = by_shape[key];
+    if (G.count == 0) continue;
+    if (small && G.count <= small) {
+      Share& S = share[turn++ % m];
+      for (const Section& sec : G.sections) {
+        S.bytes.insert(S.bytes.end(), blob + sec.off, blob + sec.off + sec.len);
+        S.ranges.push_back({ sec.first, sec.count });
+        S.items += sec.count;
+      }
+      continue;
+    }
+    // a large group: over all the members, now (one header with the group's count and every section's records behind it)
+    if (G.count > 0xffffffffu) { set_error("too many presentations of one shape"); return AFX_E_BAD_ARGS; }
+    size_t got = 0;
+    int rc;
+    if (G.sections.size() == 1) {
+      const Section& S0 = G.sections[0];
+      rc = afx_group_verify_presentations_wire(group, blob + S0.off, S0.len, status + S0.first, S0.count, &got);
+    } else {
+      const Section& S0 = G.sections[0];
+      size_t bytes = S0.hdr;
+      for (const Section& sec : G.sections) bytes += sec.len - sec.hdr;
+      merged.resize(bytes);
+      memcpy(merged.data(), blob + S0.off, S0.hdr);
+      const uint32_t c32 = (uint32_t)G.count;
+      for (int b = 0; b < 4; b++) merged[8 + b] = (uint8_t)(c32 >> (8 * b));
+      size_t w = S0.hdr;
+      for (const Section& sec : G.sections) { memcpy(merged.data() + w, blob + sec.off + sec.hdr, sec.len - sec.hdr); w += sec.len - sec.hdr; }
+      st.assign(G.count, AFX_ST_VERIFICATION_FAILURE);
+      rc = afx_group_verify_presentations_wire(group, merged.data(), merged.size(), st.data(), st.size(), &got);
+      size_t r = 0;
+      if (!rc) for (const Section& sec : G.sections) { memcpy(status + sec.first, st.data() + r, sec.count); r += sec.count; }
+    }
+    if (rc) return rc;
+  }
+  std::vector<int> rcs(m, AFX_OK);
+  std::vector<std::string> errs(m);
+  auto body = [&](uint32_t k) {
+    Share& S = share[k];
+    if (S.bytes.empty()) return;
+    GroupPin pin(group, k, k == 0);   // the member's thread on its device's NUMA node (member 0: the caller's thread, restored)
+    std::vector<uint8_t> mine(S.items, AFX_ST_VERIFICATION_FAILURE);
+    size_t got = 0;
+    rcs[k] = afx_verify_presentations_mixed_wire(afx_group_member(group, k), S.bytes.data(), S.bytes.size(), mine.data(), mine.size(), &got);
+    if (rcs[k]) { errs[k] = afx_last_error(); return; }   // the error string is per thread
+    size_t r = 0;
+    for (const auto& rg : S.ranges) { memcpy(status + rg.first, mine.data() + r, rg.second); r += rg.second; }
+  };
+  std::vector<std::thread> threads;
+  for (uint32_t k = 1; k < m; k++) {
+    if (share[k].bytes.empty()) continue;
+    try { threads.emplace_back(body, k); } catch (const std::system_error&) { body(k); }
+  }
+  body(0);
+  for (std::thread& t : threads) t.join();
+  for (uint32_t k = 0; k < m; k++)
+    if (rcs[k]) { set_error("member " + std::to_string(k) + ": " + errs[k]); return rcs[k]; }
+  return AFX_OK;
 } catch (...) { return afx::exception_rc(); }

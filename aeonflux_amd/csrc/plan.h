@@ -6,6 +6,7 @@
 #pragma once
 #include <stdint.h>
 
+#define AFX_CLOCK_SLOTS 64     /* blocks of a k_msm launch that read the clock counters (kernels.hip msm_body): (cycles, 100 MHz ticks) each */
 #define AFX_MSM_MAX_TERMS 72   /* Z job: 2 + n + #public scalars <= 2 + 2n; issuance: n + 4 */
 #define AFX_TABLE_ENTRIES 9            /* variable bases: 0*P (identity) .. 8*P, signed 4-bit windows */
 #define AFX_TABLE_STORED 8             /* entries kept per table: 1*P .. 8*P (digit 0 reads one shared identity entry), or the 8 odd
@@ -150,8 +151,9 @@ typedef struct {
   uint32_t table_slot;     /* variable terms: slot of this base's window table in table_ws (Assembler::msm; terms of one
                               launch list that share a base and a table kind share the table)              */
   uint32_t secret;         /* the scalar is a secret and the context runs with secret-independent addressing (Assembler::msm
-                              sets it): every entry of the window's table is read and the digit's entry selected; a fixed base
-                              uses the 6-bit positional tables (AFX_SEC_*) through the lane exchange            */
+                              sets it): on a per-item base both stored entries of the 2-bit window's affine table are read and
+                              the digit's selected; a fixed base uses the 6-bit positional tables (AFX_SEC_*), a window's 32
+                              multiples loaded one per lane and the digit's taken through the lane exchange (ds_bpermute_b32) */
   uint32_t dbl;            /* the base holds HALF the point the statement means (its producer left its half for k_compress2x,
                               afx_msm_job.leave_half): the term's scalar counts twice (Assembler::msm sets it)           */
 } afx_msm_term;

@@ -59,8 +59,10 @@ int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, const PlanKey& k
       // (the staging layout is part of the key: the column-array and the serialized front ends of one statement stage differently)
       const std::pair<PlanKey, uint32_t> ck(reusable ? key + (char)('0' + st->layout_tag) : key, cc);
       auto hit = reusable ? c->plan_cache.find(ck) : c->plan_cache.end();
-      if (hit != c->plan_cache.end() && hit->second->in_bytes == st->in_bytes && hit->second->out_bytes == st->out_bytes) {
-        *plan = *hit->second;
+      if (hit != c->plan_cache.end() && hit->second.plan->in_bytes == st->in_bytes && hit->second.plan->out_bytes == st->out_bytes) {
+        *plan = *hit->second.plan;
+        hit->second.last_use = ++c->plan_cache_tick;
+        c->plan_cache_hits++;
         plan->relocate(plan->blob_base, plan->ws_base, st->in_base(), st->out_base());
         if (c->plan_selfcheck) {   // a reused plan must equal a fresh one
           Plan fresh;
@@ -72,9 +74,19 @@ int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, const PlanKey& k
       } else {
         int rc = assemble(c, build, off, cc, st, *plan);
         if (rc) return rc;
-        if (reusable && c->plan_cache.size() < PLAN_CACHE_ENTRIES && c->plan_cache_bytes + plan->blob.size() <= PLAN_CACHE_BYTES) {
-          if (hit != c->plan_cache.end()) { c->plan_cache_bytes -= hit->second->blob.size(); c->plan_cache.erase(hit); }
-          c->plan_cache[ck] = std::make_shared<Plan>(*plan);
+        if (reusable && plan->blob.size() <= PLAN_CACHE_BYTES) {
+          c->plan_cache_misses++;
+          if (hit != c->plan_cache.end()) { c->plan_cache_bytes -= hit->second.plan->blob.size(); c->plan_cache.erase(hit); }
+          // room: the least recently used entries go (a linear scan of at most 512 entries, on a path that has just spent 0.3 ms assembling)
+          while (!c->plan_cache.empty() && (c->plan_cache.size() >= PLAN_CACHE_ENTRIES || c->plan_cache_bytes + plan->blob.size() > PLAN_CACHE_BYTES)) {
+            auto lru = c->plan_cache.begin();
+            for (auto it = c->plan_cache.begin(); it != c->plan_cache.end(); ++it)
+              if (it->second.last_use < lru->second.last_use) lru = it;
+            c->plan_cache_bytes -= lru->second.plan->blob.size();
+            c->plan_cache.erase(lru);   // (~Plan wipes the blob)
+            c->plan_cache_evictions++;
+          }
+          c->plan_cache[ck] = afx_ctx::CachedPlan{ std::make_shared<Plan>(*plan), ++c->plan_cache_tick };
           c->plan_cache_bytes += plan->blob.size();
         }
       }
@@ -241,7 +253,7 @@ int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey
   for (;;) {
     // ---- a session to stage into: the one that collects, or a new one on a free lane
     while (!co.open) {
-      const int lane = co.exclusive_waiters ? -1 : !co.lane_busy[0] ? 0 : !co.lane_busy[1] ? 1 : -1;
+      const int lane = co.exclusive_waiters ? -1 : !co.lane_busy[0] ? 0 : !co.lane_busy[1] ? 1 : !co.lane_busy[2] ? 2 : -1;
       if (lane < 0) { CtxLock::wait(c); continue; }
       AFX_HIP(hipSetDevice(c->device));
       std::shared_ptr<afx::Session> n(new afx::Session(c, true));
@@ -313,7 +325,7 @@ int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey
   // ---- the leader launches; everybody waits for the flush that carries their rows
   while (S->state != afx::Session::DONE) {
     if (S->leader != me || S->state != afx::Session::COLLECTING) { CtxLock::wait(c); continue; }
-    const bool go = S->full || S->hurry || co.inflight == 0 || clock::now() >= S->deadline;
+    const bool go = S->full || S->hurry || co.inflight < co.max_inflight || clock::now() >= S->deadline;
     if (!go) { co.n_waited_flushes++; CtxLock::wait_until(c, S->deadline); continue; }
     S->state = afx::Session::LAUNCHING;
     co.open.reset();

@@ -8,6 +8,7 @@
 //   /root/reference/src/amacs.rs:225-294 (Messages, Amac::tag / compute_V).
 // No arithmetic happens on the host: the host only lays out launches and transcript byte schedules.
 #include <string.h>
+#include <algorithm>
 #include <functional>
 #include <memory>
 #include <stdexcept>
@@ -71,13 +72,13 @@ extern "C" int afx_ctx_set_challenge_trace(afx_ctx* c, size_t rows, size_t count
   AFX_HIP(hipSetDevice(c->device));
   for (auto& L : c->lane)
     if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
-  c->trace = nullptr;
+  { std::lock_guard<std::mutex> sg(c->settings_mu); c->trace = nullptr; }
   c->trace_rows = c->trace_count = 0;
   if (rows == 0 || count == 0) { c->trace_buf.release(false); return AFX_OK; }
   int rc = c->trace_buf.ensure(rows * count * 32);
   if (rc) return rc;
   AFX_HIP(hipMemsetAsync(c->trace_buf.p, 0, rows * count * 32, c->stream));
-  c->trace = (uint8_t*)c->trace_buf.p;
+  { std::lock_guard<std::mutex> sg(c->settings_mu); c->trace = (uint8_t*)c->trace_buf.p; }
   c->trace_rows = rows;
   c->trace_count = count;
   return AFX_OK;
@@ -95,13 +96,13 @@ extern "C" int afx_ctx_get_challenge_trace(afx_ctx* c, uint8_t* host_out) try {
 extern "C" int afx_ctx_set_chunk_items(afx_ctx* c, uint32_t items) try {
   if (!c || (items != 0 && (items < 256 || items > (1u << 22)))) { set_error("chunk size out of range"); return AFX_E_BAD_ARGS; }
   CtxLock lock(c);
-  c->chunk_items = items;
+  { std::lock_guard<std::mutex> sg(c->settings_mu); c->chunk_items = items; }
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_set_small_batch_items(afx_ctx* c, uint32_t items) try {
   if (!c || items > (1u << 16)) { set_error("small-batch threshold out of range"); return AFX_E_BAD_ARGS; }
   CtxLock lock(c);
-  c->small_batch_items = items;
+  { std::lock_guard<std::mutex> sg(c->settings_mu); c->small_batch_items = items; }
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_set_coalescing(afx_ctx* c, uint32_t max_wait_us, uint32_t max_items) try {
@@ -122,13 +123,13 @@ extern "C" int afx_ctx_get_coalescing_stats(afx_ctx* c, afx_coalescing_stats* ou
 extern "C" int afx_ctx_set_strict(afx_ctx* c, int enable) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   CtxLock lock(c);
-  c->strict = enable != 0;
+  { std::lock_guard<std::mutex> sg(c->settings_mu); c->strict = enable != 0; }
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_set_fixed_key_schedule(afx_ctx* c, int enable) try {
   if (!c) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   CtxLock lock(c);
-  c->fixed_key_schedule = enable != 0;
+  { std::lock_guard<std::mutex> sg(c->settings_mu); c->fixed_key_schedule = enable != 0; }
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 // the generators' 6-bit positional tables (AFX_SEC_*), once per context: window bases through lane 0's workspace, like the 13-bit ones
@@ -150,13 +151,19 @@ extern "C" int afx_ctx_set_secret_independent_addressing(afx_ctx* c, int mode) t
   if (mode < 0 || mode > 2) { set_error("mode must be 0 (nowhere), 1 (everywhere) or 2 (the prover-side calls: the default)"); return AFX_E_BAD_ARGS; }
   CtxLock lock(c);
   if (mode) { const int rc = build_secret_tables(c); if (rc) return rc; }
-  c->secret_mode = mode;
+  { std::lock_guard<std::mutex> sg(c->settings_mu); c->secret_mode = mode; }
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_get_plan_stats(afx_ctx* c, afx_plan_stats* out) try {
   if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   CtxLock lock(c);
   *out = c->last_stats;
+  return AFX_OK;
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_get_plan_cache_stats(afx_ctx* c, afx_plan_cache_stats* out) try {
+  if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  CtxLock lock(c, true);
+  *out = afx_plan_cache_stats{ c->plan_cache_hits, c->plan_cache_misses, c->plan_cache_evictions, (uint64_t)c->plan_cache.size(), (uint64_t)c->plan_cache_bytes };
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_synchronize(afx_ctx* c) try {
@@ -174,19 +181,40 @@ extern "C" int afx_ctx_set_timing(afx_ctx* c, int enable) try {
   int rc = drain_timing(c);
   if (rc) return rc;
   for (int k = 0; k < (int)afx::L_KINDS; k++) { c->kind_ms[k] = 0; c->kind_launches[k] = 0; }
-  if (c->d_consts.p) AFX_HIP(hipMemsetAsync(c->clock_probe(), 0, 16, c->stream));
-  c->timing = enable != 0;
+  if (c->d_consts.p) AFX_HIP(hipMemsetAsync(c->clock_probe(), 0, 16 * AFX_CLOCK_SLOTS, c->stream));
+  { std::lock_guard<std::mutex> sg(c->settings_mu); c->timing = enable != 0; }
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
-extern "C" int afx_ctx_get_core_clock_mhz(afx_ctx* c, double* mhz) try {
-  if (!c || !mhz) { set_error("null argument"); return AFX_E_BAD_ARGS; }
-  CtxLock lock(c);
+// the clock of every probing block that ran (kernels.hip msm_body), sorted
+static int clock_samples(afx_ctx* c, std::vector<double>& out) {
   AFX_HIP(hipSetDevice(c->device));
   for (auto& L : c->lane)
     if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
-  unsigned long long v[2] = { 0, 0 };
+  unsigned long long v[2 * AFX_CLOCK_SLOTS];
   AFX_HIP(hipMemcpy(v, c->clock_probe(), sizeof v, hipMemcpyDeviceToHost));
-  *mhz = v[1] ? 100.0 * (double)v[0] / (double)v[1] : 0.0;
+  out.clear();
+  for (int k = 0; k < AFX_CLOCK_SLOTS; k++)
+    if (v[2 * k + 1]) out.push_back(100.0 * (double)v[2 * k] / (double)v[2 * k + 1]);
+  std::sort(out.begin(), out.end());
+  return AFX_OK;
+}
+extern "C" int afx_ctx_get_core_clock_mhz(afx_ctx* c, double* mhz) try {
+  if (!c || !mhz) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  CtxLock lock(c);
+  std::vector<double> s;
+  const int rc = clock_samples(c, s);
+  if (rc) return rc;
+  *mhz = s.empty() ? 0.0 : s.size() % 2 ? s[s.size() / 2] : 0.5 * (s[s.size() / 2 - 1] + s[s.size() / 2]);   // the median
+  return AFX_OK;
+} catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_get_core_clock_samples(afx_ctx* c, double* mhz_out, uint32_t cap, uint32_t* n_out) try {
+  if (!c || !n_out || (!mhz_out && cap)) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  CtxLock lock(c);
+  std::vector<double> s;
+  const int rc = clock_samples(c, s);
+  if (rc) return rc;
+  *n_out = (uint32_t)s.size();
+  for (uint32_t k = 0; k < cap && k < s.size(); k++) mhz_out[k] = s[k];
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_get_timing(afx_ctx* c, const char* kernel, double* total_ms, uint64_t* launches) try {
@@ -265,6 +293,7 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   if (n == 0 || n > AFX_MAX_ATTRIBUTES || splen != sizeof_system_parameters(n)) { set_error("SystemParameters length / attribute count"); return AFX_E_BAD_PARAMS; }
   std::unique_ptr<afx_ctx, void (*)(afx_ctx*)> c(new afx_ctx(), afx_ctx_destroy);
   { const char* sc = getenv("AFX_PLAN_SELFCHECK"); c->plan_selfcheck = sc && sc[0] == '1'; }   // tests: every plan assembled twice and compared
+  { const char* fl = getenv("AFX_COALESCE_INFLIGHT"); if (fl && (fl[0] == '1' || fl[0] == '2') && !fl[1]) c->co.max_inflight = fl[0] - '0'; }   // measurement aid
   c->device = device;
   c->n = n;
   c->g = n < 3 ? 3 : n;

@@ -25,6 +25,8 @@ struct Stager;
 // pins the calling thread to the CPUs of member `index`'s NUMA node for the life of the returned object (group.cpp; no-op where the
 // topology is not exposed); `caller_thread`: restore the thread's mask afterwards
 struct GroupPin { void* impl = nullptr; GroupPin(afx_group* g, uint32_t index, bool caller_thread); ~GroupPin(); GroupPin(const GroupPin&) = delete; };
+// member 0's afx_ctx_set_small_batch_items, read under its lock (which calls of a group are "small": group.cpp run_members, mixed.cpp)
+uint32_t afx_group_small_batch_items(afx_group* g);
 // context construction shared with afx_issuer_keygen (issuer_params may be null there)
 int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t splen, const uint8_t* key, size_t klen,
                         const uint8_t* key_scalars_only, const uint8_t* issuer_params);

@@ -125,6 +125,8 @@ def roofline_of(kt, workload, ab, items_per_step, secret=False):
             "kernel": dom, "launches_per_step": d["launches_per_step"],
             "avg_launch_ms": d["avg_launch_ms"], "items_per_launch": items_per_launch, "algorithmic_bytes_per_launch": ab * items_per_launch,
             "kernel_ms_per_step": sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS),
+            "kernel_ms_per_step_is": "the k_msm_* kernels (chains + their table builds) summed: " + " + ".join(k for k in kt if k in MSM_KERNELS) +
+                                     "; avg_launch_ms is the dominant kernel's (%s) alone" % dom,
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in kt.items()},
             "kernel_launches_per_step": {k: v["launches_per_step"] for k, v in kt.items()},
             "note": "integer-ALU bound path: the compute-side figure is in \"valu\""}
@@ -312,7 +314,7 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic (random attribute values)",
             "config": {"workload": "C5: batch issue 2^20 credentials, 16 attributes (S x8, P x4, E x4)", "credentials_per_gpu": count,
                        "secret_independent_addressing": {0: "nowhere (mode 0)", 1: "everywhere (mode 1)", 2: "prover-side calls (mode 2, the default)"}[secret_mode_of(args)],
-                       "algorithmic_bytes_per_credential": ab, "parallelism": "host-sharded x%d, no collective" % world},
+                       "algorithmic_bytes_per_credential": ab, "parallelism": "host-sharded x%d, no collective" % world, "rank_devices": RANK_DEVICES},
             "roofline": roofline_of(kt, "c5", ab, count, secret_mode_of(args) != 0),
             "valu": with_value_per_mhz(valu, count * world * args.steps / elapsed), "cpu_baseline": cpu}))
     issuer.close()
@@ -422,7 +424,7 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic (GPU-issued credentials)",
             "config": {"workload": "show 2^16 credentials, 4 attributes (s S P e)", "credentials_per_gpu": count, "algorithmic_bytes_per_presentation": ab,
                        "secret_independent_addressing": {0: "nowhere (mode 0)", 1: "everywhere (mode 1)", 2: "prover-side calls (mode 2, the default)"}[secret_mode_of(args)],
-                       "parallelism": "host-sharded x%d, no collective" % world},
+                       "parallelism": "host-sharded x%d, no collective" % world, "rank_devices": RANK_DEVICES},
             "roofline": roofline_of(kt, "show", ab, count, secret_mode_of(args) != 0),
             "valu": with_value_per_mhz(valu, count * world * args.steps / elapsed), "cpu_baseline": None}))
     issuer.close()
@@ -454,10 +456,29 @@ def valu_side(ctx, items_per_step, field_kernel_ms_per_step):
     mads = (MADS_PER_MUL * (st["field_mul"] - st["chain_mul"]) + MADS_PER_SQ * (st["field_sq"] - st["chain_sq"])
             + MADS_PER_CHAIN_MUL * st["chain_mul"] + MADS_PER_CHAIN_SQ * st["chain_sq"])
     achieved = mads * items_per_step / (field_kernel_ms_per_step / 1e3) / 1e12 if field_kernel_ms_per_step > 0 else 0.0
-    mhz = ctx.core_clock_mhz()   # measured inside the timed k_msm_window launches (shader-clock counter / 100 MHz counter)
+    # measured inside the timed k_msm_window launches (shader-clock counter / 100 MHz counter) by 64 blocks spread over each launch's
+    # duration and over the eight XCDs: the median (a launch starts at the boost clock and settles at what the power cap leaves)
+    mhz = ctx.core_clock_mhz()
+    try:
+        samples = ctx.core_clock_samples()
+    except Exception:   # an older build of the library (same-box A/Bs)
+        samples = []
     at_clock = MAD_PEAK_T * mhz / NOMINAL_MHZ if mhz > 0 else None
+    # the operation-count floor: what the statement's schedule costs if every multiply-add issued back to back - doublings shared per
+    # chain (252 per variable-base job), 64 additions per 4-bit-window term, one square root per decoded point, one inversion per
+    # encoding row: the counts in "per_item", which follow from the statement's term counts alone (Straus, 4-bit signed windows)
+    floor = None
+    if mads and at_clock:
+        floor = {"mads_per_item": mads, "items_per_s_at_nominal_clock": MAD_PEAK_T * 1e12 / mads, "items_per_s_at_measured_clock": at_clock * 1e12 / mads,
+                 "field_kernels_items_per_s": (items_per_step / (field_kernel_ms_per_step / 1e3)) if field_kernel_ms_per_step > 0 else None,
+                 "note": "items/s the field arithmetic of this statement would reach with the multiply-add port busy every cycle (peak = %.2f cycles per "
+                         "wave-instruction, measured); field_kernels_items_per_s / items_per_s_at_measured_clock = frac_at_measured_clock" % MAD_CYCLES}
     return {"unit": "T multiply-adds/s (v_mad_i64_i32 / v_mad_u64_u32)", "achieved": achieved, "peak": MAD_PEAK_T, "frac": achieved / MAD_PEAK_T,
             "core_clock_mhz_measured": mhz, "peak_at_measured_clock": at_clock, "frac_at_measured_clock": (achieved / at_clock) if at_clock else None,
+            "clock_samples": [round(x, 1) for x in samples],
+            "clock_spread_mhz": {"min": round(samples[0], 1), "p25": round(samples[len(samples) // 4], 1), "median": round(mhz, 1),
+                                 "p75": round(samples[(3 * len(samples)) // 4], 1), "max": round(samples[-1], 1), "blocks": len(samples)} if samples else None,
+            "operation_count_floor": floor,
             # the boxes of the pool run this path at 1.85-1.98 GHz (socket power cap): items per second and measured MHz of THIS
             # process's field kernels is the figure that compares across boxes and rounds
             "items_per_s_per_mhz_field_kernels": (items_per_step / (field_kernel_ms_per_step / 1e3) / mhz) if (mhz > 0 and field_kernel_ms_per_step > 0) else None,
@@ -477,7 +498,28 @@ def secret_mode_of(args):
 def with_value_per_mhz(valu, value):
     """the line's `value` (whole-job items per second) per measured MHz of the core clock: what compares across the pool's boxes"""
     mhz = valu.get("core_clock_mhz_measured") or 0
-    return dict(valu, value_per_mhz=(value / mhz) if mhz > 0 else None)
+    out = dict(valu, value_per_mhz=(value / mhz) if mhz > 0 else None)
+    fl = valu.get("operation_count_floor")
+    if fl:   # the whole step (transcripts, table building, staging included) against the field arithmetic's floor
+        out["operation_count_floor"] = dict(fl, value_over_floor_at_measured_clock=value / fl["items_per_s_at_measured_clock"])
+    return out
+
+
+RANK_DEVICES = None
+
+
+def gather_rank_devices(torch, dist, world, local_rank):
+    """["0000:05:00.0", ...]: the PCI bus id of the device each rank runs on, in rank order (hipDeviceGetPCIBusId, via torch's properties)"""
+    p = torch.cuda.get_device_properties(local_rank)
+    try:
+        mine = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except AttributeError:   # a torch build without the PCI fields: the device's uuid, or its index as a last resort
+        mine = str(getattr(p, "uuid", "device-%d" % local_rank))
+    if dist is None or world == 1:
+        return [mine]
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    return out
 
 
 def free_port():
@@ -626,6 +668,14 @@ def main():
                 dist.init_process_group(backend=backend, timeout=datetime.timedelta(minutes=10))
         except Exception as e:   # noqa: BLE001
             raise SystemExit("bench.py: rank %d: the %s process group did not form (%s)" % (rank, backend, e))
+    # which physical device every rank drives (PCI bus id): two ranks on one GPU would report a curve that is not one - refused,
+    # unless AFX_BENCH_DEVICE put them there on purpose (the launch-path check on a one-GPU box)
+    global RANK_DEVICES
+    RANK_DEVICES = gather_rank_devices(torch, dist, world, local_rank)
+    if len(set(RANK_DEVICES)) != len(RANK_DEVICES) and "AFX_BENCH_DEVICE" not in os.environ:
+        if dist is not None:
+            dist.destroy_process_group()
+        raise SystemExit("bench.py: ranks share a device: %s (set AFX_BENCH_DEVICE to run several ranks on one GPU on purpose)" % RANK_DEVICES)
     import aeonflux_amd as afx
     from aeonflux_amd import batch
 
@@ -808,7 +858,7 @@ def main():
                        "n1_vs_n_note": "the N=1 default workload is C3 (2^20 presentations on the one GPU, \"weak\"); N>1 defaults to C4 (2^22 in all, "
                                        "2^22/N per GPU, \"strong\"): the curve's first point is a different batch size from the rest - immaterial above "
                                        "2^17 items per GPU, where a pass fills the device",
-                       "ranks_seen": ranks_seen, "dist_backend": args.dist_backend if had_group else None, "launcher": "bench.py" if os.environ.get("AFX_BENCH_LAUNCHED") else
+                       "ranks_seen": ranks_seen, "rank_devices": RANK_DEVICES, "dist_backend": args.dist_backend if had_group else None, "launcher": "bench.py" if os.environ.get("AFX_BENCH_LAUNCHED") else
                        ("external" if world > 1 else "none"),
                        "group_api_presentations_per_s": group_rate, "group_api_items": group_items,
                        "group_api_note": "one process, afx_group_verify_presentations over %d device(s) on host arrays (%d copies of "

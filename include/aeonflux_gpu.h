@@ -255,6 +255,16 @@ typedef struct afx_plan_stats {
 } afx_plan_stats;
 int afx_ctx_get_plan_stats(afx_ctx* ctx, afx_plan_stats* out);
 
+/* The cache of assembled plans (small host-pointer calls reuse the plan of their statement, shape, mode and padded size: about 0.3 ms
+ * of host work per call).  At most 512 entries / 64 MB; the least recently used entry makes room for a new one, so a stream of
+ * unusual shapes - a serialized batch names its own shape - cannot pin the cache against the shapes a server really sees. */
+typedef struct afx_plan_cache_stats {
+  uint64_t hits, misses;   /* small host-pointer calls that reused a plan / assembled (and cached) one                     */
+  uint64_t evictions;      /* entries dropped to make room                                                                 */
+  uint64_t entries, bytes; /* what the cache holds now                                                                     */
+} afx_plan_cache_stats;
+int afx_ctx_get_plan_cache_stats(afx_ctx* ctx, afx_plan_cache_stats* out);
+
 /* Per-kernel device timing with HIP events on afx_ctx_stream(ctx) (measurement aid; off by default).
  * set_timing(ctx, 1) resets the counters and starts recording every launch; get_timing synchronises the
  * stream and returns the summed duration and launch count of one kernel: "k_msm_window", "k_msm_naf", "k_msm_fixed"
@@ -263,10 +273,14 @@ int afx_ctx_get_plan_stats(afx_ctx* ctx, afx_plan_stats* out);
  * "k_from_uniform", "k_reduce_wide", "k_fill_u32". */
 int afx_ctx_set_timing(afx_ctx* ctx, int enable);
 int afx_ctx_get_timing(afx_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
-/* The core clock the k_msm_window launches recorded since set_timing(ctx, 1) actually ran at, in MHz (0 if none ran): one
- * lane per launch reads the shader-clock counter and the constant 100 MHz counter around its chain.  The path runs at
- * the socket power cap, so this is below the nominal clock the multiply-add peak is usually quoted at. */
+/* The core clock the k_msm_window launches recorded since set_timing(ctx, 1) actually ran at, in MHz (0 if none ran): one lane of
+ * each of 64 blocks per launch - spread evenly over the launch's block order, that is over its duration and over the eight XCDs -
+ * reads the shader-clock counter and the constant 100 MHz counter around its chain; get_core_clock_mhz is the MEDIAN of the 64
+ * ratios, get_core_clock_samples all of them in increasing order (at most `cap` written, *n_out = how many there are).  The path
+ * runs at the socket power cap, so this is below the nominal clock the multiply-add peak is usually quoted at, and a launch's
+ * first blocks run faster than its last. */
 int afx_ctx_get_core_clock_mhz(afx_ctx* ctx, double* mhz);
+int afx_ctx_get_core_clock_samples(afx_ctx* ctx, double* mhz_out, uint32_t cap, uint32_t* n_out);
 
 /* ---- Issuer::verify (src/issuer.rs:141-147 -> src/nizk/presentation.rs:324-443) ------------- */
 

@@ -15,10 +15,25 @@
 //      GpuIssuer::issue_batch, GpuIssuer::verify_batch, GpuUser::show_batch, GpuUser::verify_issuance_batch
 //    and GpuIssuer::new_multi / GpuUser::new_multi_user put the same engine on several GPUs (afx_group_*).
 //
+// 3. The engine's fast door: bytes in, bytes out.  `presentation_to_bytes` / `presentation_from_bytes`, `encryption_proof_to_bytes` /
+//    `_from_bytes`, `issuance_to_bytes` / `issuance_from_bytes`, `issuer_parameters_to_bytes` / `_from_bytes` write and read exactly the
+//    library's AFXP / AFXI v1 records (include/aeonflux_gpu.h "wire format"; the crate's own XXX: "the commitments should be
+//    compressed", src/nizk/presentation.rs:117; style of src/parameters.rs:155-184).  `CompressedPresentation` keeps the 32-byte cells
+//    it was parsed from: `GpuIssuer::verify_wire(&[u8])` / `verify_compressed` hand a server's network bytes to the engine without one
+//    point decompressed or compressed on the host, `GpuUser::show_batch_wire` returns what `show` made as such bytes, and
+//    `GpuUser::verify_issuances_wire` checks an issuer's AFXI answer.
+//
 // Errors are values (src/errors.rs:73-89): a per-item engine status becomes the `CredentialError` the crate returns for that
-// outcome; a batch-level engine failure (no device, a HIP error, out of memory: AFX_E_*) becomes an `Err` for every item of the
-// call (`engine_error` below maps it; `last_engine_code()` keeps the raw code so a caller can tell an infrastructure failure from
-// a cryptographic one and fall back to the crate's CPU path).  Nothing here panics on caller data or on an engine fault.
+// outcome; a batch-level code about the caller's data (AFX_E_BAD_ARGS ...) becomes an `Err` for every item of the call
+// (`engine_error` below maps it).  An ENGINE FAULT - AFX_E_NO_DEVICE, AFX_E_HIP, AFX_E_NO_MEMORY: the accelerator, not the data - is
+// never turned into a cryptographic verdict: the `try_*` forms return it as `Err(EngineFault)`, and the crate-signature methods and
+// the batch forms then run the crate's own body on the CPU for that call (`fall_throughs()` counts how often; `last_fault_code()` has
+// the latest code).  A GPU reset therefore slows a server down; it does not turn honest users away.  Nothing here panics on caller
+// data or on an engine fault.
+//
+// Threads.  One engine serves every thread of a server, as `&self` does in the crate: concurrent small calls on one context are
+// COLLECTED inside the library into shared launch sets (afx_ctx_set_coalescing: 64 threads x 1 presentation = one pass of 64), so
+// `install_issuer` with ONE engine scales with the caller threads.
 //
 // Randomness.  The engine takes every random draw as an input array.  The shim draws, from the CALLER's csprng only:
 //   issue : per request, in the reference's order: 64 bytes for `Scalar::random` (t, src/amacs.rs:289), then 64 bytes for
@@ -45,15 +60,16 @@ use alloc::collections::BTreeMap;
 use alloc::vec;
 use alloc::vec::Vec;
 use core::ffi::c_void;
-use core::sync::atomic::{AtomicI32, AtomicPtr, Ordering};
+use core::sync::atomic::{AtomicI32, AtomicPtr, AtomicUsize, Ordering};
 
 use curve25519_dalek::ristretto::{CompressedRistretto, RistrettoPoint};
 use curve25519_dalek::scalar::Scalar;
+use curve25519_dalek::traits::Identity;
 use rand_core::{CryptoRng, RngCore};
 use zeroize::Zeroize;
 use zkp::CompactProof;
 
-use crate::amacs::{Amac, Attribute, EncryptedAttribute};
+use crate::amacs::{Amac, Attribute, EncryptedAttribute, SecretKey as AmacsSecretKey};
 use crate::credential::AnonymousCredential;
 use crate::errors::CredentialError;
 use crate::issuer::{CredentialIssuance, Issuer};
@@ -189,7 +205,10 @@ const ST_MAC_CREATION: u8 = 2;
 const ST_NO_SYMMETRIC_KEY: u8 = 3;
 const E_BAD_ARGS: i32 = -1;
 const E_BAD_PARAMS: i32 = -2;
+const E_NO_DEVICE: i32 = -3;
+const E_HIP: i32 = -4;
 const E_NO_KEY: i32 = -5;
+const E_NO_MEMORY: i32 = -6;
 const ATTR_PUBLIC_SCALAR: u8 = 0;
 const ATTR_SECRET_SCALAR: u8 = 1;
 const ATTR_PUBLIC_POINT: u8 = 2;
@@ -216,16 +235,27 @@ extern "C" {
     fn afx_group_size(group: *const c_void) -> u32;
     fn afx_group_member(group: *mut c_void, index: u32) -> *mut c_void;
     fn afx_ctx_set_secret_independent_addressing(ctx: *mut c_void, mode: i32) -> i32;
+    fn afx_verify_presentations_mixed_wire(ctx: *mut c_void, blob: *const u8, len: usize, status: *mut u8, status_cap: usize, count_out: *mut usize) -> i32;
+    fn afx_group_verify_presentations_mixed_wire(group: *mut c_void, blob: *const u8, len: usize, status: *mut u8, status_cap: usize, count_out: *mut usize) -> i32;
+    fn afx_verify_issuances_wire(ctx: *mut c_void, blob: *const u8, len: usize, status: *mut u8, status_cap: usize, count_out: *mut usize) -> i32;
+}
+
+/// An engine-level failure - AFX_E_NO_DEVICE, AFX_E_HIP or AFX_E_NO_MEMORY (the raw code is inside): the accelerator, not the data.
+/// The only thing that makes a call fall through to the crate's own body.
+#[derive(Clone, Copy, Debug)]
+pub struct EngineFault(pub i32);
+fn fault_of(rc: i32) -> Option<EngineFault> {
+    if rc == E_NO_DEVICE || rc == E_HIP || rc == E_NO_MEMORY { Some(EngineFault(rc)) } else { None }
 }
 
 /// Which of the crate's operations an engine failure interrupted: decides the nearest `CredentialError`.
 #[derive(Clone, Copy)]
 enum Op { Create, Issue, Verify, Show, VerifyIssuance }
 
-/// A batch-level engine return code (AFX_E_*, include/aeonflux_gpu.h) as the crate's error type (src/errors.rs:73-89), which has
-/// no variant for "the accelerator failed".  Codes about the caller's data map to what the crate would say; an infrastructure
-/// failure (no device, HIP error, out of memory) maps to the operation's own failure variant, so that nothing is ever accepted or
-/// issued on a fault: verification fails closed.  `last_engine_code()` tells the two apart.
+/// A batch-level engine return code (AFX_E_*, include/aeonflux_gpu.h) as the crate's error type (src/errors.rs:73-89).  Codes about
+/// the caller's data map to what the crate would say.  The crate has no variant for "the accelerator failed": an engine fault
+/// (`fault_of`) never reaches this function on the serving paths - those fall through to the CPU - and maps to the operation's own
+/// failure variant where there is nothing to fall back to (engine creation; the wire forms' `EngineFault` is returned as it is).
 fn engine_error(rc: i32, op: Op) -> CredentialError {
     match (rc, op) {
         (E_BAD_PARAMS, _) => CredentialError::NoSystemParameters,
@@ -258,17 +288,28 @@ fn set_secret_addressing(ctx: *mut c_void, group: *mut c_void, mode: SecretAddre
 
 /// `Issuer` with its parameters, tables and key resident on one MI355X (`ctx`) or on several (`group`: the batch is split
 /// contiguously over the devices inside the library, one host thread per device, no collective).
-pub struct GpuIssuer { ctx: *mut c_void, group: *mut c_void, n: usize, params: Vec<u8>, issuer_params: [u8; 64], last_rc: AtomicI32 }
+/// `fallback`: the engine's own copy of the crate's `Issuer` (the key is wiped with it, src/amacs.rs:64-82): what a call runs on when
+/// the accelerator fails.
+pub struct GpuIssuer { ctx: *mut c_void, group: *mut c_void, n: usize, params: Vec<u8>, issuer_params: [u8; 64], fallback: Issuer,
+                       fall_throughs: AtomicUsize, last_fault: AtomicI32 }
 
 /// The user's side (no issuer key): `AnonymousCredential::show` and `CredentialIssuance::verify`.
-pub struct GpuUser { ctx: *mut c_void, group: *mut c_void, n: usize, params: Vec<u8>, issuer_params: [u8; 64], last_rc: AtomicI32 }
+pub struct GpuUser { ctx: *mut c_void, group: *mut c_void, n: usize, params: Vec<u8>, issuer_params: [u8; 64],
+                     fallback_sp: SystemParameters, fallback_ip: IssuerParameters, fall_throughs: AtomicUsize, last_fault: AtomicI32 }
 
-// The handles are plain pointers into the library, which serialises the calls on a context with a mutex of its own
-// (include/aeonflux_gpu.h: "concurrent calls on one ctx are serialised"); a group's members likewise.
+// The handles are plain pointers into the library, which may be called from any number of threads at once (include/aeonflux_gpu.h
+// afx_ctx_create: small calls that arrive together share launch sets, everything else takes the context in turn); a group's
+// members likewise.
 unsafe impl Send for GpuIssuer {}
 unsafe impl Sync for GpuIssuer {}
 unsafe impl Send for GpuUser {}
 unsafe impl Sync for GpuUser {}
+
+/// The crate's `Issuer` again, field by field (it is not `Clone`; its parts are: src/parameters.rs:61,340, src/amacs.rs:51).
+fn issuer_copy(issuer: &Issuer) -> Issuer {
+    let k: &AmacsSecretKey = &issuer.amacs_key;
+    Issuer { system_parameters: issuer.system_parameters.clone(), issuer_parameters: issuer.issuer_parameters.clone(), amacs_key: k.clone() }
+}
 
 fn issuer_params_bytes(ip: &IssuerParameters) -> [u8; 64] {
     let mut b = [0u8; 64];                                            // C_W || I (src/issuer.rs:155,163)
@@ -334,7 +375,7 @@ impl GpuIssuer {
         let rc = unsafe { afx_ctx_create(&mut ctx, device, sp.as_ptr(), sp.len(), key.0.as_ptr(), key.0.len(), ip.as_ptr()) };
         if rc != 0 { return Err(engine_error(rc, Op::Create)); }
         Ok(GpuIssuer { ctx, group: core::ptr::null_mut(), n: issuer.system_parameters.NUMBER_OF_ATTRIBUTES as usize, params: sp, issuer_params: ip,
-                       last_rc: AtomicI32::new(0) })
+                       fallback: issuer_copy(issuer), fall_throughs: AtomicUsize::new(0), last_fault: AtomicI32::new(0) })
     }
 
     /// The same issuer on several GPUs of one node: every batch call below is split contiguously over `devices`.
@@ -346,15 +387,18 @@ impl GpuIssuer {
         let rc = unsafe { afx_group_create(&mut group, devices.as_ptr(), devices.len() as u32, sp.as_ptr(), sp.len(), key.0.as_ptr(), key.0.len(), ip.as_ptr()) };
         if rc != 0 { return Err(engine_error(rc, Op::Create)); }
         Ok(GpuIssuer { ctx: core::ptr::null_mut(), group, n: issuer.system_parameters.NUMBER_OF_ATTRIBUTES as usize, params: sp, issuer_params: ip,
-                       last_rc: AtomicI32::new(0) })
+                       fallback: issuer_copy(issuer), fall_throughs: AtomicUsize::new(0), last_fault: AtomicI32::new(0) })
     }
 
     /// Where secrets are kept out of table addresses (`SecretAddressing`; the default covers `issue`, `Everywhere` adds the issuer
     /// key's terms of `verify`).
     pub fn set_secret_addressing(&self, mode: SecretAddressing) -> Result<(), CredentialError> { set_secret_addressing(self.ctx, self.group, mode) }
 
-    /// The engine's return code (AFX_E_*, 0 = none) of the most recent call that failed as a whole.
-    pub fn last_engine_code(&self) -> i32 { self.last_rc.load(Ordering::Relaxed) }
+    /// How many calls ran the crate's CPU body because the accelerator failed under them (a health counter: it decides nothing).
+    pub fn fall_throughs(&self) -> usize { self.fall_throughs.load(Ordering::Relaxed) }
+    /// The AFX_E_* code of the latest such failure (0: none yet).
+    pub fn last_fault_code(&self) -> i32 { self.last_fault.load(Ordering::Relaxed) }
+    fn fell_through(&self, f: EngineFault) { self.fall_throughs.fetch_add(1, Ordering::Relaxed); self.last_fault.store(f.0, Ordering::Relaxed); }
 
     /// Was this engine built from `issuer`'s parameters?  (`IssuerParameters` = (C_W, I) commit to the key, src/parameters.rs:349-362.)
     pub fn serves(&self, issuer: &Issuer) -> bool {
@@ -370,7 +414,33 @@ impl GpuIssuer {
     where
         C: CryptoRng + RngCore,
     {
-        self.issue_batch(vec![request], csprng).pop().unwrap_or(Err(CredentialError::CredentialIssuance))
+        match self.try_issue(request, csprng) {
+            Ok(r) => r,
+            Err((f, request)) => { self.fell_through(f); self.issue_on_cpu(request, csprng) }
+        }
+    }
+
+    /// The same, with an engine fault handed back (together with the request, which was not consumed): what the delegating patch
+    /// of INTEGRATION.md section 1 calls before it falls through to the crate's own body.
+    pub fn try_issue<C: CryptoRng + RngCore>(&self, request: CredentialRequest, csprng: &mut C)
+        -> Result<Result<CredentialIssuance, CredentialError>, (EngineFault, CredentialRequest)>
+    {
+        match self.try_issue_batch(vec![request], csprng) {
+            Ok(mut v) => Ok(v.pop().unwrap_or(Err(CredentialError::CredentialIssuance))),
+            Err((f, mut back)) => match back.pop() {
+                Some(request) => Err((f, request)),
+                None => Ok(Err(CredentialError::CredentialIssuance)),            // (cannot happen: a fault returns every request)
+            },
+        }
+    }
+
+    /// The body of `Issuer::issue` (src/issuer.rs:119-123) on the engine's copy of the issuer: where a call goes when the
+    /// accelerator fails.  (Not `self.fallback.issue(..)`: with the delegating patch installed that would come back here.)
+    fn issue_on_cpu<C: CryptoRng + RngCore>(&self, request: CredentialRequest, csprng: &mut C) -> Result<CredentialIssuance, CredentialError> {
+        let amac = Amac::tag(csprng, &self.fallback.system_parameters, &self.fallback.amacs_key, &request.attributes)?;
+        let cred = AnonymousCredential { amac, attributes: request.attributes };
+        let proof = ProofOfIssuance::prove(&self.fallback, &cred);
+        Ok(CredentialIssuance { proof: proof, credential: cred })
     }
 
     /// `Issuer::verify` (src/issuer.rs:141-145), on the GPU: one presentation through the engine's latency plan.
@@ -379,7 +449,15 @@ impl GpuIssuer {
         presentation: &ProofOfValidCredential,
     ) -> Result<(), CredentialError>
     {
-        self.verify_batch(core::slice::from_ref(presentation)).pop().unwrap_or(Err(CredentialError::VerificationFailure))
+        match self.try_verify(presentation) {
+            Ok(r) => r,
+            Err(f) => { self.fell_through(f); presentation.verify(&self.fallback) }      // the crate's own body (src/issuer.rs:146)
+        }
+    }
+
+    /// The same, with an engine fault handed back instead of a verdict (the delegating patch falls through on it).
+    pub fn try_verify(&self, presentation: &ProofOfValidCredential) -> Result<Result<(), CredentialError>, EngineFault> {
+        Ok(self.try_verify_batch(core::slice::from_ref(presentation))?.pop().unwrap_or(Err(CredentialError::VerificationFailure)))
     }
 
     /// Batch `Issuer::issue` (src/issuer.rs:111-124) over requests of ANY attribute layouts: consumes the requests like the
@@ -388,8 +466,18 @@ impl GpuIssuer {
     pub fn issue_batch<C: CryptoRng + RngCore>(&self, requests: Vec<CredentialRequest>, csprng: &mut C)
         -> Vec<Result<CredentialIssuance, CredentialError>>
     {
+        match self.try_issue_batch(requests, csprng) {
+            Ok(v) => v,
+            Err((f, requests)) => { self.fell_through(f); requests.into_iter().map(|r| self.issue_on_cpu(r, &mut *csprng)).collect() }
+        }
+    }
+
+    /// `issue_batch` with an engine fault handed back together with the (unconsumed) requests.
+    pub fn try_issue_batch<C: CryptoRng + RngCore>(&self, requests: Vec<CredentialRequest>, csprng: &mut C)
+        -> Result<Vec<Result<CredentialIssuance, CredentialError>>, (EngineFault, Vec<CredentialRequest>)>
+    {
         let count = requests.len();
-        if count == 0 { return Vec::new(); }
+        if count == 0 { return Ok(Vec::new()); }
         // the reference's draws, in its order and the caller's (see the header of this file)
         let (mut t_wide, mut u_wide, mut seed) = (Wiped::new(64 * count), Wiped::new(64 * count), Wiped::new(32 * count));
         for i in 0..count {
@@ -435,8 +523,9 @@ impl GpuIssuer {
             else { afx_group_issue_mixed(self.group, groups.as_ptr(), groups.len(), status.as_mut_ptr(), count) }
         };
         if rc != 0 {
-            self.last_rc.store(rc, Ordering::Relaxed);
-            return (0..count).map(|_| Err(engine_error(rc, Op::Issue))).collect();
+            drop(groups);                                             // (they point into `stages`, which borrows nothing of `requests`)
+            if let Some(f) = fault_of(rc) { return Err((f, requests)); }
+            return Ok((0..count).map(|_| Err(engine_error(rc, Op::Issue))).collect());
         }
         let mut requests: Vec<Option<CredentialRequest>> = requests.into_iter().map(Some).collect();
         for st in stages.iter() {
@@ -455,7 +544,7 @@ impl GpuIssuer {
                 });
             }
         }
-        out.into_iter().map(|r| r.unwrap_or(Err(CredentialError::CredentialIssuance))).collect()
+        Ok(out.into_iter().map(|r| r.unwrap_or(Err(CredentialError::CredentialIssuance))).collect())
     }
 
     /// Batch `Issuer::verify` (src/issuer.rs:141-147) over ANY presentations: like the reference, which reads the shape from
@@ -465,8 +554,16 @@ impl GpuIssuer {
     /// fit together (lengths the reference would index out of range on, `presentation.rs:346,351,407`; a proof of encryption
     /// without its six responses, which zkp rejects) is answered with `VerificationFailure` without reaching the engine.
     pub fn verify_batch(&self, batch: &[ProofOfValidCredential]) -> Vec<Result<(), CredentialError>> {
+        match self.try_verify_batch(batch) {
+            Ok(v) => v,
+            Err(f) => { self.fell_through(f); batch.iter().map(|p| p.verify(&self.fallback)).collect() }
+        }
+    }
+
+    /// `verify_batch` with an engine fault handed back instead of verdicts.
+    pub fn try_verify_batch(&self, batch: &[ProofOfValidCredential]) -> Result<Vec<Result<(), CredentialError>>, EngineFault> {
         let total = batch.len();
-        if total == 0 { return Vec::new(); }
+        if total == 0 { return Ok(Vec::new()); }
         let mut status = vec![ST_VERIFICATION_FAILURE; total];
         let mut by_shape: BTreeMap<Vec<u8>, Vec<usize>> = BTreeMap::new();
         for (i, p) in batch.iter().enumerate() {
@@ -495,10 +592,10 @@ impl GpuIssuer {
             else { afx_group_verify_presentations_mixed(self.group, groups.as_ptr(), groups.len(), status.as_mut_ptr(), total) }
         };
         if rc != 0 {
-            self.last_rc.store(rc, Ordering::Relaxed);
-            return (0..total).map(|_| Err(engine_error(rc, Op::Verify))).collect();   // fails closed
+            if let Some(f) = fault_of(rc) { return Err(f); }                           // the accelerator: no verdict is made up
+            return Ok((0..total).map(|_| Err(engine_error(rc, Op::Verify))).collect());
         }
-        status.iter().map(|s| if *s == ST_OK { Ok(()) } else { Err(CredentialError::VerificationFailure) }).collect()
+        Ok(status.iter().map(|s| if *s == ST_OK { Ok(()) } else { Err(CredentialError::VerificationFailure) }).collect())
     }
 }
 
@@ -525,8 +622,21 @@ impl<'a> GpuCredential<'a> {
     ) -> Result<ProofOfValidCredential, CredentialError>
     {
         if !self.user.serves(system_parameters, issuer_parameters) { return Err(CredentialError::NoSystemParameters); }
-        self.user.show_batch(core::slice::from_ref(self.credential), keypair.map(core::slice::from_ref), &mut csprng)
-            .pop().unwrap_or(Err(CredentialError::MissingData))
+        match self.try_show(keypair, &mut csprng) {
+            Ok(r) => r,
+            Err(f) => {                                                                  // the crate's own body (src/credential.rs:45)
+                self.user.fell_through(f);
+                ProofOfValidCredential::prove(&system_parameters, &issuer_parameters, self.credential, keypair, &mut csprng)
+            }
+        }
+    }
+
+    /// The same without the parameter check, with an engine fault handed back (the delegating patch falls through on it).
+    pub fn try_show<C: CryptoRng + RngCore>(&self, keypair: Option<&SymmetricKeypair>, csprng: &mut C)
+        -> Result<Result<ProofOfValidCredential, CredentialError>, EngineFault>
+    {
+        Ok(self.user.try_show_batch(core::slice::from_ref(self.credential), keypair.map(core::slice::from_ref), csprng)?
+            .pop().unwrap_or(Err(CredentialError::MissingData)))
     }
 }
 
@@ -539,7 +649,27 @@ impl<'a> GpuIssuance<'a> {
     ) -> Result<AnonymousCredential, CredentialError>
     {
         if !self.user.serves(system_parameters, issuer_parameters) { return Err(CredentialError::NoSystemParameters); }
-        self.user.verify_issuance_batch(vec![self.issuance]).pop().unwrap_or(Err(CredentialError::VerificationFailure))
+        match self.user.try_verify_issuance_batch(vec![self.issuance]) {
+            Ok(mut v) => v.pop().unwrap_or(Err(CredentialError::VerificationFailure)),
+            Err((f, mut back)) => {                                                      // the crate's own body (src/issuer.rs:54-56)
+                self.user.fell_through(f);
+                match back.pop() {
+                    Some(iss) => iss.proof.verify(system_parameters, issuer_parameters, &iss.credential).and(Ok(iss.credential)),
+                    None => Err(CredentialError::VerificationFailure),
+                }
+            }
+        }
+    }
+
+    /// The same, with an engine fault handed back together with the (unconsumed) issuance.
+    pub fn try_verify(self) -> Result<Result<AnonymousCredential, CredentialError>, (EngineFault, CredentialIssuance)> {
+        match self.user.try_verify_issuance_batch(vec![self.issuance]) {
+            Ok(mut v) => Ok(v.pop().unwrap_or(Err(CredentialError::VerificationFailure))),
+            Err((f, mut back)) => match back.pop() {
+                Some(iss) => Err((f, iss)),
+                None => Ok(Err(CredentialError::VerificationFailure)),
+            },
+        }
     }
 }
 
@@ -551,7 +681,7 @@ impl GpuUser {
         let rc = unsafe { afx_ctx_create(&mut ctx, device, sp.as_ptr(), sp.len(), core::ptr::null(), 0, ip.as_ptr()) };
         if rc != 0 { return Err(engine_error(rc, Op::Create)); }
         Ok(GpuUser { ctx, group: core::ptr::null_mut(), n: system_parameters.NUMBER_OF_ATTRIBUTES as usize, params: sp, issuer_params: ip,
-                     last_rc: AtomicI32::new(0) })
+                     fallback_sp: system_parameters.clone(), fallback_ip: issuer_parameters.clone(), fall_throughs: AtomicUsize::new(0), last_fault: AtomicI32::new(0) })
     }
 
     /// The same on several GPUs of the node: batches are split contiguously over `devices` inside the library.
@@ -562,15 +692,18 @@ impl GpuUser {
         let rc = unsafe { afx_group_create(&mut group, devices.as_ptr(), devices.len() as u32, sp.as_ptr(), sp.len(), core::ptr::null(), 0, ip.as_ptr()) };
         if rc != 0 { return Err(engine_error(rc, Op::Create)); }
         Ok(GpuUser { ctx: core::ptr::null_mut(), group, n: system_parameters.NUMBER_OF_ATTRIBUTES as usize, params: sp, issuer_params: ip,
-                     last_rc: AtomicI32::new(0) })
+                     fallback_sp: system_parameters.clone(), fallback_ip: issuer_parameters.clone(), fall_throughs: AtomicUsize::new(0), last_fault: AtomicI32::new(0) })
     }
 
     /// Where secrets are kept out of table addresses (`SecretAddressing`; the default covers every scalar of `show`: blindings, the
     /// credential's `t`, the symmetric key).
     pub fn set_secret_addressing(&self, mode: SecretAddressing) -> Result<(), CredentialError> { set_secret_addressing(self.ctx, self.group, mode) }
 
-    /// The engine's return code (AFX_E_*, 0 = none) of the most recent call that failed as a whole.
-    pub fn last_engine_code(&self) -> i32 { self.last_rc.load(Ordering::Relaxed) }
+    /// How many calls ran the crate's CPU body because the accelerator failed under them (a health counter: it decides nothing).
+    pub fn fall_throughs(&self) -> usize { self.fall_throughs.load(Ordering::Relaxed) }
+    /// The AFX_E_* code of the latest such failure (0: none yet).
+    pub fn last_fault_code(&self) -> i32 { self.last_fault.load(Ordering::Relaxed) }
+    fn fell_through(&self, f: EngineFault) { self.fall_throughs.fetch_add(1, Ordering::Relaxed); self.last_fault.store(f.0, Ordering::Relaxed); }
 
     /// Was this engine built for these parameters?
     pub fn serves(&self, system_parameters: &SystemParameters, issuer_parameters: &IssuerParameters) -> bool {
@@ -590,10 +723,57 @@ impl GpuUser {
     pub fn show_batch<C: CryptoRng + RngCore>(&self, creds: &[AnonymousCredential], keypairs: Option<&[SymmetricKeypair]>, csprng: &mut C)
         -> Vec<Result<ProofOfValidCredential, CredentialError>>
     {
+        match self.try_show_batch(creds, keypairs, csprng) {
+            Ok(v) => v,
+            Err(f) => { self.fell_through(f); self.show_on_cpu(creds, keypairs, csprng) }
+        }
+    }
+
+    /// `show_batch` with an engine fault handed back instead of presentations.
+    pub fn try_show_batch<C: CryptoRng + RngCore>(&self, creds: &[AnonymousCredential], keypairs: Option<&[SymmetricKeypair]>, csprng: &mut C)
+        -> Result<Vec<Result<ProofOfValidCredential, CredentialError>>, EngineFault>
+    {
         let count = creds.len();
-        if count == 0 { return Vec::new(); }
-        if let Some(kps) = keypairs { if kps.len() != count { return (0..count).map(|_| Err(CredentialError::MissingData)).collect(); } }
-        let mut out: Vec<Option<Result<ProofOfValidCredential, CredentialError>>> = (0..count).map(|_| None).collect();
+        match self.run_show(creds, keypairs, csprng) {
+            Ok(run) => Ok(finish_show(&run, count, rebuild_presentation)),
+            Err(ShowStop::Fault(f)) => Err(f),
+            Err(ShowStop::All(e)) => Ok((0..count).map(|_| Err(e)).collect()),
+        }
+    }
+
+    /// The same presentations as the bytes a user sends to the issuer (one AFXP v1 section each: `CompressedPresentation`), written
+    /// from the 32-byte cells the engine returned - no point is decompressed on the way.
+    pub fn show_batch_wire<C: CryptoRng + RngCore>(&self, creds: &[AnonymousCredential], keypairs: Option<&[SymmetricKeypair]>, csprng: &mut C)
+        -> Vec<Result<CompressedPresentation, CredentialError>>
+    {
+        let count = creds.len();
+        match self.run_show(creds, keypairs, csprng) {
+            Ok(run) => finish_show(&run, count, record_of_shown),
+            Err(ShowStop::All(e)) => (0..count).map(|_| Err(e)).collect(),
+            Err(ShowStop::Fault(f)) => {
+                self.fell_through(f);
+                self.show_on_cpu(creds, keypairs, csprng).into_iter().map(|r| r.and_then(|p| CompressedPresentation::from_presentation(&p))).collect()
+            }
+        }
+    }
+
+    /// The crate's own `ProofOfValidCredential::prove` per credential (src/credential.rs:45): where a call goes when the accelerator fails.
+    fn show_on_cpu<C: CryptoRng + RngCore>(&self, creds: &[AnonymousCredential], keypairs: Option<&[SymmetricKeypair]>, csprng: &mut C)
+        -> Vec<Result<ProofOfValidCredential, CredentialError>>
+    {
+        if let Some(kps) = keypairs { if kps.len() != creds.len() { return (0..creds.len()).map(|_| Err(CredentialError::MissingData)).collect(); } }
+        creds.iter().enumerate().map(|(i, c)| {
+            let kp: Option<&SymmetricKeypair> = match keypairs { Some(kps) => Some(&kps[i]), None => None };
+            ProofOfValidCredential::prove(&self.fallback_sp, &self.fallback_ip, c, kp, &mut *csprng)
+        }).collect()
+    }
+
+    /// The engine part of `show`: group by layout, stage, draw, call.
+    fn run_show<C: CryptoRng + RngCore>(&self, creds: &[AnonymousCredential], keypairs: Option<&[SymmetricKeypair]>, csprng: &mut C) -> Result<ShowRun, ShowStop> {
+        let count = creds.len();
+        if count == 0 { return Ok(ShowRun { stages: Vec::new(), shapes: Vec::new(), status: Vec::new(), early: Vec::new() }); }
+        if let Some(kps) = keypairs { if kps.len() != count { return Err(ShowStop::All(CredentialError::MissingData)); } }
+        let mut early: Vec<Option<CredentialError>> = (0..count).map(|_| None).collect();
         let mut by_layout: BTreeMap<Vec<u8>, Vec<usize>> = BTreeMap::new();
         let mut nsp_of = vec![0usize; count];
         for (i, c) in creds.iter().enumerate() {
@@ -604,7 +784,7 @@ impl GpuUser {
                     nsp_of[i] = k.iter().filter(|x| **x == ATTR_SECRET_POINT).count();
                     by_layout.entry(k).or_insert_with(Vec::new).push(i);
                 }
-                None => out[i] = Some(Err(CredentialError::WrongNumberOfAttributes)),
+                None => early[i] = Some(CredentialError::WrongNumberOfAttributes),
             }
         }
         // the reference's csprng draws in its order, then the proofs' seeds (see the header of this file)
@@ -615,22 +795,18 @@ impl GpuUser {
         if enc_total != 0 { csprng.fill_bytes(&mut enc_seed.0); }                       // ... and in each ProofOfEncryption's (:301): credential by credential, attribute order
         let mut enc_at = vec![0usize; count];                                          // where credential i's enc seeds start
         for i in 1..count { enc_at[i] = enc_at[i - 1] + nsp_of[i - 1]; }
-        struct Stage { key: Vec<u8>, members: Vec<usize>, positions: Vec<u64>, hs: usize, nsp: usize,
-                       values: Wiped, m2: Wiped, m3: Wiped, t: Vec<u8>, u: Vec<u8>, v: Vec<u8>, ka: Wiped, ka0: Wiped, ka1: Wiped, kpk: Vec<u8>,
-                       z_wide: Wiped, seed: Wiped, enc_seeds: Wiped,
-                       o_ch: Vec<u8>, o_rs: Vec<u8>, o_x0: Vec<u8>, o_x1: Vec<u8>, o_cv: Vec<u8>, o_cy: Vec<u8>, o_av: Vec<u8>, enc_cols: Vec<[Vec<u8>; 9]> }
-        let mut stages: Vec<Stage> = grouped(by_layout).into_iter().map(|(key, members)| {
+        let mut stages: Vec<ShowStage> = grouped(by_layout).into_iter().map(|(key, members)| {
             let (m, na) = (members.len(), key.len());
             let hs = key.iter().filter(|x| **x == ATTR_SECRET_SCALAR).count();
             let nsp = key.iter().filter(|x| **x == ATTR_SECRET_POINT).count();
             let col = |k: usize| vec![0u8; 32 * k * m];
             // hidden attribute values are secrets of the user (amacs::Attribute zeroizes them, src/amacs.rs:184-200)
-            let mut st = Stage { positions: positions_of(&members), hs, nsp, values: Wiped::new(32 * na * m), m2: Wiped::new(32 * na * m), m3: Wiped::new(32 * na * m),
-                                 t: col(1), u: col(1), v: col(1), ka: Wiped::new(32 * m), ka0: Wiped::new(32 * m), ka1: Wiped::new(32 * m), kpk: col(1),
-                                 z_wide: Wiped::new(64 * m), seed: Wiped::new(32 * m), enc_seeds: Wiped::new(32 * m * nsp.max(1)),
-                                 o_ch: col(1), o_rs: col(3 + hs), o_x0: col(1), o_x1: col(1), o_cv: col(1), o_cy: col(na), o_av: col(na),
-                                 enc_cols: (0..nsp).map(|_| [col(1), col(6), col(1), col(1), col(1), col(1), col(1), col(1), col(1)]).collect(),
-                                 key, members };
+            let mut st = ShowStage { positions: positions_of(&members), hs, nsp, values: Wiped::new(32 * na * m), m2: Wiped::new(32 * na * m), m3: Wiped::new(32 * na * m),
+                                     t: col(1), u: col(1), v: col(1), ka: Wiped::new(32 * m), ka0: Wiped::new(32 * m), ka1: Wiped::new(32 * m), kpk: col(1),
+                                     z_wide: Wiped::new(64 * m), seed: Wiped::new(32 * m), enc_seeds: Wiped::new(32 * m * nsp.max(1)),
+                                     o_ch: col(1), o_rs: col(3 + hs), o_x0: col(1), o_x1: col(1), o_cv: col(1), o_cy: col(na), o_av: col(na),
+                                     enc_cols: (0..nsp).map(|_| [col(1), col(6), col(1), col(1), col(1), col(1), col(1), col(1), col(1)]).collect(),
+                                     key, members };
             for (j, i) in st.members.iter().enumerate() {
                 let c = &creds[*i];
                 for (k, a) in c.attributes.iter().enumerate() {
@@ -682,55 +858,31 @@ impl GpuUser {
             else { afx_group_show_mixed(self.group, groups.as_mut_ptr(), groups.len(), status.as_mut_ptr(), count) }
         };
         if rc != 0 {
-            self.last_rc.store(rc, Ordering::Relaxed);
-            return (0..count).map(|_| Err(engine_error(rc, Op::Show))).collect();
+            if let Some(f) = fault_of(rc) { return Err(ShowStop::Fault(f)); }
+            return Err(ShowStop::All(engine_error(rc, Op::Show)));
         }
-        // rebuild ProofOfValidCredential (src/nizk/presentation.rs:118-127) per item
-        for (g, st) in stages.iter().enumerate() {
-            let (m, na, shape) = (st.members.len(), st.key.len(), &groups[g].shape_out);
-            for (j, i) in st.members.iter().enumerate() {
-                out[*i] = Some(match status[*i] {
-                    ST_OK => (|| -> Result<ProofOfValidCredential, CredentialError> {
-                        let proof = CompactProof { challenge: sc(&st.o_ch, 0, m, j)?,
-                                                   responses: (0..3 + st.hs).map(|k| sc(&st.o_rs, k, m, j)).collect::<Result<Vec<Scalar>, CredentialError>>()? };
-                        let encrypted_attributes = (0..na).map(|k| -> Result<EncryptedAttribute, CredentialError> { Ok(match shape.kinds[k] {
-                            0 => EncryptedAttribute::PublicScalar(sc(&st.o_av, k, m, j)?),
-                            1 => EncryptedAttribute::SecretScalar,
-                            2 => EncryptedAttribute::PublicPoint(pt(&st.o_av, k, m, j)?),
-                            _ => EncryptedAttribute::SecretPoint,
-                        }) }).collect::<Result<Vec<EncryptedAttribute>, CredentialError>>()?;
-                        let proofs_of_encryption = (0..st.nsp).map(|e| -> Result<(u16, ProofOfEncryption), CredentialError> {
-                            let c = &st.enc_cols[e];
-                            let index = shape.enc_indices[e];
-                            Ok((index, ProofOfEncryption {
-                                proof: CompactProof { challenge: sc(&c[0], 0, m, j)?,
-                                                      responses: (0..6).map(|k| sc(&c[1], k, m, j)).collect::<Result<Vec<Scalar>, CredentialError>>()? },
-                                public_key: SymmetricPublicKey { pk: pt(&c[2], 0, m, j)? },
-                                ciphertext: Ciphertext { E1: pt(&c[3], 0, m, j)?, E2: pt(&c[4], 0, m, j)? },
-                                index,
-                                C_y_1: pt(&c[5], 0, m, j)?, C_y_2: pt(&c[6], 0, m, j)?, C_y_3: pt(&c[7], 0, m, j)?, C_y_2_prime: pt(&c[8], 0, m, j)?,
-                            }))
-                        }).collect::<Result<Vec<(u16, ProofOfEncryption)>, CredentialError>>()?;
-                        Ok(ProofOfValidCredential {
-                            proof, proofs_of_encryption, encrypted_attributes,
-                            hidden_scalar_indices: shape.hidden_scalar_indices[..shape.n_hidden_scalars as usize].to_vec(),
-                            C_x_0: pt(&st.o_x0, 0, m, j)?, C_x_1: pt(&st.o_x1, 0, m, j)?, C_V: pt(&st.o_cv, 0, m, j)?,
-                            C_y: (0..na).map(|k| pt(&st.o_cy, k, m, j)).collect::<Result<Vec<RistrettoPoint>, CredentialError>>()?,
-                        })
-                    })(),
-                    ST_NO_SYMMETRIC_KEY => Err(CredentialError::NoSymmetricKey),
-                    _ => Err(CredentialError::MissingData),                        // a status this operation does not have: no presentation is made up
-                });
-            }
-        }
-        out.into_iter().map(|r| r.unwrap_or(Err(CredentialError::MissingData))).collect()
+        let shapes: Vec<AfxShape> = groups.iter().map(|g| g.shape_out).collect();
+        Ok(ShowRun { stages, shapes, status, early })
     }
 
     /// Batch `CredentialIssuance::verify` (src/issuer.rs:48-57) over issuances of ANY attribute layouts: consumes the issuances
     /// and moves each credential out on success.
     pub fn verify_issuance_batch(&self, issuances: Vec<CredentialIssuance>) -> Vec<Result<AnonymousCredential, CredentialError>> {
+        match self.try_verify_issuance_batch(issuances) {
+            Ok(v) => v,
+            Err((f, issuances)) => {                                                   // the crate's own body (src/issuer.rs:54-56)
+                self.fell_through(f);
+                issuances.into_iter().map(|iss| iss.proof.verify(&self.fallback_sp, &self.fallback_ip, &iss.credential).and(Ok(iss.credential))).collect()
+            }
+        }
+    }
+
+    /// `verify_issuance_batch` with an engine fault handed back together with the (unconsumed) issuances.
+    pub fn try_verify_issuance_batch(&self, issuances: Vec<CredentialIssuance>)
+        -> Result<Vec<Result<AnonymousCredential, CredentialError>>, (EngineFault, Vec<CredentialIssuance>)>
+    {
         let count = issuances.len();
-        if count == 0 { return Vec::new(); }
+        if count == 0 { return Ok(Vec::new()); }
         // layout = attribute kinds + the proof's response count (zkp rejects a wrong count; the engine fails such a group whole)
         let mut by_layout: BTreeMap<Vec<u8>, Vec<usize>> = BTreeMap::new();
         for (i, iss) in issuances.iter().enumerate() {
@@ -774,15 +926,407 @@ impl GpuUser {
             else { afx_group_verify_issuances_mixed(self.group, groups.as_ptr(), groups.len(), status.as_mut_ptr(), count) }
         };
         if rc != 0 {
-            self.last_rc.store(rc, Ordering::Relaxed);
-            return (0..count).map(|_| Err(engine_error(rc, Op::VerifyIssuance))).collect();   // fails closed
+            if let Some(f) = fault_of(rc) { return Err((f, issuances)); }              // the accelerator: no verdict is made up
+            return Ok((0..count).map(|_| Err(engine_error(rc, Op::VerifyIssuance))).collect());
         }
-        issuances.into_iter().enumerate().map(|(i, iss)| if status[i] == ST_OK { Ok(iss.credential) } else { Err(CredentialError::VerificationFailure) }).collect()
+        Ok(issuances.into_iter().enumerate().map(|(i, iss)| if status[i] == ST_OK { Ok(iss.credential) } else { Err(CredentialError::VerificationFailure) }).collect())
     }
+
+    /// `CredentialIssuance::verify` over an issuer's serialized answer (an AFXI v1 batch, `issuance_to_bytes` /
+    /// afx_issuance_wire_pack): one verdict per record, nothing decompressed on the host.  `Err(MissingData)`: the bytes are no AFXI
+    /// batch.  On an engine fault the records are rebuilt and checked by the crate's own `ProofOfIssuance::verify`.
+    pub fn verify_issuances_wire(&self, blob: &[u8]) -> Result<Vec<Result<(), CredentialError>>, CredentialError> {
+        match self.try_verify_issuances_wire(blob) {
+            Ok(r) => r,
+            Err(f) => {
+                self.fell_through(f);
+                let (kinds, nr, count, off) = afxi_parse(blob).ok_or(CredentialError::MissingData)?;
+                let cells = 4 + nr + kinds.len();
+                Ok((0..count).map(|i| {
+                    let iss = issuance_from_record(&kinds, nr, &blob[off + 32 * cells * i..off + 32 * cells * (i + 1)], None)?;
+                    iss.proof.verify(&self.fallback_sp, &self.fallback_ip, &iss.credential)
+                }).collect())
+            }
+        }
+    }
+
+    /// The same, with an engine fault handed back.
+    pub fn try_verify_issuances_wire(&self, blob: &[u8]) -> Result<Result<Vec<Result<(), CredentialError>>, CredentialError>, EngineFault> {
+        let cap = blob.len() / 32 + 1;
+        let mut status = vec![ST_VERIFICATION_FAILURE; cap];
+        let mut count = 0usize;
+        let ctx = if self.group.is_null() { self.ctx } else { unsafe { afx_group_member(self.group, 0) } };   // (no group form of this call: member 0 takes it)
+        let rc = unsafe { afx_verify_issuances_wire(ctx, blob.as_ptr(), blob.len(), status.as_mut_ptr(), cap, &mut count) };
+        if rc != 0 {
+            if let Some(f) = fault_of(rc) { return Err(f); }
+            return Ok(Err(engine_error(rc, Op::VerifyIssuance)));
+        }
+        Ok(Ok(status.iter().take(count).map(|s| if *s == ST_OK { Ok(()) } else { Err(CredentialError::VerificationFailure) }).collect()))
+    }
+}
+
+/// One layout group of a `show` call: its inputs staged column-major and the arrays the engine writes.
+struct ShowStage { key: Vec<u8>, members: Vec<usize>, positions: Vec<u64>, hs: usize, nsp: usize,
+                   values: Wiped, m2: Wiped, m3: Wiped, t: Vec<u8>, u: Vec<u8>, v: Vec<u8>, ka: Wiped, ka0: Wiped, ka1: Wiped, kpk: Vec<u8>,
+                   z_wide: Wiped, seed: Wiped, enc_seeds: Wiped,
+                   o_ch: Vec<u8>, o_rs: Vec<u8>, o_x0: Vec<u8>, o_x1: Vec<u8>, o_cv: Vec<u8>, o_cy: Vec<u8>, o_av: Vec<u8>, enc_cols: Vec<[Vec<u8>; 9]> }
+/// What the engine made of a `show` call: per layout group its arrays and the presentation shape, per credential its status;
+/// `early`: credentials that never reached the engine.
+struct ShowRun { stages: Vec<ShowStage>, shapes: Vec<AfxShape>, status: Vec<u8>, early: Vec<Option<CredentialError>> }
+/// Why a `show` call made no presentations at all: the accelerator failed, or one answer fits every credential.
+enum ShowStop { Fault(EngineFault), All(CredentialError) }
+
+/// Per credential, in the caller's order: `make(group, shape, group size, index in the group)` for the ones the engine showed.
+fn finish_show<T>(run: &ShowRun, count: usize, make: fn(&ShowStage, &AfxShape, usize, usize) -> Result<T, CredentialError>) -> Vec<Result<T, CredentialError>> {
+    let mut out: Vec<Option<Result<T, CredentialError>>> = (0..count).map(|i| run.early.get(i).and_then(|e| *e).map(Err)).collect();
+    for (g, st) in run.stages.iter().enumerate() {
+        let m = st.members.len();
+        for (j, i) in st.members.iter().enumerate() {
+            out[*i] = Some(match run.status[*i] {
+                ST_OK => make(st, &run.shapes[g], m, j),
+                ST_NO_SYMMETRIC_KEY => Err(CredentialError::NoSymmetricKey),
+                _ => Err(CredentialError::MissingData),                            // a status this operation does not have: no presentation is made up
+            });
+        }
+    }
+    out.into_iter().map(|r| r.unwrap_or(Err(CredentialError::MissingData))).collect()
+}
+
+/// `ProofOfValidCredential` (src/nizk/presentation.rs:118-127) from item `j` of a group's output arrays: every point is decompressed.
+fn rebuild_presentation(st: &ShowStage, shape: &AfxShape, m: usize, j: usize) -> Result<ProofOfValidCredential, CredentialError> {
+    let na = st.key.len();
+    let proof = CompactProof { challenge: sc(&st.o_ch, 0, m, j)?,
+                               responses: (0..3 + st.hs).map(|k| sc(&st.o_rs, k, m, j)).collect::<Result<Vec<Scalar>, CredentialError>>()? };
+    let encrypted_attributes = (0..na).map(|k| -> Result<EncryptedAttribute, CredentialError> { Ok(match shape.kinds[k] {
+        0 => EncryptedAttribute::PublicScalar(sc(&st.o_av, k, m, j)?),
+        1 => EncryptedAttribute::SecretScalar,
+        2 => EncryptedAttribute::PublicPoint(pt(&st.o_av, k, m, j)?),
+        _ => EncryptedAttribute::SecretPoint,
+    }) }).collect::<Result<Vec<EncryptedAttribute>, CredentialError>>()?;
+    let proofs_of_encryption = (0..st.nsp).map(|e| -> Result<(u16, ProofOfEncryption), CredentialError> {
+        let c = &st.enc_cols[e];
+        let index = shape.enc_indices[e];
+        Ok((index, ProofOfEncryption {
+            proof: CompactProof { challenge: sc(&c[0], 0, m, j)?,
+                                  responses: (0..6).map(|k| sc(&c[1], k, m, j)).collect::<Result<Vec<Scalar>, CredentialError>>()? },
+            public_key: SymmetricPublicKey { pk: pt(&c[2], 0, m, j)? },
+            ciphertext: Ciphertext { E1: pt(&c[3], 0, m, j)?, E2: pt(&c[4], 0, m, j)? },
+            index,
+            C_y_1: pt(&c[5], 0, m, j)?, C_y_2: pt(&c[6], 0, m, j)?, C_y_3: pt(&c[7], 0, m, j)?, C_y_2_prime: pt(&c[8], 0, m, j)?,
+        }))
+    }).collect::<Result<Vec<(u16, ProofOfEncryption)>, CredentialError>>()?;
+    Ok(ProofOfValidCredential {
+        proof, proofs_of_encryption, encrypted_attributes,
+        hidden_scalar_indices: shape.hidden_scalar_indices[..shape.n_hidden_scalars as usize].to_vec(),
+        C_x_0: pt(&st.o_x0, 0, m, j)?, C_x_1: pt(&st.o_x1, 0, m, j)?, C_V: pt(&st.o_cv, 0, m, j)?,
+        C_y: (0..na).map(|k| pt(&st.o_cy, k, m, j)).collect::<Result<Vec<RistrettoPoint>, CredentialError>>()?,
+    })
+}
+
+/// The same item as the bytes that go on the wire: the engine's 32-byte cells in AFXP record order, nothing decompressed.
+fn record_of_shown(st: &ShowStage, shape: &AfxShape, m: usize, j: usize) -> Result<CompressedPresentation, CredentialError> {
+    let mut bytes = afxp_header(shape, 1).ok_or(CredentialError::MissingData)?;
+    afxp_record(&mut bytes, shape, m, j, &st.o_ch, &st.o_rs, &st.o_x0, &st.o_x1, &st.o_cv, &st.o_cy, &st.o_av, &st.enc_cols);
+    Ok(CompressedPresentation { bytes })
 }
 
 impl Drop for GpuUser {
     fn drop(&mut self) { unsafe { if self.group.is_null() { afx_ctx_destroy(self.ctx) } else { afx_group_destroy(self.group) } } }
+}
+
+// ---- the wire format: AFXP v1 (presentations) and AFXI v1 (issuances), include/aeonflux_gpu.h ----------------------------------
+// The crate has no byte form for these messages (`// XXX the commitments should be compressed`, src/nizk/presentation.rs:117; its
+// `IssuerParameters::{to,from}_bytes` are `unimplemented!()`, src/parameters.rs:365-372).  The functions below write and read exactly
+// what the library's C packers and parsers do (afx_wire_pack_presentations, afx_wire_parse, afx_issuance_wire_pack,
+// afx_issuance_wire_parse; style of src/parameters.rs:155-184: little-endian u32 counts, then 32-byte items), so the bytes a Rust
+// client writes are the bytes the engine verifies: tests/golden/wire.json holds C-packed messages and integration/pin_against_crate.rs
+// asserts these writers reproduce them byte for byte.
+//   AFXP: "AFXP" | u32 1 | u32 count | u32 cells | u32 n | u32 nr | u32 hs | u32 ne | kinds[n] | hidden[hs] u16 | enc_indices[ne] u16 | 0-pad to 32
+//         then per record: challenge | responses[nr] | C_x_0 | C_x_1 | C_V | C_y[n] | value of every public attribute | per proof of
+//         encryption: challenge | responses[6] | pk | E1 | E2 | C_y_1 | C_y_2 | C_y_3 | C_y_2'
+//   AFXI: "AFXI" | u32 1 | u32 count | u32 cells | u32 n | u32 nr | kinds[n] | 0-pad to 32
+//         then per record: t | U | V | challenge | responses[nr] | value of every attribute (a scalar, a point, or a plaintext's M1)
+
+fn is_public_kind(k: u8) -> bool { k == 0 || k == 2 }
+fn afxp_cells(shape: &AfxShape) -> usize {
+    let n = shape.n_attributes as usize;
+    let public = shape.kinds[..n.min(AFX_MAX_ATTRIBUTES)].iter().filter(|k| is_public_kind(**k)).count();
+    1 + shape.n_responses as usize + 3 + n + public + 14 * shape.n_enc_proofs as usize
+}
+/// Header of a batch of `count` presentations of this shape; `None`: a shape the format does not carry.
+fn afxp_header(shape: &AfxShape, count: u32) -> Option<Vec<u8>> {
+    let (n, nr, hs, ne) = (shape.n_attributes as usize, shape.n_responses as usize, shape.n_hidden_scalars as usize, shape.n_enc_proofs as usize);
+    if n > AFX_MAX_ATTRIBUTES || nr > 3 + AFX_MAX_ATTRIBUTES || hs > AFX_MAX_ATTRIBUTES || ne > AFX_MAX_ATTRIBUTES { return None; }
+    if shape.kinds[..n].iter().any(|k| *k > 3) { return None; }
+    let mut h = Vec::with_capacity(96);
+    h.extend_from_slice(b"AFXP");
+    for v in [1u32, count, afxp_cells(shape) as u32, n as u32, nr as u32, hs as u32, ne as u32].iter() { h.extend_from_slice(&v.to_le_bytes()); }
+    h.extend_from_slice(&shape.kinds[..n]);
+    for i in 0..hs { h.extend_from_slice(&shape.hidden_scalar_indices[i].to_le_bytes()); }
+    for i in 0..ne { h.extend_from_slice(&shape.enc_indices[i].to_le_bytes()); }
+    while h.len() % 32 != 0 { h.push(0); }
+    Some(h)
+}
+/// Appends the record of item `j` of column arrays over `m` items (the engine's struct-of-arrays layout, `Columns` / `ShowStage`).
+fn afxp_record(out: &mut Vec<u8>, shape: &AfxShape, m: usize, j: usize, challenge: &[u8], responses: &[u8], c_x_0: &[u8], c_x_1: &[u8], c_v: &[u8],
+               c_y: &[u8], attr_values: &[u8], enc: &[[Vec<u8>; 9]]) {
+    let n = shape.n_attributes as usize;
+    out.extend_from_slice(&cell(challenge, 0, m, j));
+    for k in 0..shape.n_responses as usize { out.extend_from_slice(&cell(responses, k, m, j)); }
+    out.extend_from_slice(&cell(c_x_0, 0, m, j));
+    out.extend_from_slice(&cell(c_x_1, 0, m, j));
+    out.extend_from_slice(&cell(c_v, 0, m, j));
+    for k in 0..n { out.extend_from_slice(&cell(c_y, k, m, j)); }
+    for k in 0..n { if is_public_kind(shape.kinds[k]) { out.extend_from_slice(&cell(attr_values, k, m, j)); } }
+    for e in enc.iter().take(shape.n_enc_proofs as usize) {
+        out.extend_from_slice(&cell(&e[0], 0, m, j));
+        for k in 0..6 { out.extend_from_slice(&cell(&e[1], k, m, j)); }
+        for f in 2..9 { out.extend_from_slice(&cell(&e[f], 0, m, j)); }
+    }
+}
+fn rd_u32(b: &[u8], at: usize) -> u32 { u32::from_le_bytes([b[at], b[at + 1], b[at + 2], b[at + 3]]) }
+/// The header of an AFXP section at the start of `b` (afx_wire_parse): shape, count, offset of the records, cells per record, and
+/// the section's length.  `None`: not an AFXP v1 section, or one that runs past the end of `b`.
+fn afxp_parse(b: &[u8]) -> Option<(AfxShape, usize, usize, usize, usize)> {
+    if b.len() < 32 || &b[..4] != b"AFXP" || rd_u32(b, 4) != 1 { return None; }
+    let (count, cells) = (rd_u32(b, 8) as usize, rd_u32(b, 12) as usize);
+    let (n, nr, hs, ne) = (rd_u32(b, 16) as usize, rd_u32(b, 20) as usize, rd_u32(b, 24) as usize, rd_u32(b, 28) as usize);
+    if n > AFX_MAX_ATTRIBUTES || nr > 3 + AFX_MAX_ATTRIBUTES || hs > AFX_MAX_ATTRIBUTES || ne > AFX_MAX_ATTRIBUTES { return None; }
+    let hdr = (32 + n + 2 * hs + 2 * ne + 31) & !31usize;
+    if b.len() < hdr { return None; }
+    let mut shape = AfxShape { n_attributes: n as u32, kinds: [0; AFX_MAX_ATTRIBUTES], n_responses: nr as u32, n_hidden_scalars: hs as u32,
+                               hidden_scalar_indices: [0; AFX_MAX_ATTRIBUTES], n_enc_proofs: ne as u32, enc_indices: [0; AFX_MAX_ATTRIBUTES] };
+    let mut at = 32;
+    for i in 0..n { shape.kinds[i] = b[at]; at += 1; if shape.kinds[i] > 3 { return None; } }
+    for i in 0..hs { shape.hidden_scalar_indices[i] = u16::from_le_bytes([b[at], b[at + 1]]); at += 2; }
+    for i in 0..ne { shape.enc_indices[i] = u16::from_le_bytes([b[at], b[at + 1]]); at += 2; }
+    if cells != afxp_cells(&shape) { return None; }
+    let len = hdr.checked_add(count.checked_mul(cells)?.checked_mul(32)?)?;
+    if len > b.len() { return None; }
+    Some((shape, count, hdr, cells, len))
+}
+
+/// A presentation as it travels: one AFXP v1 section with one record - the 32-byte cells exactly as they were received (or as the
+/// engine made them).  Parsing checks the framing only; no point is decompressed until `decompress` is asked for, and
+/// `GpuIssuer::verify_compressed` / `verify_wire` never ask.
+#[derive(Clone)]
+pub struct CompressedPresentation { bytes: Vec<u8> }
+
+impl CompressedPresentation {
+    /// `ProofOfValidCredential::from_bytes` without the decompression: `WrongNumberOfBytes` unless `bytes` is exactly one section
+    /// holding exactly one record.
+    pub fn from_bytes(bytes: &[u8]) -> Result<CompressedPresentation, CredentialError> {
+        match afxp_parse(bytes) {
+            Some((_, 1, _, _, len)) if len == bytes.len() => Ok(CompressedPresentation { bytes: bytes.to_vec() }),
+            _ => Err(CredentialError::WrongNumberOfBytes),
+        }
+    }
+    pub fn as_bytes(&self) -> &[u8] { &self.bytes }
+    pub fn to_bytes(&self) -> Vec<u8> { self.bytes.clone() }
+    /// The compressed form of a presentation the crate holds (every point is compressed: the one-off cost the crate's XXX is about).
+    pub fn from_presentation(p: &ProofOfValidCredential) -> Result<CompressedPresentation, CredentialError> {
+        if shape_key(p).is_none() { return Err(CredentialError::MissingData); }       // vectors that do not fit together have no byte form
+        let (shape, c) = marshal(&[p]);
+        let mut bytes = afxp_header(&shape, 1).ok_or(CredentialError::MissingData)?;
+        afxp_record(&mut bytes, &shape, 1, 0, &c.challenge, &c.responses, &c.c_x_0, &c.c_x_1, &c.c_v, &c.c_y, &c.attr_values, &c.enc);
+        Ok(CompressedPresentation { bytes })
+    }
+    /// The crate's struct again: scalars must be canonical and points must decompress (`ScalarFormatError` /
+    /// `PointDecompressionError` otherwise - the checks `from_bytes` of the crate's other types make, src/parameters.rs:92-153).
+    pub fn decompress(&self) -> Result<ProofOfValidCredential, CredentialError> {
+        let (shape, _, off, cells, _) = afxp_parse(&self.bytes).ok_or(CredentialError::WrongNumberOfBytes)?;
+        presentation_from_record(&shape, &self.bytes[off..off + 32 * cells])
+    }
+}
+
+/// `rec`: one AFXP record (cells x 32 bytes) of shape `shape`.
+fn presentation_from_record(shape: &AfxShape, rec: &[u8]) -> Result<ProofOfValidCredential, CredentialError> {
+    let (n, nr, ne) = (shape.n_attributes as usize, shape.n_responses as usize, shape.n_enc_proofs as usize);
+    if rec.len() != 32 * afxp_cells(shape) { return Err(CredentialError::WrongNumberOfBytes); }
+    // a record is a column of `cells` rows over one item
+    let s = |k: usize| sc(rec, k, 1, 0);
+    let p = |k: usize| pt(rec, k, 1, 0);
+    let proof = CompactProof { challenge: s(0)?, responses: (0..nr).map(|k| s(1 + k)).collect::<Result<Vec<Scalar>, CredentialError>>()? };
+    let at = 1 + nr;
+    let (c_x_0, c_x_1, c_v) = (p(at)?, p(at + 1)?, p(at + 2)?);
+    let c_y = (0..n).map(|k| p(at + 3 + k)).collect::<Result<Vec<RistrettoPoint>, CredentialError>>()?;
+    let mut at = at + 3 + n;
+    let mut encrypted_attributes = Vec::with_capacity(n);
+    for k in 0..n {
+        encrypted_attributes.push(match shape.kinds[k] {
+            0 => { at += 1; EncryptedAttribute::PublicScalar(s(at - 1)?) }
+            1 => EncryptedAttribute::SecretScalar,
+            2 => { at += 1; EncryptedAttribute::PublicPoint(p(at - 1)?) }
+            _ => EncryptedAttribute::SecretPoint,
+        });
+    }
+    let mut proofs_of_encryption = Vec::with_capacity(ne);
+    for e in 0..ne {
+        let index = shape.enc_indices[e];
+        proofs_of_encryption.push((index, encryption_proof_from_cells(index, &rec[32 * at..32 * (at + 14)])?));
+        at += 14;
+    }
+    Ok(ProofOfValidCredential { proof, proofs_of_encryption, encrypted_attributes,
+                                hidden_scalar_indices: shape.hidden_scalar_indices[..shape.n_hidden_scalars as usize].to_vec(),
+                                C_x_0: c_x_0, C_x_1: c_x_1, C_V: c_v, C_y: c_y })
+}
+/// 14 cells: challenge | responses[6] | pk | E1 | E2 | C_y_1 | C_y_2 | C_y_3 | C_y_2'
+fn encryption_proof_from_cells(index: u16, c: &[u8]) -> Result<ProofOfEncryption, CredentialError> {
+    if c.len() != 32 * 14 { return Err(CredentialError::WrongNumberOfBytes); }
+    Ok(ProofOfEncryption {
+        proof: CompactProof { challenge: sc(c, 0, 1, 0)?, responses: (1..7).map(|k| sc(c, k, 1, 0)).collect::<Result<Vec<Scalar>, CredentialError>>()? },
+        public_key: SymmetricPublicKey { pk: pt(c, 7, 1, 0)? },
+        ciphertext: Ciphertext { E1: pt(c, 8, 1, 0)?, E2: pt(c, 9, 1, 0)? },
+        index,
+        C_y_1: pt(c, 10, 1, 0)?, C_y_2: pt(c, 11, 1, 0)?, C_y_3: pt(c, 12, 1, 0)?, C_y_2_prime: pt(c, 13, 1, 0)?,
+    })
+}
+
+/// `ProofOfValidCredential::to_bytes` (what src/nizk/presentation.rs:117 asks for): one AFXP v1 section with one record.
+pub fn presentation_to_bytes(p: &ProofOfValidCredential) -> Result<Vec<u8>, CredentialError> { Ok(CompressedPresentation::from_presentation(p)?.bytes) }
+/// `ProofOfValidCredential::from_bytes`.
+pub fn presentation_from_bytes(bytes: &[u8]) -> Result<ProofOfValidCredential, CredentialError> { CompressedPresentation::from_bytes(bytes)?.decompress() }
+
+/// `ProofOfEncryption::to_bytes`: u32le index, then its 14 cells in the order they have inside a presentation's record.
+pub fn encryption_proof_to_bytes(q: &ProofOfEncryption) -> Result<Vec<u8>, CredentialError> {
+    if q.proof.responses.len() != 6 { return Err(CredentialError::MissingData); }
+    let mut b = Vec::with_capacity(4 + 32 * 14);
+    b.extend_from_slice(&(q.index as u32).to_le_bytes());
+    b.extend_from_slice(q.proof.challenge.as_bytes());
+    for r in q.proof.responses.iter() { b.extend_from_slice(r.as_bytes()); }
+    for point in [&q.public_key.pk, &q.ciphertext.E1, &q.ciphertext.E2, &q.C_y_1, &q.C_y_2, &q.C_y_3, &q.C_y_2_prime].iter() { b.extend_from_slice(point.compress().as_bytes()); }
+    Ok(b)
+}
+/// `ProofOfEncryption::from_bytes`.
+pub fn encryption_proof_from_bytes(bytes: &[u8]) -> Result<ProofOfEncryption, CredentialError> {
+    if bytes.len() != 4 + 32 * 14 { return Err(CredentialError::WrongNumberOfBytes); }
+    let index = rd_u32(bytes, 0);
+    if index > 0xffff { return Err(CredentialError::WrongNumberOfBytes); }
+    encryption_proof_from_cells(index as u16, &bytes[4..])
+}
+
+/// `IssuerParameters::to_bytes` as the crate intends it (src/issuer.rs:155,163: 64 bytes): C_W || I.
+pub fn issuer_parameters_to_bytes(ip: &IssuerParameters) -> Vec<u8> { issuer_params_bytes(ip).to_vec() }
+/// `IssuerParameters::from_bytes` (the crate's is `unimplemented!()`, src/parameters.rs:365-367).
+pub fn issuer_parameters_from_bytes(bytes: &[u8]) -> Result<IssuerParameters, CredentialError> {
+    if bytes.len() != 64 { return Err(CredentialError::WrongNumberOfBytes); }
+    Ok(IssuerParameters { C_W: pt(bytes, 0, 1, 0)?, I: pt(bytes, 1, 1, 0)? })
+}
+
+/// `CredentialIssuance::to_bytes`: one AFXI v1 batch with one record (t | U | V | challenge | responses | the value of every
+/// attribute: a scalar, a point, or a plaintext's M1 - what the tag and the proof are made of, src/amacs.rs:225-243).
+pub fn issuance_to_bytes(iss: &CredentialIssuance) -> Result<Vec<u8>, CredentialError> {
+    let kinds = layout_key(&iss.credential.attributes).ok_or(CredentialError::WrongNumberOfAttributes)?;
+    let (n, nr) = (kinds.len(), iss.proof.0.responses.len());
+    if nr > AFX_MAX_ATTRIBUTES + 5 { return Err(CredentialError::MissingData); }
+    let mut b = Vec::with_capacity(64 + 32 * (4 + nr + n));
+    b.extend_from_slice(b"AFXI");
+    for v in [1u32, 1u32, (4 + nr + n) as u32, n as u32, nr as u32].iter() { b.extend_from_slice(&v.to_le_bytes()); }
+    b.extend_from_slice(&kinds);
+    while b.len() % 32 != 0 { b.push(0); }
+    b.extend_from_slice(iss.credential.amac.t.as_bytes());
+    b.extend_from_slice(iss.credential.amac.U.compress().as_bytes());
+    b.extend_from_slice(iss.credential.amac.V.compress().as_bytes());
+    b.extend_from_slice(iss.proof.0.challenge.as_bytes());
+    for r in iss.proof.0.responses.iter() { b.extend_from_slice(r.as_bytes()); }
+    for a in iss.credential.attributes.iter() { b.extend_from_slice(&attribute_cells(a).1); }
+    Ok(b)
+}
+/// The header of an AFXI batch (afx_issuance_wire_parse): attribute kinds, response count, record count, offset of the records.
+fn afxi_parse(b: &[u8]) -> Option<(Vec<u8>, usize, usize, usize)> {
+    if b.len() < 24 || &b[..4] != b"AFXI" || rd_u32(b, 4) != 1 { return None; }
+    let (count, cells, n, nr) = (rd_u32(b, 8) as usize, rd_u32(b, 12) as usize, rd_u32(b, 16) as usize, rd_u32(b, 20) as usize);
+    if n > AFX_MAX_ATTRIBUTES || nr > AFX_MAX_ATTRIBUTES + 5 || cells != 4 + nr + n { return None; }
+    let hdr = (24 + n + 31) & !31usize;
+    if b.len() < hdr { return None; }
+    let kinds = b[24..24 + n].to_vec();
+    if kinds.iter().any(|k| *k > ATTR_SECRET_POINT) { return None; }
+    if hdr.checked_add(count.checked_mul(cells)?.checked_mul(32)?)? != b.len() { return None; }
+    Some((kinds, nr, count, hdr))
+}
+/// One AFXI record -> the crate's `CredentialIssuance`.  `attributes`: the user's own (from the request they sent: the message
+/// carries only what the issuer tagged - a plaintext's M2 and m3 never leave the user); each must be of the record's kind and
+/// value, else `BadAttribute`.  `None`: stand-ins with the record's values (plaintext kinds get M2 = identity, m3 = 0), good for
+/// exactly one thing - `ProofOfIssuance::verify`, which reads M1 only (src/amacs.rs:234-241).
+fn issuance_from_record(kinds: &[u8], nr: usize, rec: &[u8], attributes: Option<Vec<Attribute>>) -> Result<CredentialIssuance, CredentialError> {
+    let n = kinds.len();
+    if rec.len() != 32 * (4 + nr + n) { return Err(CredentialError::WrongNumberOfBytes); }
+    let amac = Amac { t: sc(rec, 0, 1, 0)?, U: pt(rec, 1, 1, 0)?, V: pt(rec, 2, 1, 0)? };
+    let proof = CompactProof { challenge: sc(rec, 3, 1, 0)?, responses: (0..nr).map(|k| sc(rec, 4 + k, 1, 0)).collect::<Result<Vec<Scalar>, CredentialError>>()? };
+    let attributes = match attributes {
+        Some(mine) => {
+            if mine.len() != n { return Err(CredentialError::WrongNumberOfAttributes); }
+            for (k, a) in mine.iter().enumerate() {
+                let (kind, value, _) = attribute_cells(a);
+                if kind != kinds[k] || value != cell(rec, 4 + nr + k, 1, 0) { return Err(CredentialError::BadAttribute); }
+            }
+            mine
+        }
+        None => (0..n).map(|k| -> Result<Attribute, CredentialError> { Ok(match kinds[k] {
+            ATTR_PUBLIC_SCALAR => Attribute::PublicScalar(sc(rec, 4 + nr + k, 1, 0)?),
+            ATTR_SECRET_SCALAR => Attribute::SecretScalar(sc(rec, 4 + nr + k, 1, 0)?),
+            ATTR_PUBLIC_POINT => Attribute::PublicPoint(pt(rec, 4 + nr + k, 1, 0)?),
+            ATTR_EITHER_POINT => Attribute::EitherPoint(crate::symmetric::Plaintext { M1: pt(rec, 4 + nr + k, 1, 0)?, M2: RistrettoPoint::identity(), m3: Scalar::zero() }),
+            _ => Attribute::SecretPoint(crate::symmetric::Plaintext { M1: pt(rec, 4 + nr + k, 1, 0)?, M2: RistrettoPoint::identity(), m3: Scalar::zero() }),
+        }) }).collect::<Result<Vec<Attribute>, CredentialError>>()?,
+    };
+    Ok(CredentialIssuance { proof: ProofOfIssuance(proof), credential: AnonymousCredential { amac, attributes } })
+}
+/// `CredentialIssuance::from_bytes`: the issuer's answer (one AFXI v1 record) joined with the attributes of the request it answers.
+pub fn issuance_from_bytes(bytes: &[u8], attributes: Vec<Attribute>) -> Result<CredentialIssuance, CredentialError> {
+    let (kinds, nr, count, off) = afxi_parse(bytes).ok_or(CredentialError::WrongNumberOfBytes)?;
+    if count != 1 { return Err(CredentialError::WrongNumberOfBytes); }
+    issuance_from_record(&kinds, nr, &bytes[off..], Some(attributes))
+}
+
+impl GpuIssuer {
+    /// `Issuer::verify` over presentations as they come off the network: `stream` = AFXP v1 sections back to back, in arrival order
+    /// (one per presentation - `CompressedPresentation::as_bytes`, `presentation_to_bytes` - or per same-shape run); the library groups
+    /// them by shape, verifies every group on the GPU and answers in stream order.  Nothing is decompressed or compressed on the
+    /// host.  `Err(WrongNumberOfBytes)`: the stream does not parse (nothing was verified).  On an engine fault the stream is parsed
+    /// here and every presentation checked by the crate's own `verify`.
+    pub fn verify_wire(&self, stream: &[u8]) -> Result<Vec<Result<(), CredentialError>>, CredentialError> {
+        match self.try_verify_wire(stream) {
+            Ok(r) => r,
+            Err(f) => {
+                self.fell_through(f);
+                let mut out = Vec::new();
+                let mut at = 0usize;
+                while at < stream.len() {
+                    let (shape, count, off, cells, len) = afxp_parse(&stream[at..]).ok_or(CredentialError::WrongNumberOfBytes)?;
+                    for i in 0..count {
+                        let rec = &stream[at + off + 32 * cells * i..at + off + 32 * cells * (i + 1)];
+                        out.push(presentation_from_record(&shape, rec).and_then(|p| p.verify(&self.fallback)));
+                    }
+                    at += len;
+                }
+                Ok(out)
+            }
+        }
+    }
+
+    /// The same, with an engine fault handed back.
+    pub fn try_verify_wire(&self, stream: &[u8]) -> Result<Result<Vec<Result<(), CredentialError>>, CredentialError>, EngineFault> {
+        let cap = stream.len() / 32 + 1;                              // a record is at least one cell
+        let mut status = vec![ST_VERIFICATION_FAILURE; cap];
+        let mut count = 0usize;
+        let rc = unsafe {
+            if self.group.is_null() { afx_verify_presentations_mixed_wire(self.ctx, stream.as_ptr(), stream.len(), status.as_mut_ptr(), cap, &mut count) }
+            else { afx_group_verify_presentations_mixed_wire(self.group, stream.as_ptr(), stream.len(), status.as_mut_ptr(), cap, &mut count) }
+        };
+        if rc != 0 {
+            if let Some(f) = fault_of(rc) { return Err(f); }
+            return Ok(Err(if rc == E_BAD_ARGS { CredentialError::WrongNumberOfBytes } else { engine_error(rc, Op::Verify) }));
+        }
+        Ok(Ok(status.iter().take(count).map(|s| if *s == ST_OK { Ok(()) } else { Err(CredentialError::VerificationFailure) }).collect()))
+    }
+
+    /// `verify_wire` over presentations that were parsed (framing only) on arrival.
+    pub fn verify_compressed(&self, batch: &[CompressedPresentation]) -> Result<Vec<Result<(), CredentialError>>, CredentialError> {
+        let mut stream = Vec::with_capacity(batch.iter().map(|p| p.bytes.len()).sum());
+        for p in batch.iter() { stream.extend_from_slice(&p.bytes); }
+        self.verify_wire(&stream)
+    }
 }
 
 // ---- process-wide engines, for the three-line delegation patches of INTEGRATION.md section 1 --------------------------------

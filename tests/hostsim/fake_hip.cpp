@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
 #include <time.h>
 #include <atomic>
 #include <map>
@@ -24,6 +25,10 @@ extern "C" void afx_fake_set(const char* what, int v) {
   else if (!strcmp(what, "fail_next")) g_fail_next = v;
   else if (!strcmp(what, "echo")) g_echo = v;
 }
+// the CPUs the thread that launched a device's latest finishing kernel was allowed on (bit k = CPU k, the first 64): a test reads
+// where a group's member threads ran (group.cpp PinScope)
+static std::atomic<unsigned long long> g_affinity[64];
+extern "C" unsigned long long afx_fake_affinity(int device) { return device >= 0 && device < 64 ? g_affinity[device].load() : 0; }
 static std::mutex echo_mu;   // (a global under a mutex: launches of two lanes run on two threads)
 static std::map<const void*, const uint8_t*> echo_src;   // pass (its failure words) -> first scalar array checked
 
@@ -94,11 +99,13 @@ hipError_t afxk_decode(hipStream_t, const afx_decode_job* j, uint32_t n, const a
   return hipSuccess;
 }
 hipError_t afxk_sccheck(hipStream_t, const afx_sccheck_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  std::map<const void*, const uint8_t*> first;   // per pass: the first array this launch checks (a launch set that failed leaves nothing behind)
   for (uint32_t i = 0; i < n; i++) {
     hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e;
     CHECK_PTR(job_of(j, rows, i).sc);
-    if (g_echo.load()) { std::lock_guard<std::mutex> lk(echo_mu); echo_src.emplace(pass_of(passes, rows, i).bad, job_of(j, rows, i).sc); }   // the first one of the pass stays
+    first.emplace(pass_of(passes, rows, i).bad, job_of(j, rows, i).sc);
   }
+  if (g_echo.load()) { std::lock_guard<std::mutex> lk(echo_mu); for (auto& kv : first) echo_src[kv.first] = kv.second; }
   return hipSuccess;
 }
 hipError_t afxk_pointop(hipStream_t, const afx_pointop_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
@@ -224,6 +231,14 @@ hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* p, uint32_t n, 
 }
 hipError_t afxk_finish(hipStream_t, const afx_finish_job* j, uint32_t n, const afx_row* rows, uint32_t max_count) {
   if (device_fails()) return hipErrorLaunchFailure;
+  {
+    cpu_set_t set;
+    unsigned long long m = 0;
+    if (cur_device >= 0 && cur_device < 64 && sched_getaffinity(0, sizeof set, &set) == 0) {
+      for (int k = 0; k < 64; k++) if (CPU_ISSET(k, &set)) m |= 1ull << k;
+      g_affinity[cur_device] = m;
+    }
+  }
   for (int f = g_fail_next.load(); f > 0; f = g_fail_next.load())
     if (g_fail_next.compare_exchange_strong(f, f - 1)) {
       std::lock_guard<std::mutex> lk(echo_mu);
@@ -264,4 +279,9 @@ hipError_t afxk_reduce_wide_jobs(hipStream_t, const afx_reduce_job* j, uint32_t 
 hipError_t afxk_from_uniform(hipStream_t, const uint8_t*, uint8_t*, int32_t*, uint32_t) { return hipSuccess; }
 hipError_t afxk_reduce_wide(hipStream_t, const uint8_t*, uint8_t*, uint32_t) { return hipSuccess; }
 hipError_t afxk_validate(hipStream_t, const uint8_t*, uint8_t*, uint8_t*, uint32_t) { return hipSuccess; }
-hipError_t afxk_aos_to_soa(hipStream_t, const uint8_t*, uint8_t*, const uint32_t* m, uint32_t cells, uint32_t) { for (uint32_t i = 0; i < cells; i++) sink += m[i]; return hipSuccess; }
+// (the one fake kernel that moves data: records to rows, so that the echo knob also reaches the serialized front ends)
+hipError_t afxk_aos_to_soa(hipStream_t, const uint8_t* rec, uint8_t* soa, const uint32_t* m, uint32_t cells, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++)
+    for (uint32_t c = 0; c < cells; c++) memcpy(soa + ((size_t)m[c] * n + i) * 32, rec + ((size_t)i * cells + c) * 32, 32);
+  return hipSuccess;
+}

@@ -375,3 +375,223 @@ def test_group_calls_are_race_free_under_tsan(tmp_path):
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert "tsan drive ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
     assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+CO_DRIVER = r"""
+# Concurrent small calls on ONE context (afx_ctx::co, plans.cpp coalesced_call): threads of every front end at once, calls that
+# take the context alone in between, and launch sets that fail with calls of several threads in them.  The fake runtime makes a
+# launch set "compute" for 300 us (so that calls arrive meanwhile and are collected) and echoes the first byte of every item's
+# challenge (issuances: t) as its status: every caller must get the answer to ITS rows.
+import os, sys, threading, ctypes as C
+sys.path.insert(0, %(root)r)
+import numpy as np
+import aeonflux_amd as afx
+afx.LIB_PATH = %(lib)r
+from aeonflux_amd import batch, wire
+import bench
+L = afx.lib()
+L.afx_fake_set.argtypes = [C.c_char_p, C.c_int]
+params, key, ip = bench.load_fixture("c3_8attrs_SSPPeeee")
+ctx = afx.Context(params, key, ip)
+shape = afx.Shape()
+shape.n_attributes, shape.n_responses, shape.n_hidden_scalars, shape.n_enc_proofs = 8, 3, 0, 4
+for i, k in enumerate((0, 0, 2, 2, 3, 3, 3, 3)):
+    shape.kinds[i] = k
+for e in range(4):
+    shape.enc_indices[e] = 4 + e
+sh2 = afx.Shape.from_buffer_copy(bytes(shape))
+sh2.n_enc_proofs = 0
+z = lambda *s: np.zeros(s, np.uint8)
+def mk(cnt, tag, enc=4):
+    p = {"challenge": z(cnt, 32), "responses": z(3, cnt, 32), "C_x_0": z(cnt, 32), "C_x_1": z(cnt, 32), "C_V": z(cnt, 32), "C_y": z(8, cnt, 32),
+         "attr_values": z(8, cnt, 32), "enc": [{f: (z(6, cnt, 32) if f == "responses" else z(cnt, 32)) for f in batch.ENC_FIELDS} for _ in range(enc)]}
+    p["challenge"][:, 0] = [(tag + i) %% 251 for i in range(cnt)]
+    return p
+kinds = [0] * 8
+k2 = [1, 0, 2, 2, 4, 4, 3, 3]
+L.afx_fake_set(b"echo", 1)
+L.afx_fake_set(b"sync_us", 300)
+K, reps = 12, 30
+errs, failed = [], []
+def work(t):
+    try:
+        for r in range(reps):
+            cnt, tag = 1 + (t + r) %% 5, 7 * t + r
+            want = [(tag + i) %% 251 for i in range(cnt)]
+            try:
+                kind = t %% 6
+                if kind == 0:
+                    st = batch.verify_presentations(ctx, shape, mk(cnt, tag))
+                elif kind == 1:
+                    st = batch.verify_presentations(ctx, sh2, mk(cnt, tag, 0))
+                elif kind == 2:
+                    st = wire.verify_wire(ctx, wire.pack_presentations(shape, mk(cnt, tag)))
+                elif kind == 3:
+                    o, st = batch.issue(ctx, kinds, z(8, cnt, 32), z(cnt, 64), z(cnt, 64), z(cnt, 32))
+                    want = [0] * cnt        # (zero inputs: the echoed byte of the first scalar array the pass checks)
+                elif kind == 4:
+                    iss = {"t": z(cnt, 32), "U": z(cnt, 32), "V": z(cnt, 32), "challenge": z(cnt, 32), "responses": z(13, cnt, 32)}
+                    st = batch.verify_issuances(ctx, kinds, z(8, cnt, 32), iss) if r %% 2 else ctx.verify_issuances_wire(wire.pack_issuances(kinds, z(8, cnt, 32), iss))
+                    want = [0x5a] * cnt     # (the fake runtime's negated generators encode as zeros: the statement fails whole, before any check is laid out)
+                else:
+                    kp = {f: z(cnt, 32) for f in ("a", "a0", "a1", "pk")}
+                    pg, shg, st = batch.show(ctx, k2, z(8, cnt, 32), z(cnt, 32), z(cnt, 32), z(cnt, 32), kp, z(cnt, 64), z(cnt, 32), z(2, cnt, 32), z(8, cnt, 32), z(8, cnt, 32))
+                    want = [0] * cnt
+                    assert shg.n_enc_proofs == 2
+                if st.tolist() != want:
+                    errs.append((t, r, st.tolist(), want))
+            except afx.AfxError as e:
+                if e.rc != afx.E_HIP:
+                    errs.append((t, r, repr(e)))
+                failed.append((t, r))
+    except Exception as e:
+        errs.append((t, repr(e)))
+def alone():
+    # calls that take the context for themselves while the others keep coming: a batch too large to be collected, setters, readers
+    try:
+        for r in range(6):
+            big = mk(600, r)
+            st = batch.verify_presentations(ctx, shape, big)
+            assert st.tolist() == [(r + i) %% 251 for i in range(600)]
+            ctx.set_small_batch_items(4096)
+            ctx.plan_stats()
+            assert len(batch.multiscalar_mul(ctx, z(2, 3, 32), z(2, 3, 32))[0]) == 3
+            if r == 2:
+                L.afx_fake_set(b"fail_next", 3)   # the next three launch sets fail, whoever is in them
+    except afx.AfxError as e:
+        if e.rc != afx.E_HIP:
+            errs.append(("alone", repr(e)))
+    except Exception as e:
+        errs.append(("alone", repr(e)))
+ths = [threading.Thread(target=work, args=(t,)) for t in range(K)] + [threading.Thread(target=alone)]
+[t.start() for t in ths]
+[t.join() for t in ths]
+cs = ctx.coalescing_stats()
+assert not errs, errs[:3]
+assert cs["calls"] >= K * reps - 8 and cs["sessions"] < cs["calls"] and cs["appended_calls"] > 0 and cs["max_calls"] > 1, cs
+assert 1 <= len(failed) <= 3 * K, failed          # the failed launch sets took their callers with them - and only those
+# the context is usable afterwards, collected or alone
+assert batch.verify_presentations(ctx, shape, mk(3, 9)).tolist() == [9, 10, 11]
+ctx.set_coalescing(0, 0)
+assert batch.verify_presentations(ctx, shape, mk(3, 9)).tolist() == [9, 10, 11]
+assert ctx.coalescing_stats()["calls"] == cs["calls"] + 1   # switched off: the second call ran alone
+pc = ctx.plan_cache_stats()
+assert pc["hits"] > 0 and pc["misses"] > 0 and pc["entries"] > 0 and pc["bytes"] > 0, pc
+ctx.close()
+print("coalescing drive ok", cs, len(failed))
+"""
+
+
+def _build_hostsim(out, flags):
+    srcs = [os.path.join(CSRC, f) for f in ("engine.cpp", "plans.cpp", "statements.cpp", "statements_prove.cpp", "statements_setup.cpp", "group.cpp", "mixed.cpp", "wire.cpp")]
+    srcs.append(os.path.join(ROOT, "tests", "hostsim", "fake_hip.cpp"))
+    return subprocess.run(["g++", "-g", "-O1"] + flags + ["-fPIC", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-shared", "-pthread", "-o", out] + srcs,
+                          capture_output=True, text=True)
+
+
+def test_concurrent_calls_on_one_context_under_tsan(tmp_path):
+    """join / flush / a failing flush / calls that need the context alone, from 13 threads on one context, under ThreadSanitizer"""
+    tsan = subprocess.run(["gcc", "-print-file-name=libtsan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(tsan) or not os.path.exists(tsan):
+        pytest.skip("no libtsan")
+    out = str(tmp_path / "libafx_tsan.so")
+    r = _build_hostsim(out, ["-fsanitize=thread"])
+    if r.returncode != 0:
+        pytest.skip("cannot build with -fsanitize=thread: " + r.stderr[-300:])
+    script = tmp_path / "drive.py"
+    script.write_text(CO_DRIVER % {"root": ROOT, "lib": out})
+    env = dict(os.environ, LD_PRELOAD=tsan, TSAN_OPTIONS="report_bugs=1 halt_on_error=0 exitcode=0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert "coalescing drive ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_concurrent_calls_on_one_context_under_asan(hostsim_lib, tmp_path):
+    """the same drive under ASan/UBSan with the plan self-check on: joined calls write only the item slots they were given"""
+    script = tmp_path / "drive.py"
+    script.write_text(CO_DRIVER % {"root": ROOT, "lib": hostsim_lib})
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", AFX_PLAN_SELFCHECK="1")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "coalescing drive ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+NUMA_DRIVER = r"""
+# The host threads of a group's members run on the CPUs of their device's NUMA node (group.cpp cpus_of_device / PinScope).  The fake
+# runtime names device d "0000:0d:00.0"; AFX_SYSFS_ROOT points at a two-socket tree: devices 0, 1 on node 0 (CPUs 0-1), devices 2, 3 on
+# node 1 (CPUs 2-3).  The fake finishing kernel records the affinity of the thread that launched it.
+import os, sys, ctypes as C
+sys.path.insert(0, %(root)r)
+import numpy as np
+import aeonflux_amd as afx
+afx.LIB_PATH = %(lib)r
+from aeonflux_amd import batch
+import bench
+tree = %(tree)r
+allowed = sorted(os.sched_getaffinity(0))
+assert len(allowed) >= 4, allowed
+node_cpus = [allowed[:2], allowed[2:4]]
+for d in range(4):
+    p = os.path.join(tree, "sys/bus/pci/devices/0000:%%02x:00.0" %% d)
+    os.makedirs(p)
+    open(os.path.join(p, "numa_node"), "w").write("%%d\n" %% (d // 2))
+for node, cpus in enumerate(node_cpus):
+    p = os.path.join(tree, "sys/devices/system/node/node%%d" %% node)
+    os.makedirs(p)
+    open(os.path.join(p, "cpulist"), "w").write(",".join(str(c) for c in cpus) + ",4000\n")   # (a CPU this process may not use is dropped)
+L = afx.lib()
+L.afx_fake_affinity.restype = C.c_ulonglong
+L.afx_fake_affinity.argtypes = [C.c_int]
+mask = lambda cpus: sum(1 << c for c in cpus if c < 64)
+params, key, ip = bench.load_fixture("c3_8attrs_SSPPeeee")
+shape = afx.Shape()
+shape.n_attributes, shape.n_responses, shape.n_hidden_scalars, shape.n_enc_proofs = 8, 3, 0, 0
+for i, k in enumerate((0, 0, 2, 2, 2, 2, 2, 2)):
+    shape.kinds[i] = k
+cnt = 900
+z = lambda *s: np.zeros(s, np.uint8)
+pres = {"challenge": z(cnt, 32), "responses": z(3, cnt, 32), "C_x_0": z(cnt, 32), "C_x_1": z(cnt, 32), "C_V": z(cnt, 32), "C_y": z(8, cnt, 32), "attr_values": z(8, cnt, 32), "enc": []}
+os.environ["AFX_FAKE_HIP_DEVICES"] = "4"
+def run(expect):
+    grp = afx.Group(params, key, ip, [0, 1, 2, 3])
+    for m in range(4):
+        grp.member(m).set_small_batch_items(0)     # every call is split over the members' threads
+    before = os.sched_getaffinity(0)
+    assert (batch.verify_presentations(grp, shape, pres) == 0x5a).all()
+    assert os.sched_getaffinity(0) == before, "the caller's mask was not restored"      # member 0 runs on the caller's thread
+    got = [L.afx_fake_affinity(d) for d in range(4)]
+    assert got == expect, (got, expect)
+    # a small call goes whole to one member, on the caller's thread, pinned for the call and restored
+    for m in range(4):
+        grp.member(m).set_small_batch_items(4096)
+    small = {f: (v[..., :3, :] if f != "enc" else v) for f, v in pres.items()}
+    small = {f: (np.ascontiguousarray(v) if f != "enc" else v) for f, v in small.items()}
+    for _ in range(4):
+        assert len(batch.verify_presentations(grp, shape, small)) == 3
+    assert os.sched_getaffinity(0) == before
+    assert [L.afx_fake_affinity(d) for d in range(4)] == expect
+    grp.close()
+os.environ["AFX_SYSFS_ROOT"] = tree
+run([mask(node_cpus[0])] * 2 + [mask(node_cpus[1])] * 2)
+# a topology that is not exposed (containers: no numa_node files): nobody is pinned
+os.environ["AFX_SYSFS_ROOT"] = os.path.join(tree, "nothing-here")
+run([mask(allowed)] * 4)
+# a device on a node that lists no usable CPU: that member is left alone, the others are pinned
+os.environ["AFX_SYSFS_ROOT"] = tree
+open(os.path.join(tree, "sys/devices/system/node/node1/cpulist"), "w").write("4000-4003\n")
+run([mask(node_cpus[0])] * 2 + [mask(allowed)] * 2)
+print("numa drive ok")
+"""
+
+
+def test_group_threads_follow_their_devices_numa_nodes(hostsim_lib, tmp_path):
+    if len(os.sched_getaffinity(0)) < 4:
+        pytest.skip("needs 4 usable CPUs")
+    script = tmp_path / "drive.py"
+    tree = tmp_path / "fake_root"
+    tree.mkdir()
+    script.write_text(NUMA_DRIVER % {"root": ROOT, "lib": hostsim_lib, "tree": str(tree)})
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "numa drive ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

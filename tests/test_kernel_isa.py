@@ -116,6 +116,21 @@ def test_the_four_wave_chain_kernel_exchanges_through_lds_only(code_object):
         full = count(body, r"s_waitcnt vmcnt\(0\)[^\n]*\n\s*s_barrier|s_waitcnt vmcnt\(0\) lgkmcnt\(0\)[^\n]*\n\s*s_barrier")
         assert full <= 2, (k, full, barriers)
         assert count(body, r"ds_read_b128|ds_load_b128") >= 12 and count(body, r"ds_write_b128|ds_store_b128") >= 3
+        # the order of every exchange (kernels.hip quad_post: workgroup fences on the LDS address space around the barrier): the
+        # role's store, a wait for this wave's LDS traffic, the barrier, and only then the loads of the other roles' elements - and
+        # no LDS store between the barrier and those loads (the next exchange writes the other buffer, after them)
+        ins = [ln.strip() for ln in body.split("\n")[1:] if ln.strip()]
+        ordered = 0
+        for i in [j for j, x in enumerate(ins) if x.startswith("s_barrier")]:
+            w = max([j for j in range(i) if re.match(r"ds_(write|store)", ins[j])], default=-1)
+            if w < 0:
+                continue   # the entry barrier, before anything is exchanged
+            waits = [j for j in range(w + 1, i) if re.match(r"s_waitcnt.*lgkmcnt\(0\)", ins[j])]
+            r = min([j for j in range(i + 1, len(ins)) if re.match(r"ds_(read|load)", ins[j])], default=-1)
+            w2 = min([j for j in range(i + 1, len(ins)) if re.match(r"ds_(write|store)", ins[j])], default=len(ins))
+            assert waits and i < r < w2, (k, i, ins[max(0, i - 4):i + 4])
+            ordered += 1
+        assert ordered >= barriers - 1, (k, ordered, barriers)
     for rows in ("k_msm_quad_rows", "k_msm_quadI"):
         sec = next(bodies[k] for k in quad if rows in k and "ILb1E" in k)
         plain = next(bodies[k] for k in quad if rows in k and "ILb0E" in k)
