@@ -37,3 +37,19 @@ int verify_request_stream(afx_ctx* ctx, const unsigned char* stream, size_t stre
   if (rc != AFX_OK) fprintf(stderr, "afx_verify_presentations_mixed_wire: %d %s\n", rc, afx_last_error());
   return rc;
 }
+
+/* What a server does when the ACCELERATOR fails under a call (AFX_E_NO_DEVICE, AFX_E_HIP, AFX_E_NO_MEMORY: the device, not the data): it
+ * does not answer "verification failed" - that would turn every honest user away for the length of a GPU reset - it hands the same
+ * request to its CPU verifier (for the crate: the body of Issuer::verify, /root/reference/src/issuer.rs:146; the Rust shim's
+ * `try_verify` / INTEGRATION.md section 1 do exactly this).  `cpu_verify` is that verifier (any implementation with this signature);
+ * *fell_through counts the calls that took it.  Return codes about the caller's data (AFX_E_BAD_ARGS ...) go back as they are. */
+typedef int (*afx_cpu_verify_fn)(void* cpu_issuer, const unsigned char* stream, size_t stream_len, unsigned char* status, size_t status_cap, size_t* n);
+static int is_engine_fault(int rc) { return rc == AFX_E_NO_DEVICE || rc == AFX_E_HIP || rc == AFX_E_NO_MEMORY; }
+int verify_request_stream_or_fall_through(afx_ctx* ctx, afx_cpu_verify_fn cpu_verify, void* cpu_issuer, const unsigned char* stream, size_t stream_len,
+                                          unsigned char* status, size_t status_cap, size_t* n, unsigned long* fell_through) {
+  int rc = ctx ? afx_verify_presentations_mixed_wire(ctx, stream, stream_len, status, status_cap, n) : AFX_E_NO_DEVICE;   /* (no engine at all: the CPU path) */
+  if (!is_engine_fault(rc)) return rc;
+  fprintf(stderr, "engine fault %d (%s): this request goes to the CPU verifier\n", rc, ctx ? afx_last_error() : "no context");
+  if (fell_through) ++*fell_through;
+  return cpu_verify ? cpu_verify(cpu_issuer, stream, stream_len, status, status_cap, n) : rc;
+}

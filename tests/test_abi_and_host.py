@@ -36,10 +36,30 @@ def test_header_is_valid_c_and_the_c_example_links(tmp_path):
     assert r.returncode == 0, r.stderr
     import aeonflux_amd as afx
     main = tmp_path / "main.c"
-    main.write_text('#include "aeonflux_gpu.h"\nint verify_my_range(afx_ctx*, unsigned, unsigned, const afx_shape*, const afx_presentation_soa*, size_t, unsigned char*);\n'
-                    'int verify_request_stream(afx_ctx*, const unsigned char*, size_t, unsigned char*, size_t, size_t*);\n'
-                    'int main(void) { size_t n = 7; return (verify_my_range(0, 1, 0, 0, 0, 0, 0) == AFX_E_BAD_ARGS && '
-                    'verify_request_stream(0, 0, 0, 0, 0, &n) == AFX_E_BAD_ARGS) ? 0 : 1; }\n')
+    main.write_text(r'''#include "aeonflux_gpu.h"
+int verify_my_range(afx_ctx*, unsigned, unsigned, const afx_shape*, const afx_presentation_soa*, size_t, unsigned char*);
+int verify_request_stream(afx_ctx*, const unsigned char*, size_t, unsigned char*, size_t, size_t*);
+typedef int (*afx_cpu_verify_fn)(void*, const unsigned char*, size_t, unsigned char*, size_t, size_t*);
+int verify_request_stream_or_fall_through(afx_ctx*, afx_cpu_verify_fn, void*, const unsigned char*, size_t, unsigned char*, size_t, size_t*, unsigned long*);
+/* a stand-in CPU verifier: answers 3 presentations, all accepted */
+static int stub_cpu_verify(void* issuer, const unsigned char* s, size_t l, unsigned char* st, size_t cap, size_t* n) {
+  (void)issuer; (void)s; (void)l;
+  if (cap < 3) return AFX_E_BAD_ARGS;
+  st[0] = st[1] = st[2] = AFX_ST_OK; *n = 3; return AFX_OK;
+}
+int main(void) {
+  size_t n = 7;
+  unsigned long fell = 0;
+  unsigned char st[4] = { 9, 9, 9, 9 };
+  if (verify_my_range(0, 1, 0, 0, 0, 0, 0) != AFX_E_BAD_ARGS || verify_request_stream(0, 0, 0, 0, 0, &n) != AFX_E_BAD_ARGS) return 1;
+  /* no engine (a box whose GPU is gone): the request is answered by the CPU verifier, and counted */
+  if (verify_request_stream_or_fall_through(0, stub_cpu_verify, 0, (const unsigned char*)"x", 1, st, 4, &n, &fell) != AFX_OK) return 2;
+  if (n != 3 || fell != 1 || st[0] != AFX_ST_OK || st[2] != AFX_ST_OK || st[3] != 9) return 3;
+  /* ... and without a CPU verifier the fault itself comes back: never a verdict */
+  if (verify_request_stream_or_fall_through(0, 0, 0, (const unsigned char*)"x", 1, st, 4, &n, &fell) != AFX_E_NO_DEVICE || fell != 2) return 4;
+  return 0;
+}
+''')
     exe = tmp_path / "example"
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", hdr, os.path.join(ROOT, "integration", "example_verify.c"), str(main),
                         "-L", os.path.dirname(afx.LIB_PATH), "-laeonflux_gpu", "-Wl,-rpath," + os.path.dirname(afx.LIB_PATH), "-o", str(exe)],

@@ -112,3 +112,59 @@ def test_a_wide_request_takes_longer_chains_and_the_same_statuses(batches):
     assert gpu_verify(afx, ctx, a[:1]) == want_a[:1]
     assert ctx.plan_stats()["msm_jobs"] > wide_jobs, "one call alone: one chain per term"
     ctx.close()
+
+
+def test_a_stream_of_junk_shapes_does_not_pin_the_plan_cache():
+    """Shapes come from callers (a serialized batch names its own): 10 000 distinct valid-but-unusual shapes go through the cache of
+    kept plans, which holds 512 / 64 MB and drops the least recently used.  Afterwards the shape a server really sees is kept again
+    after one call, and a small call costs what it cost before (afx_ctx_get_plan_cache_stats)."""
+    import time
+    import aeonflux_amd as afx
+    from aeonflux_amd import batch
+    params, key, ip, issuer, real = make_batch(8, "SSPPEEEE", [4, 5, 6, 7], 4, b"gpu-plans-lru")
+    want = oracle_statuses(issuer, real)
+    ctx = afx.Context(params, key, ip)
+
+    def small_call_ms(reps=30):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            assert gpu_verify(afx, ctx, real) == want
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return sorted(ts)[len(ts) // 2]
+
+    assert gpu_verify(afx, ctx, real) == want and gpu_verify(afx, ctx, real) == want
+    s0 = ctx.plan_cache_stats()
+    assert s0["hits"] >= 1 and s0["misses"] >= 1 and s0["evictions"] == 0
+    before_ms = small_call_ms()
+    # junk: 8 attributes, every pattern of revealed scalars / revealed points (256), with 0, 1 or 2 proofs of encryption attached at arbitrary
+    # positions (the reference verifies whatever is attached, presentation.rs:438-440): 256 * (1 + 8 + 31) distinct accepted shapes
+    z = lambda *s: np.zeros(s, np.uint8)
+    junk = 0
+    enc_choices = [()] + [(i,) for i in range(8)] + [(i, j) for i in range(8) for j in range(8) if i != j][:31]
+    for pattern in range(256):
+        for encs in enc_choices:
+            sh = afx.Shape()
+            sh.n_attributes, sh.n_responses, sh.n_hidden_scalars, sh.n_enc_proofs = 8, 3, 0, len(encs)
+            for i in range(8):
+                sh.kinds[i] = 2 if (pattern >> i) & 1 else 0
+            for e, idx in enumerate(encs):
+                sh.enc_indices[e] = idx
+            p = {"challenge": z(1, 32), "responses": z(3, 1, 32), "C_x_0": z(1, 32), "C_x_1": z(1, 32), "C_V": z(1, 32), "C_y": z(8, 1, 32), "attr_values": z(8, 1, 32),
+                 "enc": [{f: (z(6, 1, 32) if f == "responses" else z(1, 32)) for f in batch.ENC_FIELDS} for _ in encs]}
+            assert batch.verify_presentations(ctx, sh, p).tolist() == [1]      # (the identity commitments are rejected: zkp, SURVEY.md App. A.2)
+            junk += 1
+    assert junk >= 10000
+    s1 = ctx.plan_cache_stats()
+    assert s1["misses"] - s0["misses"] >= junk and s1["evictions"] >= junk - 512 and s1["entries"] <= 512 and s1["bytes"] <= 64 << 20, s1
+    # the real shape was dropped on the way: one call assembles and keeps it again, the next one reuses it
+    assert gpu_verify(afx, ctx, real) == want
+    s2 = ctx.plan_cache_stats()
+    assert s2["misses"] == s1["misses"] + 1
+    assert gpu_verify(afx, ctx, real) == want
+    s3 = ctx.plan_cache_stats()
+    assert s3["hits"] == s2["hits"] + 1 and s3["misses"] == s2["misses"]
+    after_ms = small_call_ms()
+    print("small call: %.3f ms before the junk, %.3f ms after; cache %s" % (before_ms, after_ms, s3))
+    assert after_ms <= max(1.0, 1.25 * before_ms), (before_ms, after_ms)
+    ctx.close()
