@@ -97,7 +97,7 @@ class ShowGroup(C.Structure):
 
 class CoalescingStats(C.Structure):
     """afx_coalescing_stats: how concurrent small calls on one context were collected (afx_ctx_set_coalescing)"""
-    _fields_ = [(k, C.c_uint64) for k in ("sessions", "calls", "items", "appended_calls", "max_calls", "leader_waits")]
+    _fields_ = [(k, C.c_uint64) for k in ("sessions", "calls", "items", "appended_calls", "max_calls", "leader_waits", "staging_ns", "launch_ns")]
 
 
 class PlanCacheStats(C.Structure):

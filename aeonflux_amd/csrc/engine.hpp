@@ -72,12 +72,13 @@ struct afx_ctx {
     std::condition_variable_any cv;   // waits on `mu`: session completed / lane free / exclusive caller done
     std::shared_ptr<afx::Session> open;   // the session that collects, or null
     int inflight = 0;                 // sessions launched and not yet completed
-    bool lane_busy[3] = { false, false, false };   // a session (collecting or in flight) owns the lane's staging images
+    bool lane_busy[5] = { false, false, false, false, false };   // a session (collecting or in flight) owns the lane's staging images (AFX_LANES entries)
     int max_inflight = 2;             // sessions computing at once (small passes leave most of the device idle); AFX_COALESCE_INFLIGHT=1|2 at context creation
     int exclusive_waiters = 0;        // callers that need the whole context (large batches, setters): no new session opens meanwhile
     std::map<std::string, uint32_t> demand;   // by join key: the items the last session carried (the item slots the next one starts with)
     uint32_t last_waves = 0, last_plans = 0;  // width of the last session launched: the merge class the next one assembles for
     uint64_t n_sessions = 0, n_calls = 0, n_items = 0, n_appended = 0, n_max_calls = 0, n_waited_flushes = 0;   // afx_ctx_get_coalescing_stats
+    uint64_t staging_ns = 0, launch_ns = 0;   // how long `mu` was held staging calls / launching sessions
   } co;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -135,7 +136,8 @@ struct afx_ctx {
     void* pin_in = nullptr;          // pinned image of a SMALL call's whole staging area: its many short input rows are gathered
     size_t pin_in_cap = 0;           // here on the host and go to HBM in one copy (statements.hpp Stager::upload); wiped on destroy
     hipEvent_t pin_in_done = nullptr;   // end of the copy that last read pin_in
-  } lane[3];   // large calls alternate between lanes 0 and 1 (host_pipe, pipelining); the coalescer's sessions take whichever of the three is free
+  } lane[5];   // AFX_LANES: large calls alternate between lanes 0 and 1 (host_pipe, pipelining); the coalescer's sessions take whichever is free
+  static constexpr int AFX_LANES = 5;
   bool pipelining = false;
   bool strict = false;   // afx_ctx_set_strict
   bool fixed_key_schedule = false;   // afx_ctx_set_fixed_key_schedule: no NAF for the issuer key's scalars

@@ -253,7 +253,10 @@ int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey
   for (;;) {
     // ---- a session to stage into: the one that collects, or a new one on a free lane
     while (!co.open) {
-      const int lane = co.exclusive_waiters ? -1 : !co.lane_busy[0] ? 0 : !co.lane_busy[1] ? 1 : !co.lane_busy[2] ? 2 : -1;
+      int lane = -1;
+      if (!co.exclusive_waiters)
+        for (int k = 0; k < afx_ctx::AFX_LANES && k <= co.max_inflight && lane < 0; k++)   // (one lane more than sessions may compute: the one that collects)
+          if (!co.lane_busy[k]) lane = k;
       if (lane < 0) { CtxLock::wait(c); continue; }
       AFX_HIP(hipSetDevice(c->device));
       std::shared_ptr<afx::Session> n(new afx::Session(c, true));
@@ -274,6 +277,7 @@ int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey
     // ---- stage this call's rows (and, unless they went into another call's free item slots, its plan)
     int rc;
     bool appended = false;
+    const clock::time_point stage_t0 = clock::now();
     {
       struct Staging {   // the context collects into S for exactly this scope
         afx_ctx* c;
@@ -296,6 +300,7 @@ int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey
           S->slots.push_back({ jkey, st.ops, st.in_at, st.out_at, st.in_bytes, st.out_bytes, st.last_dn, (uint32_t)count });
       }
     }
+    co.staging_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - stage_t0).count();
     if (rc == afx::AFX_RETRY_NOAPPEND && !no_append) { no_append = true; continue; }
     if (rc == afx::AFX_RETRY_FULL) {
       S->full = true;
@@ -309,6 +314,7 @@ int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey
       if (S->leader == me && S->calls == 0) {
         S->drop();
         S->state = afx::Session::DONE;
+        S->finish(rc, std::string());
         co.open.reset();
         co.lane_busy[S->lane] = false;
         co.cv.notify_all();
@@ -322,14 +328,25 @@ int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey
     if (S->items >= co.max_items) { S->full = true; co.cv.notify_all(); }
     break;
   }
-  // ---- the leader launches; everybody waits for the flush that carries their rows
+  // ---- everybody but the leader: sleep on the session's own condition, with the context given up for good - a completion wakes
+  // the callers it answers, and they go home without queueing on the context's lock again
+  if (S->leader != me) {
+    CtxLock* mine = CtxLock::outermost();
+    if (mine && mine->c == c && c->lock_depth == 1) mine->release();
+    else { const int d = c->lock_depth; c->lock_depth = 0; c->mu.unlock(); (void)d; }   // (not reached: host_pipe only comes here at depth 1 under a CtxLock)
+    std::unique_lock<std::mutex> lk(S->done_mu);
+    S->done_cv.wait(lk, [&] { return S->done; });
+    if (S->rc) set_error(S->err);
+    return S->rc;
+  }
+  // ---- the leader launches
   while (S->state != afx::Session::DONE) {
-    if (S->leader != me || S->state != afx::Session::COLLECTING) { CtxLock::wait(c); continue; }
     const bool go = S->full || S->hurry || co.inflight < co.max_inflight || clock::now() >= S->deadline;
     if (!go) { co.n_waited_flushes++; CtxLock::wait_until(c, S->deadline); continue; }
     S->state = afx::Session::LAUNCHING;
     co.open.reset();
     co.inflight++;
+    co.cv.notify_all();   // (callers that found the session full wait for the next one to open)
     uint64_t waves = 0;
     for (const auto& p : S->plans) waves += (p->count + 63) / 64;
     co.last_waves = (uint32_t)waves;
@@ -337,24 +354,26 @@ int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey
     for (const auto& kv : S->key_items) co.demand[kv.first] = kv.second;
     if (co.demand.size() > 4096) co.demand.clear();   // (keys come from callers' shapes)
     co.n_max_calls = std::max<uint64_t>(co.n_max_calls, S->calls);
+    const clock::time_point launch_t0 = clock::now();
     int rc = S->launch();
+    co.launch_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - launch_t0).count();
     S->state = afx::Session::INFLIGHT;
+    std::string err;
     {
       // the device wait and the scatter of the results run without the context: the next session collects meanwhile
       const int d = c->lock_depth;
       c->lock_depth = 0;
       c->mu.unlock();
       rc = S->complete(rc);
-      std::string err = rc ? afx_last_error() : "";
+      if (rc) err = afx_last_error();
+      S->finish(rc, err);          // the joined callers go home now; the context's bookkeeping follows
       c->mu.lock();
       c->lock_depth = d;
-      S->rc = rc;
-      S->err.swap(err);
     }
     S->state = afx::Session::DONE;
     co.inflight--;
     co.lane_busy[S->lane] = false;
-    co.cv.notify_all();
+    co.cv.notify_all();            // leaders waiting for a launch slot, callers waiting for a lane, callers that need the context alone
   }
   if (S->rc) set_error(S->err);
   return S->rc;

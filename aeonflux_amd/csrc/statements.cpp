@@ -117,7 +117,7 @@ extern "C" int afx_ctx_get_coalescing_stats(afx_ctx* c, afx_coalescing_stats* ou
   if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   CtxLock lock(c, true);   // (a reader: no need to wait for the sessions in flight)
   const afx_ctx::Coalesce& co = c->co;
-  *out = afx_coalescing_stats{ co.n_sessions, co.n_calls, co.n_items, co.n_appended, co.n_max_calls, co.n_waited_flushes };
+  *out = afx_coalescing_stats{ co.n_sessions, co.n_calls, co.n_items, co.n_appended, co.n_max_calls, co.n_waited_flushes, co.staging_ns, co.launch_ns };
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_set_strict(afx_ctx* c, int enable) try {
@@ -293,7 +293,7 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   if (n == 0 || n > AFX_MAX_ATTRIBUTES || splen != sizeof_system_parameters(n)) { set_error("SystemParameters length / attribute count"); return AFX_E_BAD_PARAMS; }
   std::unique_ptr<afx_ctx, void (*)(afx_ctx*)> c(new afx_ctx(), afx_ctx_destroy);
   { const char* sc = getenv("AFX_PLAN_SELFCHECK"); c->plan_selfcheck = sc && sc[0] == '1'; }   // tests: every plan assembled twice and compared
-  { const char* fl = getenv("AFX_COALESCE_INFLIGHT"); if (fl && (fl[0] == '1' || fl[0] == '2') && !fl[1]) c->co.max_inflight = fl[0] - '0'; }   // measurement aid
+  { const char* fl = getenv("AFX_COALESCE_INFLIGHT"); if (fl && fl[0] >= '1' && fl[0] <= '4' && !fl[1]) c->co.max_inflight = fl[0] - '0'; }   // measurement aid
   c->device = device;
   c->n = n;
   c->g = n < 3 ? 3 : n;
@@ -336,12 +336,14 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
       (rc = c->d_gen_ext.ensure(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)c->ngen)) || (rc = c->d_key.ensure(32 * (size_t)(4 + n))) ||
       (rc = c->d_consts.ensure(2048)) || (rc = c->lane[0].staging.ensure(32 * (size_t)c->ngen + 4 * (size_t)c->ngen)))
     return rc;
-  for (auto& L : c->lane)
+  for (int k = 0; k < afx_ctx::AFX_LANES; k++)
     for (int i = 0; i < 2; i++) {
+      afx_ctx::Lane& L = c->lane[k];
+      AFX_HIP(hipEventCreateWithFlags(&L.blob_event[i], hipEventDisableTiming));
+      if (k >= 2) continue;   // the lanes only collected small calls use get their plan buffers when the first session lands on them (engine.cpp grow_blob)
       if ((rc = L.blob_dev[i].ensure(BLOB_CAP))) return rc;
       AFX_HIP(hipHostMalloc(&L.blob_host[i], BLOB_CAP, hipHostMallocDefault));
       L.blob_host_cap[i] = BLOB_CAP;
-      AFX_HIP(hipEventCreateWithFlags(&L.blob_event[i], hipEventDisableTiming));
     }
   for (auto& L : c->lane) AFX_HIP(hipEventCreateWithFlags(&L.msm_done, hipEventDisableTiming));
   std::vector<uint8_t> flat(32 * (size_t)c->ngen);

@@ -86,7 +86,7 @@ struct Session {
   std::vector<std::function<int()>> pre;            // launches that run after the upload and before the plans (k_aos_to_soa of a serialized batch)
   // `shared`: a session of the context's coalescer (afx_ctx::co) - it is the context's `session` only while one call stages into it
   explicit Session(afx_ctx* ctx, bool shared_ = false) : c(ctx), shared(shared_) { if (!shared) c->session = this; }
-  ~Session() { if (c->session == this) c->session = nullptr; }
+  ~Session() { if (!shared && c->session == this) c->session = nullptr; }   // (a shared session's last owner may be a caller that no longer holds the context)
   Session(const Session&) = delete;
   Session& operator=(const Session&) = delete;
   bool empty() const { return plans.empty() && outs.empty() && pre.empty() && in_used == 0 && out_used == 0; }
@@ -112,6 +112,15 @@ struct Session {
   enum State { COLLECTING, LAUNCHING, INFLIGHT, DONE } state = COLLECTING;
   int rc = 0;                       // of the flush: every joined call returns it
   std::string err;
+  // what the joined callers sleep on - the session's own, not the context's: a completion wakes the callers it answers and nobody
+  // else, and they return without touching the context again (`done`, and rc / err before it, under `done_mu`)
+  std::mutex done_mu;
+  std::condition_variable done_cv;
+  bool done = false;
+  void finish(int rc_, std::string err_) {
+    { std::lock_guard<std::mutex> g(done_mu); rc = rc_; err.swap(err_); done = true; }
+    done_cv.notify_all();
+  }
   std::thread::id leader;           // the caller that opened the session launches it
   bool hurry = false, full = false; // launch now: an exclusive caller waits / the session has all it can take
   std::chrono::steady_clock::time_point deadline;
@@ -127,12 +136,27 @@ struct Session {
 // collects or is in flight (quiesce).  Re-entrant on the owning thread (the host-pointer front ends call the *_dev forms).
 struct CtxLock {
   afx_ctx* c;
+  CtxLock* outer_prev = nullptr;
+  bool is_outermost = false;
+  // the calling thread's outermost lock (per thread): a collected call that only has to wait for its session gives the context up
+  // early through it (release) instead of taking the lock again just to drop it
+  static CtxLock*& outermost() { static thread_local CtxLock* p = nullptr; return p; }
   explicit CtxLock(afx_ctx* ctx, bool joiner = false) : c(ctx) {
     if (!c) return;
     c->mu.lock();
-    if (++c->lock_depth == 1 && !joiner) quiesce(c);
+    if (++c->lock_depth == 1) {
+      is_outermost = true;
+      outer_prev = outermost();
+      outermost() = this;
+      if (!joiner) quiesce(c);
+    }
   }
-  ~CtxLock() { if (c) { --c->lock_depth; c->mu.unlock(); } }
+  ~CtxLock() {
+    if (is_outermost) outermost() = outer_prev;
+    if (c) { --c->lock_depth; c->mu.unlock(); }
+  }
+  // drops the lock now; the destructor then has nothing to do (only the outermost lock of the thread, at depth 1)
+  void release() { if (c) { --c->lock_depth; c->mu.unlock(); c = nullptr; } }
   CtxLock(const CtxLock&) = delete;
   CtxLock& operator=(const CtxLock&) = delete;
   // waits on the coalescer's condition with `mu` released (only ever at depth 1: the recursive mutex is released by ONE unlock)

@@ -219,6 +219,8 @@ typedef struct afx_coalescing_stats {
   uint64_t appended_calls;  /* calls that took free item slots of another call's pass (no plan of their own)    */
   uint64_t max_calls;       /* most calls one set of launches carried                                           */
   uint64_t leader_waits;    /* times a collection's opener slept because an earlier one was still computing     */
+  uint64_t staging_ns;      /* time the context's lock was held while calls staged their rows (sum)             */
+  uint64_t launch_ns;       /* ... and while collections were launched (sum): what serialises the callers       */
 } afx_coalescing_stats;
 int afx_ctx_get_coalescing_stats(afx_ctx* ctx, afx_coalescing_stats* out);
 

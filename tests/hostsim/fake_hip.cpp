@@ -59,7 +59,8 @@ hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, 
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)0x1; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) {
-  const int us = g_sync_us.load();
+  static const int env_us = [] { const char* e = getenv("AFX_FAKE_HIP_SYNC_US"); return e ? atoi(e) : 0; }();   // (for drivers that cannot call afx_fake_set)
+  const int us = g_sync_us.load() ? g_sync_us.load() : env_us;
   if (us > 0) { struct timespec ts = { us / 1000000, (long)(us % 1000000) * 1000 }; nanosleep(&ts, nullptr); }
   return hipSuccess;
 }
@@ -265,6 +266,7 @@ hipError_t afxk_fill_u32(hipStream_t, const afx_fill_job* j, uint32_t n, const a
     const afx_fill_job& q = job_of(j, rows, i);
     if (q.n > max_n || !canonical(q.p)) return hipErrorInvalidValue;
     for (uint32_t k = 0; k < q.n; k++) q.p[k] = q.v;
+    { std::lock_guard<std::mutex> lk(echo_mu); echo_src.erase(q.p); }   // a plan starts here: nothing an earlier (failed) launch set left behind at this address
   }
   return hipSuccess;
 }

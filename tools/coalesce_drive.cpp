@@ -172,10 +172,12 @@ int main(int argc, char** argv) {
   auto pct = [&](double p) { return all.empty() ? 0.0 : all[std::min(all.size() - 1, (size_t)(p * all.size()))]; };
   const double n_calls = (double)K * calls;
   printf("{\"op\": \"%s\", \"threads\": %d, \"contexts\": %d, \"items_per_call\": %zu, \"calls_per_s\": %.0f, \"items_per_s\": %.0f, \"p50_ms\": %.3f, \"p99_ms\": %.3f, "
-         "\"max_ms\": %.3f, \"launch_sets\": %llu, \"calls_per_launch_set\": %.1f, \"appended_calls\": %llu, \"wrong\": %d}\n",
+         "\"max_ms\": %.3f, \"launch_sets\": %llu, \"calls_per_launch_set\": %.1f, \"appended_calls\": %llu, \"staging_us_per_call\": %.2f, \"launch_us_per_set\": %.1f, \"wrong\": %d}\n",
          op.c_str(), K, one ? 1 : K, items, n_calls / secs, n_calls * items / secs, pct(0.50), pct(0.99), all.empty() ? 0.0 : all.back(),
          (unsigned long long)(s1.sessions - s0.sessions), s1.sessions > s0.sessions ? (double)(s1.calls - s0.calls) / (double)(s1.sessions - s0.sessions) : 0.0,
-         (unsigned long long)(s1.appended_calls - s0.appended_calls), bad.load());
+         (unsigned long long)(s1.appended_calls - s0.appended_calls),
+         s1.calls > s0.calls ? 1e-3 * (double)(s1.staging_ns - s0.staging_ns) / (double)(s1.calls - s0.calls) : 0.0,
+         s1.sessions > s0.sessions ? 1e-3 * (double)(s1.launch_ns - s0.launch_ns) / (double)(s1.sessions - s0.sessions) : 0.0, bad.load());
   for (auto c : ctxs) afx_ctx_destroy(c);
   return bad.load() ? 1 : 0;
 }
