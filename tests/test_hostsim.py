@@ -470,11 +470,39 @@ cs = ctx.coalescing_stats()
 assert not errs, errs[:3]
 assert cs["calls"] >= K * reps - 8 and cs["sessions"] < cs["calls"] and cs["appended_calls"] > 0 and cs["max_calls"] > 1, cs
 assert 1 <= len(failed) <= 3 * K, failed          # the failed launch sets took their callers with them - and only those
+# the collector's other ways out of a session: it holds all it may (max_items), its images are full (calls of hundreds of items), the
+# bounded wait runs out while an earlier session still computes, a call too large for the item slots on offer opens a group of its own
+def phase(threads, rounds, items_of):
+    errs2 = []
+    def w(t):
+        try:
+            for r in range(rounds):
+                cnt, tag = items_of(t, r), 11 * t + r
+                st = batch.verify_presentations(ctx, shape if t %% 2 else sh2, mk(cnt, tag, 4 if t %% 2 else 0))
+                if st.tolist() != [(tag + i) %% 251 for i in range(cnt)]:
+                    errs2.append((t, r, cnt, st.tolist()[:4]))
+        except Exception as e:
+            errs2.append((t, repr(e)))
+    ths2 = [threading.Thread(target=w, args=(t,)) for t in range(threads)]
+    [t.start() for t in ths2]
+    [t.join() for t in ths2]
+    assert not errs2, errs2[:3]
+before = ctx.coalescing_stats()
+ctx.set_coalescing(2000, 8)                 # eight items and the session goes, whatever is in flight
+phase(10, 12, lambda t, r: 1 + (t + r) %% 3)
+mid = ctx.coalescing_stats()
+assert mid["sessions"] - before["sessions"] >= (mid["items"] - before["items"]) // 12, (before, mid)
+ctx.set_coalescing(1, 4096)                 # a wait bound of a microsecond: nobody lingers behind the 300 us "kernels"
+phase(10, 8, lambda t, r: 1 + (t + r) %% 3)
+ctx.set_coalescing(2000, 4096)
+phase(12, 4, lambda t, r: 300 + 17 * ((t + r) %% 5))      # ~1 MB of rows a call: the 8 MB images fill up
+phase(10, 6, lambda t, r: (1, 70, 2, 130, 5)[(t + r) %% 5])   # calls beyond the 64 item slots a group starts with
 # the context is usable afterwards, collected or alone
+last = ctx.coalescing_stats()["calls"]
 assert batch.verify_presentations(ctx, shape, mk(3, 9)).tolist() == [9, 10, 11]
 ctx.set_coalescing(0, 0)
 assert batch.verify_presentations(ctx, shape, mk(3, 9)).tolist() == [9, 10, 11]
-assert ctx.coalescing_stats()["calls"] == cs["calls"] + 1   # switched off: the second call ran alone
+assert ctx.coalescing_stats()["calls"] == last + 1   # switched off: the second call ran alone
 pc = ctx.plan_cache_stats()
 assert pc["hits"] > 0 and pc["misses"] > 0 and pc["entries"] > 0 and pc["bytes"] > 0, pc
 ctx.close()
