@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything profiles/ holds for one round, collected on the GPU box:  gpurun -- 'bash tools/collect_profiles.sh r04'
+# Everything profiles/ holds for one round, collected on the GPU box:  gpurun -- 'bash tools/collect_profiles.sh r05'
 # Output: gpurun_out/profiles_<tag>/ (copy what should be judged into profiles/).
 #  - bench JSON lines: default = C3; C2; C5 issue and show in the library's default mode (secrets off the table addresses on the
 #    prover-side calls, afx_ctx_set_secret_independent_addressing 2) and with the fast tables (mode 0, rounds 1-3); C3 in mode 1
@@ -8,7 +8,7 @@
 #      FETCH_SIZE, WRITE_SIZE -> <tag>_traffic.json (C3 default; C5 mode 0) and <tag>_secret_traffic.json (C5 default mode; C3
 #      mode 1) with the sha256 of the kernel sources they were measured on; the SQ issue/wait counters and the instruction mix (C3),
 #      the SQ counters of C5 in both modes
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
@@ -81,4 +81,6 @@ python3 tools/mixed_concurrency.py 64 16 > $O/${TAG}_mixed_concurrency.txt 2>&1
 for a in "8 16" "64 1" "32 64" "64 256"; do python3 tools/mixed_concurrency.py $a >> $O/${TAG}_mixed_concurrency.txt 2>&1; done
 python3 tools/small_call_latency.py > $O/${TAG}_small_call_latency.txt 2>&1
 for m in 4 16 64; do AFX_PACK_LIMIT_MB=$m python3 tools/midsize_host_calls.py; done > $O/${TAG}_midsize_host_calls.txt 2>&1
+# concurrent small calls on ONE context (round 5): K threads x 1-item calls through the native driver
+python3 tools/concurrent_small_calls.py --one-context --threads 1,2,4,8,16,32,64,128,256 > $O/${TAG}_coalesced_calls.txt 2>&1
 ls -la $O
