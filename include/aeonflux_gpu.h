@@ -152,7 +152,7 @@ int afx_ctx_set_strict(afx_ctx* ctx, int enable);
  * key's NAF weight (a per-key constant, the same for every batch under that key; nothing depends on the items).  1: the key
  * scalars take the per-item window path instead (64 additions per term, whatever the key): running time independent of
  * the key, 3-5 % slower.  The reference computes these products with dalek's constant-time `*` / `multiscalar_mul`
- * (src/nizk/presentation.rs:342-351, src/amacs.rs:267-270); DESIGN.md "Documented divergences" has the threat model.
+ * (src/nizk/presentation.rs:342-351, src/amacs.rs:267-270); DESIGN.md section 1 "Secrets" (the threat model: docs/HISTORY.md section 1).
  * Results are identical in both modes. */
 int afx_ctx_set_fixed_key_schedule(afx_ctx* ctx, int enable);
 
