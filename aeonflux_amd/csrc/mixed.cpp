@@ -19,6 +19,12 @@ std::string shape_key(const afx_shape& sh) {
 }
 uint32_t rd32(const uint8_t* b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); }
 
+// does a request of several groups on this context leave its small groups with the collector's sessions (plans.cpp)?
+bool joins_the_collector(afx_ctx* ctx) {
+  CtxLock probe(ctx, true);
+  return ctx->lock_depth == 1 && ctx->co.enabled && ctx->co.max_items && ctx->small_batch_items && !ctx->trace && !ctx->pipelining && !ctx->session;
+}
+
 // positions given: each < status_len and used once over all groups; not given: contiguous after the groups before
 template <class G>
 int check_positions(const G* groups, size_t n_groups, size_t status_len) {
@@ -47,6 +53,37 @@ int run_groups(afx_ctx* ctx, G* groups, size_t n_groups, uint8_t* status, size_t
   if ((!groups && n_groups) || (!status && status_len)) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   int rc = check_positions(groups, n_groups, status_len);
   if (rc) return rc;
+  // With the context's collector on (afx_ctx_set_coalescing, the default) the request's small groups JOIN the session that is
+  // collecting - other threads' calls and requests share its launches - instead of taking the context for a session of the request's
+  // own: every group's call returns once its rows are staged (afx::DeferScope) and the request waits for all of them at the end.
+  if (ctx && n_groups > 1 && joins_the_collector(ctx)) {
+    afx::Deferred deferred;
+    std::vector<std::vector<uint8_t>> tmpj(n_groups);
+    size_t nextj = 0;
+    {
+      afx::DeferScope scope(&deferred);
+      for (size_t g = 0; g < n_groups && !rc; g++) {
+        G& grp = groups[g];
+        if (grp.count) {
+          uint8_t* st = status + nextj;
+          if (grp.positions) { tmpj[g].assign(grp.count, AFX_ST_VERIFICATION_FAILURE); st = tmpj[g].data(); }
+          rc = run_one(grp, st);
+          if (rc) set_error("group " + std::to_string(g) + ": " + afx_last_error());
+        }
+        nextj += grp.count;
+      }
+      // what the groups left with the sessions: launched (the session this thread leads) or waited for - also after a failure, since
+      // the staged rows point into this request's arrays
+      CtxLock lk(ctx, true);
+      const int rc2 = afx::drain_deferred(ctx, deferred);
+      if (!rc) rc = rc2;
+    }
+    if (rc) return rc;
+    for (size_t g = 0; g < n_groups; g++)
+      if (groups[g].positions)
+        for (size_t i = 0; i < groups[g].count; i++) status[groups[g].positions[i]] = tmpj[g][i];
+    return AFX_OK;
+  }
   std::unique_ptr<CtxLock> lock;
   std::unique_ptr<afx::Session> ses;
   if (ctx && n_groups > 1) lock.reset(new CtxLock(ctx));   // the session owns the context until its last flush
@@ -278,7 +315,12 @@ static int mixed_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* st
   std::unique_ptr<CtxLock> lock;
   std::unique_ptr<afx::Session> ses;
   int rc = AFX_OK;
-  if (ctx && order.size() > 1) lock.reset(new CtxLock(ctx));
+  // (as in run_groups: with the collector on, the stream's shape groups join the collecting session)
+  afx::Deferred deferred;
+  std::unique_ptr<afx::DeferScope> defer;
+  const bool join = ctx && order.size() > 1 && joins_the_collector(ctx);
+  if (join) defer.reset(new afx::DeferScope(&deferred));
+  if (ctx && order.size() > 1 && !join) lock.reset(new CtxLock(ctx));
   if (lock && ctx->small_batch_items && !ctx->trace && !ctx->session) {
     ses.reset(new afx::Session(ctx));
     if ((rc = ses->ensure_images(0, 0))) return rc;
@@ -327,6 +369,12 @@ static int mixed_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* st
     if (rc) ses->drop();
     else rc = ses->flush();
     ses.reset();
+  }
+  if (join) {
+    CtxLock lk(ctx, true);
+    const int rc2 = afx::drain_deferred(ctx, deferred);   // (also after a failure: the staged records point into this request's buffers)
+    if (!rc) rc = rc2;
+    defer.reset();
   }
   if (rc) return rc;
   for (size_t gi = 0; gi < order.size(); gi++) {

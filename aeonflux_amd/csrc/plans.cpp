@@ -242,104 +242,15 @@ int Stager::drain() {
 namespace {
 using SliceFn = std::function<int(Stager&, size_t, size_t)>;
 
-// One small host-pointer call on a context other threads are calling too (afx_ctx::co has the protocol).  Entered with c->mu
-// held once; returns with it held once.
-int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey& jkey) {
+// The calls of one thread that were left with collecting sessions instead of being waited for one by one: the small groups of a mixed
+// request (mixed.cpp).  `pending`: the sessions that carry them, each once.
+thread_local afx::Deferred* tl_deferred = nullptr;
+
+// The leader's part: launch S when it may go, wait for the device without the context, wake the callers S carried.  Entered with
+// c->mu held once by S's leader, S collecting; returns the flush's code with the lock held again.
+int lead(afx_ctx* c, const std::shared_ptr<afx::Session>& S) {
   afx_ctx::Coalesce& co = c->co;
   using clock = std::chrono::steady_clock;
-  const std::thread::id me = std::this_thread::get_id();
-  std::shared_ptr<afx::Session> S;
-  bool no_append = false;
-  for (;;) {
-    // ---- a session to stage into: the one that collects, or a new one on a free lane
-    while (!co.open) {
-      int lane = -1;
-      if (!co.exclusive_waiters)
-        for (int k = 0; k < afx_ctx::AFX_LANES && k <= co.max_inflight && lane < 0; k++)   // (one lane more than sessions may compute: the one that collects)
-          if (!co.lane_busy[k]) lane = k;
-      if (lane < 0) { CtxLock::wait(c); continue; }
-      AFX_HIP(hipSetDevice(c->device));
-      std::shared_ptr<afx::Session> n(new afx::Session(c, true));
-      n->lane = lane;
-      const int rc = n->ensure_images(0, 0);
-      if (rc) return rc;
-      n->leader = me;
-      n->deadline = clock::now() + std::chrono::microseconds(co.max_wait_us);
-      // the launches this session's plans will share, guessed from the last one's (afx_ctx::merge_class: how long the chains of a
-      // latency plan are; results do not depend on it)
-      n->mclass = co.last_plans > 1 ? afx_ctx::merge_class_of(co.last_waves) : 0;
-      co.open = n;
-      co.lane_busy[lane] = true;
-      co.n_sessions++;
-    }
-    S = co.open;
-    if (S->full) { CtxLock::wait(c); continue; }   // its leader is about to launch it
-    // ---- stage this call's rows (and, unless they went into another call's free item slots, its plan)
-    int rc;
-    bool appended = false;
-    const clock::time_point stage_t0 = clock::now();
-    {
-      struct Staging {   // the context collects into S for exactly this scope
-        afx_ctx* c;
-        Staging(afx_ctx* ctx, afx::Session* s) : c(ctx) { c->session = s; c->merge_class = s->mclass; }
-        ~Staging() { c->session = nullptr; c->merge_class = 0; }
-      } staging(c, S.get());
-      Stager st(c, S->lane, S.get());
-      if (!jkey.empty() && !no_append)
-        for (afx::Session::Slots& g : S->slots)
-          if (g.key == jkey && g.dn - g.used >= count) { st.app = &g; st.slot = g.used; break; }
-      if (!st.app && !jkey.empty()) {
-        auto d = co.demand.find(jkey);
-        if (d != co.demand.end()) st.slots_hint = d->second;
-      }
-      // (nothing may leave this function by exception: a session whose leader is gone would never be launched)
-      try { rc = slice(st, 0, count); } catch (...) { rc = afx::exception_rc(); }
-      if (!rc) {
-        if (st.app) { st.app->used += (uint32_t)count; appended = true; }
-        else if (!jkey.empty() && st.last_dn && st.uploaded)
-          S->slots.push_back({ jkey, st.ops, st.in_at, st.out_at, st.in_bytes, st.out_bytes, st.last_dn, (uint32_t)count });
-      }
-    }
-    co.staging_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - stage_t0).count();
-    if (rc == afx::AFX_RETRY_NOAPPEND && !no_append) { no_append = true; continue; }
-    if (rc == afx::AFX_RETRY_FULL) {
-      S->full = true;
-      co.cv.notify_all();
-      while (co.open == S) CtxLock::wait(c);
-      continue;
-    }
-    if (rc) {
-      if (rc == afx::AFX_RETRY_NOAPPEND) { set_error("internal: a call does not reproduce its own staging layout"); rc = AFX_E_BAD_ARGS; }
-      // nothing of this call is in the session (a plan is left with it last); a session its opener could not use is given up
-      if (S->leader == me && S->calls == 0) {
-        S->drop();
-        S->state = afx::Session::DONE;
-        S->finish(rc, std::string());
-        co.open.reset();
-        co.lane_busy[S->lane] = false;
-        co.cv.notify_all();
-      }
-      return rc;
-    }
-    S->calls++;
-    S->items += count;
-    if (!jkey.empty()) S->key_items[jkey] += (uint32_t)count;
-    co.n_calls++; co.n_items += count; co.n_appended += appended;
-    if (S->items >= co.max_items) { S->full = true; co.cv.notify_all(); }
-    break;
-  }
-  // ---- everybody but the leader: sleep on the session's own condition, with the context given up for good - a completion wakes
-  // the callers it answers, and they go home without queueing on the context's lock again
-  if (S->leader != me) {
-    CtxLock* mine = CtxLock::outermost();
-    if (mine && mine->c == c && c->lock_depth == 1) mine->release();
-    else { const int d = c->lock_depth; c->lock_depth = 0; c->mu.unlock(); (void)d; }   // (not reached: host_pipe only comes here at depth 1 under a CtxLock)
-    std::unique_lock<std::mutex> lk(S->done_mu);
-    S->done_cv.wait(lk, [&] { return S->done; });
-    if (S->rc) set_error(S->err);
-    return S->rc;
-  }
-  // ---- the leader launches
   while (S->state != afx::Session::DONE) {
     const bool go = S->full || S->hurry || co.inflight < co.max_inflight || clock::now() >= S->deadline;
     if (!go) { co.n_waited_flushes++; CtxLock::wait_until(c, S->deadline); continue; }
@@ -378,7 +289,152 @@ int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey
   if (S->rc) set_error(S->err);
   return S->rc;
 }
+
+// One small host-pointer call on a context other threads are calling too (afx_ctx::co has the protocol).  Entered with c->mu
+// held once; returns with it held once - or, for a caller that only had to wait for its session, given up (CtxLock::release).
+int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey& jkey) {
+  afx_ctx::Coalesce& co = c->co;
+  using clock = std::chrono::steady_clock;
+  const std::thread::id me = std::this_thread::get_id();
+  std::shared_ptr<afx::Session> S;
+  bool no_append = false;
+  for (;;) {
+    // ---- a session to stage into: the one that collects, or a new one on a free lane
+    while (!co.open) {
+      int lane = -1;
+      if (!co.exclusive_waiters)
+        for (int k = 0; k < afx_ctx::AFX_LANES && k <= co.max_inflight && lane < 0; k++)   // (one lane more than sessions may compute: the one that collects)
+          if (!co.lane_busy[k]) lane = k;
+      if (lane < 0) { CtxLock::wait(c); continue; }
+      AFX_HIP(hipSetDevice(c->device));
+      std::shared_ptr<afx::Session> n(new afx::Session(c, true));
+      n->lane = lane;
+      const int rc = n->ensure_images(0, 0);
+      if (rc) return rc;
+      n->leader = me;
+      n->deadline = clock::now() + std::chrono::microseconds(co.max_wait_us);
+      // the launches this session's plans will share, guessed from the last one's (afx_ctx::merge_class: how long the chains of a
+      // latency plan are; results do not depend on it)
+      n->mclass = co.last_plans > 1 ? afx_ctx::merge_class_of(co.last_waves) : 0;
+      co.open = n;
+      co.lane_busy[lane] = true;
+      co.n_sessions++;
+    }
+    S = co.open;
+    if (S->full) {
+      if (S->leader == me) { const int rc = lead(c, S); if (tl_deferred) tl_deferred->forget(S); if (rc) return rc; continue; }   // (only a deferring caller leads a session it is not waiting in)
+      CtxLock::wait(c);   // its leader is about to launch it
+      continue;
+    }
+    // ---- stage this call's rows (and, unless they went into another call's free item slots, its plan)
+    int rc;
+    bool appended = false;
+    const clock::time_point stage_t0 = clock::now();
+    {
+      struct Staging {   // the context collects into S for exactly this scope
+        afx_ctx* c;
+        Staging(afx_ctx* ctx, afx::Session* s) : c(ctx) { c->session = s; c->merge_class = s->mclass; }
+        ~Staging() { c->session = nullptr; c->merge_class = 0; }
+      } staging(c, S.get());
+      Stager st(c, S->lane, S.get());
+      if (!jkey.empty() && !no_append)
+        for (afx::Session::Slots& g : S->slots)
+          if (g.key == jkey && g.dn - g.used >= count) { st.app = &g; st.slot = g.used; break; }
+      if (!st.app && !jkey.empty()) {
+        auto d = co.demand.find(jkey);
+        if (d != co.demand.end()) st.slots_hint = d->second;
+      }
+      // (nothing may leave this function by exception: a session whose leader is gone would never be launched)
+      try { rc = slice(st, 0, count); } catch (...) { rc = afx::exception_rc(); }
+      if (!rc) {
+        if (st.app) { st.app->used += (uint32_t)count; appended = true; }
+        else if (!jkey.empty() && st.last_dn && st.uploaded)
+          S->slots.push_back({ jkey, st.ops, st.in_at, st.out_at, st.in_bytes, st.out_bytes, st.last_dn, (uint32_t)count });
+      }
+    }
+    co.staging_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - stage_t0).count();
+    if (rc == afx::AFX_RETRY_NOAPPEND && !no_append) { no_append = true; continue; }
+    if (rc == afx::AFX_RETRY_FULL) {
+      S->full = true;
+      co.cv.notify_all();
+      if (S->leader == me) { const int rc2 = lead(c, S); if (tl_deferred) tl_deferred->forget(S); if (rc2) return rc2; continue; }
+      while (co.open == S) CtxLock::wait(c);
+      continue;
+    }
+    if (rc) {
+      if (rc == afx::AFX_RETRY_NOAPPEND) { set_error("internal: a call does not reproduce its own staging layout"); rc = AFX_E_BAD_ARGS; }
+      // nothing of this call is in the session (a plan is left with it last); a session its opener could not use is given up
+      if (S->leader == me && S->calls == 0) {
+        S->drop();
+        S->state = afx::Session::DONE;
+        S->finish(rc, std::string());
+        co.open.reset();
+        co.lane_busy[S->lane] = false;
+        co.cv.notify_all();
+      }
+      return rc;
+    }
+    S->calls++;
+    S->items += count;
+    if (!jkey.empty()) S->key_items[jkey] += (uint32_t)count;
+    co.n_calls++; co.n_items += count; co.n_appended += appended;
+    if (S->items >= co.max_items) { S->full = true; co.cv.notify_all(); }
+    break;
+  }
+  // ---- a caller that defers (a mixed request staging its groups one after the other): the session is noted and the call returns;
+  // afx::drain_deferred waits for - or launches - what it left behind.  A session it leads and that is full goes now.
+  if (tl_deferred) {
+    tl_deferred->note(S);
+    if (S->leader == me && S->full) { const int rc = lead(c, S); tl_deferred->forget(S); return rc; }
+    return AFX_OK;
+  }
+  // ---- everybody but the leader: sleep on the session's own condition, with the context given up for good - a completion wakes
+  // the callers it answers, and they go home without queueing on the context's lock again
+  if (S->leader != me) {
+    CtxLock* mine = CtxLock::outermost();
+    if (mine && mine->c == c && c->lock_depth == 1) mine->release();
+    else { c->lock_depth = 0; c->mu.unlock(); }   // (not reached: host_pipe only comes here at depth 1 under a CtxLock)
+    std::unique_lock<std::mutex> lk(S->done_mu);
+    S->done_cv.wait(lk, [&] { return S->done; });
+    if (S->rc) set_error(S->err);
+    return S->rc;
+  }
+  return lead(c, S);
+}
 }  // namespace
+
+afx::DeferScope::DeferScope(afx::Deferred* d) : prev(tl_deferred) { tl_deferred = d; }
+afx::DeferScope::~DeferScope() { tl_deferred = (afx::Deferred*)prev; }
+
+// Entered with c->mu held once.  The sessions this thread's deferred calls were left with: the one it leads is launched, the others
+// are waited for (with the context released meanwhile: their leaders need it).  Returns the first failure.
+int afx::drain_deferred(afx_ctx* c, afx::Deferred& d) {
+  const std::thread::id me = std::this_thread::get_id();
+  int rc = AFX_OK;
+  std::string err;
+  std::vector<std::shared_ptr<afx::Session>> pending;
+  pending.swap(d.pending);
+  for (const auto& S : pending) {
+    int r;
+    if (S->leader == me && S->state == afx::Session::COLLECTING) r = lead(c, S);
+    else {
+      const int depth = c->lock_depth;
+      c->lock_depth = 0;
+      c->mu.unlock();
+      {
+        std::unique_lock<std::mutex> lk(S->done_mu);
+        S->done_cv.wait(lk, [&] { return S->done; });
+        r = S->rc;
+        if (r) set_error(S->err);
+      }
+      c->mu.lock();
+      c->lock_depth = depth;
+    }
+    if (r && !rc) { rc = r; err = afx_last_error(); }
+  }
+  if (rc) set_error(err);
+  return rc;
+}
 
 int host_pipe(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey& join_key) {
   if (c->session && !c->session->paused) {
@@ -392,6 +448,9 @@ int host_pipe(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey& joi
     if (co.enabled && co.max_items && count && count <= co.max_call_items && c->small_batch_items && count <= c->small_batch_items && !c->trace &&
         !c->pipelining && !c->cur_stager)
       return coalesced_call(c, count, slice, join_key);
+    // (a group of a mixed request too large to be collected: what the request's small groups left with the sessions goes first -
+    // quiesce would otherwise wait for a session only this thread can launch)
+    if (tl_deferred && !tl_deferred->pending.empty()) { const int rc = afx::drain_deferred(c, *tl_deferred); if (rc) return rc; }
     CtxLock::quiesce(c);
   }
   const int entry_force = c->force_lane;

@@ -131,6 +131,19 @@ struct Session {
 };
 }  // namespace afx
 
+namespace afx {
+// Calls of one thread that were LEFT with the coalescer's sessions instead of being waited for one by one (the small groups of a mixed
+// request): while a DeferScope is alive on the thread, a collected call returns as soon as its rows are staged - its results exist once
+// drain_deferred has returned.  plans.cpp.
+struct Deferred {
+  std::vector<std::shared_ptr<Session>> pending;
+  void note(const std::shared_ptr<Session>& s) { for (const auto& p : pending) if (p == s) return; pending.push_back(s); }
+  void forget(const std::shared_ptr<Session>& s) { for (size_t i = 0; i < pending.size(); i++) if (pending[i] == s) { pending.erase(pending.begin() + i); return; } }
+};
+struct DeferScope { void* prev; explicit DeferScope(Deferred* d); ~DeferScope(); DeferScope(const DeferScope&) = delete; DeferScope& operator=(const DeferScope&) = delete; };
+int drain_deferred(afx_ctx* c, Deferred& d);   // with c->mu held once (a CtxLock of the joining kind)
+}  // namespace afx
+
 // Every entry point that touches a context's host state holds this.  `joiner`: a small host-pointer front end, which may join the
 // coalescer's collecting session (host_pipe decides); everything else needs the context to itself and first waits until no session
 // collects or is in flight (quiesce).  Re-entrant on the owning thread (the host-pointer front ends call the *_dev forms).

@@ -84,6 +84,22 @@ def check_show(afx, uctx, w, lo, hi):
             assert all(cell(g[f]) == bytes(getattr(q, f)) for f in ("pk", "E1", "E2", "C_y_1", "C_y_2", "C_y_3", "C_y_2p"))
 
 
+def check_issuance_verify(afx, uctx, w, lo, hi):
+    from aeonflux_amd import batch
+    cr = w["d"]["creds"][lo:hi]
+    col = lambda f: np.stack([np.frombuffer(f(c), np.uint8) for c in cr]).copy()
+    iss = {k: col(lambda c, k=k: c[k]) for k in ("t", "U", "V", "challenge")}
+    iss["responses"] = np.stack([col(lambda c, k=k: c["responses"][k]) for k in range(N + 5)])
+    values = np.stack([col(lambda c, i=i: c["values"][i][:32]) for i in range(N)])
+    want = []
+    for i, c in enumerate(cr):
+        if (lo + i) % 2:
+            iss["responses"][2, i, 3] ^= 1
+        want.append(w["d"]["user"].issuance_verify(c["kinds"], c["values"], c["t"], c["U"], c["V"], c["challenge"],
+                                                   [iss["responses"][k, i].tobytes() for k in range(N + 5)]))
+    assert batch.verify_issuances(uctx, cr[0]["kinds"], values, iss).tolist() == want and (len(cr) < 2 or 1 in want)
+
+
 def drive(afx, world, ictx, uctx, threads, rounds):
     errs = []
 
@@ -94,13 +110,21 @@ def drive(afx, world, ictx, uctx, threads, rounds):
                 total = len(w["shown"])
                 lo = (3 * t + r) % total
                 hi = min(total, lo + 1 + (t + r) % 3)    # 1 .. 3 items a call
-                what = (t + 2 * r) % 4
-                if what <= 1:     # Issuer::verify, half the load
+                what = (t + 2 * r) % 6
+                if what <= 1:     # Issuer::verify on column arrays
                     assert gpu_verify(afx, ictx, w["damaged"][lo:hi]) == w["verdicts"][lo:hi]
                 elif what == 2:
                     check_issue(afx, ictx, w, lo, hi)
-                else:
+                elif what == 3:
                     check_show(afx, uctx, w, lo, hi)
+                elif what == 4:   # Issuer::verify on a serialized batch: the records join the same sessions
+                    from aeonflux_amd import wire
+                    from tests.soa import presentation_arrays, shape_of
+                    sub = w["damaged"][lo:hi]
+                    blob = wire.pack_presentations(afx.Shape.from_buffer_copy(bytes(shape_of(sub[0]))), presentation_arrays(sub))
+                    assert wire.verify_wire(ictx, blob).tolist() == w["verdicts"][lo:hi]
+                else:             # CredentialIssuance::verify on the user's context, one response of every other item damaged
+                    check_issuance_verify(afx, uctx, w, lo, hi)
         except BaseException as e:   # noqa: an assertion in a thread must fail the test
             errs.append((t, repr(e)[:400]))
 

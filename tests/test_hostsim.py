@@ -411,7 +411,7 @@ kinds = [0] * 8
 k2 = [1, 0, 2, 2, 4, 4, 3, 3]
 L.afx_fake_set(b"echo", 1)
 L.afx_fake_set(b"sync_us", 300)
-K, reps = 12, 30
+K, reps = 16, 24
 errs, failed = [], []
 def work(t):
     try:
@@ -419,8 +419,17 @@ def work(t):
             cnt, tag = 1 + (t + r) %% 5, 7 * t + r
             want = [(tag + i) %% 251 for i in range(cnt)]
             try:
-                kind = t %% 6
-                if kind == 0:
+                kind = t %% 8
+                if kind == 6:      # a request of two shapes: its groups join the collecting sessions (afx::DeferScope) beside the others' calls
+                    a, b = mk(cnt, tag), mk(2, tag + 100, 0)
+                    got = batch.verify_mixed(ctx, [(shape, a), (sh2, b), (shape, a)])
+                    st = np.concatenate(got)
+                    want = want + [(tag + 100 + i) %% 251 for i in range(2)] + want
+                elif kind == 7:    # ... and as a stream of serialized sections, the two of one shape apart from each other
+                    a, b = mk(cnt, tag), mk(2, tag + 100, 0)
+                    st = wire.verify_mixed_wire(ctx, wire.pack_presentations(shape, a) + wire.pack_presentations(sh2, b) + wire.pack_presentations(shape, a))
+                    want = want + [(tag + 100 + i) %% 251 for i in range(2)] + want
+                elif kind == 0:
                     st = batch.verify_presentations(ctx, shape, mk(cnt, tag))
                 elif kind == 1:
                     st = batch.verify_presentations(ctx, sh2, mk(cnt, tag, 0))
