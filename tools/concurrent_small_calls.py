@@ -131,8 +131,8 @@ def one_context(args):
         print("# tools/concurrent_small_calls.py --one-context: K threads x synchronous host-pointer calls of %d item(s) through the C ABI (native driver,"
               " tools/coalesce_drive.cpp), every call's bytes checked against one whole-batch call.  CPU oracle, Issuer::verify C3, one thread: %.0f/s"
               % (args.items, cpu1))
-        print("%-7s %-4s | %-34s | %-22s | %-22s | %-10s" % ("op", "K", "ONE context (calls/s  p50  p99 ms  calls/launch set)", "collection off (calls/s p99)",
-                                                              "K contexts (calls/s p99)", "K x CPU thread"))
+        print("%-7s %-4s | %-34s | %-22s | %-22s | %-10s" % ("op", "K", "ONE context (calls/s  p50  p99 ms  calls/launch set  lock held: us/call staging, us/set launching)",
+                                                              "collection off (calls/s p99)", "K contexts (calls/s p99)", "K x CPU thread"))
         for op in ops:
             for k in threads:
                 calls = max(50, min(400, 6000 // k))
@@ -145,9 +145,9 @@ def one_context(args):
                     row.append(json.loads(r.stdout.strip().splitlines()[-1]))
                 a, b, c = row
                 assert not (a["wrong"] or b["wrong"] or c["wrong"])
-                print("%-7s %-4d | %8.0f  %6.3f  %6.3f  %6.1f          | %8.0f  %6.3f       | %8.0f  %6.3f       | %8.0f" % (
-                    op, k, a["calls_per_s"], a["p50_ms"], a["p99_ms"], a["calls_per_launch_set"], b["calls_per_s"], b["p99_ms"], c["calls_per_s"], c["p99_ms"],
-                    cpu1 * k if op == "verify" else float("nan")), flush=True)
+                print("%-7s %-4d | %8.0f  %6.3f  %6.3f  %6.1f  %5.1f  %6.1f   | %8.0f  %6.3f       | %8.0f  %6.3f       | %8.0f" % (
+                    op, k, a["calls_per_s"], a["p50_ms"], a["p99_ms"], a["calls_per_launch_set"], a.get("staging_us_per_call", 0.0), a.get("launch_us_per_set", 0.0),
+                    b["calls_per_s"], b["p99_ms"], c["calls_per_s"], c["p99_ms"], cpu1 * k if op == "verify" else float("nan")), flush=True)
 
 
 def context_each():
