@@ -105,6 +105,15 @@ def test_a_wide_request_takes_longer_chains_and_the_same_statuses(batches):
         arr[g].shape, arr[g].batch, arr[g].count = sh, soa, 1
         arr[g].positions = pos.ctypes.data_as(C.POINTER(C.c_uint64))
         keep.append((cols, soa, encs, pos))
+    # with the context's collector on (the default) the request's groups join the collecting session and groups of ONE shape share a pass's
+    # item slots: 210 one-presentation groups are four passes of 64 - the statuses must be the same ...
+    status = np.full(total, 255, np.uint8)
+    afx.check(afx.lib().afx_verify_presentations_mixed(ctx.h, arr, total, status.ctypes.data, total))
+    assert status.tolist() == (want_a * reps)[::-1]
+    cs = ctx.coalescing_stats()
+    assert cs["calls"] == total and cs["appended_calls"] >= total - 8 and cs["sessions"] <= 4, cs
+    # ... as with the request's own session of 210 plans (collection off: the round-4 path), which is what this test is about
+    ctx.set_coalescing(0, 0)
     status = np.full(total, 255, np.uint8)
     afx.check(afx.lib().afx_verify_presentations_mixed(ctx.h, arr, total, status.ctypes.data, total))
     assert status.tolist() == (want_a * reps)[::-1]
