@@ -18,6 +18,7 @@ import tempfile
 import threading
 import time
 sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import aeonflux_amd as afx
 import bench
@@ -121,16 +122,37 @@ def cpu_single_thread_verify_rate():
     return 128 / dt
 
 
+def cpu_single_thread_prover_rates():
+    """the CPU oracle's Issuer::issue (16 attributes, C5's layout) and AnonymousCredential::show (C3 shape) rates on one thread"""
+    from tests.helpers import make_credentials
+    out = {}
+    d = make_credentials(16, "SSSSSSSSPPPPEEEE", 24, b"cpu-issue-rate")
+    cr = d["creds"]
+    t0 = time.perf_counter()
+    for c in cr:
+        assert d["issuer"].issue(c["kinds"], c["values"], *c["rnd"])[0] == 0
+    out["issue"] = len(cr) / (time.perf_counter() - t0)
+    d = make_credentials(8, "SSPPEEEE", 24, b"cpu-show-rate")
+    kinds = [4 if i >= 4 else k for i, k in enumerate(d["creds"][0]["kinds"])]
+    take, user = d["take"], d["user"]
+    args = [(c, user.keypair_derive(take(64)), take(64), take(32), take(32 * 4)) for c in d["creds"]]
+    t0 = time.perf_counter()
+    for c, kp, z, sd, es in args:
+        assert user.show(kinds, c["values"], c["t"], c["U"], c["V"], kp, z, sd, es)[0] == 0
+    out["show"] = len(args) / (time.perf_counter() - t0)
+    return out
+
+
 def one_context(args):
     threads = [int(x) for x in args.threads.split(",")]
     ops = args.ops.split(",")
     exe = build_driver()
     with tempfile.TemporaryDirectory() as tmp:
         files = dumps(max(threads) * args.items, tmp)
-        cpu1 = cpu_single_thread_verify_rate()
+        cpu = dict(cpu_single_thread_prover_rates(), verify=cpu_single_thread_verify_rate())
         print("# tools/concurrent_small_calls.py --one-context: K threads x synchronous host-pointer calls of %d item(s) through the C ABI (native driver,"
-              " tools/coalesce_drive.cpp), every call's bytes checked against one whole-batch call.  CPU oracle, Issuer::verify C3, one thread: %.0f/s"
-              % (args.items, cpu1))
+              " tools/coalesce_drive.cpp), every call's bytes checked against one whole-batch call.  CPU oracle on one thread: Issuer::verify (C3 shape) %.0f/s,"
+              " Issuer::issue (16 attributes) %.0f/s, show (C3 shape) %.0f/s" % (args.items, cpu["verify"], cpu["issue"], cpu["show"]))
         print("%-7s %-4s | %-34s | %-22s | %-22s | %-10s" % ("op", "K", "ONE context (calls/s  p50  p99 ms  calls/launch set  lock held: us/call staging, us/set launching)",
                                                               "collection off (calls/s p99)", "K contexts (calls/s p99)", "K x CPU thread"))
         for op in ops:
@@ -147,7 +169,7 @@ def one_context(args):
                 assert not (a["wrong"] or b["wrong"] or c["wrong"])
                 print("%-7s %-4d | %8.0f  %6.3f  %6.3f  %6.1f  %5.1f  %6.1f   | %8.0f  %6.3f       | %8.0f  %6.3f       | %8.0f" % (
                     op, k, a["calls_per_s"], a["p50_ms"], a["p99_ms"], a["calls_per_launch_set"], a.get("staging_us_per_call", 0.0), a.get("launch_us_per_set", 0.0),
-                    b["calls_per_s"], b["p99_ms"], c["calls_per_s"], c["p99_ms"], cpu1 * k if op == "verify" else float("nan")), flush=True)
+                    b["calls_per_s"], b["p99_ms"], c["calls_per_s"], c["p99_ms"], cpu[op] * k), flush=True)
 
 
 def context_each():
