@@ -262,11 +262,15 @@ int lead(afx_ctx* c, const std::shared_ptr<afx::Session>& S) {
     for (const auto& p : S->plans) waves += (p->count + 63) / 64;
     co.last_waves = (uint32_t)waves;
     co.last_plans = (uint32_t)S->plans.size();
-    for (const auto& kv : S->key_items) co.demand[kv.first] = kv.second;
-    if (co.demand.size() > 4096) co.demand.clear();   // (keys come from callers' shapes)
+    try {
+      for (const auto& kv : S->key_items) co.demand[kv.first] = kv.second;
+      if (co.demand.size() > 4096) co.demand.clear();   // (keys come from callers' shapes)
+    } catch (...) { }
     co.n_max_calls = std::max<uint64_t>(co.n_max_calls, S->calls);
     const clock::time_point launch_t0 = clock::now();
-    int rc = S->launch();
+    // (whatever happens in here, the session is completed and its callers are woken: an exception becomes the flush's return code)
+    int rc;
+    try { rc = S->launch(); } catch (...) { rc = afx::exception_rc(); }
     co.launch_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - launch_t0).count();
     S->state = afx::Session::INFLIGHT;
     std::string err;
@@ -275,8 +279,8 @@ int lead(afx_ctx* c, const std::shared_ptr<afx::Session>& S) {
       const int d = c->lock_depth;
       c->lock_depth = 0;
       c->mu.unlock();
-      rc = S->complete(rc);
-      if (rc) err = afx_last_error();
+      try { rc = S->complete(rc); } catch (...) { rc = afx::exception_rc(); }
+      try { if (rc) err = afx_last_error(); } catch (...) { }
       S->finish(rc, err);          // the joined callers go home now; the context's bookkeeping follows
       c->mu.lock();
       c->lock_depth = d;
@@ -347,9 +351,13 @@ int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey
       // (nothing may leave this function by exception: a session whose leader is gone would never be launched)
       try { rc = slice(st, 0, count); } catch (...) { rc = afx::exception_rc(); }
       if (!rc) {
+        // (from here on the call's rows and result declarations are with the session: nothing below may fail the call - a caller
+        // that got an error would take its arrays away from under the flush)
         if (st.app) { st.app->used += (uint32_t)count; appended = true; }
-        else if (!jkey.empty() && st.last_dn && st.uploaded)
-          S->slots.push_back({ jkey, st.ops, st.in_at, st.out_at, st.in_bytes, st.out_bytes, st.last_dn, (uint32_t)count });
+        else if (!jkey.empty() && st.last_dn && st.uploaded) {
+          try { S->slots.push_back({ jkey, st.ops, st.in_at, st.out_at, st.in_bytes, st.out_bytes, st.last_dn, (uint32_t)count }); }
+          catch (...) { }   // out of memory: the group simply takes no joiners
+        }
       }
     }
     co.staging_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - stage_t0).count();
@@ -376,7 +384,7 @@ int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey
     }
     S->calls++;
     S->items += count;
-    if (!jkey.empty()) S->key_items[jkey] += (uint32_t)count;
+    if (!jkey.empty()) { try { S->key_items[jkey] += (uint32_t)count; } catch (...) { } }   // (a hint for the next session's item slots)
     co.n_calls++; co.n_items += count; co.n_appended += appended;
     if (S->items >= co.max_items) { S->full = true; co.cv.notify_all(); }
     break;
