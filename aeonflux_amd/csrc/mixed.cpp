@@ -62,16 +62,19 @@ int run_groups(afx_ctx* ctx, G* groups, size_t n_groups, uint8_t* status, size_t
     size_t nextj = 0;
     {
       afx::DeferScope scope(&deferred);
-      for (size_t g = 0; g < n_groups && !rc; g++) {
-        G& grp = groups[g];
-        if (grp.count) {
-          uint8_t* st = status + nextj;
-          if (grp.positions) { tmpj[g].assign(grp.count, AFX_ST_VERIFICATION_FAILURE); st = tmpj[g].data(); }
-          rc = run_one(grp, st);
-          if (rc) set_error("group " + std::to_string(g) + ": " + afx_last_error());
+      // (an exception must not pass the drain below: other threads' calls may sit in a session only this thread launches)
+      try {
+        for (size_t g = 0; g < n_groups && !rc; g++) {
+          G& grp = groups[g];
+          if (grp.count) {
+            uint8_t* st = status + nextj;
+            if (grp.positions) { tmpj[g].assign(grp.count, AFX_ST_VERIFICATION_FAILURE); st = tmpj[g].data(); }
+            rc = run_one(grp, st);
+            if (rc) set_error("group " + std::to_string(g) + ": " + afx_last_error());
+          }
+          nextj += grp.count;
         }
-        nextj += grp.count;
-      }
+      } catch (...) { rc = afx::exception_rc(); }
       // what the groups left with the sessions: launched (the session this thread leads) or waited for - also after a failure, since
       // the staged rows point into this request's arrays
       CtxLock lk(ctx, true);
@@ -334,6 +337,7 @@ static int mixed_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* st
   struct WidthReset { afx_ctx* c; ~WidthReset() { if (c) c->merge_class = 0; } } width_reset = { ses ? ctx : nullptr };
   std::vector<uint8_t> merged;
   std::vector<std::vector<uint8_t>> sts(order.size());   // statuses of the groups whose sections are not adjacent: scattered after the flush
+  try {   // (an exception must not pass the drain below: see run_groups)
   for (size_t gi = 0; gi < order.size() && !rc; gi++) {
     const Group& G = by_shape[order[gi]];
     if (G.count == 0) continue;
@@ -364,6 +368,10 @@ static int mixed_wire(afx_ctx* ctx, const uint8_t* blob, size_t len, uint8_t* st
       rc = verify_section(merged.data(), merged.size(), sts[gi].data(), sts[gi].size(), &got);   // (a collected call copies its records at once)
     }
     if (ses) ses->paused = false;
+  }
+  } catch (...) {
+    if (!join) throw;
+    rc = afx::exception_rc();
   }
   if (ses) {
     if (rc) ses->drop();

@@ -197,6 +197,8 @@ int Stager::fetch_all() {
   afx_ctx::Lane& L = c->lane[ln];
   if (ses) {
     // declared, not fetched: the session's flush brings its whole output image back and scatters
+    // (all or none: a call that fails here must leave no pointer into its caller's arrays behind)
+    if (ses->outs.capacity() < ses->outs.size() + outs.size()) ses->outs.reserve(std::max(ses->outs.size() + outs.size(), 2 * ses->outs.capacity()));
     for (const Out& o : outs) ses->outs.push_back({ o.dst, out_at + o.pin_off, o.len });
     outs.clear();
     pend_.clear();
