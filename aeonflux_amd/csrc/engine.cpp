@@ -191,7 +191,7 @@ void Assembler::add_walk_rows(Launch& l, uint32_t per_row) {
 }
 void Assembler::scalarop(const std::vector<afx_scalarop_job>& jobs) { add_jobs(L_SCALAROP, jobs); }
 void Assembler::hash(const std::vector<afx_hash_program>& progs) {
-  if (!pending_cjobs_.empty()) msm(std::vector<afx_msm_job>());   // encodings still queued (Assembler::pointop, compress_also) are launched before their reader
+  flush_encodings();   // encodings still queued (Assembler::pointop, compress_also, a small pass's stages) are launched before their reader
   for (const afx_hash_program& p : progs) stats.keccak_permutations += p.n_records;
   add_jobs(L_HASH, progs);
 }
@@ -332,17 +332,23 @@ void Assembler::compress(const std::vector<afx_compress_job>& cjobs, uint32_t gr
 // Multiscalar jobs of one statement stage.  Large passes: one lane per (job, item), every job a single chain (msm_list).  Small
 // passes (at most afx_ctx_set_small_batch_items items, default 4096): the device is mostly idle and a call's duration is the
 // LONGEST chain, so every variable-base term gets a chain of its own (msm_split).
+// The queued encodings (compress_also(), the plain jobs of Assembler::pointop and msm_split, and - small passes - everything a stage's
+// chains left for k_compress2x): one launch, before their first reader.
+void Assembler::flush_encodings() {
+  if (pending_cjobs_.empty()) return;
+  for (const int32_t* v : pending_half_vars_)
+    if (!half_bases_.count(v)) throw std::logic_error("compress_also: the variable does not hold a half");
+  pending_half_vars_.clear();
+  std::vector<afx_compress_job> cjobs;
+  cjobs.swap(pending_cjobs_);
+  compress(cjobs, ctx->walk_rows(count, cjobs.size(), small()));
+}
+
 void Assembler::msm(std::vector<afx_msm_job> jobs) {
   if (jobs.empty()) {
-    // encodings queued by compress_also() ride in this call's k_compress2x launch even when it has no chains of its own
-    if (!pending_cjobs_.empty()) {
-      for (const int32_t* v : pending_half_vars_)
-        if (!half_bases_.count(v)) throw std::logic_error("compress_also: the variable does not hold a half");
-      pending_half_vars_.clear();
-      std::vector<afx_compress_job> cjobs;
-      cjobs.swap(pending_cjobs_);
-      compress(cjobs, ctx->walk_rows(count, cjobs.size(), small()));
-    }
+    // encodings queued by compress_also() ride in this call's k_compress2x launch even when it has no chains of its own (a small
+    // pass keeps them for the launch in front of their reader: see the end of this function)
+    if (!small()) flush_encodings();
     return;
   }
   for (size_t i = 0; i < jobs.size(); i++)
@@ -422,7 +428,10 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
       msm_list(std::move(rest), false, cjobs);
     }
   } else msm_list(std::move(jobs), false, cjobs);
-  // small passes: the item's commitments are encoded in a row each (8 rows when the device is busy), an inversion each, instead of one serial walk
+  // Small passes: the item's commitments are encoded in a row each (8 rows when the device is busy), an inversion each, instead of
+  // one serial walk - and not here but in front of their first reader (Assembler::hash, finish: nothing else reads an encoding a
+  // stage produced), together with whatever k_pointop left to encode after this stage: one 65 us launch instead of two in a small show.
+  if (small) { pending_cjobs_.insert(pending_cjobs_.end(), cjobs.begin(), cjobs.end()); return; }
   compress(cjobs, ctx->walk_rows(count, cjobs.size(), small));
 }
 
@@ -464,8 +473,20 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
       // small issue call)
       const uint32_t FIXED_PER_PART = 6;
       const uint32_t parts = (j.n_var + var_per_part - 1) / var_per_part + (j.n_terms - j.n_var + FIXED_PER_PART - 1) / FIXED_PER_PART;
-      if (parts <= 1) { subs.push_back(j); continue; }   // a single chain already (its addend, if any, is added by its own lane)
       const bool halved = j.out_enc && !j.addend && (!j.out_var || j.leave_half);   // only ever encoded, or leaving its half: halved scalars, k_compress2x (msm_list)
+      // Small passes: an encoding that would run INSIDE the chain's kernel (a result with an addend, or one that is also a base) goes
+      // to the k_compress2x launch behind the chains instead, as a plain job in a row of its own (as Assembler::pointop does): the
+      // square-root chain runs beside the stage's other encodings instead of behind the longest chain, and a launch without encoders
+      // may run four waves per chain (kernels.hip afxk_msm: show's first stage 757 -> 480 us).  Same point, same bytes.
+      afx_compress_job plain = { nullptr, nullptr, 0, AFX_COMPRESS_PLAIN };
+      if (no_naf && small() && j.out_enc && !halved && !j.half_var) {
+        if (!j.out_var) j.out_var = new_var();
+        plain.var = j.out_var; plain.out_enc = j.out_enc; plain.reject_identity = j.reject_identity;
+        j.out_enc = nullptr; j.reject_identity = 0;
+        cjobs.push_back(plain);
+        stats.encodings++; stats.field_mul += AFX_ENCODE_MUL; stats.field_sq += AFX_ENCODE_SQ; stats.chain_mul += AFX_CHAIN_SQRT_MUL; stats.chain_sq += AFX_CHAIN_SQRT_SQ;
+      }
+      if (parts <= 1) { subs.push_back(j); continue; }   // a single chain already (its addend, if any, is added by its own lane)
       std::vector<const int32_t*> part_vars;
       auto sub_of = [&](uint32_t first, uint32_t nterms, uint32_t nvar) {
         afx_msm_job s;
@@ -777,6 +798,7 @@ void Assembler::copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
   launches.push_back(l);
 }
 void Assembler::finish(uint8_t* status_dev, uint8_t fail_code) {
+  flush_encodings();   // (results no transcript reads; their rejections are flags k_finish folds into the status)
   const afx_finish_job j = { bad_, status_dev, count, fail_code };
   add_jobs(L_FINISH, std::vector<afx_finish_job>(1, j));
 }

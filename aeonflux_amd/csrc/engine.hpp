@@ -321,6 +321,7 @@ class Assembler {
   void compress(const std::vector<afx_compress_job>& cjobs, uint32_t groups);
   template <class T>
   void add_jobs(LaunchKind k, const std::vector<T>& jobs);
+  void flush_encodings();
   void add_walk_rows(Launch& l, uint32_t per_row);   // the afx_walk_row array of a k_compress2x / k_negenc / k_table_affine launch (+ its prefix scratch)
   std::set<const int32_t*> half_bases_;            // variables that hold HALF their point (producers with leave_half)
   std::vector<afx_compress_job> pending_cjobs_;    // compress_also()
