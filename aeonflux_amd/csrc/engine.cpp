@@ -402,7 +402,8 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
       for (const afx_msm_job& j : jobs) chains += (j.n_var + per_chain - 1) / per_chain + (j.n_terms - j.n_var + 5) / 6;
       if (chains * row_waves <= room) break;
     }
-    msm_split(std::move(jobs), cjobs, true, per_chain);
+    const bool seg = per_chain == 1 && segment_bases(jobs);
+    msm_split(std::move(jobs), cjobs, true, per_chain, seg);
   }
   else if (mid) {
     auto naf_term = [&](const afx_msm_term& t) { return t.scalar_stride == 0 && !ctx->fixed_key_schedule && !ctx->secure_plan(secret_scalars) && !t.dbl && host_scalar_of(ctx, t.scalar) != nullptr; };
@@ -435,6 +436,49 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   compress(cjobs, ctx->walk_rows(count, cjobs.size(), small));
 }
 
+// AFX_SEGMENTS=1|2|4|8 (measurement aid; default 4): into how many segments a small prover pass cuts a secret scalar on a per-item base
+uint32_t Assembler::segments() const {
+  static const uint32_t env = [] {
+    const char* e = getenv("AFX_SEGMENTS");
+    const int v = e ? atoi(e) : 4;
+    return (v == 1 || v == 2 || v == 4 || v == 8) ? (uint32_t)v : 4u;
+  }();
+  static_assert(AFX_SECVAR_WINDOWS % 8 == 0 && AFX_POWERS_MAX >= 7, "a scalar's windows divide into up to eight segments");
+  // the passes whose chains run four waves each on a device they leave idle (kernels.hip afxk_msm): up to 256 items
+  if (env <= 1 || !small() || !secret_scalars || !ctx->secure_plan(secret_scalars) || ctx->row_waves(count) > 4) return 1;
+  return env;
+}
+bool Assembler::segment_bases(const std::vector<afx_msm_job>& jobs) {
+  const uint32_t S = segments();
+  if (S <= 1) return false;
+  // a base one of THIS stage's jobs produces has no powers before the stage runs: its terms keep their full chains
+  std::set<const int32_t*> produced;
+  for (const afx_msm_job& j : jobs) { if (j.out_var) produced.insert(j.out_var); if (j.half_var) produced.insert(j.half_var); }
+  std::vector<afx_powers_job> pj;
+  bool any = false;
+  for (const afx_msm_job& j : jobs)
+    for (uint32_t t = 0; t < j.n_var; t++) {
+      const afx_msm_term& tm = j.term[t];
+      if (!tm.secret || produced.count(tm.var)) continue;
+      any = true;
+      if (powers_.count(tm.var)) continue;
+      afx_powers_job q;
+      memset(&q, 0, sizeof q);
+      q.src = tm.var;
+      q.step = AFX_SECVAR_BITS * (AFX_SECVAR_WINDOWS / S);
+      q.n_out = S - 1;
+      std::vector<int32_t*> vs;
+      for (uint32_t k = 0; k + 1 < S; k++) { vs.push_back(new_var()); q.out[k] = vs.back(); }
+      powers_[tm.var] = vs;
+      pj.push_back(q);
+      const uint64_t d = (uint64_t)q.step * q.n_out;   // doublings: four squarings, four products each (kernels.hip quad_dbl)
+      stats.doublings += d; stats.field_sq += 4 * d; stats.field_mul += 4 * d;
+    }
+  if (!pj.empty()) add_jobs(L_POWERS, pj);
+  if (any) segmenting_ = true;
+  return any;
+}
+
 void Assembler::compress_also(const int32_t* var, uint8_t* out_enc, bool negate, uint32_t reject_identity) {
   afx_compress_job cj = { var, out_enc, reject_identity, negate ? 1u : 0u };
   pending_cjobs_.push_back(cj);
@@ -447,8 +491,10 @@ void Assembler::compress_also(const int32_t* var, uint8_t* out_enc, bool negate,
 // terms six at a time - becomes that many single-part jobs writing partial sums, plus a k_pointsum row adding them (and the addend) up; a job that feeds
 // another (chain_to) is summed before the consumer's chains start, so stages run level by level.  no_naf (small passes): no NAF
 // schedules - a lone key term costs 64 additions instead of ~43, but shares the windowed launch with every other chain of its stage.
-void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compress_job>& cjobs, bool no_naf, uint32_t var_per_part) {
+void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compress_job>& cjobs, bool no_naf, uint32_t var_per_part, bool segs) {
   if (var_per_part == 0) var_per_part = 1;
+  const uint32_t S = (segs && var_per_part == 1) ? segments() : 1, W = AFX_SECVAR_WINDOWS / S;
+  auto segmented = [&](const afx_msm_term& t) { return S > 1 && t.secret && t.fixed_idx < 0 && powers_.count(t.var) != 0; };
   const size_t n = jobs.size();
   for (size_t i = 0; i < n; i++)
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
@@ -471,8 +517,10 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
       // fixed-base terms go six to a part: 120 additions, well under the 252 doublings + 64 additions of a variable-base chain
       // (the second commitment of an issuance proof has n + 3 of them: one lane with 380 additions was the longest chain of a
       // small issue call)
-      const uint32_t FIXED_PER_PART = 6;
-      const uint32_t parts = (j.n_var + var_per_part - 1) / var_per_part + (j.n_terms - j.n_var + FIXED_PER_PART - 1) / FIXED_PER_PART;
+      // (a segmenting pass, whose variable-base chains are a quarter as long, takes them two to a part)
+      const uint32_t FIXED_PER_PART = S > 1 ? 2 : 6;
+      uint32_t parts = (j.n_var + var_per_part - 1) / var_per_part + (j.n_terms - j.n_var + FIXED_PER_PART - 1) / FIXED_PER_PART;
+      for (uint32_t t = 0; t < j.n_var; t++) if (segmented(j.term[t])) parts += S - 1;
       const bool halved = j.out_enc && !j.addend && (!j.out_var || j.leave_half);   // only ever encoded, or leaving its half: halved scalars, k_compress2x (msm_list)
       // Small passes: an encoding that would run INSIDE the chain's kernel (a result with an addend, or one that is also a base) goes
       // to the k_compress2x launch behind the chains instead, as a plain job in a row of its own (as Assembler::pointop does): the
@@ -498,7 +546,19 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
         part_vars.push_back(v);
         subs.push_back(s);
       };
-      for (uint32_t t = 0; t < j.n_var; t += var_per_part) { const uint32_t k = std::min(var_per_part, j.n_var - t); sub_of(t, k, k); }
+      for (uint32_t t = 0; t < j.n_var; t += var_per_part) {
+        const uint32_t k = std::min(var_per_part, j.n_var - t);
+        if (!segmented(j.term[t])) { sub_of(t, k, k); continue; }
+        // segment g: windows [g W, (g + 1) W) of the recoded scalar on 2^(bits * g W) times the base: a chain of W windows
+        const std::vector<int32_t*>& pw = powers_[j.term[t].var];
+        for (uint32_t g = 0; g < S; g++) {
+          sub_of(t, 1, 1);
+          afx_msm_job& sg = subs.back();
+          if (g) sg.term[0].var = pw[g - 1];
+          sg.term[0].win_off = g * W;
+          sg.wins = W;
+        }
+      }
       for (uint32_t first = j.n_var; first < j.n_terms; first += FIXED_PER_PART) sub_of(first, std::min(FIXED_PER_PART, j.n_terms - first), 0);
       afx_pointsum_job sj;
       memset(&sj, 0, sizeof sj);
@@ -532,10 +592,11 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
   // encoding; 64 additions + the 9-entry table per variable base; AFX_POS_WINDOWS additions per fixed base
   auto cost = [](const afx_msm_job& j) {
     // a narrow job (a secret scalar on a variable base): AFX_SECVAR_WINDOWS additions per variable term, tables of AFX_SECVAR_STORED
-    const uint32_t per_var = j.narrow ? (AFX_SECVAR_WINDOWS * 13u) / 2u + AFX_SECVAR_STORED * 7u : 470u;
+    const uint32_t nwins = j.wins ? j.wins : AFX_SECVAR_WINDOWS;
+    const uint32_t per_var = j.narrow ? (nwins * 13u) / 2u + AFX_SECVAR_STORED * 7u : 470u;
     uint32_t c = (j.n_var ? 1320u : 160u) + j.n_uni * (330u + 45u /* more conversions to p3 */) + (j.n_var - j.n_uni) * per_var;
     for (uint32_t t = j.n_var; t < j.n_terms; t++) c += ((j.term[t].secret ? AFX_SEC_WINDOWS * 200u : AFX_POS_WINDOWS * 175u)) / 32u;
-    for (uint32_t t = 0; t < j.n_var; t++) c += j.term[t].secret ? (AFX_SECVAR_WINDOWS * AFX_SECVAR_STORED * 15u) / 64u : 0u;   // the table scans
+    for (uint32_t t = 0; t < j.n_var; t++) c += j.term[t].secret ? (nwins * AFX_SECVAR_STORED * 15u) / 64u : 0u;   // the table scans
     return c;
   };
   const size_t n = jobs.size();
@@ -587,9 +648,11 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     jobs[ji].narrow = 0;
     for (uint32_t t = 0; t < jobs[ji].n_var; t++) if (jobs[ji].term[t].secret) jobs[ji].narrow = 1;
     if (jobs[ji].narrow && jobs[ji].n_uni) throw std::logic_error("a NAF schedule in a job with secret scalars");
+    if (jobs[ji].wins && !jobs[ji].narrow) throw std::logic_error("a segment outside a job with secret scalars");
+    if (jobs[ji].narrow && !jobs[ji].wins) jobs[ji].wins = AFX_SECVAR_WINDOWS;
     const afx_msm_job& j = jobs[ji];
     const uint64_t nv = j.n_var;
-    const uint64_t wins = j.narrow ? AFX_SECVAR_WINDOWS : 64, wbits = j.narrow ? AFX_SECVAR_BITS : 4, stored = j.narrow ? AFX_SECVAR_STORED : AFX_TABLE_STORED;
+    const uint64_t wins = j.narrow ? j.wins : 64, wbits = j.narrow ? AFX_SECVAR_BITS : 4, stored = j.narrow ? AFX_SECVAR_STORED : AFX_TABLE_STORED;
     uint64_t nfa = 0;   // additions of the fixed-base terms: AFX_POS_WINDOWS each, AFX_SEC_WINDOWS for a secret scalar
     for (uint32_t t = j.n_var; t < j.n_terms; t++) nfa += j.term[t].secret ? AFX_SEC_WINDOWS : AFX_POS_WINDOWS;
     stats.msm_jobs++;
@@ -668,7 +731,50 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
   }
   std::vector<char> done(n, 0);
   const uint32_t blocks_per_row = (count + AFX_BLOCK - 1) / AFX_BLOCK, resident = 2 * ctx->n_cu;
-  uint32_t dslot = 0, tslot = 0;
+  // the narrow tables of `tr`: built (k_msm_tables, kind 2) and made affine - one inversion per item and grid row over all of the
+  // launch's tables (kernels.hip k_table_affine); a small pass, which waits for the serial walk, spreads them over up to 8 rows
+  auto emit_narrow_tables = [&](const std::vector<afx_table_job>& tr) {
+    Launch tl;
+    tl.kind = L_MSM_TABLES;
+    tl.odd = 2;
+    tl.njobs = (uint32_t)tr.size();
+    tl.jobs_off = blob_alloc(sizeof(afx_table_job) * tr.size(), 16);
+    memcpy(blob_.data() + tl.jobs_off, tr.data(), sizeof(afx_table_job) * tr.size());
+    launches.push_back(tl);
+    Launch al;
+    al.kind = L_TABLE_AFFINE;
+    al.njobs = tl.njobs;
+    al.jobs_off = blob_alloc(sizeof(afx_table_job) * tr.size(), 16);
+    memcpy(blob_.data() + al.jobs_off, tr.data(), sizeof(afx_table_job) * tr.size());
+    const uint32_t groups = ctx->walk_rows(count, tr.size(), small());
+    add_walk_rows(al, groups > 1 ? (al.njobs + groups - 1) / groups : 0);
+    launches.push_back(al);
+    // per entry: the prefix product, 1/Z and the running inverse, x and y, the niels form (4); per row the inversion
+    stats.field_mul += (uint64_t)tr.size() * AFX_SECVAR_STORED * 9 + (uint64_t)al.nrows * 11;
+    stats.field_sq += (uint64_t)al.nrows * 254;
+    stats.chain_mul += (uint64_t)al.nrows * AFX_CHAIN_INVERT_MUL; stats.chain_sq += (uint64_t)al.nrows * AFX_CHAIN_INVERT_SQ;
+  };
+  // A segmenting pass (Assembler::segments) KEEPS its narrow tables: slots from the bottom of the table workspace that no later stage
+  // hands out again, one table per base for the whole pass, the ones this stage is the first to use built by one launch pair ahead
+  // of its chains.  The proof's commitments then find the tables of the bases the first stage multiplied by.
+  std::set<const int32_t*> fresh_kept;
+  if (segmenting_) {
+    std::vector<afx_table_job> tr;
+    for (const afx_msm_job& j : jobs) {
+      if (!j.narrow) continue;
+      for (uint32_t t = 0; t < j.n_var; t++) {
+        const int32_t* v = j.term[t].var;
+        if (kept_tables_.count(v)) continue;
+        const uint32_t slot = (uint32_t)kept_tables_.size();
+        kept_tables_[v] = slot;
+        fresh_kept.insert(v);
+        afx_table_job tj = { v, slot, 0 };
+        tr.push_back(tj);
+      }
+    }
+    if (!tr.empty()) emit_narrow_tables(tr);
+  }
+  uint32_t dslot = 0, tslot = (uint32_t)kept_tables_.size();
   std::map<std::tuple<const int32_t*, bool, bool>, uint32_t> table_of;   // (base, odd multiples?, the short table of a narrow job?) -> table slot
   size_t left = n;
   static const int class_order[3] = { 2, 1, 0 };
@@ -695,6 +801,14 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
       for (uint32_t t = 0; t < j.n_var; t++) {
         const bool odd = t < j.n_uni;
         const uint32_t nstored = j.narrow ? AFX_SECVAR_STORED : AFX_TABLE_STORED;
+        if (segmenting_ && j.narrow) {
+          j.term[t].table_slot = kept_tables_.at(j.term[t].var);
+          if (!fresh_kept.erase(j.term[t].var)) {   // counted per term above; this table exists already
+            stats.table_additions -= nstored - 1;
+            stats.field_mul -= 1 + (nstored - 1) * 8;
+          }
+          continue;
+        }
         const std::tuple<const int32_t*, bool, bool> tk(j.term[t].var, odd, j.narrow != 0);
         auto hit = table_of.find(tk);
         if (hit == table_of.end()) {
@@ -728,6 +842,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     for (int odd = 2; odd >= 0; odd--) {
       const std::vector<afx_table_job>& tr = table_rows[odd];
       if (tr.empty()) continue;
+      if (odd == 2) { emit_narrow_tables(tr); continue; }
       Launch tl;
       tl.kind = L_MSM_TABLES;
       tl.odd = odd;
@@ -735,22 +850,6 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
       tl.jobs_off = blob_alloc(sizeof(afx_table_job) * tr.size(), 16);
       memcpy(blob_.data() + tl.jobs_off, tr.data(), sizeof(afx_table_job) * tr.size());
       launches.push_back(tl);
-      if (odd == 2) {
-        // the tables of narrow jobs become affine entries: one inversion per item and grid row over all of the launch's tables
-        // (kernels.hip k_table_affine); a small pass, which waits for the serial walk, spreads them over up to 8 rows
-        Launch al;
-        al.kind = L_TABLE_AFFINE;
-        al.njobs = tl.njobs;
-        al.jobs_off = blob_alloc(sizeof(afx_table_job) * tr.size(), 16);
-        memcpy(blob_.data() + al.jobs_off, tr.data(), sizeof(afx_table_job) * tr.size());
-        const uint32_t groups = ctx->walk_rows(count, tr.size(), small());
-        add_walk_rows(al, groups > 1 ? (al.njobs + groups - 1) / groups : 0);
-        launches.push_back(al);
-        // per entry: the prefix product, 1/Z and the running inverse, x and y, the niels form (4); per row the inversion
-        stats.field_mul += (uint64_t)tr.size() * AFX_SECVAR_STORED * 9 + (uint64_t)al.nrows * 11;
-        stats.field_sq += (uint64_t)al.nrows * 254;
-        stats.chain_mul += (uint64_t)al.nrows * AFX_CHAIN_INVERT_MUL; stats.chain_sq += (uint64_t)al.nrows * AFX_CHAIN_INVERT_SQ;
-      }
     }
     // a launch none of whose jobs encodes inside the kernel (every windowed launch of Issuer::verify: results that are only
     // encoded go through k_compress2x) runs the kernel compiled without the encoder (kernels.hip, k_msm<KIND, ENC>).  Splitting
@@ -775,7 +874,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
       if (j.n_terms) term_tables_.push_back({ terms_at[i], j.n_terms });
       d.addend = j.addend; d.addend_negate = j.addend_negate; d.reject_identity = j.reject_identity;
       d.out_enc = j.out_enc; d.out_var = j.out_var; d.half_var = j.half_var;
-      d.digit_slot = j.digit_slot; d.narrow = j.narrow; d.leave_half = j.leave_half;
+      d.digit_slot = j.digit_slot; d.narrow = j.narrow; d.leave_half = j.leave_half; d.wins = j.narrow ? j.wins : 0;
     }
     l.jobs_off = blob_alloc(sizeof(afx_msm_djob) * dj.size(), 16);
     for (size_t i = 0; i < dj.size(); i++) dj[i].term_off = (int32_t)((int64_t)terms_at[i] - (int64_t)(l.jobs_off + sizeof(afx_msm_djob) * i));   // from the job itself
@@ -869,6 +968,7 @@ size_t job_size(LaunchKind k) {
     case L_POINTSUM: return sizeof(afx_pointsum_job);
     case L_NEGENC: return sizeof(afx_negenc_job);
     case L_TABLE_AFFINE: return sizeof(afx_table_job);
+    case L_POWERS: return sizeof(afx_powers_job);
     default: return 0;
   }
 }
@@ -929,6 +1029,9 @@ void Plan::relocate(uint8_t* nblob, uint8_t* nws, uint8_t* nin, uint8_t* nout) {
       case L_FROM_UNIFORM: for (uint32_t i = 0; i < l.njobs; i++) { afx_uniform_job& j = ((afx_uniform_job*)J)[i]; m.fix(j.wide); m.fix(j.out_enc); m.fix(j.out_var); } break;
       case L_REDUCE_WIDE: for (uint32_t i = 0; i < l.njobs; i++) { afx_reduce_job& j = ((afx_reduce_job*)J)[i]; m.fix(j.wide); m.fix(j.out); } break;
       case L_FINISH: for (uint32_t i = 0; i < l.njobs; i++) { afx_finish_job& j = ((afx_finish_job*)J)[i]; m.fix(j.bad); m.fix(j.status); } break;
+      case L_POWERS:
+        for (uint32_t i = 0; i < l.njobs; i++) { afx_powers_job& j = ((afx_powers_job*)J)[i]; m.fix(j.src); for (uint32_t k = 0; k < AFX_POWERS_MAX; k++) m.fix(j.out[k]); }
+        break;
       case L_COPY: m.fix(l.in); m.fix(l.out); break;
       case L_KINDS: break;
     }
@@ -1138,6 +1241,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
       case L_NEGENC: AFX_HIP(afxk_negenc(s, (const afx_negenc_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
       case L_TABLE_AFFINE: AFX_HIP(afxk_table_affine(s, (const afx_table_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
       case L_POINTSUM: AFX_HIP(afxk_pointsum(s, (const afx_pointsum_job*)jobs, nrows, rw, passes, max_count)); break;
+      case L_POWERS: AFX_HIP(afxk_powers(s, (const afx_powers_job*)jobs, nrows, rw, passes, max_count)); break;
       case L_MSM_TABLES: AFX_HIP(afxk_msm_tables(s, odd, (const afx_table_job*)jobs, nrows, rw, passes, max_count)); break;
       case L_MSM_FIXED: case L_MSM_WINDOW: case L_MSM_NAF: {
         // pipelined lanes: the heavy kernel of one lane never runs beside the other lane's (only the light kernels
@@ -1378,7 +1482,33 @@ void SchnorrBuilder::prove_compact(const uint8_t* rng_seed_dev, uint8_t* challen
   // commitments R_j = sum blind[s] * P
   for (auto& cn : constraints_) {
     std::vector<afx_msm_term> terms;
-    for (auto& sp : cn.second) terms.push_back(term_for(blind[sp.first], 32, points_[sp.second], false, pre_ops));
+    for (auto& sp : cn.second) {
+      const PointVar& P = points_[sp.second];
+      // A segmenting pass (Assembler::segments): a base the prover knows as a sum of parts - a point an earlier stage of this pass
+      // computed from its inputs (t*U, C_x_0 = z*G_x_0 + U, ...) - is multiplied part by part, blind * P = sum (blind * coef_k) * base_k:
+      // the terms land on the pass's INPUT points, whose powers and tables the first stage made, and on generators.  Same group
+      // element, hence the same commitment bytes.
+      if (!P.is_const && !P.parts.empty() && pre_ops && as_.segments() > 1) {
+        for (const PointVar::Part& pt : P.parts) {
+          afx_msm_term t;
+          memset(&t, 0, sizeof t);
+          if (pt.coef) {
+            uint8_t* prod = as_.new_enc();
+            afx_scalarop_job o;
+            memset(&o, 0, sizeof o);
+            o.a = blind[sp.first]; o.a_stride = 32; o.b = pt.coef; o.b_stride = pt.coef_stride; o.out = prod;
+            pre_ops->push_back(o);
+            t.scalar = prod;
+          } else {
+            t.scalar = blind[sp.first];
+          }
+          t.scalar_stride = 32; t.var = pt.var; t.fixed_idx = pt.var ? -1 : pt.fixed; t.negate = pt.neg ? 1u : 0u;
+          terms.push_back(t);
+        }
+        continue;
+      }
+      terms.push_back(term_for(blind[sp.first], 32, P, false, pre_ops));
+    }
     afx_msm_job j;
     memset(&j, 0, sizeof j);
     order_terms(j, terms);

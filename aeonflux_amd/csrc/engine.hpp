@@ -199,7 +199,7 @@ namespace afx {
 
 // L_MSM_WINDOW keeps the slot the single k_msm kernel had (timing names: statements.cpp KIND_NAMES)
 enum LaunchKind { L_FILL_BAD, L_DECODE, L_SCCHECK, L_POINTOP, L_SCALAROP, L_MSM_WINDOW, L_HASH, L_FROM_UNIFORM, L_REDUCE_WIDE, L_COPY, L_FINISH,
-                  L_MSM_FIXED, L_MSM_NAF, L_MSM_TABLES, L_COMPRESS, L_POINTSUM, L_NEGENC, L_TABLE_AFFINE, L_KINDS };
+                  L_MSM_FIXED, L_MSM_NAF, L_MSM_TABLES, L_COMPRESS, L_POINTSUM, L_NEGENC, L_TABLE_AFFINE, L_POWERS, L_KINDS };
 // the kernels whose grid rows WALK a range of the launch's jobs (afx_walk_row) instead of taking one job each (afx_row)
 inline bool walks(LaunchKind k) { return k == L_COMPRESS || k == L_NEGENC || k == L_TABLE_AFFINE; }
 
@@ -317,7 +317,18 @@ class Assembler {
  private:
   uint8_t* ws_alloc(size_t bytes);
   void msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector<afx_compress_job>& cjobs);
-  void msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compress_job>& cjobs, bool no_naf, uint32_t var_per_part = 1);
+  void msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compress_job>& cjobs, bool no_naf, uint32_t var_per_part = 1, bool segments = false);
+ public:
+  uint32_t segments() const;                                         // 1: off
+ private:
+  // SEGMENTS (small prover passes under secret-independent addressing; engine.cpp Assembler::msm): a secret scalar on a per-item base P
+  // runs as `segments()` short chains, segment k over 2^(k * bits/segments) * P, instead of one chain over all its windows.  The
+  // points come from ONE k_powers chain per base, made the first time a stage multiplies by the base, and their two-entry tables
+  // are built once and kept for the pass: a later stage (the proof's commitments, on the same bases) waits for a quarter of a chain.
+  bool segment_bases(const std::vector<afx_msm_job>& jobs);          // makes the powers of the jobs' new bases; false: nothing to segment
+  std::map<const int32_t*, std::vector<int32_t*>> powers_;           // base -> its powers 1 .. segments() - 1
+  std::map<const int32_t*, uint32_t> kept_tables_;                   // narrow table slots that stay for the whole pass (segmenting passes: all of them)
+  bool segmenting_ = false;                                          // this pass keeps its narrow tables (set by the first segmented stage)
   void compress(const std::vector<afx_compress_job>& cjobs, uint32_t groups);
   template <class T>
   void add_jobs(LaunchKind k, const std::vector<T>& jobs);

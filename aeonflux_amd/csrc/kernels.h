@@ -29,6 +29,8 @@ hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, const af
 // out_enc = encoding of the negation of each job's decoded point
 hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count);
 hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count);
+// out[i] = 2^(step (i + 1)) * src: the segment bases of a small prover pass (plan.h afx_powers_job)
+hipError_t afxk_powers(hipStream_t s, const afx_powers_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count);
 hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, const afx_row* rows, const afx_pass* passes, uint32_t max_count);
 // the same programs with 32 lanes per (item, program): small passes, where one lane's serial permutations are what a call waits for
 hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, const afx_row* rows, const afx_pass* passes, uint32_t max_count);

@@ -355,7 +355,8 @@ __device__ __attribute__((aligned(16))) const uint32_t AFX_IDENTITY_NIELS[AFX_NA
   0, 0, 0, 0, 0, 0, 0, 0 };
 AFX_DEV void narrow_fetch(uint32_t (&buf)[AFX_SECVAR_STORED * AFX_NARROW_ENTRY_WORDS], uint64_t& digits, const msm_env& e, uint32_t t, int w) {
   // the digit's word(s) first: the loads come back in order, and the addition that consumes this fetch starts from the digit
-  const uint32_t o = AFX_SECVAR_BITS * (uint32_t)w, k = o >> 5, sh = o & 31u;
+  // (a segment's window w is digit w + win_off of the scalar: afx_msm_term.win_off, uniform)
+  const uint32_t o = AFX_SECVAR_BITS * ((uint32_t)w + e.term[t].win_off), k = o >> 5, sh = o & 31u;
   const uint32_t* dw = e.digit_ws + ((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + k) * e.count + e.item;
   digits = dw[0];
   if (sh + AFX_SECVAR_BITS > 32) digits |= (uint64_t)dw[e.count] << 32;   // uniform condition; k + 1 <= 8
@@ -374,7 +375,7 @@ AFX_DEV void narrow_fetch(uint32_t (&buf)[AFX_SECVAR_STORED * AFX_NARROW_ENTRY_W
 }
 // the entry the digit of window w names among the fetched ones (the identity for digit 0), and whether it is subtracted
 AFX_DEV void narrow_select(ge_niels& q, bool& neg, const msm_env& e, uint32_t t, int w, const uint32_t (&buf)[AFX_SECVAR_STORED * AFX_NARROW_ENTRY_WORDS], uint64_t digits) {
-  const uint32_t sh = (AFX_SECVAR_BITS * (uint32_t)w) & 31u;
+  const uint32_t sh = (AFX_SECVAR_BITS * ((uint32_t)w + e.term[t].win_off)) & 31u;
   const int d = (int)((uint32_t)(digits >> sh) & ((1u << AFX_SECVAR_BITS) - 1)) - (1 << (AFX_SECVAR_BITS - 1));
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
   neg = (d < 0) != (e.term[t].negate != 0);
@@ -392,10 +393,11 @@ AFX_DEV void narrow_select(ge_niels& q, bool& neg, const msm_env& e, uint32_t t,
 AFX_DEV ge_p3 msm_chain_narrow(const msm_env& e, ge_p3 acc, uint32_t nv) {
   uint32_t buf[AFX_SECVAR_STORED * AFX_NARROW_ENTRY_WORDS];
   uint64_t digits;
-  narrow_fetch(buf, digits, e, 0, AFX_SECVAR_WINDOWS - 1);
+  const int top = (int)e.job->wins - 1;   // (AFX_SECVAR_WINDOWS - 1, or a segment's share: uniform)
+  narrow_fetch(buf, digits, e, 0, top);
 #pragma unroll 1
-  for (int w = AFX_SECVAR_WINDOWS - 1; w >= 0; w--) {
-    if (w != AFX_SECVAR_WINDOWS - 1) {
+  for (int w = top; w >= 0; w--) {
+    if (w != top) {
       ge_p2 a2 = ge_p3_to_p2(acc);
 #pragma unroll 1
       for (int k = 0; k < AFX_SECVAR_BITS - 1; k++) a2 = ge_p1p1_to_p2_before_dbl(ge_p2_dbl(a2));
@@ -900,7 +902,7 @@ __device__ __forceinline__ void msm_quad_body(const afx_msm_djob* __restrict__ j
       chained = true;
       // everything addition (w, t) could need of the lane's two-entry table, and its digit word; requested an addition ahead
       auto fetch = [&](int w, uint32_t t, uint32_t& dword) {
-        const uint32_t o = AFX_SECVAR_BITS * (uint32_t)w;
+        const uint32_t o = AFX_SECVAR_BITS * ((uint32_t)w + e.term[t].win_off);
         dword = digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + (o >> 5)) * count + item];
         const int32_t* table = table_ws + (size_t)e.term[t].table_slot * count * AFX_VAR_TABLE_DWORDS + (size_t)item * 4;
         const size_t piece = (size_t)count * 4, entry = (size_t)count * AFX_TABLE_ENTRY_DWORDS;
@@ -918,10 +920,11 @@ __device__ __forceinline__ void msm_quad_body(const afx_msm_djob* __restrict__ j
       };
       static_assert(AFX_SECVAR_BITS == 2 && AFX_SECVAR_STORED == 2, "k_msm_quad's narrow chain reads the two stored entries of a 2-bit window");
       uint32_t nword = 0;
-      quad_narrow nxt = fetch(AFX_SECVAR_WINDOWS - 1, 0, nword);
+      const int top = (int)job->wins - 1;   // (a segment's share of the windows, or all of them)
+      quad_narrow nxt = fetch(top, 0, nword);
 #pragma unroll 1
-      for (int w = AFX_SECVAR_WINDOWS - 1; w >= 0; w--) {
-        if (w != AFX_SECVAR_WINDOWS - 1) {
+      for (int w = top; w >= 0; w--) {
+        if (w != top) {
 #pragma unroll 1
           for (int k = 0; k < AFX_SECVAR_BITS; k++) acc = quad_dbl(L, buf, role, lane, acc);
         }
@@ -931,7 +934,7 @@ __device__ __forceinline__ void msm_quad_body(const afx_msm_djob* __restrict__ j
           const uint32_t word = nword;
           const bool last = t + 1 == nv;
           if (!(last && w == 0)) nxt = fetch(last ? w - 1 : w, last ? 0 : t + 1, nword);
-          const int d = (int)((word >> ((AFX_SECVAR_BITS * (uint32_t)w) & 31u)) & 3u) - 2;
+          const int d = (int)((word >> ((AFX_SECVAR_BITS * ((uint32_t)w + e.term[t].win_off)) & 31u)) & 3u) - 2;
           const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
           const bool neg = (d < 0) != (e.term[t].negate != 0);
           // the 8 words this role multiplies by: of entry idx (the identity for 0); roles 0, 1: the half the sign names (role 0
@@ -1125,6 +1128,28 @@ k_pointsum_quad(const afx_pointsum_job* __restrict__ jobs, const afx_row* __rest
     ristretto_encode(w, acc);
     enc_store(job.out_enc, item, w);
     if (job.reject_identity && is_identity_encoding(w)) atomicOr(&bad[item], AFX_BAD_IDENTITY);
+  }
+}
+
+// k_powers: src * 2^step, * 2^(2 step), ... (plan.h afx_powers_job), four waves per item chain like k_msm_quad - these doublings are
+// what a small prover pass waits for once instead of in every stage (Assembler::msm_split cuts a secret scalar on a per-item base
+// into segments over these points).  Nothing here depends on a secret.
+__global__ void __launch_bounds__(256, 2)
+k_powers_quad(const afx_powers_job* __restrict__ jobs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  __shared__ quad_lds L;
+  const afx_powers_job job = *row_job(jobs, rows);
+  const afx_pass pass = passes[row_pass_index(rows)];   // block-uniform: scalar loads
+  const uint32_t count = pass.count;
+  if (blockIdx.x * 64u >= count) return;   // block-uniform
+  const uint32_t lane = threadIdx.x & 63u, role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t item = min(blockIdx.x * 64u + lane, count - 1);   // lanes past the end shadow the last item
+  ge_p3 acc = var_load(job.src, count, item);
+  int buf = 0;
+#pragma unroll 1
+  for (uint32_t i = 0; i < job.n_out; i++) {
+#pragma unroll 1
+    for (uint32_t k = 0; k < job.step; k++) acc = quad_dbl(L, buf, role, lane, acc);
+    if (role == 0) var_store(job.out[i], count, item, acc);
   }
 }
 
@@ -1665,6 +1690,10 @@ hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t n
     return hipGetLastError();
   }
   hipLaunchKernelGGL(k_pointsum, grid_for(max_count, njobs), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
+  return hipGetLastError();
+}
+hipError_t afxk_powers(hipStream_t s, const afx_powers_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  hipLaunchKernelGGL(k_powers_quad, dim3((max_count + 63) / 64, njobs), dim3(256), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {

@@ -156,6 +156,10 @@ typedef struct {
                               multiples loaded one per lane and the digit's taken through the lane exchange (ds_bpermute_b32) */
   uint32_t dbl;            /* the base holds HALF the point the statement means (its producer left its half for k_compress2x,
                               afx_msm_job.leave_half): the term's scalar counts twice (Assembler::msm sets it)           */
+  uint32_t win_off;        /* a SEGMENT of a secret scalar on a per-item base (Assembler::msm_split, small prover passes): the term's chain
+                              runs the job's `wins` windows and window w takes digit w + win_off of the recoded scalar; the base is the
+                              term's own point times 2^(AFX_SECVAR_BITS * win_off) (afx_powers_job made it).  0 otherwise.        */
+  uint32_t pad;
 } afx_msm_term;
 
 typedef struct {
@@ -186,6 +190,8 @@ typedef struct {
   uint32_t narrow;                      /* one of the variable terms has a secret scalar under secret-independent addressing: the job's
                                            variable terms run AFX_SECVAR_BITS-bit windows over tables of AFX_SECVAR_STORED entries
                                            (Assembler::msm sets it; only launches of the SEC kernel instances hold such jobs) */
+  uint32_t wins;                        /* narrow jobs: how many windows the chain runs - AFX_SECVAR_WINDOWS (0 means that), or a segment's
+                                           share when its terms are segments (afx_msm_term.win_off)                            */
 } afx_msm_job;
 
 /* The same job as the kernels read it (Assembler::msm_list writes this form into the plan's blob): the terms it HAS, in a side
@@ -198,7 +204,7 @@ typedef struct {
   int32_t term_off;                     /* the job's n_terms afx_msm_term entries lie at (const uint8_t*)job + term_off: an OFFSET, so that the
                                            kernels reach them from their own kernel argument (scalar loads the compiler can prove unclobbered;
                                            a loaded pointer made every term field a vector load and every branch on one an exec-mask branch) */
-  uint32_t pad0;
+  uint32_t wins;                        /* narrow jobs: windows of the chain (afx_msm_job.wins, never 0 here) */
   const int32_t* addend;
   uint32_t addend_negate;
   uint32_t reject_identity;
@@ -227,6 +233,16 @@ typedef struct {
   uint32_t table_slot;     /* slot in table_ws                                                      */
   uint32_t pad;
 } afx_table_job;
+
+/* k_powers: out[i][item] = 2^(step * (i + 1)) * src[item], i < n_out: the bases of a secret scalar's SEGMENTS on a per-item point
+ * (afx_msm_term.win_off) - `step` doublings in a row between one and the next, a chain nobody waits for twice: every later stage of
+ * the pass multiplies by short chains on these instead of a full-length one on src. */
+#define AFX_POWERS_MAX 7
+typedef struct {
+  const int32_t* src;            /* variable point (SoA) */
+  afx_var_t out[AFX_POWERS_MAX];
+  uint32_t step, n_out;
+} afx_powers_job;
 
 /* k_compress2x: out_enc[item] = encoding of 2 * var[item] (ristretto255) */
 typedef struct {

@@ -39,7 +39,7 @@ extern "C" void* afx_ctx_stream(const afx_ctx* ctx) { return ctx ? (void*)ctx->s
 
 // indexed by afx::LaunchKind.  "k_msm" (afx_ctx_get_timing) = the three chain kernels + the table kernel together
 static const char* const KIND_NAMES[] = { "k_fill_u32", "k_decode", "k_sccheck", "k_pointop", "k_scalarop", "k_msm_window", "k_hash",
-                                          "k_from_uniform", "k_reduce_wide", "copy", "k_finish", "k_msm_fixed", "k_msm_naf", "k_msm_tables", "k_compress2x", "k_pointsum", "k_negenc", "k_table_affine" };
+                                          "k_from_uniform", "k_reduce_wide", "copy", "k_finish", "k_msm_fixed", "k_msm_naf", "k_msm_tables", "k_compress2x", "k_pointsum", "k_negenc", "k_table_affine", "k_powers" };
 static_assert(sizeof KIND_NAMES / sizeof KIND_NAMES[0] == afx::L_KINDS, "one name per launch kind");
 static int drain_timing(afx_ctx* c) {
   for (auto& L : c->lane)

@@ -220,6 +220,7 @@ extern "C" int afx_issue_dev(afx_ctx* ctx, const afx_attributes_soa* requests, c
     iv.U = PointVar::Var(v_U, orow(o.U, 0));
     iv.V = PointVar::Var(nullptr, orow(o.V, 0));   // left-hand side only: the prover needs its encoding, not its coordinates
     iv.tU = PointVar::Var(v_tU, e_tU);
+    iv.tU.parts.push_back({ orow(o.t, 0), 32, false, v_U, -1 });   // tU = t * U (a segmenting pass multiplies by U instead: SchnorrBuilder::prove_compact)
     SchnorrBuilder p(as, "2019/1416 anonymous credential", "2019/1416 issuance proof");
     issuance_statement(p, c, iv);
     std::vector<afx_hash_program> rng_hash, chal_hash;
@@ -344,7 +345,10 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
     for (uint32_t j = 0; j < hs; j++) H_s[j] = p.allocate_scalar("m", sv_item(row(cr.values, sh.hidden_scalar_indices[j])));
     const int I = p.allocate_point("I", PointVar::Const(c->id_I()));
     const int C_x_1 = p.allocate_point("C_x_1", PointVar::Var(v_Cx1, orow(o.C_x_1, 0)));
-    const int C_x_0 = p.allocate_point("C_x_0", PointVar::Var(v_Cx0, orow(o.C_x_0, 0)));
+    PointVar pCx0 = PointVar::Var(v_Cx0, orow(o.C_x_0, 0));
+    pCx0.parts.push_back({ z, 32, false, nullptr, (int32_t)c->id_Gx0() });   // C_x_0 = z*G_x_0 + U (:171)
+    pCx0.parts.push_back({ nullptr, 0, false, v_U, -1 });
+    const int C_x_0 = p.allocate_point("C_x_0", pCx0);
     const int G_x_0 = p.allocate_point("G_x_0", PointVar::Const(c->id_Gx0()));
     const int G_x_1 = p.allocate_point("G_x_1", PointVar::Const(c->id_Gx1()));
     int C_y[AFX_MAX_ATTRIBUTES], G_y[AFX_MAX_ATTRIBUTES], G_m[AFX_MAX_ATTRIBUTES];
@@ -386,8 +390,8 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
     for (int d = 0; d < nD; d++) p.constrain(D[d], { { zv, G_y[D_pos[d]] }, { zv, neg_G_y_1 } });
     std::vector<afx_hash_program> rng_hash, chal_hash;
     std::vector<afx_msm_job> commit;
-    std::vector<afx_scalarop_job> resp;
-    p.prove_compact(r.rng_seed + off * 32, orow(o.challenge, 0), orow(o.responses, 0), 32 * count, rng_hash, commit, chal_hash, resp);
+    std::vector<afx_scalarop_job> resp, blind_products;   // (blinding * coefficient) of the bases a segmenting pass multiplies part by part
+    p.prove_compact(r.rng_seed + off * 32, orow(o.challenge, 0), orow(o.responses, 0), 32 * count, rng_hash, commit, chal_hash, resp, &blind_products);
 
     // proofs of encryption, one per hidden group element, in attribute order (:293-309 -> encryption.rs:58-142)
     for (uint32_t e = 0; e < nsp; e++) {
@@ -412,8 +416,10 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
       // knows term by term: E2 = a*E1 + M1 = (a*kk)*M2 + M1 and C_y_2' = a1*C_y_2 = (a1*z)*G_y_2 + a1*M2 - chains on decoded
       // inputs, beside the first stage's.  (Same group elements, hence the same encodings.)
       const bool flat = as.small();
+      uint8_t* a1z_of_flat = nullptr;
       if (flat) {
         uint8_t *akk = as.new_enc(), *a1z = as.new_enc();
+        a1z_of_flat = a1z;
         sc2.push_back(mk_scalarop(a, 32, kk, 32, nullptr, 0, false, akk));
         sc1.push_back(mk_scalarop(a1, 32, z, 32, nullptr, 0, false, a1z));
         msm1.push_back(mk_job({ mk_term(akk, 32, v_M2, -1, false) }, v_M1[i], v_E2, orow(q.E2, 0), false));
@@ -445,18 +451,28 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
       const int G_y_2 = ep.allocate_point("G_y_2", PointVar::Const(c->id_Gy(1)));
       const int G_y_3 = ep.allocate_point("G_y_3", PointVar::Const(c->id_Gy(2)));
       const int G_m_3 = ep.allocate_point("G_m_3", PointVar::Const(c->id_Gm(i)));
-      const int C_y_2 = ep.allocate_point("C_y_2", PointVar::Var(v_C2, orow(q.C_y_2, 0)));
+      PointVar pC2 = PointVar::Var(v_C2, orow(q.C_y_2, 0)), pC2p = PointVar::Var(v_C2p, orow(q.C_y_2p, 0)), pNegE1 = PointVar::NegOf(v_E1, e_D2);
+      if (flat) {
+        // what the prover knows these points to be, on the pass's inputs (SchnorrBuilder::prove_compact, segmenting passes):
+        // C_y_2 = z*G_y_2 + M2, C_y_2' = a1*C_y_2 = (a1*z)*G_y_2 + a1*M2, -E1 = -(a0 + a1*m3)*M2
+        pC2.parts.push_back({ z, 32, false, nullptr, (int32_t)c->id_Gy(1) });
+        pC2.parts.push_back({ nullptr, 0, false, v_M2, -1 });
+        pC2p.parts.push_back({ a1z_of_flat, 32, false, nullptr, (int32_t)c->id_Gy(1) });
+        pC2p.parts.push_back({ a1, 32, false, v_M2, -1 });
+        pNegE1.parts.push_back({ kk, 32, true, v_M2, -1 });
+      }
+      const int C_y_2 = ep.allocate_point("C_y_2", pC2);
       const int C_y_3 = ep.allocate_point("C_y_3", PointVar::Var(v_C3, orow(q.C_y_3, 0)));
-      const int C_y_2p = ep.allocate_point("C_y_2'", PointVar::Var(v_C2p, orow(q.C_y_2p, 0)));
+      const int C_y_2p = ep.allocate_point("C_y_2'", pC2p);
       const int C_y_1_minus_E2 = ep.allocate_point("C_y_1-E2", PointVar::Var(v_D1, e_D1));
       const int E1 = ep.allocate_point("E1", PointVar::Var(v_E1, orow(q.E1, 0)));
-      const int minus_E1 = ep.allocate_point("-E1", PointVar::NegOf(v_E1, e_D2));   // b_a*(-E1) runs as -(b_a*E1) on E1's window table
+      const int minus_E1 = ep.allocate_point("-E1", pNegE1);   // b_a*(-E1) runs as -(b_a*E1) on E1's window table
       ep.constrain(pk, { { sa, G_a }, { sa0, G_a_0 }, { sa1, G_a_1 } });
       ep.constrain(C_y_1_minus_E2, { { sz, G_y_1 }, { sa, minus_E1 } });
       ep.constrain(C_y_2p, { { sa1, C_y_2 } });
       ep.constrain(E1, { { sa0, C_y_2 }, { sm3, C_y_2p }, { sz1, G_y_2 } });
       ep.constrain(C_y_3, { { sz, G_y_3 }, { sm3, G_m_3 } });
-      ep.prove_compact(r.enc_seeds + (e * count + off) * 32, orow(q.challenge, 0), orow(q.responses, 0), 32 * count, rng_hash, commit, chal_hash, resp);
+      ep.prove_compact(r.enc_seeds + (e * count + off) * 32, orow(q.challenge, 0), orow(q.responses, 0), 32 * count, rng_hash, commit, chal_hash, resp, &blind_products);
     }
     as.sccheck(sccheck);
     as.decode(decode);
@@ -466,6 +482,7 @@ extern "C" int afx_show_dev(afx_ctx* ctx, const afx_credentials_soa* creds, cons
     as.msm(msm1b);
     as.pointop(pops);
     as.hash(rng_hash);
+    as.scalarop(blind_products);
     as.msm(commit);
     as.hash(chal_hash);
     as.scalarop(resp);

@@ -155,6 +155,12 @@ hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_ms
     for (uint32_t t = 0; t < j.n_var; t++) secret_var |= term[t].secret != 0;
     if ((j.narrow != 0) != (secret_var != 0) || (j.narrow && kind != 1)) return hipErrorInvalidValue;   // narrow windows exactly where a variable base carries a secret
     for (uint32_t t = 0; t < j.n_terms; t++) { CHECK_PTR(term[t].scalar); CHECK_PTR(term[t].var); }
+    // a chain's windows: all of them, or a segment's share with every variable term a segment inside the recoded scalar
+    if (j.narrow && (j.wins == 0 || j.wins > AFX_SECVAR_WINDOWS)) return hipErrorInvalidValue;
+    for (uint32_t t = 0; t < j.n_terms; t++) {
+      if (term[t].win_off && !(t < j.n_var && j.narrow && term[t].secret)) return hipErrorInvalidValue;
+      if (t < j.n_var && j.narrow && term[t].win_off + j.wins > AFX_SECVAR_WINDOWS) return hipErrorInvalidValue;
+    }
     CHECK_PTR(j.addend); CHECK_PTR(j.out_enc); CHECK_PTR(j.out_var); CHECK_PTR(j.half_var);
     if (j.n_uni) {   // the NAF schedule lives in the plan blob: read it to its terminator
       for (const uint32_t* e2 = j.naf_sched; ; e2++) { sink += *e2; if (*e2 == 0xffffffffu) break; }
@@ -208,6 +214,16 @@ hipError_t afxk_pointsum(hipStream_t, const afx_pointsum_job* jobs, uint32_t n, 
     if (j.n_parts < 2 || (!j.out_var && !j.half_var && !j.out_enc)) return hipErrorInvalidValue;
     for (uint32_t k = 0; k < j.n_parts; k++) CHECK_PTR(j.parts[k]);
     CHECK_PTR(j.addend); CHECK_PTR(j.out_var); CHECK_PTR(j.half_var); CHECK_PTR(j.out_enc);
+  }
+  return hipSuccess;
+}
+hipError_t afxk_powers(hipStream_t, const afx_powers_job* jobs, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  for (uint32_t i = 0; i < n; i++) {
+    hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e;
+    const afx_powers_job& j = job_of(jobs, rows, i);
+    if (j.n_out == 0 || j.n_out > AFX_POWERS_MAX || j.step == 0 || j.step * (j.n_out + 1) > 2 * AFX_SECVAR_WINDOWS || !j.src) return hipErrorInvalidValue;
+    CHECK_PTR(j.src);
+    for (uint32_t k = 0; k < j.n_out; k++) { if (!j.out[k]) return hipErrorInvalidValue; CHECK_PTR(j.out[k]); }
   }
   return hipSuccess;
 }
