@@ -436,17 +436,18 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   compress(cjobs, ctx->walk_rows(count, cjobs.size(), small));
 }
 
-// AFX_SEGMENTS=1|2|4|8 (measurement aid; default 4): into how many segments a small prover pass cuts a secret scalar on a per-item base
+// AFX_SEGMENTS=1|2|4|8 (measurement aid; default 8): into how many segments a small prover pass cuts a secret scalar on a per-item base
 uint32_t Assembler::segments() const {
   static const uint32_t env = [] {
     const char* e = getenv("AFX_SEGMENTS");
-    const int v = e ? atoi(e) : 4;
-    return (v == 1 || v == 2 || v == 4 || v == 8) ? (uint32_t)v : 4u;
+    const int v = e ? atoi(e) : 8;
+    return (v == 1 || v == 2 || v == 4 || v == 8) ? (uint32_t)v : 8u;
   }();
+  static const uint32_t wide = [] { const char* e = getenv("AFX_SEGMENT_WAVES"); return e ? (uint32_t)atoi(e) : 32u; }();   // (measurement aid; measured: up to 2048 items the segments pay)
   static_assert(AFX_SECVAR_WINDOWS % 8 == 0 && AFX_POWERS_MAX >= 7, "a scalar's windows divide into up to eight segments");
   // the passes whose chains run four waves each on a device they leave idle (kernels.hip afxk_msm): up to 256 items
-  if (env <= 1 || !small() || !secret_scalars || !ctx->secure_plan(secret_scalars) || ctx->row_waves(count) > 4) return 1;
-  return env;
+  if (env <= 1 || !small() || !secret_scalars || !ctx->secure_plan(secret_scalars) || ctx->row_waves(count) > wide) return 1;
+  return ctx->row_waves(count) > 4 ? std::min(env, 4u) : env;
 }
 bool Assembler::segment_bases(const std::vector<afx_msm_job>& jobs) {
   const uint32_t S = segments();
@@ -518,7 +519,7 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
       // (the second commitment of an issuance proof has n + 3 of them: one lane with 380 additions was the longest chain of a
       // small issue call)
       // (a segmenting pass, whose variable-base chains are a quarter as long, takes them two to a part)
-      const uint32_t FIXED_PER_PART = S > 1 ? 2 : 6;
+      const uint32_t FIXED_PER_PART = S >= 8 ? 1 : S > 1 ? 2 : 6;
       uint32_t parts = (j.n_var + var_per_part - 1) / var_per_part + (j.n_terms - j.n_var + FIXED_PER_PART - 1) / FIXED_PER_PART;
       for (uint32_t t = 0; t < j.n_var; t++) if (segmented(j.term[t])) parts += S - 1;
       const bool halved = j.out_enc && !j.addend && (!j.out_var || j.leave_half);   // only ever encoded, or leaving its half: halved scalars, k_compress2x (msm_list)
@@ -885,7 +886,20 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
   max_table_slots = std::max<size_t>(max_table_slots, tslot);
 }
 void Assembler::from_uniform(const uint8_t* wide, uint8_t* out_enc, int32_t* out_var) {
-  const afx_uniform_job j = { wide, out_enc, out_var };
+  // A small pass on an idle device: the two Elligator maps (a square-root chain each) run side by side in two grid rows, k_pointop
+  // adds them, and the encoding (a third chain) joins the stage's other encodings in k_compress2x (Assembler::pointop): the call
+  // waits for one chain here instead of three (a 1-item issue: 184 -> 67 us).  Same point, same bytes.
+  if (small() && (uint64_t)ctx->row_waves(count) * 2 <= 2ull * 4 * ctx->n_cu) {
+    int32_t *h1 = new_var(), *h2 = new_var();
+    const afx_uniform_job a = { wide, nullptr, h1, 1, 0 }, b = { wide, nullptr, h2, 2, 0 };
+    add_jobs(L_FROM_UNIFORM, std::vector<afx_uniform_job>{ a, b });
+    afx_pointop_job s;
+    memset(&s, 0, sizeof s);
+    s.a = h1; s.b = h2; s.sa = 1; s.sb = 1; s.out = out_var; s.out_enc = out_enc;
+    pointop(std::vector<afx_pointop_job>(1, s));
+    return;
+  }
+  const afx_uniform_job j = { wide, out_enc, out_var, 0, 0 };
   add_jobs(L_FROM_UNIFORM, std::vector<afx_uniform_job>(1, j));
 }
 void Assembler::reduce_wide(const uint8_t* wide, uint8_t* out) {
