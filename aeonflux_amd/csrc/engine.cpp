@@ -584,6 +584,8 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
     }
     msm_list(std::move(subs), no_naf, cjobs);
     add_jobs(L_POINTSUM, sums);
+    if (!sums.empty())   // (Launch::odd of a sum: some job has sixteen parts or more - kernels.hip afxk_pointsum)
+      for (const afx_pointsum_job& sj : sums) if (sj.n_parts >= 16) launches.back().odd = 1;
   }
 }
 
@@ -1167,6 +1169,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
         const Launch& c = plans[i]->launches[head[i]];
         const bool same = c.kind == h.kind && (h.kind != L_MSM_TABLES || c.odd == h.odd) && (h.kind != L_COPY || i == lead);
         if (!same) continue;
+        if (h.kind == L_POINTSUM && c.odd) mg.odd = 1;   // (a hint: some job of the merged launch has many parts)
         mg.parts.push_back({ (uint32_t)i, (uint32_t)head[i] });
         head[i]++;
       }
@@ -1254,7 +1257,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
       case L_COMPRESS: AFX_HIP(afxk_compress2x(s, (const afx_compress_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
       case L_NEGENC: AFX_HIP(afxk_negenc(s, (const afx_negenc_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
       case L_TABLE_AFFINE: AFX_HIP(afxk_table_affine(s, (const afx_table_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
-      case L_POINTSUM: AFX_HIP(afxk_pointsum(s, (const afx_pointsum_job*)jobs, nrows, rw, passes, max_count)); break;
+      case L_POINTSUM: AFX_HIP(afxk_pointsum(s, (const afx_pointsum_job*)jobs, nrows, rw, passes, max_count, odd)); break;
       case L_POWERS: AFX_HIP(afxk_powers(s, (const afx_powers_job*)jobs, nrows, rw, passes, max_count)); break;
       case L_MSM_TABLES: AFX_HIP(afxk_msm_tables(s, odd, (const afx_table_job*)jobs, nrows, rw, passes, max_count)); break;
       case L_MSM_FIXED: case L_MSM_WINDOW: case L_MSM_NAF: {

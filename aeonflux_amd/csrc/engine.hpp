@@ -213,7 +213,8 @@ struct Launch {
   const uint8_t* in = nullptr;
   uint8_t* out = nullptr;
   size_t bytes = 0;
-  int odd = 0;              // L_MSM_TABLES: kind of table (plan.h afx_table_job): 0 multiples 1..8, 1 odd multiples (NAF terms), 2 narrow
+  int odd = 0;              // L_MSM_TABLES: kind of table (plan.h afx_table_job): 0 multiples 1..8, 1 odd multiples (NAF terms), 2 narrow;
+                            // L_POINTSUM: 1 = some job sums sixteen parts or more (kernels.hip afxk_pointsum)
   int encodes = 1;          // L_MSM_*: some job of the launch encodes its result inside the kernel (kernels.hip k_msm<KIND, ENC, SEC>)
   int secret = 0;           // L_MSM_*: some term of the launch has a secret scalar under secret-independent addressing
 };

@@ -28,7 +28,8 @@ hipError_t afxk_table_affine(hipStream_t s, const afx_table_job* jobs, const afx
 hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count);
 // out_enc = encoding of the negation of each job's decoded point
 hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count);
-hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count);
+// many_parts: some job of the launch sums sixteen parts or more (Launch::odd): few items then take a lane per part (k_pointsum_tree)
+hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count, int many_parts);
 // out[i] = 2^(step (i + 1)) * src: the segment bases of a small prover pass (plan.h afx_powers_job)
 hipError_t afxk_powers(hipStream_t s, const afx_powers_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count);
 hipError_t afxk_hash(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, const afx_row* rows, const afx_pass* passes, uint32_t max_count);

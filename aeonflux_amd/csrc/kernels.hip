@@ -1131,6 +1131,55 @@ k_pointsum_quad(const afx_pointsum_job* __restrict__ jobs, const afx_row* __rest
   }
 }
 
+// k_pointsum for a job of MANY parts in a pass of few items (a segmenting pass: eight segments per base and a chain per generator
+// make 80-odd parts of an issuance's commitment): a block per (job, item), a lane per part, and a tree through LDS - seven
+// additions deep for up to 128 parts where each role of k_pointsum_quad adds twenty in a row.  Lane 0 finishes as k_pointsum does.
+__global__ void __launch_bounds__(256)
+k_pointsum_tree(const afx_pointsum_job* __restrict__ jobs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  __shared__ int32_t S[4 * AFX_FE_LIMBS][128];
+  const afx_pointsum_job job = *row_job(jobs, rows);
+  const afx_pass pass = passes[row_pass_index(rows)];   // block-uniform: scalar loads
+  const uint32_t count = pass.count, item = blockIdx.x;
+  uint32_t* __restrict__ bad = pass.bad;
+  if (item >= count) return;   // block-uniform
+  const uint32_t tid = threadIdx.x, n = min(job.n_parts, 256u);
+  ge_p3 acc = ge_identity();
+  if (tid < job.n_parts) acc = var_load(job.parts[tid], count, item);
+#pragma unroll 1
+  for (uint32_t k = tid + 256u; k < job.n_parts; k += 256u) acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_p3_to_cached(var_load(job.parts[k], count, item)), false));
+#pragma unroll 1
+  for (uint32_t stride = 128; stride >= 1; stride >>= 1) {
+    if (stride >= n) continue;   // (uniform) nothing up there
+    if (tid >= stride && tid < 2 * stride && tid < n) {
+#pragma unroll
+      for (int l = 0; l < AFX_FE_LIMBS; l++) {
+        S[l][tid - stride] = acc.X.v[l]; S[AFX_FE_LIMBS + l][tid - stride] = acc.Y.v[l];
+        S[2 * AFX_FE_LIMBS + l][tid - stride] = acc.Z.v[l]; S[3 * AFX_FE_LIMBS + l][tid - stride] = acc.T.v[l];
+      }
+    }
+    __syncthreads();
+    if (tid < stride && tid + stride < n) {
+      ge_p3 o;
+#pragma unroll
+      for (int l = 0; l < AFX_FE_LIMBS; l++) {
+        o.X.v[l] = S[l][tid]; o.Y.v[l] = S[AFX_FE_LIMBS + l][tid]; o.Z.v[l] = S[2 * AFX_FE_LIMBS + l][tid]; o.T.v[l] = S[3 * AFX_FE_LIMBS + l][tid];
+      }
+      acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_p3_to_cached(o), false));
+    }
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  if (job.addend) acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_p3_to_cached(var_load(job.addend, count, item)), job.addend_negate != 0));
+  if (job.out_var) var_store(job.out_var, count, item, acc);
+  if (job.half_var) { var_store(job.half_var, count, item, acc); return; }   // encoded by k_compress2x
+  if (job.out_enc) {
+    uint32_t w[8];
+    ristretto_encode(w, acc);
+    enc_store(job.out_enc, item, w);
+    if (job.reject_identity && is_identity_encoding(w)) atomicOr(&bad[item], AFX_BAD_IDENTITY);
+  }
+}
+
 // k_powers: src * 2^step, * 2^(2 step), ... (plan.h afx_powers_job), four waves per item chain like k_msm_quad - these doublings are
 // what a small prover pass waits for once instead of in every stage (Assembler::msm_split cuts a secret scalar on a per-item base
 // into segments over these points).  Nothing here depends on a secret.
@@ -1686,9 +1735,15 @@ hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, const afx_walk
   hipLaunchKernelGGL(k_negenc, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
-hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count, int many_parts) {
   // the idle-device form, under the same rule as k_msm_quad (and the same switch)
   static const bool quad_on = !(getenv("AFX_QUAD_CHAINS") && getenv("AFX_QUAD_CHAINS")[0] == '0');
+  // jobs of many parts over few items: a lane per part (AFX_POINTSUM_TREE=0 switches it off: measurement aid, same bytes)
+  static const bool tree_on = !(getenv("AFX_POINTSUM_TREE") && getenv("AFX_POINTSUM_TREE")[0] == '0');
+  if (quad_on && tree_on && many_parts && max_count && (uint64_t)max_count * njobs <= 1024) {
+    hipLaunchKernelGGL(k_pointsum_tree, dim3(max_count, njobs), dim3(256), 0, s, jobs, rows, passes);
+    return hipGetLastError();
+  }
   if (quad_on && max_count && (uint64_t)((max_count + 63) / 64) * njobs <= 512) {
     hipLaunchKernelGGL(k_pointsum_quad, dim3((max_count + 63) / 64, njobs), dim3(256), 0, s, jobs, rows, passes);
     return hipGetLastError();

@@ -207,7 +207,7 @@ hipError_t afxk_negenc(hipStream_t, const afx_negenc_job* j, const afx_walk_row*
 hipError_t afxk_compress2x(hipStream_t, const afx_compress_job* j, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
   return walk_rows((const uint8_t*)j, sizeof(afx_compress_job), rows, nrows, passes, max_count, 0);
 }
-hipError_t afxk_pointsum(hipStream_t, const afx_pointsum_job* jobs, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+hipError_t afxk_pointsum(hipStream_t, const afx_pointsum_job* jobs, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count, int) {
   for (uint32_t i = 0; i < n; i++) {
     hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e;
     const afx_pointsum_job& j = job_of(jobs, rows, i);
