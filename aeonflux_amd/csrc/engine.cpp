@@ -378,7 +378,7 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
     bool key_job = false;
     for (uint32_t t = 0; t < j.n_terms; t++) key_job |= is_key_scalar(j.term[t]);
     for (uint32_t t = 0; t < j.n_terms; t++) {
-      j.term[t].secret = (ctx->secure_plan(secret_scalars) && (secret_scalars || key_job) && j.term[t].scalar != ctx->const_one()) ? 1u : 0u;
+      j.term[t].secret = (secure() && (secret_scalars || key_job) && j.term[t].scalar != ctx->const_one()) ? 1u : 0u;
       stats.secret_terms += j.term[t].secret;
     }
   }
@@ -437,6 +437,10 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
 }
 
 // AFX_SEGMENTS=1|2|4|8 (measurement aid; default 8): into how many segments a small prover pass cuts a secret scalar on a per-item base
+// Does this pass keep secret scalars out of its addresses?  What the context's mode says (afx_ctx_set_secret_independent_addressing) -
+// and, whatever it says, a PROVER pass small enough for the segmented chains: there the secret-independent plan is also the faster
+// one (16-window chains over kept two-entry tables against 64 windows of four doublings), so mode 0 has nothing to offer it.
+bool Assembler::secure() const { return ctx->secure_plan(secret_scalars) || (secret_scalars && segments() > 1); }
 uint32_t Assembler::segments() const {
   static const uint32_t env = [] {
     const char* e = getenv("AFX_SEGMENTS");
@@ -446,7 +450,7 @@ uint32_t Assembler::segments() const {
   static const uint32_t wide = [] { const char* e = getenv("AFX_SEGMENT_WAVES"); return e ? (uint32_t)atoi(e) : 32u; }();   // (measurement aid; measured: up to 2048 items the segments pay)
   static_assert(AFX_SECVAR_WINDOWS % 8 == 0 && AFX_POWERS_MAX >= 7, "a scalar's windows divide into up to eight segments");
   // the passes whose chains run four waves each on a device they leave idle (kernels.hip afxk_msm): up to 256 items
-  if (env <= 1 || !small() || !secret_scalars || !ctx->secure_plan(secret_scalars) || ctx->row_waves(count) > wide) return 1;
+  if (env <= 1 || !small() || !secret_scalars || ctx->row_waves(count) > wide) return 1;
   return ctx->row_waves(count) > 4 ? std::min(env, 4u) : env;
 }
 bool Assembler::segment_bases(const std::vector<afx_msm_job>& jobs) {
@@ -603,7 +607,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     return c;
   };
   const size_t n = jobs.size();
-  const bool sec_mode = ctx->secure_plan(secret_scalars);   // terms were marked by Assembler::msm, before any splitting
+  const bool sec_mode = secure();   // terms were marked by Assembler::msm, before any splitting
   for (size_t i = 0; i < n; i++)
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
   // Jobs whose result is only ever encoded (no consumer of the point itself, no addend) run on halved scalars; k_compress2x

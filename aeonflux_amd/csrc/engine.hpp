@@ -321,6 +321,7 @@ class Assembler {
   void msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compress_job>& cjobs, bool no_naf, uint32_t var_per_part = 1, bool segments = false);
  public:
   uint32_t segments() const;                                         // 1: off
+  bool secure() const;                                               // this pass runs the secret-independent plan
  private:
   // SEGMENTS (small prover passes under secret-independent addressing; engine.cpp Assembler::msm): a secret scalar on a per-item base P
   // runs as `segments()` short chains, segment k over 2^(k * bits/segments) * P, instead of one chain over all its windows.  The

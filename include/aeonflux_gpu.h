@@ -168,7 +168,8 @@ int afx_ctx_set_fixed_key_schedule(afx_ctx* ctx, int enable);
  *     key's (which then also run the fixed schedule, whatever afx_ctx_set_fixed_key_schedule says) and the per-item products
  *     y_i * m_i of the key with revealed scalar attributes, whose digits would give the key away just the same.
  *   AFX_SECRETS_NOWHERE (0): the fastest tables everywhere (rounds 1-3 of this engine; a device of the engine's own, or inputs
- *     that are no secrets: synthetic benchmark data).
+ *     that are no secrets: synthetic benchmark data).  Prover-side calls of up to 2048 items run the secret-independent plan in
+ *     this mode too: at those sizes it is the faster one (its chains run in segments over the bases' powers).
  * Where the mode applies no load's address is made from a digit of a secret.  A secret term on a per-item base runs 2-bit signed
  * windows: every addition reads both stored (affine) entries of its lane's table and keeps the digit's with selects - 128 additions
  * per term instead of 64.  A secret term on a generator runs 6-bit signed windows over positional tables (155 KB per generator,

@@ -159,10 +159,18 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     assert afx.lib().afx_encrypt(ctx.h, C.byref(kpsoa), e[0].ctypes.data, e[1].ctypes.data, e[2].ctypes.data, 3, e[3].ctypes.data, e[4].ctypes.data, stx.ctypes.data) == 0
     assert ctx.plan_stats()["fixed_additions"] == 0   # E2 = a*E1 + M1: one variable base
     batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
+    sec_small = ctx.plan_stats()
+    ctx.set_small_batch_items(0)
+    batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
     sec_fixed = ctx.plan_stats()["fixed_additions"]
     ctx.set_secret_independent_addressing(False)
     batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
-    assert sec_fixed > 2 * ctx.plan_stats()["fixed_additions"] > 0   # 64 additions per secret fixed-base term instead of 20
+    assert sec_fixed > 2 * ctx.plan_stats()["fixed_additions"] > 0   # 43 additions per secret fixed-base term instead of 20
+    assert ctx.plan_stats()["secret_terms"] == 0
+    # ... but a SMALL prover pass takes the secret-independent plan in every mode: its segmented chains are the faster ones
+    ctx.set_small_batch_items(2048)
+    batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
+    assert ctx.plan_stats() == sec_small and sec_small["secret_terms"] > 3 * n
     mhz = C.c_double(-1)
     assert afx.lib().afx_ctx_get_core_clock_mhz(ctx.h, C.byref(mhz)) == 0 and mhz.value >= 0
     # a range of a batch, and the same batch over a two-member group (two fake devices)
