@@ -450,6 +450,9 @@ uint32_t Assembler::segments() const {
   static const uint32_t wide = [] { const char* e = getenv("AFX_SEGMENT_WAVES"); return e ? (uint32_t)atoi(e) : 32u; }();   // (measurement aid; measured: up to 2048 items the segments pay)
   static_assert(AFX_SECVAR_WINDOWS % 8 == 0 && AFX_POWERS_MAX >= 7, "a scalar's windows divide into up to eight segments");
   // the passes whose chains run four waves each on a device they leave idle (kernels.hip afxk_msm): up to 256 items
+  // Prover passes only.  A verifier's pass is ONE stage of public scalars on the presentation's own points: its powers (224 doublings)
+  // cost what the whole chain's 252 do, and eight times the chains to sum cost more than the 8-window chains save - measured with
+  // the same machinery (4-bit windows take win_off / wins like the 2-bit ones): 1 presentation 0.72 -> 0.73 ms, 256: 0.77 -> 0.90.
   if (env <= 1 || !small() || !secret_scalars || ctx->row_waves(count) > wide) return 1;
   return ctx->row_waves(count) > 4 ? std::min(env, 4u) : env;
 }
@@ -464,7 +467,7 @@ bool Assembler::segment_bases(const std::vector<afx_msm_job>& jobs) {
   for (const afx_msm_job& j : jobs)
     for (uint32_t t = 0; t < j.n_var; t++) {
       const afx_msm_term& tm = j.term[t];
-      if (!tm.secret || produced.count(tm.var)) continue;
+      if (produced.count(tm.var)) continue;
       any = true;
       if (powers_.count(tm.var)) continue;
       afx_powers_job q;
@@ -480,7 +483,7 @@ bool Assembler::segment_bases(const std::vector<afx_msm_job>& jobs) {
       stats.doublings += d; stats.field_sq += 4 * d; stats.field_mul += 4 * d;
     }
   if (!pj.empty()) add_jobs(L_POWERS, pj);
-  if (any) segmenting_ = true;
+  if (any && secret_scalars) segmenting_ = true;   // (a prover's pass has later stages on the same bases: its narrow tables stay)
   return any;
 }
 
@@ -498,8 +501,8 @@ void Assembler::compress_also(const int32_t* var, uint8_t* out_enc, bool negate,
 // schedules - a lone key term costs 64 additions instead of ~43, but shares the windowed launch with every other chain of its stage.
 void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compress_job>& cjobs, bool no_naf, uint32_t var_per_part, bool segs) {
   if (var_per_part == 0) var_per_part = 1;
-  const uint32_t S = (segs && var_per_part == 1) ? segments() : 1, W = AFX_SECVAR_WINDOWS / S;
-  auto segmented = [&](const afx_msm_term& t) { return S > 1 && t.secret && t.fixed_idx < 0 && powers_.count(t.var) != 0; };
+  const uint32_t S = (segs && var_per_part == 1) ? segments() : 1;
+  auto segmented = [&](const afx_msm_term& t) { return S > 1 && t.fixed_idx < 0 && powers_.count(t.var) != 0; };
   const size_t n = jobs.size();
   for (size_t i = 0; i < n; i++)
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
@@ -555,6 +558,8 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
         const uint32_t k = std::min(var_per_part, j.n_var - t);
         if (!segmented(j.term[t])) { sub_of(t, k, k); continue; }
         // segment g: windows [g W, (g + 1) W) of the recoded scalar on 2^(bits * g W) times the base: a chain of W windows
+        // (2-bit windows for a secret scalar, 4-bit ones otherwise: 256 / S bits either way, which is what the powers step by)
+        const uint32_t W = (j.term[t].secret ? AFX_SECVAR_WINDOWS : 64u) / S;
         const std::vector<int32_t*>& pw = powers_[j.term[t].var];
         for (uint32_t g = 0; g < S; g++) {
           sub_of(t, 1, 1);
@@ -599,9 +604,9 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
   // encoding; 64 additions + the 9-entry table per variable base; AFX_POS_WINDOWS additions per fixed base
   auto cost = [](const afx_msm_job& j) {
     // a narrow job (a secret scalar on a variable base): AFX_SECVAR_WINDOWS additions per variable term, tables of AFX_SECVAR_STORED
-    const uint32_t nwins = j.wins ? j.wins : AFX_SECVAR_WINDOWS;
-    const uint32_t per_var = j.narrow ? (nwins * 13u) / 2u + AFX_SECVAR_STORED * 7u : 470u;
-    uint32_t c = (j.n_var ? 1320u : 160u) + j.n_uni * (330u + 45u /* more conversions to p3 */) + (j.n_var - j.n_uni) * per_var;
+    const uint32_t nwins = j.wins ? j.wins : j.narrow ? AFX_SECVAR_WINDOWS : 64u;
+    const uint32_t per_var = j.narrow ? (nwins * 13u) / 2u + AFX_SECVAR_STORED * 7u : (470u * nwins) / 64u;
+    uint32_t c = (j.n_var ? (1320u * nwins) / (j.narrow ? AFX_SECVAR_WINDOWS : 64u) : 160u) + j.n_uni * (330u + 45u /* more conversions to p3 */) + (j.n_var - j.n_uni) * per_var;
     for (uint32_t t = j.n_var; t < j.n_terms; t++) c += ((j.term[t].secret ? AFX_SEC_WINDOWS * 200u : AFX_POS_WINDOWS * 175u)) / 32u;
     for (uint32_t t = 0; t < j.n_var; t++) c += j.term[t].secret ? (nwins * AFX_SECVAR_STORED * 15u) / 64u : 0u;   // the table scans
     return c;
@@ -655,11 +660,11 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     jobs[ji].narrow = 0;
     for (uint32_t t = 0; t < jobs[ji].n_var; t++) if (jobs[ji].term[t].secret) jobs[ji].narrow = 1;
     if (jobs[ji].narrow && jobs[ji].n_uni) throw std::logic_error("a NAF schedule in a job with secret scalars");
-    if (jobs[ji].wins && !jobs[ji].narrow) throw std::logic_error("a segment outside a job with secret scalars");
-    if (jobs[ji].narrow && !jobs[ji].wins) jobs[ji].wins = AFX_SECVAR_WINDOWS;
+    if (!jobs[ji].wins) jobs[ji].wins = jobs[ji].narrow ? AFX_SECVAR_WINDOWS : 64;
+    if (jobs[ji].wins > (jobs[ji].narrow ? AFX_SECVAR_WINDOWS : 64u)) throw std::logic_error("a chain longer than its scalar");
     const afx_msm_job& j = jobs[ji];
     const uint64_t nv = j.n_var;
-    const uint64_t wins = j.narrow ? j.wins : 64, wbits = j.narrow ? AFX_SECVAR_BITS : 4, stored = j.narrow ? AFX_SECVAR_STORED : AFX_TABLE_STORED;
+    const uint64_t wins = j.wins, wbits = j.narrow ? AFX_SECVAR_BITS : 4, stored = j.narrow ? AFX_SECVAR_STORED : AFX_TABLE_STORED;
     uint64_t nfa = 0;   // additions of the fixed-base terms: AFX_POS_WINDOWS each, AFX_SEC_WINDOWS for a secret scalar
     for (uint32_t t = j.n_var; t < j.n_terms; t++) nfa += j.term[t].secret ? AFX_SEC_WINDOWS : AFX_POS_WINDOWS;
     stats.msm_jobs++;
@@ -881,7 +886,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
       if (j.n_terms) term_tables_.push_back({ terms_at[i], j.n_terms });
       d.addend = j.addend; d.addend_negate = j.addend_negate; d.reject_identity = j.reject_identity;
       d.out_enc = j.out_enc; d.out_var = j.out_var; d.half_var = j.half_var;
-      d.digit_slot = j.digit_slot; d.narrow = j.narrow; d.leave_half = j.leave_half; d.wins = j.narrow ? j.wins : 0;
+      d.digit_slot = j.digit_slot; d.narrow = j.narrow; d.leave_half = j.leave_half; d.wins = j.wins;
     }
     l.jobs_off = blob_alloc(sizeof(afx_msm_djob) * dj.size(), 16);
     for (size_t i = 0; i < dj.size(); i++) dj[i].term_off = (int32_t)((int64_t)terms_at[i] - (int64_t)(l.jobs_off + sizeof(afx_msm_djob) * i));   // from the job itself
@@ -1539,6 +1544,12 @@ void SchnorrBuilder::prove_compact(const uint8_t* rng_seed_dev, uint8_t* challen
     sim_.append_message_hole32("val", field_of(j.out_enc));
   }
   sim_.challenge64("chal", AFX_SQ_SCALAR_OUT, 0);
+  // k_hash_coop requests a record's field bytes while the record before it permutes (kernels.hip): nothing a program squeezes out may
+  // be a field of the same table
+  for (const uint8_t* f : fields_) {
+    if (f == challenge_out) throw std::logic_error("a transcript reads its own challenge");
+    for (const uint8_t* b : blind) if (f == b) throw std::logic_error("a transcript reads a blinding it squeezed");
+  }
   // programs are made after all field_of() calls so both share the final field table
   afx_hash_program pr = make_program(rng);
   pr.outs = as_.put_ptrs(blind.data(), blind.size());

@@ -328,8 +328,9 @@ struct msm_env {
 // `next` (wave-uniform): what consumes the result, GE_FOR_* (ge.cuh)
 AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w, int next) {
   const int32_t* table = e.table_ws + ((size_t)e.term[t].table_slot * e.count + e.item) * AFX_VAR_TABLE_DWORDS;
-  const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + ((uint32_t)w >> 3)) * e.count + e.item];
-  const int d = (int)((word >> (((uint32_t)w & 7) * 4)) & 15u) - 8;
+  const uint32_t wd = (uint32_t)w + e.term[t].win_off;   // (a segment's window w is digit w + win_off of the scalar; uniform)
+  const uint32_t word = e.digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + (wd >> 3)) * e.count + e.item];
+  const int d = (int)((word >> ((wd & 7) * 4)) & 15u) - 8;
   const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
   const bool neg = (d < 0) != (e.term[t].negate != 0);
   // multiples 1..8 are stored (at 0..7); digit 0 reads the one identity entry every lane shares (an address select, no table bytes)
@@ -726,9 +727,10 @@ __device__ __forceinline__ void msm_body(const afx_msm_djob* __restrict__ job, c
       if constexpr (SEC) {
         if (env.narrow) { acc = msm_chain_narrow(env, acc, nv); chained = true; }   // wave-uniform: a property of the job
       }
+      const int top = (int)job->wins - 1;   // 63, or a segment's share of the windows (uniform)
 #pragma unroll 1
-      for (int w = (nv && !chained) ? 63 : -1; w >= 0; w--) {
-        if (w != 63) {
+      for (int w = (nv && !chained) ? top : -1; w >= 0; w--) {
+        if (w != top) {
           ge_p2 a2 = ge_p3_to_p2(acc);
 #pragma unroll 1
           for (int k = 0; k < 3; k++) a2 = ge_p1p1_to_p2_before_dbl(ge_p2_dbl(a2));
@@ -963,18 +965,20 @@ __device__ __forceinline__ void msm_quad_body(const afx_msm_djob* __restrict__ j
   // the entry of addition (w, t), requested ahead of its use: before the window's doublings for t = 0, an addition ahead otherwise
   auto var_entry = [&](int w, uint32_t t, bool& neg) {
     const int32_t* table = table_ws + ((size_t)e.term[t].table_slot * count + item) * AFX_VAR_TABLE_DWORDS;
-    const uint32_t word = digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + ((uint32_t)w >> 3)) * count + item];
-    const int d = (int)((word >> (((uint32_t)w & 7) * 4)) & 15u) - 8;
+    const uint32_t wd = (uint32_t)w + e.term[t].win_off;
+    const uint32_t word = digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + (wd >> 3)) * count + item];
+    const int d = (int)((word >> ((wd & 7) * 4)) & 15u) - 8;
     const uint32_t idx = (uint32_t)(d < 0 ? -d : d);
     neg = (d < 0) != (e.term[t].negate != 0);
     return quad_entry_load(idx ? table + (idx - 1) * AFX_TABLE_ENTRY_DWORDS : AFX_IDENTITY_ENTRY, role, neg);
   };
   bool nneg = false;
   quad_words nxt = {};
-  if (nv && !chained) nxt = var_entry(63, 0, nneg);
+  const int wtop = (int)job->wins - 1;   // 63, or a segment's share
+  if (nv && !chained) nxt = var_entry(wtop, 0, nneg);
 #pragma unroll 1
-  for (int w = (nv && !chained) ? 63 : -1; w >= 0; w--) {
-    if (w != 63) {
+  for (int w = (nv && !chained) ? wtop : -1; w >= 0; w--) {
+    if (w != wtop) {
 #pragma unroll 1
       for (int k = 0; k < 4; k++) acc = quad_dbl(L, buf, role, lane, acc);
     }
@@ -1450,17 +1454,34 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_hash_coop(const afx_hash_program*
   const uint32_t rho = KECCAK_RHO[w], pi_src = kc_lane(KECCAK_PI_SRC[w]);
   uint64_t st = prog->load_state ? prog->load_state[(size_t)w * count + item] : prog->init_state[w];
   const uint32_t nrec = prog->n_records;
+  // A record's rate word and the 16 bytes of the field it takes from are requested while the record BEFORE it permutes: three
+  // dependent loads (the word, the field's address, its bytes) that otherwise stand between two permutations, about as long as a
+  // permutation's own 24 rounds.  (No record reads what a squeeze of its own program stored: SchnorrBuilder::make_program checks.)
+  const uint32_t wl = w < 21u ? w : 0u;
+  afx_hash_word hw_n = prog->records[0].w[wl];
+  uint64_t lo_n = 0, hi_n = 0;
+  if (w < 21u && hw_n.field >= 0) {
+    const uint8_t* f = prog->fields[hw_n.field] + 32ull * item;
+    lo_n = (hw_n.q >= 0) ? load_u64(f + 8 * hw_n.q) : 0ull;
+    hi_n = (hw_n.q < 3) ? load_u64(f + 8 * (hw_n.q + 1)) : 0ull;
+  }
 #pragma unroll 1
   for (uint32_t r = 0; r < nrec; r++) {
     const afx_hash_record* rec = &prog->records[r];
+    const afx_hash_word hw = hw_n;
+    const uint64_t lo = lo_n, hi = hi_n;
+    if (r + 1 < nrec) {   // uniform
+      hw_n = prog->records[r + 1].w[wl];
+      lo_n = 0; hi_n = 0;
+      if (w < 21u && hw_n.field >= 0) {
+        const uint8_t* f = prog->fields[hw_n.field] + 32ull * item;
+        lo_n = (hw_n.q >= 0) ? load_u64(f + 8 * hw_n.q) : 0ull;
+        hi_n = (hw_n.q < 3) ? load_u64(f + 8 * (hw_n.q + 1)) : 0ull;
+      }
+    }
     if (w < 21u) {
-      const afx_hash_word hw = rec->w[w];
       uint64_t v = hw.c;
       if (hw.field >= 0) {
-        const uint8_t* f = prog->fields[hw.field] + 32ull * item;
-        const int q = hw.q;
-        const uint64_t lo = (q >= 0) ? load_u64(f + 8 * q) : 0ull;
-        const uint64_t hi = (q < 3) ? load_u64(f + 8 * (q + 1)) : 0ull;
         const uint32_t sh = 8u * hw.r;
         const uint64_t val = sh ? ((lo >> sh) | (hi << (64u - sh))) : lo;
         v ^= val & hw.fmask;

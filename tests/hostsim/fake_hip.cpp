@@ -156,10 +156,11 @@ hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_ms
     if ((j.narrow != 0) != (secret_var != 0) || (j.narrow && kind != 1)) return hipErrorInvalidValue;   // narrow windows exactly where a variable base carries a secret
     for (uint32_t t = 0; t < j.n_terms; t++) { CHECK_PTR(term[t].scalar); CHECK_PTR(term[t].var); }
     // a chain's windows: all of them, or a segment's share with every variable term a segment inside the recoded scalar
-    if (j.narrow && (j.wins == 0 || j.wins > AFX_SECVAR_WINDOWS)) return hipErrorInvalidValue;
+    const uint32_t all_wins = j.narrow ? AFX_SECVAR_WINDOWS : 64u;   // 2-bit windows of a secret on a per-item base, 4-bit ones otherwise
+    if (j.wins == 0 || j.wins > all_wins) return hipErrorInvalidValue;
     for (uint32_t t = 0; t < j.n_terms; t++) {
-      if (term[t].win_off && !(t < j.n_var && j.narrow && term[t].secret)) return hipErrorInvalidValue;
-      if (t < j.n_var && j.narrow && term[t].win_off + j.wins > AFX_SECVAR_WINDOWS) return hipErrorInvalidValue;
+      if (term[t].win_off && !(t < j.n_var && t >= j.n_uni)) return hipErrorInvalidValue;
+      if (t < j.n_var && term[t].win_off + j.wins > all_wins) return hipErrorInvalidValue;
     }
     CHECK_PTR(j.addend); CHECK_PTR(j.out_enc); CHECK_PTR(j.out_var); CHECK_PTR(j.half_var);
     if (j.n_uni) {   // the NAF schedule lives in the plan blob: read it to its terminator
