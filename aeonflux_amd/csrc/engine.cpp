@@ -104,7 +104,7 @@ size_t Assembler::blob_alloc(size_t bytes, size_t align) {
 template <class T> static void put_job(uint8_t* dst, const T& j) { memcpy(dst, &j, sizeof j); }
 template <> void put_job(uint8_t* dst, const afx_decode_job& j) {
   afx_decode_job z; memset(&z, 0, sizeof z);
-  z.enc = j.enc; z.out = j.out; z.reject_identity = j.reject_identity;
+  z.enc = j.enc; z.out = j.out; z.reject_identity = j.reject_identity; z.elligator = j.elligator;
   memcpy(dst, &z, sizeof z);
 }
 template <> void put_job(uint8_t* dst, const afx_pointop_job& j) {
@@ -133,10 +133,35 @@ void Assembler::decode(const std::vector<afx_decode_job>& jobs) {
   stats.field_sq += AFX_DECODE_SQ * jobs.size();
   stats.chain_mul += AFX_CHAIN_SQRT_MUL * jobs.size();
   stats.chain_sq += AFX_CHAIN_SQRT_SQ * jobs.size();
+  if (!pending_maps_.empty()) {
+    // the Elligator maps a small pass queued (from_uniform) ride in this launch, a grid row each beside the decodings; their sums follow
+    std::vector<afx_decode_job> all(pending_maps_);
+    all.insert(all.end(), jobs.begin(), jobs.end());
+    pending_maps_.clear();
+    add_jobs(L_DECODE, all);
+    launches.back().odd = 1;
+    flush_maps();
+    return;
+  }
   add_jobs(L_DECODE, jobs);
+}
+// what from_uniform queued and no decode() call took along: a launch of its own, then the sums
+void Assembler::flush_maps() {
+  if (!pending_maps_.empty()) {
+    std::vector<afx_decode_job> maps;
+    maps.swap(pending_maps_);
+    add_jobs(L_DECODE, maps);
+    launches.back().odd = 1;
+  }
+  if (!pending_map_sums_.empty()) {
+    std::vector<afx_pointop_job> sums;
+    sums.swap(pending_map_sums_);
+    pointop(sums);
+  }
 }
 void Assembler::sccheck(const std::vector<afx_sccheck_job>& jobs) { add_jobs(L_SCCHECK, jobs); }
 void Assembler::pointop(const std::vector<afx_pointop_job>& jobs) {
+  flush_maps();
   for (const afx_pointop_job& j : jobs) {
     stats.var_additions += j.sb != 0;
     stats.encodings += j.out_enc != nullptr;
@@ -163,6 +188,7 @@ void Assembler::pointop(const std::vector<afx_pointop_job>& jobs) {
   add_jobs(L_POINTOP, jobs);
 }
 void Assembler::negenc(const std::vector<afx_negenc_job>& jobs) {
+  flush_maps();
   if (jobs.empty()) return;
   stats.encodings += jobs.size();
   stats.field_mul += 11 + (2 * 3 + 2 + 17) * jobs.size();   // one inversion; per point: the value to invert twice, prefix products, the encoding's tail
@@ -189,8 +215,9 @@ void Assembler::add_walk_rows(Launch& l, uint32_t per_row) {
   l.rows_off = blob_alloc(sizeof(afx_walk_row) * rows.size(), 16);
   memcpy(blob_.data() + l.rows_off, rows.data(), sizeof(afx_walk_row) * rows.size());
 }
-void Assembler::scalarop(const std::vector<afx_scalarop_job>& jobs) { add_jobs(L_SCALAROP, jobs); }
+void Assembler::scalarop(const std::vector<afx_scalarop_job>& jobs) { flush_maps(); add_jobs(L_SCALAROP, jobs); }
 void Assembler::hash(const std::vector<afx_hash_program>& progs) {
+  flush_maps();
   flush_encodings();   // encodings still queued (Assembler::pointop, compress_also, a small pass's stages) are launched before their reader
   for (const afx_hash_program& p : progs) stats.keccak_permutations += p.n_records;
   add_jobs(L_HASH, progs);
@@ -345,6 +372,7 @@ void Assembler::flush_encodings() {
 }
 
 void Assembler::msm(std::vector<afx_msm_job> jobs) {
+  flush_maps();
   if (jobs.empty()) {
     // encodings queued by compress_also() ride in this call's k_compress2x launch even when it has no chains of its own (a small
     // pass keeps them for the launch in front of their reader: see the end of this function)
@@ -901,13 +929,15 @@ void Assembler::from_uniform(const uint8_t* wide, uint8_t* out_enc, int32_t* out
   // adds them, and the encoding (a third chain) joins the stage's other encodings in k_compress2x (Assembler::pointop): the call
   // waits for one chain here instead of three (a 1-item issue: 184 -> 67 us).  Same point, same bytes.
   if (small() && (uint64_t)ctx->row_waves(count) * 2 <= 2ull * 4 * ctx->n_cu) {
+    // ... and the two maps wait for the statement's decodings - a third kind of square-root chain, independent of them - to share one
+    // launch (Assembler::decode; whatever else comes first sends them off by themselves: flush_maps)
     int32_t *h1 = new_var(), *h2 = new_var();
-    const afx_uniform_job a = { wide, nullptr, h1, 1, 0 }, b = { wide, nullptr, h2, 2, 0 };
-    add_jobs(L_FROM_UNIFORM, std::vector<afx_uniform_job>{ a, b });
+    const afx_decode_job a = { wide, h1, 0, 1 }, b = { wide, h2, 0, 2 };
+    pending_maps_.push_back(a); pending_maps_.push_back(b);
     afx_pointop_job s;
     memset(&s, 0, sizeof s);
     s.a = h1; s.b = h2; s.sa = 1; s.sb = 1; s.out = out_var; s.out_enc = out_enc;
-    pointop(std::vector<afx_pointop_job>(1, s));
+    pending_map_sums_.push_back(s);
     return;
   }
   const afx_uniform_job j = { wide, out_enc, out_var, 0, 0 };
@@ -922,6 +952,7 @@ void Assembler::copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
   launches.push_back(l);
 }
 void Assembler::finish(uint8_t* status_dev, uint8_t fail_code) {
+  flush_maps();
   flush_encodings();   // (results no transcript reads; their rejections are flags k_finish folds into the status)
   const afx_finish_job j = { bad_, status_dev, count, fail_code };
   add_jobs(L_FINISH, std::vector<afx_finish_job>(1, j));
@@ -1178,7 +1209,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
         const Launch& c = plans[i]->launches[head[i]];
         const bool same = c.kind == h.kind && (h.kind != L_MSM_TABLES || c.odd == h.odd) && (h.kind != L_COPY || i == lead);
         if (!same) continue;
-        if (h.kind == L_POINTSUM && c.odd) mg.odd = 1;   // (a hint: some job of the merged launch has many parts)
+        if ((h.kind == L_POINTSUM || h.kind == L_DECODE) && c.odd) mg.odd = 1;   // (some job of the merged launch has many parts / is an Elligator map)
         mg.parts.push_back({ (uint32_t)i, (uint32_t)head[i] });
         head[i]++;
       }
@@ -1259,7 +1290,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
     const afx_row* rw = (const afx_row*)rows;
     switch (kind) {
       case L_FILL_BAD: AFX_HIP(afxk_fill_u32(s, (const afx_fill_job*)jobs, nrows, rw, max_count)); break;
-      case L_DECODE: AFX_HIP(afxk_decode(s, (const afx_decode_job*)jobs, nrows, rw, passes, max_count)); break;
+      case L_DECODE: AFX_HIP(afxk_decode(s, (const afx_decode_job*)jobs, nrows, rw, passes, max_count, odd)); break;
       case L_SCCHECK: AFX_HIP(afxk_sccheck(s, (const afx_sccheck_job*)jobs, nrows, rw, passes, max_count)); break;
       case L_POINTOP: AFX_HIP(afxk_pointop(s, (const afx_pointop_job*)jobs, nrows, rw, passes, max_count)); break;
       case L_SCALAROP: AFX_HIP(afxk_scalarop(s, (const afx_scalarop_job*)jobs, nrows, rw, passes, max_count)); break;

@@ -214,7 +214,8 @@ struct Launch {
   uint8_t* out = nullptr;
   size_t bytes = 0;
   int odd = 0;              // L_MSM_TABLES: kind of table (plan.h afx_table_job): 0 multiples 1..8, 1 odd multiples (NAF terms), 2 narrow;
-                            // L_POINTSUM: 1 = some job sums sixteen parts or more (kernels.hip afxk_pointsum)
+                            // L_POINTSUM: 1 = some job sums sixteen parts or more (kernels.hip afxk_pointsum);
+                            // L_DECODE: 1 = the launch holds Elligator jobs (afx_decode_job.elligator)
   int encodes = 1;          // L_MSM_*: some job of the launch encodes its result inside the kernel (kernels.hip k_msm<KIND, ENC, SEC>)
   int secret = 0;           // L_MSM_*: some term of the launch has a secret scalar under secret-independent addressing
 };
@@ -335,6 +336,9 @@ class Assembler {
   template <class T>
   void add_jobs(LaunchKind k, const std::vector<T>& jobs);
   void flush_encodings();
+  void flush_maps();
+  std::vector<afx_decode_job> pending_maps_;         // Elligator maps queued by from_uniform (small passes): they ride in the next decode launch
+  std::vector<afx_pointop_job> pending_map_sums_;    // ... and the additions of the pairs
   void add_walk_rows(Launch& l, uint32_t per_row);   // the afx_walk_row array of a k_compress2x / k_negenc / k_table_affine launch (+ its prefix scratch)
   std::set<const int32_t*> half_bases_;            // variables that hold HALF their point (producers with leave_half)
   std::vector<afx_compress_job> pending_cjobs_;    // compress_also()

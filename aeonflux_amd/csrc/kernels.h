@@ -7,7 +7,8 @@ hipError_t afxk_setup_generators(hipStream_t s, const uint8_t* enc, uint32_t nge
 // Plan launches: grid row r runs job jobs[r] of pass passes[0] (rows == null: a plan's own launch), or the job at byte offset
 // rows[r].job_off from `jobs` of pass passes[rows[r].pass] (a launch merged from several plans; plan.h afx_row, afx_pass).
 // `max_count` = the largest item count among the launch's passes (sizes the grid).
-hipError_t afxk_decode(hipStream_t s, const afx_decode_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count);
+// mixed: the launch may hold Elligator jobs (afx_decode_job.elligator; Launch::odd)
+hipError_t afxk_decode(hipStream_t s, const afx_decode_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count, int mixed);
 hipError_t afxk_sccheck(hipStream_t s, const afx_sccheck_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count);
 hipError_t afxk_pointop(hipStream_t s, const afx_pointop_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count);
 hipError_t afxk_scalarop(hipStream_t s, const afx_scalarop_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count);

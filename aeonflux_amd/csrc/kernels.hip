@@ -239,6 +239,30 @@ __global__ void __launch_bounds__(AFX_BLOCK, 2) k_decode(const afx_decode_job* _
   if (job.out) var_store(job.out, count, item, ok ? P : ge_identity());
 }
 
+// the same for a small pass's launch that also holds Elligator jobs (afx_decode_job.elligator): two kinds of square-root chain side by
+// side in one launch, a grid row each, instead of one launch after the other
+__global__ void __launch_bounds__(AFX_BLOCK) k_decode_mixed(const afx_decode_job* __restrict__ jobs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_decode_job job = *row_job(jobs, rows);
+  const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
+  const uint32_t count = pass.count;
+  uint32_t* __restrict__ bad = pass.bad;
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= count) return;
+  uint32_t w[8];
+  if (job.elligator) {   // (uniform)
+    enc_load(w, job.enc, 2 * item + (job.elligator - 1));
+    var_store(job.out, count, item, ristretto_elligator(fe_frombytes(w)));
+    return;
+  }
+  enc_load(w, job.enc, item);
+  ge_p3 P;
+  const bool ok = ristretto_decode(P, w);
+  uint32_t flags = ok ? 0u : AFX_BAD_DECODE;
+  if (job.reject_identity && is_identity_encoding(w)) flags |= AFX_BAD_IDENTITY;
+  if (flags) atomicOr(&bad[item], flags);
+  if (job.out) var_store(job.out, count, item, ok ? P : ge_identity());
+}
+
 __global__ void __launch_bounds__(AFX_BLOCK) k_sccheck(const afx_sccheck_job* __restrict__ jobs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
   const afx_sccheck_job job = *row_job(jobs, rows);
   const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
@@ -1647,8 +1671,9 @@ hipError_t afxk_setup_generators(hipStream_t s, const uint8_t* enc, uint32_t nge
   return hipGetLastError();
 }
 // `max_count`: the largest item count among the passes of the launch (sizes the grid; a row's lanes past its own pass's count retire)
-hipError_t afxk_decode(hipStream_t s, const afx_decode_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
-  hipLaunchKernelGGL(k_decode, grid_for(max_count, njobs), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
+hipError_t afxk_decode(hipStream_t s, const afx_decode_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count, int mixed) {
+  if (mixed) hipLaunchKernelGGL(k_decode_mixed, grid_for(max_count, njobs), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
+  else hipLaunchKernelGGL(k_decode, grid_for(max_count, njobs), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_sccheck(hipStream_t s, const afx_sccheck_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {

@@ -118,6 +118,9 @@ typedef struct {
   const uint8_t* enc;      /* [count][32] compressed input                                            */
   afx_var_t out;           /* extended coordinates out (or null)                                       */
   uint32_t reject_identity; /* the point is allocated into a transcript: identity encoding fails      */
+  uint32_t elligator;       /* 1, 2: not a decoding - `enc` is a [count][64] array of uniform bytes and out = the Elligator map of each
+                               record's first / second 32 bytes (a small pass runs from_uniform's two maps beside its decodings:
+                               Assembler::from_uniform; only launches marked Launch::odd hold such jobs, k_decode_mixed runs them) */
 } afx_decode_job;
 
 typedef struct {

@@ -95,8 +95,15 @@ static hipError_t check_pass(const afx_pass& P, uint32_t max_count) {
   P.bad[0] |= 0; P.bad[P.count - 1] |= 0;   // the failure words are real memory of the pass's workspace
   return hipSuccess;
 }
-hipError_t afxk_decode(hipStream_t, const afx_decode_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
-  for (uint32_t i = 0; i < n; i++) { hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e; CHECK_PTR(job_of(j, rows, i).enc); CHECK_PTR(job_of(j, rows, i).out); }
+hipError_t afxk_decode(hipStream_t, const afx_decode_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count, int mixed) {
+  uint32_t maps = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e; CHECK_PTR(job_of(j, rows, i).enc); CHECK_PTR(job_of(j, rows, i).out);
+    const afx_decode_job& d = job_of(j, rows, i);
+    if (d.elligator > 2 || (d.elligator && (!mixed || !d.out))) return hipErrorInvalidValue;   // Elligator jobs only in launches marked for the kernel that knows them
+    maps += d.elligator != 0;
+  }
+  if (mixed && !maps) return hipErrorInvalidValue;   // ... and a launch marked for it holds some (the mark travels with the jobs' own field)
   return hipSuccess;
 }
 hipError_t afxk_sccheck(hipStream_t, const afx_sccheck_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
