@@ -156,6 +156,9 @@ struct CtxLock {
   static CtxLock*& outermost() { static thread_local CtxLock* p = nullptr; return p; }
   explicit CtxLock(afx_ctx* ctx, bool joiner = false) : c(ctx) {
     if (!c) return;
+    // (Trying the lock for a while before sleeping on it - the hold is a few microseconds, a futex hand-over several times that - was
+    // measured and dropped: +13 % at 16 threads on 16 cores, -60 ... -90 % from 128 threads on, where the spinners take the cores the
+    // holder needs: profiles/r05_ab_lock_spin.txt.)
     c->mu.lock();
     if (++c->lock_depth == 1) {
       is_outermost = true;
