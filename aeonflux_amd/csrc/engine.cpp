@@ -960,6 +960,7 @@ void Assembler::finish(uint8_t* status_dev, uint8_t fail_code) {
 int Assembler::finish_plan(Plan& out, uint8_t* in_base, size_t in_bytes, uint8_t* out_base, size_t out_bytes) {
   if (!plan_error.empty()) { set_error(plan_error); return AFX_E_BAD_ARGS; }
   if (!pending_cjobs_.empty()) { set_error("an encoding queued by compress_also() was never launched"); return AFX_E_BAD_ARGS; }
+  if (!pending_maps_.empty() || !pending_map_sums_.empty()) { set_error("internal: from_uniform's maps were never launched"); return AFX_E_BAD_ARGS; }
   if (launches.empty() || launches[0].kind != L_FILL_BAD) { set_error("internal: plan without its opening launch"); return AFX_E_BAD_ARGS; }
   const afx_fill_job fj = { bad_, fail_all ? AFX_BAD_SHAPE : 0u, count };
   memcpy(blob_.data() + launches[0].jobs_off, &fj, sizeof fj);
