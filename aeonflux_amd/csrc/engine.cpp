@@ -641,6 +641,11 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
   };
   const size_t n = jobs.size();
   const bool sec_mode = secure();   // terms were marked by Assembler::msm, before any splitting
+  // A segmenting pass on the four-wave chains keeps the entries in the CACHED form k_msm_tables leaves (kind 3): an addition's fourth
+  // product runs on the fourth wave at no cost in rounds, and the pass does not wait for k_table_affine's inversion (64 us of a 1-item call)
+  // (up to 512 items: such a launch takes the four-wave chains whatever its size, and wider passes are better off on one wave per
+  // chain - a 2048-item show 2.59 -> 2.90 ms with them)
+  const bool cached_narrow = segmenting_ && afxk_quad_chains() != 0 && ctx->row_waves(count) <= 8;
   for (size_t i = 0; i < n; i++)
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
   // Jobs whose result is only ever encoded (no consumer of the point itself, no addend) run on halved scalars; k_compress2x
@@ -733,7 +738,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
       M += nv * (1 + (stored - 1) * (j.narrow ? 8 : 9));
       for (int w = (int)wins - 1; w >= 0; w--) {
         if (w != (int)wins - 1) { S += 4 * wbits; M += 3 * (wbits - 1) + 4; }   // the window's doublings to p2, its last to p3
-        M += nv * (j.narrow ? 3 : 4);                         // additions of window-table entries (affine ones in a narrow job)
+        M += nv * ((j.narrow && !cached_narrow) ? 3 : 4);     // additions of window-table entries (affine ones in a narrow job)
         M += nv * 4 - (w != 0 ? 1 : 0);                       // back to p3; the window's last one skips T
       }
     }
@@ -776,11 +781,12 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
   auto emit_narrow_tables = [&](const std::vector<afx_table_job>& tr) {
     Launch tl;
     tl.kind = L_MSM_TABLES;
-    tl.odd = 2;
+    tl.odd = cached_narrow ? 3 : 2;
     tl.njobs = (uint32_t)tr.size();
     tl.jobs_off = blob_alloc(sizeof(afx_table_job) * tr.size(), 16);
     memcpy(blob_.data() + tl.jobs_off, tr.data(), sizeof(afx_table_job) * tr.size());
     launches.push_back(tl);
+    if (cached_narrow) { stats.field_mul += (uint64_t)tr.size() * AFX_SECVAR_STORED; return; }   // (2dT of each entry)
     Launch al;
     al.kind = L_TABLE_AFFINE;
     al.njobs = tl.njobs;
@@ -914,7 +920,8 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
       if (j.n_terms) term_tables_.push_back({ terms_at[i], j.n_terms });
       d.addend = j.addend; d.addend_negate = j.addend_negate; d.reject_identity = j.reject_identity;
       d.out_enc = j.out_enc; d.out_var = j.out_var; d.half_var = j.half_var;
-      d.digit_slot = j.digit_slot; d.narrow = j.narrow; d.leave_half = j.leave_half; d.wins = j.wins;
+      d.digit_slot = j.digit_slot; d.narrow = (j.narrow && cached_narrow) ? 2u : j.narrow; d.leave_half = j.leave_half; d.wins = j.wins;
+      if (d.narrow == 2) l.secret |= 2;   // (kernels.h afxk_msm: the launch takes the four-wave chains whatever its size)
     }
     l.jobs_off = blob_alloc(sizeof(afx_msm_djob) * dj.size(), 16);
     for (size_t i = 0; i < dj.size(); i++) dj[i].term_off = (int32_t)((int64_t)terms_at[i] - (int64_t)(l.jobs_off + sizeof(afx_msm_djob) * i));   // from the job itself

@@ -14,12 +14,16 @@ hipError_t afxk_pointop(hipStream_t s, const afx_pointop_job* jobs, uint32_t njo
 hipError_t afxk_scalarop(hipStream_t s, const afx_scalarop_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count);
 // secret != 0: the 6-bit tables of the secret-independent path (AFX_SEC_*) instead of the 13-bit ones
 hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen, int32_t* base_scratch, int32_t* postab, int secret);
-// kind of table (plan.h afx_table_job): 0 multiples 1..8, 1 odd multiples 1..15 (NAF terms), 2 the short tables of narrow jobs
+// are the four-wave chains on (AFX_QUAD_CHAINS != 0)?  A plan may only hold cached narrow tables (afx_msm_job.narrow == 2) if so.
+int afxk_quad_chains();
+// kind of table (plan.h afx_table_job): 0 multiples 1..8, 1 odd multiples 1..15 (NAF terms), 2 the short tables of narrow jobs,
+// 3 the same in the cached form (no k_table_affine step: segmenting passes)
 hipError_t afxk_msm_tables(hipStream_t s, int kind, const afx_table_job* jobs, uint32_t nrows, const afx_row* rows, const afx_pass* passes, uint32_t max_count);
 // kind: 0 fixed bases only, 1 per-item windows, 2 uniform NAF terms (kernels.hip MSM_*)
 // clock_probe: AFX_CLOCK_SLOTS pairs of 64-bit counters (shader-clock cycles, 100 MHz ticks): lane 0 of that many blocks of the launch adds its
 // chain's span to its pair (kernels.hip msm_body); may be null
-// secret: some term of the launch has afx_msm_term.secret set (sec_tables must then be the context's AFX_SEC_* tables)
+// secret: bit 0 - some term of the launch has afx_msm_term.secret set (sec_tables must then be the context's AFX_SEC_* tables);
+//         bit 1 - some job's narrow tables hold cached entries (afx_msm_job.narrow == 2): the launch takes the four-wave chains at any size
 // rows == null (a plan's own launch): pass_host = the HOST copy of the plan's pass, whose fields go as kernel arguments; merged launches: kinds 0 and 1 only
 hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t njobs, const int32_t* pos_tables, const int32_t* sec_tables,
                     const afx_row* rows, const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* clock_probe);

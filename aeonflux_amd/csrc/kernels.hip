@@ -537,7 +537,7 @@ AFX_DEV void msm_recode(const afx_msm_djob* job, uint32_t* __restrict__ digit_ws
 // Layout inside a slot's AFX_VAR_TABLE_DWORDS * count dwords: 4-bit-window tables are item-major ([item][entry]: a lane's 8 stored
 // entries are contiguous, its digit picks one), NAF tables entry-major ([entry][item]: every lane of a wave reads the SAME
 // entry; they are stored piece-major inside an entry, see cached_store).  `stride` = dwords between consecutive entries.
-enum { TABLE_WINDOW = 0, TABLE_ODD = 1, TABLE_NARROW = 2 };
+enum { TABLE_WINDOW = 0, TABLE_ODD = 1, TABLE_NARROW = 2, TABLE_NARROW_CACHED = 3 };
 template <int TK>
 AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t chunk, const ge_p3& P) {
   ge_p3 Q = P;
@@ -551,10 +551,11 @@ AFX_DEV void msm_build_table(int32_t* __restrict__ tab, size_t stride, size_t ch
     }
   } else {
     const ge_cached cP = ge_p3_to_cached(P);   // P centred: Y+X, Y-X, 2Z within 1 unit, what ge_add_cached expects
-    // k*P at entry k - 1; the identity (digit 0) is not stored.  A narrow job's entries: X, Y, Z for k_table_affine to divide
+    // k*P at entry k - 1; the identity (digit 0) is not stored.  A narrow job's entries: X, Y, Z for k_table_affine to divide - or,
+    // TABLE_NARROW_CACHED, the cached form as it is (four-wave chains only: a product more per addition costs them no round)
     if (TK == TABLE_NARROW) xyz_store(tab, chunk, P); else cached_store(tab, chunk, cP);
 #pragma unroll 1
-    for (int k = 2; k <= (TK == TABLE_NARROW ? AFX_SECVAR_STORED : AFX_TABLE_STORED); k++) {
+    for (int k = 2; k <= ((TK == TABLE_NARROW || TK == TABLE_NARROW_CACHED) ? AFX_SECVAR_STORED : AFX_TABLE_STORED); k++) {
       Q = ge_p1p1_to_p3(ge_add_cached(Q, cP, false));
       if (TK == TABLE_NARROW) xyz_store(tab + (k - 1) * stride, chunk, Q); else cached_store(tab + (k - 1) * stride, chunk, ge_p3_to_cached(Q));
     }
@@ -926,14 +927,16 @@ __device__ __forceinline__ void msm_quad_body(const afx_msm_djob* __restrict__ j
   if constexpr (SEC) {
     if (narrow) {
       chained = true;
+      const bool cached = job->narrow == 2;   // (uniform) a segmenting pass: the tables were never made affine
       // everything addition (w, t) could need of the lane's two-entry table, and its digit word; requested an addition ahead
       auto fetch = [&](int w, uint32_t t, uint32_t& dword) {
         const uint32_t o = AFX_SECVAR_BITS * ((uint32_t)w + e.term[t].win_off);
         dword = digit_ws[((size_t)(e.dslot + t) * AFX_DIGIT_WORDS + (o >> 5)) * count + item];
         const int32_t* table = table_ws + (size_t)e.term[t].table_slot * count * AFX_VAR_TABLE_DWORDS + (size_t)item * 4;
         const size_t piece = (size_t)count * 4, entry = (size_t)count * AFX_TABLE_ENTRY_DWORDS;
-        // roles 0, 1: pieces 0, 1 and 2, 3; role 2 (and 3, which drops them): pieces 4, 5 twice - uniform offsets, every field set
-        const size_t first = role < 2 ? 0 : 4, other = role < 2 ? 2 : 4;
+        // roles 0, 1: pieces 0, 1 and 2, 3; role 2 (and 3, which drops them): pieces 4, 5 twice - uniform offsets, every field set.
+        // Cached entries (job->narrow == 2: Y+X | Y-X | 2Z | 2dT, k_msm_tables<TABLE_NARROW_CACHED>): role 2 takes 2dT (6, 7), role 3 2Z (4, 5)
+        const size_t first = role < 2 ? 0 : (cached && role == 2) ? 6 : 4, other = role < 2 ? 2 : first;
         quad_narrow q;
 #pragma unroll
         for (int m = 0; m < 2; m++)
@@ -966,12 +969,17 @@ __device__ __forceinline__ void msm_quad_body(const afx_msm_djob* __restrict__ j
           // the 8 words this role multiplies by: of entry idx (the identity for 0); roles 0, 1: the half the sign names (role 0
           // takes (y-x)/2 when subtracting, role 1 when adding).  Mask arithmetic, no branch and no address from the digit.
           const uint32_t second = quad_mask(role < 2 && (role == 0 ? neg : !neg));
+          // the identity: (1/2, 1/2, 0) with D = Z for the halved affine form, (1, 1, 0, 2) for the cached one.  Role 3 multiplies Z
+          // by the entry's 2Z - or, affine entries, by the constant 1, so that both forms take the same addition (its product is on
+          // the fourth wave, which the affine form would leave idle)
           uint32_t sel[8];
 #pragma unroll
-          for (int i = 0; i < 8; i++) sel[i] = role < 2 ? AFX_IDENTITY_NIELS[i] : 0u;   // (1/2, 1/2, 0)
+          for (int i = 0; i < 8; i++) sel[i] = (role < 2 && !cached) ? AFX_IDENTITY_NIELS[i] : 0u;
+          if (role == 3 || (role < 2 && cached)) sel[0] = (role == 3 && cached) ? 2u : 1u;
+          const uint32_t takes = quad_mask(role != 3 || cached);   // (uniform) an affine entry has nothing for role 3
 #pragma unroll
           for (uint32_t m = 0; m < 2; m++) {
-            const uint32_t hit = quad_mask(idx == m + 1);
+            const uint32_t hit = quad_mask(idx == m + 1) & takes;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
               const uint4 a = cur.a[m][h], b = cur.b[m][h];
@@ -981,7 +989,7 @@ __device__ __forceinline__ void msm_quad_body(const afx_msm_djob* __restrict__ j
               sel[4 * h + 3] = quad_pick(hit, quad_pick(second, b.w, a.w), sel[4 * h + 3]);
             }
           }
-          acc = quad_add<true>(L, buf, role, lane, acc, fe_frombytes(sel), neg);
+          acc = quad_add<false>(L, buf, role, lane, acc, fe_frombytes(sel), neg);
         }
       }
     }
@@ -1721,16 +1729,25 @@ static void launch_msm_rows(hipStream_t s, int encodes, int secret, dim3 grid, d
 }
 // rows == null: a plan's own launch; `pass_host` is the HOST copy of its pass (the fields travel as kernel arguments).  Otherwise a
 // merged launch: `jobs` is the blob's base, rows / passes are device tables.
+int afxk_quad_chains() {
+  static const bool quad_on = !(getenv("AFX_QUAD_CHAINS") && getenv("AFX_QUAD_CHAINS")[0] == '0');
+  return quad_on ? 1 : 0;
+}
 hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t njobs, const int32_t* pos_tables,
                     const int32_t* sec_tables, const afx_row* rows, const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* clock_probe) {
   if (secret && !sec_tables) return hipErrorInvalidValue;
+  // secret & 2: some job's narrow tables hold cached entries (afx_msm_job.narrow == 2): only the four-wave chains read those, whatever
+  // the launch's size (such jobs come from small prover passes; a merged launch wide enough to matter is a request of dozens of shapes)
+  const bool only_quad = (secret & 2) != 0;
+  secret = secret != 0;
   // a launch that leaves the device idle - windowed or fixed-base jobs without secret terms or in-kernel encodings, at most two
   // blocks of four waves per compute unit in all - runs four waves per item chain (k_msm_quad).  AFX_QUAD_CHAINS=0 switches it off
   // (measurement aid: the two kernels give the same bytes).
   static const bool quad_on = !(getenv("AFX_QUAD_CHAINS") && getenv("AFX_QUAD_CHAINS")[0] == '0');
   const uint32_t quad_blocks = (max_count + 63) / 64;
   // (a plan on its own up to 1024 blocks: 512-item calls gain 7 %; merged launches up to 512: at 1024 a 16-shape request loses 14 %)
-  if (quad_on && !encodes && kind != MSM_NAF && max_count && (uint64_t)quad_blocks * njobs <= (rows ? 512u : 1024u)) {
+  if (only_quad && (encodes || kind == MSM_NAF || !max_count)) return hipErrorInvalidValue;
+  if ((only_quad || quad_on) && !encodes && kind != MSM_NAF && max_count && (only_quad || (uint64_t)quad_blocks * njobs <= (rows ? 512u : 1024u))) {
     const dim3 qgrid(quad_blocks, njobs);
     if (!rows) {
       if (!pass_host) return hipErrorInvalidValue;
@@ -1765,6 +1782,7 @@ hipError_t afxk_msm_tables(hipStream_t s, int kind, const afx_table_job* jobs, u
     case TABLE_WINDOW: hipLaunchKernelGGL(k_msm_tables<TABLE_WINDOW>, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes); break;
     case TABLE_ODD: hipLaunchKernelGGL(k_msm_tables<TABLE_ODD>, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes); break;
     case TABLE_NARROW: hipLaunchKernelGGL(k_msm_tables<TABLE_NARROW>, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes); break;
+    case TABLE_NARROW_CACHED: hipLaunchKernelGGL(k_msm_tables<TABLE_NARROW_CACHED>, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -194,7 +194,8 @@ typedef struct {
   uint32_t digit_slot;                  /* first recoded-scalar slot of this job in digit_ws (one per term)   */
   uint32_t narrow;                      /* one of the variable terms has a secret scalar under secret-independent addressing: the job's
                                            variable terms run AFX_SECVAR_BITS-bit windows over tables of AFX_SECVAR_STORED entries
-                                           (Assembler::msm sets it; only launches of the SEC kernel instances hold such jobs) */
+                                           (Assembler::msm sets it; only launches of the SEC kernel instances hold such jobs).
+                                           2: the same over CACHED entries (a segmenting pass skips k_table_affine; four-wave chains only) */
   uint32_t wins;                        /* narrow jobs: how many windows the chain runs - AFX_SECVAR_WINDOWS (0 means that), or a segment's
                                            share when its terms are segments (afx_msm_term.win_off)                            */
 } afx_msm_job;

@@ -134,10 +134,11 @@ hipError_t afxk_scalarop(hipStream_t, const afx_scalarop_job* j, uint32_t n, con
 }
 hipError_t afxk_setup_postables(hipStream_t, const int32_t*, uint32_t, int32_t*, int32_t*, int) { return hipSuccess; }
 hipError_t afxk_msm_tables(hipStream_t, int kind, const afx_table_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
-  if (kind < 0 || kind > 2) return hipErrorInvalidValue;
+  if (kind < 0 || kind > 3) return hipErrorInvalidValue;
   for (uint32_t i = 0; i < n; i++) { hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e; CHECK_PTR(job_of(j, rows, i).var); sink += job_of(j, rows, i).table_slot; }
   return hipSuccess;
 }
+int afxk_quad_chains() { return !(getenv("AFX_QUAD_CHAINS") && getenv("AFX_QUAD_CHAINS")[0] == '0'); }
 hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t n, const int32_t*, const int32_t* sec_tables, const afx_row* rows,
                     const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* probe) {
   if (!rows) {   // a plan's own launch: the pass travels as kernel arguments, from its host copy - which must equal the device's
@@ -149,6 +150,9 @@ hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_ms
   for (uint32_t i = 0; i < n; i++)
     for (uint32_t t = 0; t < job_of(jobs, rows, i).n_terms; t++) any_secret |= afx_job_terms(&job_of(jobs, rows, i))[t].secret != 0;
   if (any_secret != (secret != 0)) return hipErrorInvalidValue;   // the launch's flag is the OR of its terms' flags
+  int any_cached = 0;
+  for (uint32_t i = 0; i < n; i++) any_cached |= job_of(jobs, rows, i).narrow == 2;
+  if (any_cached != ((secret & 2) != 0) || (any_cached && (encodes || kind != 1))) return hipErrorInvalidValue;   // ... bit 1 of its jobs' cached tables
   if (kind < 0 || kind > 2) return hipErrorInvalidValue;
   for (uint32_t i = 0; i < n; i++) {
     hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e;
