@@ -85,5 +85,5 @@ for m in 4 16 64; do AFX_PACK_LIMIT_MB=$m python3 tools/midsize_host_calls.py; d
 python3 tools/concurrent_small_calls.py --one-context --threads 1,2,4,8,16,32,64,128,256 > $O/${TAG}_coalesced_calls.txt 2>&1
 # one 1-item call of each prover / verifier operation, launch by launch
 tools/timeline.sh issue show verify
-(echo "# tools/timeline.sh issue show verify: rocprofv3 --kernel-trace of ONE 1-item host-pointer call each (issue: 16 attributes; show, verify: the C3 shape), launch by launch: start offset, duration, gap to the previous launch"; cat $O/timeline_issue.txt $O/timeline_show.txt $O/timeline_verify.txt) > $O/${TAG}_small_call_timeline.txt
+(echo "# tools/timeline.sh issue show verify: rocprofv3 --kernel-trace of ONE 1-item host-pointer call each (issue: 16 attributes; show, verify: the C3 shape), launch by launch: start offset, duration, gap to the previous launch"; cat $R/gpurun_out/timeline_issue.txt $R/gpurun_out/timeline_show.txt $R/gpurun_out/timeline_verify.txt) > $O/${TAG}_small_call_timeline.txt
 ls -la $O
