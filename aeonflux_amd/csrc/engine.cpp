@@ -553,7 +553,7 @@ void Assembler::msm_split(std::vector<afx_msm_job> jobs, std::vector<afx_compres
       // fixed-base terms go six to a part: 120 additions, well under the 252 doublings + 64 additions of a variable-base chain
       // (the second commitment of an issuance proof has n + 3 of them: one lane with 380 additions was the longest chain of a
       // small issue call)
-      // (a segmenting pass, whose variable-base chains are a quarter as long, takes them two to a part)
+      // (a segmenting pass, whose variable-base chains are a quarter or an eighth as long, takes them two or one to a part)
       const uint32_t FIXED_PER_PART = S >= 8 ? 1 : S > 1 ? 2 : 6;
       uint32_t parts = (j.n_var + var_per_part - 1) / var_per_part + (j.n_terms - j.n_var + FIXED_PER_PART - 1) / FIXED_PER_PART;
       for (uint32_t t = 0; t < j.n_var; t++) if (segmented(j.term[t])) parts += S - 1;
