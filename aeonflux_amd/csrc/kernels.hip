@@ -1557,6 +1557,121 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_hash_coop(const afx_hash_program*
   if (prog->save_state && holds && live) prog->save_state[(size_t)w * count + item] = st;
 }
 
+// k_hash_coop64: the same with a whole WAVE per (item, program) - for the few transcripts of a very small pass, whose permutations in
+// a row are what the call waits for (an issuance's rng squeezes 21 blindings out of one sponge: 48 permutations).  Lanes 0..31 hold
+// the LOW 32-bit halves of the state's words in k_hash_coop's layout, lanes 32..63 the high halves: every move of a round is one
+// 32-bit move instead of two - three ds_bpermute_b32 a round instead of six, ten DPP moves instead of twenty - and the two places a
+// 64-bit rotation needs the other half (theta's rotation by one, rho) fetch it with v_permlane32_swap_b32 (gfx950: lanes 32..63 of
+// one register against lanes 0..31 of another, at VALU rate).  (Theta's column parities across the two DPP rows by v_permlane16_swap_b32
+// instead of the two shuffles: no faster - 253 against 248 us for an issuance's 48 records; the round is a chain of dependent moves.)  Same schedule, same bytes; afxk_hash_coop picks it while the launch's
+// groups leave most of the device idle.
+AFX_DEV uint32_t kc_other_half(uint32_t v, bool upper) {
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // r[0]: lanes 32..63 now hold v's lanes 0..31; r[1]: lanes 0..31 hold v's 32..63
+  return upper ? r[0] : r[1];
+}
+template <int CTRL>
+AFX_DEV uint32_t kc_shift32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+template <int NEAR, int WRAP>
+AFX_DEV uint32_t kc_fetch32(uint32_t v, bool wraps) {
+  const uint32_t n = kc_shift32<NEAR>(v), w = kc_shift32<WRAP>(v);
+  return wraps ? w : n;
+}
+__global__ void __launch_bounds__(AFX_BLOCK) k_hash_coop64(const afx_hash_program* __restrict__ progs, const afx_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
+  const afx_hash_program* prog = row_job(progs, rows);
+  const afx_pass pass = passes[row_pass_index(rows)];   // wave-uniform: scalar loads
+  const uint32_t count = pass.count;
+  uint32_t* __restrict__ bad = pass.bad;
+  const uint32_t group = blockIdx.x * (blockDim.x >> 6) + ((uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6);   // a wave per (item, program)
+  if (group >= count) return;   // wave-uniform
+  const uint32_t item = group;
+  const uint32_t L = threadIdx.x & 63u, g = L & 31u;
+  const bool upper = L >= 32u;
+  const bool holds = g < 15u || (g >= 16u && g <= 25u);   // lanes 15 and 26..31 of each half take part in the moves only (never as a source)
+  const uint32_t w = !holds ? 24u : g < 15u ? g : g - 1u, x = w % 5u;
+  const uint32_t rho = KECCAK_RHO[w], rs = rho & 31u;
+  const bool rho_swaps = rho >= 32u;
+  const int half_base = (int)(L & 32u);
+  const int a_c0 = 4 * (half_base + (int)x), a_c1 = 4 * (half_base + 16 + (int)x), a_pi = 4 * (half_base + (int)kc_lane(KECCAK_PI_SRC[w]));
+  auto half_of = [&](uint64_t v) { return upper ? (uint32_t)(v >> 32) : (uint32_t)v; };
+  uint32_t st = half_of(prog->load_state ? prog->load_state[(size_t)w * count + item] : prog->init_state[w]);
+  const uint32_t nrec = prog->n_records;
+  const uint32_t wl = w < 21u ? w : 0u;
+  afx_hash_word hw_n = prog->records[0].w[wl];
+  uint64_t lo_n = 0, hi_n = 0;
+  if (w < 21u && hw_n.field >= 0) {
+    const uint8_t* f = prog->fields[hw_n.field] + 32ull * item;
+    lo_n = (hw_n.q >= 0) ? load_u64(f + 8 * hw_n.q) : 0ull;
+    hi_n = (hw_n.q < 3) ? load_u64(f + 8 * (hw_n.q + 1)) : 0ull;
+  }
+#pragma unroll 1
+  for (uint32_t r = 0; r < nrec; r++) {
+    const afx_hash_record* rec = &prog->records[r];
+    const afx_hash_word hw = hw_n;
+    const uint64_t lo = lo_n, hi = hi_n;
+    if (r + 1 < nrec) {   // uniform: the next record's words, requested while this one permutes
+      hw_n = prog->records[r + 1].w[wl];
+      lo_n = 0; hi_n = 0;
+      if (w < 21u && hw_n.field >= 0) {
+        const uint8_t* f = prog->fields[hw_n.field] + 32ull * item;
+        lo_n = (hw_n.q >= 0) ? load_u64(f + 8 * hw_n.q) : 0ull;
+        hi_n = (hw_n.q < 3) ? load_u64(f + 8 * (hw_n.q + 1)) : 0ull;
+      }
+    }
+    if (w < 21u) {
+      uint64_t v = hw.c;
+      if (hw.field >= 0) {
+        const uint32_t sh = 8u * hw.r;
+        const uint64_t val = sh ? ((lo >> sh) | (hi << (64u - sh))) : lo;
+        v ^= val & hw.fmask;
+      }
+      st = (st & half_of(hw.keep)) ^ half_of(v);
+    }
+#pragma unroll
+    for (int round = 0; round < 24; round++) {
+      // theta: column parities as in k_hash_coop, one half each; the rotation by one takes the top bit of the OTHER half's parity
+      const uint32_t p = st ^ kc_shift32<KC_SHL5>(st) ^ (g < 16u ? kc_shift32<KC_SHL10>(st) : 0u);
+      const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(a_c0, (int)p) ^ (uint32_t)__builtin_amdgcn_ds_bpermute(a_c1, (int)p);
+      const uint32_t cr = kc_fetch32<KC_SHL1, KC_SHR4>(c, x == 4u);   // column x + 1, this half
+      const uint32_t cro = kc_other_half(cr, upper);                   // ... and the other half
+      st ^= kc_fetch32<KC_SHR1, KC_SHL4>(c, x == 0u) ^ ((cr << 1) | (cro >> 31));
+      // rho: (A << s) | (B >> (32 - s)) with (A, B) = (mine, other) for a rotation under 32 bits, (other, mine) from 32 on; pi as a shuffle
+      const uint32_t so = kc_other_half(st, upper);
+      const uint32_t A = rho_swaps ? so : st, B = rho_swaps ? st : so;
+      const uint32_t rot = rs ? ((A << rs) | (B >> (32u - rs))) : A;
+      const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute(a_pi, (int)rot);
+      // chi along the row, iota on word 0
+      st = b ^ (~kc_fetch32<KC_SHL1, KC_SHR4>(b, x == 4u) & kc_fetch32<KC_SHL2, KC_SHR3>(b, x >= 3u));
+      if (w == 0u) st ^= upper ? (uint32_t)(KECCAK_RC[round] >> 32) : (uint32_t)KECCAK_RC[round];
+    }
+    if (rec->squeeze != AFX_SQ_NONE) {   // uniform: a property of the record
+      uint32_t xw[16];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        xw[2 * i] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * i, (int)st);
+        xw[2 * i + 1] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (32 + i), (int)st);
+      }
+      if (L == 0u) {
+        const sc c = sc_reduce512(xw);
+        uint32_t w8[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w8[i] = c.v[i];
+        if (rec->squeeze == AFX_SQ_CHALLENGE_COMPARE) {
+          const sc want = sc_load_item(prog->challenge, 32, item);
+          if (!sc_eq(c, want)) atomicOr(&bad[item], AFX_BAD_CHALLENGE);
+          if (prog->trace) enc_store(prog->trace, item, w8);
+        } else {
+          enc_store(prog->outs[rec->squeeze_out], item, w8);
+        }
+      }
+    }
+  }
+  if (prog->save_state && holds) {
+    // (a 64-bit store per word: the low half's lane writes, with the high half fetched from its partner)
+    const uint32_t other = kc_other_half(st, upper);
+    if (!upper) prog->save_state[(size_t)w * count + item] = (uint64_t)st | ((uint64_t)other << 32);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // status / utilities
 // ---------------------------------------------------------------------------------------------
@@ -1820,6 +1935,13 @@ hipError_t afxk_powers(hipStream_t s, const afx_powers_job* jobs, uint32_t njobs
   return hipGetLastError();
 }
 hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+  // a wave per (item, program) while that leaves the device mostly idle (AFX_HASH_WAVE=0: measurement aid, the 32-lane groups always)
+  static const bool wave_on = !(getenv("AFX_HASH_WAVE") && getenv("AFX_HASH_WAVE")[0] == '0');
+  if (wave_on && (uint64_t)max_count * nprogs <= 512) {
+    const uint32_t b64 = max_count <= 1 ? 64u : max_count <= 2 ? 128u : (uint32_t)AFX_BLOCK, per64 = b64 / 64;
+    hipLaunchKernelGGL(k_hash_coop64, dim3((max_count + per64 - 1) / per64, nprogs), dim3(b64), 0, s, progs, rows, passes);
+    return hipGetLastError();
+  }
   const uint32_t block = max_count <= 2 ? 64u : max_count <= 4 ? 128u : (uint32_t)AFX_BLOCK, per_block = block / 32;   // 32 lanes per item
   hipLaunchKernelGGL(k_hash_coop, dim3((max_count + per_block - 1) / per_block, nprogs), dim3(block), 0, s, progs, rows, passes);
   return hipGetLastError();

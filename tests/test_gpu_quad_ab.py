@@ -49,7 +49,9 @@ def digest():
 def test_four_wave_and_one_wave_chains_return_the_same_bytes():
     assert os.environ.get("AFX_QUAD_CHAINS", "1") != "0", "this process is meant to run the four-wave kernels"
     here = digest()
-    child = subprocess.run([sys.executable, "-c", "import tests.test_gpu_quad_ab as t; print(t.digest())"], cwd=ROOT,
-                           env=dict(os.environ, AFX_QUAD_CHAINS="0"), capture_output=True, text=True, timeout=600)
-    assert child.returncode == 0, child.stderr[-2000:]
-    assert child.stdout.strip().splitlines()[-1] == here
+    # (second child: the transcripts of these small passes on 32 lanes per item, k_hash_coop, instead of a wave each, k_hash_coop64)
+    for env in ({"AFX_QUAD_CHAINS": "0"}, {"AFX_HASH_WAVE": "0"}):
+        child = subprocess.run([sys.executable, "-c", "import tests.test_gpu_quad_ab as t; print(t.digest())"], cwd=ROOT,
+                               env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert child.returncode == 0, (env, child.stderr[-2000:])
+        assert child.stdout.strip().splitlines()[-1] == here, env

@@ -70,7 +70,8 @@ def digest(check_powers=False):
 def test_segmented_and_whole_chains_return_the_same_bytes():
     assert os.environ.get("AFX_SEGMENTS", "8") == "8" and os.environ.get("AFX_QUAD_CHAINS", "1") != "0", "this process is meant to run the default plan"
     here = digest(check_powers=True)
-    for env in ({"AFX_SEGMENTS": "1"}, {"AFX_SEGMENTS": "4"}, {"AFX_SEGMENTS": "2"}, {"AFX_QUAD_CHAINS": "0"}):
+    # (... and with the transcripts on 32 lanes per item instead of a wave each: kernels.hip k_hash_coop / k_hash_coop64)
+    for env in ({"AFX_SEGMENTS": "1"}, {"AFX_SEGMENTS": "4"}, {"AFX_SEGMENTS": "2"}, {"AFX_QUAD_CHAINS": "0"}, {"AFX_HASH_WAVE": "0"}):
         child = subprocess.run([sys.executable, "-c", "import tests.test_gpu_segments as t; print(t.digest())"], cwd=ROOT,
                                env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert child.returncode == 0, (env, child.stderr[-2000:])
