@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SIZES = (1, 3, 70, 257, 300)
+SIZES = (1, 3, 70, 257, 300, 600, 1100)   # (8 segments up to 256 items, 4 above; cached tables up to 512; the one-wave kernels once a stage has more than 1024 blocks)
 
 
 def digest(check_powers=False):
