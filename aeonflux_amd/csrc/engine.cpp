@@ -947,7 +947,7 @@ void Assembler::from_uniform(const uint8_t* wide, uint8_t* out_enc, int32_t* out
     pending_map_sums_.push_back(s);
     return;
   }
-  const afx_uniform_job j = { wide, out_enc, out_var, 0, 0 };
+  const afx_uniform_job j = { wide, out_enc, out_var };
   add_jobs(L_FROM_UNIFORM, std::vector<afx_uniform_job>(1, j));
 }
 void Assembler::reduce_wide(const uint8_t* wide, uint8_t* out) {

@@ -1723,10 +1723,6 @@ __global__ void __launch_bounds__(AFX_BLOCK, 2) k_from_uniform_jobs(const afx_un
   uint32_t w[16];
   enc_load(w, job.wide, 2 * item);
   enc_load(w + 8, job.wide, 2 * item + 1);
-  if (job.half) {   // (uniform) one of the two maps
-    var_store(job.out_var, count, item, ristretto_elligator(fe_frombytes(job.half == 1 ? w : w + 8)));
-    return;
-  }
   const ge_p3 P = ristretto_from_uniform(w);
   if (job.out_var) var_store(job.out_var, count, item, P);
   if (job.out_enc) {

@@ -106,9 +106,7 @@ typedef struct {
 /* rows of the small utility launches that open and close a plan */
 typedef struct { uint32_t* p; uint32_t v, n; } afx_fill_job;                                            /* p[0..n) = v                */
 typedef struct { const uint32_t* bad; uint8_t* status; uint32_t count, fail_code; } afx_finish_job;     /* status[i] = bad[i] ? code : 0 */
-/* RistrettoPoint::from_uniform_bytes.  half = 1, 2: only the Elligator map of the first / second 32 bytes, to out_var (small passes run
- * the two maps side by side and add them with k_pointop: Assembler::from_uniform) */
-typedef struct { const uint8_t* wide; uint8_t* out_enc; int32_t* out_var; uint32_t half, pad; } afx_uniform_job;
+typedef struct { const uint8_t* wide; uint8_t* out_enc; int32_t* out_var; } afx_uniform_job;            /* RistrettoPoint::from_uniform_bytes */
 typedef struct { const uint8_t* wide; uint8_t* out; } afx_reduce_job;                                   /* Scalar::from_bytes_mod_order_wide  */
 
 /* variable point storage: struct-of-arrays, limb (c*9+l) of item i at base[(c*9+l)*count + i] */

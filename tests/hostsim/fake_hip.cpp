@@ -300,8 +300,6 @@ hipError_t afxk_fill_u32(hipStream_t, const afx_fill_job* j, uint32_t n, const a
 }
 hipError_t afxk_from_uniform_jobs(hipStream_t, const afx_uniform_job* j, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
   for (uint32_t i = 0; i < n; i++) { hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e; CHECK_PTR(job_of(j, rows, i).wide); CHECK_PTR(job_of(j, rows, i).out_enc); CHECK_PTR(job_of(j, rows, i).out_var);
-    const afx_uniform_job& u = job_of(j, rows, i);
-    if (u.half > 2 || (u.half && (u.out_enc || !u.out_var))) return hipErrorInvalidValue;   // one of the two maps: to a variable, never encoded
   }
   return hipSuccess;
 }
