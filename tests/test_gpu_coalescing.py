@@ -190,3 +190,48 @@ def test_large_calls_and_setters_between_collected_calls(world):
     assert rounds >= 1
     ictx.close()
     uctx.close()
+
+
+def test_collected_calls_of_dozens_of_items_cross_the_pass_size_thresholds():
+    """Calls of 40 ... 120 items from 10 threads: the passes they share hold a few hundred to over a thousand items, on both sides of
+    where a small prover pass changes form (8 segments up to 256 items, 4 above; cached tables up to 512; the one-wave kernels beyond a
+    launch's 1024 blocks - engine.cpp Assembler::segments, msm_list) - and of where a joined call no longer fits the item slots of the
+    pass that is collecting.  Every issued and shown byte against the oracle, as above."""
+    import aeonflux_amd as afx
+    cnt = 130
+    d = make_credentials(N, "SPES", cnt, SEED + b"-dozens")
+    take, user = d["take"], d["user"]
+    kinds = list(d["creds"][0]["kinds"])
+    kinds[2] = 4
+    kinds[3] = 1
+    kps = [user.keypair_derive(take(64)) for _ in range(cnt)]
+    zw, sd, es = [take(64) for _ in range(cnt)], [take(32) for _ in range(cnt)], [take(32) for _ in range(cnt)]
+    shown = []
+    for c, kp, z, s, e in zip(d["creds"], kps, zw, sd, es):
+        st, p = user.show(kinds, c["values"], c["t"], c["U"], c["V"], kp, z, s, e)
+        assert st == 0
+        shown.append(p)
+    w = dict(d=d, show_kinds=kinds, nsp=1, kps=kps, zw=zw, sd=sd, es=es, shown=shown)
+    ictx, uctx = afx.Context(d["params"], d["key"], d["ip"]), afx.Context(d["params"], None, d["ip"])
+    errs = []
+
+    def work(t):
+        try:
+            for r in range(6):
+                n = 40 + 16 * ((t + r) % 6)          # 40 ... 120 items a call
+                lo = (7 * t + 11 * r) % (cnt - n + 1)
+                (check_issue if (t + r) % 2 else check_show)(afx, ictx if (t + r) % 2 else uctx, w, lo, lo + n)
+        except BaseException as e:   # noqa
+            errs.append((t, repr(e)[:400]))
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(10)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs[:3]
+    si, su = co_stats(afx, ictx), co_stats(afx, uctx)
+    assert si["calls"] + su["calls"] == 60 and si["sessions"] < si["calls"] and su["sessions"] < su["calls"], (si, su)
+    assert max(si["items"], su["items"]) > 1000
+    ictx.close()
+    uctx.close()
