@@ -157,7 +157,7 @@ def one_context(args):
                                                               "collection off (calls/s p99)", "K contexts (calls/s p99)", "K x CPU thread"))
         for op in ops:
             for k in threads:
-                calls = max(50, min(400, 6000 // k))
+                calls = args.calls if args.calls else max(50, min(400, 6000 // k))
                 row = []
                 for mode in (["one"], ["one", "0", "0"], ["each"]):
                     r = subprocess.run([exe, files[op], op, str(k), str(calls), str(args.items)] + mode, capture_output=True, text=True, timeout=600)
@@ -212,5 +212,6 @@ if __name__ == "__main__":
     ap.add_argument("--threads", default="1,2,4,8,16,32,64")
     ap.add_argument("--items", type=int, default=1)
     ap.add_argument("--ops", default="verify,issue,show")
+    ap.add_argument("--calls", type=int, default=0, help="calls per thread (default: about 6000 calls per row in all, 50 ... 400 per thread)")
     a = ap.parse_args()
     one_context(a) if a.one_context else context_each()
