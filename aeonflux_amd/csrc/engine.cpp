@@ -93,6 +93,7 @@ uint8_t* Assembler::ws_alloc(size_t bytes) {
 }
 int32_t* Assembler::new_var() { return (int32_t*)ws_alloc(sizeof(int32_t) * AFX_VAR_DWORDS * (size_t)count); }
 uint8_t* Assembler::new_enc() { return ws_alloc(32 * (size_t)count); }
+uint8_t* Assembler::new_wide() { return ws_alloc(64 * (size_t)count); }
 uint64_t* Assembler::new_state() { return (uint64_t*)ws_alloc(sizeof(uint64_t) * 25 * (size_t)count); }
 size_t Assembler::blob_alloc(size_t bytes, size_t align) {
   const size_t off = (blob_.size() + align - 1) & ~(align - 1);
@@ -221,6 +222,11 @@ void Assembler::hash(const std::vector<afx_hash_program>& progs) {
   flush_encodings();   // encodings still queued (Assembler::pointop, compress_also, a small pass's stages) are launched before their reader
   for (const afx_hash_program& p : progs) stats.keccak_permutations += p.n_records;
   add_jobs(L_HASH, progs);
+  if (!pending_reductions_.empty()) {   // the blindings these transcripts squeezed out unreduced (SchnorrBuilder::prove_compact, small passes)
+    std::vector<afx_reduce_job> rj;
+    rj.swap(pending_reductions_);
+    add_jobs(L_REDUCE_WIDE, rj);
+  }
 }
 // Width-5 NAF of a canonical scalar (little-endian 32 bytes): digits in {0, +-1, +-3, ..., +-15}, at most one
 // nonzero digit in any 5 consecutive positions; returns the position of the highest nonzero digit (-1 for zero).
@@ -968,6 +974,7 @@ int Assembler::finish_plan(Plan& out, uint8_t* in_base, size_t in_bytes, uint8_t
   if (!plan_error.empty()) { set_error(plan_error); return AFX_E_BAD_ARGS; }
   if (!pending_cjobs_.empty()) { set_error("an encoding queued by compress_also() was never launched"); return AFX_E_BAD_ARGS; }
   if (!pending_maps_.empty() || !pending_map_sums_.empty()) { set_error("internal: from_uniform's maps were never launched"); return AFX_E_BAD_ARGS; }
+  if (!pending_reductions_.empty()) { set_error("internal: blindings squeezed out wide were never reduced"); return AFX_E_BAD_ARGS; }
   if (launches.empty() || launches[0].kind != L_FILL_BAD) { set_error("internal: plan without its opening launch"); return AFX_E_BAD_ARGS; }
   const afx_fill_job fj = { bad_, fail_all ? AFX_BAD_SHAPE : 0u, count };
   memcpy(blob_.data() + launches[0].jobs_off, &fj, sizeof fj);
@@ -1537,11 +1544,20 @@ void SchnorrBuilder::prove_compact(const uint8_t* rng_seed_dev, uint8_t* challen
   }
   rng.meta_ad_const((const uint8_t*)"rng", 3, false);
   rng.key_hole32(field_of(rng_seed_dev));
-  std::vector<uint8_t*> blind(ns);
+  std::vector<uint8_t*> blind(ns), wide(ns, nullptr);
   for (size_t i = 0; i < ns; i++) {
     blind[i] = as_.new_enc();
     rng.meta_ad_const(len64, 4, false);
-    rng.prf64(AFX_SQ_SCALAR_OUT, (uint32_t)i);
+    // a small pass: the 64 bytes leave the sponge as they are and ONE launch behind the hash reduces all the blindings side by side
+    // (Assembler::hash) - the reduction of each between two permutations, on the sponge's lane, was 2.7 us of an issuance's 21
+    if (as_.small()) {
+      wide[i] = as_.new_wide();
+      rng.prf64(AFX_SQ_WIDE_OUT, (uint32_t)i);
+      const afx_reduce_job rj = { wide[i], blind[i] };
+      as_.pending_reductions_.push_back(rj);
+    } else {
+      rng.prf64(AFX_SQ_SCALAR_OUT, (uint32_t)i);
+    }
   }
   // the rng's last prf closes on a completed record, so emit() sees everything
   // commitments R_j = sum blind[s] * P
@@ -1591,7 +1607,7 @@ void SchnorrBuilder::prove_compact(const uint8_t* rng_seed_dev, uint8_t* challen
   }
   // programs are made after all field_of() calls so both share the final field table
   afx_hash_program pr = make_program(rng);
-  pr.outs = as_.put_ptrs(blind.data(), blind.size());
+  pr.outs = as_.put_ptrs(as_.small() ? wide.data() : blind.data(), blind.size());
   pr.n_outs = (uint32_t)blind.size();
   rng_hash.push_back(pr);
   afx_hash_program pc = make_program(sim_);

@@ -271,6 +271,7 @@ class Assembler {
   // workspace (addresses relative to the plan's provisional workspace base)
   int32_t* new_var();         // extended point, SoA [36][count]
   uint8_t* new_enc();         // [count][32]
+  uint8_t* new_wide();        // [count][64]
   uint64_t* new_state();      // [25][count]
   size_t blob_bytes() const { return blob_.size(); }
 
@@ -339,6 +340,7 @@ class Assembler {
   void flush_maps();
   std::vector<afx_decode_job> pending_maps_;         // Elligator maps queued by from_uniform (small passes): they ride in the next decode launch
   std::vector<afx_pointop_job> pending_map_sums_;    // ... and the additions of the pairs
+  std::vector<afx_reduce_job> pending_reductions_;   // blindings a small pass's transcripts squeeze out as 64 bytes: reduced by one launch behind the hash
   void add_walk_rows(Launch& l, uint32_t per_row);   // the afx_walk_row array of a k_compress2x / k_negenc / k_table_affine launch (+ its prefix scratch)
   std::set<const int32_t*> half_bases_;            // variables that hold HALF their point (producers with leave_half)
   std::vector<afx_compress_job> pending_cjobs_;    // compress_also()

@@ -1411,7 +1411,11 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_hash(const afx_hash_program* __re
       st[w] = (st[w] & hw.keep) ^ v;
     }
     keccak_f1600(st);
-    if (rec->squeeze != AFX_SQ_NONE) {
+    if (rec->squeeze == AFX_SQ_WIDE_OUT) {   // uniform
+      uint64_t* o = reinterpret_cast<uint64_t*>(prog->outs[rec->squeeze_out] + 64ull * item);
+#pragma unroll
+      for (int i = 0; i < 8; i++) o[i] = st[i];
+    } else if (rec->squeeze != AFX_SQ_NONE) {
       uint32_t x[16];
 #pragma unroll
       for (int i = 0; i < 8; i++) { x[2 * i] = (uint32_t)st[i]; x[2 * i + 1] = (uint32_t)(st[i] >> 32); }
@@ -1535,7 +1539,9 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_hash_coop(const afx_hash_program*
       st = b ^ (~kc_row_fetch<KC_SHL1, KC_SHR4>(b, x == 4u) & kc_row_fetch<KC_SHL2, KC_SHR3>(b, x >= 3u));
       if (w == 0u) st ^= KECCAK_RC[round];
     }
-    if (rec->squeeze != AFX_SQ_NONE) {   // uniform: a property of the record
+    if (rec->squeeze == AFX_SQ_WIDE_OUT) {   // uniform: the words go out as they are, a lane each
+      if (holds && w < 8u && live) *reinterpret_cast<uint64_t*>(prog->outs[rec->squeeze_out] + 64ull * item + 8u * w) = st;
+    } else if (rec->squeeze != AFX_SQ_NONE) {   // uniform: a property of the record
       uint32_t xw[16];
 #pragma unroll
       for (int i = 0; i < 8; i++) { const uint64_t t = shfl64(st, (uint32_t)i); xw[2 * i] = (uint32_t)t; xw[2 * i + 1] = (uint32_t)(t >> 32); }
@@ -1643,7 +1649,9 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_hash_coop64(const afx_hash_progra
       st = b ^ (~kc_fetch32<KC_SHL1, KC_SHR4>(b, x == 4u) & kc_fetch32<KC_SHL2, KC_SHR3>(b, x >= 3u));
       if (w == 0u) st ^= upper ? (uint32_t)(KECCAK_RC[round] >> 32) : (uint32_t)KECCAK_RC[round];
     }
-    if (rec->squeeze != AFX_SQ_NONE) {   // uniform: a property of the record
+    if (rec->squeeze == AFX_SQ_WIDE_OUT) {   // uniform: the half words go out as they are, a lane each
+      if (holds && w < 8u) *reinterpret_cast<uint32_t*>(prog->outs[rec->squeeze_out] + 64ull * item + 8u * w + (upper ? 4u : 0u)) = st;
+    } else if (rec->squeeze != AFX_SQ_NONE) {   // uniform: a property of the record
       uint32_t xw[16];
 #pragma unroll
       for (int i = 0; i < 8; i++) {
@@ -1933,7 +1941,7 @@ hipError_t afxk_powers(hipStream_t s, const afx_powers_job* jobs, uint32_t njobs
 hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
   // a wave per (item, program) while that leaves the device mostly idle (AFX_HASH_WAVE=0: measurement aid, the 32-lane groups always)
   static const bool wave_on = !(getenv("AFX_HASH_WAVE") && getenv("AFX_HASH_WAVE")[0] == '0');
-  if (wave_on && (uint64_t)max_count * nprogs <= 512) {
+  if (wave_on && (uint64_t)max_count * nprogs <= 2048) {
     const uint32_t b64 = max_count <= 1 ? 64u : max_count <= 2 ? 128u : (uint32_t)AFX_BLOCK, per64 = b64 / 64;
     hipLaunchKernelGGL(k_hash_coop64, dim3((max_count + per64 - 1) / per64, nprogs), dim3(b64), 0, s, progs, rows, passes);
     return hipGetLastError();

@@ -298,6 +298,9 @@ typedef struct {
 #define AFX_SQ_NONE 0
 #define AFX_SQ_CHALLENGE_COMPARE 1   /* reduce 64 bytes mod l, compare with challenge[item]        */
 #define AFX_SQ_SCALAR_OUT 2          /* reduce 64 bytes mod l, store to outs[squeeze_out][item]    */
+#define AFX_SQ_WIDE_OUT 3            /* store the 64 bytes as they are to outs[squeeze_out] ([count][64]): a small pass reduces all of a
+                                        transcript's blindings in ONE k_reduce_wide launch behind the hash, a lane each, instead of one
+                                        after the other on the sponge's lane between its permutations (Assembler::hash)          */
 
 typedef struct {
   afx_hash_word w[21];   /* bytes 0..167 of the block: rate (166) + the two pad bytes            */
