@@ -186,6 +186,7 @@ def lib():
         _LIB.afx_ctx_get_core_clock_mhz.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         _LIB.afx_ctx_get_core_clock_samples.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_uint32)]
         _LIB.afx_ctx_set_coalescing.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        _LIB.afx_ctx_set_host_copy_threads.argtypes = [C.c_void_p, C.c_uint32]
         _LIB.afx_ctx_get_coalescing_stats.argtypes = [C.c_void_p, C.POINTER(CoalescingStats)]
         _LIB.afx_ctx_get_plan_cache_stats.argtypes = [C.c_void_p, C.POINTER(PlanCacheStats)]
         _LIB.afx_verify_presentations_range.argtypes = [C.c_void_p, C.POINTER(Shape), C.POINTER(PresentationSoA), C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
@@ -323,6 +324,11 @@ class Context:
     def set_coalescing(self, max_wait_us=2000, max_items=4096):
         """concurrent small host-pointer calls share launch sets (on by default); max_items=0 switches it off (afx_ctx_set_coalescing)"""
         check(lib().afx_ctx_set_coalescing(self.h, max_wait_us, max_items))
+
+    def set_host_copy_threads(self, threads):
+        """host threads that gather a large host-pointer call's rows into the pinned image; 0 = the runtime's pageable copies
+        (afx_ctx_set_host_copy_threads)"""
+        check(lib().afx_ctx_set_host_copy_threads(self.h, threads))
 
     def coalescing_stats(self):
         s = CoalescingStats()

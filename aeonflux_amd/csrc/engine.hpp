@@ -4,7 +4,9 @@
 // so the statement code in statements.cpp reads like /root/reference/src/nizk/*.rs.
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <sched.h>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <map>
@@ -50,6 +52,60 @@ using Enc = std::array<uint8_t, 32>;
 
 namespace afx { struct Plan; struct Session; }
 struct Stager;
+
+namespace afx {
+// The CPUs of the NUMA node a device hangs off, intersected with what the process may use (plans.cpp; nothing where the topology
+// is not exposed: containers, the host simulation).  /sys/bus/pci/devices/<bdf>/numa_node -> /sys/devices/system/node/node<N>/cpulist;
+// AFX_SYSFS_ROOT (tests) stands in for "/".
+struct NodeCpus {
+  bool valid = false;
+  cpu_set_t set;
+};
+NodeCpus cpus_of_device(int device);
+// pins the calling thread for the scope's life (a thread the library started simply ends; a caller's own thread gets its mask back)
+struct PinScope {
+  bool restore = false;
+  cpu_set_t saved;
+  PinScope(const NodeCpus& n, bool caller_thread) {
+    if (!n.valid) return;
+    if (caller_thread) restore = sched_getaffinity(0, sizeof saved, &saved) == 0;
+    (void)sched_setaffinity(0, sizeof n.set, &n.set);
+  }
+  ~PinScope() { if (restore) (void)sched_setaffinity(0, sizeof saved, &saved); }
+  PinScope(const PinScope&) = delete;
+  PinScope& operator=(const PinScope&) = delete;
+};
+// Host copies of a LARGE host-pointer call (plans.cpp Stager::upload / drain): the caller's pageable rows are gathered into the
+// lane's pinned image by a few threads that run on the device's NUMA node, and the image goes to HBM in one transfer per
+// contiguous run.  What this replaces: 75 hipMemcpyAsync calls per slice out of pageable memory, which the runtime carries out on
+// the CALLING thread wherever the caller's scheduler put it - on the far socket of a two-socket host the slice's copy then takes
+// longer than the previous slice's kernels and the device waits (the driver's round-5 box: 90.7 % of the device-resident rate
+// against 96-97 % elsewhere).  One job at a time (large calls have the context to themselves); the caller's thread copies too.
+struct CopyPool {
+  struct Piece { uint8_t* dst; const uint8_t* src; size_t len; };
+  struct Job {
+    std::vector<Piece> pieces;
+    std::atomic<size_t> next{ 0 }, left{ 0 };
+  };
+  explicit CopyPool(int device, uint32_t threads);   // threads - 1 workers (the caller is the first)
+  ~CopyPool();
+  CopyPool(const CopyPool&) = delete;
+  CopyPool& operator=(const CopyPool&) = delete;
+  void run(std::vector<Piece> pieces);               // returns when every piece has been copied
+  uint32_t threads() const { return (uint32_t)workers_.size() + 1; }
+  static void cut(std::vector<Piece>& out, uint8_t* dst, const uint8_t* src, size_t len);   // appends [src, src + len) in pieces of at most 1 MB
+ private:
+  void work(Job& j);
+  void loop();
+  NodeCpus node_;
+  std::mutex mu_, run_mu_;
+  std::condition_variable cv_work_, cv_done_;
+  std::shared_ptr<Job> cur_;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+  std::vector<std::thread> workers_;
+};
+}  // namespace afx
 
 struct afx_ctx {
   std::recursive_mutex mu;   // the context's host state (workspace, staging, plan ring and cache) has one user at a time; see `co` below
@@ -186,6 +242,10 @@ struct afx_ctx {
   unsigned lane_next = 0;
   int force_lane = -1;   // >= 0: every *_dev call runs on this lane (host-pointer front ends pick the lane they staged on)
   Stager* cur_stager = nullptr;   // the host-pointer front end whose *_dev call is running (its staged ranges: plan reuse), or null
+  // afx_ctx_set_host_copy_threads: how many host threads gather a large host-pointer call's rows into the lane's pinned image
+  // (afx::CopyPool, made at the first such call); 0: the runtime's own copies out of pageable memory on the caller's thread
+  uint32_t host_copy_threads = 4;
+  std::unique_ptr<afx::CopyPool> copy_pool;
   // optional per-launch HIP-event timing on `stream` (bench.py's roofline figure)
   bool timing = false;
   struct TimedLaunch { int kind; hipEvent_t start, stop; };

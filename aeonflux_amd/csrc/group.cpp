@@ -18,65 +18,14 @@
 #include <vector>
 #include "statements.hpp"
 
-// Host threads follow their devices: a member's thread runs on the CPUs of the NUMA node its GPU hangs off
-// (/sys/bus/pci/devices/<bdf>/numa_node -> /sys/devices/system/node/node<N>/cpulist, intersected with what the process may use), so
-// that the pageable-to-pinned staging copies and the pinned buffers themselves (first touched by that thread) stay on the node the
-// PCIe root of the device belongs to.  Eight members pulling ~6 GB/s each out of the caller's arrays through ONE node's memory
-// controllers was the review's concern; nothing is pinned where the topology is not exposed (containers, the host simulation).
-struct NodeCpus {
-  bool valid = false;
-  cpu_set_t set;
-};
-// AFX_SYSFS_ROOT (tests): a directory that stands in for "/" when the topology is read - tests/test_hostsim.py gives the host
-// simulation a two-socket tree there
-static NodeCpus cpus_of_device(int device) {
-  NodeCpus out;
-  char bdf[64] = { 0 };
-  if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess || !bdf[0]) return out;
-  for (char* p = bdf; *p; p++) *p = (char)tolower((unsigned char)*p);
-  const char* root_env = getenv("AFX_SYSFS_ROOT");
-  const std::string root = root_env ? root_env : "";
-  int node = -1;
-  {
-    FILE* f = fopen((root + "/sys/bus/pci/devices/" + bdf + "/numa_node").c_str(), "r");
-    if (!f) return out;
-    if (fscanf(f, "%d", &node) != 1) node = -1;
-    fclose(f);
-  }
-  if (node < 0) return out;
-  FILE* f = fopen((root + "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
-  if (!f) return out;
-  char list[4096] = { 0 };
-  const size_t got = fread(list, 1, sizeof list - 1, f);
-  fclose(f);
-  list[got] = 0;
-  cpu_set_t allowed, want;
-  CPU_ZERO(&want);
-  if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
-  for (char* tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
-    int a = 0, b = 0;
-    const int k = sscanf(tok, "%d-%d", &a, &b);
-    if (k < 1) continue;
-    if (k == 1) b = a;
-    for (int c = a; c <= b && c < CPU_SETSIZE; c++)
-      if (c >= 0 && CPU_ISSET(c, &allowed)) CPU_SET(c, &want);
-  }
-  if (CPU_COUNT(&want) == 0) return out;
-  out.set = want;
-  out.valid = true;
-  return out;
-}
-// pins the calling thread for the scope's life (a thread the group started simply ends; the caller's own thread gets its mask back)
-struct PinScope {
-  bool restore = false;
-  cpu_set_t saved;
-  PinScope(const NodeCpus& n, bool caller_thread) {
-    if (!n.valid) return;
-    if (caller_thread) restore = sched_getaffinity(0, sizeof saved, &saved) == 0;
-    (void)sched_setaffinity(0, sizeof n.set, &n.set);
-  }
-  ~PinScope() { if (restore) (void)sched_setaffinity(0, sizeof saved, &saved); }
-};
+// Host threads follow their devices: a member's thread runs on the CPUs of the NUMA node its GPU hangs off (afx::cpus_of_device,
+// plans.cpp), so that the pageable-to-pinned staging copies and the pinned buffers themselves (first touched by that thread) stay
+// on the node the PCIe root of the device belongs to.  Eight members pulling ~6 GB/s each out of the caller's arrays through ONE
+// node's memory controllers was the review's concern; nothing is pinned where the topology is not exposed (containers, the host
+// simulation).
+using afx::NodeCpus;
+using afx::PinScope;
+using afx::cpus_of_device;
 
 struct afx_group {
   std::vector<afx_ctx*> members;

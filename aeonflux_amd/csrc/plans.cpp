@@ -1,8 +1,119 @@
 // How a statement's plan gets to the device: assembled (or taken from the context's cache of position-independent plans),
 // placed and launched - alone, or together with the plans of other small calls collected by a Session - and how host-pointer
 // front ends stage their arrays (Stager, host_pipe).  Declarations and the design notes: statements.hpp, engine.hpp (afx::Plan).
+#include <ctype.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include "statements.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// where a device's host threads run; the copy pool of large host-pointer calls
+// ------------------------------------------------------------------------------------------------
+afx::NodeCpus afx::cpus_of_device(int device) {
+  NodeCpus out;
+  char bdf[64] = { 0 };
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess || !bdf[0]) return out;
+  for (char* p = bdf; *p; p++) *p = (char)tolower((unsigned char)*p);
+  const char* root_env = getenv("AFX_SYSFS_ROOT");
+  const std::string root = root_env ? root_env : "";
+  int node = -1;
+  {
+    FILE* f = fopen((root + "/sys/bus/pci/devices/" + bdf + "/numa_node").c_str(), "r");
+    if (!f) return out;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+  }
+  if (node < 0) return out;
+  FILE* f = fopen((root + "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
+  if (!f) return out;
+  char list[4096] = { 0 };
+  const size_t got = fread(list, 1, sizeof list - 1, f);
+  fclose(f);
+  list[got] = 0;
+  cpu_set_t allowed, want;
+  CPU_ZERO(&want);
+  if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
+  for (char* tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+    int a = 0, b = 0;
+    const int k = sscanf(tok, "%d-%d", &a, &b);
+    if (k < 1) continue;
+    if (k == 1) b = a;
+    for (int c = a; c <= b && c < CPU_SETSIZE; c++)
+      if (c >= 0 && CPU_ISSET(c, &allowed)) CPU_SET(c, &want);
+  }
+  if (CPU_COUNT(&want) == 0) return out;
+  out.set = want;
+  out.valid = true;
+  return out;
+}
+
+afx::CopyPool::CopyPool(int device, uint32_t threads) : node_(cpus_of_device(device)) {
+  // no more threads than the node (or, with the topology hidden, the process) has CPUs for
+  cpu_set_t allowed;
+  uint32_t cpus = 1;
+  if (node_.valid) cpus = (uint32_t)CPU_COUNT(&node_.set);
+  else if (sched_getaffinity(0, sizeof allowed, &allowed) == 0) cpus = (uint32_t)CPU_COUNT(&allowed);
+  threads = std::max<uint32_t>(1, std::min(threads, cpus));
+  for (uint32_t i = 1; i < threads; i++) {
+    try { workers_.emplace_back([this] { loop(); }); } catch (const std::system_error&) { break; }   // (fewer threads copy, nothing fails)
+  }
+}
+afx::CopyPool::~CopyPool() {
+  { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+  cv_work_.notify_all();
+  for (std::thread& t : workers_) t.join();
+}
+void afx::CopyPool::cut(std::vector<Piece>& out, uint8_t* dst, const uint8_t* src, size_t len) {
+  static constexpr size_t PIECE = size_t(1) << 20;
+  for (size_t o = 0; o < len; o += PIECE) out.push_back({ dst + o, src + o, std::min(PIECE, len - o) });
+}
+void afx::CopyPool::work(Job& j) {
+  const size_t n = j.pieces.size();
+  for (;;) {
+    const size_t i = j.next.fetch_add(1, std::memory_order_relaxed);
+    if (i >= n) return;
+    const Piece& p = j.pieces[i];
+    memcpy(p.dst, p.src, p.len);
+    if (j.left.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+      std::lock_guard<std::mutex> g(mu_);
+      cv_done_.notify_all();
+    }
+  }
+}
+void afx::CopyPool::loop() {
+  PinScope pin(node_, false);
+  uint64_t seen = 0;
+  std::unique_lock<std::mutex> lk(mu_);
+  for (;;) {
+    cv_work_.wait(lk, [&] { return stop_ || gen_ != seen; });
+    if (stop_) return;
+    seen = gen_;
+    std::shared_ptr<Job> j = cur_;   // (a worker that wakes after the job is over finds none, or one with nothing left to take)
+    if (!j) continue;
+    lk.unlock();
+    work(*j);
+    lk.lock();
+  }
+}
+void afx::CopyPool::run(std::vector<Piece> pieces) {
+  if (pieces.empty()) return;
+  std::lock_guard<std::mutex> one(run_mu_);
+  std::shared_ptr<Job> j = std::make_shared<Job>();
+  j->pieces = std::move(pieces);
+  j->left.store(j->pieces.size());
+  if (!workers_.empty()) {
+    { std::lock_guard<std::mutex> g(mu_); cur_ = j; gen_++; }
+    cv_work_.notify_all();
+  }
+  {
+    // the caller copies too - from the device's node for the duration, like a group member's thread (its mask comes back)
+    PinScope pin(node_, true);
+    work(*j);
+  }
+  std::unique_lock<std::mutex> lk(mu_);
+  cv_done_.wait(lk, [&] { return j->left.load(std::memory_order_acquire) == 0; });
+  cur_.reset();
+}
 
 // ------------------------------------------------------------------------------------------------
 // run_chunked
@@ -188,6 +299,45 @@ int Stager::upload() {
     AFX_HIP(hipEventRecord(L.pin_in_done, L.stream));
     return AFX_OK;
   }
+  if (c->host_copy_threads && in_bytes > pack_limit() && !copies.empty()) {
+    // A large slice: its rows are gathered into the lane's pinned image by the context's copy pool (threads on the device's
+    // NUMA node, the caller's among them) and go to HBM as one transfer per contiguous run of the staging area - instead of one
+    // runtime copy per row out of pageable memory on the caller's thread, wherever that runs (afx::CopyPool, engine.hpp).
+    // The image is the runs packed one behind the other: what lies between them (kernel scratch: reserve()) is not sent.
+    struct Run { size_t off, len, img; };
+    std::vector<Run> runs;
+    size_t img_bytes = 0;
+    for (const Copy& k : copies) {   // (in staging order: add() / add_rows() only ever append)
+      if (!runs.empty() && k.off >= runs.back().off && k.off <= runs.back().off + runs.back().len + 4096) {
+        runs.back().len = std::max(runs.back().len, k.off + k.len - runs.back().off);
+      } else {
+        runs.push_back({ k.off, k.len, 0 });
+      }
+    }
+    for (Run& r : runs) { r.img = img_bytes; img_bytes += (r.len + 255) & ~size_t(255); }
+    if (!c->copy_pool) {
+      try { c->copy_pool.reset(new afx::CopyPool(c->device, c->host_copy_threads)); }
+      catch (const std::exception& e) { set_error(std::string("copy pool: ") + e.what()); return AFX_E_NO_MEMORY; }
+    }
+    if (!L.pin_in_done) AFX_HIP(hipEventCreateWithFlags(&L.pin_in_done, hipEventDisableTiming));
+    AFX_HIP(hipEventSynchronize(L.pin_in_done));   // the previous transfer out of this image
+    if ((rc = ensure_pinned(L.pin_in, L.pin_in_cap, img_bytes, size_t(1) << 21))) return rc;
+    uint8_t* img = (uint8_t*)L.pin_in;
+    std::vector<afx::CopyPool::Piece> pieces;
+    size_t ri = 0, covered = runs[0].off;
+    for (const Copy& k : copies) {
+      while (!(k.off >= runs[ri].off && k.off + k.len <= runs[ri].off + runs[ri].len)) covered = runs[++ri].off;
+      // the gaps a run bridges (alignment padding, at most 4 KB each) start from zero: the image is reused from call to call
+      if (k.off > covered) memset(img + runs[ri].img + (covered - runs[ri].off), 0, k.off - covered);
+      covered = std::max(covered, k.off + k.len);
+      afx::CopyPool::cut(pieces, img + runs[ri].img + (k.off - runs[ri].off), k.src, k.len);
+    }
+    c->copy_pool->run(std::move(pieces));
+    for (const Run& r : runs) AFX_HIP(hipMemcpyAsync((uint8_t*)L.staging.p + r.off, img + r.img, r.len, hipMemcpyHostToDevice, L.stream));
+    AFX_HIP(hipEventRecord(L.pin_in_done, L.stream));
+    for (const Copy& k : zeros) AFX_HIP(hipMemsetAsync((uint8_t*)L.staging.p + k.off, 0, k.len, L.stream));
+    return AFX_OK;
+  }
   for (const Copy& k : copies) AFX_HIP(hipMemcpyAsync((uint8_t*)L.staging.p + k.off, k.src, k.len, hipMemcpyHostToDevice, L.stream));
   for (const Copy& k : zeros) AFX_HIP(hipMemsetAsync((uint8_t*)L.staging.p + k.off, 0, k.len, L.stream));
   return AFX_OK;
@@ -231,8 +381,18 @@ int Stager::drain() {
   if (ses) return AFX_OK;
   afx_ctx::Lane& L = c->lane[ln];
   AFX_HIP(hipStreamSynchronize(L.stream));
-  if (fetched_)   // (a slice that failed before fetch_all() declared results it never produced)
-    for (const Out& o : outs) memcpy(o.dst, (const uint8_t*)L.pin + o.pin_off, o.len);
+  if (fetched_) {   // (a slice that failed before fetch_all() declared results it never produced)
+    size_t total = 0;
+    for (const Out& o : outs) total += o.len;
+    if (c->copy_pool && c->host_copy_threads && total >= (size_t(8) << 20)) {
+      // a large slice's results (an issuance is 800 bytes, a presentation 907 and more): scattered by the copy pool
+      std::vector<afx::CopyPool::Piece> pieces;
+      for (const Out& o : outs) afx::CopyPool::cut(pieces, o.dst, (const uint8_t*)L.pin + o.pin_off, o.len);
+      c->copy_pool->run(std::move(pieces));
+    } else {
+      for (const Out& o : outs) memcpy(o.dst, (const uint8_t*)L.pin + o.pin_off, o.len);
+    }
+  }
   outs.clear();
   pend_.clear();
   return AFX_OK;

@@ -113,6 +113,16 @@ extern "C" int afx_ctx_set_coalescing(afx_ctx* c, uint32_t max_wait_us, uint32_t
   if (max_items) c->co.max_items = max_items;
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_set_host_copy_threads(afx_ctx* c, uint32_t threads) try {
+  if (!c || threads > 64) { set_error("host copy threads out of range (0 .. 64)"); return AFX_E_BAD_ARGS; }
+  CtxLock lock(c);
+  AFX_HIP(hipSetDevice(c->device));
+  for (auto& L : c->lane)
+    if (L.stream) AFX_HIP(hipStreamSynchronize(L.stream));
+  c->copy_pool.reset();   // (made again, with the new count, by the next large host-pointer call)
+  c->host_copy_threads = threads;
+  return AFX_OK;
+} catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_get_coalescing_stats(afx_ctx* c, afx_coalescing_stats* out) try {
   if (!c || !out) { set_error("null argument"); return AFX_E_BAD_ARGS; }
   CtxLock lock(c, true);   // (a reader: no need to wait for the sessions in flight)

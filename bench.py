@@ -231,12 +231,16 @@ def corrupt(pres, count, seed):
     return want
 
 
-def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
-    """secondary metric: credentials issued / s, C5 = 2^20 issuances, 16 attributes S x8 P x4 E x4"""
-    n, layout, count = 16, "SSSSSSSSPPPPEEEE", (args.batch or (1 << 20))
+def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank, embedded=None):
+    """secondary metric: credentials issued / s, C5 = 2^20 issuances, 16 attributes S x8 P x4 E x4.
+    embedded = {"modes": [...], "steps": K, "warmup": W}: called from the C3 run (N = 1) for the line's config.secondary - the same
+    inputs timed under each secret mode, the lines returned instead of printed, no CPU timing leg (the oracle still checks bytes)."""
+    n, layout, count = 16, "SSSSSSSSPPPPEEEE", ((args.batch if not embedded else 0) or (1 << 20))
+    steps, warmup = (embedded["steps"], embedded["warmup"]) if embedded else (args.steps, args.warmup)
+    modes = embedded["modes"] if embedded else [secret_mode_of(args)]
     params, key, ip = load_fixture("c5_16attrs")
     issuer = afx.Context(params, key, ip, device=local_rank)
-    issuer.set_secret_independent_addressing(secret_mode_of(args))
+    issuer.set_secret_independent_addressing(0)   # input generation (reductions, Elligator maps of public attribute values)
     rng = np.random.default_rng(4242 + rank)
     rb = lambda *shape: rng.integers(0, 256, size=shape, dtype=np.uint8)
     dev = torch.device("cuda", local_rank)
@@ -267,69 +271,82 @@ def bench_issue(args, afx, batch, torch, dist, rank, world, local_rank):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    assert UNCHECKED or not status.cpu().numpy().any(), "issue failed"
-    # parity spot check of the first 64 credentials against the CPU oracle (checker only)
-    if rank == 0 and not args.no_cpu_baseline and not UNCHECKED:
-        import oracle
-        octx = oracle.Ctx(params, key, ip)
-        h = {k: v[..., :64, :].cpu().numpy() for k, v in d_out.items()}
-        hin = {k: v[..., :64, :].cpu().numpy() for k, v in d_in.items()}
-        for i in range(64):
-            vals = [bytes(hin["values"][k, i]) + bytes(64) for k in range(n)]
-            st, t, U, V, ch, resp = octx.issue(kinds, vals, bytes(hin["t_wide"][i]), bytes(hin["U_wide"][i]), bytes(hin["seed"][i]))
-            assert st == 0 and t == bytes(h["t"][i]) and U == bytes(h["U"][i]) and V == bytes(h["V"][i]) and ch == bytes(h["challenge"][i])
-            assert all(resp[k] == bytes(h["responses"][k, i]) for k in range(n + 5)), "GPU issuance differs from the oracle"
-    issuer.set_timing(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kt = kernel_times(issuer, args.steps)
-    valu = valu_side(issuer, count, sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS + FIELD_KERNELS))
-    issuer.set_timing(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is an N=1 figure
-        S = 256
-        hin = {k: v[..., :S, :].cpu().numpy() for k, v in d_in.items()}
+    octx = None
+    lines = []
+    for mode in modes:
+        issuer.set_secret_independent_addressing(mode)
+        for k in d_out:
+            d_out[k].zero_()
+        status.fill_(255)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        assert UNCHECKED or not status.cpu().numpy().any(), "issue failed"
+        # parity spot check of the first 64 credentials against the CPU oracle (checker only)
+        if rank == 0 and not args.no_cpu_baseline and not UNCHECKED:
+            import oracle
+            octx = octx or oracle.Ctx(params, key, ip)
+            h = {k: v[..., :64, :].cpu().numpy() for k, v in d_out.items()}
+            hin = {k: v[..., :64, :].cpu().numpy() for k, v in d_in.items()}
+            for i in range(64):
+                vals = [bytes(hin["values"][k, i]) + bytes(64) for k in range(n)]
+                st, t, U, V, ch, resp = octx.issue(kinds, vals, bytes(hin["t_wide"][i]), bytes(hin["U_wide"][i]), bytes(hin["seed"][i]))
+                assert st == 0 and t == bytes(h["t"][i]) and U == bytes(h["U"][i]) and V == bytes(h["V"][i]) and ch == bytes(h["challenge"][i])
+                assert all(resp[k] == bytes(h["responses"][k, i]) for k in range(n + 5)), "GPU issuance differs from the oracle"
+        issuer.set_timing(True)
+        fence()
         t0 = time.perf_counter()
-        for i in range(S):
-            vals = [bytes(hin["values"][k, i]) + bytes(64) for k in range(n)]
-            octx.issue(kinds, vals, bytes(hin["t_wide"][i]), bytes(hin["U_wide"][i]), bytes(hin["seed"][i]))
-        cpu = {"value": S / (time.perf_counter() - t0), "unit": "credentials/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
-               "sample": "first %d issuances of the same batch through the oracle (one thread, called from python)" % S}
-    if rank == 0:
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        kt = kernel_times(issuer, steps)
+        valu = valu_side(issuer, count, sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS + FIELD_KERNELS))
+        secret_terms = issuer.plan_stats()["secret_terms"]
+        issuer.set_timing(False)
+        assert UNCHECKED or not status.cpu().numpy().any(), "issue failed in the timed steps"
+        if dist is not None:
+            elapsed = dist.max_over_ranks(elapsed)
+        cpu = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and not embedded:   # the CPU baseline is an N=1 figure
+            S = 256
+            hin = {k: v[..., :S, :].cpu().numpy() for k, v in d_in.items()}
+            t0 = time.perf_counter()
+            for i in range(S):
+                vals = [bytes(hin["values"][k, i]) + bytes(64) for k in range(n)]
+                octx.issue(kinds, vals, bytes(hin["t_wide"][i]), bytes(hin["U_wide"][i]), bytes(hin["seed"][i]))
+            cpu = {"value": S / (time.perf_counter() - t0), "unit": "credentials/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+                   "sample": "first %d issuances of the same batch through the oracle (one thread, called from python)" % S}
         ab = 32 * n + n + 160 + 96 + 32 * (n + 6)
-        print(json.dumps({
-            "metric": "credentials issued/sec (secondary; aMAC tag + issuance NIZK)", "value": count * world * args.steps / elapsed,
-            "unit": "credentials/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        lines.append({
+            "metric": "credentials issued/sec (secondary; aMAC tag + issuance NIZK)", "value": count * world * steps / elapsed,
+            "unit": "credentials/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic (random attribute values)",
             "config": {"workload": "C5: batch issue 2^20 credentials, 16 attributes (S x8, P x4, E x4)", "credentials_per_gpu": count,
-                       "secret_independent_addressing": {0: "nowhere (mode 0)", 1: "everywhere (mode 1)", 2: "prover-side calls (mode 2, the default)"}[secret_mode_of(args)],
-                       "algorithmic_bytes_per_credential": ab, "parallelism": "host-sharded x%d, no collective" % world, "rank_devices": RANK_DEVICES},
-            "roofline": roofline_of(kt, "c5", ab, count, secret_mode_of(args) != 0),
-            "valu": with_value_per_mhz(valu, count * world * args.steps / elapsed), "cpu_baseline": cpu}))
+                       "secret_independent_addressing": SECRET_MODE_NAMES[mode], "secret_terms_in_plan": secret_terms,
+                       "algorithmic_bytes_per_credential": ab, "parallelism": "host-sharded x%d, no collective" % world, "rank_devices": RANK_DEVICES,
+                       "dist_backend": dist.backend if dist is not None else None, "dist_backend_fallback": dist.fallback if dist is not None else None},
+            "roofline": roofline_of(kt, "c5", ab, count, mode != 0),
+            "valu": with_value_per_mhz(valu, count * world * steps / elapsed), "cpu_baseline": cpu})
     issuer.close()
+    if embedded:
+        return lines
+    if rank == 0:
+        print(json.dumps(lines[0]))
     if dist is not None:
-        dist.destroy_process_group()
+        dist.destroy()
 
 
-def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
-    """secondary metric: presentations created / s (AnonymousCredential::show), C2 shape, device-resident inputs"""
-    n, layout, hide, count = 4, "SSPE", [0, 3], (args.batch or (1 << 16))
+def bench_show(args, afx, batch, torch, dist, rank, world, local_rank, embedded=None):
+    """secondary metric: presentations created / s (AnonymousCredential::show), C2 shape, device-resident inputs
+    (embedded: as in bench_issue)"""
+    n, layout, hide, count = 4, "SSPE", [0, 3], ((args.batch if not embedded else 0) or (1 << 16))
+    steps, warmup = (embedded["steps"], embedded["warmup"]) if embedded else (args.steps, args.warmup)
+    modes = embedded["modes"] if embedded else [secret_mode_of(args)]
     params, key, ip = load_fixture("readme_4attrs_sSPe")
     issuer = afx.Context(params, key, ip, device=local_rank)
     user = afx.Context(params, None, ip, device=local_rank)
     issuer.set_secret_independent_addressing(0)   # the issuer only makes the synthetic credentials here
-    user.set_secret_independent_addressing(secret_mode_of(args))
     rng = np.random.default_rng(99 + rank)
     rb = lambda *shape: rng.integers(0, 256, size=shape, dtype=np.uint8)
     dev = torch.device("cuda", local_rank)
@@ -384,53 +401,62 @@ def bench_show(args, afx, batch, torch, dist, rank, world, local_rank):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    assert not status.cpu().numpy().any(), "show failed"
-    # every presentation made here must verify on the issuer's side (GPU), and the first 16 must equal the oracle's bytes
-    pres = {f: o[f].cpu().numpy() for f in batch.PRES_FIELDS}
-    pres["enc"] = [{f: eo[f].cpu().numpy() for f in batch.ENC_FIELDS}]
-    assert not batch.verify_presentations(issuer, shape, pres).any(), "a shown presentation does not verify"
-    if rank == 0 and not args.no_cpu_baseline:
-        import oracle
-        octx = oracle.Ctx(params, None, ip)
-        for i in range(16):
-            vals = [bytes(values[k, i]) + bytes(M2[k, i]) + bytes(m3[k, i]) for k in range(n)]
-            kpb = bytes(a[i]) + bytes(a0[i]) + bytes(a1[i]) + bytes(pk[i])
-            st, p = octx.show(skinds, vals, bytes(iss["t"][i]), bytes(iss["U"][i]), bytes(iss["V"][i]), kpb, bytes(host_in["z_wide"][i]),
-                              bytes(host_in["seed"][i]), bytes(host_in["enc_seeds"][0, i]))
-            assert st == 0 and bytes(p.challenge) == bytes(pres["challenge"][i]) and bytes(p.enc[0].challenge) == bytes(pres["enc"][0]["challenge"][i])
-            assert all(bytes(p.responses[k]) == bytes(pres["responses"][k, i]) for k in range(4)), "GPU show differs from the oracle"
-    user.set_timing(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kt = kernel_times(user, args.steps)
-    valu = valu_side(user, count, sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS + FIELD_KERNELS))
-    user.set_timing(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank == 0:
+    octx = None
+    lines = []
+    for mode in modes:
+        user.set_secret_independent_addressing(mode)
+        for t_ in list(o.values()) + list(eo.values()):
+            t_.zero_()
+        status.fill_(255)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        assert not status.cpu().numpy().any(), "show failed"
+        # every presentation made here must verify on the issuer's side (GPU), and the first 16 must equal the oracle's bytes
+        pres = {f: o[f].cpu().numpy() for f in batch.PRES_FIELDS}
+        pres["enc"] = [{f: eo[f].cpu().numpy() for f in batch.ENC_FIELDS}]
+        assert not batch.verify_presentations(issuer, shape, pres).any(), "a shown presentation does not verify"
+        if rank == 0 and not args.no_cpu_baseline:
+            import oracle
+            octx = octx or oracle.Ctx(params, None, ip)
+            for i in range(16):
+                vals = [bytes(values[k, i]) + bytes(M2[k, i]) + bytes(m3[k, i]) for k in range(n)]
+                kpb = bytes(a[i]) + bytes(a0[i]) + bytes(a1[i]) + bytes(pk[i])
+                st, p = octx.show(skinds, vals, bytes(iss["t"][i]), bytes(iss["U"][i]), bytes(iss["V"][i]), kpb, bytes(host_in["z_wide"][i]),
+                                  bytes(host_in["seed"][i]), bytes(host_in["enc_seeds"][0, i]))
+                assert st == 0 and bytes(p.challenge) == bytes(pres["challenge"][i]) and bytes(p.enc[0].challenge) == bytes(pres["enc"][0]["challenge"][i])
+                assert all(bytes(p.responses[k]) == bytes(pres["responses"][k, i]) for k in range(4)), "GPU show differs from the oracle"
+        user.set_timing(True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        kt = kernel_times(user, steps)
+        valu = valu_side(user, count, sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS + FIELD_KERNELS))
+        secret_terms = user.plan_stats()["secret_terms"]
+        user.set_timing(False)
+        if dist is not None:
+            elapsed = dist.max_over_ranks(elapsed)
         ab = 32 * n + n + 96 + 32 + 128 + 96 + 64 + 32 + 32 + 907   # credential + keypair + randomness read, presentation written
-        print(json.dumps({
-            "metric": "credential presentations created/sec (secondary; AnonymousCredential::show)", "value": count * world * args.steps / elapsed,
-            "unit": "presentations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        lines.append({
+            "metric": "credential presentations created/sec (secondary; AnonymousCredential::show)", "value": count * world * steps / elapsed,
+            "unit": "presentations/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic (GPU-issued credentials)",
             "config": {"workload": "show 2^16 credentials, 4 attributes (s S P e)", "credentials_per_gpu": count, "algorithmic_bytes_per_presentation": ab,
-                       "secret_independent_addressing": {0: "nowhere (mode 0)", 1: "everywhere (mode 1)", 2: "prover-side calls (mode 2, the default)"}[secret_mode_of(args)],
+                       "secret_independent_addressing": SECRET_MODE_NAMES[mode], "secret_terms_in_plan": secret_terms,
                        "parallelism": "host-sharded x%d, no collective" % world, "rank_devices": RANK_DEVICES},
-            "roofline": roofline_of(kt, "show", ab, count, secret_mode_of(args) != 0),
-            "valu": with_value_per_mhz(valu, count * world * args.steps / elapsed), "cpu_baseline": None}))
+            "roofline": roofline_of(kt, "show", ab, count, mode != 0),
+            "valu": with_value_per_mhz(valu, count * world * steps / elapsed), "cpu_baseline": None})
     issuer.close()
     user.close()
+    if embedded:
+        return lines
+    if rank == 0:
+        print(json.dumps(lines[0]))
     if dist is not None:
-        dist.destroy_process_group()
+        dist.destroy()
 
 
 # v_mad_i64_i32 issue cost at the occupancy the kernels run at (2 waves per SIMD), measured with a pure multiply-add loop
@@ -506,6 +532,79 @@ def with_value_per_mhz(valu, value):
 
 
 RANK_DEVICES = None
+SECRET_MODE_NAMES = {0: "nowhere (mode 0)", 1: "everywhere (mode 1)", 2: "prover-side calls (mode 2, the default)"}
+
+
+PG_FAILED_EXIT = 75   # a rank whose process group did not form exits with this code (EX_TEMPFAIL): launch_ranks retries once
+
+
+class Ranks:
+    """The measurement's process group: a barrier on both sides of the timed steps and one MAX all-reduce of a double (the data path
+    has no collective).  Every rank first joins a gloo group (TCP on 127.0.0.1: it forms wherever processes can talk at all); RCCL -
+    what the contract asks for - is then tried as a SECOND group, with one test all-reduce, and the ranks AGREE over gloo whether it
+    formed everywhere: all of them use it, or all of them stay on gloo (`fallback` says why).  Ranks deciding one by one would end up
+    on different backends and hang in the first barrier; a rank that cannot even join the gloo group exits with PG_FAILED_EXIT."""
+
+    def __init__(self, torch, rank, world, local_rank, want):
+        import datetime
+        import torch.distributed as dist
+        self.torch, self.dist, self.world, self.dev = torch, dist, world, torch.device("cuda", local_rank)
+        self.group, self.backend, self.fallback = None, "gloo", None
+        try:
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(minutes=10))
+        except Exception as e:   # noqa: BLE001
+            sys.stderr.write("bench.py: rank %d: the gloo process group did not form (%s)\n" % (rank, e))
+            sys.exit(PG_FAILED_EXIT)
+        if want.split()[0] != "nccl":
+            if want != "gloo":
+                self.fallback = want
+            return
+        ok, why = 1, ""
+        if not dist.is_nccl_available():
+            ok, why = 0, "this torch build has no RCCL"
+        else:
+            os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")   # a collective that times out raises here instead of ending the process
+            try:
+                g = dist.new_group(backend="nccl", timeout=datetime.timedelta(minutes=3))
+                t = torch.ones(1, device=self.dev)
+                dist.all_reduce(t, group=g)
+                torch.cuda.synchronize()
+                if int(t.item()) != world:
+                    ok, why = 0, "test all-reduce returned %s" % t.item()
+            except Exception as e:   # noqa: BLE001
+                ok, why, g = 0, "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else ""), None
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # (gloo) everybody, or nobody
+        if int(flag.item()) == 1:
+            self.group, self.backend = g, "nccl"
+        else:
+            whys = [None] * world
+            dist.all_gather_object(whys, why)
+            self.fallback = "the RCCL group did not form on every rank (%s): the barrier and the MAX all-reduce ran on gloo" % \
+                "; ".join("rank %d: %s" % (r, w) for r, w in enumerate(whys) if w)
+
+    def barrier(self):
+        if self.group is not None:
+            self.dist.barrier(group=self.group, device_ids=[self.dev.index])
+        else:
+            self.dist.barrier()
+
+    def max_over_ranks(self, seconds):
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.dev if self.group is not None else "cpu")
+        if self.group is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_gather_object(self, obj):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def destroy(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
 
 
 def gather_rank_devices(torch, dist, world, local_rank):
@@ -517,9 +616,7 @@ def gather_rank_devices(torch, dist, world, local_rank):
         mine = str(getattr(p, "uuid", "device-%d" % local_rank))
     if dist is None or world == 1:
         return [mine]
-    out = [None] * world
-    dist.all_gather_object(out, mine)
-    return out
+    return dist.all_gather_object(mine)
 
 
 def free_port():
@@ -529,13 +626,10 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n, argv, worker=None, timeout_s=None):
-    """`python bench.py --gpus N` without a launcher around it: start N fresh child processes, one rank per GPU, with the
-    environment torch.distributed.run would give them (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR/PORT), relay rank 0's
-    output line and return non-zero if any rank failed.  The parent never touches the GPU (children are new processes, not
-    an exec of one that initialised HIP).  `worker` is the child command (tests substitute a stub)."""
+def launch_once(n, argv, worker, timeout_s):
+    """one launch of N ranks; returns (rc, rank 0's stdout bytes, the first failing rank's exit code or None)"""
     import subprocess
-    worker = worker or [sys.executable, os.path.abspath(__file__)]
+    import threading
     port = free_port()
     procs = []
     for r in range(n):
@@ -544,12 +638,11 @@ def launch_ranks(n, argv, worker=None, timeout_s=None):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen(worker + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     t0 = time.time()
-    rc = 0
-    out0 = b""
-    import threading
+    rc, first = 0, None
+    out0 = [b""]
+
     def drain():
-        nonlocal out0
-        out0 = procs[0].stdout.read()
+        out0[0] = procs[0].stdout.read()
     th = threading.Thread(target=drain, daemon=True)
     th.start()
     live = set(range(n))
@@ -561,6 +654,7 @@ def launch_ranks(n, argv, worker=None, timeout_s=None):
             live.discard(r)
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 1
+                first = code
                 sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
                 for o in live:
                     procs[o].terminate()   # exactly the processes started above
@@ -573,38 +667,190 @@ def launch_ranks(n, argv, worker=None, timeout_s=None):
         if live:
             time.sleep(0.05)
     th.join(timeout=10)
+    return rc, out0[0], first
+
+
+def launch_ranks(n, argv, worker=None, timeout_s=None):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh child processes, one rank per GPU, with the
+    environment torch.distributed.run would give them (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR/PORT), relay rank 0's
+    output line and return non-zero if any rank failed.  The parent never touches the GPU (children are new processes, not
+    an exec of one that initialised HIP).  `worker` is the child command (tests substitute a stub).
+    A launch whose first failing rank says its process group did not form (PG_FAILED_EXIT: a rendezvous port taken between
+    free_port() and the ranks' bind, a backend that cannot start on this node) is repeated ONCE with fresh children, a new port
+    and `--dist-backend gloo`; the second launch's line records why (config.dist_backend_fallback)."""
+    worker = worker or [sys.executable, os.path.abspath(__file__)]
+    rc, out0, first = launch_once(n, argv, worker, timeout_s)
+    if first == PG_FAILED_EXIT and "--dist-backend-fallback" not in argv:
+        sys.stderr.write("bench.py: a rank's process group did not form; launching the ranks once more on gloo\n")
+        retry = [a for a in argv]
+        if "--dist-backend" in retry:
+            i = retry.index("--dist-backend")
+            del retry[i:i + 2]
+        retry = [a for a in retry if not a.startswith("--dist-backend=")]
+        retry += ["--dist-backend", "gloo", "--dist-backend-fallback", "launcher: the first launch's process group did not form (a rank exited with code %d)" % PG_FAILED_EXIT]
+        rc, out0, first = launch_once(n, retry, worker, timeout_s)
     sys.stdout.write(out0.decode(errors="replace"))
     sys.stdout.flush()
     return rc
+
+
+def preflight(args):
+    """can `--gpus N` run here?  One JSON line; exit code 0 when every check passes.  Touches the GPUs (properties, free memory):
+    run it as its own process, never before a launch in the same one."""
+    n = args.gpus
+    out = {"preflight": True, "gpus_asked": n, "checks": {}}
+    ok = True
+
+    def check(name, passed, detail):
+        nonlocal ok
+        out["checks"][name] = {"ok": bool(passed), "detail": detail}
+        ok = ok and bool(passed)
+    try:
+        import torch
+        import torch.distributed as dist
+        have = torch.cuda.device_count()
+        check("devices", have >= n, "%d visible, %d asked for" % (have, n))
+        ids, free = [], []
+        for d in range(min(have, n)):
+            p = torch.cuda.get_device_properties(d)
+            try:
+                ids.append("%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id))
+            except AttributeError:
+                ids.append(str(getattr(p, "uuid", d)))
+            free.append(torch.cuda.mem_get_info(d)[0])
+        check("distinct_devices", len(set(ids)) == len(ids), ids)
+        # a pass of 2^19 C3 presentations: ~70 KB of workspace per item + the batch resident (2425 B per presentation)
+        workload = args.workload or ("c3" if n == 1 else "c4")
+        per_gpu = args.batch or (WORKLOADS[workload][3] // (n if workload == "c4" else 1) if workload in WORKLOADS else 1 << 20)
+        need = min(per_gpu, 1 << 19) * 70 * 1024 + per_gpu * 2425 * 2
+        check("free_hbm", all(f >= need for f in free) and bool(free), {"need_bytes_per_gpu": need, "free_bytes": free})
+        check("rccl", dist.is_nccl_available(), "torch.distributed.is_nccl_available(); without it the barrier and the MAX all-reduce run on gloo")
+        try:
+            avail = int(next(l.split()[1] for l in open("/proc/meminfo") if l.startswith("MemAvailable"))) * 1024
+        except (OSError, StopIteration, ValueError):
+            avail = None
+        host_need = n * per_gpu * 2425 * 4   # every rank holds its batch in numpy arrays, their concatenation parts, and the corrupted copy
+        check("host_memory", avail is None or avail >= host_need, {"need_bytes": host_need, "available_bytes": avail})
+        check("usable_cores", usable_cores() >= n, "%d usable for %d ranks" % (usable_cores(), n))
+        try:
+            import aeonflux_amd as afx
+            afx.lib()
+            check("library", True, os.path.relpath(afx.LIB_PATH, ROOT))
+        except Exception as e:   # noqa: BLE001
+            check("library", False, "%s: %s" % (type(e).__name__, e))
+    except Exception as e:   # noqa: BLE001
+        check("torch", False, "%s: %s" % (type(e).__name__, e))
+    out["ok"] = ok
+    print(json.dumps(out))
+    return 0 if ok else 1
 
 
 def tile_items(a, reps):
     return a if reps == 1 else np.ascontiguousarray(np.concatenate([a] * reps, axis=-2))
 
 
-def group_api_rate(afx, batch, params, key, ip, shape, pres, want, devices, reps):
+def group_api_rate(afx, batch, params, key, ip, shape, pres, want, devices, copies, reps=1):
     """What the single `&self` call Issuer::verify (/root/reference/src/issuer.rs:141-147) becomes on a node: ONE process, one
     afx_group over `devices`, afx_group_verify_presentations on host arrays (contiguous split, one host thread and two
     streams per member, no collective).  The batch is `reps` copies of this rank's (PCIe and staging inclusive, never
-    `value`).  Returns (presentations/s, items)."""
+    `value`).  Returns (spread of presentations/s over `reps` repetitions, items)."""
     g = afx.Group(params, key, ip, devices)
     try:
-        big = {f: tile_items(pres[f], reps) for f in batch.PRES_FIELDS}
-        big["enc"] = [{f: tile_items(d[f], reps) for f in batch.ENC_FIELDS} for d in pres["enc"]]
+        big = {f: tile_items(pres[f], copies) for f in batch.PRES_FIELDS}
+        big["enc"] = [{f: tile_items(d[f], copies) for f in batch.ENC_FIELDS} for d in pres["enc"]]
         total = big["challenge"].shape[0]
-        exp = np.concatenate([want] * reps)
+        exp = np.concatenate([want] * copies)
         soa, keep = batch.presentation_soa(big)
         st = np.full(total, 255, np.uint8)
         fn = afx.lib().afx_group_verify_presentations
-        afx.check(fn(g.h, C.byref(shape), C.byref(soa), total, st.ctypes.data))   # warm-up: workspaces, staging, pinned buffers
-        st[:] = 255
-        t0 = time.perf_counter()
-        afx.check(fn(g.h, C.byref(shape), C.byref(soa), total, st.ctypes.data))
-        dt = time.perf_counter() - t0
+        rates = timed_reps(lambda: afx.check(fn(g.h, C.byref(shape), C.byref(soa), total, st.ctypes.data)), total, max(1, reps))
         assert UNCHECKED or np.array_equal(st, exp), "group API statuses differ from the expected ones"
-        return total / dt, total
+        return spread(rates), total
     finally:
         g.close()
+
+
+def spread(rates):
+    """{"median", "min", "max", "reps"} of a leg's repetitions (items per second each)"""
+    import statistics
+    return {"median": statistics.median(rates), "min": min(rates), "max": max(rates), "reps": len(rates)}
+
+
+def timed_reps(call, items, reps):
+    """`reps` timed repetitions of a synchronous host call over `items` items, after one untimed warm-up (buffers, plans)"""
+    call()
+    rates = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        call()
+        rates.append(items / (time.perf_counter() - t0))
+    return rates
+
+
+def verify_secondary(afx, batch, torch, local_rank, workload, steps, warmup, check_oracle):
+    """one more verification workload of BASELINE.json for the line's config.secondary (N = 1): generated, 1 % corrupted, resident in
+    HBM, every status byte checked, timed like the headline; with `check_oracle` the first 256 statuses and recomputed challenges are
+    compared with the oracle's too"""
+    n, layout, hide, count, fixture, desc = WORKLOADS[workload]
+    params, key, ip = load_fixture(fixture)
+    issuer = afx.Context(params, key, ip, device=local_rank)
+    user = afx.Context(params, None, ip, device=local_rank)
+    pres, shape = generate(afx, batch, issuer, user, params, n, layout, hide, count, 555, fast_tables=True)
+    want = corrupt(pres, count, 11)
+    user.close()
+    issuer.set_secret_independent_addressing(2)
+    dev = torch.device("cuda", local_rank)
+    dpres = {f: torch.from_numpy(pres[f]).to(dev) for f in batch.PRES_FIELDS}
+    dpres["enc"] = [{f: torch.from_numpy(d[f]).to(dev) for f in batch.ENC_FIELDS} for d in pres["enc"]]
+    soa, keep = batch.presentation_soa(dpres, ptr=lambda t: t.data_ptr())
+    status = torch.full((count,), 255, dtype=torch.uint8, device=dev)
+    fn = afx.lib().afx_verify_presentations_dev
+    for _ in range(warmup):
+        afx.check(fn(issuer.h, C.byref(shape), C.byref(soa), count, status.data_ptr()))
+    torch.cuda.synchronize()
+    got = status.cpu().numpy()
+    assert UNCHECKED or np.array_equal(got, want), "%s: status mismatch" % workload
+    if check_oracle and not UNCHECKED:
+        import oracle   # checker only
+        S = min(256, count)
+        sub = {f: np.ascontiguousarray(pres[f][..., :S, :]) for f in batch.PRES_FIELDS}
+        sub["enc"] = [{f: np.ascontiguousarray(d[f][..., :S, :]) for f in batch.ENC_FIELDS} for d in pres["enc"]]
+        osoa, keep2 = batch.presentation_soa(sub)
+        octx = oracle.Ctx(params, key, ip)
+        ost = np.full(S, 255, np.uint8)
+        oracle.lib().afxo_verify_presentations_soa(octx.h, C.byref(oracle.Shape.from_buffer_copy(bytes(shape))),
+                                                   C.byref(oracle.PresentationSoA.from_buffer_copy(bytes(osoa))), S, ost.ctypes.data, 4)
+        assert np.array_equal(ost, got[:S]), "%s: GPU and oracle statuses differ" % workload
+    issuer.set_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        afx.check(fn(issuer.h, C.byref(shape), C.byref(soa), count, status.data_ptr()))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kt = kernel_times(issuer, steps)
+    valu = valu_side(issuer, count, sum(kt[k]["ms_per_step"] for k in kt if k in MSM_KERNELS + FIELD_KERNELS))
+    issuer.set_timing(False)
+    assert UNCHECKED or np.array_equal(status.cpu().numpy(), want), "%s: status mismatch after the timed steps" % workload
+    ab = algorithmic_bytes(shape)
+    line = {"metric": "credential presentations verified/sec", "value": count * steps / elapsed, "unit": "presentations/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "config": {"workload": desc, "presentations_per_gpu": count, "algorithmic_bytes_per_presentation": ab},
+            "roofline": roofline_of(kt, workload, ab, count, False), "valu": with_value_per_mhz(valu, count * steps / elapsed)}
+    issuer.close()
+    return line
+
+
+def brief(line):
+    """what config.secondary keeps of a secondary workload's full line"""
+    r, v = line["roofline"], line["valu"]
+    return {"workload": line["config"]["workload"], "metric": line["metric"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+            "steps": line["steps"], "warmup": line["warmup"],
+            "secret_independent_addressing": line["config"].get("secret_independent_addressing"), "secret_terms_in_plan": line["config"].get("secret_terms_in_plan"),
+            "algorithmic_bytes_per_item": line["config"].get("algorithmic_bytes_per_presentation", line["config"].get("algorithmic_bytes_per_credential")),
+            "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "items_per_launch", "traffic", "traffic_stale")},
+            "kernels_ms_per_step": r["kernels_ms_per_step"],
+            "valu_frac_at_measured_clock": v.get("frac_at_measured_clock"), "core_clock_mhz_measured": v.get("core_clock_mhz_measured"),
+            "value_per_mhz": v.get("value_per_mhz"), "mads_per_item": (v.get("per_item") or {}).get("mads")}
 
 
 def main():
@@ -619,6 +865,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-group-api", action="store_true", help="skip the afx_group_verify_presentations leg (rank 0, after the timed steps)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip config.secondary (N = 1, C3 only: C2, C5 in modes 2 and 0, show, a few steps each "
+                    "after the headline's timed region)")
+    ap.add_argument("--host-reps", type=int, default=5, help="repetitions of each host-side leg (host-pointer, serialized, group API): median / min / max")
     ap.add_argument("--pipelining", action="store_true", help="alternate steps between the engine's two streams (measured slower: the "
                     "path is VALU-bound, overlap only adds contention; default off)")
     ap.add_argument("--secret-mode", type=int, choices=(0, 1, 2), default=None,
@@ -628,8 +877,13 @@ def main():
     ap.add_argument("--secret-independent", action="store_true", help="= --secret-mode 1: afx_ctx_set_secret_independent_addressing everywhere (cost "
                     "measurement; results are the same bytes)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL; the driver's launch) or gloo (testing two ranks on one GPU)")
+    ap.add_argument("--dist-backend-fallback", default=None, help=argparse.SUPPRESS)   # set by launch_ranks on its second launch: why the first one failed
+    ap.add_argument("--preflight", action="store_true", help="check that --gpus N can run here (devices and their PCI ids, RCCL, free HBM, host "
+                    "memory, the library), print one JSON line and exit 0 / 1 without running anything")
     args = ap.parse_args()
 
+    if args.preflight:
+        sys.exit(preflight(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher around this process: be the launcher (before anything here touches the GPU)
         # a rank that hangs (a process group that half-formed) must not hang the launcher: an hour covers generation + parity
@@ -650,31 +904,14 @@ def main():
     if world > 1 or (os.environ.get("AFX_BENCH_PG_ALWAYS") == "1" and "RANK" in os.environ):
         # (AFX_BENCH_PG_ALWAYS: a one-rank launch under torch.distributed.run still forms the group - how the RCCL leg is
         # exercised on a one-GPU box)
-        import torch.distributed as dist
-        # the process group only carries the measurement's barrier and one MAX all-reduce of a double (the data path has no
-        # collective): RCCL as the contract asks; if it cannot start on this node, gloo serves the same purpose
-        # The backend is decided ONCE, the same way on every rank, before any group forms: --dist-backend, and gloo instead of
-        # nccl only when this build of torch has no RCCL at all (a property of the image, equal on all ranks of a node).  A rank
-        # whose group does not form exits non-zero - the launcher (torch.distributed.run, or launch_ranks above) then stops the
-        # others; ranks falling back one by one would end up on different backends and hang in the first barrier.
-        import datetime
-        if args.dist_backend == "nccl" and not dist.is_nccl_available():
-            args.dist_backend = "gloo (this torch build has no RCCL)"
-        backend = args.dist_backend.split()[0]
-        try:
-            if backend == "nccl":
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=10))
-            else:
-                dist.init_process_group(backend=backend, timeout=datetime.timedelta(minutes=10))
-        except Exception as e:   # noqa: BLE001
-            raise SystemExit("bench.py: rank %d: the %s process group did not form (%s)" % (rank, backend, e))
+        dist = Ranks(torch, rank, world, local_rank, args.dist_backend)
     # which physical device every rank drives (PCI bus id): two ranks on one GPU would report a curve that is not one - refused,
     # unless AFX_BENCH_DEVICE put them there on purpose (the launch-path check on a one-GPU box)
     global RANK_DEVICES
     RANK_DEVICES = gather_rank_devices(torch, dist, world, local_rank)
     if len(set(RANK_DEVICES)) != len(RANK_DEVICES) and "AFX_BENCH_DEVICE" not in os.environ:
         if dist is not None:
-            dist.destroy_process_group()
+            dist.destroy()
         raise SystemExit("bench.py: ranks share a device: %s (set AFX_BENCH_DEVICE to run several ranks on one GPU on purpose)" % RANK_DEVICES)
     import aeonflux_amd as afx
     from aeonflux_amd import batch
@@ -741,32 +978,29 @@ def main():
     issuer.set_timing(False)
     issuer.set_pipelining(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = dist.max_over_ranks(elapsed)
     got = status.cpu().numpy()
     assert UNCHECKED or np.array_equal(got, want), "status mismatch after the timed steps"
     ranks_seen, had_group = 1, dist is not None
+    pg_backend = pg_fallback = None
     if dist is not None:
         # the measurement is over: every rank leaves the process group here; rank 0 goes on alone with the host-side legs
-        ranks_seen = dist.get_world_size()
-        dist.barrier()
-        dist.destroy_process_group()
+        ranks_seen, pg_backend, pg_fallback = dist.world, dist.backend, dist.fallback
+        dist.destroy()
         dist = None
         if rank != 0:
             del dpres, soa, status
             issuer.close()
             return
-    # PCIe-inclusive rate through the host-pointer entry point (never `value`; DESIGN.md quotes it)
+    # PCIe-inclusive rate through the host-pointer entry point (never `value`; DESIGN.md quotes it): `--host-reps` repetitions
+    # after a warm-up call, reported as median / min / max (one repetition cannot tell a slow box from a hiccup)
     pcie = wire_rate = None
     group_rate = group_items = group_err = None
+    reps = max(1, args.host_reps)
     if rank == 0:
         hsoa, keep_h = batch.presentation_soa(pres)
         hst = np.full(count, 255, np.uint8)
-        afx.check(afx.lib().afx_verify_presentations(issuer.h, C.byref(shape), C.byref(hsoa), count, hst.ctypes.data))
-        t0 = time.perf_counter()
-        afx.check(afx.lib().afx_verify_presentations(issuer.h, C.byref(shape), C.byref(hsoa), count, hst.ctypes.data))
-        pcie = count / (time.perf_counter() - t0)
+        pcie = spread(timed_reps(lambda: afx.check(afx.lib().afx_verify_presentations(issuer.h, C.byref(shape), C.byref(hsoa), count, hst.ctypes.data)), count, reps))
         assert UNCHECKED or np.array_equal(hst, want)
         # ... and as one serialized AFXP blob in pageable host memory (afx_verify_presentations_wire: the transposition to
         # columns happens on the GPU, slice by slice); a quarter of the batch keeps the host-side packing short
@@ -776,10 +1010,7 @@ def main():
         wsub["enc"] = [{f: np.ascontiguousarray(d[f][..., :wn, :]) for f in batch.ENC_FIELDS} for d in pres["enc"]]
         blob = wire_mod.pack_presentations(shape, wsub)
         wst, wcnt = np.full(wn, 255, np.uint8), C.c_size_t(0)
-        afx.check(afx.lib().afx_verify_presentations_wire(issuer.h, blob, len(blob), wst.ctypes.data, wn, C.byref(wcnt)))
-        t0 = time.perf_counter()
-        afx.check(afx.lib().afx_verify_presentations_wire(issuer.h, blob, len(blob), wst.ctypes.data, wn, C.byref(wcnt)))
-        wire_rate = wn / (time.perf_counter() - t0)
+        wire_rate = spread(timed_reps(lambda: afx.check(afx.lib().afx_verify_presentations_wire(issuer.h, blob, len(blob), wst.ctypes.data, wn, C.byref(wcnt))), wn, reps))
         assert UNCHECKED or np.array_equal(wst, want[:wn])
         del blob, wsub
         # ... and what ONE small synchronous host-pointer call costs (the latency plan: DESIGN.md section 3): the first 64
@@ -797,12 +1028,12 @@ def main():
         small_call_ms = (time.perf_counter() - t0) / 20 * 1e3
         assert UNCHECKED or np.array_equal(sst, want[:sn])
         # ... and through ONE afx_group over the node's GPUs (one process, host arrays): the in-library split
+        del dpres, soa, status
+        torch.cuda.empty_cache()
         if not args.no_group_api:
-            del dpres, soa, status
-            torch.cuda.empty_cache()
             devices = [local_rank] * world if "AFX_BENCH_DEVICE" in os.environ else list(range(world))
             try:
-                group_rate, group_items = group_api_rate(afx, batch, params, key, ip, shape, pres, want, devices, world)
+                group_rate, group_items = group_api_rate(afx, batch, params, key, ip, shape, pres, want, devices, world, reps)
             except Exception as e:   # a missing device must not cost the headline line
                 group_err = "%s: %s" % (type(e).__name__, e)
 
@@ -824,7 +1055,7 @@ def main():
         olib.afxo_verify_presentations_soa(octx, C.byref(oshape), C.byref(osoa), S, ost.ctypes.data, threads)
         cpu_s = time.perf_counter() - t0
         assert np.array_equal(ost, got[:S]), "GPU and CPU-oracle statuses differ on the sample"
-        S1 = min(S, 256)   # single-thread figure on its own contiguous sub-batch (rows are count-strided)
+        S1 = min(S, 2048)   # single-thread figure on its own contiguous sub-batch (rows are count-strided): ~5 s of one core
         sub1 = {f: np.ascontiguousarray(pres[f][..., :S1, :]) for f in batch.PRES_FIELDS}
         sub1["enc"] = [{f: np.ascontiguousarray(d[f][..., :S1, :]) for f in batch.ENC_FIELDS} for d in pres["enc"]]
         osoa1, keep3 = batch.presentation_soa(sub1)
@@ -835,10 +1066,35 @@ def main():
         cpu1_s = time.perf_counter() - t0
         assert np.array_equal(ost1, got[:S1])
         cpu = {"value": S / cpu_s, "unit": "presentations/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
-               "sample": "first %d presentations of the same batch, oracle/ restated CPU path (gcc -O3 -march=native, 5x51 limbs, "
+               "sample": "value: first %d presentations of the same batch, oracle/ restated CPU path (gcc -O3 -march=native, 5x51 limbs, "
                          "NAF-5 Straus), %d threads = the cores this process may use (scheduler affinity mask capped by the cgroup CPU "
-                         "quota; the machine reports %d hardware threads); statuses equal to the GPU's" % (S, threads, os.cpu_count() or 0),
-               "single_thread_value": S1 / cpu1_s}
+                         "quota; the machine reports %d hardware threads), %.1f s; single_thread_value: the first %d of them on one thread, "
+                         "%.1f s; statuses equal to the GPU's in both" % (S, threads, os.cpu_count() or 0, cpu_s, S1, cpu1_s),
+               "items": S, "seconds": cpu_s,
+               "single_thread_value": S1 / cpu1_s, "single_thread_items": S1, "single_thread_seconds": cpu1_s}
+
+    # the rest of BASELINE.json's matrix in the same line (N = 1, the C3 run): C2, C5 in the library's default mode and with the
+    # fast tables, show likewise - a few steps each, every result checked (statuses; bytes of the first items against the oracle)
+    secondary = None
+    if rank == 0 and world == 1 and args.workload == "c3" and not args.no_secondary and not args.batch:
+        issuer.close()
+        issuer = None
+        del pres
+        torch.cuda.empty_cache()
+        t0 = time.time()
+        emb = {"steps": max(1, min(args.steps, 5)), "warmup": max(1, min(args.warmup, 2)), "modes": [2, 0]}
+        secondary = {}
+        try:
+            secondary["c2"] = brief(verify_secondary(afx, batch, torch, local_rank, "c2", max(1, min(args.steps, 20)), emb["warmup"], not args.no_cpu_baseline))
+            c5 = bench_issue(args, afx, batch, torch, None, 0, 1, local_rank, embedded=emb)
+            secondary["c5"], secondary["c5_fast"] = brief(c5[0]), brief(c5[1])
+            sh = bench_show(args, afx, batch, torch, None, 0, 1, local_rank, embedded=dict(emb, steps=max(1, min(args.steps, 20))))
+            secondary["show"], secondary["show_fast"] = brief(sh[0]), brief(sh[1])
+        except Exception as e:   # a secondary workload must not cost the headline line (the failure is in the line)
+            secondary["error"] = "%s: %s" % (type(e).__name__, e)
+        secondary["seconds"] = round(time.time() - t0, 1)
+        secondary["note"] = ("after the headline's timed region, same process and device; c5 / show in the library's default secret mode (2), c5_fast / "
+                             "show_fast with afx_ctx_set_secret_independent_addressing 0; full lines: python bench.py --workload c2|c5|show [--secret-mode 0]")
 
     if rank == 0:
         total = count * world * args.steps
@@ -852,18 +1108,21 @@ def main():
                        "algorithmic_bytes_per_presentation": ab, "parallelism": "host-sharded x%d, no collective" % world,
                        "step_pipelining": "2 streams" if args.pipelining else "off",
                        "secret_independent_addressing": {0: "nowhere (mode 0)", 1: "everywhere (mode 1)", 2: "prover-side calls (mode 2, the default)"}[secret_mode_of(args)],
-                       "input_generation_s": round(gen_s, 2), "host_pointer_api_presentations_per_s": pcie,
-                       "wire_blob_api_presentations_per_s": wire_rate,
+                       "input_generation_s": round(gen_s, 2),
+                       # the host-side legs: median of `reps` repetitions each (the spread beside it), PCIe and staging inclusive
+                       "host_pointer_api_presentations_per_s": pcie and pcie["median"], "host_pointer_api_spread": pcie,
+                       "host_pointer_api_over_value": (pcie["median"] / (total / elapsed)) if pcie else None,
+                       "wire_blob_api_presentations_per_s": wire_rate and wire_rate["median"], "wire_blob_api_spread": wire_rate,
                        "small_call_ms": None if pcie is None else round(small_call_ms, 4), "small_call_items": 64,
                        "n1_vs_n_note": "the N=1 default workload is C3 (2^20 presentations on the one GPU, \"weak\"); N>1 defaults to C4 (2^22 in all, "
                                        "2^22/N per GPU, \"strong\"): the curve's first point is a different batch size from the rest - immaterial above "
                                        "2^17 items per GPU, where a pass fills the device",
-                       "ranks_seen": ranks_seen, "rank_devices": RANK_DEVICES, "dist_backend": args.dist_backend if had_group else None, "launcher": "bench.py" if os.environ.get("AFX_BENCH_LAUNCHED") else
+                       "ranks_seen": ranks_seen, "rank_devices": RANK_DEVICES, "dist_backend": pg_backend, "dist_backend_fallback": pg_fallback or args.dist_backend_fallback, "launcher": "bench.py" if os.environ.get("AFX_BENCH_LAUNCHED") else
                        ("external" if world > 1 else "none"),
-                       "group_api_presentations_per_s": group_rate, "group_api_items": group_items,
+                       "group_api_presentations_per_s": group_rate and group_rate["median"], "group_api_spread": group_rate, "group_api_items": group_items,
                        "group_api_note": "one process, afx_group_verify_presentations over %d device(s) on host arrays (%d copies of "
                                          "rank 0's batch), PCIe and staging inclusive" % (world, world),
-                       "group_api_error": group_err},
+                       "group_api_error": group_err, "secondary": secondary},
             "roofline": roofline_of(kt, args.workload, ab, count, secret_mode_of(args) == 1),
             "valu": with_value_per_mhz(valu, total / elapsed),
             "cpu_baseline": cpu,
@@ -871,7 +1130,8 @@ def main():
         if UNCHECKED:
             out["unchecked_experiment"] = True
         print(json.dumps(out))
-    issuer.close()
+    if issuer is not None:
+        issuer.close()
 
 
 if __name__ == "__main__":

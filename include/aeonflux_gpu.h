@@ -225,6 +225,16 @@ typedef struct afx_coalescing_stats {
 } afx_coalescing_stats;
 int afx_ctx_get_coalescing_stats(afx_ctx* ctx, afx_coalescing_stats* out);
 
+/* Host copies of LARGE host-pointer calls (default 4 threads).  Issuer::verify on a batch in host memory (src/issuer.rs:141-147
+ * called over a vector of presentations) hands the engine ~2.4 KB per presentation in pageable memory.  A call of more than 16 MB
+ * of rows is cut into slices of 2^17 items on two streams; each slice's rows are gathered into a pinned image by `threads` host
+ * threads (the caller's own among them) that run on the CPUs of the NUMA node the device hangs off, and go to HBM in one
+ * transfer per contiguous run while the previous slice computes; large results come back the same way.  0: the runtime's own
+ * copies out of pageable memory, one per row, on the calling thread wherever it runs (rounds 1-5: 96-97 % of the device-resident
+ * rate with the caller near the device, 90.7 % measured with it elsewhere).  At most 64; no more threads are started than the
+ * node has CPUs the process may use.  Small calls are not affected (their rows already travel as one pinned image). */
+int afx_ctx_set_host_copy_threads(afx_ctx* ctx, uint32_t threads);
+
 /* Challenge trace (parity aid; off by default).  set(rows, count) allocates a device array [rows][count][32]; while it
  * exists, every verification call (presentations, proofs of encryption, issuances) of at most `count` items also
  * stores the challenge it RECOMPUTES for item i of proof r in cell (r, i): r = 0 for the main proof (or the only

@@ -553,6 +553,11 @@ def test_concurrent_calls_on_one_context_under_tsan(tmp_path):
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert "coalescing drive ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
     assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    # ... and the copy pool of large host-pointer calls (the same build)
+    script.write_text(POOL_DRIVER % {"root": ROOT, "lib": out})
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert "pool drive ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
 
 
 def test_concurrent_calls_on_one_context_under_asan(hostsim_lib, tmp_path):
@@ -563,6 +568,66 @@ def test_concurrent_calls_on_one_context_under_asan(hostsim_lib, tmp_path):
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", AFX_PLAN_SELFCHECK="1")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "coalescing drive ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+POOL_DRIVER = r"""
+# Large host-pointer calls: slices of more than 16 MB of rows are gathered into the lane's pinned image by the context's copy pool
+# (plans.cpp Stager::upload, afx::CopyPool) and their results scattered by it.  The fake runtime echoes the first byte of every
+# item's challenge as its status, so every row must land where the plan reads it - with 0 (the runtime's copies), 1, 4 threads, on
+# column arrays, on a sub-range, on a serialized batch (whose staging area has a scratch hole between its runs), and on issue
+# (800 bytes of results per item come back through the pool).
+import os, sys, ctypes as C
+sys.path.insert(0, %(root)r)
+import numpy as np
+import aeonflux_amd as afx
+afx.LIB_PATH = %(lib)r
+from aeonflux_amd import batch, wire
+import bench
+L = afx.lib()
+L.afx_fake_set.argtypes = [C.c_char_p, C.c_int]
+L.afx_fake_set(b"echo", 1)
+params, key, ip = bench.load_fixture("c3_8attrs_SSPPeeee")
+ctx = afx.Context(params, key, ip)
+ctx.set_chunk_items(32768)          # slices of 32768 items x 704 bytes = 23 MB
+shape = afx.Shape()
+shape.n_attributes, shape.n_responses, shape.n_hidden_scalars, shape.n_enc_proofs = 8, 3, 0, 0
+for i, k in enumerate((0, 0, 2, 2, 2, 2, 2, 2)):
+    shape.kinds[i] = k
+cnt = 70001
+rng = np.random.default_rng(5)
+r = lambda *s: rng.integers(0, 256, size=s, dtype=np.uint8)
+pres = {"challenge": r(cnt, 32), "responses": r(3, cnt, 32), "C_x_0": r(cnt, 32), "C_x_1": r(cnt, 32), "C_V": r(cnt, 32), "C_y": r(8, cnt, 32), "attr_values": r(8, cnt, 32), "enc": []}
+want = pres["challenge"][:, 0].copy()
+blob = wire.pack_presentations(shape, pres)
+before = os.sched_getaffinity(0)
+for threads in (4, 0, 1, 3):
+    ctx.set_host_copy_threads(threads)
+    for _ in range(2):
+        assert np.array_equal(batch.verify_presentations(ctx, shape, pres), want), threads
+    soa, keep = batch.presentation_soa(pres)
+    st = np.full(cnt, 0xEE, np.uint8)
+    afx.check(L.afx_verify_presentations_range(ctx.h, C.byref(shape), C.byref(soa), cnt, 1234, 40000, st.ctypes.data))
+    assert np.array_equal(st[1234:41234], want[1234:41234]) and (st[:1234] == 0xEE).all() and (st[41234:] == 0xEE).all(), threads
+    assert np.array_equal(wire.verify_wire(ctx, blob), want), threads
+    assert os.sched_getaffinity(0) == before, "the caller's mask was not restored"
+# issue: the fake kernels write nothing, so the outputs are the zeros the staging area starts from - what matters is that
+# 100 MB of result rows come back through the pool without touching memory that is not theirs
+kinds = [0] * 8
+ctx.set_host_copy_threads(4)
+o, st = batch.issue(ctx, kinds, r(8, cnt, 32), r(cnt, 64), r(cnt, 64), r(cnt, 32))
+assert len(st) == cnt and o["responses"].shape == (13, cnt, 32) and not o["t"].any()
+ctx.close()
+print("pool drive ok")
+"""
+
+
+def test_large_host_calls_through_the_copy_pool_under_asan(hostsim_lib, tmp_path):
+    script = tmp_path / "drive.py"
+    script.write_text(POOL_DRIVER % {"root": ROOT, "lib": hostsim_lib})
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "pool drive ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
 NUMA_DRIVER = r"""
