@@ -16,6 +16,12 @@ OK, E_BAD_ARGS, E_BAD_PARAMS, E_NO_DEVICE, E_HIP, E_NO_KEY = 0, -1, -2, -3, -4, 
 E_NO_MEMORY = -6
 ST_OK, ST_VERIFICATION_FAILURE, ST_MAC_CREATION, ST_NO_SYMMETRIC_KEY, ST_UNDECRYPTABLE = 0, 1, 2, 3, 4
 ATTR_PUBLIC_SCALAR, ATTR_SECRET_SCALAR, ATTR_PUBLIC_POINT, ATTR_EITHER_POINT, ATTR_SECRET_POINT = range(5)
+# afx_ctx_set_plan_variants (tests: the alternatives among a small pass's equivalent plans and kernels)
+VARIANT_SEGMENTS_1, VARIANT_SEGMENTS_2, VARIANT_SEGMENTS_4, VARIANT_ONE_WAVE_CHAINS, VARIANT_HASH_HALF_WAVE, VARIANT_NO_POINTSUM_TREE, VARIANT_SELFCHECK = \
+    0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40
+# Tests that drive whole scripts under one variant (tests/test_hostsim.py) set this before creating contexts: every Context made
+# afterwards starts with these flags.  A hook of this python mirror, not of the library - which reads no variant from the environment.
+DEFAULT_PLAN_VARIANTS = int(os.environ.get("AFX_TEST_PLAN_VARIANTS", "0"), 0)
 ENC_PUBLIC_SCALAR, ENC_SECRET_SCALAR, ENC_PUBLIC_POINT, ENC_SECRET_POINT = range(4)
 
 
@@ -187,6 +193,7 @@ def lib():
         _LIB.afx_ctx_get_core_clock_samples.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_uint32)]
         _LIB.afx_ctx_set_coalescing.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         _LIB.afx_ctx_set_host_copy_threads.argtypes = [C.c_void_p, C.c_uint32]
+        _LIB.afx_ctx_set_plan_variants.argtypes = [C.c_void_p, C.c_uint32]
         _LIB.afx_ctx_get_coalescing_stats.argtypes = [C.c_void_p, C.POINTER(CoalescingStats)]
         _LIB.afx_ctx_get_plan_cache_stats.argtypes = [C.c_void_p, C.POINTER(PlanCacheStats)]
         _LIB.afx_verify_presentations_range.argtypes = [C.c_void_p, C.POINTER(Shape), C.POINTER(PresentationSoA), C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
@@ -230,6 +237,8 @@ class Context:
             check(lib().afx_ctx_create(C.byref(h), device, sysparams, len(sysparams), amacs_key, len(amacs_key) if amacs_key else 0,
                                        issuer_params))
             self.h, self._owned = h, True
+        if DEFAULT_PLAN_VARIANTS:
+            check(lib().afx_ctx_set_plan_variants(self.h, DEFAULT_PLAN_VARIANTS))
         self.n = lib().afx_ctx_n_attributes(self.h)
         self.device = device
 
@@ -324,6 +333,10 @@ class Context:
     def set_coalescing(self, max_wait_us=2000, max_items=4096):
         """concurrent small host-pointer calls share launch sets (on by default); max_items=0 switches it off (afx_ctx_set_coalescing)"""
         check(lib().afx_ctx_set_coalescing(self.h, max_wait_us, max_items))
+
+    def set_plan_variants(self, flags):
+        """force the alternatives among a small pass's equivalent plans / kernels (VARIANT_*; tests) - afx_ctx_set_plan_variants"""
+        check(lib().afx_ctx_set_plan_variants(self.h, flags))
 
     def set_host_copy_threads(self, threads):
         """host threads that gather a large host-pointer call's rows into the pinned image; 0 = the runtime's pageable copies

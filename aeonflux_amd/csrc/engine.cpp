@@ -470,18 +470,15 @@ void Assembler::msm(std::vector<afx_msm_job> jobs) {
   compress(cjobs, ctx->walk_rows(count, cjobs.size(), small));
 }
 
-// AFX_SEGMENTS=1|2|4|8 (measurement aid; default 8): into how many segments a small prover pass cuts a secret scalar on a per-item base
+// Into how many segments a small prover pass cuts a secret scalar on a per-item base: 8 (4 above 256 items), or what
+// afx_ctx_set_plan_variants forces (AFX_VARIANT_SEGMENTS_1 | _2 | _4: tests)
 // Does this pass keep secret scalars out of its addresses?  What the context's mode says (afx_ctx_set_secret_independent_addressing) -
 // and, whatever it says, a PROVER pass small enough for the segmented chains: there the secret-independent plan is also the faster
 // one (16-window chains over kept two-entry tables against 64 windows of four doublings), so mode 0 has nothing to offer it.
 bool Assembler::secure() const { return ctx->secure_plan(secret_scalars) || (secret_scalars && segments() > 1); }
 uint32_t Assembler::segments() const {
-  static const uint32_t env = [] {
-    const char* e = getenv("AFX_SEGMENTS");
-    const int v = e ? atoi(e) : 8;
-    return (v == 1 || v == 2 || v == 4 || v == 8) ? (uint32_t)v : 8u;
-  }();
-  static const uint32_t wide = [] { const char* e = getenv("AFX_SEGMENT_WAVES"); return e ? (uint32_t)atoi(e) : 32u; }();   // (measurement aid; measured: up to 2048 items the segments pay)
+  const uint32_t env = (ctx->variants & AFX_VARIANT_SEGMENTS_1) ? 1u : (ctx->variants & AFX_VARIANT_SEGMENTS_2) ? 2u : (ctx->variants & AFX_VARIANT_SEGMENTS_4) ? 4u : 8u;
+  static constexpr uint32_t wide = 32;   // waves of 64 items: measured, up to 2048 items the segments pay
   static_assert(AFX_SECVAR_WINDOWS % 8 == 0 && AFX_POWERS_MAX >= 7, "a scalar's windows divide into up to eight segments");
   // the passes whose chains run four waves each on a device they leave idle (kernels.hip afxk_msm): up to 256 items
   // Prover passes only.  A verifier's pass is ONE stage of public scalars on the presentation's own points: its powers (224 doublings)
@@ -651,7 +648,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
   // product runs on the fourth wave at no cost in rounds, and the pass does not wait for k_table_affine's inversion (64 us of a 1-item call)
   // (up to 512 items: such a launch takes the four-wave chains whatever its size, and wider passes are better off on one wave per
   // chain - a 2048-item show 2.59 -> 2.90 ms with them)
-  const bool cached_narrow = segmenting_ && afxk_quad_chains() != 0 && ctx->row_waves(count) <= 8;
+  const bool cached_narrow = segmenting_ && !(ctx->variants & AFX_VARIANT_ONE_WAVE_CHAINS) && ctx->row_waves(count) <= 8;
   for (size_t i = 0; i < n; i++)
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
   // Jobs whose result is only ever encoded (no consumer of the point itself, no addend) run on halved scalars; k_compress2x
@@ -1312,7 +1309,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
       case L_COMPRESS: AFX_HIP(afxk_compress2x(s, (const afx_compress_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
       case L_NEGENC: AFX_HIP(afxk_negenc(s, (const afx_negenc_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
       case L_TABLE_AFFINE: AFX_HIP(afxk_table_affine(s, (const afx_table_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
-      case L_POINTSUM: AFX_HIP(afxk_pointsum(s, (const afx_pointsum_job*)jobs, nrows, rw, passes, max_count, odd)); break;
+      case L_POINTSUM: AFX_HIP(afxk_pointsum(s, (const afx_pointsum_job*)jobs, nrows, rw, passes, max_count, odd, ctx->variants)); break;
       case L_POWERS: AFX_HIP(afxk_powers(s, (const afx_powers_job*)jobs, nrows, rw, passes, max_count)); break;
       case L_MSM_TABLES: AFX_HIP(afxk_msm_tables(s, odd, (const afx_table_job*)jobs, nrows, rw, passes, max_count)); break;
       case L_MSM_FIXED: case L_MSM_WINDOW: case L_MSM_NAF: {
@@ -1322,13 +1319,13 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
         if (ctx->pipelining && other.msm_recorded) AFX_HIP(hipStreamWaitEvent(s, other.msm_done, 0));
         AFX_HIP(afxk_msm(s, kind == L_MSM_FIXED ? 0 : kind == L_MSM_WINDOW ? 1 : 2, encodes, secret, (const afx_msm_djob*)jobs, nrows,
                          (const int32_t*)ctx->d_pos_tables.p, (const int32_t*)ctx->d_sec_tables.p, rw, passes, pass_host, max_count,
-                         (ctx->timing && kind == L_MSM_WINDOW) ? ctx->clock_probe() : nullptr));
+                         (ctx->timing && kind == L_MSM_WINDOW) ? ctx->clock_probe() : nullptr, ctx->variants));
         if (ctx->pipelining) { AFX_HIP(hipEventRecord(L.msm_done, s)); L.msm_recorded = true; }
         break;
       }
       case L_HASH:
         // small passes: the permutation spread over 32 lanes per item (kernels.hip k_hash_coop), while the device has lanes to spare
-        if (coop) AFX_HIP(afxk_hash_coop(s, (const afx_hash_program*)jobs, nrows, rw, passes, max_count));
+        if (coop) AFX_HIP(afxk_hash_coop(s, (const afx_hash_program*)jobs, nrows, rw, passes, max_count, ctx->variants));
         else AFX_HIP(afxk_hash(s, (const afx_hash_program*)jobs, nrows, rw, passes, max_count));
         break;
       case L_FROM_UNIFORM: AFX_HIP(afxk_from_uniform_jobs(s, (const afx_uniform_job*)jobs, nrows, rw, passes, max_count)); break;

@@ -230,7 +230,8 @@ struct afx_ctx {
   std::map<std::pair<std::string, uint32_t>, CachedPlan> plan_cache;
   size_t plan_cache_bytes = 0;
   uint64_t plan_cache_tick = 0, plan_cache_hits = 0, plan_cache_misses = 0, plan_cache_evictions = 0;   // afx_ctx_get_plan_cache_stats
-  bool plan_selfcheck = false;   // AFX_PLAN_SELFCHECK=1 at context creation (tests): every plan is assembled twice against different
+  uint32_t variants = 0;         // afx_ctx_set_plan_variants (AFX_VARIANT_*; tests): forced choices among equivalent plans / kernels; part of every plan key
+  bool plan_selfcheck = false;   // AFX_VARIANT_SELFCHECK, or AFX_PLAN_SELFCHECK=1 at context creation (tests): every plan is assembled twice against different
                                  // provisional bases and both relocated copies must be byte-identical - a pointer field the relocation
                                  // does not know shows up as a difference
   afx::Session* session = nullptr;   // set while several small calls are being collected into one set of launches (statements.hpp)
@@ -244,7 +245,7 @@ struct afx_ctx {
   Stager* cur_stager = nullptr;   // the host-pointer front end whose *_dev call is running (its staged ranges: plan reuse), or null
   // afx_ctx_set_host_copy_threads: how many host threads gather a large host-pointer call's rows into the lane's pinned image
   // (afx::CopyPool, made at the first such call); 0: the runtime's own copies out of pageable memory on the caller's thread
-  uint32_t host_copy_threads = 4;
+  uint32_t host_copy_threads = 0;
   std::unique_ptr<afx::CopyPool> copy_pool;
   // optional per-launch HIP-event timing on `stream` (bench.py's roofline figure)
   bool timing = false;

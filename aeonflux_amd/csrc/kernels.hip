@@ -1848,21 +1848,17 @@ static void launch_msm_rows(hipStream_t s, int encodes, int secret, dim3 grid, d
 }
 // rows == null: a plan's own launch; `pass_host` is the HOST copy of its pass (the fields travel as kernel arguments).  Otherwise a
 // merged launch: `jobs` is the blob's base, rows / passes are device tables.
-int afxk_quad_chains() {
-  static const bool quad_on = !(getenv("AFX_QUAD_CHAINS") && getenv("AFX_QUAD_CHAINS")[0] == '0');
-  return quad_on ? 1 : 0;
-}
 hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t njobs, const int32_t* pos_tables,
-                    const int32_t* sec_tables, const afx_row* rows, const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* clock_probe) {
+                    const int32_t* sec_tables, const afx_row* rows, const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* clock_probe, uint32_t variants) {
   if (secret && !sec_tables) return hipErrorInvalidValue;
   // secret & 2: some job's narrow tables hold cached entries (afx_msm_job.narrow == 2): only the four-wave chains read those, whatever
   // the launch's size (such jobs come from small prover passes; a merged launch wide enough to matter is a request of dozens of shapes)
   const bool only_quad = (secret & 2) != 0;
   secret = secret != 0;
   // a launch that leaves the device idle - windowed or fixed-base jobs without secret terms or in-kernel encodings, at most two
-  // blocks of four waves per compute unit in all - runs four waves per item chain (k_msm_quad).  AFX_QUAD_CHAINS=0 switches it off
-  // (measurement aid: the two kernels give the same bytes).
-  static const bool quad_on = !(getenv("AFX_QUAD_CHAINS") && getenv("AFX_QUAD_CHAINS")[0] == '0');
+  // blocks of four waves per compute unit in all - runs four waves per item chain (k_msm_quad).  AFX_KV_ONE_WAVE_CHAINS switches it
+  // off (tests: the two kernels give the same bytes).
+  const bool quad_on = !(variants & AFX_KV_ONE_WAVE_CHAINS);
   const uint32_t quad_blocks = (max_count + 63) / 64;
   // (a plan on its own up to 1024 blocks: 512-item calls gain 7 %; merged launches up to 512: at 1024 a 16-shape request loses 14 %)
   if (only_quad && (encodes || kind == MSM_NAF || !max_count)) return hipErrorInvalidValue;
@@ -1918,11 +1914,11 @@ hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, const afx_walk
   hipLaunchKernelGGL(k_negenc, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
-hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count, int many_parts) {
+hipError_t afxk_pointsum(hipStream_t s, const afx_pointsum_job* jobs, uint32_t njobs, const afx_row* rows, const afx_pass* passes, uint32_t max_count, int many_parts, uint32_t variants) {
   // the idle-device form, under the same rule as k_msm_quad (and the same switch)
-  static const bool quad_on = !(getenv("AFX_QUAD_CHAINS") && getenv("AFX_QUAD_CHAINS")[0] == '0');
-  // jobs of many parts over few items: a lane per part (AFX_POINTSUM_TREE=0 switches it off: measurement aid, same bytes)
-  static const bool tree_on = !(getenv("AFX_POINTSUM_TREE") && getenv("AFX_POINTSUM_TREE")[0] == '0');
+  const bool quad_on = !(variants & AFX_KV_ONE_WAVE_CHAINS);
+  // jobs of many parts over few items: a lane per part (AFX_KV_NO_POINTSUM_TREE switches it off: tests, same bytes)
+  const bool tree_on = !(variants & AFX_KV_NO_POINTSUM_TREE);
   if (quad_on && tree_on && many_parts && max_count && (uint64_t)max_count * njobs <= 1024) {
     hipLaunchKernelGGL(k_pointsum_tree, dim3(max_count, njobs), dim3(256), 0, s, jobs, rows, passes);
     return hipGetLastError();
@@ -1938,9 +1934,9 @@ hipError_t afxk_powers(hipStream_t s, const afx_powers_job* jobs, uint32_t njobs
   hipLaunchKernelGGL(k_powers_quad, dim3((max_count + 63) / 64, njobs), dim3(256), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
-hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
-  // a wave per (item, program) while that leaves the device mostly idle (AFX_HASH_WAVE=0: measurement aid, the 32-lane groups always)
-  static const bool wave_on = !(getenv("AFX_HASH_WAVE") && getenv("AFX_HASH_WAVE")[0] == '0');
+hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* progs, uint32_t nprogs, const afx_row* rows, const afx_pass* passes, uint32_t max_count, uint32_t variants) {
+  // a wave per (item, program) while that leaves the device mostly idle (AFX_KV_HASH_HALF_WAVE: tests, the 32-lane groups always)
+  const bool wave_on = !(variants & AFX_KV_HASH_HALF_WAVE);
   if (wave_on && (uint64_t)max_count * nprogs <= 2048) {
     const uint32_t b64 = max_count <= 1 ? 64u : max_count <= 2 ? 128u : (uint32_t)AFX_BLOCK, per64 = b64 / 64;
     hipLaunchKernelGGL(k_hash_coop64, dim3((max_count + per64 - 1) / per64, nprogs), dim3(b64), 0, s, progs, rows, passes);

@@ -6,6 +6,11 @@
 #pragma once
 #include <stdint.h>
 
+// afx_ctx_set_plan_variants (include/aeonflux_gpu.h AFX_VARIANT_*): the bits the launch wrappers look at
+#define AFX_KV_ONE_WAVE_CHAINS 0x08u     /* no four-wave chains (k_msm_quad, k_pointsum_quad, k_pointsum_tree) */
+#define AFX_KV_HASH_HALF_WAVE 0x10u      /* cooperative transcripts on 32 lanes per item, never a wave each */
+#define AFX_KV_NO_POINTSUM_TREE 0x20u    /* sums of many parts without the lane-per-part kernel */
+
 #define AFX_CLOCK_SLOTS 64     /* blocks of a k_msm launch that read the clock counters (kernels.hip msm_body): (cycles, 100 MHz ticks) each */
 #define AFX_MSM_MAX_TERMS 72   /* Z job: 2 + n + #public scalars <= 2 + 2n; issuance: n + 4 */
 #define AFX_TABLE_ENTRIES 9            /* variable bases: 0*P (identity) .. 8*P, signed 4-bit windows */

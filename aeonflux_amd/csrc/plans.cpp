@@ -227,11 +227,7 @@ int run_chunked(afx_ctx* c, size_t count, const BuildFn& build, const PlanKey& k
 // ------------------------------------------------------------------------------------------------
 // Stager
 // ------------------------------------------------------------------------------------------------
-// AFX_PACK_LIMIT_MB (measurement aid): up to how many bytes a call's rows are gathered into one pinned image
-size_t Stager::pack_limit() {
-  static const size_t lim = [] { const char* e = getenv("AFX_PACK_LIMIT_MB"); return e ? (size_t)strtoull(e, nullptr, 10) << 20 : PACK_LIMIT; }();
-  return lim;
-}
+size_t Stager::pack_limit() { return PACK_LIMIT; }
 static int ensure_pinned(void*& buf, size_t& cap, size_t bytes, size_t granule) {
   if (bytes <= cap) return AFX_OK;
   if (buf) { memset(buf, 0, cap); (void)hipHostFree(buf); buf = nullptr; cap = 0; }
@@ -625,13 +621,15 @@ int host_pipe(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey& joi
   }
   const int entry_force = c->force_lane;
   Stager* const entry_stager = c->cur_stager;
-  const size_t per = host_slice_items(c);
+  // A short first slice, then whole passes: the first slice's copy is the one nothing overlaps, and slices the size of a pass
+  // compute at the large-pass rate (statements.hpp host_slice_items; profiles/r06_host_slices.txt)
+  const size_t per = host_slice_items(c), first = host_first_slice_items(c);
   std::unique_ptr<Stager> st[2];
   int rc = AFX_OK;
   size_t i = 0;
   try {
     for (size_t off = 0; off < count && !rc; i++) {
-      const size_t n = std::min(per, count - off);
+      const size_t n = std::min(i == 0 ? std::min(first, per) : per, count - off);
       const int lane = (int)(i & 1);
       if (st[lane]) { rc = st[lane]->drain(); st[lane].reset(); }
       if (rc) break;

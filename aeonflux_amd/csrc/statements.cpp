@@ -113,6 +113,13 @@ extern "C" int afx_ctx_set_coalescing(afx_ctx* c, uint32_t max_wait_us, uint32_t
   if (max_items) c->co.max_items = max_items;
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
+extern "C" int afx_ctx_set_plan_variants(afx_ctx* c, uint32_t flags) try {
+  const uint32_t seg = flags & (AFX_VARIANT_SEGMENTS_1 | AFX_VARIANT_SEGMENTS_2 | AFX_VARIANT_SEGMENTS_4);
+  if (!c || (flags & ~(uint32_t)AFX_VARIANT_ALL) || (seg & (seg - 1))) { set_error("unknown plan variant flags (at most one AFX_VARIANT_SEGMENTS_*)"); return AFX_E_BAD_ARGS; }
+  CtxLock lock(c);
+  { std::lock_guard<std::mutex> sg(c->settings_mu); c->variants = flags & ~(uint32_t)AFX_VARIANT_SELFCHECK; c->plan_selfcheck = (flags & AFX_VARIANT_SELFCHECK) != 0; }
+  return AFX_OK;
+} catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_set_host_copy_threads(afx_ctx* c, uint32_t threads) try {
   if (!c || threads > 64) { set_error("host copy threads out of range (0 .. 64)"); return AFX_E_BAD_ARGS; }
   CtxLock lock(c);
@@ -303,7 +310,6 @@ int afx_ctx_create_impl(afx_ctx** out, int device, const uint8_t* sp, size_t spl
   if (n == 0 || n > AFX_MAX_ATTRIBUTES || splen != sizeof_system_parameters(n)) { set_error("SystemParameters length / attribute count"); return AFX_E_BAD_PARAMS; }
   std::unique_ptr<afx_ctx, void (*)(afx_ctx*)> c(new afx_ctx(), afx_ctx_destroy);
   { const char* sc = getenv("AFX_PLAN_SELFCHECK"); c->plan_selfcheck = sc && sc[0] == '1'; }   // tests: every plan assembled twice and compared
-  { const char* fl = getenv("AFX_COALESCE_INFLIGHT"); if (fl && fl[0] >= '1' && fl[0] <= '4' && !fl[1]) c->co.max_inflight = fl[0] - '0'; }   // measurement aid
   c->device = device;
   c->n = n;
   c->g = n < 3 ? 3 : n;

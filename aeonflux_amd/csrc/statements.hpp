@@ -61,7 +61,7 @@ inline afx_shape canonical_shape(const afx_shape& sh) {
 inline uint64_t mode_flags(const afx_ctx* c) {
   // (bits 5-7: the chain width a collecting session asks of the latency plan; outside a session it follows from the count, which is in the key)
   return (c->strict ? 1u : 0u) | (c->fixed_key_schedule ? 2u : 0u) | ((uint64_t)(c->secret_mode & 3) << 3) | ((uint64_t)(c->merge_class & 7) << 5) |
-         ((uint64_t)c->small_batch_items << 8);
+         ((uint64_t)c->small_batch_items << 8) | ((uint64_t)(c->variants & 0x3f) << 40);   // (small_batch_items <= 2^16: bits 8-24)
 }
 
 namespace afx {
@@ -384,13 +384,17 @@ struct Stager {
 };
 
 // Items per slice of a host-pointer call: slices alternate between the two lanes, so the host-to-device copy of one
-// slice overlaps the kernels of the previous one.  2^17 items keep a pass within 1-2 % of the large-pass rate.
-static constexpr size_t HOST_SLICE_DEFAULT = size_t(1) << 17;
+// slice overlaps the kernels of the previous one.  The FIRST slice's copy overlaps nothing, so it is short (2^16 items: 159 MB of
+// C3 rows, ~4 ms; its kernels - 23 ms - then cover the next slice's 25-50 ms of copy only in part, but the slice after computes
+// meanwhile); every later slice is a whole pass (afx_ctx_set_chunk_items; 2^19), which computes at the large-pass rate.  Measured
+// on C3, 2^20 presentations in pageable memory, against the device-resident rate of the same process (profiles/r06_host_slices.txt):
+// slices of 2^17 (rounds 3-5) 96.2-96.8 %; 2^16 then 2^19: 97.9-98.4 %; 2^14, 2^16, 2^18, 2^19: 97.8-98.9 %.
+static constexpr size_t HOST_FIRST_SLICE = size_t(1) << 16;
 inline size_t host_slice_items(const afx_ctx* c) {
   if (c->trace) return ~size_t(0);   // the challenge trace is indexed by the item's position in ONE *_dev call
-  const size_t chunk = c->chunk_items ? c->chunk_items : CHUNK_DEFAULT;
-  return std::min(chunk, HOST_SLICE_DEFAULT);
+  return c->chunk_items ? c->chunk_items : CHUNK_DEFAULT;
 }
+inline size_t host_first_slice_items(const afx_ctx* c) { return c->trace ? ~size_t(0) : HOST_FIRST_SLICE; }
 // Runs `slice(stager, first, n)` over [0, count) in slices on alternating lanes; `slice` stages, launches and calls
 // fetch_all() on the Stager it is given; the pipe drains a lane before that lane is used again, and both at the end.
 // Under a Session the call is one slice whose work is left with the session.

@@ -550,6 +550,24 @@ class Ranks:
         import torch.distributed as dist
         self.torch, self.dist, self.world, self.dev = torch, dist, world, torch.device("cuda", local_rank)
         self.group, self.backend, self.fallback = None, "gloo", None
+        # (gloo and RCCL announce themselves with printf: while the groups form, file descriptor 1 is the process's stderr, so that
+        # rank 0's stdout stays the ONE JSON line of the contract)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            self._form(torch, dist, rank, world, want)
+        finally:
+            sys.stdout.flush()
+            try:
+                C.CDLL(None).fflush(None)   # (the C library's own stdout buffer: RCCL's banner would otherwise surface at exit)
+            except OSError:
+                pass
+            os.dup2(saved, 1)
+            os.close(saved)
+
+    def _form(self, torch, dist, rank, world, want):
+        import datetime
         try:
             dist.init_process_group(backend="gloo", timeout=datetime.timedelta(minutes=10))
         except Exception as e:   # noqa: BLE001

@@ -225,14 +225,35 @@ typedef struct afx_coalescing_stats {
 } afx_coalescing_stats;
 int afx_ctx_get_coalescing_stats(afx_ctx* ctx, afx_coalescing_stats* out);
 
-/* Host copies of LARGE host-pointer calls (default 4 threads).  Issuer::verify on a batch in host memory (src/issuer.rs:141-147
+/* Plan variants (test aid; 0 = every choice automatic, the default).  Which of several equivalent layouts a SMALL pass takes is
+ * decided by its size and by the width of the launch set it shares with other calls: secret scalars of a prover pass in 8, 4 or 1
+ * segment(s); chains on four waves per item or one; a transcript on a wave or on 32 lanes; sums of many parts with a lane per part
+ * or per item.  Every combination returns the same bytes.  The flags force the alternatives at any size, so that tests can compare
+ * each of them with the CPU oracle (tests/test_gpu_plan_variants.py) instead of reaching them only through particular sizes and
+ * concurrency.  AFX_VARIANT_SELFCHECK: every plan is assembled twice against different provisional addresses and the two copies,
+ * relocated to the same place, must be equal byte for byte (also: AFX_PLAN_SELFCHECK=1 in the environment at context creation).
+ * The flags are part of every plan's cache key.  Not a tuning interface: the automatic choice is the measured best. */
+#define AFX_VARIANT_SEGMENTS_1 0x01u        /* small prover passes: whole chains                                       */
+#define AFX_VARIANT_SEGMENTS_2 0x02u        /* ... two segments per secret scalar                                      */
+#define AFX_VARIANT_SEGMENTS_4 0x04u        /* ... four (what passes of 257 .. 2048 items take by themselves)          */
+#define AFX_VARIANT_ONE_WAVE_CHAINS 0x08u   /* no four-wave chains (what launch sets wider than 512 blocks take)       */
+#define AFX_VARIANT_HASH_HALF_WAVE 0x10u    /* cooperative transcripts on 32 lanes per item (more than 2048 of them)   */
+#define AFX_VARIANT_NO_POINTSUM_TREE 0x20u  /* sums of many parts on one lane per item                                 */
+#define AFX_VARIANT_SELFCHECK 0x40u
+#define AFX_VARIANT_ALL 0x7fu
+int afx_ctx_set_plan_variants(afx_ctx* ctx, uint32_t flags);
+
+/* Host copies of LARGE host-pointer calls (default 0: off).  Issuer::verify on a batch in host memory (src/issuer.rs:141-147
  * called over a vector of presentations) hands the engine ~2.4 KB per presentation in pageable memory.  A call of more than 16 MB
  * of rows is cut into slices of 2^17 items on two streams; each slice's rows are gathered into a pinned image by `threads` host
  * threads (the caller's own among them) that run on the CPUs of the NUMA node the device hangs off, and go to HBM in one
- * transfer per contiguous run while the previous slice computes; large results come back the same way.  0: the runtime's own
- * copies out of pageable memory, one per row, on the calling thread wherever it runs (rounds 1-5: 96-97 % of the device-resident
- * rate with the caller near the device, 90.7 % measured with it elsewhere).  At most 64; no more threads are started than the
- * node has CPUs the process may use.  Small calls are not affected (their rows already travel as one pinned image). */
+ * transfer per contiguous run while the previous slice computes; large results come back the same way.  0 (the default): the
+ * runtime's own copies out of pageable memory, one per row, on the calling thread wherever it runs.  Measured on a two-socket
+ * EPYC 9575F host (profiles/r06_host_pointer_numa.txt): with 0 the call keeps 95.6-96.6 % of the device-resident rate whether the
+ * caller's thread and arrays sit on the device's node or the other one; the pool keeps 93-95.4 % (its gather is a second pass over
+ * the rows that the runtime's pin-in-place transfer does not make).  It is for hosts whose runtime stages pageable copies through a
+ * single thread far from the device; this pool's boxes do not.  At most 64; no more threads are started than the node has CPUs the
+ * process may use.  Small calls are not affected (their rows already travel as one pinned image). */
 int afx_ctx_set_host_copy_threads(afx_ctx* ctx, uint32_t threads);
 
 /* Challenge trace (parity aid; off by default).  set(rows, count) allocates a device array [rows][count][32]; while it

@@ -138,9 +138,8 @@ hipError_t afxk_msm_tables(hipStream_t, int kind, const afx_table_job* j, uint32
   for (uint32_t i = 0; i < n; i++) { hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e; CHECK_PTR(job_of(j, rows, i).var); sink += job_of(j, rows, i).table_slot; }
   return hipSuccess;
 }
-int afxk_quad_chains() { return !(getenv("AFX_QUAD_CHAINS") && getenv("AFX_QUAD_CHAINS")[0] == '0'); }
 hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t n, const int32_t*, const int32_t* sec_tables, const afx_row* rows,
-                    const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* probe) {
+                    const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* probe, uint32_t variants) {
   if (!rows) {   // a plan's own launch: the pass travels as kernel arguments, from its host copy - which must equal the device's
     if (!pass_host || memcmp(pass_host, passes, sizeof(afx_pass)) != 0) return hipErrorInvalidValue;
   } else if (kind == 2) return hipErrorInvalidValue;   // no merged NAF launches
@@ -219,7 +218,7 @@ hipError_t afxk_negenc(hipStream_t, const afx_negenc_job* j, const afx_walk_row*
 hipError_t afxk_compress2x(hipStream_t, const afx_compress_job* j, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
   return walk_rows((const uint8_t*)j, sizeof(afx_compress_job), rows, nrows, passes, max_count, 0);
 }
-hipError_t afxk_pointsum(hipStream_t, const afx_pointsum_job* jobs, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count, int) {
+hipError_t afxk_pointsum(hipStream_t, const afx_pointsum_job* jobs, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count, int, uint32_t) {
   for (uint32_t i = 0; i < n; i++) {
     hipError_t e = check_pass(pass_of(passes, rows, i), max_count); if (e) return e;
     const afx_pointsum_job& j = job_of(jobs, rows, i);
@@ -252,7 +251,7 @@ hipError_t afxk_hash(hipStream_t, const afx_hash_program* p, uint32_t n, const a
   }
   return hipSuccess;
 }
-hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* p, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count) {
+hipError_t afxk_hash_coop(hipStream_t s, const afx_hash_program* p, uint32_t n, const afx_row* rows, const afx_pass* passes, uint32_t max_count, uint32_t) {
   uint64_t groups = 0;
   for (uint32_t i = 0; i < n; i++) groups += pass_of(passes, rows, i).count;
   if (groups > AFX_HASH_COOP_GROUPS) return hipErrorInvalidValue;   // only small passes hash with a lane group per item

@@ -170,7 +170,7 @@ for n, layout, hide in ((4, "SSPE", [0, 3]), (16, "SSSSSSSSPPPPEEEE", [12, 13, 1
     # ... but a SMALL prover pass takes the secret-independent plan in every mode: its segmented chains are the faster ones
     ctx.set_small_batch_items(2048)
     batch.issue(ctx, kinds, values, rb(3, 64), rb(3, 64), rb(3, 32))
-    if os.environ.get("AFX_SEGMENTS") != "1":   # (whole chains, a measurement aid: then mode 0 means the fast tables at every size)
+    if not (afx.DEFAULT_PLAN_VARIANTS & afx.VARIANT_SEGMENTS_1):   # (whole chains forced: then mode 0 means the fast tables at every size)
         assert ctx.plan_stats() == sec_small and sec_small["secret_terms"] > 3 * n
     mhz = C.c_double(-1)
     assert afx.lib().afx_ctx_get_core_clock_mhz(ctx.h, C.byref(mhz)) == 0 and mhz.value >= 0
@@ -273,8 +273,10 @@ print("hostsim ok")
 
 
 # the plans of small prover passes come in three forms (engine.cpp Assembler::segments, msm_list): segments over kept CACHED tables (the
-# default), segments over kept affine tables (no four-wave chains: AFX_QUAD_CHAINS=0), and whole chains (AFX_SEGMENTS=1)
-@pytest.mark.parametrize("plan_env", [{}, {"AFX_QUAD_CHAINS": "0", "AFX_SEGMENTS": "4"}, {"AFX_SEGMENTS": "1"}], ids=["default", "affine-segments", "whole-chains"])
+# default), segments over kept affine tables (no four-wave chains: AFX_VARIANT_ONE_WAVE_CHAINS | AFX_VARIANT_SEGMENTS_4), and whole
+# chains (AFX_VARIANT_SEGMENTS_1) - afx_ctx_set_plan_variants, applied to every context the script makes by the python mirror's
+# AFX_TEST_PLAN_VARIANTS hook (aeonflux_amd.DEFAULT_PLAN_VARIANTS)
+@pytest.mark.parametrize("plan_env", [{}, {"AFX_TEST_PLAN_VARIANTS": "0x0c"}, {"AFX_TEST_PLAN_VARIANTS": "0x01"}], ids=["default", "affine-segments", "whole-chains"])
 def test_every_entry_point_assembles_cleanly_under_asan(hostsim_lib, tmp_path, plan_env):
     script = tmp_path / "drive.py"
     script.write_text(DRIVER % {"root": ROOT, "lib": hostsim_lib})

@@ -80,7 +80,7 @@ cd $R
 python3 tools/mixed_concurrency.py 64 16 > $O/${TAG}_mixed_concurrency.txt 2>&1
 for a in "8 16" "64 1" "32 64" "64 256"; do python3 tools/mixed_concurrency.py $a >> $O/${TAG}_mixed_concurrency.txt 2>&1; done
 python3 tools/small_call_latency.py > $O/${TAG}_small_call_latency.txt 2>&1
-for m in 4 16 64; do AFX_PACK_LIMIT_MB=$m python3 tools/midsize_host_calls.py; done > $O/${TAG}_midsize_host_calls.txt 2>&1
+python3 tools/midsize_host_calls.py > $O/${TAG}_midsize_host_calls.txt 2>&1
 # concurrent small calls on ONE context (round 5): K threads x 1-item calls through the native driver
 python3 tools/concurrent_small_calls.py --one-context --threads 1,2,4,8,16,32,64,128,256 > $O/${TAG}_coalesced_calls.txt 2>&1
 # one 1-item call of each prover / verifier operation, launch by launch

@@ -4,5 +4,5 @@
 for room in 1 2048 3072 4096 6144 1000000; do
   echo "== AFX_CHAIN_ROOM=$room"
   for a in "64 16" "32 16" "32 64" "64 256" "8 1024"; do AFX_CHAIN_ROOM=$room python3 tools/mixed_concurrency.py $a | grep -v "kernels of" | cut -c1-110; done
-  AFX_CHAIN_ROOM=$room AFX_PACK_LIMIT_MB=16 python3 tools/midsize_host_calls.py
+  AFX_CHAIN_ROOM=$room python3 tools/midsize_host_calls.py
 done

@@ -1,6 +1,6 @@
 """One synchronous host-pointer afx_verify_presentations call (C3 shape) at mid sizes, ms per call: the cost of bringing ~75 input
-rows to the device (python tools/midsize_host_calls.py; AFX_PACK_LIMIT_MB picks up to which size the rows are gathered into one
-pinned image and sent in one copy instead of 75 copies from pageable memory)."""
+rows to the device (python tools/midsize_host_calls.py; up to 16 MB the rows are gathered into one pinned image and sent in one
+copy instead of 75 copies from pageable memory: Stager::PACK_LIMIT, chosen with this tool in round 4 - profiles/r04_midsize_host_calls.txt)."""
 import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -25,4 +25,4 @@ for n in (1 << 10, 1 << 11, 1 << 12, 1 << 13, 1 << 14, 1 << 15):
     for _ in range(10):
         f()
     out.append("%d: %.3f" % (n, (time.perf_counter() - t0) / 10 * 1e3))
-print("AFX_PACK_LIMIT_MB=%s  ms per host-pointer call:  " % os.environ.get("AFX_PACK_LIMIT_MB", "default") + "   ".join(out))
+print("ms per host-pointer call:  " + "   ".join(out))
