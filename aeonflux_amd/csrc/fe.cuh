@@ -208,12 +208,17 @@ AFX_DEV fe fe_mul_impl(const fe& f, const fe& g) {
   for (int m = 0; m < 8; m++) {
     int64_t H = 0;
 #pragma unroll
-    for (int i = m + 1; i < 9; i++) { H += (int64_t)f.v[i] * (int64_t)g.v[9 + m - i]; AFX_PIN(H); }
+    for (int i = m + 1; i < 9; i++) {
+      H += (int64_t)f.v[i] * (int64_t)g.v[9 + m - i];
+      // (not the chain's first product: pinned, it is computed once for the pin and once more inside the reassociated sum - a dead
+      // multiply-add per high column, 243 of the windowed kernel's 5181 until round 6)
+      if (i > m + 1) AFX_PIN(H);
+    }
     hi[m] = H;
   }
   return fe_reduce_columns<CENTRED>(hi, [&](int k, int64_t H) {
 #pragma unroll
-    for (int i = 0; i <= k; i++) { H += (int64_t)f.v[i] * (int64_t)g.v[k - i]; AFX_PIN(H); }
+    for (int i = 0; i <= k; i++) { H += (int64_t)f.v[i] * (int64_t)g.v[k - i]; if (k > 0) AFX_PIN(H); }   // (column 0 starts from a constant: see above)
     return H;
   });
 }
@@ -233,12 +238,14 @@ AFX_DEV fe fe_sq_impl(const fe& f) {
 #pragma unroll
   for (int m = 0; m < 8; m++) {
     int64_t H = 0;
+    bool first = true;
 #pragma unroll
     for (int i = m + 1; i < 9; i++) {
       const int j = 9 + m - i;
       if (j < i) continue;
       H += (int64_t)(i == j ? f.v[i] : f2[i]) * (int64_t)f.v[j];
-      AFX_PIN(H);
+      if (!first) AFX_PIN(H);   // (as in fe_mul_impl)
+      first = false;
     }
     hi[m] = H;
   }
@@ -248,7 +255,7 @@ AFX_DEV fe fe_sq_impl(const fe& f) {
       const int j = k - i;
       if (j < i) continue;
       H += (int64_t)(i == j ? f.v[i] : f2[i]) * (int64_t)f.v[j];
-      AFX_PIN(H);
+      if (k > 0) AFX_PIN(H);
     }
     return H;
   });

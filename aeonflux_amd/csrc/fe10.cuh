@@ -93,7 +93,7 @@ AFX_DEV fe10 fe10_mul_impl(const fe10& f, const fe10& g) {
       const int32_t a = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
       const int32_t b = wrap ? g19[j] : g.v[j];
       H += (int64_t)a * (int64_t)b;
-      AFX_PIN(H);
+      if (k > 0 || i > 0) AFX_PIN(H);   // (column 0 starts from a constant: its first product, pinned, would be computed twice - fe.cuh fe_mul_impl)
     }
     const int bits = (k & 1) ? 25 : 26;
     const uint32_t lo = (uint32_t)H & ((1u << bits) - 1);
@@ -135,7 +135,7 @@ AFX_DEV fe10 fe10_sq_impl(const fe10& f) {
       const int32_t a = (i == j) ? f.v[i] : f2[i];
       const int32_t b = wrap ? (odd2 ? f38[j] : f19[j]) : (odd2 ? f2[j] : f.v[j]);
       H += (int64_t)a * (int64_t)b;
-      AFX_PIN(H);
+      if (k > 0 || i > 0) AFX_PIN(H);   // (column 0 starts from a constant: its first product, pinned, would be computed twice - fe.cuh fe_mul_impl)
     }
     const int bits = (k & 1) ? 25 : 26;
     const uint32_t lo = (uint32_t)H & ((1u << bits) - 1);
