@@ -32,7 +32,10 @@ int exception_rc() noexcept {
 }
 const char* last_error() { return g_error.c_str(); }
 
+static thread_local bool g_alloc_failed = false;
+bool device_alloc_failed() { return g_alloc_failed; }
 int DevBuf::ensure(size_t n) {
+  g_alloc_failed = false;
   if (n <= cap) return AFX_OK;
   if (p) {
     // The buffer may still be in use: the *_dev entry points are asynchronous and the lanes' streams are non-blocking, so
@@ -48,7 +51,7 @@ int DevBuf::ensure(size_t n) {
   }
   const size_t want = (n + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
   hipError_t e = hipMalloc(&p, want);
-  if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e)); return AFX_E_HIP; }
+  if (e != hipSuccess) { p = nullptr; g_alloc_failed = true; set_error("hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e)); return AFX_E_HIP; }
   cap = want;
   return AFX_OK;
 }

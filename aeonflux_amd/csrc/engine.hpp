@@ -37,6 +37,9 @@ int exception_rc() noexcept;
     }                                                                                                  \
   } while (0)
 
+// true while the calling thread's most recent DevBuf::ensure failed because the device had no room (cleared by the next ensure):
+// what tells "this set of plans does not fit" from any other HIP failure (plans.cpp run_plans_fitting)
+bool device_alloc_failed();
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;

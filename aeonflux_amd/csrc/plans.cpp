@@ -460,6 +460,16 @@ int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey
   const std::thread::id me = std::this_thread::get_id();
   std::shared_ptr<afx::Session> S;
   bool no_append = false;
+  // A deferring caller (a mixed request: it comes here once per group and does not wait in between) that still LEADS a session it left
+  // rows with: that session goes now if its time has come - it is full, an exclusive caller waits for it, or its deadline has passed.
+  // (The header's promise - a collection is launched at the latest max_wait_us after it opened - would otherwise hold only once the
+  // request has staged its last group, 0.3 ms of plan assembly per new shape later.)
+  if (tl_deferred) {
+    std::vector<std::shared_ptr<afx::Session>> due;
+    for (const auto& P : tl_deferred->pending)
+      if (P->leader == me && P->state == afx::Session::COLLECTING && (P->full || P->hurry || clock::now() >= P->deadline)) due.push_back(P);
+    for (const auto& P : due) { const int rc = lead(c, P); tl_deferred->forget(P); if (rc) return rc; }
+  }
   for (;;) {
     // ---- a session to stage into: the one that collects, or a new one on a free lane
     while (!co.open) {
@@ -474,6 +484,7 @@ int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey
       const int rc = n->ensure_images(0, 0);
       if (rc) return rc;
       n->leader = me;
+      n->leader_defers = tl_deferred != nullptr;
       n->deadline = clock::now() + std::chrono::microseconds(co.max_wait_us);
       // the launches this session's plans will share, guessed from the last one's (afx_ctx::merge_class: how long the chains of a
       // latency plan are; results do not depend on it)
@@ -551,9 +562,12 @@ int coalesced_call(afx_ctx* c, size_t count, const SliceFn& slice, const PlanKey
   // afx::drain_deferred waits for - or launches - what it left behind.  A session it leads and that is full goes now.
   if (tl_deferred) {
     tl_deferred->note(S);
-    if (S->leader == me && S->full) { const int rc = lead(c, S); tl_deferred->forget(S); return rc; }
+    if (S->leader == me && (S->full || S->hurry || clock::now() >= S->deadline)) { const int rc = lead(c, S); tl_deferred->forget(S); return rc; }
     return AFX_OK;
   }
+  // ---- an ordinary caller that joined a session a deferring caller opened takes it over: it is going to wait here anyway, and the
+  // opener is busy assembling its request's next group
+  if (S->leader != me && S->leader_defers && S->state == afx::Session::COLLECTING) { S->leader = me; S->leader_defers = false; }
   // ---- everybody but the leader: sleep on the session's own condition, with the context given up for good - a completion wakes
   // the callers it answers, and they go home without queueing on the context's lock again
   if (S->leader != me) {
@@ -676,6 +690,18 @@ int afx::Session::ensure_images(size_t in_bytes, size_t out_bytes) {
   return ensure_pinned(L.pin, L.pin_cap, out_bytes, size_t(1) << 20);
 }
 
+// A set of plans whose workspaces (or blobs) do not fit the device side by side runs in halves, one behind the other on the lane's
+// stream - before every caller the session carried is sent home with an engine fault for ONE large neighbour's sake (run_plans
+// makes room for its blob and workspace before it enqueues anything: afx::device_alloc_failed tells that failure from the others)
+static int run_plans_fitting(afx_ctx* c, int lane, Plan** ps, size_t n) {
+  int rc = run_plans(c, lane, ps, n);
+  if (!rc || n <= 1 || !afx::device_alloc_failed()) return rc;
+  (void)hipGetLastError();
+  const size_t h = n / 2;
+  if ((rc = run_plans_fitting(c, lane, ps, h))) return rc;
+  return run_plans_fitting(c, lane, ps + h, n - h);
+}
+
 int afx::Session::launch() {
   if (empty()) return AFX_OK;
   afx_ctx::Lane& L = c->lane[lane];
@@ -689,7 +715,7 @@ int afx::Session::launch() {
   if (!rc && !plans.empty()) {
     std::vector<Plan*> ps;
     for (auto& p : plans) ps.push_back(p.get());
-    rc = run_plans(c, lane, ps.data(), ps.size());
+    rc = run_plans_fitting(c, lane, ps.data(), ps.size());
   }
   if (!rc && out_used && !outs.empty()) AFX_HIP(hipMemcpyAsync(L.pin, L.staging_out.p, out_used, hipMemcpyDeviceToHost, s));
   return rc;

@@ -121,7 +121,10 @@ struct Session {
     { std::lock_guard<std::mutex> g(done_mu); rc = rc_; err.swap(err_); done = true; }
     done_cv.notify_all();
   }
-  std::thread::id leader;           // the caller that opened the session launches it
+  std::thread::id leader;           // the caller that opened the session launches it ...
+  bool leader_defers = false;       // ... unless it is a deferring one (a mixed request staging its groups one after the other, afx::DeferScope):
+                                    // the first ordinary caller that joins takes the session over, so that nobody's single call waits
+                                    // for a request's remaining groups to be assembled (plans.cpp coalesced_call)
   bool hurry = false, full = false; // launch now: an exclusive caller waits / the session has all it can take
   std::chrono::steady_clock::time_point deadline;
   uint32_t mclass = 0;              // afx_ctx::merge_class while calls stage into this session
@@ -294,7 +297,9 @@ struct Stager {
     if (app) return last_dn = app->dn;
     if (!c->small_batch_items || n > c->small_batch_items || c->trace || n == 0) return last_dn = (uint32_t)n;
     uint32_t b = 16;
-    if (ses && ses->shared) b = std::max<uint32_t>(64, slots_hint);
+    // (the hint - what the last session carried of this key - rounded up to a power of two and capped: passes stay padded to powers
+    // of two, one kept plan per size, and a lone call after a burst is not laid out for thousands of items)
+    if (ses && ses->shared) { b = 64; while (b < slots_hint && b < 512) b <<= 1; }
     while (b < n) b <<= 1;
     return last_dn = (std::min<uint32_t>(b, c->small_batch_items) < n ? (uint32_t)n : std::min<uint32_t>(b, c->small_batch_items));
   }

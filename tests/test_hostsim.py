@@ -632,6 +632,118 @@ def test_large_host_calls_through_the_copy_pool_under_asan(hostsim_lib, tmp_path
     assert r.returncode == 0 and "pool drive ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+ADVICE_DRIVER = r"""
+# Round-5 advisor findings on the collector (plans.cpp coalesced_call, Session::launch), on the fake runtime with echoed statuses:
+# (1) a mixed request of many shapes stages its groups one after the other (0.3 ms of plan assembly per new shape, several ms under
+#     the sanitizer) and used to LEAD the session it opened until its last group was staged: another thread's single call that had
+#     joined that session slept the whole time.  Now the first ordinary caller that joins takes the session over, and a deferring leader
+#     launches a session whose deadline has passed on its next way through.
+# (2) a launch set whose plans do not fit the device side by side failed every call it carried; now it runs in halves.
+import os, sys, time, threading, ctypes as C
+sys.path.insert(0, %(root)r)
+import numpy as np
+import aeonflux_amd as afx
+afx.LIB_PATH = %(lib)r
+from aeonflux_amd import batch
+import bench
+L = afx.lib()
+L.afx_fake_set.argtypes = [C.c_char_p, C.c_int]
+L.afx_fake_set(b"echo", 1)
+params, key, ip = bench.load_fixture("c3_8attrs_SSPPeeee")
+ctx = afx.Context(params, key, ip)
+z = lambda *s: np.zeros(s, np.uint8)
+def shape_of(pub, enc):
+    # (pub: which of the four revealed attributes are points rather than scalars; enc: how many proofs of encryption are attached)
+    sh = afx.Shape()
+    sh.n_attributes, sh.n_responses, sh.n_hidden_scalars, sh.n_enc_proofs = 8, 3, 0, enc
+    for i in range(4):
+        sh.kinds[i] = 2 if (pub >> i) & 1 else 0
+    for i in range(4, 8):
+        sh.kinds[i] = 3
+    for e in range(enc):
+        sh.enc_indices[e] = 4 + e
+    return sh
+def mk(cnt, tag, enc=4):
+    p = {"challenge": z(cnt, 32), "responses": z(3, cnt, 32), "C_x_0": z(cnt, 32), "C_x_1": z(cnt, 32), "C_V": z(cnt, 32), "C_y": z(8, cnt, 32),
+         "attr_values": z(8, cnt, 32), "enc": [{f: (z(6, cnt, 32) if f == "responses" else z(cnt, 32)) for f in batch.ENC_FIELDS} for _ in range(enc)]}
+    p["challenge"][:, 0] = [(tag + i) %% 251 for i in range(cnt)]
+    return p
+# ---- (1) many DIFFERENT shapes in one request (distinct response counts / proofs of encryption: each is a plan of its own, none cached)
+def request(tag0):
+    return [(shape_of(g %% 16, g %% 5), mk(3, tag0 + g, g %% 5)) for g in range(48)]    # (g -> (g mod 16, g mod 5) is one-to-one below 80)
+single_shape, single = shape_of(12, 4), mk(2, 200)
+batch.verify_presentations(ctx, single_shape, single)          # (the single call's plan is kept from here on)
+ctx.set_coalescing(200000, 4096)                               # a long max_wait_us: only the hand-over can make the single call fast
+L.afx_fake_set(b"sync_us", 2000)
+t_req, t_single, errs = [0.0], [], []
+def run_request():
+    t0 = time.perf_counter()
+    got = batch.verify_mixed(ctx, request(0))
+    t_req[0] = time.perf_counter() - t0
+    for g, st in enumerate(got):
+        if st.tolist() != [(g + i) %% 251 for i in range(3)]:
+            errs.append(("request", g, st.tolist()))
+def run_singles():
+    time.sleep(0.02)                                            # the request has opened its session and is assembling
+    for _ in range(3):
+        t0 = time.perf_counter()
+        st = batch.verify_presentations(ctx, single_shape, single)
+        t_single.append(time.perf_counter() - t0)
+        if st.tolist() != [200, 201]:
+            errs.append(("single", st.tolist()))
+a, b = threading.Thread(target=run_request), threading.Thread(target=run_singles)
+a.start(); b.start(); a.join(); b.join()
+assert not errs, errs[:3]
+assert t_req[0] > 0.1, t_req                                    # (the request really is long: 48 plans under the sanitizer)
+assert min(t_single) < 0.35 * t_req[0], (t_single, t_req)       # the single calls did not wait for the request to finish staging
+cs = ctx.coalescing_stats()
+# ... and alone, past the deadline: a deferring leader launches on its way through instead of at the end
+ctx.set_coalescing(1000, 4096)
+s0 = ctx.coalescing_stats()["sessions"]
+got = batch.verify_mixed(ctx, request(50))
+assert all(st.tolist() == [(50 + g + i) %% 251 for i in range(3)] for g, st in enumerate(got))
+assert ctx.coalescing_stats()["sessions"] - s0 >= 2, "a 48-shape request that outlives max_wait_us goes out in more than one launch set"
+# ---- (2) a launch set that does not fit the device side by side: in halves
+L.afx_fake_set(b"sync_us", 0)
+ctx.set_coalescing(0, 0)                                        # collection off: the request runs its own session of merged plans
+items = [(shape_of(g, 4), mk(64, 10 * g, 4)) for g in range(8)]
+got = batch.verify_mixed(ctx, items)                            # (sizes the buffers once without a limit)
+ctx2 = afx.Context(params, key, ip)
+ctx2.set_coalescing(0, 0)
+lo = None
+for mb in (4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128):          # the smallest limit ONE such plan runs under
+    os.environ["AFX_FAKE_HIP_MAX_ALLOC"] = str(mb << 20)
+    try:
+        batch.verify_mixed(ctx2, items[:1])
+        lo = mb
+        break
+    except afx.AfxError as e:
+        assert e.rc == afx.E_HIP, e.rc
+assert lo is not None
+ctx2.close()
+del os.environ["AFX_FAKE_HIP_MAX_ALLOC"]
+ctx3 = afx.Context(params, key, ip)                             # a fresh context: no buffer is large already
+ctx3.set_coalescing(0, 0)
+os.environ["AFX_FAKE_HIP_MAX_ALLOC"] = str((2 * lo) << 20)      # two plans fit side by side, eight do not
+got = batch.verify_mixed(ctx3, items)
+del os.environ["AFX_FAKE_HIP_MAX_ALLOC"]
+for g, st in enumerate(got):
+    assert st.tolist() == [(10 * g + i) %% 251 for i in range(64)], (g, st.tolist()[:8])
+ctx3.close()
+ctx.close()
+print("advice drive ok", round(t_req[0], 3), [round(x, 3) for x in t_single], lo)
+"""
+
+
+def test_round5_advisor_findings_on_the_collector(hostsim_lib, tmp_path):
+    script = tmp_path / "drive.py"
+    script.write_text(ADVICE_DRIVER % {"root": ROOT, "lib": hostsim_lib})
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", AFX_PLAN_SELFCHECK="1")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "advice drive ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 NUMA_DRIVER = r"""
 # The host threads of a group's members run on the CPUs of their device's NUMA node (group.cpp cpus_of_device / PinScope).  The fake
 # runtime names device d "0000:0d:00.0"; AFX_SYSFS_ROOT points at a two-socket tree: devices 0, 1 on node 0 (CPUs 0-1), devices 2, 3 on
