@@ -13,7 +13,9 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); r = d['roofline']
-        print('%-40s' % '$which', round(d['value']), 'ms/step', round(d['ms_per_step'], 3), 'k_msm*', round(r['kernel_ms_per_step'], 3), r.get('kernels_ms_per_step', r.get('other_kernels_ms_per_step')))"
+        v = d.get('valu') or {}
+        print('%-40s' % '$which', round(d['value']), 'ms/step', round(d['ms_per_step'], 3), 'MHz', round(v.get('core_clock_mhz_measured') or 0, 1), 'per MHz', round(v.get('value_per_mhz') or 0, 2),
+              'k_msm*', round(r['kernel_ms_per_step'], 3), r.get('kernels_ms_per_step', r.get('other_kernels_ms_per_step')))"
   done
 done
 cp /tmp/ab_default.so $LIB
