@@ -194,6 +194,7 @@ def lib():
         _LIB.afx_ctx_set_coalescing.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         _LIB.afx_ctx_set_host_copy_threads.argtypes = [C.c_void_p, C.c_uint32]
         _LIB.afx_ctx_set_plan_variants.argtypes = [C.c_void_p, C.c_uint32]
+        _LIB.afx_merlin_challenges.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p]
         _LIB.afx_ctx_get_coalescing_stats.argtypes = [C.c_void_p, C.POINTER(CoalescingStats)]
         _LIB.afx_ctx_get_plan_cache_stats.argtypes = [C.c_void_p, C.POINTER(PlanCacheStats)]
         _LIB.afx_verify_presentations_range.argtypes = [C.c_void_p, C.POINTER(Shape), C.POINTER(PresentationSoA), C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
@@ -333,6 +334,28 @@ class Context:
     def set_coalescing(self, max_wait_us=2000, max_items=4096):
         """concurrent small host-pointer calls share launch sets (on by default); max_items=0 switches it off (afx_ctx_set_coalescing)"""
         check(lib().afx_ctx_set_coalescing(self.h, max_wait_us, max_items))
+
+    def merlin_challenges(self, label, ops, fields, count):
+        """a merlin transcript over a batch (afx_merlin_challenges).  ops: ("append", label, bytes) | ("append_field", label, index) |
+        ("challenge", label, n) last; fields: list of uint8 arrays [count][32].  Returns [count][64] (the first n bytes: the challenge)"""
+        import numpy as np
+        u32 = lambda v: int(v).to_bytes(4, "little")
+        bs = lambda b: u32(len(b)) + bytes(b)
+        script = bytes([1]) + bs(label)
+        for op in ops:
+            if op[0] == "append":
+                script += bytes([2]) + bs(op[1]) + bs(op[2])
+            elif op[0] == "append_field":
+                script += bytes([3]) + bs(op[1]) + u32(op[2])
+            elif op[0] == "challenge":
+                script += bytes([4]) + bs(op[1]) + u32(op[2])
+            else:
+                raise ValueError(op[0])
+        keep = [np.ascontiguousarray(f, dtype=np.uint8) for f in fields]
+        ptrs = (C.c_void_p * max(1, len(keep)))(*[f.ctypes.data for f in keep])
+        out = np.zeros((count, 64), np.uint8)
+        check(lib().afx_merlin_challenges(self.h, script, len(script), ptrs, len(keep), count, out.ctypes.data))
+        return out
 
     def set_plan_variants(self, flags):
         """force the alternatives among a small pass's equivalent plans / kernels (VARIANT_*; tests) - afx_ctx_set_plan_variants"""

@@ -1447,7 +1447,8 @@ static void order_terms(afx_msm_job& j, const std::vector<afx_msm_term>& terms) 
   for (const afx_msm_term& t : terms) if (t.fixed_idx < 0) { j.term[k++] = t; j.n_var++; }
   for (const afx_msm_term& t : terms) if (t.fixed_idx >= 0) j.term[k++] = t;
 }
-afx_hash_program SchnorrBuilder::make_program(const StrobeSim& sim) {
+afx_hash_program SchnorrBuilder::make_program(const StrobeSim& sim) { return make_hash_program(as_, sim, fields_); }
+afx_hash_program make_hash_program(Assembler& as_, const StrobeSim& sim, const std::vector<const uint8_t*>& fields_) {
   // The transcript's leading all-constant blocks are applied on the host, once per distinct prefix and context (SURVEY.md section 7
   // step 4): the device starts from the folded state.  A prover's prefix can hold key material (witnesses rekey the rng clone,
   // zkp's TranscriptRngBuilder): the cache is wiped with the context, the state travels in the plan blob like the constants did.

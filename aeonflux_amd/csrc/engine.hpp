@@ -418,6 +418,10 @@ class Assembler {
   friend class SchnorrBuilder;
 };
 
+// a compiled transcript (its all-constant leading blocks folded into the initial state, once per distinct prefix and context) as a
+// device hash program over the given [count][32] field arrays; the caller sets outs / challenge / trace
+afx_hash_program make_hash_program(Assembler& as, const StrobeSim& sim, const std::vector<const uint8_t*>& fields);
+
 // A point variable of a constraint system: a batch constant (generator id, maybe negated) or a per-item
 // variable (extended coordinates in the workspace + the [count][32] array holding its encoding).
 struct PointVar {

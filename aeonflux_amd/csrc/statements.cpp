@@ -794,6 +794,70 @@ extern "C" int afx_scalars_from_wide_bytes(afx_ctx* ctx, const uint8_t* wide, si
   AFX_HIP(hipStreamSynchronize(ctx->stream));
   return AFX_OK;
 } catch (...) { return afx::exception_rc(); }
+// A merlin transcript over a batch, from a script (include/aeonflux_gpu.h): compiled by StrobeSim like the statements' own transcripts,
+// run by k_hash.  What it is for: merlin's published conformance vectors - and any transcript a caller wants to cross-check - on the
+// GPU's STROBE / Keccak path itself rather than through a statement.
+extern "C" int afx_merlin_challenges(afx_ctx* ctx, const uint8_t* script, size_t script_len, const uint8_t* const* fields, uint32_t n_fields, size_t count,
+                                     uint8_t* out64) try {
+  CtxLock lock__(ctx);
+  if (!ctx || !script || !out64 || (n_fields && !fields)) { set_error("null argument"); return AFX_E_BAD_ARGS; }
+  if (n_fields > 4096) { set_error("too many fields"); return AFX_E_BAD_ARGS; }
+  for (uint32_t k = 0; k < n_fields; k++) if (!fields[k]) { set_error("null field array"); return AFX_E_BAD_ARGS; }
+  if (count == 0) return AFX_OK;
+  // ---- the script: op, then length-prefixed (u32 LE) byte strings
+  size_t at = 0;
+  auto u32 = [&](uint32_t& v) { if (script_len - at < 4) return false; v = rd32(script + at); at += 4; return true; };
+  auto bytes = [&](const uint8_t*& p, uint32_t& n) { if (!u32(n) || script_len - at < n) return false; p = script + at; at += n; return true; };
+  const uint8_t* lab = nullptr;
+  uint32_t llen = 0;
+  if (script_len < 1 || script[at++] != AFX_MERLIN_NEW || !bytes(lab, llen)) { set_error("transcript script: must open with AFX_MERLIN_NEW"); return AFX_E_BAD_ARGS; }
+  StrobeSim sim(lab, llen);
+  std::vector<int> used_fields;
+  bool closed = false;
+  while (at < script_len) {
+    if (closed) { set_error("transcript script: the challenge must be the last operation"); return AFX_E_BAD_ARGS; }
+    const uint8_t op = script[at++];
+    if (!bytes(lab, llen)) { set_error("transcript script: truncated label"); return AFX_E_BAD_ARGS; }
+    if (op == AFX_MERLIN_APPEND) {
+      const uint8_t* msg = nullptr;
+      uint32_t mlen = 0;
+      if (!bytes(msg, mlen)) { set_error("transcript script: truncated message"); return AFX_E_BAD_ARGS; }
+      sim.append_message_const(lab, llen, msg, mlen);
+    } else if (op == AFX_MERLIN_APPEND_FIELD) {
+      uint32_t f = 0;
+      if (!u32(f) || f >= n_fields) { set_error("transcript script: field index out of range"); return AFX_E_BAD_ARGS; }
+      sim.append_message_hole32(lab, llen, (int)f);
+    } else if (op == AFX_MERLIN_CHALLENGE) {
+      uint32_t n = 0;
+      if (!u32(n) || n == 0 || n > 64) { set_error("transcript script: a challenge is 1 .. 64 bytes"); return AFX_E_BAD_ARGS; }
+      sim.challenge_final(lab, llen, n, AFX_SQ_WIDE_OUT, 0);
+      closed = true;
+    } else { set_error("transcript script: unknown operation"); return AFX_E_BAD_ARGS; }
+  }
+  if (!closed) { set_error("transcript script: no challenge"); return AFX_E_BAD_ARGS; }
+  AFX_HIP(hipSetDevice(ctx->device));
+  Stager st(ctx);
+  std::vector<size_t> o_f(n_fields);
+  for (uint32_t k = 0; k < n_fields; k++) o_f[k] = st.add(fields[k], 32 * count);
+  const size_t o_out = st.add(nullptr, 64 * count), o_st = st.add(nullptr, count);
+  int rc = st.upload();
+  if (rc) return rc;
+  rc = run_chunked(ctx, count, [&](Assembler& as, size_t off, uint32_t) {
+    std::vector<const uint8_t*> f(n_fields);
+    for (uint32_t k = 0; k < n_fields; k++) f[k] = st.dev(o_f[k]) + off * 32;
+    afx_hash_program p = make_hash_program(as, sim, f);
+    uint8_t* outs[1] = { st.dev(o_out) + off * 64 };
+    p.outs = as.put_ptrs(outs, 1);
+    p.n_outs = 1;
+    JobSets js;
+    js.hash.push_back(p);
+    emit(as, js, st.dev(o_st) + off, 1);
+  });
+  if (rc) return rc;
+  AFX_HIP(hipMemcpyAsync(out64, st.dev(o_out), 64 * count, hipMemcpyDeviceToHost, ctx->stream));
+  AFX_HIP(hipStreamSynchronize(ctx->stream));
+  return AFX_OK;
+} catch (...) { return afx::exception_rc(); }
 extern "C" int afx_points_validate(afx_ctx* ctx, const uint8_t* pts, size_t count, uint8_t* ok, uint8_t* reencoded) try {
   CtxLock lock__(ctx);
   if (!ctx || !pts || !ok) { set_error("null argument"); return AFX_E_BAD_ARGS; }

@@ -69,7 +69,8 @@ class StrobeSim {
   int pos = 0, pos_begin = 0;
 
   // Strobe128::new(label) then merlin Transcript::new(label): init_state is concrete, the rest is recorded.
-  explicit StrobeSim(const char* merlin_label) {
+  explicit StrobeSim(const char* merlin_label) : StrobeSim((const uint8_t*)merlin_label, strlen(merlin_label)) {}
+  StrobeSim(const uint8_t* merlin_label, size_t label_len) {
     // the state after Strobe128::new's permutation is one constant: computed once per process
     struct Init {
       uint64_t w[25];
@@ -89,23 +90,35 @@ class StrobeSim {
     static const Init init;
     memcpy(init_state, init.w, sizeof init_state);
     meta_ad_const((const uint8_t*)"Merlin v1.0", 11, false);
-    append_message_const("dom-sep", (const uint8_t*)merlin_label, strlen(merlin_label));
+    append_message_const("dom-sep", merlin_label, label_len);
   }
 
   // ---- merlin level ----
-  void append_message_const(const char* label, const uint8_t* msg, size_t len) {
+  void append_message_const(const char* label, const uint8_t* msg, size_t len) { append_message_const((const uint8_t*)label, strlen(label), msg, len); }
+  void append_message_const(const uint8_t* label, size_t llen, const uint8_t* msg, size_t len) {
     uint8_t l4[4] = { (uint8_t)len, (uint8_t)(len >> 8), (uint8_t)(len >> 16), (uint8_t)(len >> 24) };
-    meta_ad_const((const uint8_t*)label, strlen(label), false);
+    meta_ad_const(label, llen, false);
     meta_ad_const(l4, 4, true);
     begin_op(FLAG_A, false);
     absorb_const(msg, len);
   }
-  void append_message_hole32(const char* label, int field) {
+  void append_message_hole32(const char* label, int field) { append_message_hole32((const uint8_t*)label, strlen(label), field); }
+  void append_message_hole32(const uint8_t* label, size_t llen, int field) {
     const uint8_t l4[4] = { 32, 0, 0, 0 };
-    meta_ad_const((const uint8_t*)label, strlen(label), false);
+    meta_ad_const(label, llen, false);
     meta_ad_const(l4, 4, true);
     begin_op(FLAG_A, false);
     absorb_hole32(field);
+  }
+  // challenge_bytes(label, n bytes), n <= 64, as the LAST operation of a program: the device hands out st[0..64) of the block the
+  // forced permutation closes, of which the first n are the challenge (what the sponge would do to the state afterwards - zero the n
+  // bytes, go on at position n - no longer matters).  afx_merlin_challenges (statements.cpp): third-party transcript vectors on the GPU.
+  void challenge_final(const uint8_t* label, size_t llen, uint32_t n, uint32_t squeeze_kind, uint32_t squeeze_out) {
+    if (n > 64) throw std::length_error("a final challenge of more than 64 bytes");
+    const uint8_t l4[4] = { (uint8_t)n, 0, 0, 0 };
+    meta_ad_const(label, llen, false);
+    meta_ad_const(l4, 4, true);
+    prf64(squeeze_kind, squeeze_out);
   }
   // challenge_bytes(label, 64 bytes); the squeeze action lands on the record that the forced permutation closes
   void challenge64(const char* label, uint32_t squeeze_kind, uint32_t squeeze_out) {

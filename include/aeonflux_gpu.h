@@ -626,6 +626,24 @@ int afx_multiscalar_mul(afx_ctx* ctx, uint32_t n_terms, const uint8_t* scalars /
                         const uint8_t* points /*[n_terms][count] Pt*/, size_t count, uint8_t* out /*[count] Pt*/,
                         uint8_t* ok /*[count]*/);
 
+/* A merlin transcript over a batch (the K* row's STROBE-128 / Keccak-f[1600] layer by itself: every proof of the crate is bound to a
+ * merlin transcript through zkp's TranscriptProtocol [3P], e.g. src/nizk/presentation.rs:355-356 and :435).  The
+ * transcript is given as a script - the operations of merlin::Transcript, byte strings length-prefixed with u32 LE:
+ *     AFX_MERLIN_NEW          label                      Transcript::new(label); first, once
+ *     AFX_MERLIN_APPEND       label, message             append_message(label, message): the same bytes for every item
+ *     AFX_MERLIN_APPEND_FIELD label, u32 field index     append_message(label, fields[index][item]): a 32-byte per-item message
+ *     AFX_MERLIN_CHALLENGE    label, u32 n (1 .. 64)     challenge_bytes(label, n bytes); last, once
+ * and out64[item] receives 64 bytes of which the first n are the challenge (the rest is what the sponge's state held behind them).
+ * Compiled and run exactly like the statements' own transcripts (strobe_sim.hpp, k_hash): all-constant leading blocks are absorbed
+ * once on the host, everything from the first per-item field on by the kernel.  tests/test_gpu_primitives.py runs merlin's published
+ * conformance vectors through it (chained challenges: one call per challenge, each fed back as a field of the next). */
+#define AFX_MERLIN_NEW 1
+#define AFX_MERLIN_APPEND 2
+#define AFX_MERLIN_APPEND_FIELD 3
+#define AFX_MERLIN_CHALLENGE 4
+int afx_merlin_challenges(afx_ctx* ctx, const uint8_t* script, size_t script_len, const uint8_t* const* fields /* n_fields x [count][32] */,
+                          uint32_t n_fields, size_t count, uint8_t* out64 /* [count][64] */);
+
 #ifdef __cplusplus
 }
 #endif

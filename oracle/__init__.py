@@ -183,6 +183,38 @@ def merlin_simple(label, l1, m1, l2, outlen):
     return o.raw
 
 
+def merlin_script(label, ops, fields=()):
+    """a scripted merlin transcript through the oracle's strobe / merlin layer (afxo_merlin_script).  ops: ("append", label, bytes) |
+    ("append_field", label, index) | ("challenge", label, n) | ("append_last_challenge", label); returns the list of challenges"""
+    u32 = lambda v: int(v).to_bytes(4, "little")
+    bs = lambda b: u32(len(b)) + bytes(b)
+    script, sizes = bytes([1]) + bs(label), []
+    for op in ops:
+        if op[0] == "append":
+            script += bytes([2]) + bs(op[1]) + bs(op[2])
+        elif op[0] == "append_field":
+            script += bytes([3]) + bs(op[1]) + u32(op[2])
+        elif op[0] == "challenge":
+            script += bytes([4]) + bs(op[1]) + u32(op[2])
+            sizes.append(op[2])
+        elif op[0] == "append_last_challenge":
+            script += bytes([5]) + bs(op[1])
+        else:
+            raise ValueError(op[0])
+    flat = b"".join(bytes(f) for f in fields)
+    assert len(flat) == 32 * len(fields)
+    o = _buf(max(1, sum(sizes)))
+    lib().afxo_merlin_script.restype = C.c_long
+    n = lib().afxo_merlin_script(script, len(script), flat, len(fields), o, sum(sizes))
+    if n != sum(sizes):
+        raise ValueError("afxo_merlin_script: %d" % n)
+    out, at = [], 0
+    for s in sizes:
+        out.append(o.raw[at:at + s])
+        at += s
+    return out
+
+
 def system_parameters_generate(n, stream):
     out = _buf(lib().afxo_sizeof_system_parameters(n))
     used = lib().afxo_system_parameters_generate(n, stream, len(stream), out)

@@ -893,6 +893,62 @@ void afxo_merlin_simple(const uint8_t* label, size_t llen, const uint8_t* l1, si
   merlin_append_message(&t, l1, l1len, m1, m1len);
   merlin_challenge_bytes(&t, l2, l2len, out, outlen);
 }
+/* A scripted merlin transcript (the script of include/aeonflux_gpu.h afx_merlin_challenges, for ONE item, with two liberties the
+ * checker may take: any number of challenges, and operation 5 = append_message(label, the most recent challenge's bytes)): merlin's
+ * published conformance vectors (merlin tests::equivalence_simple / equivalence_complex [3P]) run through the oracle's own
+ * strobe / merlin layer with it.  fields: [n_fields][32].  Every challenge's bytes are appended to out; returns the bytes written,
+ * -1 for a malformed script or a full buffer. */
+long afxo_merlin_script(const uint8_t* script, size_t len, const uint8_t* fields, uint32_t n_fields, uint8_t* out, size_t cap) {
+  size_t at = 0, wrote = 0;
+  uint8_t last[64];
+  uint32_t last_len = 0;
+  merlin_transcript t;
+  int opened = 0;
+  while (at < len) {
+    const uint8_t op = script[at++];
+    if (len - at < 4) return -1;
+    uint32_t llen;
+    memcpy(&llen, script + at, 4);
+    at += 4;
+    if (len - at < llen) return -1;
+    const uint8_t* lab = script + at;
+    at += llen;
+    if (op == 1) {
+      if (opened) return -1;
+      merlin_new(&t, lab, llen);
+      opened = 1;
+      continue;
+    }
+    if (!opened) return -1;
+    if (op == 2) {
+      uint32_t mlen;
+      if (len - at < 4) return -1;
+      memcpy(&mlen, script + at, 4);
+      at += 4;
+      if (len - at < mlen) return -1;
+      merlin_append_message(&t, lab, llen, script + at, mlen);
+      at += mlen;
+    } else if (op == 3 || op == 4) {
+      uint32_t v;
+      if (len - at < 4) return -1;
+      memcpy(&v, script + at, 4);
+      at += 4;
+      if (op == 3) {
+        if (v >= n_fields) return -1;
+        merlin_append_message(&t, lab, llen, fields + 32 * (size_t)v, 32);
+      } else {
+        if (v == 0 || v > 64 || cap - wrote < v) return -1;
+        merlin_challenge_bytes(&t, lab, llen, last, v);
+        last_len = v;
+        memcpy(out + wrote, last, v);
+        wrote += v;
+      }
+    } else if (op == 5) {
+      merlin_append_message(&t, lab, llen, last, last_len);
+    } else return -1;
+  }
+  return (long)wrote;
+}
 void afxo_debug_reset(void) {
   zkp_debug_ncommit = 0;
   memset(zkp_debug_commit, 0, sizeof zkp_debug_commit);

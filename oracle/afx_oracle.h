@@ -92,6 +92,7 @@ void afxo_sha512(uint8_t out[64], const uint8_t* msg, size_t len);
 void afxo_keccak_f1600(uint8_t st[200]);
 void afxo_merlin_simple(const uint8_t* label, size_t llen, const uint8_t* l1, size_t l1len, const uint8_t* m1, size_t m1len,
                         const uint8_t* l2, size_t l2len, uint8_t* out, size_t outlen);
+long afxo_merlin_script(const uint8_t* script, size_t len, const uint8_t* fields, uint32_t n_fields, uint8_t* out, size_t cap);
 void afxo_debug_last(uint8_t* commits, int* ncommit, uint8_t challenge[32]);
 void afxo_debug_reset(void);
 /* opt-in strict mode (not the reference's behaviour; see oracle/aeonflux.c) */

@@ -115,3 +115,69 @@ def test_msm_random_vs_oracle_ragged_counts(engine):
     assert ok.tolist() == [1, 0, 1] and got[0] == got[2] == oracle.point_scalarmult(five, oracle.basepoint())
     got, ok = msm(afx, ctx, [[b"\xff" * 32, five]], [[oracle.basepoint()] * 2])
     assert ok.tolist() == [0, 1]
+
+
+def test_rfc9496_appendix_a_in_full_on_the_gpu(engine, kat):
+    """RFC 9496 A.1-A.3 through the engine's primitives: k * B for k = 0 .. 15, every invalid encoding rejected (and, being the
+    reference's decompress, for the RFC's reason or another: only the verdict is contractual), the seven uniform byte strings"""
+    afx, ctx = engine
+    mult = kat["rfc9496_generator_multiples"]
+    got, ok = msm(afx, ctx, [[k.to_bytes(32, "little") for k in range(16)]], [[H(mult[1])] * 16])
+    assert ok.all() and [g.hex() for g in got] == mult
+    # ... and as sums: (k - 1) * B + B with both terms variable
+    got, ok = msm(afx, ctx, [[(1).to_bytes(32, "little")] * 15, [(1).to_bytes(32, "little")] * 15], [[H(mult[k - 1]) if k > 1 else H(mult[0]) for k in range(1, 16)], [H(mult[1])] * 15])
+    assert ok.all() and [g.hex() for g in got] == mult[1:]
+    bad = [e for encs in kat["rfc9496_bad_encodings"].values() for e in encs]
+    ins = bad + mult
+    a = arr([H(x) for x in ins])
+    okv = np.zeros(len(ins), np.uint8)
+    re = np.zeros(32 * len(ins), np.uint8)
+    afx.check(afx.lib().afx_points_validate(ctx.h, a.ctypes.data, len(ins), okv.ctypes.data, re.ctypes.data))
+    assert not okv[:len(bad)].any() and okv[len(bad):].all() and len(bad) == 29
+    assert [bytes(re[32 * i:32 * i + 32]).hex() for i in range(len(bad), len(ins))] == mult
+    fu = kat["rfc9496_from_uniform_bytes"]
+    a = arr([H(v["in"]) for v in fu])
+    out = np.zeros(32 * len(fu), np.uint8)
+    afx.check(afx.lib().afx_points_from_uniform_bytes(ctx.h, a.ctypes.data, len(fu), out.ctypes.data))
+    assert [bytes(out[32 * i:32 * i + 32]).hex() for i in range(len(fu))] == [v["out"] for v in fu]
+
+
+def test_merlins_conformance_vectors_on_the_gpu(engine, kat):
+    """merlin's two published transcript vectors through the GPU's own STROBE-128 / Keccak path (afx_merlin_challenges: StrobeSim ->
+    k_hash, the path every statement's transcript takes).  equivalence_complex chains 32 challenges, each absorbed again: one program per
+    challenge, the earlier ones fed back as per-item fields - the last program absorbs 34 KB (over 200 permutations, 1024-byte appends
+    across the 166-byte rate) on the device.  Three items per call, all equal (every lane runs the same program), plus the oracle's
+    scripted transcript for every intermediate challenge."""
+    import oracle
+    from tests.test_oracle_primitives import merlin_complex_ops
+    afx, ctx = engine
+    s = kat["merlin_equivalence_simple"]
+    out = ctx.merlin_challenges(s["label"].encode(), [("append", s["append_label"].encode(), s["append_data"].encode()), ("challenge", s["challenge_label"].encode(), 32)], [], 3)
+    assert all(bytes(out[i, :32]).hex() == s["challenge32"] for i in range(3))
+    v = kat["merlin_equivalence_complex"]
+    want = oracle.merlin_script(v["label"].encode(), merlin_complex_ops(v))
+    big = bytes([v["big_byte"]]) * v["big_len"]
+    count, chals = 3, []
+    for r in range(v["rounds"]):
+        ops = [("append", v["first_label"].encode(), v["first_data"].encode())]
+        for k in range(r):
+            ops += [("append", v["big_label"].encode(), big), ("append_field", v["feedback_label"].encode(), k)]
+        ops.append(("challenge", v["challenge_label"].encode(), 32))
+        fields = [np.tile(np.frombuffer(c, np.uint8), (count, 1)) for c in chals]
+        out = ctx.merlin_challenges(v["label"].encode(), ops, fields, count)
+        c = bytes(out[0, :32])
+        assert all(bytes(out[i, :32]) == c for i in range(count)) and c == want[r], r
+        chals.append(c)
+    assert chals[-1].hex() == v["last_challenge32"]
+    # a field that differs per item gives a challenge per item, each the oracle's
+    f = np.frombuffer(hashlib.shake_256(b"merlin-fields").digest(32 * 70), np.uint8).reshape(70, 32)
+    out = ctx.merlin_challenges(b"per item", [("append", b"a", b"constant"), ("append_field", b"val", 0), ("append_field", b"val2", 0), ("challenge", b"c", 64)], [f], 70)
+    for i in range(70):
+        assert bytes(out[i]) == oracle.merlin_script(b"per item", [("append", b"a", b"constant"), ("append_field", b"val", 0), ("append_field", b"val2", 0), ("challenge", b"c", 64)], [bytes(f[i])])[0]
+    # malformed scripts are refused
+    L = afx.lib()
+    o = np.zeros((1, 64), np.uint8)
+    for script in (b"", bytes([2]) + (0).to_bytes(4, "little"), bytes([1]) + (1).to_bytes(4, "little") + b"x",           # empty, no NEW, no challenge
+                   bytes([1]) + (1).to_bytes(4, "little") + b"x" + bytes([4]) + (1).to_bytes(4, "little") + b"c" + (65).to_bytes(4, "little"),   # 65 bytes
+                   bytes([1]) + (1).to_bytes(4, "little") + b"x" + bytes([3]) + (1).to_bytes(4, "little") + b"v" + (0).to_bytes(4, "little")):   # field 0 of none
+        assert L.afx_merlin_challenges(ctx.h, script, len(script), None, 0, 1, o.ctypes.data) == afx.E_BAD_ARGS

@@ -259,6 +259,14 @@ try:
 except afx.AfxError as e:
     assert e.rc == afx.E_HIP, e.rc
 del os.environ["AFX_FAKE_HIP_MAX_ALLOC"]
+# a scripted merlin transcript (afx_merlin_challenges): compiled like the statements' own, fields staged; malformed scripts refused
+mf = np.arange(32 * 5, dtype=np.uint8).reshape(5, 32)
+mo = ctx.merlin_challenges(b"hostsim", [("append", b"big", bytes(1000)), ("append_field", b"f", 0), ("append", b"", b""), ("append_field", b"g", 1), ("challenge", b"c", 32)], [mf, mf], 5)
+assert mo.shape == (5, 64)
+for bad_script in (b"", bytes([1]), bytes([1, 9, 0, 0, 0]) + b"xy", bytes([1, 1, 0, 0, 0]) + b"x", bytes([1, 1, 0, 0, 0]) + b"x" + bytes([7, 0, 0, 0, 0]),
+                   bytes([1, 1, 0, 0, 0]) + b"x" + bytes([4, 1, 0, 0, 0]) + b"c" + bytes([0, 0, 0, 0]),
+                   bytes([1, 1, 0, 0, 0]) + b"x" + bytes([4, 1, 0, 0, 0]) + b"c" + bytes([8, 0, 0, 0]) + bytes([2, 0, 0, 0, 0, 0, 0, 0, 0])):
+    assert afx.lib().afx_merlin_challenges(ctx.h, bad_script, len(bad_script), None, 0, 1, mo.ctypes.data) == afx.E_BAD_ARGS, bad_script
 ctx.close()
 # bad parameters / keys are rejected on the host
 d = make_credentials(2, "SP", 1, b"hostsim-bad")

@@ -103,3 +103,50 @@ def test_hash_to_scalar_group_and_encode(primitives):
             assert pt.hex() == v["point"]
         data, ctr2 = oracle.decode_from_group(H(v["point"]))
         assert ctr2 == ctr and data[:len(H(v["msg"]))] == H(v["msg"])
+
+
+def test_rfc9496_appendix_a_in_full(kat):
+    """RFC 9496 A.1 (0 .. 15 times the generator), A.2 (every invalid encoding is rejected) and A.3 (the seven uniform byte strings)"""
+    B = oracle.basepoint()
+    mult = kat["rfc9496_generator_multiples"]
+    assert len(mult) == 16 and mult[0] == "00" * 32 and mult[1] == B.hex()
+    acc = None
+    for k in range(1, 16):
+        assert oracle.point_scalarmult(k.to_bytes(32, "little"), B).hex() == mult[k], k
+        acc = B if acc is None else oracle.point_add(acc, B)          # ... and by repeated addition
+        assert acc.hex() == mult[k], k
+        assert oracle.point_decode_encode(H(mult[k])) == H(mult[k])
+    assert oracle.point_sub(B, B).hex() == mult[0]
+    n = 0
+    for reason, encs in kat["rfc9496_bad_encodings"].items():
+        for e in encs:
+            assert oracle.point_decode_encode(H(e)) is None, (reason, e)
+            n += 1
+    assert n == 29
+    for v in kat["rfc9496_from_uniform_bytes"]:
+        assert oracle.point_from_uniform(H(v["in"])).hex() == v["out"]
+    assert len(kat["rfc9496_from_uniform_bytes"]) == 7
+
+
+def merlin_complex_ops(v):
+    ops = [("append", v["first_label"].encode(), v["first_data"].encode())]
+    for _ in range(v["rounds"]):
+        ops += [("challenge", v["challenge_label"].encode(), 32), ("append", v["big_label"].encode(), bytes([v["big_byte"]]) * v["big_len"]),
+                ("append_last_challenge", v["feedback_label"].encode())]
+    return ops
+
+
+def test_merlin_multi_block_kat(kat):
+    """merlin's equivalence_complex: 1024-byte appends across the 166-byte rate, 32 chained challenges (oracle/hashes.c through
+    afxo_merlin_script); the simple vector through the same door"""
+    v = kat["merlin_equivalence_complex"]
+    chals = oracle.merlin_script(v["label"].encode(), merlin_complex_ops(v))
+    assert len(chals) == 32 and len(set(chals)) == 32 and chals[-1].hex() == v["last_challenge32"]
+    s = kat["merlin_equivalence_simple"]
+    got = oracle.merlin_script(s["label"].encode(), [("append", s["append_label"].encode(), s["append_data"].encode()), ("challenge", s["challenge_label"].encode(), 32)])
+    assert got[0].hex() == s["challenge32"]
+    # per-item fields are messages like any other
+    f = bytes(range(32))
+    a = oracle.merlin_script(b"x", [("append_field", b"val", 0), ("challenge", b"c", 64)], [f])
+    b = oracle.merlin_script(b"x", [("append", b"val", f), ("challenge", b"c", 64)])
+    assert a == b and len(a[0]) == 64

@@ -39,6 +39,29 @@ def test_pyref_primitives_against_third_party_vectors(kat, primitives):
     assert n > 600
 
 
+def test_pyref_rfc9496_appendix_a_and_merlins_multi_block_vector(kat):
+    base = ristretto.decode(H(kat["rfc9496_B"]))
+    acc = None
+    for k in range(1, 16):
+        acc = base if acc is None else ristretto.add(acc, base)
+        assert ristretto.encode(acc).hex() == kat["rfc9496_generator_multiples"][k]
+        assert ristretto.encode(ristretto.mul(k, base)).hex() == kat["rfc9496_generator_multiples"][k]
+    assert ristretto.encode(ristretto.sub(base, base)).hex() == kat["rfc9496_generator_multiples"][0]
+    for reason, encs in kat["rfc9496_bad_encodings"].items():
+        for e in encs:
+            assert ristretto.decode(H(e)) is None, (reason, e)
+    for v in kat["rfc9496_from_uniform_bytes"]:
+        assert ristretto.encode(ristretto.from_uniform_bytes(H(v["in"]))).hex() == v["out"]
+    v = kat["merlin_equivalence_complex"]
+    t = keccak.Transcript(v["label"].encode())
+    t.append_message(v["first_label"].encode(), v["first_data"].encode())
+    for _ in range(v["rounds"]):
+        chl = t.challenge_bytes(v["challenge_label"].encode(), 32)
+        t.append_message(v["big_label"].encode(), bytes([v["big_byte"]]) * v["big_len"])
+        t.append_message(v["feedback_label"].encode(), chl)
+    assert chl.hex() == v["last_challenge32"]
+
+
 def _values(rec):
     return [H(v) for v in rec["values"]]
 
