@@ -812,10 +812,12 @@ extern "C" int afx_merlin_challenges(afx_ctx* ctx, const uint8_t* script, size_t
   uint32_t llen = 0;
   if (script_len < 1 || script[at++] != AFX_MERLIN_NEW || !bytes(lab, llen)) { set_error("transcript script: must open with AFX_MERLIN_NEW"); return AFX_E_BAD_ARGS; }
   StrobeSim sim(lab, llen);
-  std::vector<int> used_fields;
+  // (a challenge that is not the script's last operation is replayed for its effect on the state; only the last one's bytes come back)
   bool closed = false;
+  const uint8_t* pend_lab = nullptr;
+  uint32_t pend_llen = 0, pend_n = 0;
   while (at < script_len) {
-    if (closed) { set_error("transcript script: the challenge must be the last operation"); return AFX_E_BAD_ARGS; }
+    if (closed) { sim.challenge_discard(pend_lab, pend_llen, pend_n); closed = false; }
     const uint8_t op = script[at++];
     if (!bytes(lab, llen)) { set_error("transcript script: truncated label"); return AFX_E_BAD_ARGS; }
     if (op == AFX_MERLIN_APPEND) {
@@ -830,11 +832,12 @@ extern "C" int afx_merlin_challenges(afx_ctx* ctx, const uint8_t* script, size_t
     } else if (op == AFX_MERLIN_CHALLENGE) {
       uint32_t n = 0;
       if (!u32(n) || n == 0 || n > 64) { set_error("transcript script: a challenge is 1 .. 64 bytes"); return AFX_E_BAD_ARGS; }
-      sim.challenge_final(lab, llen, n, AFX_SQ_WIDE_OUT, 0);
+      pend_lab = lab; pend_llen = llen; pend_n = n;
       closed = true;
     } else { set_error("transcript script: unknown operation"); return AFX_E_BAD_ARGS; }
   }
-  if (!closed) { set_error("transcript script: no challenge"); return AFX_E_BAD_ARGS; }
+  if (!closed) { set_error("transcript script: the last operation must be a challenge"); return AFX_E_BAD_ARGS; }
+  sim.challenge_final(pend_lab, pend_llen, pend_n, AFX_SQ_WIDE_OUT, 0);
   AFX_HIP(hipSetDevice(ctx->device));
   Stager st(ctx);
   std::vector<size_t> o_f(n_fields);

@@ -128,6 +128,20 @@ class StrobeSim {
     prf64(squeeze_kind, squeeze_out);
   }
 
+  // challenge_bytes(label, n bytes) somewhere BEFORE the end of a program: nothing is handed out, but the operation acts on the state
+  // like any other - its label and length are absorbed, the sponge is permuted, the n bytes it squeezes are zeroed and the position
+  // moves behind them (a transcript whose earlier challenges are known - they come back as fields - replayed up to a later one)
+  void challenge_discard(const uint8_t* label, size_t llen, uint32_t n) {
+    if (n > 64) throw std::length_error("a challenge of more than 64 bytes");
+    const uint8_t l4[4] = { (uint8_t)n, 0, 0, 0 };
+    meta_ad_const(label, llen, false);
+    meta_ad_const(l4, 4, true);
+    begin_op(FLAG_I | FLAG_A | FLAG_C, false);
+    if (pos != 0) throw std::logic_error("prf not at a block boundary");
+    for (uint32_t i = 0; i < n; i++) { cur.b[i].overwrite = true; cur.b[i].c = 0; cur.b[i].field = -1; }
+    pos = (int)n;
+  }
+
   // ---- strobe level ----
   void meta_ad_const(const uint8_t* d, size_t n, bool more) { begin_op(FLAG_M | FLAG_A, more); absorb_const(d, n); }
   void key_const(const uint8_t* d, size_t n) { begin_op(FLAG_A | FLAG_C, false); for (size_t i = 0; i < n; i++) overwrite_sym(d[i], -1, 0); }

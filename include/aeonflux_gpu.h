@@ -632,11 +632,14 @@ int afx_multiscalar_mul(afx_ctx* ctx, uint32_t n_terms, const uint8_t* scalars /
  *     AFX_MERLIN_NEW          label                      Transcript::new(label); first, once
  *     AFX_MERLIN_APPEND       label, message             append_message(label, message): the same bytes for every item
  *     AFX_MERLIN_APPEND_FIELD label, u32 field index     append_message(label, fields[index][item]): a 32-byte per-item message
- *     AFX_MERLIN_CHALLENGE    label, u32 n (1 .. 64)     challenge_bytes(label, n bytes); last, once
- * and out64[item] receives 64 bytes of which the first n are the challenge (the rest is what the sponge's state held behind them).
+ *     AFX_MERLIN_CHALLENGE    label, u32 n (1 .. 64)     challenge_bytes(label, n bytes); the script ends with one
+ * and out64[item] receives 64 bytes of which the first n are the LAST challenge (the rest is what the sponge's state held behind
+ * them).  A challenge earlier in the script acts on the transcript as it must - label and length absorbed, the sponge permuted, its
+ * bytes zeroed - but is not returned: a caller that chains challenges (each absorbed again) runs one call per challenge and feeds
+ * the earlier ones back as fields.
  * Compiled and run exactly like the statements' own transcripts (strobe_sim.hpp, k_hash): all-constant leading blocks are absorbed
  * once on the host, everything from the first per-item field on by the kernel.  tests/test_gpu_primitives.py runs merlin's published
- * conformance vectors through it (chained challenges: one call per challenge, each fed back as a field of the next). */
+ * conformance vectors through it. */
 #define AFX_MERLIN_NEW 1
 #define AFX_MERLIN_APPEND 2
 #define AFX_MERLIN_APPEND_FIELD 3

@@ -160,8 +160,8 @@ def test_merlins_conformance_vectors_on_the_gpu(engine, kat):
     count, chals = 3, []
     for r in range(v["rounds"]):
         ops = [("append", v["first_label"].encode(), v["first_data"].encode())]
-        for k in range(r):
-            ops += [("append", v["big_label"].encode(), big), ("append_field", v["feedback_label"].encode(), k)]
+        for k in range(r):    # the earlier rounds: their challenge operation (not returned), the big append, the challenge absorbed again
+            ops += [("challenge", v["challenge_label"].encode(), 32), ("append", v["big_label"].encode(), big), ("append_field", v["feedback_label"].encode(), k)]
         ops.append(("challenge", v["challenge_label"].encode(), 32))
         fields = [np.tile(np.frombuffer(c, np.uint8), (count, 1)) for c in chals]
         out = ctx.merlin_challenges(v["label"].encode(), ops, fields, count)
@@ -178,6 +178,7 @@ def test_merlins_conformance_vectors_on_the_gpu(engine, kat):
     L = afx.lib()
     o = np.zeros((1, 64), np.uint8)
     for script in (b"", bytes([2]) + (0).to_bytes(4, "little"), bytes([1]) + (1).to_bytes(4, "little") + b"x",           # empty, no NEW, no challenge
+                   bytes([1]) + (1).to_bytes(4, "little") + b"x" + bytes([4]) + (1).to_bytes(4, "little") + b"c" + (8).to_bytes(4, "little") + bytes([2]) + bytes(8),   # ends with an append
                    bytes([1]) + (1).to_bytes(4, "little") + b"x" + bytes([4]) + (1).to_bytes(4, "little") + b"c" + (65).to_bytes(4, "little"),   # 65 bytes
                    bytes([1]) + (1).to_bytes(4, "little") + b"x" + bytes([3]) + (1).to_bytes(4, "little") + b"v" + (0).to_bytes(4, "little")):   # field 0 of none
         assert L.afx_merlin_challenges(ctx.h, script, len(script), None, 0, 1, o.ctypes.data) == afx.E_BAD_ARGS
