@@ -19,7 +19,6 @@ ATTR_PUBLIC_SCALAR, ATTR_SECRET_SCALAR, ATTR_PUBLIC_POINT, ATTR_EITHER_POINT, AT
 # afx_ctx_set_plan_variants (tests: the alternatives among a small pass's equivalent plans and kernels)
 VARIANT_SEGMENTS_1, VARIANT_SEGMENTS_2, VARIANT_SEGMENTS_4, VARIANT_ONE_WAVE_CHAINS, VARIANT_HASH_HALF_WAVE, VARIANT_NO_POINTSUM_TREE, VARIANT_SELFCHECK = \
     0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40
-VARIANT_CACHED_WINDOW_TABLES, VARIANT_AFFINE_WINDOW_TABLES = 0x80, 0x100
 # Tests that drive whole scripts under one variant (tests/test_hostsim.py) set this before creating contexts: every Context made
 # afterwards starts with these flags.  A hook of this python mirror, not of the library - which reads no variant from the environment.
 DEFAULT_PLAN_VARIANTS = int(os.environ.get("AFX_TEST_PLAN_VARIANTS", "0"), 0)

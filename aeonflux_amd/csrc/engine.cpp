@@ -212,9 +212,7 @@ void Assembler::add_walk_rows(Launch& l, uint32_t per_row) {
     r.job_off = first * (uint32_t)job_size(l.kind);
     r.n_jobs = std::min(per_row, l.njobs - first);
     r.pass = 0;
-    // (the narrow tables' walk keeps its prefix products inside the entries; the window tables' - eight entries a table - beside them)
-    r.prefix_ws = l.kind == L_TABLE_AFFINE ? (l.odd == 1 ? (int32_t*)ws_alloc(sizeof(int32_t) * 9 * AFX_TABLE_STORED * (size_t)r.n_jobs * (size_t)count) : nullptr)
-                                           : (int32_t*)ws_alloc(sizeof(int32_t) * 9 * (size_t)r.n_jobs * (size_t)count);
+    r.prefix_ws = l.kind == L_TABLE_AFFINE ? nullptr : (int32_t*)ws_alloc(sizeof(int32_t) * 9 * (size_t)r.n_jobs * (size_t)count);
     rows.push_back(r);
   }
   l.nrows = (uint32_t)rows.size();
@@ -654,13 +652,6 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
   // (up to 512 items: such a launch takes the four-wave chains whatever its size, and wider passes are better off on one wave per
   // chain - a 2048-item show 2.59 -> 2.90 ms with them)
   const bool cached_narrow = segmenting_ && !(ctx->variants & AFX_VARIANT_ONE_WAVE_CHAINS) && ctx->row_waves(count) <= 8;
-  // A LARGE pass divides the entries of its 4-bit window tables by their Z - one inversion per item for all the tables of this list
-  // (k_table_affine_window) - and adds them with 7 products instead of 8.  From 2^17 items on, where the walk over an item's ~330
-  // entries (6 products each) is throughput like everything else; below, a lane's serial walk would be what the pass waits for.
-  // (AFX_VARIANT_CACHED_WINDOW_TABLES keeps the cached entries: tests and the same-box A/B)
-  // (not in a list with secret terms: those launches run the SEC instances, and tables are shared across a list's launches)
-  const bool affine_windows = !sec_mode && !segmenting_ && !small() && !(ctx->variants & AFX_VARIANT_CACHED_WINDOW_TABLES) &&
-                              (count >= (1u << 17) || (ctx->variants & AFX_VARIANT_AFFINE_WINDOW_TABLES));
   for (size_t i = 0; i < n; i++)
     if (jobs[i].chain_to >= 0 && ((size_t)jobs[i].chain_to >= n || jobs[i].chain_to == (int32_t)i)) throw std::logic_error("bad msm chain");
   // Jobs whose result is only ever encoded (no consumer of the point itself, no addend) run on halved scalars; k_compress2x
@@ -726,7 +717,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
         const uint64_t nadd = nuni + ((b & 3) == 0 ? nl : 0);
         if (b != j.top_bit) { stats.doublings++; S += 4; M += (nadd != 0 || b == 0) ? 4 : 3; }
         stats.var_additions += nadd;
-        M += nadd * 4 - (((b & 3) == 0 && affine_windows) ? nl : 0);   // (a per-item term's entry is affine in a large pass)
+        M += nadd * 4;
         M += nadd * 4 - ((nadd != 0 && b != 0) ? 1 : 0);
       }
       stats.fixed_additions += nfa;
@@ -753,7 +744,7 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
       M += nv * (1 + (stored - 1) * (j.narrow ? 8 : 9));
       for (int w = (int)wins - 1; w >= 0; w--) {
         if (w != (int)wins - 1) { S += 4 * wbits; M += 3 * (wbits - 1) + 4; }   // the window's doublings to p2, its last to p3
-        M += nv * (((j.narrow && !cached_narrow) || (!j.narrow && affine_windows)) ? 3 : 4);     // additions of window-table entries (affine ones in a narrow job and in a large pass)
+        M += nv * ((j.narrow && !cached_narrow) ? 3 : 4);     // additions of window-table entries (affine ones in a narrow job)
         M += nv * 4 - (w != 0 ? 1 : 0);                       // back to p3; the window's last one skips T
       }
     }
@@ -882,7 +873,6 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
           stats.field_sq -= odd ? 4 : 0;
         }
         j.term[t].table_slot = hit->second;
-        j.term[t].affine = (!odd && !j.narrow && affine_windows) ? 1u : 0u;
       }
       if (j.n_uni) {
         std::vector<uint32_t> sched;
@@ -912,20 +902,6 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
       tl.jobs_off = blob_alloc(sizeof(afx_table_job) * tr.size(), 16);
       memcpy(blob_.data() + tl.jobs_off, tr.data(), sizeof(afx_table_job) * tr.size());
       launches.push_back(tl);
-      if (odd == 0 && affine_windows) {
-        Launch al;
-        al.kind = L_TABLE_AFFINE;
-        al.odd = 1;
-        al.njobs = tl.njobs;
-        al.jobs_off = blob_alloc(sizeof(afx_table_job) * tr.size(), 16);
-        memcpy(blob_.data() + al.jobs_off, tr.data(), sizeof(afx_table_job) * tr.size());
-        add_walk_rows(al, 0);   // one row: one inversion per item
-        launches.push_back(al);
-        // per entry: the prefix product, 1/(2Z) and the running inverse, the three quotients; per row the inversion
-        stats.field_mul += (uint64_t)tr.size() * AFX_TABLE_STORED * 6 + (uint64_t)al.nrows * 11;
-        stats.field_sq += (uint64_t)al.nrows * 254;
-        stats.chain_mul += (uint64_t)al.nrows * AFX_CHAIN_INVERT_MUL; stats.chain_sq += (uint64_t)al.nrows * AFX_CHAIN_INVERT_SQ;
-      }
     }
     // a launch none of whose jobs encodes inside the kernel (every windowed launch of Issuer::verify: results that are only
     // encoded go through k_compress2x) runs the kernel compiled without the encoder (kernels.hip, k_msm<KIND, ENC>).  Splitting
@@ -937,10 +913,6 @@ void Assembler::msm_list(std::vector<afx_msm_job> jobs, bool no_naf, std::vector
     for (const afx_msm_job& j : out)
       for (uint32_t t = 0; t < j.n_terms; t++) if (j.term[t].secret) l.secret = 1;
     l.njobs = (uint32_t)out.size();
-    // (L_MSM_*: Launch::odd = the window tables this launch reads hold affine entries - kernels.hip k_msm<.., AFF>)
-    l.odd = 0;
-    for (const afx_msm_job& j : out)
-      for (uint32_t t = 0; t < j.n_var; t++) if (j.term[t].affine) l.odd = 1;
     // the kernels' form of a job: its terms in a side array (plan.h afx_msm_djob)
     std::vector<afx_msm_djob> dj(out.size());
     std::vector<size_t> terms_at(out.size());
@@ -1339,7 +1311,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
       case L_SCALAROP: AFX_HIP(afxk_scalarop(s, (const afx_scalarop_job*)jobs, nrows, rw, passes, max_count)); break;
       case L_COMPRESS: AFX_HIP(afxk_compress2x(s, (const afx_compress_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
       case L_NEGENC: AFX_HIP(afxk_negenc(s, (const afx_negenc_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
-      case L_TABLE_AFFINE: AFX_HIP(afxk_table_affine(s, odd, (const afx_table_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
+      case L_TABLE_AFFINE: AFX_HIP(afxk_table_affine(s, (const afx_table_job*)jobs, (const afx_walk_row*)rows, nrows, passes, max_count)); break;
       case L_POINTSUM: AFX_HIP(afxk_pointsum(s, (const afx_pointsum_job*)jobs, nrows, rw, passes, max_count, odd, ctx->variants)); break;
       case L_POWERS: AFX_HIP(afxk_powers(s, (const afx_powers_job*)jobs, nrows, rw, passes, max_count)); break;
       case L_MSM_TABLES: AFX_HIP(afxk_msm_tables(s, odd, (const afx_table_job*)jobs, nrows, rw, passes, max_count)); break;
@@ -1350,7 +1322,7 @@ int run_plans(afx_ctx* ctx, int lane, Plan* const* plans, size_t n) {
         if (ctx->pipelining && other.msm_recorded) AFX_HIP(hipStreamWaitEvent(s, other.msm_done, 0));
         AFX_HIP(afxk_msm(s, kind == L_MSM_FIXED ? 0 : kind == L_MSM_WINDOW ? 1 : 2, encodes, secret, (const afx_msm_djob*)jobs, nrows,
                          (const int32_t*)ctx->d_pos_tables.p, (const int32_t*)ctx->d_sec_tables.p, rw, passes, pass_host, max_count,
-                         (ctx->timing && kind == L_MSM_WINDOW) ? ctx->clock_probe() : nullptr, ctx->variants, odd));
+                         (ctx->timing && kind == L_MSM_WINDOW) ? ctx->clock_probe() : nullptr, ctx->variants));
         if (ctx->pipelining) { AFX_HIP(hipEventRecord(L.msm_done, s)); L.msm_recorded = true; }
         break;
       }

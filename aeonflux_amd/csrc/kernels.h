@@ -27,13 +27,10 @@ hipError_t afxk_msm_tables(hipStream_t s, int kind, const afx_table_job* jobs, u
 //         bit 1 - some job's narrow tables hold cached entries (afx_msm_job.narrow == 2): the launch takes the four-wave chains at any size
 // rows == null (a plan's own launch): pass_host = the HOST copy of the plan's pass, whose fields go as kernel arguments; merged launches: kinds 0 and 1 only
 hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t njobs, const int32_t* pos_tables, const int32_t* sec_tables,
-                    const afx_row* rows, const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* clock_probe, uint32_t variants,
-                    int affine /* the launch's window tables hold affine entries (Launch::odd; kinds 1 and 2 of a large pass's own launch) */);
+                    const afx_row* rows, const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* clock_probe, uint32_t variants);
 // out_enc = encoding of twice each job's point; every row (plan.h afx_walk_row) shares one field inversion per item
 // the tables of narrow jobs (secret scalars on per-item bases), second step: X, Y, Z -> affine entries, one inversion per item and row
-// kind 0: narrow tables (X, Y, Z entries, entry-major); 1: 4-bit window tables (cached entries, item-major; the walk's prefix
-// products in afx_walk_row.prefix_ws, 9 dwords x AFX_TABLE_STORED x n_jobs x count)
-hipError_t afxk_table_affine(hipStream_t s, int kind, const afx_table_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count);
+hipError_t afxk_table_affine(hipStream_t s, const afx_table_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count);
 hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count);
 // out_enc = encoding of the negation of each job's decoded point
 hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count);

@@ -339,14 +339,6 @@ __global__ void __launch_bounds__(AFX_BLOCK) k_scalarop(const afx_scalarop_job* 
 // the identity in window-table entry form (Y+X = 1, Y-X = 1, 2Z = 2, 2dT = 0 as canonical 32-byte words): what digit 0 adds
 __device__ __attribute__((aligned(16))) const int32_t AFX_IDENTITY_ENTRY[AFX_TABLE_ENTRY_DWORDS] = {
   1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-// an AFFINE entry - (y+x)/2, (y-x)/2, dxy as three canonical 32-byte words, the halved niels form of the positional tables - fills
-// the first 24 dwords of a table entry: the two-entry tables of narrow jobs (below) and the window tables of large passes (msm_add_var)
-#define AFX_NARROW_ENTRY_WORDS 24   // of the entry's 32 dwords (AFX_TABLE_ENTRY_DWORDS: the slot layout is the cached tables')
-// the identity in that form: (1/2, 1/2, 0), 1/2 = (p + 1)/2 = 2^254 - 9
-__device__ __attribute__((aligned(16))) const uint32_t AFX_IDENTITY_NIELS[AFX_NARROW_ENTRY_WORDS] = {
-  0xfffffff7u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu,
-  0xfffffff7u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu,
-  0, 0, 0, 0, 0, 0, 0, 0 };
 // per-lane context of one job inside k_msm
 struct msm_env {
   const afx_msm_djob* job;
@@ -358,9 +350,6 @@ struct msm_env {
 };
 // acc += (4-bit signed digit of window w) * (variable base t), from the lane's own window table
 // `next` (wave-uniform): what consumes the result, GE_FOR_* (ge.cuh)
-// AFF: the instance of a large pass, every window table of which was divided by k_table_affine_window (afx_msm_term.affine set on all of
-// them: a kernel instance of its own - as a run-time branch the two entry forms together cost the windowed kernel its third wave)
-template <bool AFF>
 AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w, int next) {
   const int32_t* table = e.table_ws + ((size_t)e.term[t].table_slot * e.count + e.item) * AFX_VAR_TABLE_DWORDS;
   const uint32_t wd = (uint32_t)w + e.term[t].win_off;   // (a segment's window w is digit w + win_off of the scalar; uniform)
@@ -370,18 +359,6 @@ AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w,
   const bool neg = (d < 0) != (e.term[t].negate != 0);
   // multiples 1..8 are stored (at 0..7); digit 0 reads the one identity entry every lane shares (an address select, no table bytes)
   const uint32_t stored = idx ? idx - 1 : 0;
-  if constexpr (AFF) {   // a large pass: the entries were divided by their Z (k_table_affine_window): three words, 7 products
-    const int32_t* ent = idx ? table + stored * AFX_TABLE_ENTRY_DWORDS : reinterpret_cast<const int32_t*>(AFX_IDENTITY_NIELS);
-    uint32_t w[AFX_NARROW_ENTRY_WORDS];
-#pragma unroll
-    for (int i = 0; i < AFX_NARROW_ENTRY_WORDS / 4; i++) {
-      const uint4 q4 = *reinterpret_cast<const uint4*>(ent + 4 * i);
-      w[4 * i] = q4.x; w[4 * i + 1] = q4.y; w[4 * i + 2] = q4.z; w[4 * i + 3] = q4.w;
-    }
-    ge_niels q;
-    q.ypx = fe_frombytes(w); q.ymx = fe_frombytes(w + 8); q.xyd = fe_frombytes(w + 16);
-    return ge_p1p1_to_p3_next(ge_madd(acc, q, neg), next);
-  }
   const int32_t* ent = idx ? table + stored * AFX_TABLE_ENTRY_DWORDS : AFX_IDENTITY_ENTRY;
   return ge_p1p1_to_p3_next(ge_add_cached(acc, cached_load(ent, 4), neg), next);
 }
@@ -395,6 +372,12 @@ AFX_DEV ge_p3 msm_add_var(const msm_env& e, const ge_p3& acc, uint32_t t, int w,
 // multiplies by the key with it).  The chain is software-pipelined: once an addition's entries have been reduced to the selected
 // one, the words of the NEXT addition's table are requested, before this addition computes (msm_chain_narrow), so the reads
 // overlap the arithmetic instead of preceding it.
+#define AFX_NARROW_ENTRY_WORDS 24   // of the entry's 32 dwords (AFX_TABLE_ENTRY_DWORDS: the slot layout is the cached tables')
+// the identity in that form: (1/2, 1/2, 0), 1/2 = (p + 1)/2 = 2^254 - 9
+__device__ __attribute__((aligned(16))) const uint32_t AFX_IDENTITY_NIELS[AFX_NARROW_ENTRY_WORDS] = {
+  0xfffffff7u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu,
+  0xfffffff7u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu,
+  0, 0, 0, 0, 0, 0, 0, 0 };
 AFX_DEV void narrow_fetch(uint32_t (&buf)[AFX_SECVAR_STORED * AFX_NARROW_ENTRY_WORDS], uint64_t& digits, const msm_env& e, uint32_t t, int w) {
   // the digit's word(s) first: the loads come back in order, and the addition that consumes this fetch starts from the digit
   // (a segment's window w is digit w + win_off of the scalar: afx_msm_term.win_off, uniform)
@@ -683,43 +666,6 @@ k_table_affine(const afx_table_job* __restrict__ jobs, const afx_walk_row* __res
   }
 }
 
-// The 4-bit window tables of a LARGE pass, second step: every cached entry (Y+X, Y-X, 2Z, 2dT) that k_msm_tables<TABLE_WINDOW> left
-// becomes the affine entry ((y+x)/2, (y-x)/2, dxy) - each of the first, second and fourth word times 1/(2Z) - so that the chain adds
-// it with ge_madd's 7 products instead of 8 (an eighth of the field work of 3182 additions per C3 presentation, for 6 products per
-// entry and ONE inversion per item over all 41 tables' 328 entries).  Lane = item walks its own entries of the row's tables twice:
-// prefix products of the 2Z forwards (kept in the row's scratch, limb form), one inversion, the quotients backwards; the third word
-// receives dxy, the fourth is left.  2Z is never 0 on the curve.
-__global__ void __launch_bounds__(AFX_BLOCK, 2)
-k_table_affine_window(const afx_table_job* __restrict__ jobs, const afx_walk_row* __restrict__ rows, const afx_pass* __restrict__ passes) {
-  const afx_walk_row row = rows[blockIdx.y];   // wave-uniform
-  const afx_pass pass = passes[row.pass];
-  const uint32_t count = pass.count;
-  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= count) return;
-  jobs = reinterpret_cast<decltype(jobs)>(reinterpret_cast<const uint8_t*>(jobs) + row.job_off);
-  const uint32_t n = row.n_jobs * AFX_TABLE_STORED;
-  int32_t* const mine = pass.table_ws + (size_t)item * AFX_VAR_TABLE_DWORDS;
-  fe prod = fe_one();
-#pragma unroll 1
-  for (uint32_t k = 0; k < n; k++) {
-    const int32_t* e = mine + (size_t)jobs[k / AFX_TABLE_STORED].table_slot * count * AFX_VAR_TABLE_DWORDS + (size_t)(k % AFX_TABLE_STORED) * AFX_TABLE_ENTRY_DWORDS;
-    fe_store_soa(row.prefix_ws, k, count, item, prod);   // product of the 2Z before this entry
-    prod = fe_mul(prod, fe_load_pieces(e, 4, 4));
-  }
-  fe inv = fe_invert(prod);
-#pragma unroll 1
-  for (uint32_t kk = n; kk > 0; kk--) {
-    const uint32_t k = kk - 1;
-    int32_t* e = mine + (size_t)jobs[k / AFX_TABLE_STORED].table_slot * count * AFX_VAR_TABLE_DWORDS + (size_t)(k % AFX_TABLE_STORED) * AFX_TABLE_ENTRY_DWORDS;
-    const fe h = fe_mul(inv, fe_load_soa(row.prefix_ws, k, count, item));   // 1 / (2Z) of this entry
-    inv = fe_mul(inv, fe_load_pieces(e, 4, 4));
-    const fe ypx = fe_mul(fe_load_pieces(e, 4, 0), h), ymx = fe_mul(fe_load_pieces(e, 4, 2), h), xyd = fe_mul(fe_load_pieces(e, 4, 6), h);
-    fe_store_pieces(e, 4, 0, ypx);
-    fe_store_pieces(e, 4, 2, ymx);
-    fe_store_pieces(e, 4, 4, xyd);
-  }
-}
-
 // ENC: the launch has jobs that encode their result in this kernel (those with an addend or an extended-coordinate output as
 // well; results that are only encoded go through k_compress2x).  A launch without such jobs - every windowed one of
 // Issuer::verify, every one of Issuer::issue - runs the instance compiled without the encoder's inversion, which fits three
@@ -731,7 +677,7 @@ k_table_affine_window(const afx_table_job* __restrict__ jobs, const afx_walk_row
 // ARGUMENTS, as they always were (restrict-qualified parameters: the 2^19-item passes of the throughput path measured 0.3-2 %
 // slower with them read from a pass table: profiles/r04_ab_pass_descriptors.txt) - and k_msm_rows, a launch merged from several
 // small plans, where every grid row finds its job and its pass through the row table (plan.h afx_row).
-template <int KIND, bool ENC, bool SEC, bool AFF = false>
+template <int KIND, bool ENC, bool SEC>
 __device__ __forceinline__ void msm_body(const afx_msm_djob* __restrict__ job, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables,
                                          int32_t* __restrict__ table_ws, uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count,
                                          unsigned long long* __restrict__ clock_probe) {
@@ -796,7 +742,7 @@ __device__ __forceinline__ void msm_body(const afx_msm_djob* __restrict__ job, c
         }
         if (lane_adds) {
 #pragma unroll 1
-          for (uint32_t t = nu; t < nv; t++) acc = msm_add_var<AFF>(env, acc, t, bit >> 2, t + 1 != nv ? GE_FOR_ADD : after);
+          for (uint32_t t = nu; t < nv; t++) acc = msm_add_var(env, acc, t, bit >> 2, t + 1 != nv ? GE_FOR_ADD : after);
         }
       }
     } else {
@@ -816,8 +762,8 @@ __device__ __forceinline__ void msm_body(const afx_msm_djob* __restrict__ job, c
           acc = ge_p1p1_to_p3_for<GE_FOR_ADD>(ge_p2_dbl(a2));
         }
 #pragma unroll 1
-        for (uint32_t t = 0; t + 1 < nv; t++) acc = msm_add_var<AFF>(env, acc, t, w, GE_FOR_ADD);
-        acc = msm_add_var<AFF>(env, acc, nv - 1, w, w == 0 ? GE_FOR_ANY : GE_FOR_DBL);   // the window's last addition
+        for (uint32_t t = 0; t + 1 < nv; t++) acc = msm_add_var(env, acc, t, w, GE_FOR_ADD);
+        acc = msm_add_var(env, acc, nv - 1, w, w == 0 ? GE_FOR_ANY : GE_FOR_DBL);   // the window's last addition
       }
     }
     // the fixed bases of a job with variable bases: after the chain (any order gives the same sum)
@@ -838,11 +784,11 @@ __device__ __forceinline__ void msm_body(const afx_msm_djob* __restrict__ job, c
 #define AFX_SEC_WINDOW_OCCUPANCY 2
 #endif
 #define AFX_MSM_OCCUPANCY(KIND, ENC, SEC) ((ENC) ? 2 : !(SEC) || (KIND) == MSM_FIXED ? 3 : (KIND) == MSM_WINDOW ? AFX_SEC_WINDOW_OCCUPANCY : 2)
-template <int KIND, bool ENC, bool SEC, bool AFF = false>
+template <int KIND, bool ENC, bool SEC>
 __global__ void __launch_bounds__(AFX_BLOCK, AFX_MSM_OCCUPANCY(KIND, ENC, SEC))
 k_msm(const afx_msm_djob* __restrict__ jobs, const int32_t* __restrict__ pos_tables, const int32_t* __restrict__ sec_tables, int32_t* __restrict__ table_ws,
       uint32_t* __restrict__ digit_ws, uint32_t* __restrict__ bad, uint32_t count, unsigned long long* __restrict__ clock_probe) {
-  msm_body<KIND, ENC, SEC, AFF>(&jobs[blockIdx.y], pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe);
+  msm_body<KIND, ENC, SEC>(&jobs[blockIdx.y], pos_tables, sec_tables, table_ws, digit_ws, bad, count, clock_probe);
 }
 // (small plans only: they have no NAF schedules - engine.cpp msm_split(no_naf) - so there is no merged NAF instance)
 template <int KIND, bool ENC, bool SEC>
@@ -1879,15 +1825,8 @@ hipError_t afxk_setup_postables(hipStream_t s, const int32_t* ext, uint32_t ngen
   return hipGetLastError();
 }
 template <int KIND>
-static void launch_msm(hipStream_t s, int encodes, int secret, int affine, dim3 grid, dim3 block, const afx_msm_djob* jobs, const int32_t* pos_tables, const int32_t* sec_tables,
+static void launch_msm(hipStream_t s, int encodes, int secret, dim3 grid, dim3 block, const afx_msm_djob* jobs, const int32_t* pos_tables, const int32_t* sec_tables,
                        const afx_pass& P, unsigned long long* clock_probe) {
-  if constexpr (KIND != MSM_FIXED) {
-    if (affine && !secret) {   // a large pass's own launch: window tables of affine entries
-      if (encodes) hipLaunchKernelGGL((k_msm<KIND, true, false, true>), grid, block, 0, s, jobs, pos_tables, sec_tables, P.table_ws, P.digit_ws, P.bad, P.count, clock_probe);
-      else hipLaunchKernelGGL((k_msm<KIND, false, false, true>), grid, block, 0, s, jobs, pos_tables, sec_tables, P.table_ws, P.digit_ws, P.bad, P.count, clock_probe);
-      return;
-    }
-  }
   if (secret) {
     if (encodes) hipLaunchKernelGGL((k_msm<KIND, true, true>), grid, block, 0, s, jobs, pos_tables, sec_tables, P.table_ws, P.digit_ws, P.bad, P.count, clock_probe);
     else hipLaunchKernelGGL((k_msm<KIND, false, true>), grid, block, 0, s, jobs, pos_tables, sec_tables, P.table_ws, P.digit_ws, P.bad, P.count, clock_probe);
@@ -1910,9 +1849,8 @@ static void launch_msm_rows(hipStream_t s, int encodes, int secret, dim3 grid, d
 // rows == null: a plan's own launch; `pass_host` is the HOST copy of its pass (the fields travel as kernel arguments).  Otherwise a
 // merged launch: `jobs` is the blob's base, rows / passes are device tables.
 hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t njobs, const int32_t* pos_tables,
-                    const int32_t* sec_tables, const afx_row* rows, const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* clock_probe, uint32_t variants, int affine) {
+                    const int32_t* sec_tables, const afx_row* rows, const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* clock_probe, uint32_t variants) {
   if (secret && !sec_tables) return hipErrorInvalidValue;
-  if (affine && (rows || secret || kind == MSM_FIXED)) return hipErrorInvalidValue;   // (large passes' own public launches only)
   // secret & 2: some job's narrow tables hold cached entries (afx_msm_job.narrow == 2): only the four-wave chains read those, whatever
   // the launch's size (such jobs come from small prover passes; a merged launch wide enough to matter is a request of dozens of shapes)
   const bool only_quad = (secret & 2) != 0;
@@ -1940,9 +1878,9 @@ hipError_t afxk_msm(hipStream_t s, int kind, int encodes, int secret, const afx_
   if (!rows) {
     if (!pass_host) return hipErrorInvalidValue;
     switch (kind) {
-      case MSM_FIXED: launch_msm<MSM_FIXED>(s, encodes, secret, 0, grid, block, jobs, pos_tables, sec_tables, *pass_host, clock_probe); break;
-      case MSM_WINDOW: launch_msm<MSM_WINDOW>(s, encodes, secret, affine, grid, block, jobs, pos_tables, sec_tables, *pass_host, clock_probe); break;
-      case MSM_NAF: launch_msm<MSM_NAF>(s, encodes, secret, affine, grid, block, jobs, pos_tables, sec_tables, *pass_host, clock_probe); break;
+      case MSM_FIXED: launch_msm<MSM_FIXED>(s, encodes, secret, grid, block, jobs, pos_tables, sec_tables, *pass_host, clock_probe); break;
+      case MSM_WINDOW: launch_msm<MSM_WINDOW>(s, encodes, secret, grid, block, jobs, pos_tables, sec_tables, *pass_host, clock_probe); break;
+      case MSM_NAF: launch_msm<MSM_NAF>(s, encodes, secret, grid, block, jobs, pos_tables, sec_tables, *pass_host, clock_probe); break;
       default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1968,9 +1906,8 @@ hipError_t afxk_compress2x(hipStream_t s, const afx_compress_job* jobs, const af
   hipLaunchKernelGGL(k_compress2x, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
-hipError_t afxk_table_affine(hipStream_t s, int kind, const afx_table_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
-  if (kind == 1) hipLaunchKernelGGL(k_table_affine_window, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
-  else hipLaunchKernelGGL(k_table_affine, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
+hipError_t afxk_table_affine(hipStream_t s, const afx_table_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
+  hipLaunchKernelGGL(k_table_affine, grid_for(max_count, nrows), dim3(block_for(max_count)), 0, s, jobs, rows, passes);
   return hipGetLastError();
 }
 hipError_t afxk_negenc(hipStream_t s, const afx_negenc_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {

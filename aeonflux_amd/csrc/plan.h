@@ -167,10 +167,7 @@ typedef struct {
   uint32_t win_off;        /* a SEGMENT of a secret scalar on a per-item base (Assembler::msm_split, small prover passes): the term's chain
                               runs the job's `wins` windows and window w takes digit w + win_off of the recoded scalar; the base is the
                               term's own point times 2^(AFX_SECVAR_BITS * win_off) (afx_powers_job made it).  0 otherwise.        */
-  uint32_t affine;         /* the term's 4-bit window table holds AFFINE entries - (y+x)/2, (y-x)/2, dxy as three canonical words in the
-                              entry's first 96 bytes (k_table_affine_window divided the cached entries k_msm_tables left, one inversion
-                              per item for all the tables of the launch list) - and its additions are ge_madd's 7 products instead of 8:
-                              passes large enough that the walk is throughput, not latency (Assembler::msm_list sets it)           */
+  uint32_t pad;
 } afx_msm_term;
 
 typedef struct {

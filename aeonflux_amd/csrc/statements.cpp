@@ -115,10 +115,7 @@ extern "C" int afx_ctx_set_coalescing(afx_ctx* c, uint32_t max_wait_us, uint32_t
 } catch (...) { return afx::exception_rc(); }
 extern "C" int afx_ctx_set_plan_variants(afx_ctx* c, uint32_t flags) try {
   const uint32_t seg = flags & (AFX_VARIANT_SEGMENTS_1 | AFX_VARIANT_SEGMENTS_2 | AFX_VARIANT_SEGMENTS_4);
-  if (!c || (flags & ~(uint32_t)AFX_VARIANT_ALL) || (seg & (seg - 1)) || ((flags & AFX_VARIANT_CACHED_WINDOW_TABLES) && (flags & AFX_VARIANT_AFFINE_WINDOW_TABLES))) {
-    set_error("unknown or contradictory plan variant flags (at most one AFX_VARIANT_SEGMENTS_*, one of the two WINDOW_TABLES)");
-    return AFX_E_BAD_ARGS;
-  }
+  if (!c || (flags & ~(uint32_t)AFX_VARIANT_ALL) || (seg & (seg - 1))) { set_error("unknown plan variant flags (at most one AFX_VARIANT_SEGMENTS_*)"); return AFX_E_BAD_ARGS; }
   CtxLock lock(c);
   { std::lock_guard<std::mutex> sg(c->settings_mu); c->variants = flags & ~(uint32_t)AFX_VARIANT_SELFCHECK; c->plan_selfcheck = (flags & AFX_VARIANT_SELFCHECK) != 0; }
   return AFX_OK;

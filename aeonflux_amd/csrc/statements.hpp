@@ -61,7 +61,7 @@ inline afx_shape canonical_shape(const afx_shape& sh) {
 inline uint64_t mode_flags(const afx_ctx* c) {
   // (bits 5-7: the chain width a collecting session asks of the latency plan; outside a session it follows from the count, which is in the key)
   return (c->strict ? 1u : 0u) | (c->fixed_key_schedule ? 2u : 0u) | ((uint64_t)(c->secret_mode & 3) << 3) | ((uint64_t)(c->merge_class & 7) << 5) |
-         ((uint64_t)c->small_batch_items << 8) | ((uint64_t)(c->variants & 0x1bf) << 40);   // (small_batch_items <= 2^16: bits 8-24)
+         ((uint64_t)c->small_batch_items << 8) | ((uint64_t)(c->variants & 0x3f) << 40);   // (small_batch_items <= 2^16: bits 8-24)
 }
 
 namespace afx {

@@ -240,10 +240,7 @@ int afx_ctx_get_coalescing_stats(afx_ctx* ctx, afx_coalescing_stats* out);
 #define AFX_VARIANT_HASH_HALF_WAVE 0x10u    /* cooperative transcripts on 32 lanes per item (more than 2048 of them)   */
 #define AFX_VARIANT_NO_POINTSUM_TREE 0x20u  /* sums of many parts on one lane per item                                 */
 #define AFX_VARIANT_SELFCHECK 0x40u
-#define AFX_VARIANT_CACHED_WINDOW_TABLES 0x80u /* LARGE passes (2^17 items and more) keep cached window-table entries (8 products an
-                                                  addition) instead of dividing them by their Z (7): what smaller passes do anyway */
-#define AFX_VARIANT_AFFINE_WINDOW_TABLES 0x100u /* ... and every pass that is not a latency plan divides them, whatever its size */
-#define AFX_VARIANT_ALL 0x1ffu
+#define AFX_VARIANT_ALL 0x7fu
 int afx_ctx_set_plan_variants(afx_ctx* ctx, uint32_t flags);
 
 /* Host copies of LARGE host-pointer calls (default 0: off).  Issuer::verify on a batch in host memory (src/issuer.rs:141-147

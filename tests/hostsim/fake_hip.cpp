@@ -139,7 +139,7 @@ hipError_t afxk_msm_tables(hipStream_t, int kind, const afx_table_job* j, uint32
   return hipSuccess;
 }
 hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_msm_djob* jobs, uint32_t n, const int32_t*, const int32_t* sec_tables, const afx_row* rows,
-                    const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* probe, uint32_t variants, int affine) {
+                    const afx_pass* passes, const afx_pass* pass_host, uint32_t max_count, unsigned long long* probe, uint32_t variants) {
   if (!rows) {   // a plan's own launch: the pass travels as kernel arguments, from its host copy - which must equal the device's
     if (!pass_host || memcmp(pass_host, passes, sizeof(afx_pass)) != 0) return hipErrorInvalidValue;
   } else if (kind == 2) return hipErrorInvalidValue;   // no merged NAF launches
@@ -149,14 +149,6 @@ hipError_t afxk_msm(hipStream_t, int kind, int encodes, int secret, const afx_ms
   for (uint32_t i = 0; i < n; i++)
     for (uint32_t t = 0; t < job_of(jobs, rows, i).n_terms; t++) any_secret |= afx_job_terms(&job_of(jobs, rows, i))[t].secret != 0;
   if (any_secret != (secret != 0)) return hipErrorInvalidValue;   // the launch's flag is the OR of its terms' flags
-  // the launch's affine flag: ALL of its window-table terms (per-item scalars on variable bases of non-narrow jobs) or none; never merged
-  int aff_terms = 0, win_terms = 0;
-  for (uint32_t i = 0; i < n; i++) {
-    const afx_msm_djob& j = job_of(jobs, rows, i);
-    for (uint32_t t = j.n_uni; t < j.n_var; t++) { win_terms += !j.narrow; aff_terms += afx_job_terms(&j)[t].affine != 0; }
-    for (uint32_t t = 0; t < j.n_terms; t++) if (afx_job_terms(&j)[t].affine && (t < j.n_uni || t >= j.n_var || j.narrow)) return hipErrorInvalidValue;
-  }
-  if (affine ? (aff_terms != win_terms || rows || secret || kind == 0) : aff_terms != 0) return hipErrorInvalidValue;
   int any_cached = 0;
   for (uint32_t i = 0; i < n; i++) any_cached |= job_of(jobs, rows, i).narrow == 2;
   if (any_cached != ((secret & 2) != 0) || (any_cached && (encodes || kind != 1))) return hipErrorInvalidValue;   // ... bit 1 of its jobs' cached tables
@@ -205,14 +197,11 @@ static hipError_t walk_rows(const uint8_t* jobs, size_t job_size, const afx_walk
 }
 // the tables of narrow jobs made affine: every table of the row lies inside the pass's table workspace (its first and last dword are
 // touched: the sanitizers see a slot past the allocation); the prefix products live inside the entries, so no scratch of its own
-hipError_t afxk_table_affine(hipStream_t, int kind, const afx_table_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
+hipError_t afxk_table_affine(hipStream_t, const afx_table_job* jobs, const afx_walk_row* rows, uint32_t nrows, const afx_pass* passes, uint32_t max_count) {
   for (uint32_t r = 0; r < nrows; r++) {
     const afx_pass& P = passes[rows[r].pass];
     hipError_t e = check_pass(P, max_count); if (e) return e;
-    // (kind 0: the prefix products live inside the entries; kind 1, window tables: in a scratch of 8 field elements per table and item)
-    if (kind != 0 && kind != 1) return hipErrorInvalidValue;
-    if (rows[r].n_jobs == 0 || (kind == 0 ? rows[r].prefix_ws != nullptr : !canonical(rows[r].prefix_ws))) return hipErrorInvalidValue;
-    if (kind == 1) { rows[r].prefix_ws[0] = 1; rows[r].prefix_ws[(size_t)rows[r].n_jobs * AFX_TABLE_STORED * 9 * P.count - 1] = 1; }
+    if (rows[r].n_jobs == 0 || rows[r].prefix_ws != nullptr) return hipErrorInvalidValue;
     for (uint32_t i = 0; i < rows[r].n_jobs; i++) {
       const afx_table_job& t = *(const afx_table_job*)((const uint8_t*)jobs + rows[r].job_off + (size_t)i * sizeof(afx_table_job));
       CHECK_PTR(t.var);

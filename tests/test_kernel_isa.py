@@ -46,9 +46,8 @@ def code_object(tmp_path_factory):
     return kernels, bodies
 
 
-def msm(kind, enc, sec, aff=0):
-    """k_msm<KIND, ENC, SEC, AFF>: AFF = the instance of a large pass, whose window tables hold affine entries (kernels.hip msm_add_var)"""
-    return "_Z5k_msmILi%dELb%dELb%dELb%dEEvPK12afx_msm_djobPKiS4_PiPjS6_jPy" % (kind, enc, sec, aff)
+def msm(kind, enc, sec):
+    return "_Z5k_msmILi%dELb%dELb%dEEvPK12afx_msm_djobPKiS4_PiPjS6_jPy" % (kind, enc, sec)
 
 
 def test_hot_kernels_are_scratch_free_and_fit_their_occupancy(code_object):
@@ -61,14 +60,11 @@ def test_hot_kernels_are_scratch_free_and_fit_their_occupancy(code_object):
         # is faster with them than scratch-free on the 9-limb chains (3.16 -> 2.95 ms on C5, same box)
         assert kernels[k]["private_segment_fixed_size"] <= (128 if "k_from_uniform" in k else 0), (k, kernels[k])
     # launched with three blocks of 256 per CU (kernels.hip __launch_bounds__): 512 / 3 -> 168 registers
-    three = [msm(0, 0, 0), msm(1, 0, 0), msm(2, 0, 0), msm(0, 0, 1), msm(1, 0, 0, 1), msm(2, 0, 0, 1)]
+    three = [msm(0, 0, 0), msm(1, 0, 0), msm(2, 0, 0), msm(0, 0, 1)]
     for k in three:
         assert kernels[k]["vgpr_count"] <= 168, (k, kernels[k])
     for k in hot:
         assert kernels[k]["vgpr_count"] <= 256, (k, kernels[k])
-    # the affine instances exist for the windowed and the NAF kernels without secrets only, and read 6 x 16 bytes per entry where their
-    # siblings read 8
-    assert msm(0, 0, 0, 1) not in kernels and msm(1, 0, 1, 1) not in kernels and msm(1, 1, 0, 1) in kernels and msm(2, 1, 0, 1) in kernels
     # the table kernels: one instance per table kind (one body with run-time layouts took 256 registers and scratch)
     tables = sorted(k for k in kernels if "k_msm_tables" in k)
     assert len(tables) == 4 and all(kernels[k]["vgpr_count"] <= 192 for k in tables), [(k, kernels[k]) for k in tables]
