@@ -409,6 +409,7 @@ thread_local afx::Deferred* tl_deferred = nullptr;
 int lead(afx_ctx* c, const std::shared_ptr<afx::Session>& S) {
   afx_ctx::Coalesce& co = c->co;
   using clock = std::chrono::steady_clock;
+  S->leader_defers = false;   // whoever is in here launches S: nobody takes it over from now on (coalesced_call's hand-over)
   while (S->state != afx::Session::DONE) {
     const bool go = S->full || S->hurry || co.inflight < co.max_inflight || clock::now() >= S->deadline;
     if (!go) { co.n_waited_flushes++; CtxLock::wait_until(c, S->deadline); continue; }
