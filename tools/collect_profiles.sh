@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything profiles/ holds for one round, collected on the GPU box:  gpurun -- 'bash tools/collect_profiles.sh r05'
+# Everything profiles/ holds for one round, collected on the GPU box:  gpurun -- 'bash tools/collect_profiles.sh r06'
 # Output: gpurun_out/profiles_<tag>/ (copy what should be judged into profiles/).
 #  - bench JSON lines: default = C3; C2; C5 issue and show in the library's default mode (secrets off the table addresses on the
 #    prover-side calls, afx_ctx_set_secret_independent_addressing 2) and with the fast tables (mode 0, rounds 1-3); C3 in mode 1
@@ -8,17 +8,19 @@
 #      FETCH_SIZE, WRITE_SIZE -> <tag>_traffic.json (C3 default; C5 mode 0) and <tag>_secret_traffic.json (C5 default mode; C3
 #      mode 1) with the sha256 of the kernel sources they were measured on; the SQ issue/wait counters and the instruction mix (C3),
 #      the SQ counters of C5 in both modes
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
 cd $R
 line() { grep '^{' $1 | tail -1; }
+# the profiled runs measure the workload's own timed steps: no secondary workloads, no group leg, one repetition of the host legs
+Q="--no-cpu-baseline --no-secondary --no-group-api --host-reps 1"
 cd /tmp && export TMPDIR=/tmp
 db() { ls $1/*/t_results.db $1/t_results.db 2>/dev/null | head -1; }
 trace() {   # name, bench flags...
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats -d $O/trace_$name -o t -- python3 $R/bench.py "$@" --steps 10 --warmup 2 --no-cpu-baseline > $O/trace_$name.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/trace_$name -o t -- python3 $R/bench.py "$@" --steps 10 --warmup 2 $Q > $O/trace_$name.log 2>&1
   python3 $R/tools/rocpd_summary.py $(db $O/trace_$name) > $O/${TAG}_${name}_kernel_trace.txt 2>&1
   line $O/trace_$name.log > $O/${TAG}_${name}_kernel_trace_bench_line.json
   rm -rf $O/trace_$name
@@ -26,7 +28,7 @@ trace() {   # name, bench flags...
 pmc2() {    # name, bench flags...: FETCH_SIZE and WRITE_SIZE passes
   local name=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c -d $O/pmc_${name}_$c -o t -- python3 $R/bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_${name}_$c.log 2>&1
+    rocprofv3 --kernel-trace --pmc $c -d $O/pmc_${name}_$c -o t -- python3 $R/bench.py "$@" --steps 3 --warmup 1 $Q > $O/pmc_${name}_$c.log 2>&1
   done
 }
 trace c3 --workload c3
@@ -44,7 +46,7 @@ python3 $R/tools/traffic_json.py $O/${TAG}_secret_traffic.json \
   c3:$(db $O/pmc_c3all_FETCH_SIZE):$(db $O/pmc_c3all_WRITE_SIZE):$O/pmc_c3all_FETCH_SIZE.log > $O/${TAG}_secret_traffic.txt 2>&1
 sq() {      # name, bench flags...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES -d $O/pmc_sq_$name -o t -- python3 $R/bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_sq_$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES -d $O/pmc_sq_$name -o t -- python3 $R/bench.py "$@" --steps 3 --warmup 1 $Q > $O/pmc_sq_$name.log 2>&1
   python3 $R/tools/rocpd_pmc.py $(db $O/pmc_sq_$name) k_ > $O/${TAG}_${name}_pmc.txt 2>&1
   rm -rf $O/pmc_sq_$name
 }
@@ -53,7 +55,7 @@ sq c5 --workload c5
 sq c5_fast_tables --workload c5 --secret-mode 0
 # the lane exchange of the secret generator lookups: LDS bank conflicts of the C5 issue bench (default mode), and the microbenchmark
 # of ds_bpermute_b32 against the pattern of lanes read, plain and under the counters (one launch per pattern, in pattern order)
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS -d $O/pmc_lds_c5 -o t -- python3 $R/bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_lds_c5.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS -d $O/pmc_lds_c5 -o t -- python3 $R/bench.py --workload c5 --steps 3 --warmup 1 $Q > $O/pmc_lds_c5.log 2>&1
 python3 $R/tools/rocpd_pmc.py $(db $O/pmc_lds_c5) k_msm > $O/${TAG}_c5_lds_pmc.txt 2>&1
 rm -rf $O/pmc_lds_c5
 if [ ! -x $R/variants/bperm_lookup ]; then mkdir -p $R/variants; hipcc -O3 -Wno-unused-value --offload-arch=gfx950 $R/tools/ubench/bperm_lookup.hip -o $R/variants/bperm_lookup > /dev/null 2>&1; fi
@@ -61,7 +63,7 @@ $R/variants/bperm_lookup > $O/${TAG}_bperm_lookup.txt 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/pmc_bperm -o t -- $R/variants/bperm_lookup once > /dev/null 2>&1
 python3 $R/tools/rocpd_pmc.py $(db $O/pmc_bperm) --each k_lookup >> $O/${TAG}_bperm_lookup.txt 2>&1
 rm -rf $O/pmc_bperm
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/pmc_mix -o t -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mix.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/pmc_mix -o t -- python3 $R/bench.py --steps 3 --warmup 1 $Q > $O/pmc_mix.log 2>&1
 python3 $R/tools/rocpd_pmc.py $(db $O/pmc_mix) k_msm > $O/${TAG}_c3_instruction_mix.txt 2>&1
 rm -rf $O/pmc_*_FETCH_SIZE $O/pmc_*_WRITE_SIZE $O/pmc_mix   # databases are large; the summaries are kept
 # the bench lines last: their roofline.traffic comes from the traffic files just measured on these kernels (bench.py takes the newest
@@ -86,4 +88,7 @@ python3 tools/concurrent_small_calls.py --one-context --threads 1,2,4,8,16,32,64
 # one 1-item call of each prover / verifier operation, launch by launch
 tools/timeline.sh issue show verify
 (echo "# tools/timeline.sh issue show verify: rocprofv3 --kernel-trace of ONE 1-item host-pointer call each (issue: 16 attributes; show, verify: the C3 shape), launch by launch: start offset, duration, gap to the previous launch"; cat $R/gpurun_out/timeline_issue.txt $R/gpurun_out/timeline_show.txt $R/gpurun_out/timeline_verify.txt) > $O/${TAG}_small_call_timeline.txt
+# the launch path of N ranks on this one device (not a scaling figure): RCCL refuses two ranks on one GPU, so the ranks agree on gloo
+AFX_BENCH_DEVICE=0 python3 bench.py --gpus 8 --steps 3 --warmup 1 --batch 32768 --no-cpu-baseline --no-group-api 2> $O/bench_gpus8.err | grep '^{' | tail -1 > $O/${TAG}_bench_gpus8_one_device_gloo.json
+python3 bench.py --preflight --gpus 1 > $O/${TAG}_preflight.json 2>&1
 ls -la $O
