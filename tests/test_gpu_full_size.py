@@ -254,3 +254,48 @@ def test_c5_issue_2_20_credentials_16_attributes():
                                     [bytes(iss["responses"][k, i]) for k in range(n + 5)]) == 1
     user.close()
     issuer.close()
+
+
+def test_large_host_calls_with_and_without_the_copy_pool():
+    """Host-pointer calls of more than 16 MB of rows: the runtime's pageable copies (the default) and the context's copy pool
+    (afx_ctx_set_host_copy_threads: rows gathered into the lane's pinned image by host threads on the device's NUMA node, one transfer per
+    contiguous run) stage the same bytes - on column arrays, on a sub-range and on a serialized batch (2^17 + 1 C2 presentations = 119 MB:
+    a first slice of 2^16 items and a whole pass, statements.hpp host_slice_items), statuses of a 1 % corrupted batch equal either way
+    and equal to the expected ones; issue through the pool returns the bytes it returns without (100 MB of results scattered by it)."""
+    import aeonflux_amd as afx
+    import bench
+    from aeonflux_amd import batch, wire
+    n, layout, hide, count = 4, "SSPE", [0, 3], (1 << 17) + 1
+    params, key, ip = bench.load_fixture("readme_4attrs_sSPe")
+    issuer = afx.Context(params, key, ip)
+    user = afx.Context(params, None, ip)
+    parts = [bench.generate(afx, batch, issuer, user, params, n, layout, hide, min(1 << 16, count - o), 77 + o, fast_tables=True) for o in range(0, count, 1 << 16)]
+    shape = parts[0][1]
+    pres = {f: np.concatenate([p[0][f] for p in parts], axis=-2) for f in batch.PRES_FIELDS}
+    pres["enc"] = [{f: np.concatenate([p[0]["enc"][e][f] for p in parts], axis=-2) for f in batch.ENC_FIELDS} for e in range(shape.n_enc_proofs)]
+    user.close()
+    want = bench.corrupt(pres, count, 5)
+    blob = wire.pack_presentations(shape, pres)
+    soa, keep = batch.presentation_soa(pres)
+    for threads in (0, 4, 1):
+        issuer.set_host_copy_threads(threads)
+        assert np.array_equal(batch.verify_presentations(issuer, shape, pres), want), threads
+        st = np.full(count, 0xEE, np.uint8)
+        afx.check(afx.lib().afx_verify_presentations_range(issuer.h, C.byref(shape), C.byref(soa), count, 1000, 100000, st.ctypes.data))
+        assert np.array_equal(st[1000:101000], want[1000:101000]) and (st[:1000] == 0xEE).all() and (st[101000:] == 0xEE).all(), threads
+        assert np.array_equal(wire.verify_wire(issuer, blob), want), threads
+    rng = np.random.default_rng(3)
+    rb = lambda *s: rng.integers(0, 256, size=s, dtype=np.uint8)
+    kinds = [afx.ATTR_PUBLIC_SCALAR, afx.ATTR_PUBLIC_SCALAR, afx.ATTR_PUBLIC_POINT, afx.ATTR_PUBLIC_POINT]
+    values = np.stack([batch.scalars_from_wide(issuer, rb(count, 64)), batch.scalars_from_wide(issuer, rb(count, 64)),
+                       batch.points_from_uniform(issuer, rb(count, 64)), batch.points_from_uniform(issuer, rb(count, 64))])
+    tw, uw, sd = rb(count, 64), rb(count, 64), rb(count, 32)
+    outs = []
+    for threads in (0, 4):
+        issuer.set_host_copy_threads(threads)
+        o, st = batch.issue(issuer, kinds, values, tw, uw, sd)
+        assert not st.any()
+        outs.append(o)
+    for f in ("t", "U", "V", "challenge", "responses"):
+        assert np.array_equal(outs[0][f], outs[1][f]), f
+    issuer.close()
