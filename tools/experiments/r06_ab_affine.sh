@@ -1,5 +1,5 @@
 #!/bin/bash
-# same box, alternating: default (affine window tables from 2^17 items) vs AFX_VARIANT_CACHED_WINDOW_TABLES (0x80) through the python mirror's hook
+# same box, alternating, on a build with tools/experiments/r06_affine_window_tables.patch applied: default (affine window tables from 2^17 items) vs AFX_VARIANT_CACHED_WINDOW_TABLES (0x80) through the python mirror's hook
 for r in 1 2 3; do
   for v in 0 0x80; do
     AFX_TEST_PLAN_VARIANTS=$v python bench.py --workload ${1:-c3} --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --no-secondary --no-group-api --host-reps 1 ${2:-} 2>/dev/null | python -c "
