@@ -132,7 +132,7 @@ struct afx_ctx {
     std::shared_ptr<afx::Session> open;   // the session that collects, or null
     int inflight = 0;                 // sessions launched and not yet completed
     bool lane_busy[5] = { false, false, false, false, false };   // a session (collecting or in flight) owns the lane's staging images (AFX_LANES entries)
-    int max_inflight = 2;             // sessions computing at once (small passes leave most of the device idle); AFX_COALESCE_INFLIGHT=1|2 at context creation
+    int max_inflight = 2;             // sessions computing at once (small passes leave most of the device idle); two measured best: profiles/r05_ab_sessions_in_flight.txt
     int exclusive_waiters = 0;        // callers that need the whole context (large batches, setters): no new session opens meanwhile
     std::map<std::string, uint32_t> demand;   // by join key: the items the last session carried (the item slots the next one starts with)
     uint32_t last_waves = 0, last_plans = 0;  // width of the last session launched: the merge class the next one assembles for
