@@ -56,6 +56,25 @@ static void hit(const Bytes& b) {
   free(p);
   calls++;
 }
+// a merlin transcript script (afx_merlin_challenges): the same rule - AFX_OK or AFX_E_BAD_ARGS, whatever the bytes say
+static unsigned long long merlin_calls = 0, merlin_ok = 0;
+static void hit_merlin(const Bytes& b) {
+  static std::vector<uint8_t> f0(3 * 32, 0x11), f1(3 * 32, 0x22), out(3 * 64);
+  const uint8_t* fields[2] = { f0.data(), f1.data() };
+  const size_t n = b.size();
+  uint8_t* p = (uint8_t*)malloc(n ? n : 1);
+  if (n) memcpy(p, b.data(), n);
+  const int rc = afx_merlin_challenges(ctx, p, n, fields, 2, 3, out.data());
+  if (rc != AFX_OK && rc != AFX_E_BAD_ARGS) {
+    fprintf(stderr, "afx_merlin_challenges returned %d (%s) on a %zu-byte script starting", rc, afx_last_error(), n);
+    for (size_t k = 0; k < n && k < 48; k++) fprintf(stderr, " %02x", p[k]);
+    fprintf(stderr, "\n");
+    exit(1);
+  }
+  merlin_ok += rc == AFX_OK;
+  free(p);
+  merlin_calls++;
+}
 static void put32(Bytes& b, size_t at, uint32_t v) { for (int k = 0; k < 4 && at + k < b.size(); k++) b[at + k] = (uint8_t)(v >> (8 * k)); }
 
 int main(int argc, char** argv) {
@@ -102,7 +121,33 @@ int main(int argc, char** argv) {
     else if (r < 25 && b.size() > 8) { const size_t a = rnd() % (b.size() - 4), c = rnd() % (b.size() - 4); memmove(&b[a], &b[c], 4); }
     hit(b); m++;
   }
+  // (5) transcript scripts: a valid one (every operation, a 400-byte message across two rate blocks, both fields), every length word
+  // and operation byte at every edge value, truncations at every byte, random damage
+  Bytes S;
+  auto op = [&](uint8_t o, const char* label) { S.push_back(o); const uint32_t l = (uint32_t)strlen(label); for (int k = 0; k < 4; k++) S.push_back((uint8_t)(l >> (8 * k))); S.insert(S.end(), label, label + l); };
+  auto u32 = [&](uint32_t v) { for (int k = 0; k < 4; k++) S.push_back((uint8_t)(v >> (8 * k))); };
+  op(AFX_MERLIN_NEW, "fuzz protocol");
+  op(AFX_MERLIN_APPEND, "msg"); u32(400); S.insert(S.end(), 400, 0x63);
+  op(AFX_MERLIN_APPEND_FIELD, "f0"); u32(0);
+  op(AFX_MERLIN_CHALLENGE, "mid"); u32(32);
+  op(AFX_MERLIN_APPEND, ""); u32(0);
+  op(AFX_MERLIN_APPEND_FIELD, "f1"); u32(1);
+  op(AFX_MERLIN_CHALLENGE, "chal"); u32(64);
+  hit_merlin(S);
+  if (merlin_ok != 1) { fprintf(stderr, "the valid script was refused: %s\n", afx_last_error()); return 1; }
+  for (size_t at = 0; at + 4 <= S.size(); at++) {
+    if (at > 40 && at < 420) continue;   // (inside the 400-byte message: nothing is parsed there)
+    for (uint32_t v : EDGE) { Bytes b = S; put32(b, at, v); hit_merlin(b); }
+    for (int o = 0; o < 8; o++) { Bytes b = S; b[at] = (uint8_t)o; hit_merlin(b); }
+  }
+  for (size_t cut = 0; cut <= S.size(); cut++) hit_merlin(Bytes(S.begin(), S.begin() + cut));
+  for (unsigned long long k = 0; k < target / 8; k++) {
+    Bytes b = S;
+    for (int j = 1 + (int)(rnd() % 3); j > 0; j--) { const size_t bit = rnd() % (8 * b.size()); b[bit >> 3] ^= (uint8_t)(1u << (bit & 7)); }
+    if (rnd() % 100 < 15) b.resize(rnd() % (b.size() + 1));
+    hit_merlin(b);
+  }
   afx_ctx_destroy(ctx);
-  printf("wire fuzz ok: %llu mutated streams, %llu x 6 entry-point calls\n", m, calls);
+  printf("wire fuzz ok: %llu mutated streams, %llu x 6 entry-point calls; %llu transcript scripts (%llu accepted)\n", m, calls, merlin_calls, merlin_ok);
   return 0;
 }
