@@ -38,12 +38,18 @@ pmc2 c3 --workload c3
 pmc2 c5fast --workload c5 --secret-mode 0
 pmc2 c5 --workload c5
 pmc2 c3all --workload c3 --secret-mode 1
+pmc2 c2 --workload c2
+pmc2 show --workload show
+pmc2 showfast --workload show --secret-mode 0
 python3 $R/tools/traffic_json.py $O/${TAG}_traffic.json \
   c3:$(db $O/pmc_c3_FETCH_SIZE):$(db $O/pmc_c3_WRITE_SIZE):$O/pmc_c3_FETCH_SIZE.log \
-  c5:$(db $O/pmc_c5fast_FETCH_SIZE):$(db $O/pmc_c5fast_WRITE_SIZE):$O/pmc_c5fast_FETCH_SIZE.log > $O/${TAG}_traffic.txt 2>&1
+  c5:$(db $O/pmc_c5fast_FETCH_SIZE):$(db $O/pmc_c5fast_WRITE_SIZE):$O/pmc_c5fast_FETCH_SIZE.log \
+  c2:$(db $O/pmc_c2_FETCH_SIZE):$(db $O/pmc_c2_WRITE_SIZE):$O/pmc_c2_FETCH_SIZE.log \
+  show:$(db $O/pmc_showfast_FETCH_SIZE):$(db $O/pmc_showfast_WRITE_SIZE):$O/pmc_showfast_FETCH_SIZE.log > $O/${TAG}_traffic.txt 2>&1
 python3 $R/tools/traffic_json.py $O/${TAG}_secret_traffic.json \
   c5:$(db $O/pmc_c5_FETCH_SIZE):$(db $O/pmc_c5_WRITE_SIZE):$O/pmc_c5_FETCH_SIZE.log \
-  c3:$(db $O/pmc_c3all_FETCH_SIZE):$(db $O/pmc_c3all_WRITE_SIZE):$O/pmc_c3all_FETCH_SIZE.log > $O/${TAG}_secret_traffic.txt 2>&1
+  c3:$(db $O/pmc_c3all_FETCH_SIZE):$(db $O/pmc_c3all_WRITE_SIZE):$O/pmc_c3all_FETCH_SIZE.log \
+  show:$(db $O/pmc_show_FETCH_SIZE):$(db $O/pmc_show_WRITE_SIZE):$O/pmc_show_FETCH_SIZE.log > $O/${TAG}_secret_traffic.txt 2>&1
 sq() {      # name, bench flags...
   local name=$1; shift
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES -d $O/pmc_sq_$name -o t -- python3 $R/bench.py "$@" --steps 3 --warmup 1 $Q > $O/pmc_sq_$name.log 2>&1
